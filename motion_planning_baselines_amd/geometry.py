@@ -1,0 +1,281 @@
+"""Geometry back-end specification: robots, collision primitives, packed device layout.
+
+The reference delegates forward kinematics and signed-distance fields to the
+un-vendored ``torch_robotics`` package (reference call sites:
+mp_baselines/planners/costs/cost_functions.py:50-52 ``robot.get_position /
+get_velocity / fk_map_collision`` and costs/factors/field_factor.py:39
+``field.compute_cost``).  That package is not part of the reference tree, so the
+geometry here is BUILD-DEFINED (parity with torch_robotics is unpinned, see
+DESIGN.md).  This module holds only *data*: the analytic definitions are
+evaluated on the GPU by csrc/mpb_collision.h and, for checking, on the CPU by
+oracle/geometry_ref.py from the very same arrays.
+
+Definitions (all fp32):
+  * point robot, D in {2,3}: one collision sphere at (q0, q1, q2|0), radius r.
+  * serial revolute chain (Panda): frame_0 = I; frame_{j+1} = frame_j * P_j * Rz(q_j)
+    for j < D; an optional fixed tool frame_{D+1} = frame_D * P_D.  P_j are constant
+    3x4 transforms (modified-DH: Rx(alpha_{j-1}) Tx(a_{j-1}) Tz(d_j)).
+    Collision sphere l sits at frame_{link_frame[l]} * offset_l with radius r_l.
+  * obstacle sphere: sdf(x) = |x - c| - r.
+  * axis-aligned box: q = |x - c| - h; sdf = |max(q,0)| + min(max(qx,qy,qz), 0).
+  * per-waypoint collision cost: sum_l relu(margin + r_l - min_o sdf_o(x_l)).
+"""
+import math
+
+import numpy as np
+
+GEOM_MAGIC = 0x4D504247  # 'MPBG'
+GEOM_VERSION = 1
+GEOM_HEADER_WORDS = 16
+KIND_POINT = 0
+KIND_CHAIN = 1
+MAX_DOF = 8
+BOX_2D_HALF_Z = 1.0e6  # 2-D boxes are 3-D boxes that are effectively infinite in z
+
+
+def _rot_x(a):
+    c, s = math.cos(a), math.sin(a)
+    return np.array([[1, 0, 0], [0, c, -s], [0, s, c]], dtype=np.float64)
+
+
+def _rot_z(a):
+    c, s = math.cos(a), math.sin(a)
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]], dtype=np.float64)
+
+
+def _mdh(alpha, a, d):
+    """Modified-DH constant part: Rx(alpha) * Tx(a) * Tz(d) as a 3x4 matrix."""
+    R = _rot_x(alpha)
+    t = R @ np.array([a, 0.0, d])
+    # Rx(alpha) Tx(a) Tz(d): translation = Rx * (a,0,d)  (Tx and Tz act in the rotated frame)
+    out = np.zeros((3, 4), dtype=np.float64)
+    out[:, :3] = R
+    out[:, 3] = t
+    return out
+
+
+class Robot:
+    """Common robot interface mirroring what the reference consumes
+    (cost_functions.py:21 ``q_dim``; :50-51 ``get_position``/``get_velocity``;
+    :412-420 ``q_min``/``q_max``; :380 ``dt``)."""
+
+    kind = None
+
+    def __init__(self, q_dim, q_min, q_max, dt=None):
+        self.q_dim = int(q_dim)
+        self.q_min_np = np.asarray(q_min, dtype=np.float32)
+        self.q_max_np = np.asarray(q_max, dtype=np.float32)
+        self.dt = dt
+
+    # state slicing -- same meaning as torch_robotics' RobotBase (positions first, velocities last)
+    def get_position(self, x):
+        return x[..., :self.q_dim]
+
+    def get_velocity(self, x):
+        return x[..., self.q_dim:2 * self.q_dim]
+
+    def spec(self):
+        raise NotImplementedError
+
+
+class RobotPointMass(Robot):
+    """Point-mass robot in 2-D or 3-D with one collision sphere of radius ``radius``."""
+
+    kind = KIND_POINT
+
+    def __init__(self, q_dim=2, radius=0.01, q_limits=(-1.0, 1.0), dt=None):
+        super().__init__(q_dim, [q_limits[0]] * q_dim, [q_limits[1]] * q_dim, dt=dt)
+        assert q_dim in (2, 3)
+        self.radius = float(radius)
+
+    def spec(self):
+        return dict(
+            kind=KIND_POINT, n_dof=self.q_dim,
+            joint_tf=np.zeros((0, 3, 4), np.float32),
+            link_frame=np.zeros((1,), np.int32),
+            link_offset=np.zeros((1, 3), np.float32),
+            link_radius=np.array([self.radius], np.float32),
+        )
+
+
+class RobotSerialChain(Robot):
+    """Serial chain of revolute joints with a fixed set of collision spheres."""
+
+    kind = KIND_CHAIN
+
+    def __init__(self, joint_tf, link_frame, link_offset, link_radius, q_min, q_max, dt=None):
+        joint_tf = np.asarray(joint_tf, dtype=np.float32)
+        n_dof = len(q_min)
+        assert joint_tf.shape in ((n_dof, 3, 4), (n_dof + 1, 3, 4))
+        if joint_tf.shape[0] == n_dof:  # no tool frame: append identity
+            eye = np.zeros((1, 3, 4), np.float32)
+            eye[0, :, :3] = np.eye(3)
+            joint_tf = np.concatenate([joint_tf, eye], 0)
+        assert n_dof <= MAX_DOF
+        super().__init__(n_dof, q_min, q_max, dt=dt)
+        self.joint_tf = joint_tf
+        self.link_frame = np.asarray(link_frame, dtype=np.int32)
+        self.link_offset = np.asarray(link_offset, dtype=np.float32).reshape(-1, 3)
+        self.link_radius = np.asarray(link_radius, dtype=np.float32)
+        assert self.link_frame.min() >= 1 and self.link_frame.max() <= n_dof + 1
+        # kernels walk the chain once and emit spheres frame by frame
+        assert np.all(np.diff(self.link_frame) >= 0), "collision spheres must be sorted by frame"
+
+    def spec(self):
+        return dict(
+            kind=KIND_CHAIN, n_dof=self.q_dim, joint_tf=self.joint_tf,
+            link_frame=self.link_frame, link_offset=self.link_offset, link_radius=self.link_radius,
+        )
+
+
+# Franka Emika Panda, public modified-DH table (Franka Control Interface documentation):
+#   joint : a_{i-1}   d_i    alpha_{i-1}
+_PANDA_MDH = [
+    (0.0, 0.333, 0.0),
+    (0.0, 0.0, -math.pi / 2),
+    (0.0, 0.316, math.pi / 2),
+    (0.0825, 0.0, math.pi / 2),
+    (-0.0825, 0.384, -math.pi / 2),
+    (0.0, 0.0, math.pi / 2),
+    (0.088, 0.0, math.pi / 2),
+]
+_PANDA_FLANGE_D = 0.107
+_PANDA_Q_MIN = [-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973]
+_PANDA_Q_MAX = [2.8973, 1.7628, 2.8973, -0.0698, 2.8973, 3.7525, 2.8973]
+
+# Build-defined collision-sphere set: (frame, x, y, z, radius); frame j = link j (after joint j),
+# frame 8 = flange + hand (Tz(0.107) Rz(-pi/4)).
+_PANDA_SPHERES = [
+    (1, 0.0, 0.0, -0.20, 0.08), (1, 0.0, 0.0, -0.10, 0.08), (1, 0.0, -0.03, 0.0, 0.08),
+    (2, 0.0, 0.0, 0.03, 0.08), (2, 0.0, -0.07, 0.0, 0.07), (2, 0.0, -0.14, 0.0, 0.07),
+    (3, 0.0, 0.0, -0.12, 0.07), (3, 0.0, 0.0, -0.05, 0.07), (3, 0.04, 0.0, -0.02, 0.07),
+    (3, 0.0825, 0.03, 0.0, 0.07),
+    (4, 0.0, 0.0, 0.03, 0.07), (4, -0.04, 0.02, 0.0, 0.07), (4, -0.0825, 0.06, 0.0, 0.07),
+    (4, -0.0825, 0.10, 0.02, 0.06),
+    (5, 0.0, 0.0, -0.26, 0.07), (5, 0.0, 0.04, -0.20, 0.06), (5, 0.0, 0.07, -0.14, 0.055),
+    (5, 0.0, 0.08, -0.08, 0.055), (5, 0.0, 0.05, -0.02, 0.06), (5, 0.0, 0.0, 0.0, 0.07),
+    (6, 0.0, 0.0, 0.01, 0.07), (6, 0.06, 0.0, 0.01, 0.06), (6, 0.088, 0.02, 0.0, 0.06),
+    (7, 0.0, 0.0, 0.07, 0.06), (7, 0.03, 0.03, 0.09, 0.045), (7, -0.03, -0.03, 0.09, 0.045),
+    (8, 0.0, 0.0, 0.03, 0.06), (8, 0.0, 0.06, 0.04, 0.045), (8, 0.0, -0.06, 0.04, 0.045),
+    (8, 0.0, 0.04, 0.09, 0.03), (8, 0.0, -0.04, 0.09, 0.03),
+]
+
+
+class RobotPanda(RobotSerialChain):
+    """7-DoF Franka Panda: public DH kinematics + a build-defined set of 31 collision spheres."""
+
+    def __init__(self, dt=None):
+        tfs = [_mdh(alpha, a, d) for (a, d, alpha) in _PANDA_MDH]
+        tool = np.zeros((3, 4))
+        tool[:, :3] = _rot_z(-math.pi / 4)
+        tool[:, 3] = [0.0, 0.0, _PANDA_FLANGE_D]
+        tfs.append(tool)
+        sph = np.array(_PANDA_SPHERES, dtype=np.float64)
+        super().__init__(
+            joint_tf=np.stack(tfs), link_frame=sph[:, 0].astype(np.int32),
+            link_offset=sph[:, 1:4], link_radius=sph[:, 4],
+            q_min=_PANDA_Q_MIN, q_max=_PANDA_Q_MAX, dt=dt)
+
+
+class CollisionField:
+    """Set of sphere / axis-aligned-box obstacles plus the hinge margin.
+
+    Stands in for torch_robotics' collision distance fields (reference call site
+    field_factor.py:39 ``field.compute_cost(q_pos, link_pos, **kwargs)``).
+    """
+
+    def __init__(self, spheres=None, boxes=None, margin=0.05):
+        def _arr(x, w):
+            a = np.zeros((0, w), np.float32) if x is None else np.asarray(x, dtype=np.float32)
+            return a.reshape(-1, w)
+        sp = np.asarray(spheres, np.float32) if spheres is not None and len(spheres) else None
+        if sp is not None and sp.shape[-1] == 3:  # 2-D circles (cx, cy, r)
+            sp = np.concatenate([sp[:, :2], np.zeros((len(sp), 1), np.float32), sp[:, 2:3]], 1)
+        bx = np.asarray(boxes, np.float32) if boxes is not None and len(boxes) else None
+        if bx is not None and bx.shape[-1] == 4:  # 2-D boxes (cx, cy, hx, hy)
+            n = len(bx)
+            bx = np.concatenate([bx[:, :2], np.zeros((n, 1), np.float32), bx[:, 2:4],
+                                 np.full((n, 1), BOX_2D_HALF_Z, np.float32)], 1)
+        self.spheres = _arr(sp, 4)
+        self.boxes = _arr(bx, 6)
+        self.margin = float(margin)
+        assert len(self.spheres) + len(self.boxes) > 0, "empty collision field"
+
+    def spec(self):
+        return dict(spheres=self.spheres, boxes=self.boxes, margin=np.float32(self.margin))
+
+    def zero_grad(self):  # reference calls field.zero_grad() (field_factor.py:56); nothing to clear here
+        pass
+
+
+def pack_geometry(robot, field):
+    """Pack robot + field into the flat fp32 word buffer the HIP kernels read.
+
+    Layout (32-bit words; ints stored bit-exact), mirrored by csrc/mpb_geom.h:
+      [0] magic [1] version [2] kind [3] n_dof [4] n_frames_tf (0 or n_dof+1) [5] n_links
+      [6] n_spheres [7] n_boxes [8] margin(f32) [9] off_tf [10] off_links [11] off_spheres
+      [12] off_boxes [13] total_words [14..15] reserved
+      joint_tf   : n_frames_tf x 12   (row-major 3x4)
+      links      : n_links x 8        (frame:int, ox, oy, oz, radius, 0, 0, 0)
+      spheres    : n_spheres x 4      (cx, cy, cz, r)
+      boxes      : n_boxes x 8        (cx, cy, cz, 0, hx, hy, hz, 0)
+    """
+    rs, fs = robot.spec(), field.spec()
+    n_tf = rs['joint_tf'].shape[0]
+    n_links = len(rs['link_radius'])
+    n_sph, n_box = len(fs['spheres']), len(fs['boxes'])
+    off_tf = GEOM_HEADER_WORDS
+    off_links = off_tf + 12 * n_tf
+    off_sph = off_links + 8 * n_links
+    off_box = off_sph + 4 * n_sph
+    total = off_box + 8 * n_box
+    buf = np.zeros((total,), dtype=np.float32)
+    ibuf = buf.view(np.int32)
+    ibuf[0:8] = [GEOM_MAGIC, GEOM_VERSION, rs['kind'], rs['n_dof'], n_tf, n_links, n_sph, n_box]
+    buf[8] = fs['margin']
+    ibuf[9:14] = [off_tf, off_links, off_sph, off_box, total]
+    buf[off_tf:off_links] = rs['joint_tf'].astype(np.float32).reshape(-1)
+    links = np.zeros((n_links, 8), np.float32)
+    links.view(np.int32)[:, 0] = rs['link_frame']
+    links[:, 1:4] = rs['link_offset']
+    links[:, 4] = rs['link_radius']
+    buf[off_links:off_sph] = links.reshape(-1)
+    buf[off_sph:off_box] = fs['spheres'].reshape(-1)
+    boxes = np.zeros((n_box, 8), np.float32)
+    if n_box:
+        boxes[:, 0:3] = fs['boxes'][:, 0:3]
+        boxes[:, 4:7] = fs['boxes'][:, 3:6]
+    buf[off_box:total] = boxes.reshape(-1)
+    return buf
+
+
+# ----------------------------------------------------------------------------------------------
+# Synthetic environments for BASELINE.md configs (stand-ins for torch_robotics environments)
+# ----------------------------------------------------------------------------------------------
+
+def env_grid_circles_2d(margin=0.005, radius=0.05, n=7, extent=0.75):
+    """C1: n x n grid of circles on [-extent, extent]^2 (stand-in for EnvGridCircles2D)."""
+    xs = np.linspace(-extent, extent, n)
+    c = np.array([(x, y, radius) for x in xs for y in xs], dtype=np.float32)
+    return CollisionField(spheres=c, margin=margin)
+
+
+def env_dense_2d(seed=3, n_circles=32, n_boxes=8, margin=0.01):
+    """C2: random circles + boxes in [-1,1]^2, sizes U[0.05,0.15] (stand-in for EnvDense2D)."""
+    rng = np.random.RandomState(seed)
+    circles = np.concatenate([rng.uniform(-1, 1, (n_circles, 2)), rng.uniform(0.05, 0.15, (n_circles, 1))], 1)
+    boxes = np.concatenate([rng.uniform(-1, 1, (n_boxes, 2)), rng.uniform(0.05, 0.15, (n_boxes, 2))], 1)
+    return CollisionField(spheres=circles.astype(np.float32), boxes=boxes.astype(np.float32), margin=margin)
+
+
+def env_spheres_3d(seed=0, n_spheres=16, margin=0.05):
+    """C3/C4/C5: random spheres r U[0.05,0.15], centres U[-0.8,0.8]^3, none within 0.2 of the base axis."""
+    rng = np.random.RandomState(seed)
+    out = []
+    while len(out) < n_spheres:
+        c = rng.uniform(-0.8, 0.8, 3)
+        r = rng.uniform(0.05, 0.15)
+        if math.hypot(c[0], c[1]) - r < 0.2:
+            continue
+        out.append((c[0], c[1], c[2], r))
+    return CollisionField(spheres=np.array(out, np.float32), margin=margin)

@@ -1,0 +1,38 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False))
+
+
+def ref_geometry_from_golden(g, dtype=torch.float32):
+    """(RefRobot, RefCollisionField) of the oracle from the arrays stored in a golden file."""
+    from oracle.geometry_ref import RefRobot, RefCollisionField
+    ta = dict(device='cpu', dtype=dtype)
+    spec = dict(kind=int(g['robot_kind']), n_dof=int(g['n_dof']), joint_tf=g['joint_tf'],
+                link_frame=g['link_frame'], link_offset=g['link_offset'], link_radius=g['link_radius'])
+    robot = RefRobot(spec, tensor_args=ta)
+    field = RefCollisionField(dict(spheres=g['spheres'], boxes=g['boxes'], margin=g['margin']),
+                              g['link_radius'], tensor_args=ta)
+    return robot, field
+
+
+@pytest.fixture(scope='session')
+def gpu_device():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    return torch.device('cuda:0')
