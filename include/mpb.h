@@ -1,0 +1,156 @@
+/*
+ * mpb.h -- C-ABI of libmpb_hip.so: MI355X (gfx950) kernels for the batched trajectory-optimisation
+ * inner loops of anindex/motion_planning_baselines (mp_baselines/planners).
+ *
+ * The reference has NO FFI of its own (it is pure Python/PyTorch): the seam is the
+ * planners' Python methods.  Each entry point below replaces the body of the reference method(s)
+ * cited next to it; the classes in motion_planning_baselines_amd/planners keep the reference's class / ctor /
+ * optimize() / reset() surface and call these through ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous row-major fp32 unless stated otherwise
+ *     (obtained from tensor.data_ptr() of a PyTorch-ROCm tensor); the library never allocates,
+ *     frees or retains caller memory and keeps no state between calls (thread-safe);
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream; NULL = default);
+ *     all work is enqueued asynchronously on it, nothing synchronises the device;
+ *   - return value 0 = ok; non-zero = MPB_E_*; mpb_last_error() gives the message of the calling
+ *     thread's last failure;
+ *   - shapes: P particles, S samples per particle, B = P*S rollouts, H support points (horizon),
+ *     D degrees of freedom, d = optimised state width (D if pos_only else 2D).
+ *   - `geom` is the packed geometry word buffer (motion_planning_baselines_amd/geometry.py
+ *     pack_geometry; layout in csrc/mpb_geom.h): robot kinematics + collision spheres + obstacle
+ *     spheres / boxes + hinge margin.  It stands in for the reference's external robot / field objects
+ *     (cost_functions.py:50-52 robot.fk_map_collision, field_factor.py:39 field.compute_cost).
+ */
+#ifndef MPB_H
+#define MPB_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPB_OK 0
+#define MPB_E_INVALID 1     /* bad argument (null pointer, shape out of range, bad geometry header) */
+#define MPB_E_UNSUPPORTED 2 /* valid request this build cannot serve (e.g. H too large for LDS) */
+#define MPB_E_HIP 3         /* a HIP runtime call failed; see mpb_last_error() */
+
+#define MPB_MAX_H 256
+#define MPB_MAX_DOF 8
+
+int mpb_version(void);
+const char *mpb_last_error(void);
+
+/* Validate a packed geometry buffer held in HOST memory (n_words 32-bit words). */
+int mpb_geom_check(const float *geom_host, int n_words);
+
+/* ---------------------------------------------------------------------------------------------
+ * Collision cost  -- replaces CostCollision.eval (costs/cost_functions.py:171-189) over
+ * get_q_pos_vel_and_fk_map (:41-53) + FieldFactor.get_error (costs/factors/field_factor.py:17-39):
+ *   out[b] = weight * (k_sigma * sum_{h >= h_begin} field_cost(q[b,h,:D]))       (h_begin = 1: Q5)
+ * trajs (B,H,d); out (B).
+ * mpb_cost_collision_grad additionally writes grad (B,H,d) = d out[b] / d trajs[b] (the quantity the
+ * reference obtains by autograd: chomp.py:139, field_factor.py:54); velocity channels get 0.
+ * per_waypoint (B,H) optional (may be NULL): un-scaled field cost of every waypoint (0 for h < h_begin).
+ * ------------------------------------------------------------------------------------------- */
+int mpb_cost_collision_eval(const float *trajs, const float *geom, float *out, float *per_waypoint,
+                            int B, int H, int d, int h_begin, float k_sigma, float weight, void *stream);
+int mpb_cost_collision_grad(const float *trajs, const float *geom, float *out, float *grad,
+                            int B, int H, int d, int h_begin, float k_sigma, float weight, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * STOMP -- replaces STOMP._run_optimization's loop body (stomp.py:150-160):
+ *   sample (stomp.py:97-108 + MultivariateNormal.rsample), _get_costs (base.py:218-223) with the
+ *   collision cost above, _calc_sample_weights (stomp.py:219-220), _update_distribution (:199-211).
+ *
+ * means (P,H,d) in/out, updated in place n_iters times.
+ * eps: NULL -> standard normals are generated on the device (Philox4x32-10 keyed by `seed`,
+ *      counter = (particle_offset + p, s, waypoint, iter0 + i); result independent of sharding);
+ *      else (n_iters, S, d, P, H): pre-drawn standard normals in the reference's draw order
+ *      (one MultivariateNormal.sample((S,d)) of batch shape (P,) and event shape (H,) per iteration).
+ * samples (P,S,H,d), costs (P,S), weights (P,S): outputs of the LAST iteration (all required).
+ * L (H,H): scale_tril of the noise distribution, Sigma (H,H) = inverse(R): constants the host
+ *      computes exactly as the reference does (stomp.py:63-64, :88-95) -- SURVEY.md H2.
+ * mpb_stomp_step runs the fused path (sample+cost kernel, update kernel per iteration).
+ * mpb_stomp_sample / mpb_stomp_update expose the two halves (the two kernels of one iteration) so that
+ * a caller-supplied cost callable (any Python cost on device tensors) can sit between them; with
+ * geom + costs given, mpb_stomp_sample is exactly the first kernel of mpb_stomp_step.
+ * ------------------------------------------------------------------------------------------- */
+int mpb_stomp_step(float *means, const float *eps, float *samples, float *costs, float *weights,
+                   const float *L, const float *Sigma, const float *geom,
+                   int P, int S, int H, int d, int D,
+                   float k_sigma, float weight, float lr, float temperature,
+                   int n_iters, uint64_t seed, uint32_t iter0, uint32_t particle_offset, void *stream);
+int mpb_stomp_sample(const float *means, const float *eps, float *samples, const float *L,
+                     const float *geom, float *costs, /* both NULL: sample only; both set: fused cost */
+                     int P, int S, int H, int d, float k_sigma, float weight,
+                     uint64_t seed, uint32_t iter, uint32_t particle_offset, void *stream);
+int mpb_stomp_update(float *means, const float *samples, const float *costs, float *weights,
+                     const float *Sigma, int P, int S, int H, int d, float lr, float temperature,
+                     void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * CHOMP -- replaces CHOMP._run_optimization's loop body (chomp.py:127-151) and _eval (:153-169):
+ *   g = d/dx [ collision cost + w_prior * B_global * sum_c x_c^T R x_c ]   (quirk Q3: the batch-total
+ *   smoothness scalar is added to every particle's cost and costs.sum() is differentiated, so the
+ *   smoothness gradient carries the GLOBAL batch size), clamp to +-grad_clip, zero the two endpoint
+ *   rows, x -= lr * g;  repeated n_iters times inside one launch.
+ * means (B_local,H,d) in/out.  R (H,H): CHOMP._get_R_mat (chomp.py:81-101), computed by the host;
+ * only its tridiagonal band is read.  costs_out (B_local) optional: collision cost (scaled) of the
+ * iterate BEFORE the last update, without the smoothness scalar.
+ * ------------------------------------------------------------------------------------------- */
+int mpb_chomp_step(float *means, const float *R, const float *geom, float *costs_out,
+                   int B_local, int B_global, int H, int d, int D,
+                   float k_sigma, float weight, float w_prior, float lr, float grad_clip,
+                   int n_iters, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * GPMP2 -- replaces GPMP2._step (gpmp2.py:308-342): CostComposite.get_linear_system
+ * (cost_functions.py:107-144 over CostGP :291-314, CostGoalPrior :538-554, CostCollision :191-231),
+ * _get_grad_terms dense branch (gpmp2.py:355-368), get_torch_solve('cholesky') (:451-452) and the
+ * update (:339), WITHOUT materialising the dense (A,b,K): the normal equations A^T K A are
+ * block-tridiagonal with 2D x 2D blocks and are assembled and solved per particle by block Cholesky.
+ *
+ * x (B,H,2D) in/out; start (2D), goal (2D) states (zero velocities appended by the host);
+ * damping: trust_region == 0 -> + delta * I; else + delta * diag_mean, where diag_mean (H*2D) is the
+ * batch mean of diag(A^T K A) (quirk Q9).  mpb_gpmp2_diag computes the LOCAL SUM of the diagonal
+ * into diag_sum (H*2D) (host divides by the global B, after an all-reduce when sharded);
+ * mpb_gpmp2_step consumes diag_mean (may be NULL when trust_region == 0).
+ * costs_out (B) optional: b^T K b of the iterate BEFORE the update (gpmp2.py:493-495).
+ * Internal arithmetic is fp64 (weights reach 1/sigma^2 = 1e10); storage is fp32.
+ * ------------------------------------------------------------------------------------------- */
+int mpb_gpmp2_diag(const float *x, const float *geom, float *diag_sum, int B, int H, int D, float dt,
+                   float sigma_start, float sigma_gp, float sigma_goal, float sigma_coll, void *stream);
+int mpb_gpmp2_step(float *x, const float *start, const float *goal, const float *geom,
+                   const float *diag_mean, float *costs_out, int B, int H, int D, float dt,
+                   float sigma_start, float sigma_gp, float sigma_goal, float sigma_coll,
+                   float delta, int trust_region, float step_size, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * MPPI -- replaces MPPI.optimize's loop body (mppi.py:145-152): ControlTrajectoryGaussian.sample
+ * (priors/gaussian.py:276-298), get_state_trajectories_rollout (mppi.py:190-210) over
+ * PointParticleDynamics.dynamics (dynamics/point.py:102-140, deterministic), traj_cost (:154-226),
+ * the importance-sampling term (mppi.py:125-128) and update_controller (:72-86).
+ * One problem per workgroup; NP independent problems per launch (the reference class is NP = 1).
+ *
+ * mean (NP,T,c) in/out; eps NULL -> device Philox, else (NP,c,S,T) standard normals (per control
+ * dimension, in the reference's draw order); scale_tril, cov_inv (c,T,T); state0 (NP,sd);
+ * goal (NP,sd); ctrl_min / ctrl_max (c); discount (T); c_weights = {pos, vel, ctrl, pos_T};
+ * control_type 0 = velocity (sd = c), 1 = acceleration (sd = 2c).
+ * geom optional (NULL = no collision term).  With geom, the reference's quirk Q6 is reproduced:
+ * the per-sample collision costs are summed into ONE scalar that is added to every sample's cost.
+ * Outputs of the last iteration: controls (NP,S,T,c), states (NP,S,T,sd), costs (NP,S), weights (NP,S).
+ * ------------------------------------------------------------------------------------------- */
+int mpb_mppi_step(float *mean, const float *eps, const float *scale_tril, const float *cov_inv,
+                  const float *state0, const float *goal, const float *ctrl_min, const float *ctrl_max,
+                  const float *discount, const float *c_weights, const float *geom,
+                  float *controls, float *states, float *costs, float *weights,
+                  int NP, int S, int T, int c, int control_type,
+                  float k_sigma, float weight, float temp, float step_size,
+                  int n_iters, uint64_t seed, uint32_t iter0, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPB_H */

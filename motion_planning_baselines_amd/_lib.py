@@ -1,0 +1,74 @@
+"""ctypes binding of csrc/libmpb_hip.so (C-ABI declared in include/mpb.h).
+
+The HIP extension is the product: there is no CPU or PyTorch fallback.  If the shared library is
+missing or does not export a symbol the header declares, importing this module's ``lib()`` raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libmpb_hip.so')
+
+_f = ctypes.c_float
+_i = ctypes.c_int
+_p = ctypes.c_void_p
+_u64 = ctypes.c_uint64
+_u32 = ctypes.c_uint32
+
+# name -> argtypes ; mirrors include/mpb.h one to one
+SIGNATURES = {
+    'mpb_version': [],
+    'mpb_last_error': [],
+    'mpb_geom_check': [_p, _i],
+    'mpb_cost_collision_eval': [_p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
+    'mpb_cost_collision_grad': [_p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
+    'mpb_stomp_step': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _u64, _u32, _u32, _p],
+    'mpb_stomp_sample': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _u64, _u32, _u32, _p],
+    'mpb_stomp_update': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
+    'mpb_chomp_step': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _p],
+    'mpb_gpmp2_diag': [_p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _f, _p],
+    'mpb_gpmp2_step': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _f, _f, _i, _f, _p],
+    'mpb_mppi_step': [_p] * 15 + [_i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _u64, _u32, _p],
+}
+
+_lib = None
+
+
+class MPBError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; fail loudly if the HIP extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MPBError(
+            f'{LIB_PATH} not found: the HIP extension is not built. Run '
+            f'`python -c "import __graft_entry__ as g; g.build()"` (or motion_planning_baselines_amd/build.py). '
+            f'There is no CPU fallback.')
+    h = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(h, name)
+        except AttributeError as e:
+            raise MPBError(f'{LIB_PATH} does not export {name} (declared in include/mpb.h)') from e
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_char_p if name == 'mpb_last_error' else ctypes.c_int
+    _lib = h
+    return h
+
+
+def check(code, what=''):
+    if code != 0:
+        msg = lib().mpb_last_error()
+        raise MPBError(f'{what} failed with code {code}: {msg.decode() if msg else "?"}')
+
+
+def geom_check(buf):
+    """Validate a packed geometry buffer (numpy fp32) on the host side of the C-ABI."""
+    buf = np.ascontiguousarray(buf, dtype=np.float32)
+    check(lib().mpb_geom_check(buf.ctypes.data_as(ctypes.c_void_p), int(buf.size)), 'mpb_geom_check')

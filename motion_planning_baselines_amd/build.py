@@ -1,0 +1,50 @@
+"""Build csrc/libmpb_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m motion_planning_baselines_amd.build
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+SOURCES = ['mpb_kernels.hip', 'mpb_gpmp2.hip', 'mpb_mppi.hip']
+OUT = os.path.join(CSRC, 'libmpb_hip.so')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
+         '-ffinite-math-only', '-fno-signed-zeros']
+
+
+def _stale():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h'))]
+    deps.append(os.path.join(os.path.dirname(HERE), 'include', 'mpb.h'))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not _stale():
+        return OUT
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, src.replace('.hip', '.o'))
+        objs.append(obj)
+        cmd = [hipcc, *FLAGS, '-c', os.path.join(CSRC, src), '-o', obj]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError('hipcc failed: ' + ' '.join(cmd))
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', OUT]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

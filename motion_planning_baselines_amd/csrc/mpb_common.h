@@ -1,0 +1,60 @@
+// mpb_common.h -- error plumbing and small device helpers shared by the translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/mpb.h"
+
+// thread-local last-error string (defined in mpb_kernels.hip)
+char* mpb_err_buf();
+static inline int mpb_fail(int code, const char* msg) {
+    snprintf(mpb_err_buf(), 512, "%s", msg);
+    return code;
+}
+static inline int mpb_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(mpb_err_buf(), 512, "%s: HIP launch failed: %s", what, hipGetErrorString(e));
+        return MPB_E_HIP;
+    }
+    return MPB_OK;
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// Philox4x32-10 (Salmon et al. 2011), counter-based: no state, result depends only on (key, counter).
+__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
+        const uint32_t hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
+        ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+        key.x += W0;
+        key.y += W1;
+    }
+    return ctr;
+}
+// two uniforms -> two standard normals (Box-Muller on the hardware log2 / sin / cos units)
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
+    const float u1 = ((a >> 8) + 1u) * (1.0f / 16777216.0f);  // (0,1]
+    const float u2 = (b >> 8) * (1.0f / 16777216.0f);         // [0,1)
+    const float r = __builtin_sqrtf(-1.3862943611198906f * __log2f(u1));  // sqrt(-2 ln u1)
+    n0 = r * __builtin_amdgcn_cosf(u2);  // v_cos_f32 takes revolutions: cos(2*pi*u2)
+    n1 = r * __builtin_amdgcn_sinf(u2);
+}

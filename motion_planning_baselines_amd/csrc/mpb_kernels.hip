@@ -1,0 +1,604 @@
+// mpb_kernels.hip -- gfx950 kernels + C-ABI (include/mpb.h) for the STOMP / CHOMP / collision-cost paths.
+//
+// Work mapping (CDNA4: 64-lane waves, 4 SIMDs per CU, 256 CUs):
+//   * one WAVE per rollout (trajectory), one LANE per waypoint -- H = 64 fills a wave exactly; longer
+//     horizons loop in 64-waypoint chunks.  FK + SDF of a waypoint run entirely in registers with all
+//     geometry constants as scalar (SGPR) operands; the per-trajectory cost is a wave reduction.
+//   * B = P*S rollouts -> B waves; C3 (B = 4096) is exactly 4 waves per SIMD over the whole chip.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "mpb_common.h"
+#include "mpb_geom.h"
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+char* mpb_err_buf() { return g_err; }
+
+static int fail(int code, const char* fmt, const char* a = "", long b = 0, long c = 0) {
+    snprintf(g_err, sizeof(g_err), fmt, a, b, c);
+    return code;
+}
+
+#define MPB_REQUIRE(cond, msg)                                                     \
+    do {                                                                           \
+        if (!(cond)) return fail(MPB_E_INVALID, "%s: requirement failed: " msg " [%ld,%ld]", __func__, 0, 0); \
+    } while (0)
+
+static int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "%s: HIP launch failed: %s", what, hipGetErrorString(e));
+        return MPB_E_HIP;
+    }
+    return MPB_OK;
+}
+
+extern "C" int mpb_version(void) { return 1; }
+extern "C" const char* mpb_last_error(void) { return g_err; }
+
+extern "C" int mpb_geom_check(const float* g, int n_words) {
+    if (!g || n_words < MPB_GEOM_HEADER_WORDS) return fail(MPB_E_INVALID, "%s: geometry buffer too small", __func__);
+    const int32_t* gi = reinterpret_cast<const int32_t*>(g);
+    if (gi[0] != MPB_GEOM_MAGIC || gi[1] != MPB_GEOM_VERSION) return fail(MPB_E_INVALID, "%s: bad magic/version", __func__);
+    const int kind = gi[2], n_dof = gi[3], n_tf = gi[4], n_links = gi[5], n_sph = gi[6], n_box = gi[7];
+    if (kind != MPB_KIND_POINT && kind != MPB_KIND_CHAIN) return fail(MPB_E_INVALID, "%s: unknown robot kind", __func__);
+    if (n_dof < 1 || n_dof > MPB_MAX_DOF) return fail(MPB_E_INVALID, "%s: n_dof out of range", __func__);
+    if (kind == MPB_KIND_POINT && (n_dof < 2 || n_dof > 3 || n_links != 1)) return fail(MPB_E_INVALID, "%s: point robot must be 2-D/3-D with one sphere", __func__);
+    if (kind == MPB_KIND_CHAIN && n_tf != n_dof + 1) return fail(MPB_E_INVALID, "%s: chain needs n_dof+1 transforms", __func__);
+    if (n_links < 1 || n_sph < 0 || n_box < 0 || n_sph + n_box < 1) return fail(MPB_E_INVALID, "%s: empty link/obstacle set", __func__);
+    const int off_tf = gi[9], off_links = gi[10], off_sph = gi[11], off_box = gi[12], total = gi[13];
+    if (off_tf != MPB_GEOM_HEADER_WORDS || off_links != off_tf + 12 * n_tf || off_sph != off_links + 8 * n_links ||
+        off_box != off_sph + 4 * n_sph || total != off_box + 8 * n_box || total > n_words)
+        return fail(MPB_E_INVALID, "%s: inconsistent section offsets", __func__);
+    if ((off_links | off_sph | off_box) & 3) return fail(MPB_E_INVALID, "%s: sections must be 16-byte aligned", __func__);
+    int prev = 1;
+    for (int l = 0; l < n_links; ++l) {
+        const int f = gi[off_links + 8 * l];
+        if (kind == MPB_KIND_CHAIN && (f < prev || f > n_dof + 1)) return fail(MPB_E_INVALID, "%s: link frames must be sorted in [1, n_dof+1]", __func__);
+        prev = f > prev ? f : prev;
+    }
+    return MPB_OK;
+}
+
+#define MPB_MAX_D (2 * MPB_MAX_DOF)
+
+// ------------------------------------------------------------------------------------------------
+// STOMP kernel A: sample one rollout per wave, write it, evaluate its collision cost.
+//   noise[h][c] = sum_k L[h][k] eps[c][k]; rows 0 and H-1 zeroed; sample = mean + noise
+//   (stomp.py:97-108).  L^T is staged in LDS so lane h reads L[h][k] conflict-free; eps lives one
+//   value per lane (lane k) and is broadcast with v_readlane.
+// ------------------------------------------------------------------------------------------------
+template <bool WITH_COST>
+__global__ __launch_bounds__(256) void stomp_sample_cost_kernel(
+    const float* __restrict__ means, const float* __restrict__ eps, float* __restrict__ samples,
+    float* __restrict__ costs, const float* __restrict__ Lmat, const float* __restrict__ geom,
+    int P, int S, int H, int d, int D, float k_sigma, float weight,
+    uint32_t seed_lo, uint32_t seed_hi, uint32_t iter, uint32_t particle_offset) {
+    extern __shared__ float lds[];  // Lt[k*H + h]
+    for (int i = threadIdx.x; i < H * H; i += blockDim.x) {
+        const int h = i / H, k = i - h * H;
+        lds[k * H + h] = Lmat[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * (blockDim.x >> 6) + wave;  // rollout index
+    if (r >= P * S) return;
+    const int p = r / S, s = r - p * S;
+    GeomView G;
+    if (WITH_COST) G = geom_view(geom);
+    double csum = 0.0;
+    const int nchunk = (H + 63) >> 6;
+    for (int hc = 0; hc < nchunk; ++hc) {
+        const int h = hc * 64 + lane;
+        float acc[MPB_MAX_D];
+#pragma unroll
+        for (int c = 0; c < MPB_MAX_D; ++c) acc[c] = 0.f;
+        // L is lower triangular: rows of this chunk only need k < (hc+1)*64
+        const int kend = min(H, (hc + 1) * 64);
+        for (int kc = 0; kc * 64 < kend; ++kc) {
+            const int k0 = kc * 64;
+            const int kl = k0 + lane;
+            // this lane's eps[c][kl] for every channel
+            float e[MPB_MAX_D];
+            if (eps != nullptr) {
+#pragma unroll
+                for (int c = 0; c < MPB_MAX_D; ++c)
+                    e[c] = (c < d && kl < H) ? eps[(((size_t)s * d + c) * P + p) * H + kl] : 0.f;
+            } else {
+#pragma unroll
+                for (int c4 = 0; c4 < MPB_MAX_D / 4; ++c4) {
+                    float n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
+                    if (c4 * 4 < d) {
+                        const uint4 rr = philox4x32_10(
+                            make_uint4(particle_offset + (uint32_t)p, (uint32_t)s, ((uint32_t)kl << 4) | (uint32_t)c4, iter),
+                            make_uint2(seed_lo, seed_hi));
+                        box_muller(rr.x, rr.y, n0, n1);
+                        box_muller(rr.z, rr.w, n2, n3);
+                    }
+                    e[c4 * 4 + 0] = n0; e[c4 * 4 + 1] = n1; e[c4 * 4 + 2] = n2; e[c4 * 4 + 3] = n3;
+                }
+            }
+            const int kn = min(64, kend - k0);
+            for (int kk = 0; kk < kn; ++kk) {
+                const float lv = (h < H) ? lds[(k0 + kk) * H + h] : 0.f;
+#pragma unroll
+                for (int c = 0; c < MPB_MAX_D; ++c) {
+                    if (c < d) {
+                        const float ev = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[c]), kk));
+                        acc[c] = fmaf(lv, ev, acc[c]);
+                    }
+                }
+            }
+        }
+        if (h < H) {
+            const bool edge = (h == 0) || (h == H - 1);
+            const float* mrow = means + ((size_t)p * H + h) * d;
+            float* srow = samples + (((size_t)p * S + s) * H + h) * d;
+            float q[MPB_MAX_DOF];
+#pragma unroll
+            for (int c = 0; c < MPB_MAX_D; ++c) {
+                if (c < d) {
+                    const float v = mrow[c] + (edge ? 0.f : acc[c]);
+                    srow[c] = v;
+                    if (c < MPB_MAX_DOF) q[c] = v;
+                } else if (c < MPB_MAX_DOF) {
+                    q[c] = 0.f;
+                }
+            }
+            if (WITH_COST && h >= 1) {
+                float dq[MPB_MAX_DOF];
+                csum += (double)waypoint_cost<false>(G, q, dq);
+            }
+        }
+    }
+    if (WITH_COST) {
+        csum = wave_sum_f64(csum);
+        if (lane == 0) costs[r] = weight * (k_sigma * (float)csum);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// STOMP kernel A, H = 64 fast path: the time-correlated noise  N = L * eps  (64x64 lower-triangular L,
+// the scale_tril of the precision matrix R; eps 64 x d) runs on the matrix cores as exact-fp32
+// v_mfma_f32_16x16x4_f32 tiles, one rollout per wave:
+//   A operand  L[16m+i][4ks+g]   (lane i = l&15, g = l>>4)  from an LDS image laid out so that one
+//                                 ds_read_b128 per lane delivers four k-steps, conflict-free;
+//   B operand  eps[c=j][4ks+g]   (lane j = l&15, g = l>>4)  generated in registers (Philox) or loaded;
+//   lower-triangular: row tile m only needs k-steps ks <= 4m+3  ->  40 instead of 64 MFMAs.
+// The D tiles (lane = channel) go through a padded LDS tile to the lane = waypoint layout the
+// FK + SDF cost evaluation wants.  DCH = d is a compile-time channel count (no per-channel branches).
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define NT_STRIDE 20  // floats per waypoint row of the noise tile: 80 B keeps ds_read_b128 conflict-free
+
+template <int DCH, bool WITH_COST>
+__global__ __launch_bounds__(256) void stomp_sample_cost_h64_kernel(
+    const float* __restrict__ means, const float* __restrict__ eps, float* __restrict__ samples,
+    float* __restrict__ costs, const float* __restrict__ Lmat, const float* __restrict__ geom,
+    int P, int S, float k_sigma, float weight, uint32_t seed_lo, uint32_t seed_hi, uint32_t iter,
+    uint32_t particle_offset) {
+    constexpr int H = 64;
+    __shared__ __attribute__((aligned(16))) float Lp[H * H];             // permuted L, 16 KB
+    __shared__ __attribute__((aligned(16))) float Nt[4][H * NT_STRIDE];  // per-wave noise tile, 4 x 5 KB
+    // Lp[(((m*4 + ks4)*4 + g)*16 + i)*4 + kk] = L[16m+i][4*(4*ks4+kk) + g]
+    for (int idx = threadIdx.x; idx < H * H; idx += 256) {
+        const int kk = idx & 3, i = (idx >> 2) & 15, g = (idx >> 6) & 3, ks4 = (idx >> 8) & 3, m = idx >> 10;
+        Lp[idx] = Lmat[(16 * m + i) * H + 4 * (4 * ks4 + kk) + g];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wave;  // rollout index
+    const bool live = r < P * S;
+    const int p = live ? r / S : 0, s = live ? r - p * S : 0;
+    const int j = lane & 15, g = lane >> 4;
+
+    // ---- B operand: eps[c=j][k=4ks+g], ks = 0..15
+    float e[16];
+    if (eps != nullptr) {
+        const float* ep = eps + (((size_t)s * DCH + (j < DCH ? j : 0)) * P + p) * H + g;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) e[ks] = (j < DCH) ? ep[4 * ks] : 0.f;
+    } else {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            float n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
+            if (j < DCH) {
+                const uint4 rr = philox4x32_10(
+                    make_uint4(particle_offset + (uint32_t)p, (uint32_t)s, ((uint32_t)j << 16) | ((uint32_t)g << 8) | (uint32_t)q4, iter),
+                    make_uint2(seed_lo, seed_hi));
+                box_muller(rr.x, rr.y, n0, n1);
+                box_muller(rr.z, rr.w, n2, n3);
+            }
+            e[4 * q4 + 0] = n0; e[4 * q4 + 1] = n1; e[4 * q4 + 2] = n2; e[4 * q4 + 3] = n3;
+        }
+    }
+    // ---- N = L * eps on the matrix cores
+    const f32x4* Lp4 = reinterpret_cast<const f32x4*>(Lp);
+    float* nt = Nt[wave];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks4 = 0; ks4 <= m; ++ks4) {
+            const f32x4 a = Lp4[((m * 4 + ks4) * 4 + g) * 16 + j];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], e[4 * ks4 + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], e[4 * ks4 + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], e[4 * ks4 + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], e[4 * ks4 + 3], acc, 0, 0, 0);
+        }
+        // D[row = 4g + rr][col = j] -> noise tile [waypoint][channel]
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) nt[(16 * m + 4 * g + rr) * NT_STRIDE + j] = acc[rr];
+    }
+    __syncthreads();  // tile written by lane = channel, read by lane = waypoint
+    // ---- lane = waypoint h
+    const int h = lane;
+    float nz[16];
+    {
+        const f32x4* row = reinterpret_cast<const f32x4*>(nt + h * NT_STRIDE);
+#pragma unroll
+        for (int v = 0; v < (DCH + 3) / 4; ++v) {
+            const f32x4 t = row[v];
+            nz[4 * v + 0] = t[0]; nz[4 * v + 1] = t[1]; nz[4 * v + 2] = t[2]; nz[4 * v + 3] = t[3];
+        }
+    }
+    if (!live) return;
+    const bool edge = (h == 0) || (h == H - 1);
+    const float* mrow = means + ((size_t)p * H + h) * DCH;
+    float* srow = samples + (((size_t)p * S + s) * H + h) * DCH;
+    float x[DCH];
+    if (DCH % 2 == 0) {
+#pragma unroll
+        for (int c = 0; c < DCH; c += 2) {
+            const float2 mv = *reinterpret_cast<const float2*>(mrow + c);
+            x[c] = mv.x + (edge ? 0.f : nz[c]);
+            x[c + 1] = mv.y + (edge ? 0.f : nz[c + 1]);
+            *reinterpret_cast<float2*>(srow + c) = make_float2(x[c], x[c + 1]);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < DCH; ++c) {
+            x[c] = mrow[c] + (edge ? 0.f : nz[c]);
+            srow[c] = x[c];
+        }
+    }
+    if (WITH_COST) {
+        const GeomView G = geom_view(geom);
+        float q[MPB_MAX_DOF], dq[MPB_MAX_DOF];
+#pragma unroll
+        for (int i = 0; i < MPB_MAX_DOF; ++i) q[i] = (i < DCH) ? x[i < DCH ? i : 0] : 0.f;
+        float c = 0.f;
+        if (h >= 1) c = waypoint_cost<false>(G, q, dq);
+        const double csum = wave_sum_f64((double)c);
+        if (lane == 0) costs[r] = weight * (k_sigma * (float)csum);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// STOMP kernel B: one workgroup per particle.
+//   w = softmax(-c/T) over S (stomp.py:219-220); delta = sum_s w_s (sample_s - mean);
+//   mean += (lr*Sigma) @ delta (stomp.py:207-211; `lr * Sigma @ x` binds as (lr*Sigma) @ x).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void stomp_update_kernel(
+    float* __restrict__ means, const float* __restrict__ samples, const float* __restrict__ costs,
+    float* __restrict__ weights, const float* __restrict__ Sigma, int P, int S, int H, int d, float lr,
+    float temperature, int sigma_in_lds) {
+    extern __shared__ float lds[];
+    const int n = H * d;
+    const int SG = (S >= 4) ? 4 : 1;  // sample groups reduced in parallel, combined in fixed order
+    float* w_lds = lds;               // S
+    float* delta = w_lds + S;         // n
+    float* part = delta + n;          // SG * n
+    float* sig = part + SG * n;       // H*H when staged
+    __shared__ float red[16];
+    const int p = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    if (sigma_in_lds)
+        for (int i = tid; i < H * H; i += blockDim.x) sig[i] = lr * Sigma[i];
+    // ---- softmax over S
+    float m = -3.0e38f;
+    for (int s = tid; s < S; s += blockDim.x) {
+        const float x = -costs[(size_t)p * S + s] / temperature;
+        w_lds[s] = x;
+        m = fmaxf(m, x);
+    }
+    m = wave_max_f32(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = red[0];
+    for (int i = 1; i < nw; ++i) m = fmaxf(m, red[i]);
+    __syncthreads();
+    float z = 0.f;
+    for (int s = tid; s < S; s += blockDim.x) {
+        const float e = expf(w_lds[s] - m);
+        w_lds[s] = e;
+        z += e;
+    }
+    z = wave_sum_f32(z);
+    if (lane == 0) red[wave] = z;
+    __syncthreads();
+    z = 0.f;
+    for (int i = 0; i < nw; ++i) z += red[i];
+    for (int s = tid; s < S; s += blockDim.x) {
+        const float w = w_lds[s] / z;
+        w_lds[s] = w;
+        weights[(size_t)p * S + s] = w;
+    }
+    __syncthreads();
+    // ---- weighted noise reduce: (element, sample-group) work items, coalesced over the H*d row
+    for (int idx = tid; idx < n * SG; idx += blockDim.x) {
+        const int sg = idx / n, i = idx - sg * n;
+        const int s0 = (sg * S) / SG, s1 = ((sg + 1) * S) / SG;
+        const float mu = means[(size_t)p * n + i];
+        const float* sp = samples + ((size_t)p * S) * n + i;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int s = s0; s < s1; ++s) acc += w_lds[s] * (sp[(size_t)s * n] - mu);
+        part[idx] = acc;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += blockDim.x) {
+        float acc = part[i];
+        for (int sg = 1; sg < SG; ++sg) acc += part[sg * n + i];
+        delta[i] = acc;
+    }
+    __syncthreads();
+    // ---- covariance-weighted step: mean += (lr*Sigma) @ delta
+    for (int i = tid; i < n; i += blockDim.x) {
+        const int h = i / d, c = i - h * d;
+        float acc = 0.f;
+        if (sigma_in_lds) {
+            for (int k = 0; k < H; ++k) acc = fmaf(sig[h * H + k], delta[k * d + c], acc);
+        } else {
+            for (int k = 0; k < H; ++k) acc = fmaf(lr * Sigma[h * H + k], delta[k * d + c], acc);
+        }
+        means[(size_t)p * n + i] += acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stand-alone collision cost (and gradient): one wave per trajectory, lane = waypoint.
+// ------------------------------------------------------------------------------------------------
+template <bool GRAD>
+__global__ __launch_bounds__(256) void collision_cost_kernel(
+    const float* __restrict__ trajs, const float* __restrict__ geom, float* __restrict__ out,
+    float* __restrict__ per_wp, float* __restrict__ grad, int B, int H, int d, int h_begin, float k_sigma,
+    float weight) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const GeomView G = geom_view(geom);
+    const int D = G.n_dof;
+    double csum = 0.0;
+    for (int h = lane; h < ((H + 63) & ~63); h += 64) {
+        float c = 0.f;
+        if (h < H) {
+            const float* row = trajs + ((size_t)b * H + h) * d;
+            float q[MPB_MAX_DOF], dq[MPB_MAX_DOF];
+#pragma unroll
+            for (int i = 0; i < MPB_MAX_DOF; ++i) q[i] = (i < D) ? row[i] : 0.f;
+            if (h >= h_begin) c = waypoint_cost<GRAD>(G, q, dq);
+            if (per_wp) per_wp[(size_t)b * H + h] = c;
+            if (GRAD) {
+                float* grow = grad + ((size_t)b * H + h) * d;
+                const float sc = weight * k_sigma;
+#pragma unroll
+                for (int i = 0; i < MPB_MAX_D; ++i)
+                    if (i < d) grow[i] = (i < MPB_MAX_DOF && i < D && h >= h_begin) ? sc * dq[i < MPB_MAX_DOF ? i : 0] : 0.f;
+            }
+        }
+        csum += (double)c;
+    }
+    csum = wave_sum_f64(csum);
+    if (lane == 0) out[b] = weight * (k_sigma * (float)csum);
+}
+
+// ------------------------------------------------------------------------------------------------
+// CHOMP: one workgroup per particle, one thread per waypoint, the whole optimisation loop in one
+// launch.  The trajectory tile lives in LDS (the finite-difference stencil reads the h-1 / h+1 rows
+// from there); each thread keeps its own row in registers.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void chomp_kernel(float* __restrict__ means, const float* __restrict__ R,
+                             const float* __restrict__ geom, float* __restrict__ costs_out, int B_global,
+                             int H, int d, int D, float k_sigma, float weight, float w_prior, float lr,
+                             float grad_clip, int n_iters) {
+    extern __shared__ float tile[];  // H x d
+    __shared__ double red[16];
+    const int b = blockIdx.x;
+    const int h = threadIdx.x;
+    const bool active = h < H;
+    const GeomView G = geom_view(geom);
+    float x[MPB_MAX_D];
+    float* row = means + ((size_t)b * H + (active ? h : 0)) * d;
+#pragma unroll
+    for (int c = 0; c < MPB_MAX_D; ++c) x[c] = (active && c < d) ? row[c] : 0.f;
+    // tridiagonal band of R (chomp.py:81-101) for this row
+    const float r_lo = (active && h > 0) ? R[h * H + h - 1] : 0.f;
+    const float r_di = active ? R[h * H + h] : 0.f;
+    const float r_up = (active && h < H - 1) ? R[h * H + h + 1] : 0.f;
+    // d/dx of w_prior * sum_b sum_c x^T R x summed over B costs: (B*w) * (R x + R^T x)
+    const float bw = (float)B_global * w_prior;
+    const bool interior = active && h > 0 && h < H - 1;
+    for (int it = 0; it < n_iters; ++it) {
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int c = 0; c < MPB_MAX_D; ++c)
+                if (c < d) tile[h * d + c] = x[c];
+        }
+        __syncthreads();
+        float dq[MPB_MAX_DOF];
+        float cw = 0.f;
+        if (active && h >= 1) {
+            float q[MPB_MAX_DOF];
+#pragma unroll
+            for (int i = 0; i < MPB_MAX_DOF; ++i) q[i] = x[i];
+            cw = waypoint_cost<true>(G, q, dq);
+        } else {
+#pragma unroll
+            for (int i = 0; i < MPB_MAX_DOF; ++i) dq[i] = 0.f;
+        }
+        if (costs_out != nullptr && it == n_iters - 1) {
+            double cs = wave_sum_f64((double)cw);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cs;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double t = 0.0;
+                for (int i = 0; i < (int)((blockDim.x + 63) >> 6); ++i) t += red[i];
+                costs_out[b] = weight * (k_sigma * (float)t);
+            }
+        }
+        if (interior) {
+            const float sc = weight * k_sigma;
+#pragma unroll
+            for (int c = 0; c < MPB_MAX_D; ++c) {
+                if (c < d) {
+                    const float xm = tile[(h - 1) * d + c], xp = tile[(h + 1) * d + c];
+                    const float rx = r_lo * xm + r_di * x[c] + r_up * xp;
+                    float g = bw * (rx + rx);
+                    if (c < MPB_MAX_DOF && c < D) g += sc * dq[c < MPB_MAX_DOF ? c : 0];
+                    g = fminf(fmaxf(g, -grad_clip), grad_clip);
+                    x[c] += -lr * g;
+                }
+            }
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int c = 0; c < MPB_MAX_D; ++c)
+            if (c < d) row[c] = x[c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------------------
+// LDS budget of the update kernel: weights + delta + 4 partial tiles (+ lr*Sigma when it fits)
+static bool update_lds(int S, int H, int d, size_t& bytes, int& sigma_in_lds) {
+    const size_t base = ((size_t)S + 5 * (size_t)H * d) * 4;
+    const size_t with_sigma = base + (size_t)H * H * 4;
+    sigma_in_lds = with_sigma <= 64 * 1024;
+    bytes = sigma_in_lds ? with_sigma : base;
+    return bytes <= 150 * 1024;
+}
+
+// kernel A launcher: H = 64 takes the MFMA fast path for the channel counts of the reference's robots
+template <bool WITH_COST>
+static void launch_sample(const float* means, const float* eps, float* samples, float* costs, const float* L,
+                          const float* geom, int P, int S, int H, int d, float k_sigma, float weight, uint64_t seed,
+                          uint32_t iter, uint32_t particle_offset, hipStream_t st) {
+    const int B = P * S;
+    const dim3 grid((B + 3) / 4), block(256);
+    const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
+#define MPB_A_CASE(DCH)                                                                                          \
+    case DCH:                                                                                                    \
+        hipLaunchKernelGGL((stomp_sample_cost_h64_kernel<DCH, WITH_COST>), grid, block, 0, st, means, eps, samples, \
+                           costs, L, geom, P, S, k_sigma, weight, lo, hi, iter, particle_offset);                \
+        return;
+    if (H == 64) {
+        switch (d) {
+            MPB_A_CASE(2) MPB_A_CASE(3) MPB_A_CASE(4) MPB_A_CASE(6) MPB_A_CASE(7) MPB_A_CASE(14)
+            default: break;
+        }
+    }
+#undef MPB_A_CASE
+    hipLaunchKernelGGL(stomp_sample_cost_kernel<WITH_COST>, grid, block, (size_t)H * H * 4, st, means, eps, samples,
+                       costs, L, geom, P, S, H, d, d, k_sigma, weight, lo, hi, iter, particle_offset);
+}
+
+static bool shape_ok(int H, int d, int D) {
+    return H >= 3 && H <= MPB_MAX_H && D >= 1 && D <= MPB_MAX_DOF && (d == D || d == 2 * D);
+}
+
+extern "C" int mpb_cost_collision_eval(const float* trajs, const float* geom, float* out, float* per_waypoint,
+                                       int B, int H, int d, int h_begin, float k_sigma, float weight, void* stream) {
+    if (!trajs || !geom || !out) return fail(MPB_E_INVALID, "%s: null pointer", __func__);
+    if (B < 0 || H < 1 || d < 1 || d > MPB_MAX_D || h_begin < 0) return fail(MPB_E_INVALID, "%s: bad shape", __func__);
+    if (B == 0) return MPB_OK;
+    hipLaunchKernelGGL(collision_cost_kernel<false>, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, trajs, geom,
+                       out, per_waypoint, (float*)nullptr, B, H, d, h_begin, k_sigma, weight);
+    return check_launch(__func__);
+}
+
+extern "C" int mpb_cost_collision_grad(const float* trajs, const float* geom, float* out, float* grad, int B, int H,
+                                       int d, int h_begin, float k_sigma, float weight, void* stream) {
+    if (!trajs || !geom || !out || !grad) return fail(MPB_E_INVALID, "%s: null pointer", __func__);
+    if (B < 0 || H < 1 || d < 1 || d > MPB_MAX_D || h_begin < 0) return fail(MPB_E_INVALID, "%s: bad shape", __func__);
+    if (B == 0) return MPB_OK;
+    hipLaunchKernelGGL(collision_cost_kernel<true>, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, trajs, geom,
+                       out, (float*)nullptr, grad, B, H, d, h_begin, k_sigma, weight);
+    return check_launch(__func__);
+}
+
+extern "C" int mpb_stomp_sample(const float* means, const float* eps, float* samples, const float* L,
+                                const float* geom, float* costs, int P, int S, int H, int d, float k_sigma,
+                                float weight, uint64_t seed, uint32_t iter, uint32_t particle_offset, void* stream) {
+    if (!means || !samples || !L) return fail(MPB_E_INVALID, "%s: null pointer", __func__);
+    if ((geom == nullptr) != (costs == nullptr)) return fail(MPB_E_INVALID, "%s: geom and costs must be given together", __func__);
+    if (P < 0 || S < 1 || H < 3 || H > MPB_MAX_H || d < 1 || d > MPB_MAX_D) return fail(MPB_E_INVALID, "%s: bad shape", __func__);
+    if ((size_t)H * H * 4 > 160 * 1024) return fail(MPB_E_UNSUPPORTED, "%s: H too large for LDS staging of L", __func__);
+    if (P == 0) return MPB_OK;
+    if (geom)
+        launch_sample<true>(means, eps, samples, costs, L, geom, P, S, H, d, k_sigma, weight, seed, iter,
+                            particle_offset, (hipStream_t)stream);
+    else
+        launch_sample<false>(means, eps, samples, nullptr, L, nullptr, P, S, H, d, 0.f, 0.f, seed, iter,
+                             particle_offset, (hipStream_t)stream);
+    return check_launch(__func__);
+}
+
+extern "C" int mpb_stomp_update(float* means, const float* samples, const float* costs, float* weights,
+                                const float* Sigma, int P, int S, int H, int d, float lr, float temperature,
+                                void* stream) {
+    if (!means || !samples || !costs || !weights || !Sigma) return fail(MPB_E_INVALID, "%s: null pointer", __func__);
+    if (P < 0 || S < 1 || H < 3 || H > MPB_MAX_H || d < 1 || d > MPB_MAX_D) return fail(MPB_E_INVALID, "%s: bad shape", __func__);
+    if (!(temperature > 0.f)) return fail(MPB_E_INVALID, "%s: temperature must be > 0", __func__);
+    if (P == 0) return MPB_OK;
+    size_t lds;
+    int sig_lds;
+    if (!update_lds(S, H, d, lds, sig_lds)) return fail(MPB_E_UNSUPPORTED, "%s: S + H*d too large for LDS", __func__);
+    hipLaunchKernelGGL(stomp_update_kernel, dim3(P), dim3(1024), lds, (hipStream_t)stream, means, samples, costs,
+                       weights, Sigma, P, S, H, d, lr, temperature, sig_lds);
+    return check_launch(__func__);
+}
+
+extern "C" int mpb_stomp_step(float* means, const float* eps, float* samples, float* costs, float* weights,
+                              const float* L, const float* Sigma, const float* geom, int P, int S, int H, int d, int D,
+                              float k_sigma, float weight, float lr, float temperature, int n_iters, uint64_t seed,
+                              uint32_t iter0, uint32_t particle_offset, void* stream) {
+    if (!means || !samples || !costs || !weights || !L || !Sigma || !geom) return fail(MPB_E_INVALID, "%s: null pointer", __func__);
+    if (P < 0 || S < 1 || !shape_ok(H, d, D) || n_iters < 0) return fail(MPB_E_INVALID, "%s: bad shape", __func__);
+    if (!(temperature > 0.f)) return fail(MPB_E_INVALID, "%s: temperature must be > 0", __func__);
+    if ((size_t)H * H * 4 > 160 * 1024) return fail(MPB_E_UNSUPPORTED, "%s: H too large for LDS staging of L", __func__);
+    size_t lds_b;
+    int sig_lds;
+    if (!update_lds(S, H, d, lds_b, sig_lds)) return fail(MPB_E_UNSUPPORTED, "%s: S + H*d too large for LDS", __func__);
+    if (P == 0) return MPB_OK;
+    const size_t eps_stride = (size_t)S * d * P * H;
+    for (int it = 0; it < n_iters; ++it) {
+        launch_sample<true>(means, eps ? eps + (size_t)it * eps_stride : nullptr, samples, costs, L, geom, P, S, H, d,
+                            k_sigma, weight, seed, iter0 + (uint32_t)it, particle_offset, (hipStream_t)stream);
+        hipLaunchKernelGGL(stomp_update_kernel, dim3(P), dim3(1024), lds_b, (hipStream_t)stream, means, samples, costs,
+                           weights, Sigma, P, S, H, d, lr, temperature, sig_lds);
+    }
+    return check_launch(__func__);
+}
+
+extern "C" int mpb_chomp_step(float* means, const float* R, const float* geom, float* costs_out, int B_local,
+                              int B_global, int H, int d, int D, float k_sigma, float weight, float w_prior, float lr,
+                              float grad_clip, int n_iters, void* stream) {
+    if (!means || !R || !geom) return fail(MPB_E_INVALID, "%s: null pointer", __func__);
+    if (B_local < 0 || B_global < B_local || !shape_ok(H, d, D) || n_iters < 0) return fail(MPB_E_INVALID, "%s: bad shape", __func__);
+    if (B_local == 0 || n_iters == 0) return MPB_OK;
+    const int threads = (H + 63) & ~63;
+    hipLaunchKernelGGL(chomp_kernel, dim3(B_local), dim3(threads), (size_t)H * d * 4, (hipStream_t)stream, means, R,
+                       geom, costs_out, B_global, H, d, D, k_sigma, weight, w_prior, lr, grad_clip, n_iters);
+    return check_launch(__func__);
+}

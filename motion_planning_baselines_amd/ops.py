@@ -1,0 +1,136 @@
+"""Tensor-level wrappers over the C-ABI: take PyTorch-ROCm tensors, pass raw device pointers + the
+current HIP stream.  PyTorch is plumbing here (device memory, streams); all arithmetic is in
+csrc/*.hip.  Every wrapper validates device / dtype / contiguity / shape on the host before
+launching (a kernel that faults can reset the whole GPU host).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .geometry import pack_geometry
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _chk(t, shape, name, allow_none=False):
+    if t is None:
+        if allow_none:
+            return
+        raise ValueError(f'{name} is required')
+    if not t.is_cuda:
+        raise ValueError(f'{name} must live on the GPU (got {t.device}); there is no CPU path')
+    if t.dtype != torch.float32:
+        raise ValueError(f'{name} must be float32 (got {t.dtype})')
+    if not t.is_contiguous():
+        raise ValueError(f'{name} must be contiguous')
+    if tuple(t.shape) != tuple(shape):
+        raise ValueError(f'{name} has shape {tuple(t.shape)}, expected {tuple(shape)}')
+
+
+class DeviceGeometry:
+    """Packed robot + field geometry resident in HBM (one small fp32 buffer)."""
+
+    def __init__(self, robot, field, device):
+        self.robot, self.field = robot, field
+        host = pack_geometry(robot, field)
+        _lib.geom_check(host)
+        self.host = host
+        self.n_dof = robot.q_dim
+        self.buf = torch.from_numpy(host.copy()).to(device)
+
+    @classmethod
+    def from_packed(cls, packed, device):
+        self = cls.__new__(cls)
+        host = np.ascontiguousarray(packed, dtype=np.float32)
+        _lib.geom_check(host)
+        self.robot = self.field = None
+        self.host = host
+        self.n_dof = int(host.view(np.int32)[3])
+        self.buf = torch.from_numpy(host.copy()).to(device)
+        return self
+
+
+def cost_collision_eval(trajs, geom, k_sigma, weight=1.0, h_begin=1, per_waypoint=False):
+    B, H, d = trajs.shape
+    _chk(trajs, (B, H, d), 'trajs')
+    out = torch.empty(B, device=trajs.device, dtype=torch.float32)
+    pw = torch.empty(B, H, device=trajs.device, dtype=torch.float32) if per_waypoint else None
+    _lib.check(_lib.lib().mpb_cost_collision_eval(_ptr(trajs), _ptr(geom.buf), _ptr(out), _ptr(pw), B, H, d, h_begin,
+                                                 float(k_sigma), float(weight), _stream()), 'mpb_cost_collision_eval')
+    return (out, pw) if per_waypoint else out
+
+
+def cost_collision_grad(trajs, geom, k_sigma, weight=1.0, h_begin=1):
+    B, H, d = trajs.shape
+    _chk(trajs, (B, H, d), 'trajs')
+    out = torch.empty(B, device=trajs.device, dtype=torch.float32)
+    grad = torch.empty_like(trajs)
+    _lib.check(_lib.lib().mpb_cost_collision_grad(_ptr(trajs), _ptr(geom.buf), _ptr(out), _ptr(grad), B, H, d, h_begin,
+                                                 float(k_sigma), float(weight), _stream()), 'mpb_cost_collision_grad')
+    return out, grad
+
+
+def stomp_step(means, eps, samples, costs, weights, L, Sigma, geom, S, D, k_sigma, weight, lr, temperature,
+               n_iters=1, seed=0, iter0=0, particle_offset=0):
+    P, H, d = means.shape
+    _chk(means, (P, H, d), 'means')
+    _chk(samples, (P, S, H, d), 'samples')
+    _chk(costs, (P, S), 'costs')
+    _chk(weights, (P, S), 'weights')
+    _chk(L, (H, H), 'L')
+    _chk(Sigma, (H, H), 'Sigma')
+    if eps is not None:
+        _chk(eps, (n_iters, S, d, P, H), 'eps')
+    _lib.check(_lib.lib().mpb_stomp_step(
+        _ptr(means), _ptr(eps), _ptr(samples), _ptr(costs), _ptr(weights), _ptr(L), _ptr(Sigma), _ptr(geom.buf),
+        P, S, H, d, D, float(k_sigma), float(weight), float(lr), float(temperature), int(n_iters),
+        int(seed) & (2 ** 64 - 1), int(iter0), int(particle_offset), _stream()), 'mpb_stomp_step')
+
+
+def stomp_sample(means, eps, samples, L, S, seed=0, it=0, particle_offset=0, geom=None, costs=None, k_sigma=0.0,
+                 weight=1.0):
+    """First kernel of an iteration: draw + write samples; with geom/costs also the fused collision cost."""
+    P, H, d = means.shape
+    _chk(means, (P, H, d), 'means')
+    _chk(samples, (P, S, H, d), 'samples')
+    _chk(L, (H, H), 'L')
+    if eps is not None:
+        _chk(eps, (S, d, P, H), 'eps')
+    if (geom is None) != (costs is None):
+        raise ValueError('geom and costs must be given together')
+    if costs is not None:
+        _chk(costs, (P, S), 'costs')
+    _lib.check(_lib.lib().mpb_stomp_sample(_ptr(means), _ptr(eps), _ptr(samples), _ptr(L),
+                                          _ptr(None if geom is None else geom.buf), _ptr(costs), P, S, H, d,
+                                          float(k_sigma), float(weight), int(seed) & (2 ** 64 - 1), int(it),
+                                          int(particle_offset), _stream()), 'mpb_stomp_sample')
+
+
+def stomp_update(means, samples, costs, weights, Sigma, lr, temperature):
+    P, S, H, d = samples.shape
+    _chk(means, (P, H, d), 'means')
+    _chk(samples, (P, S, H, d), 'samples')
+    _chk(costs, (P, S), 'costs')
+    _chk(weights, (P, S), 'weights')
+    _chk(Sigma, (H, H), 'Sigma')
+    _lib.check(_lib.lib().mpb_stomp_update(_ptr(means), _ptr(samples), _ptr(costs), _ptr(weights), _ptr(Sigma),
+                                          P, S, H, d, float(lr), float(temperature), _stream()), 'mpb_stomp_update')
+
+
+def chomp_step(means, R, geom, D, k_sigma, weight, w_prior, lr, grad_clip, n_iters=1, B_global=None, costs_out=None):
+    B, H, d = means.shape
+    _chk(means, (B, H, d), 'means')
+    _chk(R, (H, H), 'R')
+    _chk(costs_out, (B,), 'costs_out', allow_none=True)
+    _lib.check(_lib.lib().mpb_chomp_step(_ptr(means), _ptr(R), _ptr(geom.buf), _ptr(costs_out), B,
+                                        B if B_global is None else int(B_global), H, d, D, float(k_sigma), float(weight),
+                                        float(w_prior), float(lr), float(grad_clip), int(n_iters), _stream()),
+               'mpb_chomp_step')

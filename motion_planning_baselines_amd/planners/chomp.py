@@ -1,0 +1,80 @@
+"""CHOMP with the reference's class surface (mp_baselines/planners/chomp.py), iterations on the GPU.
+
+The reference obtains the gradient by autograd through FK + SDF and a dense x^T R x (chomp.py:135-169);
+mpb_chomp_step evaluates the same gradient analytically (J^T grad sdf, tridiagonal R x) and runs the
+whole ``opt_iters`` loop -- clamp, endpoint mask, step -- inside one launch.
+"""
+import torch
+
+from .. import ops
+from .base import OptimizationPlanner
+from .costs.cost_functions import fusable_collision
+
+
+def chomp_precision_matrix(dt=0.01, n_support_points=64, tensor_args=None):
+    """R = K^T K with K the (H+1) x H backward-difference operator (last row -1) scaled 1/dt^2 --
+    CHOMP._get_R_mat (chomp.py:81-101)."""
+    H = n_support_points
+    K = torch.eye(H) - torch.diag(torch.ones(H - 1), -1)
+    K = torch.cat((K, torch.zeros(1, H)), dim=0)
+    K[-1, -1] = -1.
+    K = K * 1. / dt ** 2
+    return (K.t() @ K).to(**tensor_args)
+
+
+class CHOMP(OptimizationPlanner):
+    """Drop-in for mp_baselines.planners.chomp.CHOMP (ctor kwargs chomp.py:11-30).
+
+    Extra keyword argument: ``global_batch`` -- total number of particles across all shards (quirk Q3:
+    the reference's smoothness gradient is scaled by the batch size; a shard must use the global one).
+    """
+
+    def __init__(self, n_dof, n_support_points, num_particles_per_goal, opt_iters, dt, start_state, cost=None,
+                 weight_prior_cost=0.1, initial_particle_means=None, step_size=1., grad_clip=.01,
+                 multi_goal_states=None, sigma_start_init=0.001, sigma_goal_init=0.001, sigma_gp_init=10.,
+                 pos_only=True, global_batch=None, **kwargs):
+        super().__init__(name='CHOMP', n_dof=n_dof, n_support_points=n_support_points,
+                         num_particles_per_goal=num_particles_per_goal, opt_iters=opt_iters, dt=dt,
+                         start_state=start_state, cost=cost, initial_particle_means=initial_particle_means,
+                         multi_goal_states=multi_goal_states, sigma_start_init=sigma_start_init,
+                         sigma_goal_init=sigma_goal_init, sigma_gp_init=sigma_gp_init, pos_only=pos_only, **kwargs)
+        self.lr = step_size
+        self.grad_clip = grad_clip
+        self.global_batch = global_batch
+        cpu = dict(device='cpu', dtype=torch.float32)
+        R = self._get_R_mat(dt=dt, n_support_points=n_support_points, tensor_args=cpu)
+        self.Sigma_inv = R.to(self.device).contiguous()
+        self.Sigma = torch.inverse(R).to(self.device)
+        self.reset(initial_particle_means=initial_particle_means)
+        self.weight_prior_cost = weight_prior_cost
+        self.costs = torch.zeros(self.num_particles, device=self.device, dtype=torch.float32)
+
+    @classmethod
+    def _get_R_mat(cls, dt=0.01, n_support_points=64, tensor_args=None, **kwargs):
+        return chomp_precision_matrix(dt=dt, n_support_points=n_support_points, tensor_args=tensor_args)
+
+    def reset(self, initial_particle_means=None):
+        """chomp.py:103-111."""
+        if initial_particle_means is not None:
+            m = initial_particle_means.clone()
+        else:
+            m = self.get_random_trajs()
+        self._particle_means = m.to(device=self.device, dtype=torch.float32).contiguous()
+
+    def optimize(self, opt_iters=None, **observation):
+        """chomp.py:113-125."""
+        self._run_optimization(opt_iters, **observation)
+        return self._get_traj()
+
+    def _run_optimization(self, opt_iters, **observation):
+        if opt_iters is None:
+            opt_iters = self.opt_iters
+        fused = fusable_collision(self.cost)
+        if fused is None:
+            raise NotImplementedError(
+                'CHOMP needs the analytic gradient of its cost: pass a CostCollision / single-field '
+                'CostComposite (the case every reference example uses)')
+        cc, weight = fused
+        ops.chomp_step(self._particle_means, self.Sigma_inv, cc.device_geometry(self.device), self.n_dof,
+                       cc.k_sigma, weight, self.weight_prior_cost, self.lr, self.grad_clip, n_iters=opt_iters,
+                       B_global=self.global_batch or self.num_particles, costs_out=self.costs)

@@ -1,0 +1,147 @@
+"""STOMP with the reference's class surface (mp_baselines/planners/stomp.py), iterations on the GPU.
+
+Host side (this file): constants R / Sigma / scale_tril computed with the same torch calls as the
+reference (stomp.py:63-64, :68-95 -- SURVEY.md H2: they are ill-conditioned in fp32 and must be
+bit-identical), buffer ownership, noise-source selection.  Device side: mpb_stomp_step
+(csrc/mpb_kernels.hip) runs sample -> cost -> softmax -> covariance-weighted update for all
+``opt_iters`` iterations without returning to Python.
+"""
+import torch
+
+from .. import ops
+from .base import OptimizationPlanner
+from .costs.cost_functions import fusable_collision
+
+
+def stomp_precision_matrix(n_support_points, dt, sigma_spectral, tensor_args):
+    """R = A^T A with A the (H+2) x H second-difference operator (unit corner entries) scaled by
+    sigma_spectral / dt^2 -- STOMP._get_R_mat (stomp.py:68-86)."""
+    H = n_support_points
+    inner = -2 * torch.eye(H) + torch.diag(torch.ones(H - 1), 1) + torch.diag(torch.ones(H - 1), -1)
+    A = torch.cat((torch.zeros(1, H), inner, torch.zeros(1, H)), dim=0)
+    A[0, 0] = 1.
+    A[-1, -1] = 1.
+    A = A * 1. / dt ** 2 * sigma_spectral
+    return (A.t() @ A).to(**tensor_args)
+
+
+def precision_to_scale_tril(P):
+    """scale_tril L (L L^T = P^-1) exactly as MultivariateNormal(precision_matrix=P) derives it
+    (torch/distributions/multivariate_normal.py:80-86)."""
+    Lf = torch.linalg.cholesky(torch.flip(P, (-2, -1)))
+    L_inv = torch.transpose(torch.flip(Lf, (-2, -1)), -2, -1)
+    Id = torch.eye(P.shape[-1], dtype=P.dtype, device=P.device)
+    return torch.linalg.solve_triangular(L_inv, Id, upper=False)
+
+
+class STOMP(OptimizationPlanner):
+    """Drop-in for mp_baselines.planners.stomp.STOMP (ctor kwargs stomp.py:10-32).
+
+    Extra keyword arguments (not in the reference):
+      noise: 'philox' (default) -- standard normals generated inside the kernel (counter-based, result
+             independent of sharding); 'torch_cpu' -- drawn per iteration with the CPU generator in the
+             reference's (S,d,P,H) order, so that `torch.manual_seed(s)` reproduces a CPU reference run
+             bit for bit in the noise; 'torch' -- same draw on the planner's device.
+      seed / particle_offset: Philox key and global index of this shard's first particle.
+    """
+
+    def __init__(self, n_dof, n_support_points, num_particles_per_goal, num_samples, opt_iters, dt, start_state,
+                 cost=None, initial_particle_means=None, multi_goal_states=None, sigma_start_init=0.001,
+                 sigma_goal_init=0.001, sigma_gp_init=10., temperature=1., step_size=1., sigma_spectral=0.1,
+                 goal_state=None, pos_only=True, tensor_args=None, noise='philox', seed=0, particle_offset=0,
+                 **kwargs):
+        super().__init__(name='STOMP', n_dof=n_dof, n_support_points=n_support_points,
+                         num_particles_per_goal=num_particles_per_goal, opt_iters=opt_iters, dt=dt,
+                         start_state=start_state, cost=cost, initial_particle_means=initial_particle_means,
+                         multi_goal_states=multi_goal_states, sigma_start_init=sigma_start_init,
+                         sigma_goal_init=sigma_goal_init, sigma_gp_init=sigma_gp_init, pos_only=pos_only,
+                         tensor_args=tensor_args)
+        assert noise in ('philox', 'torch', 'torch_cpu')
+        self.lr = step_size
+        self.sigma_spectral = sigma_spectral
+        self.start_state = start_state          # quirk Q10: overwrites the zero-velocity-extended state
+        self.goal_state = goal_state
+        self.num_samples = num_samples
+        self.temperature = temperature
+        self.noise = noise
+        self.seed = int(seed)
+        self.particle_offset = int(particle_offset)
+        self._iter = 0
+        self._weights = None
+        # constants on the CPU with the reference's own op sequence, then moved (H2)
+        cpu = dict(device='cpu', dtype=torch.float32)
+        R = stomp_precision_matrix(n_support_points, dt, sigma_spectral, cpu)
+        self.Sigma_inv = R.to(self.device)
+        self.Sigma = torch.inverse(R).to(self.device).contiguous()
+        self.scale_tril = precision_to_scale_tril(R).to(self.device).contiguous()
+        P, S, H, d = self.num_particles, num_samples, n_support_points, self.d_state_opt
+        self.state_particles = torch.empty(P, S, H, d, device=self.device, dtype=torch.float32)
+        self.costs = torch.zeros(P, S, device=self.device, dtype=torch.float32)
+        self._weights_buf = torch.empty(P, S, device=self.device, dtype=torch.float32)
+        self.reset(initial_particle_means=initial_particle_means)
+        self.best_cost = torch.inf
+
+    # ---- noise -------------------------------------------------------------------------------
+    def _draw_eps(self, n_iters):
+        """Standard normals in the reference's draw order: one (S,d,P,H) block per iteration."""
+        if self.noise == 'philox':
+            return None
+        S, d, P, H = self.num_samples, self.d_state_opt, self.num_particles, self.n_support_points
+        dev = 'cpu' if self.noise == 'torch_cpu' else self.device
+        blocks = [torch.empty(S, d, P, H, device=dev, dtype=torch.float32).normal_() for _ in range(n_iters)]
+        return torch.stack(blocks).to(self.device).contiguous()
+
+    def sample(self):
+        """stomp.py:97-108: fresh state_particles (P,S,H,d) around the current means."""
+        eps = self._draw_eps(1)
+        ops.stomp_sample(self._particle_means, None if eps is None else eps[0], self.state_particles,
+                         self.scale_tril, self.num_samples, seed=self.seed, it=self._iter,
+                         particle_offset=self.particle_offset)
+        self._iter += 1
+        return self.state_particles
+
+    def reset(self, initial_particle_means=None):
+        """stomp.py:110-120."""
+        if initial_particle_means is not None:
+            m = initial_particle_means.clone()
+        else:
+            m = self.get_random_trajs()
+        self._particle_means = m.to(device=self.device, dtype=torch.float32).contiguous()
+        self.state_particles = self.sample()
+
+    # ---- optimisation ------------------------------------------------------------------------
+    def optimize(self, opt_iters=None, **observation):
+        """stomp.py:137-148: run the iterations, return the current trajectory (P,H,d)."""
+        self._run_optimization(opt_iters, **observation)
+        return self._get_traj()
+
+    def _run_optimization(self, opt_iters, **observation):
+        if opt_iters is None:
+            opt_iters = self.opt_iters
+        fused = fusable_collision(self.cost)
+        if fused is not None and not observation:
+            cc, weight = fused
+            eps = self._draw_eps(opt_iters)
+            ops.stomp_step(self._particle_means, eps, self.state_particles, self.costs, self._weights_buf,
+                           self.scale_tril, self.Sigma, cc.device_geometry(self.device), self.num_samples,
+                           self.n_dof, cc.k_sigma, weight, self.lr, self.temperature, n_iters=opt_iters,
+                           seed=self.seed, iter0=self._iter, particle_offset=self.particle_offset)
+            self._iter += opt_iters
+        else:
+            # caller-supplied cost callable: sample kernel -> user cost on device tensors -> update kernel
+            for _ in range(opt_iters):
+                self.costs = self._sample_and_eval(**observation)
+                self._update_distribution(self.costs, self.state_particles)
+        self._weights = self._weights_buf.reshape(self.num_particles, self.num_samples, 1, 1)
+
+    def _sample_and_eval(self, **observation):
+        """stomp.py:162-197."""
+        self.state_particles = self.sample()
+        costs = self._get_costs(self.state_particles.flatten(0, 1), **observation)
+        return costs.reshape(self.num_particles, self.num_samples).to(torch.float32).contiguous()
+
+    def _update_distribution(self, costs, traj_particles):
+        """stomp.py:199-211 (softmax over samples, covariance-weighted mean update)."""
+        ops.stomp_update(self._particle_means, traj_particles, costs, self._weights_buf, self.Sigma, self.lr,
+                         self.temperature)
+        self._weights = self._weights_buf.reshape(self.num_particles, self.num_samples, 1, 1)

@@ -18,6 +18,11 @@ by autograd through these calls (chomp.py:139, field_factor.py:54).
 import torch
 
 
+def _safe_norm(v):
+    """sqrt(x^2 + y^2 + z^2) with a zero (not NaN) sub-gradient at the origin."""
+    return torch.sqrt((v * v).sum(-1).clamp_min(1e-30))
+
+
 class RefRobot:
     """Duck-typed ``robot`` (q_dim, get_position, get_velocity, fk_map_collision, q_min, q_max, dt)."""
 
@@ -90,12 +95,12 @@ class RefCollisionField:
         sds = []
         if len(self.spheres):
             d = x.unsqueeze(-2) - self.spheres[:, :3]
-            dist = torch.sqrt((d * d).sum(-1))
+            dist = _safe_norm(d)
             sds.append(dist - self.spheres[:, 3])
         if len(self.boxes):
             qv = (x.unsqueeze(-2) - self.boxes[:, :3]).abs() - self.boxes[:, 3:6]
             qo = torch.clamp(qv, min=0.0)
-            outside = torch.sqrt((qo * qo).sum(-1))
+            outside = _safe_norm(qo)
             inside = torch.clamp(qv.max(dim=-1)[0], max=0.0)
             sds.append(outside + inside)
         sd = torch.cat(sds, dim=-1)

@@ -291,7 +291,9 @@ def main():
     gen_stomp('stomp_panda_stiff', panda, sph3, q[0], q[1], P=4, S=8, H=64, dt=5 / 64, sigma_coll=1e-3,
               pos_only=False, iters=4, seed=2)
     gen_stomp('stomp_panda_benign', panda, sph3, q[0], q[1], P=4, S=8, H=64, dt=5 / 64, sigma_coll=1.0,
-              pos_only=True, iters=4, seed=3, temperature=0.1)
+              pos_only=True, iters=4, seed=3, temperature=0.1, sigma_spectral=0.8)
+    gen_stomp('stomp_panda_t1', panda, sph3, q[0], q[1], P=4, S=8, H=64, dt=5 / 64, sigma_coll=1.0,
+              pos_only=False, iters=6, seed=6, temperature=1.0, sigma_spectral=0.5)
     gen_stomp('stomp_pm2d_h48', pm, dense, s2, g2, P=3, S=5, H=48, dt=0.05, sigma_coll=0.1,
               pos_only=True, iters=3, seed=4, init_noise=0.01)
 

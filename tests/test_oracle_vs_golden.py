@@ -11,7 +11,7 @@ TA = dict(device='cpu', dtype=torch.float32)
 T = torch.from_numpy
 
 STOMP_CASES = ['stomp_pm2d_stiff', 'stomp_pm2d_benign', 'stomp_pm2d_c1', 'stomp_panda_stiff',
-               'stomp_panda_benign', 'stomp_pm2d_h48']
+               'stomp_panda_benign', 'stomp_panda_t1', 'stomp_pm2d_h48']
 
 
 @pytest.mark.parametrize('name', STOMP_CASES)
