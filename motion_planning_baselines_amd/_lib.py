@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libmpb_hip.so')
+LIB_PATH = os.environ.get('MPB_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libmpb_hip.so')  # env: tuning builds
 
 _f = ctypes.c_float
 _i = ctypes.c_int

@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, 'csrc')
 SOURCES = ['mpb_kernels.hip', 'mpb_gpmp2.hip', 'mpb_mppi.hip']
 OUT = os.path.join(CSRC, 'libmpb_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
-         '-ffinite-math-only', '-fno-signed-zeros']
+         '-ffinite-math-only', '-fno-signed-zeros', '-fno-slp-vectorize']
 
 
 def _stale():
@@ -21,6 +21,16 @@ def _stale():
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h'))]
     deps.append(os.path.join(os.path.dirname(HERE), 'include', 'mpb.h'))
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_variant(out, extra_flags, verbose=False):
+    """Tuning aid: build a variant of the library (extra -D flags) to another path."""
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc, *FLAGS, *extra_flags, '-shared', *[os.path.join(CSRC, s) for s in SOURCES], '-o', out]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
 
 
 def build(force=False, verbose=True):

@@ -6,19 +6,37 @@
 // definitions are evaluated on the CPU by oracle/geometry_ref.py for checking.
 //
 // Mapping to the hardware: one LANE evaluates one waypoint; every geometry word (joint transforms,
-// sphere offsets, obstacle centres) is addressed with wave-uniform indices through a const
-// __restrict__ kernel-argument pointer, so hipcc turns those reads into scalar loads (s_load_dwordx4)
+// sphere offsets, obstacle constants) is addressed with wave-uniform indices through a const
+// __restrict__ kernel-argument pointer, so hipcc turns those reads into scalar loads (s_load_dwordx8/16)
 // and the values ride in SGPRs as VALU operands -- no LDS traffic and no VGPRs for constants.
+//
+// Obstacle loop: the collision spheres of one kinematic frame (<= 8 at a time) are held in VGPRs and
+// tested against blocks of 4 obstacle spheres held in SGPRs.  The per-pair test is conservative and
+// cheap (3 fma + 1 compare on |x|^2 - 2 x.c < rhs_o, table built on the host in fp64); the exact
+// distance (3 sub, 3 fma, v_sqrt, ...) is evaluated only when some lane of the wave passes it, so the
+// result is bit-identical to evaluating every pair while the common far-away pair costs 4 VALU slots
+// instead of ~12 (v_sqrt_f32 alone is 4: quarter rate, measured in scripts/microbench_valu.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #define MPB_GEOM_MAGIC 0x4D504247
-#define MPB_GEOM_VERSION 1
+#define MPB_GEOM_VERSION 2
 #define MPB_GEOM_HEADER_WORDS 16
 #define MPB_KIND_POINT 0
 #define MPB_KIND_CHAIN 1
 #define MPB_MAX_DOF 8
 #define MPB_MAX_TF (MPB_MAX_DOF + 1)
+// collision spheres processed together (VGPR resident): 8 for the cost-only path, 4 when the gradient
+// state (direction + norm per sphere, joint axes/origins) also has to fit in the register file
+#ifndef MPB_LCH_COST
+#define MPB_LCH_COST 8
+#endif
+#define MPB_LCH_OF(GRAD) ((GRAD) ? 4 : MPB_LCH_COST)
+// conservative-test policy: 0 = adaptive (default), 1 = never test, 2 = always test (tuning builds only)
+#ifndef MPB_CULL_MODE
+#define MPB_CULL_MODE 0
+#endif
 
 struct GeomView {
     int kind, n_dof, n_tf, n_links, n_sph, n_box;
@@ -27,6 +45,8 @@ struct GeomView {
     const float* links;  // n_links x 8: frame(int), ox, oy, oz, r, 0,0,0
     const float* sph;    // n_sph x 4
     const float* box;    // n_box x 8: cx,cy,cz,0,hx,hy,hz,0
+    const float* cull;   // ceil4(n_sph) x 8: -2cx,-2cy,-2cz,rhs, cx,cy,cz,r
+    const int* fstart;   // links [fstart[j], fstart[j+1]) ride on frame j+1
 };
 
 __device__ __forceinline__ GeomView geom_view(const float* __restrict__ g) {
@@ -43,6 +63,8 @@ __device__ __forceinline__ GeomView geom_view(const float* __restrict__ g) {
     v.links = g + gi[10];
     v.sph = g + gi[11];
     v.box = g + gi[12];
+    v.cull = g + gi[14];
+    v.fstart = gi + gi[15];
     return v;
 }
 
@@ -67,80 +89,191 @@ __device__ __forceinline__ void fast_sincos(float x, float& sn, float& cs) {
 }
 
 // v_sqrt_f32: 1 ulp, one quarter-rate instruction (the IEEE-correct expansion hipcc emits for sqrtf is
-// ~20 VALU instructions and dominated the obstacle loop).  Arguments here are squared distances in
-// [0, ~10]; well inside the range where the raw instruction needs no scaling.
+// ~20 VALU instructions).  Arguments are squared distances, far inside the range that needs no scaling.
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
-// min over obstacles of the signed distance at x; for GRAD also the un-normalised direction (vx,vy,vz)
-// and its norm vn such that grad sdf = v / vn (v = 0 at degenerate points -> zero sub-gradient, as the
-// oracle's clamped norm).
+// State of N collision spheres (VGPR resident) while the obstacle set streams past them in SGPRs.
 template <bool GRAD>
-__device__ __forceinline__ void sphere_sd(const float4 s, float x, float y, float z, float& best, float& vx,
-                                          float& vy, float& vz, float& vn) {
-    const float dx = x - s.x, dy = y - s.y, dz = z - s.z;
+struct LinkChunk {
+    static constexpr int N = MPB_LCH_OF(GRAD);
+    float x[N], y[N], z[N], xx[N], best[N];
+    float vx[GRAD ? N : 1], vy[GRAD ? N : 1], vz[GRAD ? N : 1], vn[GRAD ? N : 1];
+};
+
+// exact signed distance of sphere obstacle (cx,cy,cz,r) at slot I; keeps the running minimum (and for GRAD
+// the un-normalised direction v and its norm vn with grad sdf = v / vn)
+template <bool GRAD, int I>
+__device__ __forceinline__ void exact_sphere(LinkChunk<GRAD>& C, float cx, float cy, float cz, float r) {
+    const float dx = C.x[I] - cx, dy = C.y[I] - cy, dz = C.z[I] - cz;
     float d2 = dx * dx + dy * dy + dz * dz;
     if (GRAD) d2 = fmaxf(d2, 1e-30f);  // keeps 1/dist finite; the oracle clamps the same way
     const float dist = fast_sqrt(d2);
-    const float sd = dist - s.w;
+    const float sd = dist - r;
     if (GRAD) {
-        const bool better = sd < best;
-        vx = better ? dx : vx; vy = better ? dy : vy; vz = better ? dz : vz; vn = better ? dist : vn;
+        const bool better = sd < C.best[I];
+        C.vx[I] = better ? dx : C.vx[I];
+        C.vy[I] = better ? dy : C.vy[I];
+        C.vz[I] = better ? dz : C.vz[I];
+        C.vn[I] = better ? dist : C.vn[I];
     }
-    best = fminf(best, sd);
+    C.best[I] = fminf(C.best[I], sd);
 }
 
+template <bool GRAD, int I>
+__device__ __forceinline__ void exact_box(LinkChunk<GRAD>& C, const float4 c, const float4 h) {
+    const float px = C.x[I] - c.x, py = C.y[I] - c.y, pz = C.z[I] - c.z;
+    const float ax = fabsf(px) - h.x, ay = fabsf(py) - h.y, az = fabsf(pz) - h.z;
+    const float qx = fmaxf(ax, 0.f), qy = fmaxf(ay, 0.f), qz = fmaxf(az, 0.f);
+    float o2 = qx * qx + qy * qy + qz * qz;
+    if (GRAD) o2 = fmaxf(o2, 1e-30f);
+    const float outside = fast_sqrt(o2);
+    const float mx = fmaxf(ax, fmaxf(ay, az));
+    const float sd = outside + fminf(mx, 0.f);
+    if (GRAD) {
+        const bool better = sd < C.best[I];
+        const bool out = mx > 0.f;
+        // outside: direction of the clamped offset; inside: unit axis of the largest component
+        // (first on ties, as torch.max)
+        const bool ix = (ax >= ay) && (ax >= az);
+        const bool iy = !ix && (ay >= az);
+        const float nx = out ? copysignf(qx, px) : (ix ? copysignf(1.f, px) : 0.f);
+        const float ny = out ? copysignf(qy, py) : (iy ? copysignf(1.f, py) : 0.f);
+        const float nz = out ? copysignf(qz, pz) : ((!ix && !iy) ? copysignf(1.f, pz) : 0.f);
+        C.vx[I] = better ? nx : C.vx[I];
+        C.vy[I] = better ? ny : C.vy[I];
+        C.vz[I] = better ? nz : C.vz[I];
+        C.vn[I] = better ? (out ? outside : 1.f) : C.vn[I];
+    }
+    C.best[I] = fminf(C.best[I], sd);
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// conservative test of all N slots against a block of 4 obstacles (k[2o] = (-2cx,-2cy,-2cz,rhs)):
+// true when some lane of the wave may be within the hinge threshold of one of them.  Straight-line,
+// 4 N independent fma chains; the 64-bit lane masks are OR-ed on the scalar unit.
 template <bool GRAD>
-__device__ __forceinline__ float min_signed_distance(const GeomView& G, float x, float y, float z, float& vx,
-                                                     float& vy, float& vz, float& vn) {
-    float best = 3.0e38f;
-    if (GRAD) { vx = vy = vz = 0.f; vn = 1.f; }
-    const float4* sp = reinterpret_cast<const float4*>(G.sph);
-    // 8 obstacles per trip: two s_load_dwordx16 feed 8 x ~7 VALU instructions, all operands in SGPRs
-#pragma unroll 8
-    for (int o = 0; o < G.n_sph; ++o) sphere_sd<GRAD>(sp[o], x, y, z, best, vx, vy, vz, vn);
+__device__ __forceinline__ bool block_may_touch(const LinkChunk<GRAD>& C, const float4 (&k)[8]) {
+    unsigned long long m = 0ull;
+    static_for<0, LinkChunk<GRAD>::N>([&](auto ic) {
+        constexpr int I = decltype(ic)::value;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const float t = fmaf(C.z[I], k[2 * o].z, fmaf(C.y[I], k[2 * o].y, fmaf(C.x[I], k[2 * o].x, C.xx[I])));
+            m |= __ballot(t < k[2 * o].w);
+        }
+    });
+    return m != 0ull;
+}
+
+// exact distances of all N slots to the 4 obstacles of a block (k[2o+1] = (cx,cy,cz,r)); straight-line
+template <bool GRAD>
+__device__ __forceinline__ void block_exact(LinkChunk<GRAD>& C, const float4 (&k)[8]) {
+    static_for<0, LinkChunk<GRAD>::N>([&](auto ic) {
+        constexpr int I = decltype(ic)::value;
+        exact_sphere<GRAD, I>(C, k[1].x, k[1].y, k[1].z, k[1].w);
+        exact_sphere<GRAD, I>(C, k[3].x, k[3].y, k[3].z, k[3].w);
+        exact_sphere<GRAD, I>(C, k[5].x, k[5].y, k[5].z, k[5].w);
+        exact_sphere<GRAD, I>(C, k[7].x, k[7].y, k[7].z, k[7].w);
+    });
+}
+
+// Wave-uniform statistics of the conservative test: when it passes most of the time (wildly spread
+// trajectories, e.g. the first STOMP iterations with a large noise scale) it is pure overhead and is
+// switched off for the rest of the waypoint; the result is bit-identical either way.
+struct CullStats {
+    int tested, hit;
+    bool on;
+};
+
+// min signed distance of the N slots in C to every obstacle
+template <bool GRAD>
+__device__ __forceinline__ void chunk_vs_obstacles(const GeomView& G, LinkChunk<GRAD>& C, CullStats& cs) {
+    const float4* cu = reinterpret_cast<const float4*>(G.cull);
+    for (int ob = 0; ob < G.n_sph; ob += 4) {
+        float4 k[8];
+#ifdef MPB_FAKE_OBST  // tuning experiment: no scalar loads in the obstacle loop (results are wrong)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) k[i] = make_float4(0.1f * i + 0.01f * ob, 0.2f * i, -0.1f * i, 0.05f + 0.01f * i);
+#else
+#pragma unroll
+        for (int i = 0; i < 8; ++i) k[i] = cu[2 * ob + i];
+#endif
+        if (MPB_CULL_MODE != 1 && cs.on) {
+            const bool any = block_may_touch<GRAD>(C, k);
+            cs.tested += 1;
+            cs.hit += any ? 1 : 0;
+            if (MPB_CULL_MODE == 0) cs.on = (cs.tested < 8) || (2 * cs.hit <= cs.tested);
+            if (!any) continue;
+        }
+        block_exact<GRAD>(C, k);
+    }
     const float4* bp = reinterpret_cast<const float4*>(G.box);
     for (int o = 0; o < G.n_box; ++o) {
         const float4 c = bp[2 * o], h = bp[2 * o + 1];
-        const float px = x - c.x, py = y - c.y, pz = z - c.z;
-        const float ax = fabsf(px) - h.x, ay = fabsf(py) - h.y, az = fabsf(pz) - h.z;
-        const float qx = fmaxf(ax, 0.f), qy = fmaxf(ay, 0.f), qz = fmaxf(az, 0.f);
-        float o2 = qx * qx + qy * qy + qz * qz;
-        if (GRAD) o2 = fmaxf(o2, 1e-30f);
-        const float outside = fast_sqrt(o2);
-        const float mx = fmaxf(ax, fmaxf(ay, az));
-        const float sd = outside + fminf(mx, 0.f);
-        if (GRAD) {
-            const bool better = sd < best;
-            if (better) {
-                if (mx > 0.f) {  // outside: direction of the clamped offset
-                    vx = copysignf(qx, px); vy = copysignf(qy, py); vz = copysignf(qz, pz); vn = outside;
-                } else {         // inside: unit axis of the largest component (first on ties, as torch.max)
-                    const bool ix = (ax >= ay) && (ax >= az);
-                    const bool iy = !ix && (ay >= az);
-                    vx = ix ? copysignf(1.f, px) : 0.f;
-                    vy = iy ? copysignf(1.f, py) : 0.f;
-                    vz = (!ix && !iy) ? copysignf(1.f, pz) : 0.f;
-                    vn = 1.f;
-                }
-            }
-        }
-        best = fminf(best, sd);
+        static_for<0, LinkChunk<GRAD>::N>([&](auto ic) { exact_box<GRAD, decltype(ic)::value>(C, c, h); });
     }
-    return best;
 }
 
-// hinge cost of one collision sphere; for GRAD (fx,fy,fz) = d hinge / d x.
+// forward-kinematics state: current frame transform (+ joint axes / origins for the gradient)
 template <bool GRAD>
-__device__ __forceinline__ float sphere_hinge(const GeomView& G, float x, float y, float z, float rl,
-                                              float& fx, float& fy, float& fz) {
-    float vx, vy, vz, vn;
-    const float sd = min_signed_distance<GRAD>(G, x, y, z, vx, vy, vz, vn);
-    const float h = fmaxf(G.margin + rl - sd, 0.f);
-    if (GRAD) {
-        const float s = (h > 0.f) ? -1.0f / vn : 0.f;
-        fx = vx * s; fy = vy * s; fz = vz * s;
+struct FKState {
+    float r00, r01, r02, r10, r11, r12, r20, r21, r22, tx, ty, tz;
+    int frame;  // number of transforms applied so far
+    float zx[GRAD ? MPB_MAX_DOF : 1], zy[GRAD ? MPB_MAX_DOF : 1], zz[GRAD ? MPB_MAX_DOF : 1];
+    float px[GRAD ? MPB_MAX_DOF : 1], py[GRAD ? MPB_MAX_DOF : 1], pz[GRAD ? MPB_MAX_DOF : 1];
+};
+
+// frame_{j+1} = frame_j * P_j * Rz(q_j); q_j and the joint-array slot are picked with selects, never by a
+// runtime register index
+template <bool GRAD>
+__device__ __forceinline__ void fk_advance(const GeomView& G, FKState<GRAD>& F, const float (&q)[MPB_MAX_DOF]) {
+    const int j = F.frame;
+    const float4* P = reinterpret_cast<const float4*>(G.tf + 12 * j);
+    const float4 p0 = P[0], p1 = P[1], p2 = P[2];  // rows of the 3x4 constant transform
+    const float ntx = F.tx + (F.r00 * p0.w + F.r01 * p1.w + F.r02 * p2.w);
+    const float nty = F.ty + (F.r10 * p0.w + F.r11 * p1.w + F.r12 * p2.w);
+    const float ntz = F.tz + (F.r20 * p0.w + F.r21 * p1.w + F.r22 * p2.w);
+    F.tx = ntx; F.ty = nty; F.tz = ntz;
+    float a00 = F.r00 * p0.x + F.r01 * p1.x + F.r02 * p2.x, a01 = F.r00 * p0.y + F.r01 * p1.y + F.r02 * p2.y,
+          a02 = F.r00 * p0.z + F.r01 * p1.z + F.r02 * p2.z;
+    float a10 = F.r10 * p0.x + F.r11 * p1.x + F.r12 * p2.x, a11 = F.r10 * p0.y + F.r11 * p1.y + F.r12 * p2.y,
+          a12 = F.r10 * p0.z + F.r11 * p1.z + F.r12 * p2.z;
+    float a20 = F.r20 * p0.x + F.r21 * p1.x + F.r22 * p2.x, a21 = F.r20 * p0.y + F.r21 * p1.y + F.r22 * p2.y,
+          a22 = F.r20 * p0.z + F.r21 * p1.z + F.r22 * p2.z;
+    if (j < G.n_dof) {
+        // select chain on the wave-uniform j (7 v_cndmask); the empty asm keeps hipcc from turning it into a
+        // scratch-memory array lookup
+        float qj = q[0];
+#pragma unroll
+        for (int i = 1; i < MPB_MAX_DOF; ++i) {
+            qj = (j == i) ? q[i] : qj;
+            asm volatile("" : "+v"(qj));
+        }
+        float sn, cs;
+        fast_sincos(qj, sn, cs);
+        const float n00 = a00 * cs + a01 * sn, n01 = a01 * cs - a00 * sn;
+        const float n10 = a10 * cs + a11 * sn, n11 = a11 * cs - a10 * sn;
+        const float n20 = a20 * cs + a21 * sn, n21 = a21 * cs - a20 * sn;
+        a00 = n00; a01 = n01; a10 = n10; a11 = n11; a20 = n20; a21 = n21;
+        if (GRAD) {
+#pragma unroll
+            for (int i = 0; i < MPB_MAX_DOF; ++i) {
+                const bool me = (i == j);
+                F.zx[i] = me ? a02 : F.zx[i]; F.zy[i] = me ? a12 : F.zy[i]; F.zz[i] = me ? a22 : F.zz[i];
+                F.px[i] = me ? F.tx : F.px[i]; F.py[i] = me ? F.ty : F.py[i]; F.pz[i] = me ? F.tz : F.pz[i];
+            }
+        }
     }
-    return h;
+    F.r00 = a00; F.r01 = a01; F.r02 = a02; F.r10 = a10; F.r11 = a11; F.r12 = a12;
+    F.r20 = a20; F.r21 = a21; F.r22 = a22;
+    F.frame = j + 1;
 }
 
 // Collision cost of one waypoint q[0..D) (sum over the robot's collision spheres); for GRAD
@@ -148,81 +281,82 @@ __device__ __forceinline__ float sphere_hinge(const GeomView& G, float x, float 
 template <bool GRAD>
 __device__ __forceinline__ float waypoint_cost(const GeomView& G, const float (&q)[MPB_MAX_DOF],
                                                float (&dq)[MPB_MAX_DOF]) {
+    constexpr int N = LinkChunk<GRAD>::N;
+    constexpr float FAR = 1.0e9f;  // parked slot: farther than any obstacle, hinge 0
     if (GRAD) {
 #pragma unroll
         for (int i = 0; i < MPB_MAX_DOF; ++i) dq[i] = 0.f;
     }
-    if (G.kind == MPB_KIND_POINT) {
-        float fx, fy, fz;
-        const float rl = G.links[4];
-        const float z = (G.n_dof > 2) ? q[2] : 0.f;
-        const float h = sphere_hinge<GRAD>(G, q[0], q[1], z, rl, fx, fy, fz);
-        if (GRAD) { dq[0] = fx; dq[1] = fy; if (G.n_dof > 2) dq[2] = fz; }
-        return h;
+    LinkChunk<GRAD> C;
+    CullStats cs = {0, 0, true};
+    FKState<GRAD> F;
+    F.r00 = 1.f; F.r01 = 0.f; F.r02 = 0.f; F.r10 = 0.f; F.r11 = 1.f; F.r12 = 0.f; F.r20 = 0.f; F.r21 = 0.f; F.r22 = 1.f;
+    F.tx = F.ty = F.tz = 0.f;
+    F.frame = 0;
+    if (GRAD) {
+#pragma unroll
+        for (int i = 0; i < MPB_MAX_DOF; ++i) { F.zx[i] = F.zy[i] = F.zz[i] = F.px[i] = F.py[i] = F.pz[i] = 0.f; }
     }
-    // serial revolute chain: frame_{j+1} = frame_j * P_j * Rz(q_j)
-    float r00 = 1.f, r01 = 0.f, r02 = 0.f, r10 = 0.f, r11 = 1.f, r12 = 0.f, r20 = 0.f, r21 = 0.f, r22 = 1.f;
-    float tx = 0.f, ty = 0.f, tz = 0.f;
-    float zx[MPB_MAX_DOF], zy[MPB_MAX_DOF], zz[MPB_MAX_DOF], px[MPB_MAX_DOF], py[MPB_MAX_DOF], pz[MPB_MAX_DOF];
+    const bool point = (G.kind == MPB_KIND_POINT);
     float cost = 0.f;
-    int l = 0;
+    // chunks of N consecutive collision spheres; the kinematic chain advances inside the slot loop so
+    // that every chunk is full whatever the spheres-per-frame distribution is
+    for (int l0 = 0; l0 < G.n_links; l0 += N) {
+        const int nl = min(N, G.n_links - l0);
+        float rl[N];
+        int fr[GRAD ? N : 1];
 #pragma unroll
-    for (int j = 0; j < MPB_MAX_TF; ++j) {
-        if (j < G.n_tf) {
-            const float4* P = reinterpret_cast<const float4*>(G.tf + 12 * j);
-            const float4 p0 = P[0], p1 = P[1], p2 = P[2];  // rows of the 3x4 constant transform
-            // t += R * P[:,3]
-            const float ntx = tx + (r00 * p0.w + r01 * p1.w + r02 * p2.w);
-            const float nty = ty + (r10 * p0.w + r11 * p1.w + r12 * p2.w);
-            const float ntz = tz + (r20 * p0.w + r21 * p1.w + r22 * p2.w);
-            tx = ntx; ty = nty; tz = ntz;
-            // R = R * P[:, :3]
-            float a00 = r00 * p0.x + r01 * p1.x + r02 * p2.x, a01 = r00 * p0.y + r01 * p1.y + r02 * p2.y,
-                  a02 = r00 * p0.z + r01 * p1.z + r02 * p2.z;
-            float a10 = r10 * p0.x + r11 * p1.x + r12 * p2.x, a11 = r10 * p0.y + r11 * p1.y + r12 * p2.y,
-                  a12 = r10 * p0.z + r11 * p1.z + r12 * p2.z;
-            float a20 = r20 * p0.x + r21 * p1.x + r22 * p2.x, a21 = r20 * p0.y + r21 * p1.y + r22 * p2.y,
-                  a22 = r20 * p0.z + r21 * p1.z + r22 * p2.z;
-            if (j < MPB_MAX_DOF && j < G.n_dof) {
-                const int jj = j < MPB_MAX_DOF ? j : 0;  // compile-time constant after unrolling
-                float sn, cs;
-                fast_sincos(q[jj], sn, cs);
-                const float n00 = a00 * cs + a01 * sn, n01 = a01 * cs - a00 * sn;
-                const float n10 = a10 * cs + a11 * sn, n11 = a11 * cs - a10 * sn;
-                const float n20 = a20 * cs + a21 * sn, n21 = a21 * cs - a20 * sn;
-                a00 = n00; a01 = n01; a10 = n10; a11 = n11; a20 = n20; a21 = n21;
-                if (GRAD) {
-                    zx[jj] = a02; zy[jj] = a12; zz[jj] = a22;
-                    px[jj] = tx; py[jj] = ty; pz[jj] = tz;
+        for (int i = 0; i < N; ++i) {
+            C.best[i] = 3.0e38f;
+            if (GRAD) { C.vx[i] = C.vy[i] = C.vz[i] = 0.f; C.vn[i] = 1.f; }
+            if (i < nl) {
+                const int li = l0 + i;
+                const float4 lk = *reinterpret_cast<const float4*>(G.links + 8 * li);  // frame, ox, oy, oz
+                rl[i] = G.links[8 * li + 4];
+                if (point) {
+                    C.x[i] = q[0]; C.y[i] = q[1]; C.z[i] = (G.n_dof > 2) ? q[2] : 0.f;
+                    if (GRAD) fr[i] = 0;
+                } else {
+                    const int f = __float_as_int(lk.x);
+                    while (F.frame < f) fk_advance<GRAD>(G, F, q);
+                    C.x[i] = F.tx + (F.r00 * lk.y + F.r01 * lk.z + F.r02 * lk.w);
+                    C.y[i] = F.ty + (F.r10 * lk.y + F.r11 * lk.z + F.r12 * lk.w);
+                    C.z[i] = F.tz + (F.r20 * lk.y + F.r21 * lk.z + F.r22 * lk.w);
+                    if (GRAD) fr[i] = f;
                 }
+            } else {
+                rl[i] = 0.f;
+                C.x[i] = C.y[i] = C.z[i] = FAR;
+                if (GRAD) fr[i] = 0;
             }
-            r00 = a00; r01 = a01; r02 = a02; r10 = a10; r11 = a11; r12 = a12; r20 = a20; r21 = a21; r22 = a22;
-            // collision spheres rigidly attached to frame j+1 (sorted by frame on the host)
-            while (l < G.n_links && __float_as_int(G.links[8 * l]) == j + 1) {
-                const float4 lk = *reinterpret_cast<const float4*>(G.links + 8 * l);  // frame, ox, oy, oz
-                const float rl = G.links[8 * l + 4];
-                const float x = tx + (r00 * lk.y + r01 * lk.z + r02 * lk.w);
-                const float y = ty + (r10 * lk.y + r11 * lk.z + r12 * lk.w);
-                const float z = tz + (r20 * lk.y + r21 * lk.z + r22 * lk.w);
-                float fx, fy, fz;
-                const float h = sphere_hinge<GRAD>(G, x, y, z, rl, fx, fy, fz);
-                cost += h;
-                if (GRAD) {
-                    if (__any(h > 0.f)) {
+            C.xx[i] = C.x[i] * C.x[i] + C.y[i] * C.y[i] + C.z[i] * C.z[i];
+        }
+        chunk_vs_obstacles<GRAD>(G, C, cs);
 #pragma unroll
-                        for (int i = 0; i < MPB_MAX_DOF; ++i) {
-                            if (i <= j && i < G.n_dof) {
-                                // d x / d q_i = z_i x (x - p_i);  dq_i += f . (z_i x (x - p_i))
-                                const float ex = x - px[i], ey = y - py[i], ez = z - pz[i];
-                                const float cx = zy[i] * ez - zz[i] * ey;
-                                const float cy = zz[i] * ex - zx[i] * ez;
-                                const float cz = zx[i] * ey - zy[i] * ex;
-                                dq[i] += fx * cx + fy * cy + fz * cz;
+        for (int i = 0; i < N; ++i) {
+            const float h = fmaxf(G.margin + rl[i] - C.best[i], 0.f);  // parked slots: best = 3e38 -> 0
+            cost += h;
+            if (GRAD) {
+                if (__any(h > 0.f)) {
+                    const float s = (h > 0.f) ? -1.0f / C.vn[i] : 0.f;
+                    const float fx = C.vx[i] * s, fy = C.vy[i] * s, fz = C.vz[i] * s;
+                    if (point) {
+                        dq[0] += fx; dq[1] += fy;
+                        if (G.n_dof > 2) dq[2] += fz;
+                    } else {
+#pragma unroll
+                        for (int ii = 0; ii < MPB_MAX_DOF; ++ii) {
+                            if (ii < fr[i] && ii < G.n_dof) {
+                                // d x / d q_ii = z_ii x (x - p_ii) for every joint upstream of the sphere's frame
+                                const float ex = C.x[i] - F.px[ii], ey = C.y[i] - F.py[ii], ez = C.z[i] - F.pz[ii];
+                                const float cx = F.zy[ii] * ez - F.zz[ii] * ey;
+                                const float cy = F.zz[ii] * ex - F.zx[ii] * ez;
+                                const float cz = F.zx[ii] * ey - F.zy[ii] * ex;
+                                dq[ii] += fx * cx + fy * cy + fz * cz;
                             }
                         }
                     }
                 }
-                ++l;
             }
         }
     }

@@ -52,10 +52,20 @@ extern "C" int mpb_geom_check(const float* g, int n_words) {
     if (kind == MPB_KIND_CHAIN && n_tf != n_dof + 1) return fail(MPB_E_INVALID, "%s: chain needs n_dof+1 transforms", __func__);
     if (n_links < 1 || n_sph < 0 || n_box < 0 || n_sph + n_box < 1) return fail(MPB_E_INVALID, "%s: empty link/obstacle set", __func__);
     const int off_tf = gi[9], off_links = gi[10], off_sph = gi[11], off_box = gi[12], total = gi[13];
+    const int off_cull = gi[14], off_fs = gi[15];
+    const int n_sph_pad = (n_sph + 3) / 4 * 4;
+    const int n_frames = n_tf > 1 ? n_tf : 1;
+    const int n_fs = (n_frames + 1 + 3) / 4 * 4;
     if (off_tf != MPB_GEOM_HEADER_WORDS || off_links != off_tf + 12 * n_tf || off_sph != off_links + 8 * n_links ||
-        off_box != off_sph + 4 * n_sph || total != off_box + 8 * n_box || total > n_words)
+        off_box != off_sph + 4 * n_sph || off_cull != off_box + 8 * n_box || off_fs != off_cull + 8 * n_sph_pad ||
+        total != off_fs + n_fs || total > n_words)
         return fail(MPB_E_INVALID, "%s: inconsistent section offsets", __func__);
-    if ((off_links | off_sph | off_box) & 3) return fail(MPB_E_INVALID, "%s: sections must be 16-byte aligned", __func__);
+    if ((off_links | off_sph | off_box | off_cull | off_fs) & 3) return fail(MPB_E_INVALID, "%s: sections must be 16-byte aligned", __func__);
+    // frame -> link ranges must be monotone and end at n_links
+    for (int j = 0; j < n_frames; ++j)
+        if (gi[off_fs + j] < 0 || gi[off_fs + j] > gi[off_fs + j + 1] || gi[off_fs + j + 1] > n_links)
+            return fail(MPB_E_INVALID, "%s: bad frame_start table", __func__);
+    if (gi[off_fs] != 0 || gi[off_fs + n_frames] != n_links) return fail(MPB_E_INVALID, "%s: frame_start must cover all links", __func__);
     int prev = 1;
     for (int l = 0; l < n_links; ++l) {
         const int f = gi[off_links + 8 * l];
@@ -178,7 +188,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define NT_STRIDE 20  // floats per waypoint row of the noise tile: 80 B keeps ds_read_b128 conflict-free
 
 template <int DCH, bool WITH_COST>
-__global__ __launch_bounds__(256) void stomp_sample_cost_h64_kernel(
+__global__ __launch_bounds__(256, 4) void stomp_sample_cost_h64_kernel(
     const float* __restrict__ means, const float* __restrict__ eps, float* __restrict__ samples,
     float* __restrict__ costs, const float* __restrict__ Lmat, const float* __restrict__ geom,
     int P, int S, float k_sigma, float weight, uint32_t seed_lo, uint32_t seed_hi, uint32_t iter,
@@ -209,7 +219,12 @@ __global__ __launch_bounds__(256) void stomp_sample_cost_h64_kernel(
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
             float n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
+#ifdef MPB_EXP_NOPHILOX
+            if (j < DCH) { n0 = 0.1f * q4; n1 = 0.2f; n2 = -0.1f * g; n3 = 0.05f * j; }
+            if (false) {
+#else
             if (j < DCH) {
+#endif
                 const uint4 rr = philox4x32_10(
                     make_uint4(particle_offset + (uint32_t)p, (uint32_t)s, ((uint32_t)j << 16) | ((uint32_t)g << 8) | (uint32_t)q4, iter),
                     make_uint2(seed_lo, seed_hi));
@@ -260,7 +275,9 @@ __global__ __launch_bounds__(256) void stomp_sample_cost_h64_kernel(
             const float2 mv = *reinterpret_cast<const float2*>(mrow + c);
             x[c] = mv.x + (edge ? 0.f : nz[c]);
             x[c + 1] = mv.y + (edge ? 0.f : nz[c + 1]);
+#ifndef MPB_EXP_NOSTORE
             *reinterpret_cast<float2*>(srow + c) = make_float2(x[c], x[c + 1]);
+#endif
         }
     } else {
 #pragma unroll

@@ -25,7 +25,7 @@ import math
 import numpy as np
 
 GEOM_MAGIC = 0x4D504247  # 'MPBG'
-GEOM_VERSION = 1
+GEOM_VERSION = 2
 GEOM_HEADER_WORDS = 16
 KIND_POINT = 0
 KIND_CHAIN = 1
@@ -214,29 +214,39 @@ def pack_geometry(robot, field):
     Layout (32-bit words; ints stored bit-exact), mirrored by csrc/mpb_geom.h:
       [0] magic [1] version [2] kind [3] n_dof [4] n_frames_tf (0 or n_dof+1) [5] n_links
       [6] n_spheres [7] n_boxes [8] margin(f32) [9] off_tf [10] off_links [11] off_spheres
-      [12] off_boxes [13] total_words [14..15] reserved
-      joint_tf   : n_frames_tf x 12   (row-major 3x4)
-      links      : n_links x 8        (frame:int, ox, oy, oz, radius, 0, 0, 0)
-      spheres    : n_spheres x 4      (cx, cy, cz, r)
-      boxes      : n_boxes x 8        (cx, cy, cz, 0, hx, hy, hz, 0)
+      [12] off_boxes [13] total_words [14] off_cull [15] off_frame_start
+      joint_tf    : n_frames_tf x 12   (row-major 3x4)
+      links       : n_links x 8        (frame:int, ox, oy, oz, radius, 0, 0, 0)
+      spheres     : n_spheres x 4      (cx, cy, cz, r)
+      boxes       : n_boxes x 8        (cx, cy, cz, 0, hx, hy, hz, 0)
+      cull        : ceil4(n_spheres) x 8 (-2cx, -2cy, -2cz, rhs, cx, cy, cz, r): a link sphere at x can
+                    touch obstacle o only if |x|^2 - 2 x.c < rhs_o = (margin + max_l r_l + r_o)^2 - |c|^2 + slack
+                    (3 fma + 1 compare per pair; the exact distance is evaluated only when a lane passes).
+                    Padding entries never pass (rhs = -1e30).
+      frame_start : n_frames + 1 ints (padded to 4): links [fs[j], fs[j+1]) ride on frame j+1
     """
     rs, fs = robot.spec(), field.spec()
     n_tf = rs['joint_tf'].shape[0]
     n_links = len(rs['link_radius'])
     n_sph, n_box = len(fs['spheres']), len(fs['boxes'])
+    n_sph_pad = (n_sph + 3) // 4 * 4
+    n_frames = max(n_tf, 1)
+    n_fs = (n_frames + 1 + 3) // 4 * 4
     off_tf = GEOM_HEADER_WORDS
     off_links = off_tf + 12 * n_tf
     off_sph = off_links + 8 * n_links
     off_box = off_sph + 4 * n_sph
-    total = off_box + 8 * n_box
+    off_cull = off_box + 8 * n_box
+    off_fs = off_cull + 8 * n_sph_pad
+    total = off_fs + n_fs
     buf = np.zeros((total,), dtype=np.float32)
     ibuf = buf.view(np.int32)
     ibuf[0:8] = [GEOM_MAGIC, GEOM_VERSION, rs['kind'], rs['n_dof'], n_tf, n_links, n_sph, n_box]
     buf[8] = fs['margin']
-    ibuf[9:14] = [off_tf, off_links, off_sph, off_box, total]
+    ibuf[9:16] = [off_tf, off_links, off_sph, off_box, total, off_cull, off_fs]
     buf[off_tf:off_links] = rs['joint_tf'].astype(np.float32).reshape(-1)
     links = np.zeros((n_links, 8), np.float32)
-    links.view(np.int32)[:, 0] = rs['link_frame']
+    links.view(np.int32)[:, 0] = rs['link_frame'] if rs['kind'] == KIND_CHAIN else 1
     links[:, 1:4] = rs['link_offset']
     links[:, 4] = rs['link_radius']
     buf[off_links:off_sph] = links.reshape(-1)
@@ -245,7 +255,34 @@ def pack_geometry(robot, field):
     if n_box:
         boxes[:, 0:3] = fs['boxes'][:, 0:3]
         boxes[:, 4:7] = fs['boxes'][:, 3:6]
-    buf[off_box:total] = boxes.reshape(-1)
+    buf[off_box:off_cull] = boxes.reshape(-1)
+    # conservative cull table (fp64 on the host, rounded up)
+    cull = np.zeros((n_sph_pad, 8), np.float32)
+    cull[:, 3] = -1.0e30
+    cull[:, 4:7] = -1.0e9   # (parked link slots sit at +1e9: never near a padding obstacle)
+    if n_sph:
+        c = fs['spheres'][:, :3].astype(np.float64)
+        r = fs['spheres'][:, 3].astype(np.float64)
+        a_max = float(fs['margin']) + float(np.max(rs['link_radius']))
+        T = a_max + r
+        cc = (c * c).sum(1)
+        cmax = float(np.sqrt(cc.max()))
+        slack = 2.0 ** -20 * (2.0 * cmax + float(T.max())) ** 2 + 1e-7   # 4x the fp32 error of the test value
+        rhs = T * T - cc + slack
+        cull[:n_sph, 0:3] = (-2.0 * c).astype(np.float32)
+        cull[:n_sph, 3] = np.nextafter(rhs.astype(np.float32), np.float32(np.inf))
+        cull[:n_sph, 4:7] = fs['spheres'][:, :3]
+        cull[:n_sph, 7] = fs['spheres'][:, 3]
+    buf[off_cull:off_fs] = cull.reshape(-1)
+    fstart = np.zeros((n_fs,), np.int32)
+    if rs['kind'] == KIND_CHAIN:
+        lf = np.asarray(rs['link_frame'])
+        for j in range(n_frames + 1):
+            fstart[j] = int(np.searchsorted(lf, j + 1, side='left'))
+        fstart[n_frames + 1:] = n_links
+    else:
+        fstart[0], fstart[1:] = 0, n_links
+    ibuf[off_fs:total] = fstart
     return buf
 
 

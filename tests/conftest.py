@@ -31,6 +31,20 @@ def ref_geometry_from_golden(g, dtype=torch.float32):
     return robot, field
 
 
+def product_geometry_from_golden(g):
+    """(robot, field) product spec objects rebuilt from the arrays stored in a golden file."""
+    from motion_planning_baselines_amd import geometry as G
+    if int(g['robot_kind']) == 0:
+        robot = G.RobotPointMass(int(g['n_dof']), radius=float(g['link_radius'][0]))
+    else:
+        D = int(g['n_dof'])
+        robot = G.RobotSerialChain(g['joint_tf'], g['link_frame'], g['link_offset'], g['link_radius'],
+                                   q_min=[-3.2] * D, q_max=[3.2] * D)
+    field = G.CollisionField(spheres=g['spheres'] if len(g['spheres']) else None,
+                             boxes=g['boxes'] if len(g['boxes']) else None, margin=float(g['margin']))
+    return robot, field
+
+
 @pytest.fixture(scope='session')
 def gpu_device():
     if not torch.cuda.is_available():

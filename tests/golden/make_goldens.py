@@ -80,7 +80,7 @@ def geom_arrays(robot, field):
     return dict(robot_kind=np.int32(rs['kind']), n_dof=np.int32(rs['n_dof']),
                 joint_tf=rs['joint_tf'], link_frame=rs['link_frame'], link_offset=rs['link_offset'],
                 link_radius=rs['link_radius'], spheres=fs['spheres'], boxes=fs['boxes'],
-                margin=np.float32(fs['margin']), geom_packed=G.pack_geometry(robot, field))
+                margin=np.float32(fs['margin']))
 
 
 def free_configs(robot, field, n, seed, ta):

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, ref_geometry_from_golden
+from conftest import load_golden, product_geometry_from_golden, ref_geometry_from_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -21,7 +21,8 @@ def rel_err(a, b):
 
 def dev_geom(g, device):
     from motion_planning_baselines_amd.ops import DeviceGeometry
-    return DeviceGeometry.from_packed(g['geom_packed'], device)
+    robot, field = product_geometry_from_golden(g)
+    return DeviceGeometry(robot, field, device)
 
 
 def random_trajs(g, B, H, d, seed, spread):
@@ -208,6 +209,19 @@ def test_stomp_device_rng(gpu_device):
     assert float((emp - Sg).abs().max() / Sg.abs().max()) < 0.06
 
 
+def chomp_reference_fp32_envelope(g):
+    """|reference fp32 golden - oracle in fp64| / |.| on the final means (free running)."""
+    from oracle import planners_ref as O
+    robot, field = ref_geometry_from_golden(g, torch.float64)
+    R = O.chomp_precision(int(g['H']), float(g['dt']), dict(device='cpu', dtype=torch.float32)).double()
+    m = T(g['means0']).double()
+    for _ in range(g['means'].shape[0]):
+        m = O.chomp_iteration(m, R, lambda x: O.collision_cost(x, robot, field, float(g['sigma_coll']),
+                                                               weight=float(g['weight'])),
+                              float(g['w_prior']), float(g['lr']), float(g['clip']))['means']
+    return rel_err(T(g['means'][-1]), m)
+
+
 @pytest.mark.parametrize('name', ['chomp_pm2d_dense', 'chomp_pm2d_soft', 'chomp_panda'])
 def test_chomp_vs_golden(gpu_device, name):
     from motion_planning_baselines_amd import ops
@@ -218,17 +232,27 @@ def test_chomp_vs_golden(gpu_device, name):
     n = g['means'].shape[0]
     kw = dict(D=int(g['D']), k_sigma=1.0 / float(g['sigma_coll']) ** 2, weight=float(g['weight']),
               w_prior=float(g['w_prior']), lr=float(g['lr']), grad_clip=float(g['clip']))
-    # one iteration per call, free running
+    # teacher forced: one pass of the loop body from the reference's own iterate -- strict
+    prev = T(g['means0'])
+    for it in range(n):
+        means = prev.clone().to(dev)
+        ops.chomp_step(means, R, geom, n_iters=1, **kw)
+        torch.cuda.synchronize()
+        assert rel_err(means, T(g['means'][it])) < 1e-5, it
+        prev = T(g['means'][it])
+    # free running, one iteration per call and the whole loop inside one launch: identical results
     means = T(g['means0']).clone().to(dev)
     for it in range(n):
         ops.chomp_step(means, R, geom, n_iters=1, **kw)
-        torch.cuda.synchronize()
-        assert rel_err(means, T(g['means'][it])) < REL, it
-    # the whole loop inside one launch
     m2 = T(g['means0']).clone().to(dev)
     costs = torch.empty(m2.shape[0], device=dev)
     ops.chomp_step(m2, R, geom, n_iters=n, costs_out=costs, **kw)
     torch.cuda.synchronize()
     assert torch.equal(m2, means)
-    assert rel_err(m2, T(g['means'][-1])) < REL
     assert torch.isfinite(costs).all()
+    # free running vs the reference: 1e-4, or the reference's own fp32 rounding envelope where the
+    # clipped, B-scaled smoothness gradient (quirk Q3) amplifies rounding noise beyond that
+    err = rel_err(m2, T(g['means'][-1]))
+    env = chomp_reference_fp32_envelope(g)
+    print(name, 'free-running final rel err', err, 'reference fp32-vs-fp64 envelope', env)
+    assert err < max(REL, 2.0 * env)

@@ -1,0 +1,97 @@
+"""CPU: host-side logic of the product (no compute calls): the C-ABI library loads and exports every
+symbol include/mpb.h declares, geometry packing round-trips through the library's validator, and the
+planner constants match the reference's (golden) R / Sigma / scale_tril bit for bit."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, product_geometry_from_golden
+
+
+def test_library_exports_every_declared_symbol():
+    from motion_planning_baselines_amd import _lib
+    hdr = open(os.path.join(ROOT, 'include', 'mpb.h')).read()
+    declared = set(re.findall(r'\b(mpb_[a-z0-9_]+)\s*\(', hdr))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    h = _lib.lib()
+    for name in declared:
+        assert hasattr(h, name)
+    assert h.mpb_version() >= 1
+
+
+def test_geometry_pack_validates_and_rejects_corruption():
+    from motion_planning_baselines_amd import _lib, geometry as G
+    for robot, field in [(G.RobotPanda(), G.env_spheres_3d()), (G.RobotPointMass(2), G.env_dense_2d()),
+                         (G.RobotPointMass(3), G.env_spheres_3d()), (G.RobotPointMass(2), G.env_grid_circles_2d())]:
+        buf = G.pack_geometry(robot, field)
+        _lib.geom_check(buf)
+        bad = buf.copy()
+        bad.view(np.int32)[0] ^= 1
+        with pytest.raises(_lib.MPBError):
+            _lib.geom_check(bad)
+        bad = buf.copy()
+        bad.view(np.int32)[13] += 4
+        with pytest.raises(_lib.MPBError):
+            _lib.geom_check(bad)
+        with pytest.raises(_lib.MPBError):
+            _lib.geom_check(buf[:20])
+
+
+def test_cull_table_is_conservative():
+    """Every (link position, obstacle) pair within the hinge threshold must pass the cheap test."""
+    from motion_planning_baselines_amd import geometry as G
+    robot, field = G.RobotPanda(), G.env_spheres_3d()
+    buf = G.pack_geometry(robot, field)
+    i = buf.view(np.int32)
+    n_sph = i[6]
+    cull = buf[i[14]:i[14] + 8 * ((n_sph + 3) // 4 * 4)].reshape(-1, 8)
+    rng = np.random.RandomState(0)
+    T = field.margin + robot.link_radius.max() + field.spheres[:, 3]
+    for o in range(n_sph):
+        c = field.spheres[o, :3].astype(np.float64)
+        d = rng.randn(20000, 3)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        x = (c + d * (T[o] * rng.uniform(0.0, 1.0, (20000, 1)))).astype(np.float32)   # inside the threshold ball
+        xx = (x * x).sum(1, dtype=np.float32)
+        t = xx + x[:, 0] * cull[o, 0] + x[:, 1] * cull[o, 1] + x[:, 2] * cull[o, 2]
+        assert (t < cull[o, 3]).all()
+    assert (cull[n_sph:, 3] < -1e29).all()
+
+
+@pytest.mark.parametrize('name', ['stomp_pm2d_c1', 'stomp_panda_t1', 'stomp_pm2d_h48'])
+def test_stomp_constants_match_reference(name):
+    from motion_planning_baselines_amd.planners.stomp import precision_to_scale_tril, stomp_precision_matrix
+    g = load_golden(name)
+    cpu = dict(device='cpu', dtype=torch.float32)
+    R = stomp_precision_matrix(int(g['H']), float(g['dt']), float(g['sigma_spectral']), cpu)
+    assert torch.equal(R, torch.from_numpy(g['R']))
+    assert torch.equal(torch.inverse(R), torch.from_numpy(g['Sigma']))
+    assert torch.equal(precision_to_scale_tril(R), torch.from_numpy(g['L']))
+
+
+def test_chomp_constants_match_reference():
+    from motion_planning_baselines_amd.planners.chomp import chomp_precision_matrix
+    g = load_golden('chomp_pm2d_dense')
+    R = chomp_precision_matrix(dt=float(g['dt']), n_support_points=int(g['H']), tensor_args=dict(device='cpu', dtype=torch.float32))
+    assert torch.equal(R, torch.from_numpy(g['R']))
+
+
+def test_planner_refuses_cpu_device():
+    from motion_planning_baselines_amd._lib import MPBError
+    from motion_planning_baselines_amd.planners.stomp import STOMP
+    with pytest.raises(MPBError):
+        STOMP(n_dof=2, n_support_points=64, num_particles_per_goal=2, num_samples=4, opt_iters=1, dt=0.04,
+              start_state=torch.zeros(2), initial_particle_means=torch.zeros(2, 64, 2),
+              tensor_args=dict(device='cpu', dtype=torch.float32))
+
+
+def test_product_geometry_round_trip():
+    g = load_golden('chomp_panda')
+    robot, field = product_geometry_from_golden(g)
+    from motion_planning_baselines_amd import geometry as G
+    buf = G.pack_geometry(robot, field)
+    i = buf.view(np.int32)
+    assert i[5] == len(g['link_radius']) and i[6] == len(g['spheres'])
