@@ -25,6 +25,7 @@
 #ifndef MPB_H
 #define MPB_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -111,42 +112,61 @@ int mpb_chomp_step(float *means, const float *R, const float *geom, float *costs
  * _get_grad_terms dense branch (gpmp2.py:355-368), get_torch_solve('cholesky') (:451-452) and the
  * update (:339), WITHOUT materialising the dense (A,b,K): the normal equations A^T K A are
  * block-tridiagonal with 2D x 2D blocks and are assembled and solved per particle by block Cholesky.
+ * Internal arithmetic is fp64 (weights reach 1/sigma^2 = 1e10); x is stored in fp32.
  *
- * x (B,H,2D) in/out; start (2D), goal (2D) states (zero velocities appended by the host);
- * damping: trust_region == 0 -> + delta * I; else + delta * diag_mean, where diag_mean (H*2D) is the
- * batch mean of diag(A^T K A) (quirk Q9).  mpb_gpmp2_diag computes the LOCAL SUM of the diagonal
- * into diag_sum (H*2D) (host divides by the global B, after an all-reduce when sharded);
- * mpb_gpmp2_step consumes diag_mean (may be NULL when trust_region == 0).
- * costs_out (B) optional: b^T K b of the iterate BEFORE the update (gpmp2.py:493-495).
- * Internal arithmetic is fp64 (weights reach 1/sigma^2 = 1e10); storage is fp32.
+ * x (B,H,2D) in/out; start (B,2D), goal (B,2D) per-particle states (zero velocities appended by the
+ * host; the reference's single start / goal is broadcast by the caller).
+ * workspace: caller-allocated device scratch of mpb_gpmp2_workspace_bytes(B,H,D) bytes, 256-byte
+ * aligned (collision Jacobians, the diagonal sums and the per-step elimination factors).
+ *
+ * One iteration = linearize -> [diag] -> solve:
+ *   mpb_gpmp2_linearize : collision cost c_t and Jacobian h_t = -dc_t/dq of every waypoint (FieldFactor
+ *                         get_error(calc_jacobian=True), field_factor.py:41-57) into the workspace;
+ *   mpb_gpmp2_diag      : LOCAL SUM over the B particles of diag(A^T K A) (H*2D fp64) -- quirk Q9: the
+ *                         trust-region damping uses the BATCH MEAN of that diagonal (gpmp2.py:361-367).
+ *                         diag_sum_out NULL: kept in the workspace.  When sharded, the host all-reduces
+ *                         the sums and passes diag_mean = sum / B_global to mpb_gpmp2_solve;
+ *   mpb_gpmp2_solve     : assemble + block-Cholesky solve + x += step_size * dtheta.
+ *                         trust_region == 0: damping delta * I (diag_mean ignored);
+ *                         else delta * diag_mean (diag_mean NULL: workspace mean written by mpb_gpmp2_step).
+ *                         costs_out (B) optional: b^T K b of the iterate BEFORE the update (gpmp2.py:493-495).
+ *   mpb_gpmp2_step      : n_iters full iterations on one GPU (mean over the local B).
  * ------------------------------------------------------------------------------------------- */
-int mpb_gpmp2_diag(const float *x, const float *geom, float *diag_sum, int B, int H, int D, float dt,
+size_t mpb_gpmp2_workspace_bytes(int B, int H, int D);
+int mpb_gpmp2_linearize(const float *x, const float *geom, void *workspace, int B, int H, int D, void *stream);
+int mpb_gpmp2_diag(void *workspace, double *diag_sum_out, int B, int H, int D, float dt,
                    float sigma_start, float sigma_gp, float sigma_goal, float sigma_coll, void *stream);
-int mpb_gpmp2_step(float *x, const float *start, const float *goal, const float *geom,
-                   const float *diag_mean, float *costs_out, int B, int H, int D, float dt,
+int mpb_gpmp2_solve(float *x, const float *start, const float *goal, const double *diag_mean, void *workspace,
+                    float *costs_out, int B, int H, int D, float dt,
+                    float sigma_start, float sigma_gp, float sigma_goal, float sigma_coll,
+                    float delta, int trust_region, float step_size, void *stream);
+int mpb_gpmp2_step(float *x, const float *start, const float *goal, const float *geom, void *workspace,
+                   float *costs_out, int B, int H, int D, float dt,
                    float sigma_start, float sigma_gp, float sigma_goal, float sigma_coll,
-                   float delta, int trust_region, float step_size, void *stream);
+                   float delta, int trust_region, float step_size, int n_iters, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * MPPI -- replaces MPPI.optimize's loop body (mppi.py:145-152): ControlTrajectoryGaussian.sample
  * (priors/gaussian.py:276-298), get_state_trajectories_rollout (mppi.py:190-210) over
  * PointParticleDynamics.dynamics (dynamics/point.py:102-140, deterministic), traj_cost (:154-226),
  * the importance-sampling term (mppi.py:125-128) and update_controller (:72-86).
- * One problem per workgroup; NP independent problems per launch (the reference class is NP = 1).
+ * One problem per workgroup; NP independent problems per launch (the reference class is NP = 1);
+ * all n_iters iterations inside one launch.
  *
- * mean (NP,T,c) in/out; eps NULL -> device Philox, else (NP,c,S,T) standard normals (per control
- * dimension, in the reference's draw order); scale_tril, cov_inv (c,T,T); state0 (NP,sd);
- * goal (NP,sd); ctrl_min / ctrl_max (c); discount (T); c_weights = {pos, vel, ctrl, pos_T};
- * control_type 0 = velocity (sd = c), 1 = acceleration (sd = 2c).
+ * mean (NP,T,c) in/out; eps NULL -> device Philox, else (n_iters,NP,c,S,T) standard normals (per
+ * control dimension, in the reference's draw order); scale_tril, cov_inv (c,T,T); state0 (NP,c);
+ * goal (NP,c); ctrl_min / ctrl_max (c); discount (T); c_weights = {pos, vel, ctrl, pos_T};
+ * control_type 0 = velocity (state_dim = c); 1 = acceleration is MPB_E_UNSUPPORTED (the reference's
+ * acceleration mode slices an empty tensor, point.py:114-118, and cannot run).
  * geom optional (NULL = no collision term).  With geom, the reference's quirk Q6 is reproduced:
  * the per-sample collision costs are summed into ONE scalar that is added to every sample's cost.
- * Outputs of the last iteration: controls (NP,S,T,c), states (NP,S,T,sd), costs (NP,S), weights (NP,S).
+ * Outputs of the last iteration: controls (NP,S,T,c), states (NP,S,T,c), costs (NP,S), weights (NP,S).
  * ------------------------------------------------------------------------------------------- */
 int mpb_mppi_step(float *mean, const float *eps, const float *scale_tril, const float *cov_inv,
                   const float *state0, const float *goal, const float *ctrl_min, const float *ctrl_max,
                   const float *discount, const float *c_weights, const float *geom,
                   float *controls, float *states, float *costs, float *weights,
-                  int NP, int S, int T, int c, int control_type,
+                  int NP, int S, int T, int c, int control_type, float dt,
                   float k_sigma, float weight, float temp, float step_size,
                   int n_iters, uint64_t seed, uint32_t iter0, void *stream);
 

@@ -28,9 +28,12 @@ SIGNATURES = {
     'mpb_stomp_sample': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _u64, _u32, _u32, _p],
     'mpb_stomp_update': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     'mpb_chomp_step': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _p],
-    'mpb_gpmp2_diag': [_p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _f, _p],
-    'mpb_gpmp2_step': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _f, _f, _i, _f, _p],
-    'mpb_mppi_step': [_p] * 15 + [_i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _u64, _u32, _p],
+    'mpb_gpmp2_workspace_bytes': [_i, _i, _i],
+    'mpb_gpmp2_linearize': [_p, _p, _p, _i, _i, _i, _p],
+    'mpb_gpmp2_diag': [_p, _p, _i, _i, _i, _f, _f, _f, _f, _f, _p],
+    'mpb_gpmp2_solve': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _f, _f, _i, _f, _p],
+    'mpb_gpmp2_step': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _f, _f, _i, _f, _i, _p],
+    'mpb_mppi_step': [_p] * 15 + [_i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _u64, _u32, _p],
 }
 
 _lib = None
@@ -57,7 +60,8 @@ def lib():
         except AttributeError as e:
             raise MPBError(f'{LIB_PATH} does not export {name} (declared in include/mpb.h)') from e
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_char_p if name == 'mpb_last_error' else ctypes.c_int
+        fn.restype = (ctypes.c_char_p if name == 'mpb_last_error' else
+                      ctypes.c_size_t if name == 'mpb_gpmp2_workspace_bytes' else ctypes.c_int)
     _lib = h
     return h
 

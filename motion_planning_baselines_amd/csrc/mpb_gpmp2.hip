@@ -1,10 +1,432 @@
-// placeholder until the block-tridiagonal GPMP2 kernels land
-#include "../../include/mpb.h"
+// mpb_gpmp2.hip -- GPMP2 Gauss-Newton step without the dense (A, b, K).
+//
+// The reference (gpmp2.py:308-368, cost_functions.py:107-144,191-231,291-314,538-554) stacks a dense
+// A (B,M,N), K (B,M,M) with N = 2D*H, forms A^T K A (B,N,N) and runs a dense Cholesky.  The factor graph
+// is a chain, so A^T K A is block tridiagonal with 2D x 2D blocks (tests/golden: |outside band| == 0):
+//
+//   diag block t : [t=0] K_s + [t<H-1] Phi^T Qi Phi + [t>0] Qi + [t=H-1] K_g
+//                  + [t>0] (1/sigma_c^2) h_t h_t^T (position rows/cols) + damping
+//   block (t,t+1): U = -Phi^T Qi                                  (constant)
+//   rhs block t  : [t=0] K_s (mu_s - x_0) + [t<H-1] Phi^T Qi e_t - [t>0] Qi e_{t-1}
+//                  + [t=H-1] K_g (goal - x_{H-1}) + [t>0] (1/sigma_c^2) h_t c_t
+//   with e_t = x_{t+1} - Phi x_t (gp_factor.py:52-56), c_t the collision cost of waypoint t and
+//   h_t = -d c_t / d q_t (field_factor.py:54).
+//
+// Solve per particle by block elimination (block Thomas / block Cholesky):
+//   S_0 = D_0, r_0 = g_0;   S_t [F_t | z_t] = [U | r_t];   S_{t+1} = D_{t+1} - U^T F_t;  r_{t+1} = g_{t+1} - U^T z_t
+//   dtheta_{H-1} = z_{H-1};  dtheta_t = z_t - F_t dtheta_{t+1}
+// One wave per particle; the 2D x 2D blocks live in LDS as 16 x 16 fp64 tiles; F_t, z_t go to a
+// caller-provided workspace.  All arithmetic is fp64: the weights reach 1/sigma^2 = 1e10 (gpmp2.py:32-35)
+// and fp32 Cholesky at that conditioning is not reproducible; storage stays fp32.
 #include "mpb_common.h"
-extern "C" int mpb_gpmp2_diag(const float*, const float*, float*, int, int, int, float, float, float, float, float, void*) {
-    return mpb_fail(MPB_E_UNSUPPORTED, "mpb_gpmp2_diag: not implemented in this build");
+#include "mpb_geom.h"
+
+#define GP_N 16            // padded block size (2D <= 16)
+#define GP_LD 17           // LDS leading dimension (fp64 words)
+#define GP_MAXH MPB_MAX_H
+
+// ------------------------------------------------------------------------------------------------
+// linearisation of the collision factor: jac[b][t][0..D) = h_t = -d c_t/d q, jac[b][t][D] = c_t
+// (t = 0 is excluded from the collision factor: traj_range [1, None]).  One wave per particle, lane = waypoint.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gpmp2_linearize_kernel(const float* __restrict__ x, const float* __restrict__ geom,
+                                                              float* __restrict__ jac, int B, int H, int D) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const GeomView G = geom_view(geom);
+    const int dim = 2 * D;
+    for (int t = lane; t < H; t += 64) {
+        const float* row = x + ((size_t)b * H + t) * dim;
+        float q[MPB_MAX_DOF], dq[MPB_MAX_DOF];
+#pragma unroll
+        for (int i = 0; i < MPB_MAX_DOF; ++i) q[i] = (i < D) ? row[i] : 0.f;
+        float c = 0.f;
+        if (t >= 1) {
+            c = waypoint_cost<true>(G, q, dq);
+        } else {
+#pragma unroll
+            for (int i = 0; i < MPB_MAX_DOF; ++i) dq[i] = 0.f;
+        }
+        float* o = jac + ((size_t)b * H + t) * (D + 1);
+#pragma unroll
+        for (int i = 0; i < MPB_MAX_DOF; ++i)
+            if (i < D) o[i] = -dq[i];
+        o[D] = c;
+    }
 }
-extern "C" int mpb_gpmp2_step(float*, const float*, const float*, const float*, const float*, float*, int, int, int, float,
-                              float, float, float, float, float, int, float, void*) {
-    return mpb_fail(MPB_E_UNSUPPORTED, "mpb_gpmp2_step: not implemented in this build");
+
+// ------------------------------------------------------------------------------------------------
+// local SUM over particles of diag(A^T K A) (quirk Q9 needs its batch mean).  grid = H, block = 256.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gpmp2_diag_kernel(const float* __restrict__ jac, double* __restrict__ diag_sum,
+                                                         int B, int H, int D, double dt, double ks, double kgp,
+                                                         double kg, double kc) {
+    const int t = blockIdx.x;
+    const int dim = 2 * D;
+    __shared__ double red[4][MPB_MAX_DOF];
+    double acc[MPB_MAX_DOF];
+#pragma unroll
+    for (int i = 0; i < MPB_MAX_DOF; ++i) acc[i] = 0.0;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const float* o = jac + ((size_t)b * H + t) * (D + 1);
+#pragma unroll
+        for (int i = 0; i < MPB_MAX_DOF; ++i)
+            if (i < D) acc[i] += (double)o[i] * (double)o[i];
+    }
+#pragma unroll
+    for (int i = 0; i < MPB_MAX_DOF; ++i) acc[i] = wave_sum_f64(acc[i]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < MPB_MAX_DOF; ++i) red[threadIdx.x >> 6][i] = acc[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < dim) {
+        const int i = threadIdx.x;
+        const bool pos = i < D;
+        // constant part of the diagonal (identical for every particle)
+        double c = 0.0;
+        if (t == 0) c += ks;
+        if (t < H - 1) c += pos ? 12.0 / (dt * dt * dt) * kgp : 4.0 / dt * kgp;   // Phi^T Qi Phi
+        if (t > 0) c += pos ? 12.0 / (dt * dt * dt) * kgp : 4.0 / dt * kgp;       // Qi
+        if (t == H - 1) c += kg;
+        double s = c * (double)B;
+        if (pos && t > 0) {
+            double h2 = 0.0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) h2 += red[w][i < MPB_MAX_DOF ? i : 0];
+            s += kc * h2;
+        }
+        diag_sum[(size_t)t * dim + i] = s;
+    }
+}
+
+__global__ void gpmp2_scale_kernel(const double* __restrict__ in, double* __restrict__ out, int n, double s) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] * s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// wave-cooperative dense helpers on GP_N x GP_N fp64 tiles in LDS (n = live size)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+// in-place lower Cholesky of S (n x n, lower part read/written)
+__device__ void tile_cholesky(double* S, int n, int lane) {
+    for (int k = 0; k < n; ++k) {
+        const double piv = sqrt(S[k * GP_LD + k]);
+        wave_sync();
+        if (lane == 0) S[k * GP_LD + k] = piv;
+        if (lane > k && lane < n) S[lane * GP_LD + k] /= piv;
+        wave_sync();
+        // trailing update: (i,j), k < j <= i < n
+        for (int e = lane; e < GP_N * GP_N; e += 64) {
+            const int i = e >> 4, j = e & 15;
+            if (j > k && j <= i && i < n) S[i * GP_LD + j] -= S[i * GP_LD + k] * S[j * GP_LD + k];
+        }
+        wave_sync();
+    }
+}
+
+// solve L L^T X = Bm in place; Bm is n x m (m <= GP_N + 1 columns, leading dimension GP_LD + 1)
+#define GP_LDB 18
+__device__ void tile_chol_solve(const double* L, double* Bm, int n, int m, int lane) {
+    // forward: L Y = B
+    for (int k = 0; k < n; ++k) {
+        const double inv = 1.0 / L[k * GP_LD + k];
+        if (lane < m) Bm[k * GP_LDB + lane] *= inv;
+        wave_sync();
+        for (int e = lane; e < GP_N * GP_LDB; e += 64) {
+            const int i = e / GP_LDB, c = e - i * GP_LDB;
+            if (i > k && i < n && c < m) Bm[i * GP_LDB + c] -= L[i * GP_LD + k] * Bm[k * GP_LDB + c];
+        }
+        wave_sync();
+    }
+    // backward: L^T X = Y
+    for (int k = n - 1; k >= 0; --k) {
+        const double inv = 1.0 / L[k * GP_LD + k];
+        if (lane < m) Bm[k * GP_LDB + lane] *= inv;
+        wave_sync();
+        for (int e = lane; e < GP_N * GP_LDB; e += 64) {
+            const int i = e / GP_LDB, c = e - i * GP_LDB;
+            if (i < k && c < m) Bm[i * GP_LDB + c] -= L[k * GP_LD + i] * Bm[k * GP_LDB + c];
+        }
+        wave_sync();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// block-tridiagonal solve + update, one wave per particle
+// ------------------------------------------------------------------------------------------------
+struct GpConst {
+    double dt, ks, kgp, kg, kc, delta, step;
+    int trust;
+};
+
+__global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, const float* __restrict__ start,
+                                                         const float* __restrict__ goal, const float* __restrict__ jac,
+                                                         const double* __restrict__ diag_mean, double* __restrict__ work,
+                                                         float* __restrict__ costs_out, int B, int H, int D, GpConst K) {
+    __shared__ double S[GP_N * GP_LD];    // current Schur complement / its Cholesky factor
+    __shared__ double Bm[GP_N * GP_LDB];  // [U | r_t] -> [F_t | z_t]
+    __shared__ double xs[2][GP_N];        // x_t, x_{t+1} (fp64 copies)
+    __shared__ double gnext[GP_N];        // part of g_{t+1} produced by factor t
+    __shared__ double dth[GP_N];          // dtheta_{t+1} during the backward pass
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;
+    const int dim = 2 * D;
+    const double dt = K.dt;
+    // 2x2 GP coefficient matrices (Kronecker with I_D)
+    const double a = 12.0 / (dt * dt * dt) * K.kgp, bq = -6.0 / (dt * dt) * K.kgp, cq = 4.0 / dt * K.kgp;  // Qi
+    const double p00 = a, p01 = 6.0 / (dt * dt) * K.kgp, p11 = cq;                                            // Phi^T Qi Phi
+    // U = -Phi^T Qi = -[[a, bq],[a dt + bq, bq dt + cq]]
+    const double u00 = -a, u01 = -bq, u10 = -(a * dt + bq), u11 = -(bq * dt + cq);
+    double* wF = work + (size_t)b * H * (GP_N * GP_N + GP_N);  // per t: F_t (dim x dim, row-major GP_N) then z_t
+    float* xb = x + (size_t)b * H * dim;
+    const float* jb = jac + (size_t)b * H * (D + 1);
+    double cost = 0.0;
+
+    // S = D_0 (without the Schur term), r_0 = g_0 assembled on the fly inside the loop
+    for (int t = 0; t < H; ++t) {
+        // ---- load x_t, x_{t+1}
+        if (lane < dim) {
+            xs[0][lane] = (double)xb[t * dim + lane];
+            xs[1][lane] = (t + 1 < H) ? (double)xb[(t + 1) * dim + lane] : 0.0;
+        }
+        wave_sync();
+        // ---- GP error of factor t: e = x_{t+1} - Phi x_t   (pos: x1p - x0p - dt x0v ; vel: x1v - x0v)
+        double e_i = 0.0;
+        if (lane < dim && t + 1 < H) {
+            const bool pos = lane < D;
+            e_i = pos ? xs[1][lane] - (xs[0][lane] + dt * xs[0][lane + D]) : xs[1][lane] - xs[0][lane];
+        }
+        // Qi e and Phi^T Qi e   (Kronecker: mixes component i with its pos/vel partner)
+        double qe_i = 0.0, pqe_i = 0.0;
+        {
+            const double e_partner = __shfl(e_i, (lane < D) ? lane + D : lane - D, 64);
+            if (lane < dim && t + 1 < H) {
+                const bool pos = lane < D;
+                const double ep = pos ? e_i : e_partner, ev = pos ? e_partner : e_i;
+                const double qp = a * ep + bq * ev, qv = bq * ep + cq * ev;      // Qi e
+                qe_i = pos ? qp : qv;
+                pqe_i = pos ? qp : dt * qp + qv;                                 // Phi^T (Qi e)
+                if (pos) cost += ep * qp;
+                else cost += ev * qv;
+            }
+        }
+        // ---- assemble D_t into S (adding to the Schur part already there for t > 0) and r_t into Bm[:, dim]
+        const double ct = (t > 0) ? (double)jb[t * (D + 1) + D] : 0.0;
+        for (int e = lane; e < GP_N * GP_N; e += 64) {
+            const int i = e >> 4, j = e & 15;
+            if (i < dim && j < dim) {
+                double v = (t > 0) ? S[i * GP_LD + j] : 0.0;   // S currently holds -(U^T F_{t-1}) for t > 0
+                const bool ip = i < D, jp = j < D;
+                const int ii = ip ? i : i - D, jj = jp ? j : j - D;
+                if (ii == jj) {
+                    double g = 0.0;
+                    if (t < H - 1) g += ip ? (jp ? p00 : p01) : (jp ? p01 : p11);
+                    if (t > 0) g += ip ? (jp ? a : bq) : (jp ? bq : cq);
+                    v += g;
+                }
+                if (i == j) {
+                    if (t == 0) v += K.ks;
+                    if (t == H - 1) v += K.kg;
+                    v += K.trust ? K.delta * diag_mean[(size_t)t * dim + i] : K.delta;
+                }
+                if (t > 0 && ip && jp) v += K.kc * (double)jb[t * (D + 1) + i] * (double)jb[t * (D + 1) + j];
+                S[i * GP_LD + j] = v;
+            }
+        }
+        if (lane < dim) {
+            double r = (t > 0) ? Bm[lane * GP_LDB + dim] : 0.0;   // carries g-part and -U^T z_{t-1} from the previous step
+            if (t == 0) {
+                const double es = (double)start[(size_t)b * dim + lane] - xs[0][lane];
+                r += K.ks * es;
+                cost += K.ks * es * es;
+            }
+            if (t == H - 1) {
+                const double eg = (double)goal[(size_t)b * dim + lane] - xs[0][lane];
+                r += K.kg * eg;
+                cost += K.kg * eg * eg;
+            }
+            if (t < H - 1) r += pqe_i;
+            if (t > 0 && lane < D) r += K.kc * (double)jb[t * (D + 1) + lane] * ct;
+            gnext[lane] = -qe_i;                                   // contribution of factor t to g_{t+1}
+            Bm[lane * GP_LDB + dim] = r;
+        }
+        if (lane == 0 && t > 0) cost += K.kc * ct * ct;
+        // U into Bm[:, 0..dim)
+        for (int e = lane; e < GP_N * GP_N; e += 64) {
+            const int i = e >> 4, j = e & 15;
+            if (i < dim && j < dim) {
+                const bool ip = i < D, jp = j < D;
+                const int ii = ip ? i : i - D, jj = jp ? j : j - D;
+                Bm[i * GP_LDB + j] = (ii == jj) ? (ip ? (jp ? u00 : u01) : (jp ? u10 : u11)) : 0.0;
+            }
+        }
+        wave_sync();
+        // ---- factor and solve S [F | z] = [U | r]
+        tile_cholesky(S, dim, lane);
+        tile_chol_solve(S, Bm, dim, (t < H - 1) ? dim + 1 : dim + 1, lane);
+        // ---- store F_t, z_t
+        double* wt = wF + (size_t)t * (GP_N * GP_N + GP_N);
+        for (int e = lane; e < GP_N * GP_N; e += 64) {
+            const int i = e >> 4, j = e & 15;
+            if (i < dim && j < dim) wt[i * GP_N + j] = Bm[i * GP_LDB + j];
+        }
+        if (lane < dim) wt[GP_N * GP_N + lane] = Bm[lane * GP_LDB + dim];
+        wave_sync();
+        if (t < H - 1) {
+            // ---- S <- -(U^T F_t),  r_{t+1} <- gnext - U^T z_t     (U^T = -(Qi Phi): 2x2 Kronecker)
+            // (U^T v)_i : pos row i: u00 v_p + u10 v_v ; vel row: u01 v_p + u11 v_v
+            double newS[4];
+#pragma unroll
+            for (int cnt = 0; cnt < 4; ++cnt) {
+                const int e = lane + 64 * cnt;
+                const int i = e >> 4, j = e & 15;
+                double v = 0.0;
+                if (i < dim && j < dim) {
+                    const bool ip = i < D;
+                    const int ii = ip ? i : i - D;
+                    const double fp = Bm[ii * GP_LDB + j], fv = Bm[(ii + D) * GP_LDB + j];
+                    v = -(ip ? u00 * fp + u10 * fv : u01 * fp + u11 * fv);
+                }
+                newS[cnt] = v;
+            }
+            double rn = 0.0;
+            if (lane < dim) {
+                const bool ip = lane < D;
+                const int ii = ip ? lane : lane - D;
+                const double zp = Bm[ii * GP_LDB + dim], zv = Bm[(ii + D) * GP_LDB + dim];
+                rn = gnext[lane] - (ip ? u00 * zp + u10 * zv : u01 * zp + u11 * zv);
+            }
+            wave_sync();
+#pragma unroll
+            for (int cnt = 0; cnt < 4; ++cnt) {
+                const int e = lane + 64 * cnt;
+                const int i = e >> 4, j = e & 15;
+                if (i < dim && j < dim) S[i * GP_LD + j] = newS[cnt];
+            }
+            if (lane < dim) Bm[lane * GP_LDB + dim] = rn;
+            wave_sync();
+        }
+    }
+    // ---- backward substitution and update: dtheta_t = z_t - F_t dtheta_{t+1}
+    for (int t = H - 1; t >= 0; --t) {
+        const double* wt = wF + (size_t)t * (GP_N * GP_N + GP_N);
+        double d = 0.0;
+        if (lane < dim) {
+            d = wt[GP_N * GP_N + lane];
+            if (t < H - 1) {
+                for (int j = 0; j < dim; ++j) d -= wt[lane * GP_N + j] * dth[j];
+            }
+        }
+        wave_sync();
+        if (lane < dim) {
+            dth[lane] = d;
+            xb[t * dim + lane] = (float)((double)xb[t * dim + lane] + K.step * d);
+        }
+        wave_sync();
+    }
+    cost = wave_sum_f64(cost);
+    if (costs_out != nullptr && lane == 0) costs_out[b] = (float)cost;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------------------
+static bool gp_shape_ok(int B, int H, int D) { return B >= 0 && H >= 2 && H <= GP_MAXH && D >= 1 && D <= MPB_MAX_DOF; }
+
+extern "C" size_t mpb_gpmp2_workspace_bytes(int B, int H, int D) {
+    if (!gp_shape_ok(B, H, D)) return 0;
+    const size_t jac = (size_t)B * H * (D + 1) * sizeof(float);
+    const size_t diag = 2 * (size_t)H * 2 * D * sizeof(double);
+    const size_t fz = (size_t)B * H * (GP_N * GP_N + GP_N) * sizeof(double);
+    return ((jac + 255) / 256) * 256 + ((diag + 255) / 256) * 256 + fz;
+}
+
+struct GpWork {
+    float* jac;
+    double* diag_sum;
+    double* diag_mean;
+    double* fz;
+};
+static GpWork gp_carve(void* ws, int B, int H, int D) {
+    GpWork w;
+    char* p = (char*)ws;
+    w.jac = (float*)p;
+    p += (((size_t)B * H * (D + 1) * sizeof(float)) + 255) / 256 * 256;
+    w.diag_sum = (double*)p;
+    w.diag_mean = w.diag_sum + (size_t)H * 2 * D;
+    p += ((2 * (size_t)H * 2 * D * sizeof(double)) + 255) / 256 * 256;
+    w.fz = (double*)p;
+    return w;
+}
+
+extern "C" int mpb_gpmp2_linearize(const float* x, const float* geom, void* workspace, int B, int H, int D, void* stream) {
+    if (!x || !geom || !workspace) return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_linearize: null pointer");
+    if (!gp_shape_ok(B, H, D)) return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_linearize: bad shape");
+    if (B == 0) return MPB_OK;
+    GpWork w = gp_carve(workspace, B, H, D);
+    hipLaunchKernelGGL(gpmp2_linearize_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, geom, w.jac, B, H, D);
+    return mpb_check_launch("mpb_gpmp2_linearize");
+}
+
+extern "C" int mpb_gpmp2_diag(void* workspace, double* diag_sum_out, int B, int H, int D, float dt, float sigma_start,
+                              float sigma_gp, float sigma_goal, float sigma_coll, void* stream) {
+    if (!workspace) return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_diag: null pointer");
+    if (!gp_shape_ok(B, H, D)) return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_diag: bad shape");
+    GpWork w = gp_carve(workspace, B, H, D);
+    double* out = diag_sum_out ? diag_sum_out : w.diag_sum;
+    hipLaunchKernelGGL(gpmp2_diag_kernel, dim3(H), dim3(256), 0, (hipStream_t)stream, w.jac, out, B, H, D, (double)dt,
+                       1.0 / ((double)sigma_start * sigma_start), 1.0 / ((double)sigma_gp * sigma_gp),
+                       1.0 / ((double)sigma_goal * sigma_goal), 1.0 / ((double)sigma_coll * sigma_coll));
+    return mpb_check_launch("mpb_gpmp2_diag");
+}
+
+extern "C" int mpb_gpmp2_solve(float* x, const float* start, const float* goal, const double* diag_mean, void* workspace,
+                               float* costs_out, int B, int H, int D, float dt, float sigma_start, float sigma_gp,
+                               float sigma_goal, float sigma_coll, float delta, int trust_region, float step_size,
+                               void* stream) {
+    if (!x || !start || !goal || !workspace) return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_solve: null pointer");
+    if (!gp_shape_ok(B, H, D)) return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_solve: bad shape");
+    if (B == 0) return MPB_OK;
+    GpWork w = gp_carve(workspace, B, H, D);
+    GpConst K;
+    K.dt = dt;
+    K.ks = 1.0 / ((double)sigma_start * sigma_start);
+    K.kgp = 1.0 / ((double)sigma_gp * sigma_gp);
+    K.kg = 1.0 / ((double)sigma_goal * sigma_goal);
+    K.kc = 1.0 / ((double)sigma_coll * sigma_coll);
+    K.delta = delta;
+    K.step = step_size;
+    K.trust = trust_region;
+    const double* dm = trust_region ? (diag_mean ? diag_mean : w.diag_mean) : nullptr;
+    hipLaunchKernelGGL(gpmp2_solve_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, x, start, goal, w.jac, dm, w.fz,
+                       costs_out, B, H, D, K);
+    return mpb_check_launch("mpb_gpmp2_solve");
+}
+
+extern "C" int mpb_gpmp2_step(float* x, const float* start, const float* goal, const float* geom, void* workspace,
+                              float* costs_out, int B, int H, int D, float dt, float sigma_start, float sigma_gp,
+                              float sigma_goal, float sigma_coll, float delta, int trust_region, float step_size,
+                              int n_iters, void* stream) {
+    if (!x || !start || !goal || !geom || !workspace) return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_step: null pointer");
+    if (!gp_shape_ok(B, H, D) || n_iters < 0) return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_step: bad shape");
+    if (B == 0) return MPB_OK;
+    GpWork w = gp_carve(workspace, B, H, D);
+    for (int it = 0; it < n_iters; ++it) {
+        int rc = mpb_gpmp2_linearize(x, geom, workspace, B, H, D, stream);
+        if (rc) return rc;
+        if (trust_region) {
+            rc = mpb_gpmp2_diag(workspace, nullptr, B, H, D, dt, sigma_start, sigma_gp, sigma_goal, sigma_coll, stream);
+            if (rc) return rc;
+            const int n = H * 2 * D;
+            hipLaunchKernelGGL(gpmp2_scale_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, w.diag_sum,
+                               w.diag_mean, n, 1.0 / (double)B);
+        }
+        rc = mpb_gpmp2_solve(x, start, goal, nullptr, workspace, costs_out, B, H, D, dt, sigma_start, sigma_gp, sigma_goal,
+                             sigma_coll, delta, trust_region, step_size, stream);
+        if (rc) return rc;
+    }
+    return mpb_check_launch("mpb_gpmp2_step");
 }

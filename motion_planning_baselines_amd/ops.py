@@ -134,3 +134,79 @@ def chomp_step(means, R, geom, D, k_sigma, weight, w_prior, lr, grad_clip, n_ite
                                         B if B_global is None else int(B_global), H, d, D, float(k_sigma), float(weight),
                                         float(w_prior), float(lr), float(grad_clip), int(n_iters), _stream()),
                'mpb_chomp_step')
+
+
+def gpmp2_workspace(B, H, D, device):
+    n = int(_lib.lib().mpb_gpmp2_workspace_bytes(B, H, D))
+    if n == 0:
+        raise ValueError(f'unsupported GPMP2 shape B={B} H={H} D={D}')
+    return torch.empty(n, dtype=torch.uint8, device=device)
+
+
+def gpmp2_step(x, start, goal, geom, workspace, sigmas, dt, delta, trust_region, step_size, n_iters=1, costs_out=None):
+    """n_iters Gauss-Newton iterations on one GPU.  sigmas = (start, gp, goal, coll)."""
+    B, H, dim = x.shape
+    D = dim // 2
+    _chk(x, (B, H, dim), 'x')
+    _chk(start, (B, dim), 'start')
+    _chk(goal, (B, dim), 'goal')
+    _chk(costs_out, (B,), 'costs_out', allow_none=True)
+    assert workspace.numel() >= _lib.lib().mpb_gpmp2_workspace_bytes(B, H, D)
+    _lib.check(_lib.lib().mpb_gpmp2_step(
+        _ptr(x), _ptr(start), _ptr(goal), _ptr(geom.buf), _ptr(workspace), _ptr(costs_out), B, H, D, float(dt),
+        float(sigmas[0]), float(sigmas[1]), float(sigmas[2]), float(sigmas[3]), float(delta), int(bool(trust_region)),
+        float(step_size), int(n_iters), _stream()), 'mpb_gpmp2_step')
+
+
+def gpmp2_linearize(x, geom, workspace):
+    B, H, dim = x.shape
+    _chk(x, (B, H, dim), 'x')
+    _lib.check(_lib.lib().mpb_gpmp2_linearize(_ptr(x), _ptr(geom.buf), _ptr(workspace), B, H, dim // 2, _stream()),
+               'mpb_gpmp2_linearize')
+
+
+def gpmp2_diag(workspace, B, H, D, sigmas, dt):
+    """Local SUM over particles of diag(A^T K A) as an (H*2D,) fp64 tensor."""
+    out = torch.empty(H * 2 * D, dtype=torch.float64, device=workspace.device)
+    _lib.check(_lib.lib().mpb_gpmp2_diag(_ptr(workspace), _ptr(out), B, H, D, float(dt), float(sigmas[0]),
+                                        float(sigmas[1]), float(sigmas[2]), float(sigmas[3]), _stream()), 'mpb_gpmp2_diag')
+    return out
+
+
+def gpmp2_solve(x, start, goal, diag_mean, workspace, sigmas, dt, delta, trust_region, step_size, costs_out=None):
+    B, H, dim = x.shape
+    _chk(x, (B, H, dim), 'x')
+    _chk(start, (B, dim), 'start')
+    _chk(goal, (B, dim), 'goal')
+    if diag_mean is not None:
+        assert diag_mean.dtype == torch.float64 and diag_mean.is_cuda and diag_mean.numel() == H * dim
+    _lib.check(_lib.lib().mpb_gpmp2_solve(
+        _ptr(x), _ptr(start), _ptr(goal), _ptr(diag_mean), _ptr(workspace), _ptr(costs_out), B, H, dim // 2, float(dt),
+        float(sigmas[0]), float(sigmas[1]), float(sigmas[2]), float(sigmas[3]), float(delta), int(bool(trust_region)),
+        float(step_size), _stream()), 'mpb_gpmp2_solve')
+
+
+def mppi_step(mean, eps, scale_tril, cov_inv, state0, goal, ctrl_min, ctrl_max, discount, c_weights, geom, controls,
+              states, costs, weights, dt, k_sigma=0.0, weight=1.0, temp=1.0, step_size=1.0, n_iters=1, seed=0, iter0=0):
+    NP, T, c = mean.shape
+    S = controls.shape[1]
+    _chk(mean, (NP, T, c), 'mean')
+    if eps is not None:
+        _chk(eps, (n_iters, NP, c, S, T), 'eps')
+    _chk(scale_tril, (c, T, T), 'scale_tril')
+    _chk(cov_inv, (c, T, T), 'cov_inv')
+    _chk(state0, (NP, c), 'state0')
+    _chk(goal, (NP, c), 'goal')
+    _chk(ctrl_min, (c,), 'ctrl_min')
+    _chk(ctrl_max, (c,), 'ctrl_max')
+    _chk(discount, (T,), 'discount')
+    _chk(c_weights, (4,), 'c_weights')
+    _chk(controls, (NP, S, T, c), 'controls')
+    _chk(states, (NP, S, T, c), 'states')
+    _chk(costs, (NP, S), 'costs')
+    _chk(weights, (NP, S), 'weights')
+    _lib.check(_lib.lib().mpb_mppi_step(
+        _ptr(mean), _ptr(eps), _ptr(scale_tril), _ptr(cov_inv), _ptr(state0), _ptr(goal), _ptr(ctrl_min), _ptr(ctrl_max),
+        _ptr(discount), _ptr(c_weights), _ptr(None if geom is None else geom.buf), _ptr(controls), _ptr(states),
+        _ptr(costs), _ptr(weights), NP, S, T, c, 0, float(dt), float(k_sigma), float(weight), float(temp),
+        float(step_size), int(n_iters), int(seed) & (2 ** 64 - 1), int(iter0), _stream()), 'mpb_mppi_step')

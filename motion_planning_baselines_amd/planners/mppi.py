@@ -1,0 +1,170 @@
+"""MPPI with the reference's class surface (mp_baselines/planners/mppi.py); iterations on the GPU.
+
+Host side: the per-control-dimension covariance priors (priors/gaussian.py:143-198), their Cholesky
+factors and inverses, computed with the same torch calls as the reference.  Device side:
+mpb_mppi_step (csrc/mpb_mppi.hip) runs sampling, rollout, cost, importance term, softmax and mean update.
+"""
+import numpy as np
+import torch
+
+from .. import ops
+from .base import MPPlanner, require_cuda
+from .costs.cost_functions import fusable_collision
+
+
+def diag_Cov(sigma, length, ctrl_dim, tensor_args):
+    """Time-independent diagonal covariance (gaussian.py:143-163); (T,T,c)."""
+    Cov = torch.eye(length, **tensor_args).unsqueeze(-1).repeat(1, 1, ctrl_dim)
+    if isinstance(sigma, (list, tuple)):
+        return Cov * torch.Tensor(np.array(sigma)).to(**tensor_args) ** 2
+    return Cov * sigma ** 2
+
+
+def const_ctrl_Cov(sigma, length, ctrl_dim, tensor_args):
+    """Constant-control covariance prior (gaussian.py:166-198); (T,T,c)."""
+    if isinstance(sigma, (list, tuple)):
+        sigma = torch.from_numpy(np.array(sigma)).to(**tensor_args)
+    L = torch.tril(torch.ones(length, length - 1, **tensor_args), diagonal=-1)
+    LL_t = torch.matmul(L, L.transpose(0, 1)) + torch.ones(length, length, **tensor_args)
+    return LL_t.unsqueeze(-1).repeat(1, 1, ctrl_dim) * sigma ** 2
+
+
+class PointParticleDynamics:
+    """Parameters of the reference's point-particle system (dynamics/point.py:5-74); the dynamics and
+    trajectory cost themselves run inside the MPPI kernel."""
+
+    def __init__(self, rollout_steps=None, control_dim=2, state_dim=2, dt=0.01, discount=1.0, goal_state=None,
+                 ctrl_min=None, ctrl_max=None, control_type='velocity', c_weights=None, tensor_args=None, **kwargs):
+        if control_type != 'velocity':
+            raise IOError('only control_type "velocity" is served (the reference\'s acceleration mode cannot run)')
+        self.control_dim = control_dim
+        self.state_dim = state_dim
+        self.dt = dt
+        self.rollout_steps = rollout_steps
+        self.tensor_args = tensor_args
+        self._c_weights = c_weights or {'pos': 10., 'vel': 10., 'ctrl': 0., 'pos_T': 10., 'vel_T': 0.}
+        assert len(ctrl_min) == control_dim and len(ctrl_max) == control_dim
+        self.ctrl_min, self.ctrl_max = list(ctrl_min), list(ctrl_max)
+        self.goal_state = goal_state
+        seq = torch.cumprod(torch.ones(rollout_steps) * discount, dim=0) / discount   # point.py:145-152
+        self.discount_seq = seq
+
+
+class MPPI(MPPlanner):
+    """Drop-in for mp_baselines.planners.mppi.MPPI (ctor kwargs mppi.py:8-21).
+
+    ``optimize(state=..., goal_state=..., cost=...)`` as in the reference (mppi.py:136-162).  Extra kwargs:
+    noise 'philox' | 'torch_cpu' | 'torch' and seed, as for STOMP.
+    """
+
+    def __init__(self, system, num_ctrl_samples, rollout_steps, opt_iters, control_std=None, initial_mean=None,
+                 step_size=1., temp=1., cov_prior_type='indep_ctrl', tensor_args=None, noise='philox', seed=0,
+                 **kwargs):
+        super().__init__(name='MPPI', tensor_args=tensor_args)
+        self.device = require_cuda(tensor_args)
+        assert cov_prior_type in ('indep_ctrl', 'const_ctrl')
+        self.system = system
+        self.state_dim = system.state_dim
+        self.control_dim = system.control_dim
+        self.rollout_steps = rollout_steps
+        self.num_ctrl_samples = num_ctrl_samples
+        self.opt_iters = opt_iters
+        self.step_size = step_size
+        self.temp = temp
+        self.control_std = control_std
+        self.cov_prior_type = cov_prior_type
+        self.noise = noise
+        self.seed = int(seed)
+        self._iter = 0
+        cpu = dict(device='cpu', dtype=torch.float32)
+        gen = const_ctrl_Cov if cov_prior_type == 'const_ctrl' else diag_Cov
+        Cov = gen(control_std, rollout_steps, self.control_dim, cpu)
+        self.Cov = Cov.to(self.device)
+        # MultivariateNormal(covariance_matrix=C).scale_tril == cholesky(C); Cov_inv as mppi.py:49-52
+        self._scale_tril = torch.stack([torch.linalg.cholesky(Cov[..., i]) for i in range(self.control_dim)]).to(self.device).contiguous()
+        self.Cov_inv = torch.stack([Cov[..., i].inverse() for i in range(self.control_dim)]).to(self.device).contiguous()
+        T, c, S = rollout_steps, self.control_dim, num_ctrl_samples
+        f = lambda a: torch.as_tensor(a, dtype=torch.float32).to(self.device).contiguous()
+        self._cmin, self._cmax = f(system.ctrl_min), f(system.ctrl_max)
+        self._disc = f(system.discount_seq)
+        cw = system._c_weights
+        self._cw = f([cw['pos'], cw['vel'], cw['ctrl'], cw['pos_T']])
+        self._controls = torch.empty(1, S, T, c, device=self.device)
+        self._states = torch.empty(1, S, T, c, device=self.device)
+        self._costs = torch.empty(1, S, device=self.device)
+        self._weights = torch.empty(1, S, device=self.device)
+        self.best_cost = torch.inf
+        self.weights = None
+        self.reset(initial_mean=initial_mean)
+
+    def reset(self, initial_mean=None):
+        T, c = self.rollout_steps, self.control_dim
+        if initial_mean is not None:
+            self._mean = initial_mean.clone().to(device=self.device, dtype=torch.float32).reshape(T, c).contiguous()
+        else:
+            self._mean = torch.zeros(T, c, device=self.device, dtype=torch.float32)
+
+    def _draw_eps(self, n_iters):
+        if self.noise == 'philox':
+            return None
+        S, T, c = self.num_ctrl_samples, self.rollout_steps, self.control_dim
+        dev = 'cpu' if self.noise == 'torch_cpu' else self.device
+        # the reference draws one (S,T) block per control dimension per iteration (gaussian.py:291-297)
+        blocks = [torch.stack([torch.empty(S, T, device=dev).normal_() for _ in range(c)]) for _ in range(n_iters)]
+        return torch.stack(blocks).reshape(n_iters, 1, c, S, T).to(self.device).contiguous()
+
+    def optimize(self, opt_iters=None, **observation):
+        if opt_iters is None:
+            opt_iters = self.opt_iters
+        c = self.control_dim
+        state = observation['state'].to(device=self.device, dtype=torch.float32).reshape(1, c).contiguous()
+        goal = observation.get('goal_state', self.system.goal_state)
+        goal = goal.to(device=self.device, dtype=torch.float32)[..., :c].reshape(1, c).contiguous()
+        cost = observation.get('cost', None)
+        geom, k_sigma, weight = None, 0.0, 1.0
+        if cost is not None:
+            fused = fusable_collision(cost)
+            if fused is None:
+                raise NotImplementedError('MPPI fuses a single collision cost; other cost objects are not wired in')
+            cc, weight = fused
+            geom, k_sigma = cc.device_geometry(self.device), cc.k_sigma
+        mean = self._mean.reshape(1, self.rollout_steps, c)
+        ops.mppi_step(mean, self._draw_eps(opt_iters), self._scale_tril, self.Cov_inv, state, goal, self._cmin,
+                      self._cmax, self._disc, self._cw, geom, self._controls, self._states, self._costs, self._weights,
+                      self.system.dt, k_sigma=k_sigma, weight=weight, temp=self.temp, step_size=self.step_size,
+                      n_iters=opt_iters, seed=self.seed, iter0=self._iter)
+        self._iter += opt_iters
+        self.costs = self._costs.reshape(-1, 1)
+        self.weights = self._weights.reshape(-1, 1)
+        self.state_trajectories = self._states[0]
+        self._save_best()
+        self._recent_control_samples = self._controls[0]
+        self._recent_state_trajectories = self._states[0]
+        self._recent_weights = self.weights
+        return self._controls[0], self._states[0], self.costs
+
+    def _save_best(self):
+        best_cost = torch.min(self.costs)
+        if best_cost < self.best_cost:
+            self.best_cost = best_cost
+            self.best_traj = self.state_trajectories[torch.argmin(self.costs)].clone()
+
+    def pop(self):
+        action = self._mean[0, :].clone().detach()
+        self.shift()
+        return action
+
+    def shift(self):
+        """mppi.py:176-178 -- quirk Q7: the roll is along the control axis, reproduced as is."""
+        self._mean = self._mean.roll(shifts=-1, dims=-1).contiguous()
+        self._mean[-1:] = 0.
+
+    def get_recent_samples(self):
+        return (self._recent_control_samples.detach().clone(), self._recent_state_trajectories.detach().clone(),
+                self._recent_weights.detach().clone())
+
+    def get_mean_controls(self):
+        return self._mean
+
+    def render(self, ax, **kwargs):
+        raise NotImplementedError

@@ -1,0 +1,175 @@
+"""GPU: the drop-in planner classes (reference ctor kwargs / optimize / reset / attributes) against the
+goldens produced by the reference classes with the same torch seed."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, product_geometry_from_golden
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def rel_err(a, b):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def make_cost(g, dev, weight=None):
+    from motion_planning_baselines_amd.planners.costs.cost_functions import CostCollision, CostComposite
+    robot, field = product_geometry_from_golden(g)
+    ta = dict(device=dev, dtype=torch.float32)
+    H = int(g['H']) if 'H' in g else int(g['T'])
+    cc = CostCollision(robot, H, field=field, sigma_coll=float(g['sigma_coll']) if 'sigma_coll' in g else 1e-3, tensor_args=ta)
+    return CostComposite(robot, H, [cc], weights_cost_l=None if weight is None else [weight], tensor_args=ta), robot, field
+
+
+@pytest.mark.parametrize('name', ['stomp_pm2d_c1', 'stomp_panda_t1', 'stomp_pm2d_benign'])
+def test_stomp_class_same_seed_as_reference(gpu_device, name):
+    from motion_planning_baselines_amd.planners.stomp import STOMP
+    g = load_golden(name)
+    dev = gpu_device
+    cost, robot, _ = make_cost(g, dev)
+    torch.manual_seed(int(g['seed']))
+    pl = STOMP(n_dof=int(g['D']), n_support_points=int(g['H']), num_particles_per_goal=int(g['P']),
+               num_samples=int(g['S']), opt_iters=1, dt=float(g['dt']), start_state=T(g['start']).to(dev), cost=cost,
+               initial_particle_means=T(g['means0']).to(dev), multi_goal_states=T(g['goal']).unsqueeze(0).to(dev),
+               temperature=float(g['temperature']), step_size=float(g['lr']), sigma_spectral=float(g['sigma_spectral']),
+               pos_only=bool(g['pos_only']), tensor_args=dict(device=dev, dtype=torch.float32), noise='torch_cpu')
+    # R^-1 and the scale_tril of R are ill-conditioned fp32 LAPACK results: they are
+    # bit-identical to the reference's when computed on the same host (tests/test_host_logic.py, build
+    # container) but differ by ~1e-3 between CPU models / BLAS code paths.  The golden was produced on the
+    # build container's CPU, so its constants are injected here; the un-injected path is checked below at
+    # the constants' own cross-machine tolerance.
+    loose = rel_err(pl.Sigma, T(g['Sigma']))
+    pl.Sigma = T(g['Sigma']).to(dev).contiguous()
+    pl.scale_tril = T(g['L']).to(dev).contiguous()
+    n = g['eps'].shape[0]
+    for it in range(n):
+        traj = pl.optimize()                       # opt_iters=1, as the reference examples call it
+        assert traj.shape == tuple(g['traj'][it].shape)
+    torch.cuda.synchronize()
+    assert rel_err(pl.state_particles, T(g['samples'][-1])) < 1e-4
+    assert rel_err(pl._particle_means, T(g['means'][-1])) < 1e-4
+    assert loose < 1e-2, loose
+    assert pl._weights.shape == (int(g['P']), int(g['S']), 1, 1)
+    assert pl.costs.shape == (int(g['P']), int(g['S']))
+    # same thing in one call (opt_iters=n) from a fresh planner
+    torch.manual_seed(int(g['seed']))
+    pl2 = STOMP(n_dof=int(g['D']), n_support_points=int(g['H']), num_particles_per_goal=int(g['P']),
+                num_samples=int(g['S']), opt_iters=n, dt=float(g['dt']), start_state=T(g['start']).to(dev), cost=cost,
+                initial_particle_means=T(g['means0']).to(dev), multi_goal_states=T(g['goal']).unsqueeze(0).to(dev),
+                temperature=float(g['temperature']), step_size=float(g['lr']), sigma_spectral=float(g['sigma_spectral']),
+                pos_only=bool(g['pos_only']), tensor_args=dict(device=dev, dtype=torch.float32), noise='torch_cpu')
+    pl2.Sigma, pl2.scale_tril = pl.Sigma, pl.scale_tril
+    pl2.optimize()
+    assert torch.equal(pl2._particle_means, pl._particle_means)
+
+
+def test_stomp_user_cost_callable_matches_fused(gpu_device):
+    """A caller-supplied cost callable (any Python on device tensors) takes the sample / update split path."""
+    from motion_planning_baselines_amd.planners.stomp import STOMP
+    g = load_golden('stomp_panda_t1')
+    dev = gpu_device
+    cost, _, _ = make_cost(g, dev)
+    kw = dict(n_dof=int(g['D']), n_support_points=int(g['H']), num_particles_per_goal=int(g['P']),
+              num_samples=int(g['S']), opt_iters=3, dt=float(g['dt']), start_state=T(g['start']).to(dev),
+              initial_particle_means=T(g['means0']).to(dev), temperature=1.0, step_size=0.1, sigma_spectral=0.5,
+              pos_only=False, tensor_args=dict(device=dev, dtype=torch.float32), noise='philox', seed=7)
+    a = STOMP(cost=cost, **kw)
+    b = STOMP(cost=lambda trajs, **obs: cost(trajs), **kw)
+    a.optimize()
+    b.optimize()
+    torch.cuda.synchronize()
+    assert torch.equal(a._particle_means, b._particle_means)
+    assert torch.equal(a.costs, b.costs)
+
+
+def test_stomp_philox_reduces_cost(gpu_device):
+    """Device-noise STOMP on straight lines that DO collide: the collision cost of the means must drop."""
+    from motion_planning_baselines_amd import workloads
+    from motion_planning_baselines_amd.planners.costs.cost_functions import CostCollision, CostComposite
+    from motion_planning_baselines_amd.planners.stomp import STOMP
+    dev = gpu_device
+    wl = workloads.panda_spheres_stomp(32, dev, S=32, pos_only=True)
+    ta = dict(device=dev, dtype=torch.float32)
+    cost = CostComposite(wl['robot'], 64, [CostCollision(wl['robot'], 64, field=wl['field'], sigma_coll=1.0, tensor_args=ta)],
+                         tensor_args=ta)
+    prm = dict(wl['params'])
+    prm.update(sigma_spectral=1.0, temperature=0.5)
+    pl = STOMP(opt_iters=1, start_state=torch.from_numpy(wl['starts'][0]).to(dev), cost=cost,
+               initial_particle_means=wl['means0'], tensor_args=ta, **prm)
+    c0 = cost(pl._particle_means).clone()
+    assert float(c0.sum()) > 0, 'workload must start in collision somewhere'
+    pl.optimize(opt_iters=40)
+    c1 = cost(pl._particle_means)
+    torch.cuda.synchronize()
+    assert torch.isfinite(pl._particle_means).all()
+    print('collision cost of the means', float(c0.sum()), '->', float(c1.sum()))
+    assert float(c1.sum()) < 0.7 * float(c0.sum())
+
+
+@pytest.mark.parametrize('name', ['chomp_pm2d_soft', 'chomp_panda'])
+def test_chomp_class(gpu_device, name):
+    from motion_planning_baselines_amd.planners.chomp import CHOMP
+    g = load_golden(name)
+    dev = gpu_device
+    cost, _, _ = make_cost(g, dev, weight=float(g['weight']))
+    B = int(g['B'])
+    pl = CHOMP(n_dof=int(g['D']), n_support_points=int(g['H']), num_particles_per_goal=B, opt_iters=1,
+               dt=float(g['dt']), start_state=T(g['means0'][0, 0, :int(g['D'])]).to(dev), cost=cost,
+               weight_prior_cost=float(g['w_prior']), initial_particle_means=T(g['means0']).to(dev),
+               step_size=float(g['lr']), grad_clip=float(g['clip']), pos_only=bool(g['pos_only']),
+               tensor_args=dict(device=dev, dtype=torch.float32))
+    for it in range(g['means'].shape[0]):
+        traj = pl.optimize()
+        assert rel_err(traj, T(g['traj'][it])) < 1e-4, it
+
+
+@pytest.mark.parametrize('name', ['gpmp2_pm2d_h8_f64', 'gpmp2_panda_h16_f64'])
+def test_gpmp2_class(gpu_device, name):
+    from motion_planning_baselines_amd.planners.gpmp2 import GPMP2
+    g = load_golden(name)
+    dev = gpu_device
+    robot, field = product_geometry_from_golden(g)
+    B, H, D = int(g['B']), int(g['H']), int(g['D'])
+    pl = GPMP2(robot=robot, n_dof=D, n_support_points=H, num_particles_per_goal=B, opt_iters=1, dt=float(g['dt']),
+               start_state=T(g['start']).float().to(dev), step_size=float(g['step_size']),
+               multi_goal_states=T(g['goal']).float().unsqueeze(0).to(dev),
+               initial_particle_means=T(g['means0']).float().unsqueeze(0).to(dev),
+               solver_params=dict(delta=float(g['delta']), trust_region=bool(g['trust_region']), method='cholesky'),
+               collision_fields=[field], sigma_start=float(g['sigma_start']), sigma_gp=float(g['sigma_gp']),
+               sigma_coll=float(g['sigma_coll']), sigma_goal_prior=float(g['sigma_goal_prior']),
+               tensor_args=dict(device=dev, dtype=torch.float32))
+    for it in range(g['means'].shape[0]):
+        traj = pl.optimize(opt_iters=1)
+        print(name, it, rel_err(traj, T(g['means'][it])))
+        assert rel_err(traj, T(g['means'][it])) < 1e-4
+        np.testing.assert_allclose(pl.costs.cpu().numpy(), g['costs'][it], rtol=5e-3)
+
+
+@pytest.mark.parametrize('name', ['mppi_pm2d_const', 'mppi_pm2d_indep_cost'])
+def test_mppi_class_same_seed_as_reference(gpu_device, name):
+    from motion_planning_baselines_amd.planners.mppi import MPPI, PointParticleDynamics
+    g = load_golden(name)
+    dev = gpu_device
+    ta = dict(device=dev, dtype=torch.float32)
+    S, Tn = int(g['S']), int(g['T'])
+    system = PointParticleDynamics(rollout_steps=Tn, control_dim=2, state_dim=2, dt=float(g['dt']), discount=1.,
+                                   goal_state=T(g['goal']).to(dev), ctrl_min=[-100, -100], ctrl_max=[100, 100],
+                                   c_weights={'pos': float(g['c_pos']), 'vel': float(g['c_vel']), 'ctrl': float(g['c_ctrl']),
+                                              'pos_T': float(g['c_pos_T']), 'vel_T': 0.}, tensor_args=ta)
+    torch.manual_seed(0 if name == 'mppi_pm2d_const' else 1)
+    pl = MPPI(system, num_ctrl_samples=S, rollout_steps=Tn, opt_iters=1, control_std=[float(v) for v in g['control_std']],
+              temp=float(g['temp']), step_size=float(g['step_size']), cov_prior_type=str(g['cov_type']), tensor_args=ta,
+              noise='torch_cpu')
+    assert rel_err(pl.Cov, T(g['Cov'])) == 0.0
+    obs = dict(state=T(g['start']).to(dev), goal_state=T(g['goal']).to(dev))
+    if bool(g['with_cost']):
+        obs['cost'], _, _ = make_cost(g, dev)
+    for it in range(g['eps'].shape[0]):
+        U, X, c = pl.optimize(**obs)
+        assert U.shape == (S, Tn, 2) and X.shape == (S, Tn, 2) and c.shape == (S, 1)
+        np.testing.assert_allclose(c.cpu().numpy(), g['costs'][it], rtol=5e-5)
+        assert rel_err(pl.get_mean_controls(), T(g['mean'][it])) < 1e-3, it
