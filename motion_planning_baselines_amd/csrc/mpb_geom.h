@@ -21,8 +21,12 @@
 #include <type_traits>
 
 #define MPB_GEOM_MAGIC 0x4D504247
-#define MPB_GEOM_VERSION 2
-#define MPB_GEOM_HEADER_WORDS 16
+#define MPB_GEOM_VERSION 3
+#define MPB_GEOM_HEADER_WORDS 32
+#define MPB_GRID_MAX_CELLS 4096
+#define MPB_GRID_MAX_SPH 63      // obstacle table in LDS: 63 spheres + one far-away dummy
+#define MPB_GRID_EMPTY 0xFFFFFFFFu
+#define MPB_GRID_OVERFLOW 0xFFFFFFFEu
 #define MPB_KIND_POINT 0
 #define MPB_KIND_CHAIN 1
 #define MPB_MAX_DOF 8
@@ -47,6 +51,10 @@ struct GeomView {
     const float* box;    // n_box x 8: cx,cy,cz,0,hx,hy,hz,0
     const float* cull;   // ceil4(n_sph) x 8: -2cx,-2cy,-2cz,rhs, cx,cy,cz,r
     const int* fstart;   // links [fstart[j], fstart[j+1]) ride on frame j+1
+    // broad-phase grid over the inflated obstacle spheres (n_cells == 0: none)
+    const unsigned* grid;
+    int gnx, gny, gnz, n_cells;
+    float glx, gly, glz, gix, giy, giz;  // origin, 1 / cell size
 };
 
 __device__ __forceinline__ GeomView geom_view(const float* __restrict__ g) {
@@ -65,6 +73,11 @@ __device__ __forceinline__ GeomView geom_view(const float* __restrict__ g) {
     v.box = g + gi[12];
     v.cull = g + gi[14];
     v.fstart = gi + gi[15];
+    v.grid = reinterpret_cast<const unsigned*>(g) + gi[16];
+    v.gnx = gi[17]; v.gny = gi[18]; v.gnz = gi[19];
+    v.glx = g[20]; v.gly = g[21]; v.glz = g[22];
+    v.gix = g[23]; v.giy = g[24]; v.giz = g[25];
+    v.n_cells = gi[26];
     return v;
 }
 
@@ -358,6 +371,91 @@ __device__ __forceinline__ float waypoint_cost(const GeomView& G, const float (&
                     }
                 }
             }
+        }
+    }
+    return cost;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Broad-phase variant of the cost-only path.  The wave-level conservative test above cannot skip work
+// when the 64 waypoints of a trajectory are spread over the workspace (wide STOMP noise): some lane is
+// always near every obstacle.  A uniform grid culls PER LANE: each collision sphere looks up the cell
+// that contains it (one LDS word: up to four obstacle indices, host-built in fp64, conservative) and
+// evaluates exact distances only to those candidates; the wave iterates max-over-lanes(candidates)
+// times (typically 1-3 instead of n_sph).  The minimum over the candidates equals the minimum over
+// all obstacles whenever the hinge is active, so the cost is bit-identical to the exhaustive loop.
+//   gridw : n_cells words in LDS;  otab : (cx,cy,cz,r) of the n_sph spheres + a far dummy at n_sph, in LDS.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool grid_usable(const GeomView& G) {
+    return G.n_cells > 0 && G.n_cells <= MPB_GRID_MAX_CELLS && G.n_sph <= MPB_GRID_MAX_SPH;
+}
+
+// cooperative staging by `nthreads` threads (caller synchronises before and after)
+__device__ __forceinline__ void grid_stage(const GeomView& G, unsigned* gridw, float4* otab, int tid, int nthreads) {
+    for (int i = tid; i < G.n_cells; i += nthreads) gridw[i] = G.grid[i];
+    const float4* sp = reinterpret_cast<const float4*>(G.sph);
+    for (int i = tid; i <= G.n_sph; i += nthreads)
+        otab[i] = (i < G.n_sph) ? sp[i] : make_float4(-1.0e9f, -1.0e9f, -1.0e9f, 0.f);
+}
+
+__device__ __forceinline__ float sphere_hinge_grid(const GeomView& G, const unsigned* gridw, const float4* otab,
+                                                   float x, float y, float z, float rl) {
+    const float fx = (x - G.glx) * G.gix, fy = (y - G.gly) * G.giy, fz = (z - G.glz) * G.giz;
+    const int ix = (int)floorf(fx), iy = (int)floorf(fy), iz = (int)floorf(fz);
+    const bool inb = (unsigned)ix < (unsigned)G.gnx && (unsigned)iy < (unsigned)G.gny && (unsigned)iz < (unsigned)G.gnz;
+    const int cell = inb ? (iz * G.gny + iy) * G.gnx + ix : 0;
+    unsigned w = gridw[cell];
+    w = inb ? w : MPB_GRID_EMPTY;
+    float best = 3.0e38f;
+    if (__builtin_expect(__ballot(w == MPB_GRID_OVERFLOW) != 0ull, 0)) {
+        // some lane sits in a crowded cell: exhaustive exact loop for this sphere (rare)
+        for (int o = 0; o < G.n_sph; ++o) {
+            const float4 s = otab[o];
+            const float dx = x - s.x, dy = y - s.y, dz = z - s.z;
+            best = fminf(best, fast_sqrt(dx * dx + dy * dy + dz * dz) - s.w);
+        }
+    } else {
+        while (__ballot((w & 0xFFu) != 0xFFu) != 0ull) {
+            const unsigned idx = w & 0xFFu;
+            w = (w >> 8) | 0xFF000000u;
+            const float4 s = otab[idx == 0xFFu ? (unsigned)G.n_sph : idx];
+            const float dx = x - s.x, dy = y - s.y, dz = z - s.z;
+            best = fminf(best, fast_sqrt(dx * dx + dy * dy + dz * dz) - s.w);
+        }
+    }
+    // boxes are few: exhaustive
+    const float4* bp = reinterpret_cast<const float4*>(G.box);
+    for (int o = 0; o < G.n_box; ++o) {
+        const float4 c = bp[2 * o], h = bp[2 * o + 1];
+        const float px = x - c.x, py = y - c.y, pz = z - c.z;
+        const float ax = fabsf(px) - h.x, ay = fabsf(py) - h.y, az = fabsf(pz) - h.z;
+        const float qx = fmaxf(ax, 0.f), qy = fmaxf(ay, 0.f), qz = fmaxf(az, 0.f);
+        const float sd = fast_sqrt(qx * qx + qy * qy + qz * qz) + fminf(fmaxf(ax, fmaxf(ay, az)), 0.f);
+        best = fminf(best, sd);
+    }
+    return fmaxf(G.margin + rl - best, 0.f);
+}
+
+__device__ __forceinline__ float waypoint_cost_grid(const GeomView& G, const unsigned* gridw, const float4* otab,
+                                                    const float (&q)[MPB_MAX_DOF]) {
+    if (G.kind == MPB_KIND_POINT)
+        return sphere_hinge_grid(G, gridw, otab, q[0], q[1], (G.n_dof > 2) ? q[2] : 0.f, G.links[4]);
+    FKState<false> F;
+    F.r00 = 1.f; F.r01 = 0.f; F.r02 = 0.f; F.r10 = 0.f; F.r11 = 1.f; F.r12 = 0.f; F.r20 = 0.f; F.r21 = 0.f; F.r22 = 1.f;
+    F.tx = F.ty = F.tz = 0.f;
+    F.frame = 0;
+    float cost = 0.f;
+    for (int j = 0; j < G.n_tf; ++j) {
+        fk_advance<false>(G, F, q);
+        const int l_end = G.fstart[j + 1];
+        for (int l = G.fstart[j]; l < l_end; ++l) {
+            const float4 lk = *reinterpret_cast<const float4*>(G.links + 8 * l);  // frame, ox, oy, oz
+            const float rl = G.links[8 * l + 4];
+            const float x = F.tx + (F.r00 * lk.y + F.r01 * lk.z + F.r02 * lk.w);
+            const float y = F.ty + (F.r10 * lk.y + F.r11 * lk.z + F.r12 * lk.w);
+            const float z = F.tz + (F.r20 * lk.y + F.r21 * lk.z + F.r22 * lk.w);
+            cost += sphere_hinge_grid(G, gridw, otab, x, y, z, rl);
         }
     }
     return cost;

@@ -52,15 +52,26 @@ extern "C" int mpb_geom_check(const float* g, int n_words) {
     if (kind == MPB_KIND_CHAIN && n_tf != n_dof + 1) return fail(MPB_E_INVALID, "%s: chain needs n_dof+1 transforms", __func__);
     if (n_links < 1 || n_sph < 0 || n_box < 0 || n_sph + n_box < 1) return fail(MPB_E_INVALID, "%s: empty link/obstacle set", __func__);
     const int off_tf = gi[9], off_links = gi[10], off_sph = gi[11], off_box = gi[12], total = gi[13];
-    const int off_cull = gi[14], off_fs = gi[15];
+    const int off_cull = gi[14], off_fs = gi[15], off_grid = gi[16];
+    const int gnx = gi[17], gny = gi[18], gnz = gi[19], n_cells = gi[26];
     const int n_sph_pad = (n_sph + 3) / 4 * 4;
     const int n_frames = n_tf > 1 ? n_tf : 1;
     const int n_fs = (n_frames + 1 + 3) / 4 * 4;
     if (off_tf != MPB_GEOM_HEADER_WORDS || off_links != off_tf + 12 * n_tf || off_sph != off_links + 8 * n_links ||
         off_box != off_sph + 4 * n_sph || off_cull != off_box + 8 * n_box || off_fs != off_cull + 8 * n_sph_pad ||
-        total != off_fs + n_fs || total > n_words)
+        off_grid != off_fs + n_fs || total != off_grid + (n_cells + 3) / 4 * 4 || total > n_words)
         return fail(MPB_E_INVALID, "%s: inconsistent section offsets", __func__);
-    if ((off_links | off_sph | off_box | off_cull | off_fs) & 3) return fail(MPB_E_INVALID, "%s: sections must be 16-byte aligned", __func__);
+    if ((off_links | off_sph | off_box | off_cull | off_fs | off_grid) & 3) return fail(MPB_E_INVALID, "%s: sections must be 16-byte aligned", __func__);
+    if (n_cells < 0 || (n_cells > 0 && (gnx < 1 || gny < 1 || gnz < 1 || gnx * gny * gnz != n_cells)))
+        return fail(MPB_E_INVALID, "%s: bad broad-phase grid dims", __func__);
+    for (int i = 0; i < n_cells; ++i) {   // every packed obstacle index must exist
+        const uint32_t w = (uint32_t)gi[off_grid + i];
+        if (w == 0xFFFFFFFEu) continue;
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t idx = (w >> (8 * k)) & 0xFFu;
+            if (idx != 0xFFu && (int)idx >= n_sph) return fail(MPB_E_INVALID, "%s: grid cell references a missing obstacle", __func__);
+        }
+    }
     // frame -> link ranges must be monotone and end at n_links
     for (int j = 0; j < n_frames; ++j)
         if (gi[off_fs + j] < 0 || gi[off_fs + j] > gi[off_fs + j + 1] || gi[off_fs + j + 1] > n_links)
@@ -196,6 +207,7 @@ __global__ __launch_bounds__(256, 4) void stomp_sample_cost_h64_kernel(
     constexpr int H = 64;
     __shared__ __attribute__((aligned(16))) float Lp[H * H];             // permuted L, 16 KB
     __shared__ __attribute__((aligned(16))) float Nt[4][H * NT_STRIDE];  // per-wave noise tile, 4 x 5 KB
+    __shared__ float4 otab[MPB_GRID_MAX_SPH + 1];                        // obstacle table of the broad phase
     // Lp[(((m*4 + ks4)*4 + g)*16 + i)*4 + kk] = L[16m+i][4*(4*ks4+kk) + g]
     for (int idx = threadIdx.x; idx < H * H; idx += 256) {
         const int kk = idx & 3, i = (idx >> 2) & 15, g = (idx >> 6) & 3, ks4 = (idx >> 8) & 3, m = idx >> 10;
@@ -264,7 +276,6 @@ __global__ __launch_bounds__(256, 4) void stomp_sample_cost_h64_kernel(
             nz[4 * v + 0] = t[0]; nz[4 * v + 1] = t[1]; nz[4 * v + 2] = t[2]; nz[4 * v + 3] = t[3];
         }
     }
-    if (!live) return;
     const bool edge = (h == 0) || (h == H - 1);
     const float* mrow = means + ((size_t)p * H + h) * DCH;
     float* srow = samples + (((size_t)p * S + s) * H + h) * DCH;
@@ -276,14 +287,14 @@ __global__ __launch_bounds__(256, 4) void stomp_sample_cost_h64_kernel(
             x[c] = mv.x + (edge ? 0.f : nz[c]);
             x[c + 1] = mv.y + (edge ? 0.f : nz[c + 1]);
 #ifndef MPB_EXP_NOSTORE
-            *reinterpret_cast<float2*>(srow + c) = make_float2(x[c], x[c + 1]);
+            if (live) *reinterpret_cast<float2*>(srow + c) = make_float2(x[c], x[c + 1]);
 #endif
         }
     } else {
 #pragma unroll
         for (int c = 0; c < DCH; ++c) {
             x[c] = mrow[c] + (edge ? 0.f : nz[c]);
-            srow[c] = x[c];
+            if (live) srow[c] = x[c];
         }
     }
     if (WITH_COST) {
@@ -292,9 +303,19 @@ __global__ __launch_bounds__(256, 4) void stomp_sample_cost_h64_kernel(
 #pragma unroll
         for (int i = 0; i < MPB_MAX_DOF; ++i) q[i] = (i < DCH) ? x[i < DCH ? i : 0] : 0.f;
         float c = 0.f;
-        if (h >= 1) c = waypoint_cost<false>(G, q, dq);
+        if (grid_usable(G)) {
+            // the permuted-L image is dead: its 16 KB now hold the broad-phase grid (all waves of the block
+            // take this branch together: G is wave- and block-uniform)
+            unsigned* gridw = reinterpret_cast<unsigned*>(Lp);
+            __syncthreads();
+            grid_stage(G, gridw, otab, threadIdx.x, 256);
+            __syncthreads();
+            if (live && h >= 1) c = waypoint_cost_grid(G, gridw, otab, q);
+        } else if (live && h >= 1) {
+            c = waypoint_cost<false>(G, q, dq);
+        }
         const double csum = wave_sum_f64((double)c);
-        if (lane == 0) costs[r] = weight * (k_sigma * (float)csum);
+        if (live && lane == 0) costs[r] = weight * (k_sigma * (float)csum);
     }
 }
 
@@ -390,9 +411,16 @@ __global__ __launch_bounds__(256) void collision_cost_kernel(
     float weight) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (b >= B) return;
     const GeomView G = geom_view(geom);
     const int D = G.n_dof;
+    __shared__ unsigned gridw[GRAD ? 1 : MPB_GRID_MAX_CELLS];
+    __shared__ float4 otab[GRAD ? 1 : MPB_GRID_MAX_SPH + 1];
+    const bool use_grid = !GRAD && grid_usable(G);
+    if (use_grid) {
+        grid_stage(G, gridw, otab, threadIdx.x, blockDim.x);
+        __syncthreads();
+    }
+    if (b >= B) return;
     double csum = 0.0;
     for (int h = lane; h < ((H + 63) & ~63); h += 64) {
         float c = 0.f;
@@ -401,7 +429,7 @@ __global__ __launch_bounds__(256) void collision_cost_kernel(
             float q[MPB_MAX_DOF], dq[MPB_MAX_DOF];
 #pragma unroll
             for (int i = 0; i < MPB_MAX_DOF; ++i) q[i] = (i < D) ? row[i] : 0.f;
-            if (h >= h_begin) c = waypoint_cost<GRAD>(G, q, dq);
+            if (h >= h_begin) c = use_grid ? waypoint_cost_grid(G, gridw, otab, q) : waypoint_cost<GRAD>(G, q, dq);
             if (per_wp) per_wp[(size_t)b * H + h] = c;
             if (GRAD) {
                 float* grow = grad + ((size_t)b * H + h) * d;

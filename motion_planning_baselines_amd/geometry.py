@@ -25,8 +25,12 @@ import math
 import numpy as np
 
 GEOM_MAGIC = 0x4D504247  # 'MPBG'
-GEOM_VERSION = 2
-GEOM_HEADER_WORDS = 16
+GEOM_VERSION = 3
+GEOM_HEADER_WORDS = 32
+GRID_MAX_DIM = 16       # cells per axis of the broad-phase grid (<= 4096 cells = 16 KB of LDS)
+GRID_CELL = 0.14        # target cell edge [m]
+GRID_EMPTY = 0xFFFFFFFF
+GRID_OVERFLOW = 0xFFFFFFFE  # more than 4 candidates in the cell: the kernel tests every obstacle
 KIND_POINT = 0
 KIND_CHAIN = 1
 MAX_DOF = 8
@@ -208,6 +212,51 @@ class CollisionField:
         pass
 
 
+def build_grid(spheres, a_max, slack=1e-4):
+    """Uniform broad-phase grid over the inflated obstacle spheres (host, fp64).  None when there are no
+    spheres or more than 254 of them (8-bit indices)."""
+    n = len(spheres)
+    if n == 0 or n > 254:
+        return None
+    c = spheres[:, :3].astype(np.float64)
+    R = spheres[:, 3].astype(np.float64) + a_max + slack      # a sphere at x can matter only if |x - c| < R
+    lo = (c - R[:, None]).min(0)
+    hi = (c + R[:, None]).max(0)
+    ext = np.maximum(hi - lo, 1e-6)
+    dims = np.clip(np.ceil(ext / GRID_CELL).astype(np.int64), 1, GRID_MAX_DIM)
+    for ax in range(3):   # planar problems: one layer of cells along a degenerate axis
+        if np.ptp(c[:, ax]) == 0.0:
+            dims[ax] = 1
+    cell = ext / dims
+    # the kernel computes floor((x - lo32) * inv32) in fp32: keep lo / inv exactly as stored, and add the
+    # worst-case fp32 index error (a point within 1e-5 of a cell face may land in the neighbour) to R
+    lo32 = lo.astype(np.float32)
+    inv32 = (1.0 / cell).astype(np.float32)
+    cell_eff = 1.0 / inv32.astype(np.float64)
+    Rg = R + 1e-5 + 1e-6 * np.abs(np.concatenate([lo, hi])).max()
+    words = np.full(int(dims.prod()), GRID_EMPTY, dtype=np.uint32)
+    ix = [np.arange(d) for d in dims]
+    X, Y, Z = np.meshgrid(ix[0], ix[1], ix[2], indexing='ij')
+    cmin = lo32.astype(np.float64) + np.stack([X, Y, Z], -1) * cell_eff          # (nx,ny,nz,3)
+    cmax = cmin + cell_eff
+    counts = np.zeros(dims, dtype=np.int64)
+    lists = np.full((*dims, 4), 0xFF, dtype=np.uint32)
+    for o in range(n):
+        d = np.maximum(np.maximum(cmin - c[o], c[o] - cmax), 0.0)
+        hit = (d * d).sum(-1) < Rg[o] ** 2
+        idx = np.nonzero(hit)
+        k = counts[idx]
+        ok = k < 4
+        sel = tuple(a[ok] for a in idx)
+        lists[sel + (k[ok],)] = o
+        counts[idx] += 1
+    w = lists[..., 0] | (lists[..., 1] << 8) | (lists[..., 2] << 16) | (lists[..., 3] << 24)
+    w = np.where(counts > 4, np.uint32(GRID_OVERFLOW), w.astype(np.uint32))
+    words = np.ascontiguousarray(w.transpose(2, 1, 0)).reshape(-1).astype(np.uint32)   # x fastest
+    return dict(dims=dims.astype(np.int32), lo=lo32, inv=inv32, words=words,
+                stats=dict(mean=float(counts.mean()), max=int(counts.max()), overflow=int((counts > 4).sum())))
+
+
 def pack_geometry(robot, field):
     """Pack robot + field into the flat fp32 word buffer the HIP kernels read.
 
@@ -215,6 +264,8 @@ def pack_geometry(robot, field):
       [0] magic [1] version [2] kind [3] n_dof [4] n_frames_tf (0 or n_dof+1) [5] n_links
       [6] n_spheres [7] n_boxes [8] margin(f32) [9] off_tf [10] off_links [11] off_spheres
       [12] off_boxes [13] total_words [14] off_cull [15] off_frame_start
+      [16] off_grid [17..19] grid dims nx,ny,nz [20..22] grid origin (f32) [23..25] 1/cell size (f32)
+      [26] n_cells (0: no grid) [27..31] reserved
       joint_tf    : n_frames_tf x 12   (row-major 3x4)
       links       : n_links x 8        (frame:int, ox, oy, oz, radius, 0, 0, 0)
       spheres     : n_spheres x 4      (cx, cy, cz, r)
@@ -224,6 +275,11 @@ def pack_geometry(robot, field):
                     (3 fma + 1 compare per pair; the exact distance is evaluated only when a lane passes).
                     Padding entries never pass (rhs = -1e30).
       frame_start : n_frames + 1 ints (padded to 4): links [fs[j], fs[j+1]) ride on frame j+1
+      grid        : nx*ny*nz uint32 words, x fastest.  Broad phase for the obstacle spheres: a word packs up
+                    to four 8-bit obstacle indices (0xFF = none) -- exactly the obstacles whose ball inflated
+                    by (margin + max_l r_l + slack) touches the cell; GRID_OVERFLOW when more than four do.
+                    A collision sphere at x can only be within its hinge threshold of the obstacles listed
+                    in the cell containing x (none outside the grid), so per-LANE culling is exact.
     """
     rs, fs = robot.spec(), field.spec()
     n_tf = rs['joint_tf'].shape[0]
@@ -238,12 +294,21 @@ def pack_geometry(robot, field):
     off_box = off_sph + 4 * n_sph
     off_cull = off_box + 8 * n_box
     off_fs = off_cull + 8 * n_sph_pad
-    total = off_fs + n_fs
+    off_grid = off_fs + n_fs
+    grid = build_grid(fs['spheres'], float(fs['margin']) + float(np.max(rs['link_radius'])))
+    n_cells = 0 if grid is None else int(grid['words'].size)
+    total = off_grid + (n_cells + 3) // 4 * 4
     buf = np.zeros((total,), dtype=np.float32)
     ibuf = buf.view(np.int32)
     ibuf[0:8] = [GEOM_MAGIC, GEOM_VERSION, rs['kind'], rs['n_dof'], n_tf, n_links, n_sph, n_box]
     buf[8] = fs['margin']
-    ibuf[9:16] = [off_tf, off_links, off_sph, off_box, total, off_cull, off_fs]
+    ibuf[9:17] = [off_tf, off_links, off_sph, off_box, total, off_cull, off_fs, off_grid]
+    if grid is not None:
+        ibuf[17:20] = grid['dims']
+        buf[20:23] = grid['lo']
+        buf[23:26] = grid['inv']
+        ibuf[26] = n_cells
+        buf.view(np.uint32)[off_grid:off_grid + n_cells] = grid['words']
     buf[off_tf:off_links] = rs['joint_tf'].astype(np.float32).reshape(-1)
     links = np.zeros((n_links, 8), np.float32)
     links.view(np.int32)[:, 0] = rs['link_frame'] if rs['kind'] == KIND_CHAIN else 1
@@ -282,7 +347,7 @@ def pack_geometry(robot, field):
         fstart[n_frames + 1:] = n_links
     else:
         fstart[0], fstart[1:] = 0, n_links
-    ibuf[off_fs:total] = fstart
+    ibuf[off_fs:off_grid] = fstart
     return buf
 
 
