@@ -37,11 +37,14 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     return v;
 }
 
-// Philox4x32-10 (Salmon et al. 2011), counter-based: no state, result depends only on (key, counter).
-__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
+// Philox4x32-R (Salmon et al., SC'11), counter-based: no state, result depends only on (key, counter).
+// R = 10 is the library default; R = 7 is the smallest round count the authors report as passing
+// BigCrush ("Crush-resistant") and is what the STOMP kernel uses (the generator is ~15 % of its VALU work).
+template <int ROUNDS>
+__device__ __forceinline__ uint4 philox4x32(uint4 ctr, uint2 key) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < ROUNDS; ++r) {
         const uint32_t hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
         const uint32_t hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
         ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
@@ -50,6 +53,7 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
     }
     return ctr;
 }
+__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) { return philox4x32<10>(ctr, key); }
 // two uniforms -> two standard normals (Box-Muller on the hardware log2 / sin / cos units)
 __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
     const float u1 = ((a >> 8) + 1u) * (1.0f / 16777216.0f);  // (0,1]

@@ -208,10 +208,17 @@ __global__ __launch_bounds__(256, 4) void stomp_sample_cost_h64_kernel(
     __shared__ __attribute__((aligned(16))) float Lp[H * H];             // permuted L, 16 KB
     __shared__ __attribute__((aligned(16))) float Nt[4][H * NT_STRIDE];  // per-wave noise tile, 4 x 5 KB
     __shared__ float4 otab[MPB_GRID_MAX_SPH + 1];                        // obstacle table of the broad phase
-    // Lp[(((m*4 + ks4)*4 + g)*16 + i)*4 + kk] = L[16m+i][4*(4*ks4+kk) + g]
-    for (int idx = threadIdx.x; idx < H * H; idx += 256) {
-        const int kk = idx & 3, i = (idx >> 2) & 15, g = (idx >> 6) & 3, ks4 = (idx >> 8) & 3, m = idx >> 10;
-        Lp[idx] = Lmat[(16 * m + i) * H + 4 * (4 * ks4 + kk) + g];
+    // Lp[(((m*4 + ks4)*4 + g)*16 + i)*4 + kk] = L[16m+i][4*(4*ks4+kk) + g]; coalesced float4 reads of L,
+    // scattered LDS writes
+    for (int v4 = threadIdx.x; v4 < H * H / 4; v4 += 256) {
+        const f32x4 lv = reinterpret_cast<const f32x4*>(Lmat)[v4];
+        const int row = v4 >> 4, col0 = (v4 & 15) << 2;
+        const int m = row >> 4, i = row & 15;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int col = col0 + e, ks = col >> 2, g = col & 3;
+            Lp[((((m * 4 + (ks >> 2)) * 4 + g) * 16 + i) << 2) + (ks & 3)] = lv[e];
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(256, 4) void stomp_sample_cost_h64_kernel(
 #else
             if (j < DCH) {
 #endif
-                const uint4 rr = philox4x32_10(
+                const uint4 rr = philox4x32<7>(
                     make_uint4(particle_offset + (uint32_t)p, (uint32_t)s, ((uint32_t)j << 16) | ((uint32_t)g << 8) | (uint32_t)q4, iter),
                     make_uint2(seed_lo, seed_hi));
                 box_muller(rr.x, rr.y, n0, n1);
@@ -286,17 +293,26 @@ __global__ __launch_bounds__(256, 4) void stomp_sample_cost_h64_kernel(
             const float2 mv = *reinterpret_cast<const float2*>(mrow + c);
             x[c] = mv.x + (edge ? 0.f : nz[c]);
             x[c + 1] = mv.y + (edge ? 0.f : nz[c + 1]);
-#ifndef MPB_EXP_NOSTORE
-            if (live) *reinterpret_cast<float2*>(srow + c) = make_float2(x[c], x[c + 1]);
-#endif
         }
     } else {
 #pragma unroll
-        for (int c = 0; c < DCH; ++c) {
-            x[c] = mrow[c] + (edge ? 0.f : nz[c]);
-            if (live) srow[c] = x[c];
+        for (int c = 0; c < DCH; ++c) x[c] = mrow[c] + (edge ? 0.f : nz[c]);
+    }
+    // sample tile out through LDS: the wave's (64 x DCH) tile is contiguous in HBM, so pack it in the
+    // (already consumed) noise tile and write 16-byte lanes, 1 KB per store instruction
+    {
+        float* pk = nt;
+#pragma unroll
+        for (int c = 0; c < DCH; ++c) pk[h * DCH + c] = x[c];
+        const f32x4* pk4 = reinterpret_cast<const f32x4*>(pk);
+        f32x4* out4 = reinterpret_cast<f32x4*>(samples + ((size_t)p * S + s) * H * DCH);
+#pragma unroll
+        for (int k = 0; k < (16 * DCH + 63) / 64; ++k) {
+            const int idx = lane + 64 * k;
+            if (idx < 16 * DCH && live) out4[idx] = pk4[idx];
         }
     }
+    (void)srow;
     if (WITH_COST) {
         const GeomView G = geom_view(geom);
         float q[MPB_MAX_DOF], dq[MPB_MAX_DOF];
@@ -397,6 +413,106 @@ __global__ __launch_bounds__(1024) void stomp_update_kernel(
         } else {
             for (int k = 0; k < H; ++k) acc = fmaf(lr * Sigma[h * H + k], delta[k * d + c], acc);
         }
+        means[(size_t)p * n + i] += acc;
+    }
+}
+
+// Vectorised variant of kernel B for H*d divisible by 4 and <= 1024: thread = (float4 element, sample
+// group); each thread's first 8 sample loads are issued BEFORE the softmax (they do not depend on the
+// weights), so the whole (S,H,d) tile of the particle is in flight in one memory round trip.
+__global__ __launch_bounds__(1024) void stomp_update_v4_kernel(
+    float* __restrict__ means, const float* __restrict__ samples, const float* __restrict__ costs,
+    float* __restrict__ weights, const float* __restrict__ Sigma, int P, int S, int H, int d, float lr,
+    float temperature) {
+    extern __shared__ float lds[];
+    const int n = H * d, n4 = n >> 2;
+    const int SG = min(4, 1024 / n4);                 // sample groups
+    const int spg = (S + SG - 1) / SG;                // samples per group
+    float* w_lds = lds;                               // S
+    float* delta = w_lds + ((S + 3) & ~3);            // n
+    float4* part = reinterpret_cast<float4*>(delta + n);  // SG * n4 float4
+    float* sig = reinterpret_cast<float*>(part + SG * n4);  // H*H : lr * Sigma
+    __shared__ float red[16];
+    const int p = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int sg = tid / n4, i4 = tid - sg * n4;
+    const bool worker = sg < SG;
+    const int s0 = sg * spg, s1 = min(S, s0 + spg);
+    const float4* smp4 = reinterpret_cast<const float4*>(samples) + (size_t)p * S * n4 + i4;
+    // ---- issue the first chunk of sample loads and the mean
+    float4 v[8];
+    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (worker) {
+        mu = reinterpret_cast<const float4*>(means)[(size_t)p * n4 + i4];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            v[k] = (s0 + k < s1) ? smp4[(size_t)(s0 + k) * n4] : mu;
+    }
+    for (int i = tid; i < H * H; i += blockDim.x) sig[i] = lr * Sigma[i];
+    // ---- softmax over S
+    float m = -3.0e38f;
+    for (int s = tid; s < S; s += blockDim.x) {
+        const float x = -costs[(size_t)p * S + s] / temperature;
+        w_lds[s] = x;
+        m = fmaxf(m, x);
+    }
+    m = wave_max_f32(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = red[0];
+    for (int i = 1; i < nw; ++i) m = fmaxf(m, red[i]);
+    __syncthreads();
+    float z = 0.f;
+    for (int s = tid; s < S; s += blockDim.x) {
+        const float e = expf(w_lds[s] - m);
+        w_lds[s] = e;
+        z += e;
+    }
+    z = wave_sum_f32(z);
+    if (lane == 0) red[wave] = z;
+    __syncthreads();
+    z = 0.f;
+    for (int i = 0; i < nw; ++i) z += red[i];
+    for (int s = tid; s < S; s += blockDim.x) {
+        const float w = w_lds[s] / z;
+        w_lds[s] = w;
+        weights[(size_t)p * S + s] = w;
+    }
+    __syncthreads();
+    // ---- weighted noise reduce
+    if (worker) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (s0 + k < s1) {
+                const float w = w_lds[s0 + k];
+                acc.x += w * (v[k].x - mu.x); acc.y += w * (v[k].y - mu.y);
+                acc.z += w * (v[k].z - mu.z); acc.w += w * (v[k].w - mu.w);
+            }
+        }
+        for (int s = s0 + 8; s < s1; ++s) {
+            const float4 t = smp4[(size_t)s * n4];
+            const float w = w_lds[s];
+            acc.x += w * (t.x - mu.x); acc.y += w * (t.y - mu.y);
+            acc.z += w * (t.z - mu.z); acc.w += w * (t.w - mu.w);
+        }
+        part[sg * n4 + i4] = acc;
+    }
+    __syncthreads();
+    if (tid < n4) {
+        float4 a = part[tid];
+        for (int g = 1; g < SG; ++g) {
+            const float4 b = part[g * n4 + tid];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        reinterpret_cast<float4*>(delta)[tid] = a;
+    }
+    __syncthreads();
+    // ---- covariance-weighted step: mean += (lr*Sigma) @ delta
+    for (int i = tid; i < n; i += blockDim.x) {
+        const int h = i / d, c = i - h * d;
+        float acc = 0.f;
+        for (int k = 0; k < H; ++k) acc = fmaf(sig[h * H + k], delta[k * d + c], acc);
         means[(size_t)p * n + i] += acc;
     }
 }
@@ -534,6 +650,28 @@ static bool update_lds(int S, int H, int d, size_t& bytes, int& sigma_in_lds) {
     return bytes <= 150 * 1024;
 }
 
+// kernel B launcher: vectorised path when the (H,d) tile is float4-divisible and fits 1024 threads
+static bool launch_update(float* means, const float* samples, const float* costs, float* weights, const float* Sigma,
+                          int P, int S, int H, int d, float lr, float temperature, hipStream_t st) {
+    const int n = H * d;
+    if ((n & 3) == 0 && n <= 1024 && (size_t)H * H * 4 <= 64 * 1024) {
+        const int n4 = n >> 2;
+        const int SG = (1024 / n4) < 4 ? (1024 / n4) : 4;
+        const size_t lds = (((size_t)S + 3) & ~(size_t)3) * 4 + (size_t)n * 4 + (size_t)SG * n4 * 16 + (size_t)H * H * 4;
+        if (lds <= 150 * 1024) {
+            hipLaunchKernelGGL(stomp_update_v4_kernel, dim3(P), dim3(1024), lds, st, means, samples, costs, weights, Sigma,
+                               P, S, H, d, lr, temperature);
+            return true;
+        }
+    }
+    size_t lds;
+    int sig_lds;
+    if (!update_lds(S, H, d, lds, sig_lds)) return false;
+    hipLaunchKernelGGL(stomp_update_kernel, dim3(P), dim3(1024), lds, st, means, samples, costs, weights, Sigma, P, S, H,
+                       d, lr, temperature, sig_lds);
+    return true;
+}
+
 // kernel A launcher: H = 64 takes the MFMA fast path for the channel counts of the reference's robots
 template <bool WITH_COST>
 static void launch_sample(const float* means, const float* eps, float* samples, float* costs, const float* L,
@@ -606,11 +744,8 @@ extern "C" int mpb_stomp_update(float* means, const float* samples, const float*
     if (P < 0 || S < 1 || H < 3 || H > MPB_MAX_H || d < 1 || d > MPB_MAX_D) return fail(MPB_E_INVALID, "%s: bad shape", __func__);
     if (!(temperature > 0.f)) return fail(MPB_E_INVALID, "%s: temperature must be > 0", __func__);
     if (P == 0) return MPB_OK;
-    size_t lds;
-    int sig_lds;
-    if (!update_lds(S, H, d, lds, sig_lds)) return fail(MPB_E_UNSUPPORTED, "%s: S + H*d too large for LDS", __func__);
-    hipLaunchKernelGGL(stomp_update_kernel, dim3(P), dim3(1024), lds, (hipStream_t)stream, means, samples, costs,
-                       weights, Sigma, P, S, H, d, lr, temperature, sig_lds);
+    if (!launch_update(means, samples, costs, weights, Sigma, P, S, H, d, lr, temperature, (hipStream_t)stream))
+        return fail(MPB_E_UNSUPPORTED, "%s: S + H*d too large for LDS", __func__);
     return check_launch(__func__);
 }
 
@@ -630,8 +765,7 @@ extern "C" int mpb_stomp_step(float* means, const float* eps, float* samples, fl
     for (int it = 0; it < n_iters; ++it) {
         launch_sample<true>(means, eps ? eps + (size_t)it * eps_stride : nullptr, samples, costs, L, geom, P, S, H, d,
                             k_sigma, weight, seed, iter0 + (uint32_t)it, particle_offset, (hipStream_t)stream);
-        hipLaunchKernelGGL(stomp_update_kernel, dim3(P), dim3(1024), lds_b, (hipStream_t)stream, means, samples, costs,
-                           weights, Sigma, P, S, H, d, lr, temperature, sig_lds);
+        launch_update(means, samples, costs, weights, Sigma, P, S, H, d, lr, temperature, (hipStream_t)stream);
     }
     return check_launch(__func__);
 }
