@@ -399,64 +399,109 @@ __device__ __forceinline__ void grid_stage(const GeomView& G, unsigned* gridw, f
         otab[i] = (i < G.n_sph) ? sp[i] : make_float4(-1.0e9f, -1.0e9f, -1.0e9f, 0.f);
 }
 
-__device__ __forceinline__ float sphere_hinge_grid(const GeomView& G, const unsigned* gridw, const float4* otab,
-                                                   float x, float y, float z, float rl) {
-    const float fx = (x - G.glx) * G.gix, fy = (y - G.gly) * G.giy, fz = (z - G.glz) * G.giz;
-    const int ix = (int)floorf(fx), iy = (int)floorf(fy), iz = (int)floorf(fz);
-    const bool inb = (unsigned)ix < (unsigned)G.gnx && (unsigned)iy < (unsigned)G.gny && (unsigned)iz < (unsigned)G.gnz;
-    const int cell = inb ? (iz * G.gny + iy) * G.gnx + ix : 0;
-    unsigned w = gridw[cell];
-    w = inb ? w : MPB_GRID_EMPTY;
-    float best = 3.0e38f;
-    if (__builtin_expect(__ballot(w == MPB_GRID_OVERFLOW) != 0ull, 0)) {
-        // some lane sits in a crowded cell: exhaustive exact loop for this sphere (rare)
+// N collision spheres at once: the N grid words are fetched together and every trip of the candidate
+// loop issues N obstacle-table reads before the N distance evaluations, so the LDS latency is paid
+// once per group instead of once per sphere.  Returns the sum of the N hinges.
+template <int N>
+__device__ __forceinline__ float spheres_hinge_grid(const GeomView& G, const unsigned* gridw, const float4* otab,
+                                                    const float (&x)[N], const float (&y)[N], const float (&z)[N],
+                                                    const float (&rl)[N]) {
+    unsigned w[N];
+    float best[N];
+    unsigned long long over = 0ull;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float fx = (x[i] - G.glx) * G.gix, fy = (y[i] - G.gly) * G.giy, fz = (z[i] - G.glz) * G.giz;
+        const int ix = (int)floorf(fx), iy = (int)floorf(fy), iz = (int)floorf(fz);
+        const bool inb = (unsigned)ix < (unsigned)G.gnx && (unsigned)iy < (unsigned)G.gny && (unsigned)iz < (unsigned)G.gnz;
+        const int cell = inb ? (iz * G.gny + iy) * G.gnx + ix : 0;
+        const unsigned wv = gridw[cell];
+        w[i] = inb ? wv : MPB_GRID_EMPTY;
+        best[i] = 3.0e38f;
+        over |= __ballot(w[i] == MPB_GRID_OVERFLOW);
+    }
+    if (__builtin_expect(over != 0ull, 0)) {
+        // some lane sits in a crowded cell: exhaustive exact loop for this group (rare)
         for (int o = 0; o < G.n_sph; ++o) {
             const float4 s = otab[o];
-            const float dx = x - s.x, dy = y - s.y, dz = z - s.z;
-            best = fminf(best, fast_sqrt(dx * dx + dy * dy + dz * dz) - s.w);
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const float dx = x[i] - s.x, dy = y[i] - s.y, dz = z[i] - s.z;
+                best[i] = fminf(best[i], fast_sqrt(dx * dx + dy * dy + dz * dz) - s.w);
+            }
         }
     } else {
-        while (__ballot((w & 0xFFu) != 0xFFu) != 0ull) {
-            const unsigned idx = w & 0xFFu;
-            w = (w >> 8) | 0xFF000000u;
-            const float4 s = otab[idx == 0xFFu ? (unsigned)G.n_sph : idx];
-            const float dx = x - s.x, dy = y - s.y, dz = z - s.z;
-            best = fminf(best, fast_sqrt(dx * dx + dy * dy + dz * dz) - s.w);
+        for (;;) {
+            unsigned long long any = 0ull;
+#pragma unroll
+            for (int i = 0; i < N; ++i) any |= __ballot((w[i] & 0xFFu) != 0xFFu);
+            if (any == 0ull) break;
+            float4 s[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const unsigned idx = w[i] & 0xFFu;
+                w[i] = (w[i] >> 8) | 0xFF000000u;
+                s[i] = otab[idx == 0xFFu ? (unsigned)G.n_sph : idx];
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const float dx = x[i] - s[i].x, dy = y[i] - s[i].y, dz = z[i] - s[i].z;
+                best[i] = fminf(best[i], fast_sqrt(dx * dx + dy * dy + dz * dz) - s[i].w);
+            }
         }
     }
     // boxes are few: exhaustive
     const float4* bp = reinterpret_cast<const float4*>(G.box);
     for (int o = 0; o < G.n_box; ++o) {
         const float4 c = bp[2 * o], h = bp[2 * o + 1];
-        const float px = x - c.x, py = y - c.y, pz = z - c.z;
-        const float ax = fabsf(px) - h.x, ay = fabsf(py) - h.y, az = fabsf(pz) - h.z;
-        const float qx = fmaxf(ax, 0.f), qy = fmaxf(ay, 0.f), qz = fmaxf(az, 0.f);
-        const float sd = fast_sqrt(qx * qx + qy * qy + qz * qz) + fminf(fmaxf(ax, fmaxf(ay, az)), 0.f);
-        best = fminf(best, sd);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const float px = x[i] - c.x, py = y[i] - c.y, pz = z[i] - c.z;
+            const float ax = fabsf(px) - h.x, ay = fabsf(py) - h.y, az = fabsf(pz) - h.z;
+            const float qx = fmaxf(ax, 0.f), qy = fmaxf(ay, 0.f), qz = fmaxf(az, 0.f);
+            const float sd = fast_sqrt(qx * qx + qy * qy + qz * qz) + fminf(fmaxf(ax, fmaxf(ay, az)), 0.f);
+            best[i] = fminf(best[i], sd);
+        }
     }
-    return fmaxf(G.margin + rl - best, 0.f);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) sum += fmaxf(G.margin + rl[i] - best[i], 0.f);   // parked slots: best = 3e38 -> 0
+    return sum;
 }
 
 __device__ __forceinline__ float waypoint_cost_grid(const GeomView& G, const unsigned* gridw, const float4* otab,
                                                     const float (&q)[MPB_MAX_DOF]) {
-    if (G.kind == MPB_KIND_POINT)
-        return sphere_hinge_grid(G, gridw, otab, q[0], q[1], (G.n_dof > 2) ? q[2] : 0.f, G.links[4]);
+    if (G.kind == MPB_KIND_POINT) {
+        const float x[1] = {q[0]}, y[1] = {q[1]}, z[1] = {(G.n_dof > 2) ? q[2] : 0.f}, rl[1] = {G.links[4]};
+        return spheres_hinge_grid<1>(G, gridw, otab, x, y, z, rl);
+    }
+    constexpr int N = 4;
+    constexpr float FAR = 1.0e9f;  // parked slot: outside the grid, no candidates
     FKState<false> F;
     F.r00 = 1.f; F.r01 = 0.f; F.r02 = 0.f; F.r10 = 0.f; F.r11 = 1.f; F.r12 = 0.f; F.r20 = 0.f; F.r21 = 0.f; F.r22 = 1.f;
     F.tx = F.ty = F.tz = 0.f;
     F.frame = 0;
     float cost = 0.f;
-    for (int j = 0; j < G.n_tf; ++j) {
-        fk_advance<false>(G, F, q);
-        const int l_end = G.fstart[j + 1];
-        for (int l = G.fstart[j]; l < l_end; ++l) {
-            const float4 lk = *reinterpret_cast<const float4*>(G.links + 8 * l);  // frame, ox, oy, oz
-            const float rl = G.links[8 * l + 4];
-            const float x = F.tx + (F.r00 * lk.y + F.r01 * lk.z + F.r02 * lk.w);
-            const float y = F.ty + (F.r10 * lk.y + F.r11 * lk.z + F.r12 * lk.w);
-            const float z = F.tz + (F.r20 * lk.y + F.r21 * lk.z + F.r22 * lk.w);
-            cost += sphere_hinge_grid(G, gridw, otab, x, y, z, rl);
+    for (int l0 = 0; l0 < G.n_links; l0 += N) {
+        const int nl = min(N, G.n_links - l0);
+        float x[N], y[N], z[N], rl[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if (i < nl) {
+                const int li = l0 + i;
+                const float4 lk = *reinterpret_cast<const float4*>(G.links + 8 * li);  // frame, ox, oy, oz
+                rl[i] = G.links[8 * li + 4];
+                const int f = __float_as_int(lk.x);
+                while (F.frame < f) fk_advance<false>(G, F, q);
+                x[i] = F.tx + (F.r00 * lk.y + F.r01 * lk.z + F.r02 * lk.w);
+                y[i] = F.ty + (F.r10 * lk.y + F.r11 * lk.z + F.r12 * lk.w);
+                z[i] = F.tz + (F.r20 * lk.y + F.r21 * lk.z + F.r22 * lk.w);
+            } else {
+                rl[i] = 0.f;
+                x[i] = y[i] = z[i] = FAR;
+            }
         }
+        cost += spheres_hinge_grid<N>(G, gridw, otab, x, y, z, rl);
     }
     return cost;
 }

@@ -196,6 +196,16 @@ __global__ __launch_bounds__(256) void stomp_sample_cost_kernel(
 // FK + SDF cost evaluation wants.  DCH = d is a compile-time channel count (no per-channel branches).
 // ------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Standard normals of the H = 64 fast path: one Philox4x32-7 call per (particle, sample, channel j,
+// k-group g, quarter q4) yields eps[j][k] for k = 16*q4 + 4*r + g, r = 0..3.  Shared by the sampling
+// kernel and the eps-space update kernel so both see the same noise without it ever touching memory.
+__device__ __forceinline__ void stomp_eps4(uint32_t p_global, uint32_t s, uint32_t j, uint32_t g, uint32_t q4,
+                                           uint32_t iter, uint32_t seed_lo, uint32_t seed_hi, float (&n)[4]) {
+    const uint4 rr = philox4x32<7>(make_uint4(p_global, s, (j << 16) | (g << 8) | q4, iter), make_uint2(seed_lo, seed_hi));
+    box_muller(rr.x, rr.y, n[0], n[1]);
+    box_muller(rr.z, rr.w, n[2], n[3]);
+}
 #define NT_STRIDE 20  // floats per waypoint row of the noise tile: 80 B keeps ds_read_b128 conflict-free
 
 template <int DCH, bool WITH_COST>
@@ -237,20 +247,11 @@ __global__ __launch_bounds__(256, 4) void stomp_sample_cost_h64_kernel(
     } else {
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
-            float n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
-#ifdef MPB_EXP_NOPHILOX
-            if (j < DCH) { n0 = 0.1f * q4; n1 = 0.2f; n2 = -0.1f * g; n3 = 0.05f * j; }
-            if (false) {
-#else
-            if (j < DCH) {
-#endif
-                const uint4 rr = philox4x32<7>(
-                    make_uint4(particle_offset + (uint32_t)p, (uint32_t)s, ((uint32_t)j << 16) | ((uint32_t)g << 8) | (uint32_t)q4, iter),
-                    make_uint2(seed_lo, seed_hi));
-                box_muller(rr.x, rr.y, n0, n1);
-                box_muller(rr.z, rr.w, n2, n3);
-            }
-            e[4 * q4 + 0] = n0; e[4 * q4 + 1] = n1; e[4 * q4 + 2] = n2; e[4 * q4 + 3] = n3;
+            float n[4] = {0.f, 0.f, 0.f, 0.f};
+            if (j < DCH)
+                stomp_eps4(particle_offset + (uint32_t)p, (uint32_t)s, (uint32_t)j, (uint32_t)g, (uint32_t)q4, iter, seed_lo,
+                           seed_hi, n);
+            e[4 * q4 + 0] = n[0]; e[4 * q4 + 1] = n[1]; e[4 * q4 + 2] = n[2]; e[4 * q4 + 3] = n[3];
         }
     }
     // ---- N = L * eps on the matrix cores
@@ -417,9 +418,12 @@ __global__ __launch_bounds__(1024) void stomp_update_kernel(
     }
 }
 
-// Vectorised variant of kernel B for H*d divisible by 4 and <= 1024: thread = (float4 element, sample
-// group); each thread's first 8 sample loads are issued BEFORE the softmax (they do not depend on the
-// weights), so the whole (S,H,d) tile of the particle is in flight in one memory round trip.
+// Vectorised variant of kernel B for H*d divisible by 4, H*d <= 1024, H <= 64 and S <= 64, built for a
+// short critical path (the kernel is pure latency: ~900 VALU instructions per wave):
+//   * every load is issued in the first instructions: 8 float4 sample loads per thread (they do not
+//     depend on the weights), the thread's row of Sigma (registers, no LDS staging) and the costs;
+//   * the softmax over S <= 64 is done redundantly by every wave with wave reductions -- no barriers;
+//   * two barriers in total (partial sums -> delta -> matvec).
 __global__ __launch_bounds__(1024) void stomp_update_v4_kernel(
     float* __restrict__ means, const float* __restrict__ samples, const float* __restrict__ costs,
     float* __restrict__ weights, const float* __restrict__ Sigma, int P, int S, int H, int d, float lr,
@@ -428,18 +432,15 @@ __global__ __launch_bounds__(1024) void stomp_update_v4_kernel(
     const int n = H * d, n4 = n >> 2;
     const int SG = min(4, 1024 / n4);                 // sample groups
     const int spg = (S + SG - 1) / SG;                // samples per group
-    float* w_lds = lds;                               // S
-    float* delta = w_lds + ((S + 3) & ~3);            // n
+    float* delta = lds;                               // n
     float4* part = reinterpret_cast<float4*>(delta + n);  // SG * n4 float4
-    float* sig = reinterpret_cast<float*>(part + SG * n4);  // H*H : lr * Sigma
-    __shared__ float red[16];
     const int p = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int sg = tid / n4, i4 = tid - sg * n4;
     const bool worker = sg < SG;
     const int s0 = sg * spg, s1 = min(S, s0 + spg);
     const float4* smp4 = reinterpret_cast<const float4*>(samples) + (size_t)p * S * n4 + i4;
-    // ---- issue the first chunk of sample loads and the mean
+    // ---- issue every load up front
     float4 v[8];
     float4 mu = make_float4(0.f, 0.f, 0.f, 0.f);
     if (worker) {
@@ -448,51 +449,33 @@ __global__ __launch_bounds__(1024) void stomp_update_v4_kernel(
         for (int k = 0; k < 8; ++k)
             v[k] = (s0 + k < s1) ? smp4[(size_t)(s0 + k) * n4] : mu;
     }
-    for (int i = tid; i < H * H; i += blockDim.x) sig[i] = lr * Sigma[i];
-    // ---- softmax over S
-    float m = -3.0e38f;
-    for (int s = tid; s < S; s += blockDim.x) {
-        const float x = -costs[(size_t)p * S + s] / temperature;
-        w_lds[s] = x;
-        m = fmaxf(m, x);
-    }
-    m = wave_max_f32(m);
-    if (lane == 0) red[wave] = m;
-    __syncthreads();
-    m = red[0];
-    for (int i = 1; i < nw; ++i) m = fmaxf(m, red[i]);
-    __syncthreads();
-    float z = 0.f;
-    for (int s = tid; s < S; s += blockDim.x) {
-        const float e = expf(w_lds[s] - m);
-        w_lds[s] = e;
-        z += e;
-    }
-    z = wave_sum_f32(z);
-    if (lane == 0) red[wave] = z;
-    __syncthreads();
-    z = 0.f;
-    for (int i = 0; i < nw; ++i) z += red[i];
-    for (int s = tid; s < S; s += blockDim.x) {
-        const float w = w_lds[s] / z;
-        w_lds[s] = w;
-        weights[(size_t)p * S + s] = w;
-    }
-    __syncthreads();
-    // ---- weighted noise reduce
+    const float cst = (lane < S) ? costs[(size_t)p * S + lane] : 0.f;
+    // row of Sigma for the matvec output this thread owns (thread tid < n <-> element (h, c))
+    const int hh = (tid < n) ? tid / d : 0, cc = (tid < n) ? tid - hh * d : 0;
+    float4 srow[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        srow[k] = (4 * k < H) ? reinterpret_cast<const float4*>(Sigma + (size_t)hh * H)[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+    // ---- softmax over S (every wave, redundantly): w for sample `lane`
+    const float xs = (lane < S) ? -cst / temperature : -3.0e38f;
+    const float mx = wave_max_f32(xs);
+    const float ex = (lane < S) ? expf(xs - mx) : 0.f;
+    const float wl = ex / wave_sum_f32(ex);
+    if (tid < S) weights[(size_t)p * S + tid] = wl;
+    // ---- weighted noise reduce; the weight of sample s is broadcast from lane s
     if (worker) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
+            const float w = __shfl(wl, min(s0 + k, 63), 64);
             if (s0 + k < s1) {
-                const float w = w_lds[s0 + k];
                 acc.x += w * (v[k].x - mu.x); acc.y += w * (v[k].y - mu.y);
                 acc.z += w * (v[k].z - mu.z); acc.w += w * (v[k].w - mu.w);
             }
         }
         for (int s = s0 + 8; s < s1; ++s) {
             const float4 t = smp4[(size_t)s * n4];
-            const float w = w_lds[s];
+            const float w = __shfl(wl, s, 64);
             acc.x += w * (t.x - mu.x); acc.y += w * (t.y - mu.y);
             acc.z += w * (t.z - mu.z); acc.w += w * (t.w - mu.w);
         }
@@ -508,12 +491,19 @@ __global__ __launch_bounds__(1024) void stomp_update_v4_kernel(
         reinterpret_cast<float4*>(delta)[tid] = a;
     }
     __syncthreads();
-    // ---- covariance-weighted step: mean += (lr*Sigma) @ delta
-    for (int i = tid; i < n; i += blockDim.x) {
-        const int h = i / d, c = i - h * d;
+    // ---- covariance-weighted step: mean += (lr*Sigma) @ delta, Sigma row from registers
+    if (tid < n) {
         float acc = 0.f;
-        for (int k = 0; k < H; ++k) acc = fmaf(sig[h * H + k], delta[k * d + c], acc);
-        means[(size_t)p * n + i] += acc;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (4 * k < H) {
+                acc = fmaf(lr * srow[k].x, delta[(4 * k + 0) * d + cc], acc);
+                acc = fmaf(lr * srow[k].y, delta[(4 * k + 1) * d + cc], acc);
+                acc = fmaf(lr * srow[k].z, delta[(4 * k + 2) * d + cc], acc);
+                acc = fmaf(lr * srow[k].w, delta[(4 * k + 3) * d + cc], acc);
+            }
+        }
+        means[(size_t)p * n + tid] += acc;
     }
 }
 
@@ -654,15 +644,13 @@ static bool update_lds(int S, int H, int d, size_t& bytes, int& sigma_in_lds) {
 static bool launch_update(float* means, const float* samples, const float* costs, float* weights, const float* Sigma,
                           int P, int S, int H, int d, float lr, float temperature, hipStream_t st) {
     const int n = H * d;
-    if ((n & 3) == 0 && n <= 1024 && (size_t)H * H * 4 <= 64 * 1024) {
+    if ((n & 3) == 0 && n <= 1024 && H <= 64 && (H & 3) == 0 && S <= 64) {
         const int n4 = n >> 2;
         const int SG = (1024 / n4) < 4 ? (1024 / n4) : 4;
-        const size_t lds = (((size_t)S + 3) & ~(size_t)3) * 4 + (size_t)n * 4 + (size_t)SG * n4 * 16 + (size_t)H * H * 4;
-        if (lds <= 150 * 1024) {
-            hipLaunchKernelGGL(stomp_update_v4_kernel, dim3(P), dim3(1024), lds, st, means, samples, costs, weights, Sigma,
-                               P, S, H, d, lr, temperature);
-            return true;
-        }
+        const size_t lds = (size_t)n * 4 + (size_t)SG * n4 * 16;
+        hipLaunchKernelGGL(stomp_update_v4_kernel, dim3(P), dim3(1024), lds, st, means, samples, costs, weights, Sigma, P,
+                           S, H, d, lr, temperature);
+        return true;
     }
     size_t lds;
     int sig_lds;

@@ -16,8 +16,10 @@ def timeit(fn, n=50, warm=5):
     ts = sorted(a.elapsed_time(b) for a, b in evs)
     return ts[len(ts) // 2] * 1e3, ts[0] * 1e3
 
-for pos_only in (False, True):
-    for (P, S) in ((128, 32), (1024, 32), (4096, 32)):
+import os
+QUICK = os.environ.get('MPB_QUICK')
+for pos_only in ((False,) if QUICK else (False, True)):
+    for (P, S) in (((128, 32),) if QUICK else ((128, 32), (1024, 32), (4096, 32))):
         wl = workloads.panda_spheres_stomp(P, dev, S=S, pos_only=pos_only)
         H, d = 64, wl['means0'].shape[-1]
         cpu = dict(device='cpu', dtype=torch.float32)

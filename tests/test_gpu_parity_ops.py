@@ -178,7 +178,10 @@ def test_stomp_split_halves_equal_fused(gpu_device):
     c2 = ops.cost_collision_eval(s2.flatten(0, 1), geom, 1.0).reshape(P, S)
     ops.stomp_update(m2, s2, c2, w2, Sigma, 0.1, 0.1)
     torch.cuda.synchronize()
-    assert torch.equal(s2, samples) and torch.equal(c2, costs) and torch.equal(w2, weights) and torch.equal(m1, m2)
+    assert torch.equal(s2, samples) and torch.equal(c2, costs) and torch.equal(w2, weights)
+    # the fused step updates in eps space (E = sum_s w_s eps_s, then Z L E), the split path from the samples:
+    # same mathematics, different fp32 summation order
+    assert rel_err(m1, m2) < 1e-5
 
 
 def test_stomp_device_rng(gpu_device):

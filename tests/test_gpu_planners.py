@@ -82,8 +82,9 @@ def test_stomp_user_cost_callable_matches_fused(gpu_device):
     a.optimize()
     b.optimize()
     torch.cuda.synchronize()
-    assert torch.equal(a._particle_means, b._particle_means)
-    assert torch.equal(a.costs, b.costs)
+    # fused step: eps-space update; split path: update from the samples -- same maths, fp32 order differs
+    assert rel_err(a._particle_means, b._particle_means) < 1e-5
+    assert rel_err(a.costs, b.costs) < 1e-4
 
 
 def test_stomp_philox_reduces_cost(gpu_device):
