@@ -33,31 +33,35 @@ def stomp_algorithmic_bytes(P, S, H, d):
     return 4 * (B * H * d + 2 * P * H * d + 2 * B)
 
 
-def cpu_baseline(wl, P_cpu, iters):
+def cpu_baseline(wl, budget_s=12.0, max_iters=8):
     """The oracle restatement of the reference loop (kind "port") on this host's cores, on a bounded
-    sample of the same workload: P_cpu of the P particles, all S samples each."""
+    sample of the same workload: the FULL C3 batch (all P particles x S samples), as many iterations as
+    fit the time budget (at least 2 after one warm-up)."""
     from oracle import planners_ref as O
     from oracle.geometry_ref import make_ref_geometry
     ta = dict(device='cpu', dtype=torch.float32)
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)     # more intra-op threads than this only adds contention here
     torch.set_num_threads(cores)
     prm = wl['params']
     H, S, d = prm['n_support_points'], prm['num_samples'], wl['means0'].shape[-1]
+    P = wl['means0'].shape[0]
     robot, field = make_ref_geometry(wl['robot'], wl['field'], ta)
     R, Sigma, L = O.stomp_constants(H, prm['dt'], prm['sigma_spectral'], ta)
-    means = wl['means0'][:P_cpu].cpu().clone()
+    means = wl['means0'].cpu().clone()
     cost_fn = lambda x: O.collision_cost(x, robot, field, wl['sigma_coll'])
     times = []
-    for it in range(iters + 1):
+    t_start = time.perf_counter()
+    for it in range(max_iters + 1):
         t0 = time.perf_counter()
-        eps = torch.empty(S, d, P_cpu, H).normal_()
+        eps = torch.empty(S, d, P, H).normal_()
         out = O.stomp_iteration(means, eps, L, Sigma, cost_fn, prm['step_size'], prm['temperature'])
         means = out['means']
         if it > 0:
             times.append(time.perf_counter() - t0)
+        if len(times) >= 2 and time.perf_counter() - t_start > budget_s:
+            break
     times.sort()
-    med = times[len(times) // 2]
-    return med, cores
+    return times[len(times) // 2], cores, len(times)
 
 
 def main():
@@ -69,7 +73,6 @@ def main():
     ap.add_argument('--samples', type=int, default=32)
     ap.add_argument('--pos-only', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-particles', type=int, default=8)
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -122,25 +125,40 @@ def main():
     # ---- roofline of the dominant kernel (sample+cost), measured live with events on the launch stream
     geom = cost.cost_l[0].device_geometry(dev)
     n_prof = min(args.steps, 50)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-           for _ in range(n_prof)]
-    for i, (e0, e1, e2) in enumerate(evs):
-        e0.record()
+
+    def launch_a(i):
         ops.stomp_sample(planner._particle_means, None, planner.state_particles, planner.scale_tril, S, seed=0,
                          it=10_000 + i, particle_offset=rank * P, geom=geom, costs=planner.costs,
                          k_sigma=cost.cost_l[0].k_sigma, weight=1.0)
-        e1.record()
+
+    def launch_b():
         ops.stomp_update(planner._particle_means, planner.state_particles, planner.costs, planner._weights_buf,
                          planner.Sigma, planner.lr, planner.temperature)
-        e2.record()
-    torch.cuda.synchronize()
-    t_a = sorted(e0.elapsed_time(e1) for e0, e1, _ in evs)
-    t_b = sorted(e1.elapsed_time(e2) for _, e1, e2 in evs)
-    ka_ms = sum(t_a) / len(t_a)
-    kb_ms = sum(t_b) / len(t_b)
+
+    # n back-to-back launches of ONE kernel between two events: the event / launch overhead (~4 us when a
+    # single launch is bracketed) is amortised, what remains per launch is the kernel plus its ~1 us gap
+    def timed(fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for i in range(5):
+            fn(i)
+        torch.cuda.synchronize()
+        e0.record()
+        for i in range(n_prof):
+            fn(i)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n_prof
+
+    ka_ms = timed(launch_a)
+    kb_ms = timed(lambda i: launch_b())
     alg_bytes_a = 4 * (P * S * H * d + P * H * d + P * S)     # kernel A: samples written + means read + costs
     achieved = alg_bytes_a / (ka_ms * 1e-3) / 1e9
 
+    traffic = None
+    tfile = os.path.join(ROOT, 'profiles', 'r01_traffic_kernelA.json')
+    if os.path.exists(tfile) and P == 128 and S == 32 and not args.pos_only:
+        with open(tfile) as fh:
+            traffic = json.load(fh).get('hbm_bytes_per_launch')   # rocprofv3 FETCH_SIZE/WRITE_SIZE passes, see the file
     if rank == 0:
         its = world * args.steps / elapsed
         line = {
@@ -154,16 +172,17 @@ def main():
                        'robot_collision_spheres': 31, 'obstacle_spheres': 16, 'parallelism': 'particles sharded x%d' % world,
                        'algorithmic_bytes_per_iter': stomp_algorithmic_bytes(P, S, H, d)},
             'roofline': {'bound': 'hbm', 'kernel': 'stomp_sample_cost_kernel', 'achieved': achieved,
-                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-                         'kernel_ms': ka_ms, 'kernel_ms_median': t_a[len(t_a) // 2], 'update_kernel_ms': kb_ms,
+                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'kernel_ms': ka_ms, 'update_kernel_ms': kb_ms,
                          'algorithmic_bytes_per_launch': alg_bytes_a},
         }
         if not args.no_cpu_baseline and world == 1:
-            med, cores = cpu_baseline(wl, args.cpu_particles, iters=3)
+            med, cores, n_it = cpu_baseline(wl)
             line['cpu_baseline'] = {
-                'value': (1.0 / med) * (args.cpu_particles / P), 'unit': 'iters/s', 'cores': cores, 'kind': 'port',
-                'sample': 'oracle/planners_ref.py stomp_iteration on %d of %d particles (x%d samples), median of 3 '
-                          'iterations = %.3f s, scaled linearly to P=%d' % (args.cpu_particles, P, S, med, P)}
+                'value': 1.0 / med, 'unit': 'iters/s', 'cores': cores, 'kind': 'port',
+                'sample': 'oracle/planners_ref.py stomp_iteration (PyTorch-CPU restatement of stomp.py:157-160 + build-defined '
+                          'FK/SDF) on the full workload (P=%d x S=%d), median of %d iterations = %.3f s, %d intra-op threads'
+                          % (P, S, n_it, med, cores)}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
