@@ -170,6 +170,17 @@ int mpb_mppi_step(float *mean, const float *eps, const float *scale_tril, const 
                   float k_sigma, float weight, float temp, float step_size,
                   int n_iters, uint64_t seed, uint32_t iter0, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * GP-prior initial particles -- replaces OptimizationPlanner.get_random_trajs (base.py:155-202) over
+ * MultiMPPrior (costs/factors/mp_priors_multi.py:100-110, :213-256): x = mean + scale_tril @ eps with
+ * scale_tril = U^-T, K^-1 = U U^T block upper-bidiagonal with (2x2) (x) I_D blocks (fp64 throughout).
+ * out (G*n, H, 2D) fp32, particle index = mode * n + sample (base.py:202); means (G,H,2D) fp64;
+ * eps NULL -> device Philox, else (n, G, H*2D) fp64 standard normals (MultivariateNormal draw order);
+ * Udiag (H,3) = (u00,u01,u11) of U_tt, Uoff (H-1,4) = row-major 2x2 U_{t,t+1}; both fp64, device.
+ * ------------------------------------------------------------------------------------------- */
+int mpb_gp_prior_sample(float *out, const double *means, const double *eps, const double *Udiag,
+                        const double *Uoff, int G, int n, int H, int D, uint64_t seed, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -289,6 +289,60 @@ __device__ __forceinline__ void fk_advance(const GeomView& G, FKState<GRAD>& F, 
     F.frame = j + 1;
 }
 
+// Point robot: one collision sphere at q -- straight loops over the obstacle spheres (4 per trip, SGPR
+// operands) and boxes; no chunk state, so the CHOMP / MPPI kernels of the 2-D examples carry no dead slots.
+template <bool GRAD>
+__device__ __forceinline__ float point_cost(const GeomView& G, float x, float y, float z, float& gx, float& gy,
+                                            float& gz) {
+    float best = 3.0e38f, vx = 0.f, vy = 0.f, vz = 0.f, vn = 1.f;
+    const float4* sp = reinterpret_cast<const float4*>(G.sph);
+#pragma unroll 4
+    for (int o = 0; o < G.n_sph; ++o) {
+        const float4 s = sp[o];
+        const float dx = x - s.x, dy = y - s.y, dz = z - s.z;
+        float d2 = dx * dx + dy * dy + dz * dz;
+        if (GRAD) d2 = fmaxf(d2, 1e-30f);
+        const float dist = fast_sqrt(d2);
+        const float sd = dist - s.w;
+        if (GRAD) {
+            const bool better = sd < best;
+            vx = better ? dx : vx; vy = better ? dy : vy; vz = better ? dz : vz; vn = better ? dist : vn;
+        }
+        best = fminf(best, sd);
+    }
+    const float4* bp = reinterpret_cast<const float4*>(G.box);
+#pragma unroll 2
+    for (int o = 0; o < G.n_box; ++o) {
+        const float4 c = bp[2 * o], h = bp[2 * o + 1];
+        const float px = x - c.x, py = y - c.y, pz = z - c.z;
+        const float ax = fabsf(px) - h.x, ay = fabsf(py) - h.y, az = fabsf(pz) - h.z;
+        const float qx = fmaxf(ax, 0.f), qy = fmaxf(ay, 0.f), qz = fmaxf(az, 0.f);
+        float o2 = qx * qx + qy * qy + qz * qz;
+        if (GRAD) o2 = fmaxf(o2, 1e-30f);
+        const float outside = fast_sqrt(o2);
+        const float mx = fmaxf(ax, fmaxf(ay, az));
+        const float sd = outside + fminf(mx, 0.f);
+        if (GRAD) {
+            const bool better = sd < best;
+            const bool out = mx > 0.f;
+            const bool ix = (ax >= ay) && (ax >= az);
+            const bool iy = !ix && (ay >= az);
+            const float nx = out ? copysignf(qx, px) : (ix ? copysignf(1.f, px) : 0.f);
+            const float ny = out ? copysignf(qy, py) : (iy ? copysignf(1.f, py) : 0.f);
+            const float nz = out ? copysignf(qz, pz) : ((!ix && !iy) ? copysignf(1.f, pz) : 0.f);
+            vx = better ? nx : vx; vy = better ? ny : vy; vz = better ? nz : vz;
+            vn = better ? (out ? outside : 1.f) : vn;
+        }
+        best = fminf(best, sd);
+    }
+    const float h = fmaxf(G.margin + G.links[4] - best, 0.f);
+    if (GRAD) {
+        const float sc = (h > 0.f) ? -1.0f / vn : 0.f;
+        gx = vx * sc; gy = vy * sc; gz = vz * sc;
+    }
+    return h;
+}
+
 // Collision cost of one waypoint q[0..D) (sum over the robot's collision spheres); for GRAD
 // dq[i] = d cost / d q_i (i < D).  q / dq are register arrays indexed only with compile-time indices.
 template <bool GRAD>
@@ -299,6 +353,12 @@ __device__ __forceinline__ float waypoint_cost(const GeomView& G, const float (&
     if (GRAD) {
 #pragma unroll
         for (int i = 0; i < MPB_MAX_DOF; ++i) dq[i] = 0.f;
+    }
+    if (G.kind == MPB_KIND_POINT) {
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        const float h = point_cost<GRAD>(G, q[0], q[1], (G.n_dof > 2) ? q[2] : 0.f, gx, gy, gz);
+        if (GRAD) { dq[0] = gx; dq[1] = gy; if (G.n_dof > 2) dq[2] = gz; }
+        return h;
     }
     LinkChunk<GRAD> C;
     CullStats cs = {0, 0, true};

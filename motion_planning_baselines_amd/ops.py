@@ -210,3 +210,19 @@ def mppi_step(mean, eps, scale_tril, cov_inv, state0, goal, ctrl_min, ctrl_max, 
         _ptr(discount), _ptr(c_weights), _ptr(None if geom is None else geom.buf), _ptr(controls), _ptr(states),
         _ptr(costs), _ptr(weights), NP, S, T, c, 0, float(dt), float(k_sigma), float(weight), float(temp),
         float(step_size), int(n_iters), int(seed) & (2 ** 64 - 1), int(iter0), _stream()), 'mpb_mppi_step')
+
+
+def gp_prior_sample(means, eps, Udiag, Uoff, n, D, seed=0):
+    """Initial particles from the GP prior: means (G,H,2D) fp64, eps None or (n,G,H*2D) fp64 -> (G*n,H,2D) fp32."""
+    G, H, dim = means.shape
+    for t, nm in ((means, 'means'), (Udiag, 'Udiag'), (Uoff, 'Uoff')):
+        if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
+            raise ValueError(f'{nm} must be a contiguous CUDA float64 tensor')
+    assert tuple(Udiag.shape) == (H, 3) and tuple(Uoff.shape) == (H - 1, 4) and dim == 2 * D
+    if eps is not None:
+        if not (eps.is_cuda and eps.dtype == torch.float64 and eps.is_contiguous() and tuple(eps.shape) == (n, G, H * dim)):
+            raise ValueError('eps must be a contiguous CUDA float64 tensor of shape (n, G, H*2D)')
+    out = torch.empty(G * n, H, dim, device=means.device, dtype=torch.float32)
+    _lib.check(_lib.lib().mpb_gp_prior_sample(_ptr(out), _ptr(means), _ptr(eps), _ptr(Udiag), _ptr(Uoff), G, n, H, D,
+                                             int(seed) & (2 ** 64 - 1), _stream()), 'mpb_gp_prior_sample')
+    return out

@@ -7,8 +7,10 @@ file is host-side bookkeeping only.
 import abc
 from abc import ABC, abstractmethod
 
+import numpy as np
 import torch
 
+from .. import ops
 from .._lib import MPBError
 
 
@@ -30,6 +32,54 @@ def finite_difference_vector(x, dt=1.0):
     out = torch.zeros_like(x)
     out[..., 1:-1, :] = (x[..., 2:, :] - x[..., :-2, :]) / (2 * dt)
     return out
+
+
+def gp_prior_factor(H, dt, sigma_start, sigma_gp, sigma_goal=None):
+    """Block upper-bidiagonal factor U of the GP-prior precision K^-1 = A^T Q^-1 A = U U^T
+    (mp_priors_multi.py:213-251), in its (2x2) (x) I_D form, fp64 on the host.
+
+    K^-1 diagonal 2x2 blocks: [t=0] K_s + Phi^T Qi Phi, [0<t<H-1] Qi + Phi^T Qi Phi, [t=H-1] Qi (+ K_g);
+    off-diagonal (t,t+1): -Phi^T Qi  (gp_factor.py:34-50).  Returns Udiag (H,3) = (u00,u01,u11), Uoff (H-1,4).
+    """
+    k = 1.0 / sigma_gp ** 2
+    Qi = np.array([[12.0 / dt ** 3, -6.0 / dt ** 2], [-6.0 / dt ** 2, 4.0 / dt]]) * k
+    Phi = np.array([[1.0, dt], [0.0, 1.0]])
+    PQP = Phi.T @ Qi @ Phi
+    off = -Phi.T @ Qi
+    Ud = np.zeros((H, 3))
+    Uo = np.zeros((max(H - 1, 0), 4))
+    Unext = None
+    for t in range(H - 1, -1, -1):
+        Pt = np.zeros((2, 2))
+        if t == 0:
+            Pt += np.eye(2) / sigma_start ** 2
+        if t < H - 1:
+            Pt += PQP
+        if t > 0:
+            Pt += Qi
+        if t == H - 1 and sigma_goal is not None:
+            Pt += np.eye(2) / sigma_goal ** 2
+        if t < H - 1:
+            O = off @ np.linalg.inv(Unext).T          # U_{t,t+1} = P_{t,t+1} U_{t+1,t+1}^-T
+            Pt = Pt - O @ O.T
+            Uo[t] = O.reshape(-1)
+        u11 = np.sqrt(Pt[1, 1])                        # "upper Cholesky": Pt = U U^T, U upper triangular
+        u01 = Pt[0, 1] / u11
+        u00 = np.sqrt(Pt[0, 0] - u01 ** 2)
+        Unext = np.array([[u00, u01], [0.0, u11]])
+        Ud[t] = (u00, u01, u11)
+    return Ud, Uo
+
+
+def const_vel_mean(start_pos, goal_pos, H, dt):
+    """Straight line with constant velocity, zero velocity at both ends (mp_priors_multi.py:130-151)."""
+    D = start_pos.shape[-1]
+    n = H - 1
+    traj = torch.zeros(H, 2 * D, dtype=torch.float64)
+    i = torch.arange(H, dtype=torch.float64).reshape(H, 1)
+    traj[:, :D] = start_pos.double().cpu() * (n - i) * 1. / n + goal_pos.double().cpu() * i * 1. / n
+    traj[1:-1, D:] = (goal_pos.double().cpu() - start_pos.double().cpu()) / (n * dt)
+    return traj
 
 
 class MPPlanner(ABC):
@@ -94,12 +144,30 @@ class OptimizationPlanner(MPPlanner):
         self.sigma_goal_init = sigma_goal_init
         self.sigma_gp_init = sigma_gp_init
 
-    def get_random_trajs(self):
-        """Initial particles from the GP prior (base.py:155-202).  SURVEY.md 8(f) rank 1 ("next"): the
-        native block-tridiagonal sampler is not built yet -- pass ``initial_particle_means``."""
-        raise NotImplementedError(
-            'GP-prior initial sampling (base.py:155-202) is outside the hot path built so far; '
-            'pass initial_particle_means (e.g. workloads.straight_line_means)')
+    def get_random_trajs(self, noise='torch_cpu', seed=0):
+        """Initial particles from the constant-velocity GP prior (base.py:155-202): num_particles_per_goal
+        samples per goal around the straight line, returned as (num_goals * ppg, H, 2D) fp32 -- 2D wide
+        whatever ``pos_only`` is, like the reference.  The (2x2) (x) I_D structure of the prior precision is
+        exploited (csrc/mpb_prior.hip); eps is drawn like MultivariateNormal.sample((ppg,)) does (fp64, CPU
+        generator) unless noise='philox'."""
+        D, H = self.n_dof, self.n_support_points
+        start = self.start_state[..., :D]
+        goal_directed = self.multi_goal_states is not None
+        goals = self.multi_goal_states[..., :D] if goal_directed else start.reshape(1, D)
+        G = goals.shape[0]
+        if goal_directed:
+            means = torch.stack([const_vel_mean(start, goals[i], H, self.dt) for i in range(G)])
+        else:   # no goal: the prior mean is the start state repeated (mp_priors_multi.py:176)
+            s = torch.cat([start.double().cpu(), torch.zeros(D, dtype=torch.float64)])
+            means = s.repeat(1, H, 1)
+        Ud, Uo = gp_prior_factor(H, self.dt, self.sigma_start_init, self.sigma_gp_init,
+                                 self.sigma_goal_init if goal_directed else None)
+        n = self.num_particles_per_goal
+        eps = None
+        if noise != 'philox':
+            eps = torch.empty(n, G, H * 2 * D, dtype=torch.float64).normal_().to(self.device)
+        f64 = lambda a: torch.as_tensor(a, dtype=torch.float64).to(self.device).contiguous()
+        return ops.gp_prior_sample(f64(means), eps, f64(Ud), f64(Uo), n, D, seed=seed)
 
     def _get_traj(self):
         trajs = self._particle_means.clone()

@@ -121,3 +121,51 @@ def test_mppi_vs_golden(gpu_device, name):
     err = rel_err(mean[0], T(g['mean'][-1]))
     print(name, 'free-running rel err', err)
     assert err < 5e-3
+
+
+def test_gp_prior_sampling_vs_golden(gpu_device):
+    """Initial particles: structured U^-T eps on the GPU == MultiMPPrior.sample of the reference (fp64)."""
+    from motion_planning_baselines_amd import ops
+    from motion_planning_baselines_amd.planners.base import const_vel_mean, gp_prior_factor
+    g = load_golden('gp_prior_d2_h8')
+    dev = gpu_device
+    D, H, dt = int(g['D']), int(g['H']), float(g['dt'])
+    Ud, Uo = gp_prior_factor(H, dt, float(g['sigma_start']), float(g['sigma_gp']), float(g['sigma_goal']))
+    mean = const_vel_mean(T(g['start'])[:D], T(g['goal'])[:D], H, dt)
+    np.testing.assert_allclose(mean.reshape(-1).numpy(), g['mean'].reshape(-1), rtol=1e-12, atol=1e-15)
+    f64 = lambda a: torch.as_tensor(a, dtype=torch.float64).to(dev).contiguous()
+    eps = f64(g['eps'])                                   # (n, G=1, M)
+    n = eps.shape[0]
+    out = ops.gp_prior_sample(f64(mean).unsqueeze(0), eps, f64(Ud), f64(Uo), n, D)
+    torch.cuda.synchronize()
+    ref = T(g['samples']).reshape(n, H, 2 * D)            # (modes=1, n, H, 2D)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.float().numpy(), rtol=2e-6, atol=1e-7)
+    # device-noise path: finite, endpoints pinned by the tight start / goal priors
+    out2 = ops.gp_prior_sample(f64(mean).unsqueeze(0), None, f64(Ud), f64(Uo), 64, D, seed=5)
+    assert torch.isfinite(out2).all()
+    assert float((out2[:, 0, :D].cpu() - T(g['start'])[:D].float()).abs().max()) < 0.02
+    assert float((out2[:, -1, :D].cpu() - T(g['goal'])[:D].float()).abs().max()) < 0.02
+    assert float(out2.std(0).max()) > 1e-3
+
+
+def test_stomp_initialised_from_gp_prior(gpu_device):
+    """STOMP without initial_particle_means: get_random_trajs (base.py:155-202) runs on the GPU."""
+    from motion_planning_baselines_amd.planners.stomp import STOMP
+    from motion_planning_baselines_amd.planners.costs.cost_functions import CostCollision, CostComposite
+    g = load_golden('stomp_pm2d_c1')
+    dev = gpu_device
+    robot, field = product_geometry_from_golden(g)
+    ta = dict(device=dev, dtype=torch.float32)
+    cost = CostComposite(robot, 64, [CostCollision(robot, 64, field=field, sigma_coll=1e-3, tensor_args=ta)], tensor_args=ta)
+    goals = torch.tensor([[0.8, 0.8], [0.8, -0.8]], device=dev)
+    pl = STOMP(n_dof=2, n_support_points=64, num_particles_per_goal=5, num_samples=8, opt_iters=1, dt=0.04,
+               start_state=torch.tensor([-0.8, -0.8], device=dev), cost=cost, multi_goal_states=goals, temperature=1.,
+               step_size=0.1, sigma_spectral=0.1, sigma_start_init=1e-3, sigma_goal_init=1e-3, sigma_gp_init=5.,
+               pos_only=False, tensor_args=ta)
+    assert pl._particle_means.shape == (10, 64, 4)
+    m = pl._particle_means.cpu()
+    assert float((m[:, 0, :2] - torch.tensor([-0.8, -0.8])).abs().max()) < 0.02
+    assert float((m[:5, -1, :2] - torch.tensor([0.8, 0.8])).abs().max()) < 0.02       # goal-major particle order
+    assert float((m[5:, -1, :2] - torch.tensor([0.8, -0.8])).abs().max()) < 0.02
+    traj = pl.optimize(opt_iters=5)
+    assert torch.isfinite(traj).all()
