@@ -12,10 +12,10 @@
 //   with e_t = x_{t+1} - Phi x_t (gp_factor.py:52-56), c_t the collision cost of waypoint t and
 //   h_t = -d c_t / d q_t (field_factor.py:54).
 //
-// Solve per particle by block elimination (block Thomas / block Cholesky):
-//   S_0 = D_0, r_0 = g_0;   S_t [F_t | z_t] = [U | r_t];   S_{t+1} = D_{t+1} - U^T F_t;  r_{t+1} = g_{t+1} - U^T z_t
-//   dtheta_{H-1} = z_{H-1};  dtheta_t = z_t - F_t dtheta_{t+1}
-// One wave per particle; the 2D x 2D blocks live in LDS as 16 x 16 fp64 tiles; F_t, z_t go to a
+// Solve per particle by block elimination (block Thomas):
+//   S_0 = D_0, r_0 = g_0;   W_t = S_t^-1, z_t = W_t r_t;   S_{t+1} = D_{t+1} - U^T W_t U;  r_{t+1} = g_{t+1} - U^T z_t
+//   dtheta_{H-1} = z_{H-1};  dtheta_t = z_t - W_t U dtheta_{t+1}
+// One wave per particle; the 2D x 2D blocks live in LDS as 16 x 16 fp64 tiles; W_t, z_t go to a
 // caller-provided workspace.  All arithmetic is fp64: the weights reach 1/sigma^2 = 1e10 (gpmp2.py:32-35)
 // and fp32 Cholesky at that conditioning is not reproducible; storage stays fp32.
 #include "mpb_common.h"
@@ -106,71 +106,33 @@ __global__ void gpmp2_scale_kernel(const double* __restrict__ in, double* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// wave-cooperative dense helpers on GP_N x GP_N fp64 tiles in LDS (n = live size)
+// block-tridiagonal solve + update, one wave per particle.
+//
+// U = -Phi^T Qi is (2x2) (x) I_D, so F_t = S_t^-1 U is a combination of column blocks of W_t = S_t^-1 and
+//   S_{t+1} = D_{t+1} - U^T W_t U,   z_t = W_t r_t,   r_{t+1} = g_{t+1} - U^T z_t,
+//   dtheta_t = z_t - W_t (U dtheta_{t+1}).
+// The only dense operation per waypoint is the SPD inverse W_t: in-place Gauss-Jordan (no pivoting: the
+// pivots of an SPD matrix are positive) on a 16 x 16 fp64 tile, ping-ponging between two LDS buffers so
+// that each of the 2D elimination steps costs ONE wave-level synchronisation (64 lanes x 4 elements).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
-// in-place lower Cholesky of S (n x n, lower part read/written)
-__device__ void tile_cholesky(double* S, int n, int lane) {
-    for (int k = 0; k < n; ++k) {
-        const double piv = sqrt(S[k * GP_LD + k]);
-        wave_sync();
-        if (lane == 0) S[k * GP_LD + k] = piv;
-        if (lane > k && lane < n) S[lane * GP_LD + k] /= piv;
-        wave_sync();
-        // trailing update: (i,j), k < j <= i < n
-        for (int e = lane; e < GP_N * GP_N; e += 64) {
-            const int i = e >> 4, j = e & 15;
-            if (j > k && j <= i && i < n) S[i * GP_LD + j] -= S[i * GP_LD + k] * S[j * GP_LD + k];
-        }
-        wave_sync();
-    }
-}
-
-// solve L L^T X = Bm in place; Bm is n x m (m <= GP_N + 1 columns, leading dimension GP_LD + 1)
-#define GP_LDB 18
-__device__ void tile_chol_solve(const double* L, double* Bm, int n, int m, int lane) {
-    // forward: L Y = B
-    for (int k = 0; k < n; ++k) {
-        const double inv = 1.0 / L[k * GP_LD + k];
-        if (lane < m) Bm[k * GP_LDB + lane] *= inv;
-        wave_sync();
-        for (int e = lane; e < GP_N * GP_LDB; e += 64) {
-            const int i = e / GP_LDB, c = e - i * GP_LDB;
-            if (i > k && i < n && c < m) Bm[i * GP_LDB + c] -= L[i * GP_LD + k] * Bm[k * GP_LDB + c];
-        }
-        wave_sync();
-    }
-    // backward: L^T X = Y
-    for (int k = n - 1; k >= 0; --k) {
-        const double inv = 1.0 / L[k * GP_LD + k];
-        if (lane < m) Bm[k * GP_LDB + lane] *= inv;
-        wave_sync();
-        for (int e = lane; e < GP_N * GP_LDB; e += 64) {
-            const int i = e / GP_LDB, c = e - i * GP_LDB;
-            if (i < k && c < m) Bm[i * GP_LDB + c] -= L[k * GP_LD + i] * Bm[k * GP_LDB + c];
-        }
-        wave_sync();
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// block-tridiagonal solve + update, one wave per particle
-// ------------------------------------------------------------------------------------------------
 struct GpConst {
     double dt, ks, kgp, kg, kc, delta, step;
     int trust;
 };
 
+#define GP_WS_PER_T (GP_N * GP_N + GP_N)   // workspace doubles per waypoint: W_t (16x16 row-major) + z_t
+
 __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, const float* __restrict__ start,
                                                          const float* __restrict__ goal, const float* __restrict__ jac,
                                                          const double* __restrict__ diag_mean, double* __restrict__ work,
                                                          float* __restrict__ costs_out, int B, int H, int D, GpConst K) {
-    __shared__ double S[GP_N * GP_LD];    // current Schur complement / its Cholesky factor
-    __shared__ double Bm[GP_N * GP_LDB];  // [U | r_t] -> [F_t | z_t]
-    __shared__ double xs[2][GP_N];        // x_t, x_{t+1} (fp64 copies)
-    __shared__ double gnext[GP_N];        // part of g_{t+1} produced by factor t
-    __shared__ double dth[GP_N];          // dtheta_{t+1} during the backward pass
+    __shared__ double Sb[2][GP_N * GP_LD];  // ping-pong tile: Schur complement -> its inverse
+    __shared__ double xs[2][GP_N];          // x_t, x_{t+1} (fp64 copies)
+    __shared__ double rv[GP_N];             // r_t
+    __shared__ double zv[GP_N];             // z_t / scratch vector
+    __shared__ double dth[GP_N];            // dtheta_{t+1} during the backward pass
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
     const int dim = 2 * D;
@@ -178,14 +140,17 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
     // 2x2 GP coefficient matrices (Kronecker with I_D)
     const double a = 12.0 / (dt * dt * dt) * K.kgp, bq = -6.0 / (dt * dt) * K.kgp, cq = 4.0 / dt * K.kgp;  // Qi
     const double p00 = a, p01 = 6.0 / (dt * dt) * K.kgp, p11 = cq;                                            // Phi^T Qi Phi
-    // U = -Phi^T Qi = -[[a, bq],[a dt + bq, bq dt + cq]]
+    // U = -Phi^T Qi = -[[a, bq],[a dt + bq, bq dt + cq]]   (U[c][e]: c,e in {pos, vel})
     const double u00 = -a, u01 = -bq, u10 = -(a * dt + bq), u11 = -(bq * dt + cq);
-    double* wF = work + (size_t)b * H * (GP_N * GP_N + GP_N);  // per t: F_t (dim x dim, row-major GP_N) then z_t
+    double* wW = work + (size_t)b * H * GP_WS_PER_T;
     float* xb = x + (size_t)b * H * dim;
     const float* jb = jac + (size_t)b * H * (D + 1);
     double cost = 0.0;
+    // element ownership for the 16x16 tile: lane -> row i = lane >> 2, columns j0 .. j0+3 with j0 = 4 (lane & 3)
+    const int ei = lane >> 2, ej0 = (lane & 3) << 2;
+    int cur = 0;  // Sb[cur] holds -(U^T W_{t-1} U) on entry to step t > 0
+    double rcarry = 0.0;  // lane < dim: r_t contribution carried from step t-1 (gnext - U^T z)
 
-    // S = D_0 (without the Schur term), r_0 = g_0 assembled on the fly inside the loop
     for (int t = 0; t < H; ++t) {
         // ---- load x_t, x_{t+1}
         if (lane < dim) {
@@ -193,13 +158,12 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
             xs[1][lane] = (t + 1 < H) ? (double)xb[(t + 1) * dim + lane] : 0.0;
         }
         wave_sync();
-        // ---- GP error of factor t: e = x_{t+1} - Phi x_t   (pos: x1p - x0p - dt x0v ; vel: x1v - x0v)
+        // ---- GP error of factor t: e = x_{t+1} - Phi x_t
         double e_i = 0.0;
         if (lane < dim && t + 1 < H) {
             const bool pos = lane < D;
             e_i = pos ? xs[1][lane] - (xs[0][lane] + dt * xs[0][lane + D]) : xs[1][lane] - xs[0][lane];
         }
-        // Qi e and Phi^T Qi e   (Kronecker: mixes component i with its pos/vel partner)
         double qe_i = 0.0, pqe_i = 0.0;
         {
             const double e_partner = __shfl(e_i, (lane < D) ? lane + D : lane - D, 64);
@@ -209,16 +173,18 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
                 const double qp = a * ep + bq * ev, qv = bq * ep + cq * ev;      // Qi e
                 qe_i = pos ? qp : qv;
                 pqe_i = pos ? qp : dt * qp + qv;                                 // Phi^T (Qi e)
-                if (pos) cost += ep * qp;
-                else cost += ev * qv;
+                cost += pos ? ep * qp : ev * qv;
             }
         }
-        // ---- assemble D_t into S (adding to the Schur part already there for t > 0) and r_t into Bm[:, dim]
+        // ---- S = D_t (+ Schur term already in the tile for t > 0); padding rows/cols = identity
         const double ct = (t > 0) ? (double)jb[t * (D + 1) + D] : 0.0;
-        for (int e = lane; e < GP_N * GP_N; e += 64) {
-            const int i = e >> 4, j = e & 15;
+        double* S = Sb[cur];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = ei, j = ej0 + q;
+            double v;
             if (i < dim && j < dim) {
-                double v = (t > 0) ? S[i * GP_LD + j] : 0.0;   // S currently holds -(U^T F_{t-1}) for t > 0
+                v = (t > 0) ? S[i * GP_LD + j] : 0.0;
                 const bool ip = i < D, jp = j < D;
                 const int ii = ip ? i : i - D, jj = jp ? j : j - D;
                 if (ii == jj) {
@@ -233,11 +199,15 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
                     v += K.trust ? K.delta * diag_mean[(size_t)t * dim + i] : K.delta;
                 }
                 if (t > 0 && ip && jp) v += K.kc * (double)jb[t * (D + 1) + i] * (double)jb[t * (D + 1) + j];
-                S[i * GP_LD + j] = v;
+            } else {
+                v = (i == j) ? 1.0 : 0.0;
             }
+            S[i * GP_LD + j] = v;
         }
+        // ---- r_t
+        double gnext = 0.0;
         if (lane < dim) {
-            double r = (t > 0) ? Bm[lane * GP_LDB + dim] : 0.0;   // carries g-part and -U^T z_{t-1} from the previous step
+            double r = (t > 0) ? rcarry : 0.0;
             if (t == 0) {
                 const double es = (double)start[(size_t)b * dim + lane] - xs[0][lane];
                 r += K.ks * es;
@@ -250,80 +220,95 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
             }
             if (t < H - 1) r += pqe_i;
             if (t > 0 && lane < D) r += K.kc * (double)jb[t * (D + 1) + lane] * ct;
-            gnext[lane] = -qe_i;                                   // contribution of factor t to g_{t+1}
-            Bm[lane * GP_LDB + dim] = r;
+            gnext = -qe_i;                                         // contribution of factor t to g_{t+1}
+            rv[lane] = r;
         }
         if (lane == 0 && t > 0) cost += K.kc * ct * ct;
-        // U into Bm[:, 0..dim)
-        for (int e = lane; e < GP_N * GP_N; e += 64) {
-            const int i = e >> 4, j = e & 15;
-            if (i < dim && j < dim) {
-                const bool ip = i < D, jp = j < D;
-                const int ii = ip ? i : i - D, jj = jp ? j : j - D;
-                Bm[i * GP_LDB + j] = (ii == jj) ? (ip ? (jp ? u00 : u01) : (jp ? u10 : u11)) : 0.0;
-            }
-        }
         wave_sync();
-        // ---- factor and solve S [F | z] = [U | r]
-        tile_cholesky(S, dim, lane);
-        tile_chol_solve(S, Bm, dim, (t < H - 1) ? dim + 1 : dim + 1, lane);
-        // ---- store F_t, z_t
-        double* wt = wF + (size_t)t * (GP_N * GP_N + GP_N);
-        for (int e = lane; e < GP_N * GP_N; e += 64) {
-            const int i = e >> 4, j = e & 15;
-            if (i < dim && j < dim) wt[i * GP_N + j] = Bm[i * GP_LDB + j];
+        // ---- W = S^-1 : Gauss-Jordan, one synchronisation per elimination step
+        for (int k = 0; k < dim; ++k) {
+            const double* A = Sb[cur];
+            double* Bn = Sb[cur ^ 1];
+            const double pinv = 1.0 / A[k * GP_LD + k];
+            const double aik = A[ei * GP_LD + k];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = ej0 + q;
+                const double akj = A[k * GP_LD + j];
+                double v;
+                if (ei == k) v = (j == k) ? pinv : akj * pinv;
+                else if (j == k) v = -aik * pinv;
+                else v = A[ei * GP_LD + j] - aik * akj * pinv;
+                Bn[ei * GP_LD + j] = v;
+            }
+            cur ^= 1;
+            wave_sync();
         }
-        if (lane < dim) wt[GP_N * GP_N + lane] = Bm[lane * GP_LDB + dim];
+        const double* W = Sb[cur];
+        // ---- z = W r ; store W_t, z_t
+        double* wt = wW + (size_t)t * GP_WS_PER_T;
+        double zi = 0.0;
+        if (lane < dim) {
+            for (int j = 0; j < dim; ++j) zi = fma(W[lane * GP_LD + j], rv[j], zi);
+            zv[lane] = zi;
+            wt[GP_N * GP_N + lane] = zi;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wt[ei * GP_N + ej0 + q] = W[ei * GP_LD + ej0 + q];
         wave_sync();
         if (t < H - 1) {
-            // ---- S <- -(U^T F_t),  r_{t+1} <- gnext - U^T z_t     (U^T = -(Qi Phi): 2x2 Kronecker)
-            // (U^T v)_i : pos row i: u00 v_p + u10 v_v ; vel row: u01 v_p + u11 v_v
+            // ---- next tile: -(U^T W U), block (a,b) (i',j') = -sum_{c,e} U[c][a] U[e][b] W[i'+cD][j'+eD]
             double newS[4];
 #pragma unroll
-            for (int cnt = 0; cnt < 4; ++cnt) {
-                const int e = lane + 64 * cnt;
-                const int i = e >> 4, j = e & 15;
+            for (int q = 0; q < 4; ++q) {
+                const int i = ei, j = ej0 + q;
                 double v = 0.0;
                 if (i < dim && j < dim) {
-                    const bool ip = i < D;
-                    const int ii = ip ? i : i - D;
-                    const double fp = Bm[ii * GP_LDB + j], fv = Bm[(ii + D) * GP_LDB + j];
-                    v = -(ip ? u00 * fp + u10 * fv : u01 * fp + u11 * fv);
+                    const bool ip = i < D, jp = j < D;
+                    const int ii = ip ? i : i - D, jj = jp ? j : j - D;
+                    const double wpp = W[ii * GP_LD + jj], wpv = W[ii * GP_LD + jj + D];
+                    const double wvp = W[(ii + D) * GP_LD + jj], wvv = W[(ii + D) * GP_LD + jj + D];
+                    const double uca0 = ip ? u00 : u01, uca1 = ip ? u10 : u11;   // U[c][a], c = 0,1
+                    const double ueb0 = jp ? u00 : u01, ueb1 = jp ? u10 : u11;   // U[e][b], e = 0,1
+                    v = -(uca0 * (wpp * ueb0 + wpv * ueb1) + uca1 * (wvp * ueb0 + wvv * ueb1));
                 }
-                newS[cnt] = v;
+                newS[q] = v;
             }
-            double rn = 0.0;
+            // r_{t+1} carry = gnext - U^T z
             if (lane < dim) {
                 const bool ip = lane < D;
                 const int ii = ip ? lane : lane - D;
-                const double zp = Bm[ii * GP_LDB + dim], zv = Bm[(ii + D) * GP_LDB + dim];
-                rn = gnext[lane] - (ip ? u00 * zp + u10 * zv : u01 * zp + u11 * zv);
+                const double zp = zv[ii], zvv = zv[ii + D];
+                rcarry = gnext - (ip ? u00 * zp + u10 * zvv : u01 * zp + u11 * zvv);
             }
             wave_sync();
+            double* Sn = Sb[cur];
 #pragma unroll
-            for (int cnt = 0; cnt < 4; ++cnt) {
-                const int e = lane + 64 * cnt;
-                const int i = e >> 4, j = e & 15;
-                if (i < dim && j < dim) S[i * GP_LD + j] = newS[cnt];
-            }
-            if (lane < dim) Bm[lane * GP_LDB + dim] = rn;
+            for (int q = 0; q < 4; ++q) Sn[ei * GP_LD + ej0 + q] = newS[q];
             wave_sync();
         }
     }
-    // ---- backward substitution and update: dtheta_t = z_t - F_t dtheta_{t+1}
+    // ---- backward substitution and update: dtheta_t = z_t - W_t (U dtheta_{t+1})
     for (int t = H - 1; t >= 0; --t) {
-        const double* wt = wF + (size_t)t * (GP_N * GP_N + GP_N);
+        const double* wt = wW + (size_t)t * GP_WS_PER_T;
         double d = 0.0;
         if (lane < dim) {
             d = wt[GP_N * GP_N + lane];
             if (t < H - 1) {
-                for (int j = 0; j < dim; ++j) d -= wt[lane * GP_N + j] * dth[j];
+                for (int j = 0; j < dim; ++j) d -= wt[lane * GP_N + j] * zv[j];   // zv holds U dtheta_{t+1}
             }
         }
         wave_sync();
         if (lane < dim) {
             dth[lane] = d;
             xb[t * dim + lane] = (float)((double)xb[t * dim + lane] + K.step * d);
+        }
+        wave_sync();
+        if (lane < dim) {   // v = U dtheta_t for the next (earlier) waypoint
+            const bool ip = lane < D;
+            const int ii = ip ? lane : lane - D;
+            const double dp = dth[ii], dv = dth[ii + D];
+            zv[lane] = ip ? u00 * dp + u01 * dv : u10 * dp + u11 * dv;
         }
         wave_sync();
     }
@@ -340,7 +325,7 @@ extern "C" size_t mpb_gpmp2_workspace_bytes(int B, int H, int D) {
     if (!gp_shape_ok(B, H, D)) return 0;
     const size_t jac = (size_t)B * H * (D + 1) * sizeof(float);
     const size_t diag = 2 * (size_t)H * 2 * D * sizeof(double);
-    const size_t fz = (size_t)B * H * (GP_N * GP_N + GP_N) * sizeof(double);
+    const size_t fz = (size_t)B * H * GP_WS_PER_T * sizeof(double);
     return ((jac + 255) / 256) * 256 + ((diag + 255) / 256) * 256 + fz;
 }
 
