@@ -74,6 +74,7 @@ int mpb_cost_collision_grad(const float *trajs, const float *geom, float *out, f
  * L (H,H): scale_tril of the noise distribution, Sigma (H,H) = inverse(R): constants the host
  *      computes exactly as the reference does (stomp.py:63-64, :88-95) -- SURVEY.md H2.
  * mpb_stomp_step runs the fused path (sample+cost kernel, update kernel per iteration).
+ * mpb_stomp_update accepts Sigma == NULL (update without the covariance product, used by StochGPMP).
  * mpb_stomp_sample / mpb_stomp_update expose the two halves (the two kernels of one iteration) so that
  * a caller-supplied cost callable (any Python cost on device tensors) can sit between them; with
  * geom + costs given, mpb_stomp_sample is exactly the first kernel of mpb_stomp_step.
@@ -169,6 +170,23 @@ int mpb_mppi_step(float *mean, const float *eps, const float *scale_tril, const 
                   int NP, int S, int T, int c, int control_type, float dt,
                   float k_sigma, float weight, float temp, float step_size,
                   int n_iters, uint64_t seed, uint32_t iter0, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * StochGPMP -- replaces StochGPMP.sample_and_eval / _get_costs / _update_distribution
+ * (stoch_gpmp.py:235-279).  One iteration is three calls:
+ *   mpb_gp_prior_sample   samples (P*S,H,2D) around the particle means from the sampling prior (below);
+ *   mpb_stoch_gpmp_costs  costs (P,S) = CostGP.eval + CostGoalPrior.eval + CostCollision.eval
+ *                         (cost_functions.py:271-289, :520-536, :171-189) + T * V Sigma^-1 U^T
+ *                         (stoch_gpmp.py:239-241), evaluated factor-wise without the dense Sigma^-1;
+ *                         means (P,H,2D) particle means, start / goal (P,2D);
+ *   mpb_stomp_update      with Sigma == NULL: softmax over S and means += lr * sum_s w_s (sample_s - mean)
+ *                         (stoch_gpmp.py:267-275, no covariance in the update).
+ * ------------------------------------------------------------------------------------------- */
+int mpb_stoch_gpmp_costs(const float *samples, const float *means, const float *start, const float *goal,
+                         const float *geom, float *costs, int P, int S, int H, int D, float dt,
+                         float sigma_start, float sigma_gp, float sigma_goal, float sigma_coll,
+                         float sigma_start_sample, float sigma_gp_sample, float sigma_goal_sample,
+                         float temperature, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * GP-prior initial particles -- replaces OptimizationPlanner.get_random_trajs (base.py:155-202) over

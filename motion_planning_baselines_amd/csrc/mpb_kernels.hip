@@ -197,6 +197,24 @@ __global__ __launch_bounds__(256) void stomp_sample_cost_kernel(
 // ------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef MPB_STAMPS  // diagnostic build only: per-wave s_memtime stamps of the phases of kernel A
+__device__ unsigned long long g_stamps[4096 * 8];
+#define MPB_STAMP(k)                                                                              \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        unsigned long long t_;                                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x * 4 + (threadIdx.x >> 6) < 4096)                \
+            g_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = t_;                       \
+    } while (0)
+extern "C" int mpb_debug_read_stamps(unsigned long long* dst, int n) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : 3;
+}
+#else
+#define MPB_STAMP(k)
+#endif
+
 // Standard normals of the H = 64 fast path: one Philox4x32-7 call per (particle, sample, channel j,
 // k-group g, quarter q4) yields eps[j][k] for k = 16*q4 + 4*r + g, r = 0..3.  Shared by the sampling
 // kernel and the eps-space update kernel so both see the same noise without it ever touching memory.
@@ -215,6 +233,7 @@ __global__ __launch_bounds__(256, 4) void stomp_sample_cost_h64_kernel(
     int P, int S, float k_sigma, float weight, uint32_t seed_lo, uint32_t seed_hi, uint32_t iter,
     uint32_t particle_offset) {
     constexpr int H = 64;
+    MPB_STAMP(0);
     __shared__ __attribute__((aligned(16))) float Lp[H * H];             // permuted L, 16 KB
     __shared__ __attribute__((aligned(16))) float Nt[4][H * NT_STRIDE];  // per-wave noise tile, 4 x 5 KB
     __shared__ float4 otab[MPB_GRID_MAX_SPH + 1];                        // obstacle table of the broad phase
@@ -238,6 +257,7 @@ __global__ __launch_bounds__(256, 4) void stomp_sample_cost_h64_kernel(
     const int p = live ? r / S : 0, s = live ? r - p * S : 0;
     const int j = lane & 15, g = lane >> 4;
 
+    MPB_STAMP(1);
     // ---- B operand: eps[c=j][k=4ks+g], ks = 0..15
     float e[16];
     if (eps != nullptr) {
@@ -254,6 +274,7 @@ __global__ __launch_bounds__(256, 4) void stomp_sample_cost_h64_kernel(
             e[4 * q4 + 0] = n[0]; e[4 * q4 + 1] = n[1]; e[4 * q4 + 2] = n[2]; e[4 * q4 + 3] = n[3];
         }
     }
+    MPB_STAMP(2);
     // ---- N = L * eps on the matrix cores
     const f32x4* Lp4 = reinterpret_cast<const f32x4*>(Lp);
     float* nt = Nt[wave];
@@ -272,7 +293,9 @@ __global__ __launch_bounds__(256, 4) void stomp_sample_cost_h64_kernel(
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) nt[(16 * m + 4 * g + rr) * NT_STRIDE + j] = acc[rr];
     }
+    MPB_STAMP(3);
     __syncthreads();  // tile written by lane = channel, read by lane = waypoint
+    MPB_STAMP(4);
     // ---- lane = waypoint h
     const int h = lane;
     float nz[16];
@@ -314,6 +337,7 @@ __global__ __launch_bounds__(256, 4) void stomp_sample_cost_h64_kernel(
         }
     }
     (void)srow;
+    MPB_STAMP(5);
     if (WITH_COST) {
         const GeomView G = geom_view(geom);
         float q[MPB_MAX_DOF], dq[MPB_MAX_DOF];
@@ -327,6 +351,7 @@ __global__ __launch_bounds__(256, 4) void stomp_sample_cost_h64_kernel(
             __syncthreads();
             grid_stage(G, gridw, otab, threadIdx.x, 256);
             __syncthreads();
+            MPB_STAMP(6);
             if (live && h >= 1) c = waypoint_cost_grid(G, gridw, otab, q);
         } else if (live && h >= 1) {
             c = waypoint_cost<false>(G, q, dq);
@@ -334,6 +359,7 @@ __global__ __launch_bounds__(256, 4) void stomp_sample_cost_h64_kernel(
         const double csum = wave_sum_f64((double)c);
         if (live && lane == 0) costs[r] = weight * (k_sigma * (float)csum);
     }
+    MPB_STAMP(7);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -355,7 +381,7 @@ __global__ __launch_bounds__(1024) void stomp_update_kernel(
     __shared__ float red[16];
     const int p = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-    if (sigma_in_lds)
+    if (sigma_in_lds && Sigma != nullptr)
         for (int i = tid; i < H * H; i += blockDim.x) sig[i] = lr * Sigma[i];
     // ---- softmax over S
     float m = -3.0e38f;
@@ -409,7 +435,9 @@ __global__ __launch_bounds__(1024) void stomp_update_kernel(
     for (int i = tid; i < n; i += blockDim.x) {
         const int h = i / d, c = i - h * d;
         float acc = 0.f;
-        if (sigma_in_lds) {
+        if (Sigma == nullptr) {
+            acc = lr * delta[i];      // update without the covariance product (StochGPMP, stoch_gpmp.py:272-275)
+        } else if (sigma_in_lds) {
             for (int k = 0; k < H; ++k) acc = fmaf(sig[h * H + k], delta[k * d + c], acc);
         } else {
             for (int k = 0; k < H; ++k) acc = fmaf(lr * Sigma[h * H + k], delta[k * d + c], acc);
@@ -644,7 +672,7 @@ static bool update_lds(int S, int H, int d, size_t& bytes, int& sigma_in_lds) {
 static bool launch_update(float* means, const float* samples, const float* costs, float* weights, const float* Sigma,
                           int P, int S, int H, int d, float lr, float temperature, hipStream_t st) {
     const int n = H * d;
-    if ((n & 3) == 0 && n <= 1024 && H <= 64 && (H & 3) == 0 && S <= 64) {
+    if (Sigma != nullptr && (n & 3) == 0 && n <= 1024 && H <= 64 && (H & 3) == 0 && S <= 64) {
         const int n4 = n >> 2;
         const int SG = (1024 / n4) < 4 ? (1024 / n4) : 4;
         const size_t lds = (size_t)n * 4 + (size_t)SG * n4 * 16;
@@ -728,7 +756,7 @@ extern "C" int mpb_stomp_sample(const float* means, const float* eps, float* sam
 extern "C" int mpb_stomp_update(float* means, const float* samples, const float* costs, float* weights,
                                 const float* Sigma, int P, int S, int H, int d, float lr, float temperature,
                                 void* stream) {
-    if (!means || !samples || !costs || !weights || !Sigma) return fail(MPB_E_INVALID, "%s: null pointer", __func__);
+    if (!means || !samples || !costs || !weights) return fail(MPB_E_INVALID, "%s: null pointer", __func__);
     if (P < 0 || S < 1 || H < 3 || H > MPB_MAX_H || d < 1 || d > MPB_MAX_D) return fail(MPB_E_INVALID, "%s: bad shape", __func__);
     if (!(temperature > 0.f)) return fail(MPB_E_INVALID, "%s: temperature must be > 0", __func__);
     if (P == 0) return MPB_OK;

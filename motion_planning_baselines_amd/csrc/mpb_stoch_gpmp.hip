@@ -1,0 +1,101 @@
+// mpb_stoch_gpmp.hip -- cost of StochGPMP's samples (stoch_gpmp.py:235-242).
+//
+// costs = CostComposite.eval(samples) + T * V Sigma^-1 U^T with the cost list of
+// build_gpmp2_cost_composite (gpmp2.py:23-91): CostGP.eval (cost_functions.py:271-289: start prior +
+// GP factors), CostGoalPrior.eval (:520-536), CostCollision.eval (:171-189).  Sigma^-1 = A^T Q^-1 A is the
+// precision of the SAMPLING prior (mp_priors_multi.py:213-251), so v^T Sigma^-1 u = (A v)^T Q^-1 (A u):
+// the importance term is the bilinear twin of the GP cost and is evaluated factor by factor -- the
+// dense N x N matrix of the reference (N = 2D*H) is never formed.
+// One wave per sample trajectory, lane = waypoint; every term is local to (row t, row t+1).
+#include "mpb_common.h"
+#include "mpb_geom.h"
+
+struct SgConst {
+    float dt, ks, kgp, kg, kc;      // cost weights 1/sigma^2 (start, gp, goal prior, collision)
+    float ss, sgp, sg;              // sampling-prior weights 1/sigma^2 (start, gp, goal)
+    float temperature;
+};
+
+__global__ __launch_bounds__(256) void stoch_gpmp_cost_kernel(const float* __restrict__ samples,
+                                                              const float* __restrict__ means,
+                                                              const float* __restrict__ start,
+                                                              const float* __restrict__ goal,
+                                                              const float* __restrict__ geom, float* __restrict__ costs,
+                                                              int P, int S, int H, int D, SgConst K) {
+    __shared__ unsigned gridw[MPB_GRID_MAX_CELLS];
+    __shared__ float4 otab[MPB_GRID_MAX_SPH + 1];
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // sample index p*S + s
+    const GeomView G = geom_view(geom);
+    const bool use_grid = grid_usable(G);
+    if (use_grid) {
+        grid_stage(G, gridw, otab, threadIdx.x, blockDim.x);
+        __syncthreads();
+    }
+    if (r >= P * S) return;
+    const int p = r / S;
+    const int dim = 2 * D;
+    const float dt = K.dt;
+    const float* xs = samples + (size_t)r * H * dim;
+    const float* us = means + (size_t)p * H * dim;
+    // Qi = [[12/dt^3, -6/dt^2],[-6/dt^2, 4/dt]] (gp_factor.py:42-50), scaled per use
+    const double qa = 12.0 / ((double)dt * dt * dt), qb = -6.0 / ((double)dt * dt), qc = 4.0 / (double)dt;
+    double acc = 0.0;
+    for (int t = lane; t < ((H + 63) & ~63); t += 64) {
+        if (t >= H) continue;
+        const float* x0 = xs + t * dim;
+        const float* u0 = us + t * dim;
+        // collision (waypoint 0 excluded)
+        if (t >= 1) {
+            float q[MPB_MAX_DOF], dq[MPB_MAX_DOF];
+#pragma unroll
+            for (int i = 0; i < MPB_MAX_DOF; ++i) q[i] = (i < D) ? x0[i] : 0.f;
+            const float c = use_grid ? waypoint_cost_grid(G, gridw, otab, q) : waypoint_cost<false>(G, q, dq);
+            acc += (double)K.kc * (double)c;
+        }
+        for (int i = 0; i < D; ++i) {
+            const double xp = x0[i], xv = x0[D + i], up = u0[i], uv = u0[D + i];
+            if (t == 0) {   // start prior (unary_factor.py:24) and its bilinear twin
+                const double ep = (double)start[(size_t)p * dim + i] - xp, ev = (double)start[(size_t)p * dim + D + i] - xv;
+                acc += (double)K.ks * (ep * ep + ev * ev);
+                acc += (double)K.temperature * (double)K.ss * (xp * up + xv * uv);
+            }
+            if (t == H - 1) {   // goal prior
+                const double ep = (double)goal[(size_t)p * dim + i] - xp, ev = (double)goal[(size_t)p * dim + D + i] - xv;
+                acc += (double)K.kg * (ep * ep + ev * ev);
+                acc += (double)K.temperature * (double)K.sg * (xp * up + xv * uv);
+            }
+            if (t < H - 1) {   // GP factor t: e = x_{t+1} - Phi x_t (gp_factor.py:52-56)
+                const double xp1 = x0[dim + i], xv1 = x0[dim + D + i], up1 = u0[dim + i], uv1 = u0[dim + D + i];
+                const double exp_ = xp1 - (xp + (double)dt * xv), exv = xv1 - xv;
+                const double eup = up1 - (up + (double)dt * uv), euv = uv1 - uv;
+                acc += (double)K.kgp * (qa * exp_ * exp_ + 2.0 * qb * exp_ * exv + qc * exv * exv);
+                acc += (double)K.temperature * (double)K.sgp *
+                       (qa * exp_ * eup + qb * (exp_ * euv + exv * eup) + qc * exv * euv);
+            }
+        }
+    }
+    acc = wave_sum_f64(acc);
+    if (lane == 0) costs[r] = (float)acc;
+}
+
+extern "C" int mpb_stoch_gpmp_costs(const float* samples, const float* means, const float* start, const float* goal,
+                                    const float* geom, float* costs, int P, int S, int H, int D, float dt,
+                                    float sigma_start, float sigma_gp, float sigma_goal, float sigma_coll,
+                                    float sigma_start_sample, float sigma_gp_sample, float sigma_goal_sample,
+                                    float temperature, void* stream) {
+    if (!samples || !means || !start || !goal || !geom || !costs) return mpb_fail(MPB_E_INVALID, "mpb_stoch_gpmp_costs: null pointer");
+    if (P < 0 || S < 1 || H < 2 || H > 4096 || D < 1 || D > MPB_MAX_DOF) return mpb_fail(MPB_E_INVALID, "mpb_stoch_gpmp_costs: bad shape");
+    if (P == 0) return MPB_OK;
+    SgConst K;
+    K.dt = dt;
+    K.ks = 1.f / (sigma_start * sigma_start); K.kgp = 1.f / (sigma_gp * sigma_gp);
+    K.kg = 1.f / (sigma_goal * sigma_goal); K.kc = 1.f / (sigma_coll * sigma_coll);
+    K.ss = 1.f / (sigma_start_sample * sigma_start_sample); K.sgp = 1.f / (sigma_gp_sample * sigma_gp_sample);
+    K.sg = 1.f / (sigma_goal_sample * sigma_goal_sample);
+    K.temperature = temperature;
+    const int B = P * S;
+    hipLaunchKernelGGL(stoch_gpmp_cost_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, samples, means, start,
+                       goal, geom, costs, P, S, H, D, K);
+    return mpb_check_launch("mpb_stoch_gpmp_costs");
+}

@@ -120,7 +120,7 @@ def stomp_update(means, samples, costs, weights, Sigma, lr, temperature):
     _chk(samples, (P, S, H, d), 'samples')
     _chk(costs, (P, S), 'costs')
     _chk(weights, (P, S), 'weights')
-    _chk(Sigma, (H, H), 'Sigma')
+    _chk(Sigma, (H, H), 'Sigma', allow_none=True)   # None: update without the covariance product (StochGPMP)
     _lib.check(_lib.lib().mpb_stomp_update(_ptr(means), _ptr(samples), _ptr(costs), _ptr(weights), _ptr(Sigma),
                                           P, S, H, d, float(lr), float(temperature), _stream()), 'mpb_stomp_update')
 
@@ -226,3 +226,19 @@ def gp_prior_sample(means, eps, Udiag, Uoff, n, D, seed=0):
     _lib.check(_lib.lib().mpb_gp_prior_sample(_ptr(out), _ptr(means), _ptr(eps), _ptr(Udiag), _ptr(Uoff), G, n, H, D,
                                              int(seed) & (2 ** 64 - 1), _stream()), 'mpb_gp_prior_sample')
     return out
+
+
+def stoch_gpmp_costs(samples, means, start, goal, geom, costs, S, sig_cost, sig_sample, dt, temperature):
+    """costs (P,S) of StochGPMP samples (P*S,H,2D): composite cost + importance term.
+    sig_cost = (start, gp, goal_prior, coll); sig_sample = (start, gp, goal)."""
+    B, H, dim = samples.shape
+    P = B // S
+    _chk(samples, (P * S, H, dim), 'samples')
+    _chk(means, (P, H, dim), 'means')
+    _chk(start, (P, dim), 'start')
+    _chk(goal, (P, dim), 'goal')
+    _chk(costs, (P, S), 'costs')
+    _lib.check(_lib.lib().mpb_stoch_gpmp_costs(
+        _ptr(samples), _ptr(means), _ptr(start), _ptr(goal), _ptr(geom.buf), _ptr(costs), P, S, H, dim // 2, float(dt),
+        float(sig_cost[0]), float(sig_cost[1]), float(sig_cost[2]), float(sig_cost[3]), float(sig_sample[0]),
+        float(sig_sample[1]), float(sig_sample[2]), float(temperature), _stream()), 'mpb_stoch_gpmp_costs')

@@ -1,0 +1,101 @@
+"""StochGPMP with the reference's class surface (mp_baselines/planners/stoch_gpmp.py), iterations on the GPU.
+
+Per iteration (stoch_gpmp.py:289-298): sample S trajectories per particle from the full GP prior around the
+particle mean, evaluate the composite cost + importance term, softmax, mean += step * sum_s w_s (x_s - mean).
+The reference materialises a dense N x N precision / scale_tril (N = 2D*H); here the prior's
+(2x2) (x) I_D block-bidiagonal factor is used for sampling (csrc/mpb_prior.hip) and the importance term is
+evaluated factor-wise (csrc/mpb_stoch_gpmp.hip).
+"""
+import torch
+
+from .. import ops
+from .base import OptimizationPlanner, gp_prior_factor
+
+
+class StochGPMP(OptimizationPlanner):
+    """Drop-in for mp_baselines.planners.stoch_gpmp.StochGPMP (ctor kwargs stoch_gpmp.py:16-38 plus the cost
+    kwargs of build_gpmp2_cost_composite: collision_fields (exactly one), sigma_start, sigma_gp, sigma_coll,
+    sigma_goal_prior).  Extra kwargs: noise 'torch_cpu' | 'philox', seed."""
+
+    def __init__(self, robot=None, n_dof=None, n_support_points=None, num_particles_per_goal=None, opt_iters=None,
+                 dt=None, start_state=None, step_size=1., multi_goal_states=None, initial_particle_means=None,
+                 sigma_start_init=None, sigma_start_sample=None, sigma_goal_init=None, sigma_goal_sample=None,
+                 sigma_gp_init=None, sigma_gp_sample=None, num_samples=2, temperature=1., collision_fields=None,
+                 sigma_start=1e-5, sigma_gp=1e-2, sigma_coll=1e-5, sigma_goal_prior=1e-5, tensor_args=None,
+                 noise='torch_cpu', seed=0, **kwargs):
+        super().__init__(name='StochGPMP', n_dof=n_dof, n_support_points=n_support_points,
+                         num_particles_per_goal=num_particles_per_goal, opt_iters=opt_iters, dt=dt,
+                         start_state=start_state, initial_particle_means=initial_particle_means,
+                         multi_goal_states=multi_goal_states, sigma_start_init=sigma_start_init,
+                         sigma_goal_init=sigma_goal_init, sigma_gp_init=sigma_gp_init, pos_only=False,
+                         tensor_args=tensor_args)
+        if not collision_fields or len(collision_fields) != 1:
+            raise NotImplementedError('StochGPMP on the GPU takes exactly one CollisionField')
+        assert multi_goal_states is not None, 'StochGPMP kernels need goal states'
+        self.robot = robot
+        self.d_state_opt = 2 * n_dof
+        self.num_samples = num_samples
+        self.step_size = step_size
+        self.temperature = temperature
+        self.sig_sample = (sigma_start_sample, sigma_gp_sample, sigma_goal_sample)
+        self.sig_cost = (sigma_start, sigma_gp, sigma_goal_prior, sigma_coll)
+        self.noise, self.seed, self._iter = noise, int(seed), 0
+        self.geom = ops.DeviceGeometry(robot, collision_fields[0], self.device)
+        H, D = n_support_points, n_dof
+        Ud, Uo = gp_prior_factor(H, dt, sigma_start_sample, sigma_gp_sample, sigma_goal_sample)
+        f64 = lambda a: torch.as_tensor(a, dtype=torch.float64).to(self.device).contiguous()
+        self._Ud, self._Uo = f64(Ud), f64(Uo)
+        self._weights = None
+        self.reset(initial_particle_means=initial_particle_means)
+
+    def reset(self, start_state=None, multi_goal_states=None, initial_particle_means=None):
+        """stoch_gpmp.py:97-141."""
+        if initial_particle_means is None:
+            m = self.get_random_trajs()
+        elif isinstance(initial_particle_means, str) and initial_particle_means == 'const_vel':
+            raise NotImplementedError("initial_particle_means='const_vel': pass the trajectories explicitly")
+        else:
+            m = initial_particle_means
+        if m.ndim == 4:
+            m = m.flatten(0, 1)
+        self._particle_means = m.to(device=self.device, dtype=torch.float32).contiguous()
+        P, dim = self.num_particles, self.d_state_opt
+        assert self._particle_means.shape[0] == P
+        ss = self.start_state.to(device=self.device, dtype=torch.float32).reshape(-1, dim)
+        self._start = ss.expand(P, dim).contiguous()
+        gs = self.multi_goal_states.to(device=self.device, dtype=torch.float32).reshape(-1, dim)
+        self._goal = gs.repeat_interleave(self.num_particles_per_goal, 0).contiguous()
+        self.costs = torch.zeros(P, self.num_samples, device=self.device, dtype=torch.float32)
+        self._weights_buf = torch.empty(P, self.num_samples, device=self.device, dtype=torch.float32)
+        self.state_samples = self._sample()      # the reference samples once in reset (:141)
+
+    def _sample(self):
+        P, S, H, dim = self.num_particles, self.num_samples, self.n_support_points, self.d_state_opt
+        eps = None
+        if self.noise != 'philox':   # MultivariateNormal.sample((S,)) of batch shape (P,) and event shape (M,)
+            eps = torch.empty(S, P, H * dim, dtype=torch.float64).normal_().to(self.device)
+        out = ops.gp_prior_sample(self._particle_means.double().contiguous(), eps, self._Ud, self._Uo, S, self.n_dof,
+                                  seed=self.seed + self._iter)
+        self._iter += 1
+        return out.reshape(P, S, H, dim)
+
+    def optimize(self, opt_iters=None, debug=False, **observation):
+        """stoch_gpmp.py:281-313."""
+        if opt_iters is None:
+            opt_iters = self.opt_iters
+        P, S, H, dim = self.num_particles, self.num_samples, self.n_support_points, self.d_state_opt
+        for _ in range(opt_iters):
+            self.state_samples = self._sample()
+            flat = self.state_samples.reshape(P * S, H, dim)
+            ops.stoch_gpmp_costs(flat, self._particle_means, self._start, self._goal, self.geom, self.costs, S,
+                                 self.sig_cost, self.sig_sample, self.dt, self.temperature)
+            ops.stomp_update(self._particle_means, self.state_samples, self.costs, self._weights_buf, None,
+                             self.step_size, self.temperature)
+        self._weights = self._weights_buf.reshape(P, S, 1, 1)
+        self._recent_weights = self._weights
+        return self._get_traj()
+
+    def get_recent_samples(self):
+        D = self.n_dof
+        return (self.state_samples[..., :D].clone(), self._particle_means[..., :D].clone(),
+                self.state_samples[..., -D:].clone(), self._particle_means[..., -D:].clone(), self._weights.clone())

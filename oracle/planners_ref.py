@@ -343,3 +343,34 @@ def mppi_iteration(mean, eps, scale_tril, cov_inv, state, goal_state, dt, ctrl_m
     w = torch.softmax(-costs / temp, dim=0)                  # mppi.py:73-76
     new_mean = mean + step_size * (w.reshape(-1, 1, 1) * (U - mean.unsqueeze(0))).sum(0)
     return dict(controls=U, states=X, costs=costs, weights=w, mean=new_mean)
+
+
+# ------------------------------------------------------------------------------------------------
+# StochGPMP  (mp_baselines/planners/stoch_gpmp.py)
+# ------------------------------------------------------------------------------------------------
+
+def goal_prior_eval(x, goal_state, sigma_goal):
+    """CostGoalPrior.eval for one goal (cost_functions.py:520-536): (goal - x_{H-1})^T K (goal - x_{H-1})."""
+    err = goal_state - x[:, -1]
+    return (err * err).sum(-1) / sigma_goal ** 2
+
+
+def stoch_gpmp_iteration(means, eps, scale_tril, Sigma_inv, cost_fn, temperature, step_size):
+    """One pass of StochGPMP.optimize's loop body (stoch_gpmp.py:289-298): sample_and_eval (:244-265) with
+    _get_costs (:235-242: composite cost + T * V Sigma^-1 U^T) and _update_distribution (:267-279).
+
+    means (P,H,dim); eps (S,P,M) standard normals in MultivariateNormal's draw order; scale_tril (M,M) of the
+    sampling prior; Sigma_inv (M,M) its precision.  Returns dict(samples (P,S,H,dim), costs, weights, means).
+    """
+    P, H, dim = means.shape
+    S = eps.shape[0]
+    M = H * dim
+    smp = means.reshape(1, P, M) + (scale_tril @ eps.unsqueeze(-1)).squeeze(-1)      # mp_priors_multi.py:253-256
+    samples = smp.view(S, P, H, dim).transpose(1, 0)
+    costs = cost_fn(samples.reshape(P * S, H, dim)).reshape(P, S)
+    V = samples.reshape(P, S, M)
+    U = means.reshape(P, 1, M)
+    costs = costs + temperature * (V @ Sigma_inv @ U.transpose(1, 2)).squeeze(2)     # stoch_gpmp.py:239-241
+    w = torch.softmax(-costs / temperature, dim=1)
+    grad = (w.reshape(P, S, 1, 1) * (samples - means.unsqueeze(1))).sum(1)
+    return dict(samples=samples, costs=costs, weights=w, means=means + step_size * grad)

@@ -29,6 +29,7 @@ from mp_baselines.planners.stomp import STOMP  # noqa: E402
 from mp_baselines.planners.chomp import CHOMP  # noqa: E402
 from mp_baselines.planners.gpmp2 import GPMP2  # noqa: E402
 from mp_baselines.planners.mppi import MPPI  # noqa: E402
+from mp_baselines.planners.stoch_gpmp import StochGPMP  # noqa: E402
 from mp_baselines.planners.dynamics.point import PointParticleDynamics  # noqa: E402
 from mp_baselines.planners.costs.cost_functions import CostCollision, CostComposite  # noqa: E402
 from mp_baselines.planners.costs.factors.mp_priors_multi import MultiMPPrior  # noqa: E402
@@ -212,6 +213,48 @@ def gen_gpmp2(name, robot, field, start, goal, B, H, dt, iters, seed, ta, sig=No
     print(name, 'costs', rec['costs'][0][:3], '->', rec['costs'][-1][:3])
 
 
+def gen_stoch_gpmp(name, robot, field, start, goal, P, S, H, dt, iters, seed, ta, temperature=1.0, step_size=0.5,
+                   sig_sample=(1e-3, 1e-3, 0.5), sig_cost=None, init_noise=0.02):
+    """StochGPMP (stoch_gpmp.py): samples from the full GP prior around each particle, composite cost
+    (GP + goal prior + collision) + importance term, softmax update without Sigma."""
+    sig_cost = sig_cost or dict(sigma_start=1e-2, sigma_gp=1.0, sigma_coll=1e-1, sigma_goal_prior=1e-2)
+    rr, rf = make_ref_geometry(robot, field, ta)
+    start, goal = start.to(**ta), goal.to(**ta)
+    g = torch.Generator().manual_seed(seed + 1000)
+    means0 = straight_line_means(start.float(), goal.float(), H, dt, P, False, noise=init_noise, gen=g).to(**ta)
+    torch.manual_seed(seed)
+    with EpsRecorder() as rec:
+        pl = StochGPMP(robot=rr, n_dof=robot.q_dim, n_support_points=H, num_particles_per_goal=P, opt_iters=1, dt=dt,
+                       start_state=start, step_size=step_size, multi_goal_states=goal.unsqueeze(0),
+                       initial_particle_means=means0.clone().unsqueeze(0),
+                       sigma_start_init=1e-3, sigma_goal_init=1e-3, sigma_gp_init=1.0,
+                       sigma_start_sample=sig_sample[0], sigma_goal_sample=sig_sample[1], sigma_gp_sample=sig_sample[2],
+                       num_samples=S, temperature=temperature, collision_fields=[rf], tensor_args=ta, **sig_cost)
+        n_reset = len(rec.draws)
+        out = dict(samples=[], costs=[], weights=[], means=[])
+        orig_costs = pl._get_costs
+
+        def rec_costs(**kw):     # the class does not keep the costs: record what sample_and_eval sees
+            c = orig_costs(**kw)
+            out['costs'].append(npf(c))
+            return c
+        pl._get_costs = rec_costs
+        for _ in range(iters):
+            pl.optimize(opt_iters=1)
+            out['samples'].append(npf(pl.state_samples))
+            out['weights'].append(npf(pl._weights).reshape(P, S))
+            out['means'].append(npf(pl._particle_means))
+    eps = np.stack([npf(e) for e in rec.draws[n_reset:]])
+    np.savez_compressed(
+        os.path.join(HERE, name + '.npz'), planner='stoch_gpmp', P=P, S=S, H=H, D=robot.q_dim, dt=dt,
+        temperature=temperature, step_size=step_size, dtype=str(ta['dtype']), start=npf(start), goal=npf(goal),
+        means0=npf(means0), eps=eps, sigma_start_sample=sig_sample[0], sigma_goal_sample=sig_sample[1],
+        sigma_gp_sample=sig_sample[2], Sigma_inv=npf(pl.Sigma_inv), **sig_cost,
+        **{k: np.stack(v) for k, v in out.items()}, **geom_arrays(robot, field))
+    print(name, 'eps', eps.shape, 'cost range', out['costs'][-1].min(), out['costs'][-1].max(),
+          'moved', np.abs(out['means'][-1] - npf(means0)).max())
+
+
 def gen_mppi(name, S, T, dt, iters, seed, cov_type='const_ctrl', control_std=(0.15, 0.15), temp=1.0,
              step_size=1.0, with_cost=False):
     ta = TA32
@@ -315,6 +358,11 @@ def main():
     gen_gpmp2('gpmp2_pm2d_h8_notr_f64', pm, dense, s2 * 0.5, g2 * 0.5, B=3, H=8, dt=0.04, iters=3, seed=0, ta=TA64,
               trust_region=False)
     gen_gpmp2('gpmp2_panda_h16_f64', panda, sph3, q[0], q[1], B=2, H=16, dt=5 / 16, iters=3, seed=1, ta=TA64)
+
+    # StochGPMP (fp64 reference run: its fp32 dense scale_tril is not reproducible)
+    gen_stoch_gpmp('sgpmp_pm2d_h16_f64', pm, dense, s2 * 0.5, g2 * 0.5, P=3, S=8, H=16, dt=0.08, iters=3, seed=0, ta=TA64)
+    gen_stoch_gpmp('sgpmp_panda_h16_f64', panda, sph3, q[0], q[1], P=2, S=8, H=16, dt=5 / 16, iters=3, seed=1, ta=TA64,
+                   sig_sample=(1e-3, 1e-3, 0.2))
 
     # MPPI
     gen_mppi('mppi_pm2d_const', S=32, T=64, dt=0.04, iters=5, seed=0)

@@ -169,3 +169,61 @@ def test_stomp_initialised_from_gp_prior(gpu_device):
     assert float((m[5:, -1, :2] - torch.tensor([0.8, -0.8])).abs().max()) < 0.02
     traj = pl.optimize(opt_iters=5)
     assert torch.isfinite(traj).all()
+
+
+@pytest.mark.parametrize('name', ['sgpmp_pm2d_h16_f64', 'sgpmp_panda_h16_f64'])
+def test_stoch_gpmp_vs_golden(gpu_device, name):
+    """StochGPMP teacher-forced iterations against the reference run in fp64 (its fp32 dense scale_tril of a
+    kappa ~ 1e10 precision is not reproducible); samples / costs / weights / means."""
+    from motion_planning_baselines_amd import ops
+    from motion_planning_baselines_amd.planners.base import gp_prior_factor
+    g = load_golden(name)
+    dev = gpu_device
+    geom = dev_geom(g, dev)
+    P, S, H, D = int(g['P']), int(g['S']), int(g['H']), int(g['D'])
+    dim = 2 * D
+    dt = float(g['dt'])
+    sig_sample = (float(g['sigma_start_sample']), float(g['sigma_gp_sample']), float(g['sigma_goal_sample']))
+    sig_cost = (float(g['sigma_start']), float(g['sigma_gp']), float(g['sigma_goal_prior']), float(g['sigma_coll']))
+    Ud, Uo = gp_prior_factor(H, dt, *sig_sample)
+    f64 = lambda a: torch.as_tensor(a, dtype=torch.float64).to(dev).contiguous()
+    start = torch.cat([T(g['start']).float(), torch.zeros(D)]).repeat(P, 1).contiguous().to(dev)
+    goal = torch.cat([T(g['goal']).float(), torch.zeros(D)]).repeat(P, 1).contiguous().to(dev)
+    costs = torch.empty(P, S, device=dev)
+    weights = torch.empty(P, S, device=dev)
+    prev = T(g['means0'])
+    for it in range(g['eps'].shape[0]):
+        means = prev.float().contiguous().to(dev)
+        smp = ops.gp_prior_sample(f64(prev), f64(g['eps'][it]), f64(Ud), f64(Uo), S, D).reshape(P, S, H, dim)
+        assert rel_err(smp, T(g['samples'][it])) < 1e-6
+        ops.stoch_gpmp_costs(smp.reshape(P * S, H, dim), means, start, goal, geom, costs, S, sig_cost, sig_sample, dt,
+                             float(g['temperature']))
+        ops.stomp_update(means, smp, costs, weights, None, float(g['step_size']), float(g['temperature']))
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(costs.cpu().numpy(), g['costs'][it], rtol=2e-6)
+        # costs ~ 1e6..1e7 with T = 1: the softmax is one-hot up to fp32 cost resolution
+        assert int(weights.argmax(1).cpu().eq(T(g['weights'][it]).argmax(1)).sum()) == P
+        assert rel_err(means, T(g['means'][it])) < 5e-3
+        prev = T(g['means'][it])
+
+
+def test_stoch_gpmp_class(gpu_device):
+    from motion_planning_baselines_amd.planners.stoch_gpmp import StochGPMP
+    g = load_golden('sgpmp_panda_h16_f64')
+    dev = gpu_device
+    robot, field = product_geometry_from_golden(g)
+    P, S, H, D = int(g['P']), int(g['S']), int(g['H']), int(g['D'])
+    pl = StochGPMP(robot=robot, n_dof=D, n_support_points=H, num_particles_per_goal=P, opt_iters=1, dt=float(g['dt']),
+                   start_state=T(g['start']).float().to(dev), step_size=float(g['step_size']),
+                   multi_goal_states=T(g['goal']).float().unsqueeze(0).to(dev),
+                   initial_particle_means=T(g['means0']).float().unsqueeze(0).to(dev),
+                   sigma_start_init=1e-3, sigma_goal_init=1e-3, sigma_gp_init=1.0,
+                   sigma_start_sample=float(g['sigma_start_sample']), sigma_goal_sample=float(g['sigma_goal_sample']),
+                   sigma_gp_sample=float(g['sigma_gp_sample']), num_samples=S, temperature=float(g['temperature']),
+                   collision_fields=[field], sigma_start=float(g['sigma_start']), sigma_gp=float(g['sigma_gp']),
+                   sigma_coll=float(g['sigma_coll']), sigma_goal_prior=float(g['sigma_goal_prior']),
+                   tensor_args=dict(device=dev, dtype=torch.float32), noise='philox', seed=3)
+    traj = pl.optimize(opt_iters=5)
+    assert traj.shape == (P, H, 2 * D) and torch.isfinite(traj).all()
+    assert pl._weights.shape == (P, S, 1, 1)
+    assert abs(float(pl._weights.sum()) - P) < 1e-4

@@ -128,3 +128,31 @@ def test_gp_prior():
     smp = mean.reshape(1, -1) + (L @ T(g['eps']).unsqueeze(-1)).squeeze(-1)
     np.testing.assert_allclose(smp.reshape(g['samples'].shape[1], g['samples'].shape[0], H, 2 * D).transpose(0, 1).numpy(),
                                g['samples'], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize('name', ['sgpmp_pm2d_h16_f64', 'sgpmp_panda_h16_f64'])
+def test_stoch_gpmp_iterations(name):
+    g = load_golden(name)
+    dtype = torch.float64
+    ta = dict(device='cpu', dtype=dtype)
+    robot, field = ref_geometry_from_golden(g, dtype)
+    D, H = int(g['D']), int(g['H'])
+    start = torch.cat([T(g['start']), torch.zeros(D, dtype=dtype)])
+    goal = torch.cat([T(g['goal']), torch.zeros(D, dtype=dtype)])
+    Kinv = O.gp_prior_precision(H, float(g['dt']), D, float(g['sigma_start_sample']), float(g['sigma_gp_sample']),
+                                float(g['sigma_goal_sample']))
+    np.testing.assert_allclose(Kinv.numpy(), g['Sigma_inv'], rtol=1e-12)
+    L = O.precision_to_scale_tril(Kinv)
+
+    def cost_fn(x):
+        return (O.cost_gp_eval(x, start, D, float(g['dt']), float(g['sigma_start']), float(g['sigma_gp']), ta)
+                + O.goal_prior_eval(x, goal, float(g['sigma_goal_prior']))
+                + O.collision_cost(x, robot, field, float(g['sigma_coll'])))
+    means = T(g['means0'])
+    for it in range(g['eps'].shape[0]):
+        out = O.stoch_gpmp_iteration(means, T(g['eps'][it]), L, Kinv, cost_fn, float(g['temperature']), float(g['step_size']))
+        np.testing.assert_allclose(out['samples'].numpy(), g['samples'][it], rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(out['costs'].numpy(), g['costs'][it], rtol=1e-9)
+        np.testing.assert_allclose(out['weights'].numpy(), g['weights'][it], rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(out['means'].numpy(), g['means'][it], rtol=1e-7, atol=1e-9)
+        means = T(g['means'][it])
