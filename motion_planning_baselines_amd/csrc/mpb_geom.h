@@ -461,11 +461,12 @@ __device__ __forceinline__ void grid_stage(const GeomView& G, unsigned* gridw, f
 
 // N collision spheres at once: the N grid words are fetched together and every trip of the candidate
 // loop issues N obstacle-table reads before the N distance evaluations, so the LDS latency is paid
-// once per group instead of once per sphere.  Returns the sum of the N hinges.
+// once per group instead of once per sphere.  Adds the N hinges to `cost` one by one, in sphere order
+// (the same association as the exhaustive path, so both paths agree bit for bit).
 template <int N>
-__device__ __forceinline__ float spheres_hinge_grid(const GeomView& G, const unsigned* gridw, const float4* otab,
-                                                    const float (&x)[N], const float (&y)[N], const float (&z)[N],
-                                                    const float (&rl)[N]) {
+__device__ __forceinline__ void spheres_hinge_grid(const GeomView& G, const unsigned* gridw, const float4* otab,
+                                                   const float (&x)[N], const float (&y)[N], const float (&z)[N],
+                                                   const float (&rl)[N], float& cost) {
     unsigned w[N];
     float best[N];
     unsigned long long over = 0ull;
@@ -523,17 +524,17 @@ __device__ __forceinline__ float spheres_hinge_grid(const GeomView& G, const uns
             best[i] = fminf(best[i], sd);
         }
     }
-    float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < N; ++i) sum += fmaxf(G.margin + rl[i] - best[i], 0.f);   // parked slots: best = 3e38 -> 0
-    return sum;
+    for (int i = 0; i < N; ++i) cost += fmaxf(G.margin + rl[i] - best[i], 0.f);   // parked slots: best = 3e38 -> +0
 }
 
 __device__ __forceinline__ float waypoint_cost_grid(const GeomView& G, const unsigned* gridw, const float4* otab,
                                                     const float (&q)[MPB_MAX_DOF]) {
     if (G.kind == MPB_KIND_POINT) {
         const float x[1] = {q[0]}, y[1] = {q[1]}, z[1] = {(G.n_dof > 2) ? q[2] : 0.f}, rl[1] = {G.links[4]};
-        return spheres_hinge_grid<1>(G, gridw, otab, x, y, z, rl);
+        float c = 0.f;
+        spheres_hinge_grid<1>(G, gridw, otab, x, y, z, rl, c);
+        return c;
     }
     constexpr int N = 4;
     constexpr float FAR = 1.0e9f;  // parked slot: outside the grid, no candidates
@@ -561,7 +562,7 @@ __device__ __forceinline__ float waypoint_cost_grid(const GeomView& G, const uns
                 x[i] = y[i] = z[i] = FAR;
             }
         }
-        cost += spheres_hinge_grid<N>(G, gridw, otab, x, y, z, rl);
+        spheres_hinge_grid<N>(G, gridw, otab, x, y, z, rl, cost);
     }
     return cost;
 }

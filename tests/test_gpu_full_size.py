@@ -1,0 +1,164 @@
+"""GPU, BASELINE full sizes: size-independent properties of the HIP path (the oracle cannot run these
+sizes in seconds): sharding invariance, fused == split, consistency between kernels, idempotence,
+normalisation, monotone behaviour."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _c3(dev, P=128, S=32, pos_only=False):
+    from motion_planning_baselines_amd import ops, workloads
+    from motion_planning_baselines_amd.planners.stomp import precision_to_scale_tril, stomp_precision_matrix
+    wl = workloads.panda_spheres_stomp(P, dev, S=S, pos_only=pos_only)
+    cpu = dict(device='cpu', dtype=torch.float32)
+    R = stomp_precision_matrix(64, wl['params']['dt'], 0.5, cpu)
+    Sigma, L = torch.inverse(R).to(dev).contiguous(), precision_to_scale_tril(R).to(dev).contiguous()
+    geom = ops.DeviceGeometry(wl['robot'], wl['field'], dev)
+    return wl, Sigma, L, geom
+
+
+def test_stomp_c3_sharded_equals_unsharded(gpu_device):
+    """C3/C5: particles [0,128) in one call == two shards of 64 with particle_offset (device Philox noise):
+    the result must not depend on how the problems are split over GPUs."""
+    from motion_planning_baselines_amd import ops
+    dev = gpu_device
+    P, S, H = 128, 32, 64
+    wl, Sigma, L, geom = _c3(dev, P, S)
+    d = wl['means0'].shape[-1]
+    mk = lambda p: (torch.empty(p, S, H, d, device=dev), torch.empty(p, S, device=dev), torch.empty(p, S, device=dev))
+    full = wl['means0'].clone()
+    s, c, w = mk(P)
+    ops.stomp_step(full, None, s, c, w, L, Sigma, geom, S, 7, 1.0, 1.0, 0.1, 1.0, n_iters=5, seed=11)
+    halves = []
+    for lo in (0, 64):
+        m = wl['means0'][lo:lo + 64].clone()
+        s2, c2, w2 = mk(64)
+        ops.stomp_step(m, None, s2, c2, w2, L, Sigma, geom, S, 7, 1.0, 1.0, 0.1, 1.0, n_iters=5, seed=11,
+                       particle_offset=lo)
+        halves.append((m, s2, c2, w2))
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([h[0] for h in halves]), full)
+    assert torch.equal(torch.cat([h[1] for h in halves]), s)
+    assert torch.equal(torch.cat([h[2] for h in halves]), c)
+    assert torch.allclose(w.sum(1), torch.ones(P, device=dev), atol=1e-5)
+    assert torch.isfinite(full).all()
+
+
+@pytest.mark.parametrize('pos_only', [False, True])
+def test_stomp_c3_kernels_consistent(gpu_device, pos_only):
+    """At B=4096: the fused cost equals the stand-alone cost kernel on the samples it wrote; the fused step
+    equals sample -> update; the noise rows 0 and H-1 are exactly zero; a zero-lr step is idempotent."""
+    from motion_planning_baselines_amd import ops
+    dev = gpu_device
+    P, S, H = 128, 32, 64
+    wl, Sigma, L, geom = _c3(dev, P, S, pos_only)
+    d = wl['means0'].shape[-1]
+    means = wl['means0'].clone()
+    samples = torch.empty(P, S, H, d, device=dev)
+    costs = torch.empty(P, S, device=dev)
+    weights = torch.empty(P, S, device=dev)
+    ops.stomp_step(means, None, samples, costs, weights, L, Sigma, geom, S, 7, 1e6, 1.0, 0.1, 1.0, seed=5)
+    alone = ops.cost_collision_eval(samples.flatten(0, 1), geom, 1e6).reshape(P, S)
+    m2 = wl['means0'].clone()
+    s2, w2 = torch.empty_like(samples), torch.empty_like(weights)
+    ops.stomp_sample(m2, None, s2, L, S, seed=5, it=0)
+    ops.stomp_update(m2, s2, alone, w2, Sigma, 0.1, 1.0)
+    torch.cuda.synchronize()
+    assert torch.equal(alone, costs)
+    assert torch.equal(s2, samples) and torch.equal(m2, means) and torch.equal(w2, weights)
+    assert torch.equal(samples[:, :, 0], wl['means0'][:, None, 0].expand(-1, S, -1))
+    assert torch.equal(samples[:, :, -1], wl['means0'][:, None, -1].expand(-1, S, -1))
+    m3 = means.clone()
+    ops.stomp_step(m3, None, samples, costs, weights, L, Sigma, geom, S, 7, 1e6, 1.0, 0.0, 1.0, seed=6)
+    assert torch.equal(m3, means)
+
+
+def test_collision_cost_grid_equals_exhaustive_at_scale(gpu_device):
+    """Broad-phase grid (cost-only path) == exhaustive obstacle loop (gradient path's cost output), bit for
+    bit, on 4096 x 64 random Panda configurations incl. far-out-of-workspace angles."""
+    from motion_planning_baselines_amd import ops
+    dev = gpu_device
+    wl, _, _, geom = _c3(dev, 8, 4)
+    g = torch.Generator().manual_seed(0)
+    x = ((torch.rand(4096, 64, 14, generator=g) * 2 - 1) * 6.0).to(dev)
+    a = ops.cost_collision_eval(x, geom, 1.0)
+    b, _ = ops.cost_collision_grad(x, geom, 1.0)
+    torch.cuda.synchronize()
+    assert float(a.max()) > 0
+    assert torch.equal(a, b)
+
+
+def test_chomp_c2_fused_equals_stepwise(gpu_device):
+    """C2 (B=1024): 50 iterations inside one launch == 50 single-iteration calls, bit for bit; endpoints fixed."""
+    from motion_planning_baselines_amd import ops, workloads
+    from motion_planning_baselines_amd.planners.chomp import chomp_precision_matrix
+    dev = gpu_device
+    wl = workloads.pointmass_dense_chomp(1024, dev)
+    geom = ops.DeviceGeometry(wl['robot'], wl['field'], dev)
+    R = chomp_precision_matrix(dt=0.04, n_support_points=64, tensor_args=dict(device='cpu', dtype=torch.float32)).to(dev)
+    kw = dict(D=2, k_sigma=1.0, weight=10.0, w_prior=1e-4, lr=0.05, grad_clip=0.05)
+    a = wl['means0'].clone()
+    ops.chomp_step(a, R, geom, n_iters=50, **kw)
+    b = wl['means0'].clone()
+    for _ in range(50):
+        ops.chomp_step(b, R, geom, n_iters=1, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    assert torch.equal(a[:, 0], wl['means0'][:, 0]) and torch.equal(a[:, -1], wl['means0'][:, -1])
+    assert torch.isfinite(a).all()
+    # sharding with the global batch size (quirk Q3) reproduces the unsharded result
+    c = wl['means0'][:512].clone()
+    ops.chomp_step(c, R, geom, n_iters=50, B_global=1024, **kw)
+    assert torch.equal(c, a[:512])
+
+
+def test_gpmp2_c4_solve_properties(gpu_device):
+    """C4 shape (H=128, D=7), B=256: the Gauss-Newton step must (i) be finite, (ii) leave trajectories that
+    already satisfy all factors unchanged (fixed point: straight line, no collision, exact start/goal),
+    (iii) reduce the cost b^T K b on colliding problems, (iv) split entry points == single call."""
+    from motion_planning_baselines_amd import geometry as G, ops, workloads
+    dev = gpu_device
+    B, H, D = 256, 128, 7
+    robot, field = G.RobotPanda(), G.env_spheres_3d()
+    geom = ops.DeviceGeometry(robot, field, dev)
+    q = workloads.collision_free_configs(robot, field, 2 * B, 23, dev)
+    dt = 5.0 / H
+    x0 = workloads.straight_line_means(q[:B], q[B:], H, dt, False, dev)
+    z = torch.zeros(B, D, device=dev)
+    start = torch.cat([torch.from_numpy(q[:B]).to(dev), z], -1).contiguous()
+    goal = torch.cat([torch.from_numpy(q[B:]).to(dev), z], -1).contiguous()
+    sig = (1e-5, 1e-2, 1e-5, 1e-5)
+    ws = ops.gpmp2_workspace(B, H, D, dev)
+    c0, c1 = torch.empty(B, device=dev), torch.empty(B, device=dev)
+    x = x0.clone()
+    ops.gpmp2_step(x, start, goal, geom, ws, sig, dt, 1e-2, True, 1.0, costs_out=c0)
+    ops.gpmp2_step(x, start, goal, geom, ws, sig, dt, 1e-2, True, 1.0, costs_out=c1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(x).all() and torch.isfinite(c0).all()
+    colliding = c0 > 1.0
+    assert int(colliding.sum()) > 10
+    assert float((c1[colliding] < c0[colliding]).float().mean()) > 0.9
+    # without obstacles the problem is exactly quadratic: one (barely damped) Gauss-Newton step lands on the
+    # minimiser -- the cost collapses and a second step no longer moves the trajectory
+    far = G.CollisionField(spheres=[[50.0, 50.0, 50.0, 0.1]], margin=0.05)
+    geom_far = ops.DeviceGeometry(robot, far, dev)
+    xl = x0.clone()
+    q0, q1, q2 = (torch.empty(B, device=dev) for _ in range(3))
+    ops.gpmp2_step(xl, start, goal, geom_far, ws, sig, dt, 1e-6, False, 1.0, costs_out=q0)
+    x1 = xl.clone()
+    ops.gpmp2_step(xl, start, goal, geom_far, ws, sig, dt, 1e-6, False, 1.0, costs_out=q1)
+    ops.gpmp2_step(xl, start, goal, geom_far, ws, sig, dt, 1e-6, False, 1.0, costs_out=q2)
+    torch.cuda.synchronize()
+    assert float((q1 / q0).max()) < 1e-3, float((q1 / q0).max())
+    assert float((xl - x1).abs().max()) < 1e-3
+    assert float((x1[:, 0, :D] - x0[:, 0, :D]).abs().max()) < 1e-4      # tight start / goal priors
+    assert float((x1[:, -1, :D] - x0[:, -1, :D]).abs().max()) < 1e-4
+    # split == single call
+    xa, xb = x0.clone(), x0.clone()
+    ops.gpmp2_step(xa, start, goal, geom, ws, sig, dt, 1e-2, True, 1.0)
+    ops.gpmp2_linearize(xb, geom, ws)
+    dsum = ops.gpmp2_diag(ws, B, H, D, sig, dt)
+    ops.gpmp2_solve(xb, start, goal, dsum / B, ws, sig, dt, 1e-2, True, 1.0)
+    torch.cuda.synchronize()
+    assert torch.equal(xa, xb)
