@@ -73,7 +73,9 @@ int mpb_cost_collision_grad(const float *trajs, const float *geom, float *out, f
  * samples (P,S,H,d), costs (P,S), weights (P,S): outputs of the LAST iteration (all required).
  * L (H,H): scale_tril of the noise distribution, Sigma (H,H) = inverse(R): constants the host
  *      computes exactly as the reference does (stomp.py:63-64, :88-95) -- SURVEY.md H2.
- * mpb_stomp_step runs the fused path (sample+cost kernel, update kernel per iteration).
+ * mpb_stomp_step runs the fused path (sample+cost kernel, update kernel per iteration).  Everything is
+ * enqueued asynchronously; only for n_iters > 256 (and never under stream capture) the call blocks on its
+ * own events so that at most 256 iterations are queued ahead of the GPU.
  * mpb_stomp_update accepts Sigma == NULL (update without the covariance product, used by StochGPMP).
  * mpb_stomp_sample / mpb_stomp_update expose the two halves (the two kernels of one iteration) so that
  * a caller-supplied cost callable (any Python cost on device tensors) can sit between them; with

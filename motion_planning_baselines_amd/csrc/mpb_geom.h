@@ -536,7 +536,10 @@ __device__ __forceinline__ float waypoint_cost_grid(const GeomView& G, const uns
         spheres_hinge_grid<1>(G, gridw, otab, x, y, z, rl, c);
         return c;
     }
-    constexpr int N = 4;
+#ifndef MPB_GRID_N
+#define MPB_GRID_N 4
+#endif
+    constexpr int N = MPB_GRID_N;
     constexpr float FAR = 1.0e9f;  // parked slot: outside the grid, no candidates
     FKState<false> F;
     F.r00 = 1.f; F.r01 = 0.f; F.r02 = 0.f; F.r10 = 0.f; F.r11 = 1.f; F.r12 = 0.f; F.r20 = 0.f; F.r21 = 0.f; F.r22 = 1.f;

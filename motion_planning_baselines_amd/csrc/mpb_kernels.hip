@@ -252,7 +252,19 @@ __global__ __launch_bounds__(256, 4) void stomp_sample_cost_h64_kernel(
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int r = blockIdx.x * 4 + wave;  // rollout index
+    // XCD-aware block -> rollout map (speed only, any map is correct): workgroups are dealt round-robin
+    // over the 8 XCDs, so blocks with equal blockIdx % 8 share an L2.  All S/4 blocks of particle p are
+    // given blockIdx % 8 == p % 8; the update kernel's block p lands on the same XCD and finds the samples
+    // this kernel wrote still resident in that L2 instead of fetching them across the fabric.
+    int lb = blockIdx.x;
+    {
+        const int nb = S >> 2;                       // blocks per particle
+        if ((S & 3) == 0 && (P & 7) == 0) {
+            const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+            lb = (8 * (q / nb) + x) * nb + (q % nb); // particle 8*(q/nb)+x, its (q%nb)-th block
+        }
+    }
+    const int r = lb * 4 + wave;  // rollout index
     const bool live = r < P * S;
     const int p = live ? r / S : 0, s = live ? r - p * S : 0;
     const int j = lane & 15, g = lane >> 4;
@@ -778,11 +790,28 @@ extern "C" int mpb_stomp_step(float* means, const float* eps, float* samples, fl
     if (!update_lds(S, H, d, lds_b, sig_lds)) return fail(MPB_E_UNSUPPORTED, "%s: S + H*d too large for LDS", __func__);
     if (P == 0) return MPB_OK;
     const size_t eps_stride = (size_t)S * d * P * H;
+    // Launch-queue throttle: long runs keep at most two chunks of MPB_CHUNK iterations queued ahead of the
+    // GPU (before queueing chunk k+2 the host waits on an event recorded after chunk k), so the host never
+    // sits on thousands of pending launches.  Short calls (<= 2 chunks) and calls made while the stream is
+    // being captured into a graph never wait.
+    constexpr int MPB_CHUNK = 128;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool throttle = n_iters > 2 * MPB_CHUNK &&
+                          hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;
     for (int it = 0; it < n_iters; ++it) {
+        if (throttle && it % MPB_CHUNK == 0) {
+            const int k = (it / MPB_CHUNK) & 1;
+            if (ev[k]) (void)hipEventSynchronize(ev[k]);                 // chunk it/MPB_CHUNK - 2 has finished
+            else (void)hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
+        }
         launch_sample<true>(means, eps ? eps + (size_t)it * eps_stride : nullptr, samples, costs, L, geom, P, S, H, d,
                             k_sigma, weight, seed, iter0 + (uint32_t)it, particle_offset, (hipStream_t)stream);
         launch_update(means, samples, costs, weights, Sigma, P, S, H, d, lr, temperature, (hipStream_t)stream);
+        if (throttle && it % MPB_CHUNK == MPB_CHUNK - 1) (void)hipEventRecord(ev[(it / MPB_CHUNK) & 1], (hipStream_t)stream);
     }
+    for (int k = 0; k < 2; ++k)
+        if (ev[k]) (void)hipEventDestroy(ev[k]);
     return check_launch(__func__);
 }
 
