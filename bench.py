@@ -109,6 +109,8 @@ def main():
         torch.cuda.synchronize()
 
     planner.optimize(opt_iters=args.warmup)          # W untimed steps
+    if dist is not None:                             # RCCL communicator / xGMI set-up is part of the warm-up
+        dist.all_gather(gathered, planner._particle_means)
     barrier()
     t0 = time.perf_counter()
     planner.optimize(opt_iters=args.steps)           # EXACTLY K steps: one C-ABI call, 2K launches
