@@ -45,13 +45,14 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
     float* wvec = lds;           // c*T : Cov_inv[i] @ mean[:, i]
     float* red = wvec + c * T;   // 32 floats of scratch for block reductions
     float* wts = red + 32;       // S : sample weights
+    const int SP = blockDim.x;   // controls slab in LDS, sample index fastest: Us[(t*c + i)*SP + s] (conflict-free)
+    float* Us = wts + ((S + 3) & ~3);
     const int prob = blockIdx.x;
     const int s = threadIdx.x;
     const bool live = s < S;
     const int lane = s & 63, wave = s >> 6, nw = blockDim.x >> 6;
     float* m = mean + (size_t)prob * T * c;
-    float* Ub = controls + (size_t)prob * S * T * c;
-    float* U = Ub + (size_t)(live ? s : 0) * T * c;
+    float* U = controls + ((size_t)prob * S + (live ? s : 0)) * T * c;
     float* X = states + ((size_t)prob * S + (live ? s : 0)) * T * c;  // velocity control: state_dim == c
     const float w_pos = cw[0], w_ctrl = cw[2], w_posT = cw[3];
     GeomView G;
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
             for (int i = 0; i < c; ++i) {
                 if (eps != nullptr) {
                     const float* ep = eps + ((((size_t)it * gridDim.x + prob) * c + i) * S + s) * T;
-                    for (int t = 0; t < T; ++t) U[t * c + i] = ep[t];
+                    for (int t = 0; t < T; ++t) Us[(t * c + i) * SP + s] = ep[t];
                 } else {
                     for (int t4 = 0; t4 < T; t4 += 4) {
                         const uint4 r = philox4x32_10(
@@ -85,13 +86,17 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
                         box_muller(r.z, r.w, n[2], n[3]);
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            if (t4 + q < T) U[(t4 + q) * c + i] = n[q];
+                            if (t4 + q < T) Us[((t4 + q) * c + i) * SP + s] = n[q];
                     }
                 }
                 for (int t = T - 1; t >= 0; --t) {
+                    const float* trow = tril + ((size_t)i * T + t) * T;   // wave-uniform row: scalar loads
                     float a = 0.f;
-                    for (int k = 0; k <= t; ++k) a = fmaf(tril[((size_t)i * T + t) * T + k], U[k * c + i], a);
-                    U[t * c + i] = m[t * c + i] + a;
+#pragma unroll 8
+                    for (int k = 0; k <= t; ++k) a = fmaf(trow[k], Us[(k * c + i) * SP + s], a);
+                    const float u = m[t * c + i] + a;
+                    Us[(t * c + i) * SP + s] = u;
+                    U[t * c + i] = u;                                      // API-visible controls
                 }
             }
             // ---- Euler rollout (mppi.py:205-209) + quadratic cost (point.py:198-226)
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
                         const float dx = x[i] - goal[(size_t)prob * c + i];
                         pc += dx * dx * w_pos;
                         tc += dx * dx * w_posT;
-                        const float u = U[t * c + i];
+                        const float u = Us[(t * c + i) * SP + s];
                         cc += u * u * w_ctrl;
                         is_term[i] = fmaf(u, wvec[i * T + t], is_term[i]);
                     }
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
 #pragma unroll
                     for (int i = 0; i < MPPI_MAX_C; ++i) {
                         if (i < c) {
-                            const float u = fminf(fmaxf(U[t * c + i], ctrl_min[i]), ctrl_max[i]);  // point.py:112
+                            const float u = fminf(fmaxf(Us[(t * c + i) * SP + s], ctrl_min[i]), ctrl_max[i]);  // point.py:112
                             x[i] = x[i] + u * dt;                                                   // point.py:139
                         }
                     }
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
         for (int e = threadIdx.x; e < T * c; e += blockDim.x) {
             const float mu = m[e];
             float a = 0.f;
-            for (int ss = 0; ss < S; ++ss) a += wts[ss] * (Ub[(size_t)ss * T * c + e] - mu);
+            for (int ss = 0; ss < S; ++ss) a += wts[ss] * (Us[e * SP + ss] - mu);
             m[e] = mu + step_size * a;
         }
         __threadfence_block();
@@ -185,7 +190,8 @@ extern "C" int mpb_mppi_step(float* mean, const float* eps, const float* scale_t
         return mpb_fail(MPB_E_UNSUPPORTED, "mpb_mppi_step: only velocity control (the reference's acceleration mode cannot run)");
     if (NP == 0 || n_iters == 0) return MPB_OK;
     const int threads = (S + 63) & ~63;
-    const size_t lds = ((size_t)c * T + 32 + S) * sizeof(float);
+    const size_t lds = ((size_t)c * T + 32 + ((S + 3) & ~3) + (size_t)T * c * threads) * sizeof(float);
+    if (lds > 150 * 1024) return mpb_fail(MPB_E_UNSUPPORTED, "mpb_mppi_step: S*T*c too large for the LDS controls slab");
     hipLaunchKernelGGL(mppi_kernel, dim3(NP), dim3(threads), lds, (hipStream_t)stream, mean, eps, scale_tril, cov_inv,
                        state0, goal, ctrl_min, ctrl_max, discount, c_weights, geom, controls, states, costs, weights, S, T,
                        c, dt, k_sigma, weight, temp, step_size, n_iters, (uint32_t)seed, (uint32_t)(seed >> 32), iter0);
