@@ -730,6 +730,7 @@ static bool shape_ok(int H, int d, int D) {
 
 extern "C" int mpb_cost_collision_eval(const float* trajs, const float* geom, float* out, float* per_waypoint,
                                        int B, int H, int d, int h_begin, float k_sigma, float weight, void* stream) {
+    if (B == 0) return MPB_OK;   // empty batch: nothing to do (and torch hands out null pointers for it)
     if (!trajs || !geom || !out) return fail(MPB_E_INVALID, "%s: null pointer", __func__);
     if (B < 0 || H < 1 || d < 1 || d > MPB_MAX_D || h_begin < 0) return fail(MPB_E_INVALID, "%s: bad shape", __func__);
     if (B == 0) return MPB_OK;
@@ -740,6 +741,7 @@ extern "C" int mpb_cost_collision_eval(const float* trajs, const float* geom, fl
 
 extern "C" int mpb_cost_collision_grad(const float* trajs, const float* geom, float* out, float* grad, int B, int H,
                                        int d, int h_begin, float k_sigma, float weight, void* stream) {
+    if (B == 0) return MPB_OK;
     if (!trajs || !geom || !out || !grad) return fail(MPB_E_INVALID, "%s: null pointer", __func__);
     if (B < 0 || H < 1 || d < 1 || d > MPB_MAX_D || h_begin < 0) return fail(MPB_E_INVALID, "%s: bad shape", __func__);
     if (B == 0) return MPB_OK;
@@ -751,6 +753,7 @@ extern "C" int mpb_cost_collision_grad(const float* trajs, const float* geom, fl
 extern "C" int mpb_stomp_sample(const float* means, const float* eps, float* samples, const float* L,
                                 const float* geom, float* costs, int P, int S, int H, int d, float k_sigma,
                                 float weight, uint64_t seed, uint32_t iter, uint32_t particle_offset, void* stream) {
+    if (P == 0) return MPB_OK;
     if (!means || !samples || !L) return fail(MPB_E_INVALID, "%s: null pointer", __func__);
     if ((geom == nullptr) != (costs == nullptr)) return fail(MPB_E_INVALID, "%s: geom and costs must be given together", __func__);
     if (P < 0 || S < 1 || H < 3 || H > MPB_MAX_H || d < 1 || d > MPB_MAX_D) return fail(MPB_E_INVALID, "%s: bad shape", __func__);
@@ -768,6 +771,7 @@ extern "C" int mpb_stomp_sample(const float* means, const float* eps, float* sam
 extern "C" int mpb_stomp_update(float* means, const float* samples, const float* costs, float* weights,
                                 const float* Sigma, int P, int S, int H, int d, float lr, float temperature,
                                 void* stream) {
+    if (P == 0) return MPB_OK;
     if (!means || !samples || !costs || !weights) return fail(MPB_E_INVALID, "%s: null pointer", __func__);
     if (P < 0 || S < 1 || H < 3 || H > MPB_MAX_H || d < 1 || d > MPB_MAX_D) return fail(MPB_E_INVALID, "%s: bad shape", __func__);
     if (!(temperature > 0.f)) return fail(MPB_E_INVALID, "%s: temperature must be > 0", __func__);
@@ -781,6 +785,7 @@ extern "C" int mpb_stomp_step(float* means, const float* eps, float* samples, fl
                               const float* L, const float* Sigma, const float* geom, int P, int S, int H, int d, int D,
                               float k_sigma, float weight, float lr, float temperature, int n_iters, uint64_t seed,
                               uint32_t iter0, uint32_t particle_offset, void* stream) {
+    if (P == 0) return MPB_OK;
     if (!means || !samples || !costs || !weights || !L || !Sigma || !geom) return fail(MPB_E_INVALID, "%s: null pointer", __func__);
     if (P < 0 || S < 1 || !shape_ok(H, d, D) || n_iters < 0) return fail(MPB_E_INVALID, "%s: bad shape", __func__);
     if (!(temperature > 0.f)) return fail(MPB_E_INVALID, "%s: temperature must be > 0", __func__);
@@ -818,6 +823,7 @@ extern "C" int mpb_stomp_step(float* means, const float* eps, float* samples, fl
 extern "C" int mpb_chomp_step(float* means, const float* R, const float* geom, float* costs_out, int B_local,
                               int B_global, int H, int d, int D, float k_sigma, float weight, float w_prior, float lr,
                               float grad_clip, int n_iters, void* stream) {
+    if (B_local == 0) return MPB_OK;
     if (!means || !R || !geom) return fail(MPB_E_INVALID, "%s: null pointer", __func__);
     if (B_local < 0 || B_global < B_local || !shape_ok(H, d, D) || n_iters < 0) return fail(MPB_E_INVALID, "%s: bad shape", __func__);
     if (B_local == 0 || n_iters == 0) return MPB_OK;

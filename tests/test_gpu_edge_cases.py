@@ -1,0 +1,142 @@
+"""GPU: edge cases of the HIP path against the oracle on small seeded inputs -- ragged / odd sizes, generic-H
+and generic-d kernels, obstacle sets that defeat the broad phase (crowded cells, > 63 spheres), boxes with a
+chain robot, 3-D point robot, empty batches, argument validation."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def _geoms():
+    from motion_planning_baselines_amd import geometry as G
+    rng = np.random.RandomState(1)
+    crowded = np.concatenate([rng.uniform(-0.15, 0.15, (12, 3)) + [0.4, 0.1, 0.4], rng.uniform(0.03, 0.06, (12, 1))], 1)
+    many = np.concatenate([rng.uniform(-0.9, 0.9, (100, 3)), rng.uniform(0.02, 0.05, (100, 1))], 1)
+    boxes3 = np.concatenate([rng.uniform(-0.6, 0.6, (5, 3)), rng.uniform(0.05, 0.15, (5, 3))], 1)
+    return {
+        'panda_crowded': (G.RobotPanda(), G.CollisionField(spheres=crowded, margin=0.05)),          # grid cells overflow
+        'panda_many': (G.RobotPanda(), G.CollisionField(spheres=many, margin=0.03)),                # > 63 spheres: no grid
+        'panda_boxes': (G.RobotPanda(), G.CollisionField(spheres=crowded[:3], boxes=boxes3, margin=0.05)),
+        'panda_boxes_only': (G.RobotPanda(), G.CollisionField(boxes=boxes3, margin=0.05)),
+        'point3d': (G.RobotPointMass(3, radius=0.05), G.env_spheres_3d(seed=2)),
+        'point2d_boxes': (G.RobotPointMass(2, radius=0.02), G.env_dense_2d(seed=5)),
+    }
+
+
+def _trajs(robot, B, H, d, seed):
+    g = torch.Generator().manual_seed(seed)
+    D = robot.q_dim
+    lo, hi = torch.from_numpy(robot.q_min_np), torch.from_numpy(robot.q_max_np)
+    a = lo + (hi - lo) * torch.rand(B, 1, D, generator=g)
+    b = lo + (hi - lo) * torch.rand(B, 1, D, generator=g)
+    t = torch.linspace(0, 1, H).reshape(1, H, 1)
+    q = a * (1 - t) + b * t + 0.03 * torch.randn(B, H, D, generator=g)
+    return (torch.cat([q, torch.randn(B, H, d - D, generator=g)], -1) if d > D else q).contiguous()
+
+
+@pytest.mark.parametrize('name', ['panda_crowded', 'panda_many', 'panda_boxes', 'panda_boxes_only', 'point3d', 'point2d_boxes'])
+@pytest.mark.parametrize('H', [64, 37])
+def test_cost_and_grad_vs_oracle(gpu_device, name, H):
+    from motion_planning_baselines_amd import ops
+    from oracle import planners_ref as O
+    from oracle.geometry_ref import make_ref_geometry
+    robot, field = _geoms()[name]
+    rr, rf = make_ref_geometry(robot, field)
+    D = robot.q_dim
+    x = _trajs(robot, 21, H, 2 * D, 3).requires_grad_(True)
+    ref = O.collision_cost(x, rr, rf, 0.5, weight=2.0)
+    ref.sum().backward()
+    geom = ops.DeviceGeometry(robot, field, gpu_device)
+    out = ops.cost_collision_eval(x.detach().to(gpu_device), geom, 4.0, weight=2.0)
+    out2, grad = ops.cost_collision_grad(x.detach().to(gpu_device), geom, 4.0, weight=2.0)
+    torch.cuda.synchronize()
+    assert float(ref.detach().max()) > 0, 'inputs must collide'
+    np.testing.assert_allclose(out.cpu().numpy(), ref.detach().numpy(), rtol=3e-5, atol=1e-5)
+    assert torch.equal(out, out2)              # broad-phase path == exhaustive path, bit for bit
+    diff = (grad.cpu() - x.grad).abs()
+    tol = 2e-4 * x.grad.abs().max() + 2e-4 * x.grad.abs()
+    assert float((diff > tol).float().mean()) < 3e-3
+
+
+@pytest.mark.parametrize('name,P,S,H,pos_only', [
+    ('panda_crowded', 3, 5, 64, True),       # ragged: P*S not a multiple of the 4 rollouts per block, fast path d=7
+    ('panda_boxes', 2, 8, 64, False),        # d = 14
+    ('point3d', 5, 3, 64, False),            # d = 6
+    ('point3d', 4, 7, 64, True),             # d = 3
+    ('panda_many', 2, 4, 80, True),          # generic-H kernel
+    ('point2d_boxes', 3, 9, 100, False),     # generic-H kernel, H > 64
+])
+def test_stomp_iteration_vs_oracle(gpu_device, name, P, S, H, pos_only):
+    from motion_planning_baselines_amd import ops
+    from motion_planning_baselines_amd.planners.stomp import precision_to_scale_tril, stomp_precision_matrix
+    from oracle import planners_ref as O
+    from oracle.geometry_ref import make_ref_geometry
+    dev = gpu_device
+    robot, field = _geoms()[name]
+    rr, rf = make_ref_geometry(robot, field)
+    D = robot.q_dim
+    d = D if pos_only else 2 * D
+    cpu = dict(device='cpu', dtype=torch.float32)
+    R = stomp_precision_matrix(H, 0.05, 1.0, cpu)
+    Sigma, L = torch.inverse(R).contiguous(), precision_to_scale_tril(R).contiguous()
+    means0 = _trajs(robot, P, H, d, 5)
+    g = torch.Generator().manual_seed(9)
+    eps = torch.randn(2, S, d, P, H, generator=g)
+    sigma = 0.3
+    ref = means0.clone()
+    for it in range(2):
+        out = O.stomp_iteration(ref, eps[it], L, Sigma, lambda x: O.collision_cost(x, rr, rf, sigma), 0.2, 0.7)
+        ref = out['means']
+    geom = ops.DeviceGeometry(robot, field, dev)
+    means = means0.clone().to(dev)
+    samples = torch.empty(P, S, H, d, device=dev)
+    costs = torch.empty(P, S, device=dev)
+    weights = torch.empty(P, S, device=dev)
+    ops.stomp_step(means, eps.to(dev), samples, costs, weights, L.to(dev), Sigma.to(dev), geom, S, D, 1.0 / sigma ** 2, 1.0,
+                   0.2, 0.7, n_iters=2)
+    torch.cuda.synchronize()
+    assert rel_err(samples, out['samples']) < 1e-4
+    np.testing.assert_allclose(costs.cpu().numpy(), out['costs'].numpy(), rtol=1e-4, atol=1e-4)
+    assert rel_err(means, ref) < 1e-4
+
+
+def test_empty_and_invalid_arguments(gpu_device):
+    from motion_planning_baselines_amd import ops
+    from motion_planning_baselines_amd._lib import MPBError
+    dev = gpu_device
+    robot, field = _geoms()['point3d']
+    geom = ops.DeviceGeometry(robot, field, dev)
+    # empty batches are accepted and do nothing
+    out = ops.cost_collision_eval(torch.empty(0, 64, 3, device=dev), geom, 1.0)
+    assert out.shape == (0,)
+    H, d, S = 64, 3, 4
+    L = torch.eye(H, device=dev)
+    m = torch.empty(0, H, d, device=dev)
+    ops.stomp_step(m, None, torch.empty(0, S, H, d, device=dev), torch.empty(0, S, device=dev), torch.empty(0, S, device=dev),
+                   L, L, geom, S, 3, 1.0, 1.0, 0.1, 1.0)
+    # wrong device / dtype / shape / contiguity are rejected on the host before any launch
+    x = torch.zeros(2, H, d, device=dev)
+    with pytest.raises(ValueError):
+        ops.cost_collision_eval(x.cpu(), geom, 1.0)
+    with pytest.raises(ValueError):
+        ops.cost_collision_eval(x.double(), geom, 1.0)
+    with pytest.raises(ValueError):
+        ops.cost_collision_eval(x.transpose(0, 1), geom, 1.0)
+    with pytest.raises(ValueError):
+        ops.stomp_step(x, None, torch.empty(2, S, H, d, device=dev), torch.empty(2, S + 1, device=dev),
+                       torch.empty(2, S, device=dev), L, L, geom, S, 3, 1.0, 1.0, 0.1, 1.0)
+    # the C-ABI itself rejects out-of-range shapes and bad temperatures
+    with pytest.raises(MPBError):
+        ops.stomp_step(x, None, torch.empty(2, S, H, d, device=dev), torch.empty(2, S, device=dev),
+                       torch.empty(2, S, device=dev), L, L, geom, S, 3, 1.0, 1.0, 0.1, 0.0)
+    big = torch.zeros(1, 300, d, device=dev)
+    with pytest.raises(MPBError):
+        ops.stomp_sample(big, None, torch.empty(1, S, 300, d, device=dev), torch.eye(300, device=dev), S)
+    torch.cuda.synchronize()
