@@ -21,6 +21,7 @@
 #include "mpb_common.h"
 #include "mpb_geom.h"
 
+typedef double f64x4 __attribute__((ext_vector_type(4)));
 #define GP_N 16            // padded block size (2D <= 16)
 #define GP_LD 17           // LDS leading dimension (fp64 words)
 #define GP_MAXH MPB_MAX_H
@@ -111,10 +112,20 @@ __global__ void gpmp2_scale_kernel(const double* __restrict__ in, double* __rest
 // U = -Phi^T Qi is (2x2) (x) I_D, so F_t = S_t^-1 U is a combination of column blocks of W_t = S_t^-1 and
 //   S_{t+1} = D_{t+1} - U^T W_t U,   z_t = W_t r_t,   r_{t+1} = g_{t+1} - U^T z_t,
 //   dtheta_t = z_t - W_t (U dtheta_{t+1}).
-// The only dense operation per waypoint is the SPD inverse W_t: in-place Gauss-Jordan (no pivoting: the
-// pivots of an SPD matrix are positive) on a 16 x 16 fp64 tile, ping-ponging between two LDS buffers so
-// that each of the 2D elimination steps costs ONE wave-level synchronisation (64 lanes x 4 elements).
+// The only dense operation per waypoint is the SPD inverse W_t: blocked Gauss-Jordan (no pivoting: the
+// pivot blocks of an SPD matrix are SPD) on a 16 x 16 fp64 tile with 4 x 4 pivot blocks; each block step is
+// one v_mfma_f64_16x16x4_f64 rank-4 update of the whole tile, ping-ponging between two LDS buffers
+// (4 wave-level synchronisations per inverse).
 // ------------------------------------------------------------------------------------------------
+// 1/x in fp64: v_rcp_f64 (about 2^-26 accurate) + two Newton steps; the IEEE division hipcc emits costs
+// ~40 instructions and there are 16 of them per waypoint in the pivot-block inverses
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
 struct GpConst {
@@ -133,6 +144,7 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
     __shared__ double rv[GP_N];             // r_t
     __shared__ double zv[GP_N];             // z_t / scratch vector
     __shared__ double dth[GP_N];            // dtheta_{t+1} during the backward pass
+    __shared__ double hv[GP_N];             // collision Jacobian h_t (D values) and cost c_t at [D]
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
     const int dim = 2 * D;
@@ -151,12 +163,21 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
     int cur = 0;  // Sb[cur] holds -(U^T W_{t-1} U) on entry to step t > 0
     double rcarry = 0.0;  // lane < dim: r_t contribution carried from step t-1 (gnext - U^T z)
 
+    // software prefetch: rows t+1 of x and of the Jacobian are loaded one step ahead so that their global
+    // latency hides behind the inverse of step t instead of sitting on the sequential critical path
+    float xr0 = (lane < dim) ? xb[lane] : 0.f;
+    float xr1 = (lane < dim && H > 1) ? xb[dim + lane] : 0.f;
+    float jr = 0.f;                                                   // row 0 takes no collision factor
+    float jr1 = (lane <= D && H > 1) ? jb[(D + 1) + lane] : 0.f;
     for (int t = 0; t < H; ++t) {
-        // ---- load x_t, x_{t+1}
+        // ---- x_t, x_{t+1}, h_t from the prefetched registers; issue the loads of step t+1
         if (lane < dim) {
-            xs[0][lane] = (double)xb[t * dim + lane];
-            xs[1][lane] = (t + 1 < H) ? (double)xb[(t + 1) * dim + lane] : 0.0;
+            xs[0][lane] = (double)xr0;
+            xs[1][lane] = (t + 1 < H) ? (double)xr1 : 0.0;
         }
+        if (lane <= D) hv[lane] = (t > 0) ? (double)jr : 0.0;
+        const float xr2 = (lane < dim && t + 2 < H) ? xb[(t + 2) * dim + lane] : 0.f;
+        const float jr2 = (lane <= D && t + 2 < H) ? jb[(t + 2) * (D + 1) + lane] : 0.f;
         wave_sync();
         // ---- GP error of factor t: e = x_{t+1} - Phi x_t
         double e_i = 0.0;
@@ -177,7 +198,7 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
             }
         }
         // ---- S = D_t (+ Schur term already in the tile for t > 0); padding rows/cols = identity
-        const double ct = (t > 0) ? (double)jb[t * (D + 1) + D] : 0.0;
+        const double ct = hv[D];
         double* S = Sb[cur];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -198,7 +219,7 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
                     if (t == H - 1) v += K.kg;
                     v += K.trust ? K.delta * diag_mean[(size_t)t * dim + i] : K.delta;
                 }
-                if (t > 0 && ip && jp) v += K.kc * (double)jb[t * (D + 1) + i] * (double)jb[t * (D + 1) + j];
+                if (t > 0 && ip && jp) v += K.kc * hv[i] * hv[j];
             } else {
                 v = (i == j) ? 1.0 : 0.0;
             }
@@ -219,30 +240,70 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
                 cost += K.kg * eg * eg;
             }
             if (t < H - 1) r += pqe_i;
-            if (t > 0 && lane < D) r += K.kc * (double)jb[t * (D + 1) + lane] * ct;
+            if (t > 0 && lane < D) r += K.kc * hv[lane] * ct;
             gnext = -qe_i;                                         // contribution of factor t to g_{t+1}
             rv[lane] = r;
         }
         if (lane == 0 && t > 0) cost += K.kc * ct * ct;
         wave_sync();
-        // ---- W = S^-1 : Gauss-Jordan, one synchronisation per elimination step
-        for (int k = 0; k < dim; ++k) {
-            const double* A = Sb[cur];
-            double* Bn = Sb[cur ^ 1];
-            const double pinv = 1.0 / A[k * GP_LD + k];
-            const double aik = A[ei * GP_LD + k];
+        // ---- W = S^-1 : blocked Gauss-Jordan with 4x4 pivot blocks; the rank-4 trailing update of the whole
+        //      16 x 16 tile is ONE v_mfma_f64_16x16x4_f64 per block step (4 steps, one synchronisation each):
+        //        D = (-A[:,K]) * (Pinv * A'[K,:]) + C_in,  A'[K,K] := I,  C_in := A with columns K zeroed,
+        //      then rows K := Pinv * A'[K,:]  (which is exactly this lane's own B operand).
+        //      Lane maps (f64 16x16x4): A-op lane l -> [i = l&15][k = l>>4]; B-op [k = l>>4][j = l&15];
+        //      C/D: column l&15, rows (l>>4) + 4*reg.
+        {
+            const int li = lane & 15, lk = lane >> 4;
+            for (int kb = 0; 4 * kb < dim; ++kb) {
+                const double* A = Sb[cur];
+                double* Bn = Sb[cur ^ 1];
+                const int k0 = 4 * kb;
+                // pivot block inverse, redundantly in every lane (4x4 Gauss-Jordan in registers)
+                double pv[4][4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int j = ej0 + q;
-                const double akj = A[k * GP_LD + j];
-                double v;
-                if (ei == k) v = (j == k) ? pinv : akj * pinv;
-                else if (j == k) v = -aik * pinv;
-                else v = A[ei * GP_LD + j] - aik * akj * pinv;
-                Bn[ei * GP_LD + j] = v;
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c2 = 0; c2 < 4; ++c2) pv[r][c2] = A[(k0 + r) * GP_LD + k0 + c2];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const double ip = fast_rcp(pv[k][k]);
+#pragma unroll
+                    for (int c2 = 0; c2 < 4; ++c2) pv[k][c2] = (c2 == k) ? ip : pv[k][c2] * ip;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (r != k) {
+                            const double f = pv[r][k];
+#pragma unroll
+                            for (int c2 = 0; c2 < 4; ++c2) pv[r][c2] = (c2 == k) ? -f * ip : pv[r][c2] - f * pv[k][c2];
+                        }
+                    }
+                }
+                // B operand: (Pinv * A'[K,:])[lk][li]
+                const bool jin = (li >= k0) && (li < k0 + 4);
+                double bop = 0.0;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const double am = jin ? ((li - k0 == m) ? 1.0 : 0.0) : A[(k0 + m) * GP_LD + li];
+                    // Pinv[lk][m] with a lane-dependent row: select
+                    const double pm = (lk == 0) ? pv[0][m] : (lk == 1) ? pv[1][m] : (lk == 2) ? pv[2][m] : pv[3][m];
+                    bop = fma(pm, am, bop);
+                }
+                // A operand: -A[li][k0 + lk]
+                const double aop = -A[li * GP_LD + k0 + lk];
+                // C in: rows lk + 4*reg, column li; columns of the pivot block start from zero
+                f64x4 cin;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cin[q] = jin ? 0.0 : A[(lk + 4 * q) * GP_LD + li];
+                f64x4 dd = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, cin, 0, 0, 0);
+                // rows of the pivot block: row k0 + lk lives in register kb of lane (lk, li)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double v = (q == kb) ? bop : dd[q];
+                    Bn[(lk + 4 * q) * GP_LD + li] = v;
+                }
+                cur ^= 1;
+                wave_sync();
             }
-            cur ^= 1;
-            wave_sync();
         }
         const double* W = Sb[cur];
         // ---- z = W r ; store W_t, z_t
@@ -287,6 +348,7 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
             for (int q = 0; q < 4; ++q) Sn[ei * GP_LD + ej0 + q] = newS[q];
             wave_sync();
         }
+        xr0 = xr1; xr1 = xr2; jr = jr1; jr1 = jr2;
     }
     // ---- backward substitution and update: dtheta_t = z_t - W_t (U dtheta_{t+1})
     for (int t = H - 1; t >= 0; --t) {
