@@ -61,6 +61,37 @@ int mpb_cost_collision_grad(const float *trajs, const float *geom, float *out, f
                             int B, int H, int d, int h_begin, float k_sigma, float weight, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Trajectory-only cost terms -- replaces the eval() of CostGP (costs/cost_functions.py:271-289),
+ * CostGPTrajectory (:344-354), CostGPTrajectoryPositionOnlyWrapper (:365-368), CostSmoothnessCHOMP
+ * (:384-387), CostJointLimits (:406-426) and CostGoalPrior (:523-536); any subset in one pass over the
+ * batch (what CostComposite.eval, :70-87, sums term by term):
+ *   out[b] (+)= k_gp    * sum_t e_t^T ([[12/dt^3,-6/dt^2],[-6/dt^2,4/dt]] (x) I) e_t, e_t = x_{t+1} - Phi x_t
+ *            + k_start * |start_state - x_0|^2            (UnaryFactor, K = I/sigma^2 folded into k_*)
+ *            + k_goal  * |goal_states[b / trajs_per_goal] - x_{H-1}|^2
+ *            + k_smooth* sum_cols x^T R x, R = CHOMP._get_R_mat(dt, H) (chomp.py:81-101)
+ *   *jl_total   = k_jlim * sum over the WHOLE batch of squared joint-limit violations beyond
+ *                 q_min + jl_eps / q_max - jl_eps (the reference's `.sum(-1)` of a 1-D gather is a scalar);
+ *                 broadcast_jlim != 0 also adds it to every out[b] (what the composite's `+=` does).
+ * k_* = composite weight / sigma^2 of the term.  trajs (B,H,d) with d == 2*n_dof, or d == n_dof with
+ * MPB_TERM_VEL_FD (velocities = central differences, zero end rows) for the GP term / any d for
+ * SMOOTH / d >= n_dof for JLIM.  start_state (2*n_dof), goal_states (G, 2*n_dof), q_min/q_max (n_dof),
+ * jl_total: one fp64 word, all device memory; pointers of disabled terms may be NULL.
+ * accumulate != 0 adds onto the existing out[b] (e.g. the collision costs mpb_stomp_sample wrote).
+ * ------------------------------------------------------------------------------------------- */
+#define MPB_TERM_GP 1u
+#define MPB_TERM_START 2u
+#define MPB_TERM_GOAL 4u
+#define MPB_TERM_SMOOTH 8u
+#define MPB_TERM_JLIM 16u
+#define MPB_TERM_VEL_FD 32u
+#define MPB_TERM_ALL 63u
+int mpb_cost_terms_eval(const float *trajs, float *out, double *jl_total, const float *start_state,
+                        const float *goal_states, const float *q_min, const float *q_max,
+                        int B, int H, int d, int n_dof, int trajs_per_goal, uint32_t flags, float dt,
+                        float k_gp, float k_start, float k_goal, float k_smooth, float k_jlim, float jl_eps,
+                        int accumulate, int broadcast_jlim, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * STOMP -- replaces STOMP._run_optimization's loop body (stomp.py:150-160):
  *   sample (stomp.py:97-108 + MultivariateNormal.rsample), _get_costs (base.py:218-223) with the
  *   collision cost above, _calc_sample_weights (stomp.py:219-220), _update_distribution (:199-211).

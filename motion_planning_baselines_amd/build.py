@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['mpb_kernels.hip', 'mpb_gpmp2.hip', 'mpb_mppi.hip', 'mpb_prior.hip', 'mpb_stoch_gpmp.hip']
+SOURCES = ['mpb_kernels.hip', 'mpb_gpmp2.hip', 'mpb_mppi.hip', 'mpb_prior.hip', 'mpb_stoch_gpmp.hip', 'mpb_costs.hip']
 OUT = os.path.join(CSRC, 'libmpb_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
          '-ffinite-math-only', '-fno-signed-zeros', '-fno-slp-vectorize']

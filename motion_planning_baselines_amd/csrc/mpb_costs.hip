@@ -1,0 +1,152 @@
+// mpb_costs.hip -- the trajectory-only cost terms of costs/cost_functions.py in ONE streaming pass.
+//
+// Replaces the eval() of CostGP (cost_functions.py:271-289), CostGPTrajectory (:344-354),
+// CostGPTrajectoryPositionOnlyWrapper (:365-368), CostSmoothnessCHOMP (:384-387), CostJointLimits
+// (:406-426) and CostGoalPrior (:523-536).  The reference launches a handful of broadcast / matmul ATen
+// ops per term and re-reads the (B,H,d) batch for each; here one wave owns one trajectory, stages it
+// once in LDS with coalesced loads, and every enabled term is evaluated from that tile (lane = waypoint),
+// so a CostComposite of several such terms costs one read of the batch.  HBM-bound: algorithmic bytes
+// 4*B*H*d read + 4*B written.  Sums are carried in fp64 (free: the kernel waits on memory).
+#include "mpb_common.h"
+
+#define COSTS_WAVES 4
+
+__global__ __launch_bounds__(64 * COSTS_WAVES) void cost_terms_kernel(
+    const float* __restrict__ trajs, float* __restrict__ out, double* __restrict__ jl_total,
+    const float* __restrict__ start_state, const float* __restrict__ goal_states, const float* __restrict__ q_min,
+    const float* __restrict__ q_max, int B, int H, int d, int D, int trajs_per_goal, uint32_t flags, float dt,
+    float k_gp, float k_start, float k_goal, float k_smooth, float k_jlim, float jl_eps, int accumulate) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * COSTS_WAVES + wave;
+    if (b >= B) return;                                   // whole wave leaves together; no block barriers below
+    const int LD = d | 1;                                 // odd row stride: lanes (= rows) hit distinct banks
+    float* X = lds + (size_t)wave * H * LD;               // this wave's trajectory tile, rows of LD words
+    const float* src = trajs + (size_t)b * H * d;
+    const int n = H * d;
+    for (int e = lane; e < n; e += 64) {                  // coalesced: consecutive lanes, consecutive words
+        const int r = e / d;
+        X[r * LD + (e - r * d)] = src[e];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+    const bool vel_fd = flags & MPB_TERM_VEL_FD;          // velocities = central differences of positions
+    const double ddt = (double)dt;
+    const double q11 = 12.0 / (ddt * ddt * ddt), q12 = -6.0 / (ddt * ddt), q22 = 4.0 / ddt;
+    const double inv_dt4 = 1.0 / (ddt * ddt * ddt * ddt), inv_2dt = 1.0 / (2.0 * ddt);
+    double acc = 0.0, jl = 0.0;
+    for (int h = lane; h < H; h += 64) {
+        const float* xh = X + h * LD;
+        // ---- GP prior factor h -> h+1 (gp_factor.py:52-56 error, :42-50 Q^-1)
+        if ((flags & MPB_TERM_GP) && h + 1 < H) {
+            const float* xn = xh + LD;
+            double s = 0.0;
+            for (int i = 0; i < D; ++i) {
+                double v0, v1;
+                if (vel_fd) {
+                    v0 = (h >= 1) ? ((double)xn[i] - (double)xh[i - LD]) * inv_2dt : 0.0;
+                    v1 = (h + 2 < H) ? ((double)xn[i + LD] - (double)xh[i]) * inv_2dt : 0.0;
+                } else {
+                    v0 = (double)xh[D + i];
+                    v1 = (double)xn[D + i];
+                }
+                const double ep = (double)xn[i] - ((double)xh[i] + ddt * v0), ev = v1 - v0;
+                s += q11 * ep * ep + 2.0 * q12 * ep * ev + q22 * ev * ev;
+            }
+            acc += (double)k_gp * s;
+        }
+        // ---- start prior on x_0 (unary_factor.py:18-32), all 2D state dims
+        if ((flags & MPB_TERM_START) && h == 0) {
+            double s = 0.0;
+            for (int i = 0; i < 2 * D; ++i) {
+                const double e = (double)start_state[i] - (double)xh[i];
+                s += e * e;
+            }
+            acc += (double)k_start * s;
+        }
+        // ---- goal prior on x_{H-1}: trajectory b belongs to goal b / trajs_per_goal (cost_functions.py:525-533)
+        if ((flags & MPB_TERM_GOAL) && h == H - 1) {
+            const float* g = goal_states + (size_t)(b / trajs_per_goal) * 2 * D;
+            double s = 0.0;
+            for (int i = 0; i < 2 * D; ++i) {
+                const double e = (double)g[i] - (double)xh[i];
+                s += e * e;
+            }
+            acc += (double)k_goal * s;
+        }
+        // ---- CHOMP smoothness x^T R x with R = K^T K (chomp.py:81-101) in factored form: rows of K x are
+        //      x_0, x_h - x_{h-1}, -x_{H-1}; every state column of the trajectory takes part
+        if (flags & MPB_TERM_SMOOTH) {
+            double s = 0.0;
+            for (int i = 0; i < d; ++i) {
+                const double x = (double)xh[i];
+                const double df = (h >= 1) ? x - (double)xh[i - LD] : x;
+                s += df * df;
+                if (h == H - 1) s += x * x;
+            }
+            acc += (double)k_smooth * inv_dt4 * s;
+        }
+        // ---- joint limits (cost_functions.py:406-426)
+        if (flags & MPB_TERM_JLIM) {
+            for (int i = 0; i < D; ++i) {
+                const double q = (double)xh[i];
+                const double lo = (double)q_min[i] + (double)jl_eps - q, hi = q - ((double)q_max[i] - (double)jl_eps);
+                if (lo > 0.0) jl += lo * lo;
+                if (hi > 0.0) jl += hi * hi;
+            }
+        }
+    }
+    acc = wave_sum_f64(acc);
+    if (flags & MPB_TERM_JLIM) {
+        jl = wave_sum_f64(jl);
+        if (lane == 0 && jl != 0.0) atomicAdd(jl_total, (double)k_jlim * jl);
+    }
+    if (lane == 0) out[b] = (accumulate ? out[b] : 0.f) + (float)acc;
+}
+
+// the reference's joint-limit cost is one scalar for the whole batch that the composite broadcasts
+__global__ void cost_add_scalar_kernel(float* __restrict__ out, const double* __restrict__ v, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) out[b] += (float)v[0];
+}
+
+extern "C" int mpb_cost_terms_eval(const float* trajs, float* out, double* jl_total, const float* start_state,
+                                   const float* goal_states, const float* q_min, const float* q_max, int B, int H,
+                                   int d, int n_dof, int trajs_per_goal, uint32_t flags, float dt, float k_gp,
+                                   float k_start, float k_goal, float k_smooth, float k_jlim, float jl_eps,
+                                   int accumulate, int broadcast_jlim, void* stream) {
+    if (B < 0 || H < 2 || H > MPB_MAX_H || n_dof < 1 || d < 1)
+        return mpb_fail(MPB_E_INVALID, "mpb_cost_terms_eval: bad shape");
+    if (flags & ~(uint32_t)MPB_TERM_ALL) return mpb_fail(MPB_E_INVALID, "mpb_cost_terms_eval: unknown term flag");
+    const bool fd = flags & MPB_TERM_VEL_FD;
+    if ((flags & (MPB_TERM_GP | MPB_TERM_JLIM)) && d < n_dof)
+        return mpb_fail(MPB_E_INVALID, "mpb_cost_terms_eval: d < n_dof");
+    if ((flags & MPB_TERM_GP) && !fd && d != 2 * n_dof)
+        return mpb_fail(MPB_E_INVALID, "mpb_cost_terms_eval: the GP term needs d == 2*n_dof (or MPB_TERM_VEL_FD with d == n_dof)");
+    if (fd && d != n_dof) return mpb_fail(MPB_E_INVALID, "mpb_cost_terms_eval: MPB_TERM_VEL_FD needs d == n_dof");
+    if ((flags & (MPB_TERM_START | MPB_TERM_GOAL)) && d != 2 * n_dof)
+        return mpb_fail(MPB_E_INVALID, "mpb_cost_terms_eval: start / goal priors need d == 2*n_dof");
+    if ((flags & MPB_TERM_GP) && !(dt > 0.f)) return mpb_fail(MPB_E_INVALID, "mpb_cost_terms_eval: dt must be > 0");
+    if ((flags & MPB_TERM_SMOOTH) && !(dt > 0.f)) return mpb_fail(MPB_E_INVALID, "mpb_cost_terms_eval: dt must be > 0");
+    if (B == 0) return MPB_OK;
+    if (!trajs || !out) return mpb_fail(MPB_E_INVALID, "mpb_cost_terms_eval: null pointer");
+    if ((flags & MPB_TERM_START) && !start_state) return mpb_fail(MPB_E_INVALID, "mpb_cost_terms_eval: start_state is NULL");
+    if ((flags & MPB_TERM_GOAL) && (!goal_states || trajs_per_goal < 1))
+        return mpb_fail(MPB_E_INVALID, "mpb_cost_terms_eval: goal_states NULL or trajs_per_goal < 1");
+    if ((flags & MPB_TERM_JLIM) && (!q_min || !q_max || !jl_total))
+        return mpb_fail(MPB_E_INVALID, "mpb_cost_terms_eval: joint-limit term needs q_min, q_max, jl_total");
+    const size_t lds = (size_t)COSTS_WAVES * H * (d | 1) * sizeof(float);
+    if (lds > 150 * 1024) return mpb_fail(MPB_E_UNSUPPORTED, "mpb_cost_terms_eval: H*d too large for the LDS tile");
+    hipStream_t st = (hipStream_t)stream;
+    if (flags & MPB_TERM_JLIM) {
+        if (hipMemsetAsync(jl_total, 0, sizeof(double), st) != hipSuccess)
+            return mpb_fail(MPB_E_HIP, "mpb_cost_terms_eval: hipMemsetAsync failed");
+    }
+    hipLaunchKernelGGL(cost_terms_kernel, dim3((B + COSTS_WAVES - 1) / COSTS_WAVES), dim3(64 * COSTS_WAVES), lds, st,
+                       trajs, out, jl_total, start_state, goal_states, q_min, q_max, B, H, d, n_dof, trajs_per_goal,
+                       flags, dt, k_gp, k_start, k_goal, k_smooth, k_jlim, jl_eps, accumulate);
+    if ((flags & MPB_TERM_JLIM) && broadcast_jlim)
+        hipLaunchKernelGGL(cost_add_scalar_kernel, dim3((B + 255) / 256), dim3(256), 0, st, out, jl_total, B);
+    return mpb_check_launch("mpb_cost_terms_eval");
+}

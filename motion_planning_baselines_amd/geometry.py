@@ -23,6 +23,7 @@ Definitions (all fp32):
 import math
 
 import numpy as np
+import torch
 
 GEOM_MAGIC = 0x4D504247  # 'MPBG'
 GEOM_VERSION = 3
@@ -70,6 +71,14 @@ class Robot:
         self.q_min_np = np.asarray(q_min, dtype=np.float32)
         self.q_max_np = np.asarray(q_max, dtype=np.float32)
         self.dt = dt
+
+    @property
+    def q_min(self):
+        return torch.from_numpy(self.q_min_np)
+
+    @property
+    def q_max(self):
+        return torch.from_numpy(self.q_max_np)
 
     # state slicing -- same meaning as torch_robotics' RobotBase (positions first, velocities last)
     def get_position(self, x):

@@ -78,6 +78,58 @@ def cost_collision_grad(trajs, geom, k_sigma, weight=1.0, h_begin=1):
     return out, grad
 
 
+TERM_GP, TERM_START, TERM_GOAL, TERM_SMOOTH, TERM_JLIM, TERM_VEL_FD = 1, 2, 4, 8, 16, 32   # include/mpb.h MPB_TERM_*
+
+
+def cost_terms_eval(trajs, n_dof, dt=0.0, k_gp=0.0, vel_fd=False, k_start=0.0, start_state=None, k_goal=0.0,
+                    goal_states=None, trajs_per_goal=1, k_smooth=0.0, k_jlim=0.0, q_min=None, q_max=None, jl_eps=0.0,
+                    out=None, accumulate=False, broadcast_jlim=True, terms=None):
+    """One pass over trajs (B,H,d) evaluating the enabled trajectory-only cost terms (mpb_cost_terms_eval).
+    A term is enabled by naming it in `terms` (iterable of 'gp','start','goal','smooth','jlim').
+    Returns (out (B,), jl_total 0-dim fp64 tensor or None)."""
+    B, H, d = trajs.shape
+    _chk(trajs, (B, H, d), 'trajs')
+    terms = set(terms or ())
+    unknown = terms - {'gp', 'start', 'goal', 'smooth', 'jlim'}
+    if unknown:
+        raise ValueError(f'unknown cost terms {sorted(unknown)}')
+    flags = 0
+    if 'gp' in terms:
+        flags |= TERM_GP | (TERM_VEL_FD if vel_fd else 0)
+    if 'start' in terms:
+        flags |= TERM_START
+        _chk(start_state, (2 * n_dof,), 'start_state')
+    if 'goal' in terms:
+        flags |= TERM_GOAL
+        if goal_states is None or goal_states.ndim != 2:
+            raise ValueError('goal_states (G, 2*n_dof) is required')
+        _chk(goal_states, (goal_states.shape[0], 2 * n_dof), 'goal_states')
+        if trajs_per_goal < 1 or goal_states.shape[0] * trajs_per_goal < B:
+            raise ValueError(f'{goal_states.shape[0]} goals x {trajs_per_goal} trajectories do not cover B={B}')
+    if 'smooth' in terms:
+        flags |= TERM_SMOOTH
+    jl_total = None
+    if 'jlim' in terms:
+        flags |= TERM_JLIM
+        _chk(q_min, (n_dof,), 'q_min')
+        _chk(q_max, (n_dof,), 'q_max')
+        jl_total = torch.zeros((), device=trajs.device, dtype=torch.float64)
+    if out is None:
+        if accumulate:
+            raise ValueError('accumulate needs an existing out buffer')
+        out = torch.empty(B, device=trajs.device, dtype=torch.float32)
+    else:
+        if out.numel() != B:
+            raise ValueError(f'out has {out.numel()} elements, expected {B}')
+        _chk(out, out.shape, 'out')
+    _lib.check(_lib.lib().mpb_cost_terms_eval(
+        _ptr(trajs), _ptr(out), _ptr(jl_total), _ptr(start_state), _ptr(goal_states), _ptr(q_min), _ptr(q_max),
+        B, H, d, int(n_dof), int(trajs_per_goal), flags, float(dt), float(k_gp), float(k_start), float(k_goal),
+        float(k_smooth), float(k_jlim), float(jl_eps), int(bool(accumulate)), int(bool(broadcast_jlim)), _stream()),
+        'mpb_cost_terms_eval')
+    return out, jl_total
+
+
 def stomp_step(means, eps, samples, costs, weights, L, Sigma, geom, S, D, k_sigma, weight, lr, temperature,
                n_iters=1, seed=0, iter0=0, particle_offset=0):
     P, H, d = means.shape

@@ -10,7 +10,7 @@ import torch
 
 from .. import ops
 from .base import OptimizationPlanner
-from .costs.cost_functions import fusable_collision
+from .costs.cost_functions import device_plan, fusable_collision
 
 
 def stomp_precision_matrix(n_support_points, dt, sigma_spectral, tensor_args):
@@ -127,6 +127,24 @@ class STOMP(OptimizationPlanner):
                            self.n_dof, cc.k_sigma, weight, self.lr, self.temperature, n_iters=opt_iters,
                            seed=self.seed, iter0=self._iter, particle_offset=self.particle_offset)
             self._iter += opt_iters
+        elif not observation and device_plan(self.cost, self.device) is not None:
+            # composite of HIP-served members: sample(+collision) kernel -> trajectory-terms kernel(s) -> update
+            # kernel, all queued on the stream without a host round trip
+            cc, weight, groups = device_plan(self.cost, self.device)
+            flat = self.state_particles.view(-1, self.n_support_points, self.d_state_opt)
+            for _ in range(opt_iters):
+                eps = self._draw_eps(1)
+                ops.stomp_sample(self._particle_means, None if eps is None else eps[0], self.state_particles,
+                                 self.scale_tril, self.num_samples, seed=self.seed, it=self._iter,
+                                 particle_offset=self.particle_offset,
+                                 geom=None if cc is None else cc.device_geometry(self.device),
+                                 costs=None if cc is None else self.costs,
+                                 k_sigma=0.0 if cc is None else cc.k_sigma, weight=weight)
+                self._iter += 1
+                for gi, spec in enumerate(groups):
+                    ops.cost_terms_eval(flat, self.n_dof, out=self.costs, accumulate=(cc is not None or gi > 0), **spec)
+                ops.stomp_update(self._particle_means, self.state_particles, self.costs, self._weights_buf,
+                                 self.Sigma, self.lr, self.temperature)
         else:
             # caller-supplied cost callable: sample kernel -> user cost on device tensors -> update kernel
             for _ in range(opt_iters):

@@ -184,6 +184,54 @@ def cost_gp_eval(x, start_state, D, dt, sigma_start, sigma_gp, tensor_args):
     return start_costs + gp_costs
 
 
+def cost_gp_trajectory_eval(x, D, dt, sigma_gp, tensor_args):
+    """CostGPTrajectory.eval (cost_functions.py:344-354): sum_t err_t^T Q^-1 err_t, no start term."""
+    dim = 2 * D
+    e = gp_error(x, gp_phi(D, dt, tensor_args)).unsqueeze(-1)
+    Qi = gp_Q_inv(D, dt, sigma_gp, tensor_args).reshape(1, 1, dim, dim)
+    return (e.transpose(2, 3) @ Qi @ e).sum(1).reshape(-1)
+
+
+def finite_difference_central(x, dt):
+    """Build-defined stand-in for torch_robotics' finite_difference_vector(method='central') (external;
+    call sites base.py:211, cost_functions.py:366): interior (x_{t+1}-x_{t-1})/(2 dt), zero end rows."""
+    out = torch.zeros_like(x)
+    out[..., 1:-1, :] = (x[..., 2:, :] - x[..., :-2, :]) / (2 * dt)
+    return out
+
+
+def cost_gp_trajectory_pos_only_eval(x_pos, D, dt, sigma_gp, tensor_args):
+    """CostGPTrajectoryPositionOnlyWrapper.eval (cost_functions.py:365-368)."""
+    x = torch.cat((x_pos, finite_difference_central(x_pos, dt)), dim=-1)
+    return cost_gp_trajectory_eval(x, D, dt, sigma_gp, tensor_args)
+
+
+def cost_smoothness_chomp_eval(x, dt, tensor_args):
+    """CostSmoothnessCHOMP.eval (cost_functions.py:384-387) with R from CHOMP._get_R_mat (chomp.py:81-101):
+    per (trajectory, state column) x^T R x.  The reference returns whatever the external
+    batched_weighted_dot_prod returns; the build defines the cost as the sum over columns -> (B,)."""
+    R = chomp_precision(x.shape[1], dt, tensor_args)
+    per_col = (x.transpose(-2, -1) @ R.unsqueeze(0) @ x).diagonal(dim1=-2, dim2=-1)      # (B, d)
+    return per_col.sum(-1), per_col
+
+
+def cost_joint_limits_eval(x, D, q_min, q_max, eps):
+    """CostJointLimits.eval (cost_functions.py:406-426).  `.sum(-1)` of the gathered 1-D violation vector
+    is a scalar: the cost is ONE number for the whole batch (quirk, like Q6), broadcast by the composite."""
+    pos = x[..., :D]
+    lo = torch.clamp(q_min + eps - pos, min=0.0)
+    hi = torch.clamp(pos - (q_max - eps), min=0.0)
+    return (lo ** 2).sum() + (hi ** 2).sum()
+
+
+def cost_goal_prior_multi_eval(x, goal_states, trajs_per_goal, sigma_goal):
+    """CostGoalPrior.eval (cost_functions.py:523-536): trajectory b belongs to goal b // trajs_per_goal."""
+    B = x.shape[0]
+    g = goal_states[torch.arange(B) // trajs_per_goal]
+    err = g - x[:, -1]
+    return (err * err).sum(-1) / sigma_goal ** 2
+
+
 def gpmp2_linear_system(x, robot, field, start_state, goal_state, D, dt,
                         sigma_start, sigma_gp, sigma_goal, sigma_coll, tensor_args):
     """Dense (A, b, K) exactly as CostComposite.get_linear_system stacks it (cost_functions.py:107-144)

@@ -32,6 +32,9 @@ from mp_baselines.planners.mppi import MPPI  # noqa: E402
 from mp_baselines.planners.stoch_gpmp import StochGPMP  # noqa: E402
 from mp_baselines.planners.dynamics.point import PointParticleDynamics  # noqa: E402
 from mp_baselines.planners.costs.cost_functions import CostCollision, CostComposite  # noqa: E402
+from mp_baselines.planners.costs.cost_functions import (CostGP, CostGPTrajectory,  # noqa: E402
+                                                        CostGPTrajectoryPositionOnlyWrapper, CostSmoothnessCHOMP,
+                                                        CostJointLimits, CostGoalPrior)
 from mp_baselines.planners.costs.factors.mp_priors_multi import MultiMPPrior  # noqa: E402
 from mp_baselines.planners.costs.factors.gp_factor import GPFactor  # noqa: E402
 from mp_baselines.planners.costs.factors.unary_factor import UnaryFactor  # noqa: E402
@@ -314,8 +317,49 @@ def gen_gp_prior(name, D, H, dt, seed):
     print(name, 'samples', smp.shape)
 
 
+def gen_cost_terms(name, robot, D, H, G_, npg, S, dt, seed):
+    """The trajectory-only cost classes of cost_functions.py (CostGP :234-314, CostGPTrajectory :317-357,
+    the position-only wrapper :360-368, CostSmoothnessCHOMP :371-390, CostJointLimits :393-429,
+    CostGoalPrior :488-536) evaluated by the reference on one batch, in fp32 and fp64."""
+    g = torch.Generator().manual_seed(seed)
+    B = G_ * npg * S
+    out = {}
+    qmin, qmax = torch.as_tensor(robot.q_min_np), torch.as_tensor(robot.q_max_np)
+    span = qmax - qmin
+    a = torch.linspace(0, 1, H).reshape(1, H, 1)
+    q0 = qmin + span * torch.rand(B, 1, D, generator=g)
+    q1 = qmin + span * (torch.rand(B, 1, D, generator=g) * 1.1 - 0.05)      # a few ends beyond the limits
+    pos = q0 * (1 - a) + q1 * a + 0.02 * span * torch.randn(B, H, D, generator=g)
+    vel = (q1 - q0) / ((H - 1) * dt) + 0.05 * torch.randn(B, H, D, generator=g)
+    trajs32 = torch.cat([pos, vel.expand(B, H, D)], -1).float().contiguous()
+    start = torch.cat([q0[0, 0], torch.zeros(D)]).float()
+    goals = torch.cat([q1[::npg * S, 0][:G_], torch.zeros(G_, D)], -1).float()
+    sig = dict(sigma_start=1e-2, sigma_gp=0.5)
+    for tag, ta in (('f32', TA32), ('f64', TA64)):
+        rr, _ = make_ref_geometry(robot, G.CollisionField(spheres=np.array([[9., 9., 9., 0.1]], np.float32)), ta)
+        rr.dt = dt
+        x = trajs32.to(**ta)
+        out['gp_' + tag] = npf(CostGP(rr, H, start.to(**ta), dt, sig, tensor_args=ta).eval(x))
+        out['gptraj_' + tag] = npf(CostGPTrajectory(rr, H, dt, sigma_gp=0.5, tensor_args=ta).eval(x))
+        out['gptraj_posonly_' + tag] = npf(
+            CostGPTrajectoryPositionOnlyWrapper(rr, H, dt, sigma_gp=0.5, tensor_args=ta).eval(x[..., :D]))
+        out['smooth_' + tag] = npf(CostSmoothnessCHOMP(rr, H, tensor_args=ta).eval(x))           # (B, d): see test
+        out['jlim_' + tag] = npf(CostJointLimits(rr, H, eps=float(np.deg2rad(3)), tensor_args=ta).eval(x))
+        out['goalprior_' + tag] = npf(CostGoalPrior(rr, H, multi_goal_states=goals.to(**ta), num_particles_per_goal=npg,
+                                                    num_samples=S, sigma_goal_prior=0.1, tensor_args=ta).eval(x))
+    np.savez_compressed(
+        os.path.join(HERE, name + '.npz'), planner='cost_terms', D=D, H=H, B=B, G=G_, npg=npg, S=S, dt=dt,
+        trajs=npf(trajs32), start=npf(start), goals=npf(goals), sigma_start=1e-2, sigma_gp=0.5, sigma_goal_prior=0.1,
+        jl_eps=float(np.deg2rad(3)), q_min=robot.q_min_np, q_max=robot.q_max_np, **out)
+    print(name, {k: (v.shape, float(np.sum(v))) for k, v in out.items() if k.endswith('f64')})
+
+
 def main():
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == 'cost_terms':
+        gen_cost_terms('cost_terms_pm2d', G.RobotPointMass(2, radius=0.01), D=2, H=64, G_=2, npg=3, S=4, dt=0.04, seed=0)
+        gen_cost_terms('cost_terms_panda', G.RobotPanda(), D=7, H=48, G_=1, npg=2, S=5, dt=0.1, seed=1)
+        return
     pm = G.RobotPointMass(2, radius=0.01)
     grid = G.env_grid_circles_2d()
     dense = G.env_dense_2d()
@@ -370,6 +414,10 @@ def main():
 
     # GP-prior initial sampling
     gen_gp_prior('gp_prior_d2_h8', D=2, H=8, dt=0.04, seed=0)
+
+    # trajectory-only cost classes
+    gen_cost_terms('cost_terms_pm2d', pm, D=2, H=64, G_=2, npg=3, S=4, dt=0.04, seed=0)
+    gen_cost_terms('cost_terms_panda', panda, D=7, H=48, G_=1, npg=2, S=5, dt=0.1, seed=1)
 
 
 if __name__ == '__main__':

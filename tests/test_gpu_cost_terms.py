@@ -1,0 +1,207 @@
+"""GPU: the trajectory-only cost classes (CostGP, CostGPTrajectory, position-only wrapper,
+CostSmoothnessCHOMP, CostJointLimits, CostGoalPrior, CostGoal) and CostComposite through
+mpb_cost_terms_eval, against goldens produced by the reference's own classes
+(tests/golden/make_goldens.py gen_cost_terms) and against the oracle on other inputs."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, product_geometry_from_golden, ref_geometry_from_golden
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+RTOL = 1e-4          # north_star tolerance (fp32, relative)
+
+
+def _robot(name, dt):
+    from motion_planning_baselines_amd import geometry as G
+    r = G.RobotPointMass(2, radius=0.01) if 'pm2d' in name else G.RobotPanda()
+    r.dt = dt
+    return r
+
+
+def _bar(g, key):
+    """max(1e-4, 2 x the reference's own fp32-vs-fp64 spread) for a golden quantity."""
+    a, b = g[key + '_f32'].astype(np.float64), g[key + '_f64']
+    env = float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+    return max(RTOL, 2 * env)
+
+
+def _close(got, want, bar):
+    got = got.detach().cpu().double().numpy()
+    err = float(np.max(np.abs(got - want)) / max(np.max(np.abs(want)), 1e-300))
+    assert err < bar, (err, bar)
+
+
+@pytest.mark.parametrize('name', ['cost_terms_pm2d', 'cost_terms_panda'])
+def test_cost_classes_vs_reference_golden(gpu_device, name):
+    from motion_planning_baselines_amd.planners.costs import cost_functions as C
+    g = load_golden(name)
+    dev = gpu_device
+    ta = dict(device=dev, dtype=torch.float32)
+    D, H, dt = int(g['D']), int(g['H']), float(g['dt'])
+    robot = _robot(name, dt)
+    assert np.array_equal(robot.q_min_np, g['q_min']) and np.array_equal(robot.q_max_np, g['q_max'])
+    x = T(g['trajs']).to(dev)
+    sig = dict(sigma_start=float(g['sigma_start']), sigma_gp=float(g['sigma_gp']))
+    gp = C.CostGP(robot, H, T(g['start']).to(dev), dt, sig, tensor_args=ta)
+    _close(gp(x), g['gp_f64'], _bar(g, 'gp'))
+    _close(C.CostGPTrajectory(robot, H, dt, sigma_gp=sig['sigma_gp'], tensor_args=ta)(x), g['gptraj_f64'], _bar(g, 'gptraj'))
+    _close(C.CostGPTrajectoryPositionOnlyWrapper(robot, H, dt, sigma_gp=sig['sigma_gp'], tensor_args=ta)(
+        x[..., :D].contiguous()), g['gptraj_posonly_f64'], _bar(g, 'gptraj_posonly'))
+    # the reference's stub returns per-column values (B, d); the build's cost is their sum
+    _close(C.CostSmoothnessCHOMP(robot, H, tensor_args=ta)(x), g['smooth_f64'].sum(-1), RTOL)
+    jl = C.CostJointLimits(robot, H, eps=float(g['jl_eps']), tensor_args=ta)(x)
+    assert jl.ndim == 0 and jl.dtype == torch.float32                  # batch-global scalar, as in the reference
+    _close(jl, g['jlim_f64'], _bar(g, 'jlim'))
+    gpr = C.CostGoalPrior(robot, H, multi_goal_states=T(g['goals']).to(dev), num_particles_per_goal=int(g['npg']),
+                          num_samples=int(g['S']), sigma_goal_prior=float(g['sigma_goal_prior']), tensor_args=ta)
+    _close(gpr(x), g['goalprior_f64'], _bar(g, 'goalprior'))
+    # 4-D input (N, B, H, d) is flattened like get_q_pos_vel_and_fk_map does (cost_functions.py:42-48)
+    x4 = x.reshape(2, -1, H, 2 * D)
+    _close(C.CostGPTrajectory(robot, H, dt, sigma_gp=sig['sigma_gp'], tensor_args=ta)(x4), g['gptraj_f64'], _bar(g, 'gptraj'))
+    # dense linear systems of the GP / goal factors reproduce the costs: b^T K b == cost
+    A, b, K = gp.get_linear_system(x)
+    _close((b.transpose(1, 2) @ K @ b).reshape(-1), g['gp_f64'], 1e-3)
+    A, b, K = gpr.get_linear_system(x[:int(g['G']) * int(g['npg'])])
+    assert A.shape == (int(g['G']) * int(g['npg']), 2 * D, 2 * D * H)
+
+
+@pytest.mark.parametrize('name', ['cost_terms_pm2d', 'cost_terms_panda'])
+def test_composite_one_pass_equals_sum_of_members(gpu_device, name):
+    """CostComposite.eval (cost_functions.py:70-87): weighted sum; all trajectory terms in one launch, the
+    joint-limit scalar broadcast to every trajectory, collision on the interpolated trajectories if given."""
+    from motion_planning_baselines_amd import geometry as G
+    from motion_planning_baselines_amd.planners.costs import cost_functions as C
+    from oracle import planners_ref as O
+    from oracle.geometry_ref import make_ref_geometry
+    g = load_golden(name)
+    dev = gpu_device
+    ta = dict(device=dev, dtype=torch.float32)
+    D, H, dt = int(g['D']), int(g['H']), float(g['dt'])
+    robot = _robot(name, dt)
+    field = G.env_grid_circles_2d() if D == 2 else G.env_spheres_3d()
+    x = T(g['trajs']).to(dev)
+    members = [
+        C.CostCollision(robot, H, field=field, sigma_coll=0.1, tensor_args=ta),
+        C.CostGPTrajectory(robot, H, dt, sigma_gp=float(g['sigma_gp']), tensor_args=ta),
+        C.CostJointLimits(robot, H, eps=float(g['jl_eps']), tensor_args=ta),
+        C.CostGoalPrior(robot, H, multi_goal_states=T(g['goals']).to(dev), num_particles_per_goal=int(g['npg']),
+                        num_samples=int(g['S']), sigma_goal_prior=float(g['sigma_goal_prior']), tensor_args=ta),
+        C.CostSmoothnessCHOMP(robot, H, tensor_args=ta),
+    ]
+    w = [1.0, 0.5, 3.0, 2.0, 1e-3]
+    comp = C.CostComposite(robot, H, members, weights_cost_l=w, tensor_args=ta)
+    coll, groups, other = comp.device_plan(dev)
+    assert len(coll) == 1 and len(groups) == 1 and not other           # four trajectory terms, one launch
+    total = comp(x)
+    # oracle: the same sum in fp64
+    ta64 = dict(device='cpu', dtype=torch.float64)
+    rr, rf = make_ref_geometry(robot, field, ta64)
+    x64 = T(g['trajs']).to(**ta64)
+    want = (w[0] * O.collision_cost(x64, rr, rf, 0.1)
+            + w[1] * O.cost_gp_trajectory_eval(x64, D, dt, float(g['sigma_gp']), ta64)
+            + w[2] * O.cost_joint_limits_eval(x64, D, T(g['q_min']).double(), T(g['q_max']).double(), float(g['jl_eps']))
+            + w[3] * O.cost_goal_prior_multi_eval(x64, T(g['goals']).double(), int(g['npg']) * int(g['S']),
+                                                  float(g['sigma_goal_prior']))
+            + w[4] * O.cost_smoothness_chomp_eval(x64, dt, ta64)[0])
+    _close(total, want.numpy(), RTOL)
+    # member list form
+    costs, weights = comp(x, return_invidual_costs_and_weights=True)
+    assert len(costs) == 5 and weights == w
+    acc = sum(wi * ci for wi, ci in zip(w, costs))
+    _close(acc, want.numpy(), RTOL)
+    # two members of the same kind cannot share a launch: they are accumulated by a second one
+    comp2 = C.CostComposite(robot, H, [members[1], members[1]], weights_cost_l=[1.0, 2.0], tensor_args=ta)
+    assert len(comp2.device_plan(dev)[1]) == 2
+    _close(comp2(x), 3.0 * O.cost_gp_trajectory_eval(x64, D, dt, float(g['sigma_gp']), ta64).numpy(), RTOL)
+    # interpolated trajectories feed the collision member only (cost_functions.py:77-84)
+    xi = torch.cat([x, x[:, -1:]], 1).contiguous()                      # (B, H+1, d) stand-in
+    tot_i = comp(x, trajs_interpolated=xi)
+    want_i = want - w[0] * O.collision_cost(x64, rr, rf, 0.1) + w[0] * O.collision_cost(
+        torch.cat([x64, x64[:, -1:]], 1), rr, rf, 0.1)
+    _close(tot_i, want_i.numpy(), RTOL)
+
+
+def test_cost_goal_last_waypoint(gpu_device):
+    from motion_planning_baselines_amd import geometry as G
+    from motion_planning_baselines_amd.planners.costs import cost_functions as C
+    from oracle.geometry_ref import make_ref_geometry
+    dev = gpu_device
+    ta = dict(device=dev, dtype=torch.float32)
+    robot, field = G.RobotPointMass(2, radius=0.01), G.env_dense_2d()
+    gen = torch.Generator().manual_seed(0)
+    x = (torch.rand(32, 16, 4, generator=gen) * 2 - 1).to(dev)
+    cg = C.CostGoal(robot, 16, field=field, sigma_goal=0.5, tensor_args=ta)
+    rr, rf = make_ref_geometry(robot, field, dict(device='cpu', dtype=torch.float64))
+    q = x[:, -1:, :2].cpu().double()
+    want = rf.compute_cost(q, rr.fk_map_collision(q)).reshape(32, 1).sum(1) / 0.5 ** 2
+    _close(cg(x), want.numpy(), RTOL)
+    assert C.CostGoal(robot, 16, field=None, sigma_goal=0.5, tensor_args=ta)(x) == 0
+    A, b, K = cg.get_linear_system(x)
+    assert A.shape == (32, 1, 64) and b.shape == (32, 1, 1) and K.shape == (32, 1, 1)
+
+
+def test_stomp_with_gp_and_collision_composite(gpu_device):
+    """STOMP on CostComposite([CostCollision, CostGPTrajectory]) runs sample -> terms -> update on the device
+    and follows the oracle's iteration with the same injected noise."""
+    from motion_planning_baselines_amd.planners.costs import cost_functions as C
+    from motion_planning_baselines_amd.planners.stomp import STOMP
+    from oracle import planners_ref as O
+    g = load_golden('stomp_pm2d_benign')
+    dev = gpu_device
+    ta = dict(device=dev, dtype=torch.float32)
+    robot, field = product_geometry_from_golden(g)
+    rr, rf = ref_geometry_from_golden(g, dtype=torch.float64)
+    P, S, H, D, dt = int(g['P']), int(g['S']), int(g['H']), int(g['D']), float(g['dt'])
+    sigma_coll, sigma_gp, w_gp = float(g['sigma_coll']), 2.0, 0.05
+    comp = C.CostComposite(robot, H, [C.CostCollision(robot, H, field=field, sigma_coll=sigma_coll, tensor_args=ta),
+                                      C.CostGPTrajectory(robot, H, dt, sigma_gp=sigma_gp, tensor_args=ta)],
+                           weights_cost_l=[1.0, w_gp], tensor_args=ta)
+    assert C.device_plan(comp, dev) is not None
+    pl = STOMP(n_dof=D, n_support_points=H, num_particles_per_goal=P, num_samples=S, opt_iters=1, dt=dt,
+               start_state=T(g['start']).to(dev), cost=comp, initial_particle_means=T(g['means0']).to(dev),
+               temperature=float(g['temperature']), step_size=float(g['lr']), sigma_spectral=float(g['sigma_spectral']),
+               pos_only=bool(g['pos_only']), tensor_args=ta, noise='torch_cpu')
+    pl.Sigma = T(g['Sigma']).to(dev).contiguous()
+    pl.scale_tril = T(g['L']).to(dev).contiguous()
+    ta64 = dict(device='cpu', dtype=torch.float64)
+    L64, Sig64 = T(g['L']).double(), T(g['Sigma']).double()
+    means = T(g['means0']).double()
+    cost_fn = lambda xx: (O.collision_cost(xx, rr, rf, sigma_coll)
+                          + w_gp * O.cost_gp_trajectory_eval(xx, D, dt, sigma_gp, ta64))
+    torch.manual_seed(11)
+    eps_all = [torch.empty(S, 2 * D, P, H).normal_() for _ in range(4)]
+    torch.manual_seed(11)
+    for it in range(4):
+        pl.optimize()
+        out = O.stomp_iteration(means, eps_all[it].double(), L64, Sig64, cost_fn, float(g['lr']), float(g['temperature']))
+        means = out['means']
+        _close(pl.costs.reshape(-1), out['costs'].reshape(-1).numpy(), 1e-3 if it else RTOL)
+    _close(pl._particle_means, means.numpy(), 1e-3)
+
+
+def test_cost_terms_error_behaviour(gpu_device):
+    from motion_planning_baselines_amd import ops
+    from motion_planning_baselines_amd._lib import MPBError
+    dev = gpu_device
+    x = torch.zeros(4, 16, 4, device=dev)
+    with pytest.raises(MPBError):
+        ops.cost_terms_eval(x, 3, dt=0.1, k_gp=1.0, terms={'gp'})               # d != 2 * n_dof
+    with pytest.raises(MPBError):
+        ops.cost_terms_eval(x, 2, dt=0.0, k_gp=1.0, terms={'gp'})               # dt
+    with pytest.raises(ValueError):
+        ops.cost_terms_eval(x, 2, dt=0.1, terms={'nope'})
+    with pytest.raises(ValueError):
+        ops.cost_terms_eval(x.cpu(), 2, dt=0.1, k_gp=1.0, terms={'gp'})         # no CPU path
+    with pytest.raises(ValueError):
+        ops.cost_terms_eval(x, 2, k_goal=1.0, goal_states=torch.zeros(1, 4, device=dev), trajs_per_goal=2, terms={'goal'})
+    out, _ = ops.cost_terms_eval(torch.zeros(0, 16, 4, device=dev), 2, dt=0.1, k_gp=1.0, terms={'gp'})
+    assert out.shape == (0,)
+    # long horizon (several waypoints per lane) against the oracle
+    from oracle import planners_ref as O
+    gen = torch.Generator().manual_seed(3)
+    xl = torch.randn(5, 200, 6, generator=gen)
+    want = O.cost_gp_trajectory_eval(xl.double(), 3, 0.05, 1.5, dict(device='cpu', dtype=torch.float64))
+    got, _ = ops.cost_terms_eval(xl.to(dev), 3, dt=0.05, k_gp=1 / 1.5 ** 2, terms={'gp'})
+    _close(got, want.numpy(), RTOL)

@@ -156,3 +156,26 @@ def test_stoch_gpmp_iterations(name):
         np.testing.assert_allclose(out['weights'].numpy(), g['weights'][it], rtol=1e-5, atol=1e-9)
         np.testing.assert_allclose(out['means'].numpy(), g['means'][it], rtol=1e-7, atol=1e-9)
         means = T(g['means'][it])
+
+
+@pytest.mark.parametrize('name', ['cost_terms_pm2d', 'cost_terms_panda'])
+@pytest.mark.parametrize('tag', ['f32', 'f64'])
+def test_cost_terms(name, tag):
+    """Trajectory-only cost classes (CostGP, CostGPTrajectory, position-only wrapper, CostSmoothnessCHOMP,
+    CostJointLimits, CostGoalPrior) as the reference evaluates them."""
+    g = load_golden(name)
+    ta = dict(device='cpu', dtype=torch.float32 if tag == 'f32' else torch.float64)
+    x = T(g['trajs']).to(**ta)
+    D, dt = int(g['D']), float(g['dt'])
+    rtol = 2e-5 if tag == 'f32' else 1e-12
+    ck = lambda got, key: np.testing.assert_allclose(got.numpy(), g[key + '_' + tag], rtol=rtol, atol=0)
+    ck(O.cost_gp_eval(x, T(g['start']).to(**ta), D, dt, float(g['sigma_start']), float(g['sigma_gp']), ta), 'gp')
+    ck(O.cost_gp_trajectory_eval(x, D, dt, float(g['sigma_gp']), ta), 'gptraj')
+    ck(O.cost_gp_trajectory_pos_only_eval(x[..., :D], D, dt, float(g['sigma_gp']), ta), 'gptraj_posonly')
+    tot, per_col = O.cost_smoothness_chomp_eval(x, dt, ta)
+    ck(per_col, 'smooth')
+    jl = O.cost_joint_limits_eval(x, D, T(g['q_min']).to(**ta), T(g['q_max']).to(**ta), float(g['jl_eps']))
+    assert g['jlim_' + tag].shape == ()                       # the reference's batch-global scalar
+    ck(jl, 'jlim')
+    ck(O.cost_goal_prior_multi_eval(x, T(g['goals']).to(**ta), int(g['npg']) * int(g['S']),
+                                    float(g['sigma_goal_prior'])), 'goalprior')
