@@ -92,6 +92,18 @@ int mpb_cost_terms_eval(const float *trajs, float *out, double *jl_total, const 
                         int accumulate, int broadcast_jlim, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Trajectory utilities either side of the loop (both external to the reference: torch_robotics).
+ *   mpb_traj_interpolate       -- interpolate_points_v1 (call site cost_functions.py:118): n_interp evenly
+ *                                 spaced points inserted between consecutive waypoints, linear in joint
+ *                                 space: trajs (B,H,d) -> out (B,(H-1)*(n_interp+1)+1,d).
+ *   mpb_traj_finite_difference -- finite_difference_vector(method='central') + the concatenation of
+ *                                 OptimizationPlanner._get_traj (base.py:204-213): pos (B,H,D) ->
+ *                                 out (B,H,2D) = [pos, (pos_{t+1}-pos_{t-1})/(2 dt)], zero end velocities.
+ * ------------------------------------------------------------------------------------------- */
+int mpb_traj_interpolate(const float *trajs, float *out, int B, int H, int d, int n_interp, void *stream);
+int mpb_traj_finite_difference(const float *pos, float *out, int B, int H, int D, float dt, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * STOMP -- replaces STOMP._run_optimization's loop body (stomp.py:150-160):
  *   sample (stomp.py:97-108 + MultivariateNormal.rsample), _get_costs (base.py:218-223) with the
  *   collision cost above, _calc_sample_weights (stomp.py:219-220), _update_distribution (:199-211).
@@ -155,7 +167,10 @@ int mpb_chomp_step(float *means, const float *R, const float *geom, float *costs
  *
  * One iteration = linearize -> [diag] -> solve:
  *   mpb_gpmp2_linearize : collision cost c_t and Jacobian h_t = -dc_t/dq of every waypoint (FieldFactor
- *                         get_error(calc_jacobian=True), field_factor.py:41-57) into the workspace;
+ *                         get_error(calc_jacobian=True), field_factor.py:41-57) into the workspace.
+ *                         n_interp > 0 (CostComposite.get_linear_system(n_interpolated_points),
+ *                         cost_functions.py:115-119): h_t = -d/dq_t of the summed cost of the trajectory
+ *                         with n_interp points inserted per segment (see mpb_traj_interpolate); c_t unchanged;
  *   mpb_gpmp2_diag      : LOCAL SUM over the B particles of diag(A^T K A) (H*2D fp64) -- quirk Q9: the
  *                         trust-region damping uses the BATCH MEAN of that diagonal (gpmp2.py:361-367).
  *                         diag_sum_out NULL: kept in the workspace.  When sharded, the host all-reduces
@@ -167,7 +182,8 @@ int mpb_chomp_step(float *means, const float *R, const float *geom, float *costs
  *   mpb_gpmp2_step      : n_iters full iterations on one GPU (mean over the local B).
  * ------------------------------------------------------------------------------------------- */
 size_t mpb_gpmp2_workspace_bytes(int B, int H, int D);
-int mpb_gpmp2_linearize(const float *x, const float *geom, void *workspace, int B, int H, int D, void *stream);
+int mpb_gpmp2_linearize(const float *x, const float *geom, void *workspace, int B, int H, int D, int n_interp,
+                        void *stream);
 int mpb_gpmp2_diag(void *workspace, double *diag_sum_out, int B, int H, int D, float dt,
                    float sigma_start, float sigma_gp, float sigma_goal, float sigma_coll, void *stream);
 int mpb_gpmp2_solve(float *x, const float *start, const float *goal, const double *diag_mean, void *workspace,
@@ -177,7 +193,7 @@ int mpb_gpmp2_solve(float *x, const float *start, const float *goal, const doubl
 int mpb_gpmp2_step(float *x, const float *start, const float *goal, const float *geom, void *workspace,
                    float *costs_out, int B, int H, int D, float dt,
                    float sigma_start, float sigma_gp, float sigma_goal, float sigma_coll,
-                   float delta, int trust_region, float step_size, int n_iters, void *stream);
+                   float delta, int trust_region, float step_size, int n_iters, int n_interp, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * MPPI -- replaces MPPI.optimize's loop body (mppi.py:145-152): ControlTrajectoryGaussian.sample

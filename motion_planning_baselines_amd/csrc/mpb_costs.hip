@@ -150,3 +150,66 @@ extern "C" int mpb_cost_terms_eval(const float* trajs, float* out, double* jl_to
         hipLaunchKernelGGL(cost_add_scalar_kernel, dim3((B + 255) / 256), dim3(256), 0, st, out, jl_total, B);
     return mpb_check_launch("mpb_cost_terms_eval");
 }
+
+// ------------------------------------------------------------------------------------------------
+// trajectory utilities: streaming element-wise kernels, one thread per output word (coalesced stores)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void traj_interpolate_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                               size_t total, int H, int Ho, int d, int n1) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = e / d;
+        const int i = (int)(e - row * d);
+        const size_t b = row / Ho;
+        const int ho = (int)(row - b * Ho);
+        const int seg = ho / n1, k = ho - seg * n1;              // ho = seg*(n+1) + k; the last row is seg = H-1, k = 0
+        const float* p = x + ((size_t)b * H + seg) * d + i;
+        const float x0 = p[0];
+        float v = x0;
+        if (k > 0) v = x0 + ((float)k / (float)n1) * (p[d] - x0);
+        out[e] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void traj_fd_kernel(const float* __restrict__ pos, float* __restrict__ out, size_t total,
+                                                      int H, int D, float inv_2dt) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = e / (2 * D);
+        const int i = (int)(e - row * 2 * D);
+        const int t = (int)(row % H);
+        const float* p = pos + row * D;
+        float v;
+        if (i < D) {
+            v = p[i];
+        } else {
+            const int j = i - D;
+            v = (t >= 1 && t + 1 < H) ? (p[D + j] - p[j - D]) * inv_2dt : 0.f;
+        }
+        out[e] = v;
+    }
+}
+
+static inline int stream_grid(size_t total) {
+    size_t g = (total + 255) / 256;
+    return (int)(g > 16384 ? 16384 : g);
+}
+
+extern "C" int mpb_traj_interpolate(const float* trajs, float* out, int B, int H, int d, int n_interp, void* stream) {
+    if (B < 0 || H < 2 || d < 1 || n_interp < 0) return mpb_fail(MPB_E_INVALID, "mpb_traj_interpolate: bad shape");
+    if (B == 0) return MPB_OK;
+    if (!trajs || !out) return mpb_fail(MPB_E_INVALID, "mpb_traj_interpolate: null pointer");
+    const int n1 = n_interp + 1, Ho = (H - 1) * n1 + 1;
+    const size_t total = (size_t)B * Ho * d;
+    hipLaunchKernelGGL(traj_interpolate_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, trajs, out, total,
+                       H, Ho, d, n1);
+    return mpb_check_launch("mpb_traj_interpolate");
+}
+
+extern "C" int mpb_traj_finite_difference(const float* pos, float* out, int B, int H, int D, float dt, void* stream) {
+    if (B < 0 || H < 2 || D < 1 || !(dt > 0.f)) return mpb_fail(MPB_E_INVALID, "mpb_traj_finite_difference: bad shape or dt");
+    if (B == 0) return MPB_OK;
+    if (!pos || !out) return mpb_fail(MPB_E_INVALID, "mpb_traj_finite_difference: null pointer");
+    const size_t total = (size_t)B * H * 2 * D;
+    hipLaunchKernelGGL(traj_fd_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, pos, out, total, H, D,
+                       1.f / (2.f * dt));
+    return mpb_check_launch("mpb_traj_finite_difference");
+}

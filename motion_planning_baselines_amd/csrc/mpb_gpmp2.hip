@@ -31,29 +31,66 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 // (t = 0 is excluded from the collision factor: traj_range [1, None]).  One wave per particle, lane = waypoint.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gpmp2_linearize_kernel(const float* __restrict__ x, const float* __restrict__ geom,
-                                                              float* __restrict__ jac, int B, int H, int D) {
+                                                              float* __restrict__ jac, int B, int H, int D, int n_interp) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (b >= B) return;
     const GeomView G = geom_view(geom);
     const int dim = 2 * D;
-    for (int t = lane; t < H; t += 64) {
-        const float* row = x + ((size_t)b * H + t) * dim;
-        float q[MPB_MAX_DOF], dq[MPB_MAX_DOF];
+    // n_interp > 0 (CostComposite.get_linear_system with n_interpolated_points, cost_functions.py:115-119;
+    // field_factor.py:42-54): the Jacobian row of support point t is d/dq_t of the summed cost of the
+    // INTERPOLATED trajectory, i.e. its own gradient plus (1-a) * grad of every interior point of segment
+    // (t, t+1) plus a * grad of every interior point of segment (t-1, t); the error c_t stays the support
+    // point's own.  Lane t evaluates the interior points of ITS segment once and hands the a-weighted part
+    // to lane t+1 (carry across 64-waypoint chunks).
+    float carry[MPB_MAX_DOF];
 #pragma unroll
-        for (int i = 0; i < MPB_MAX_DOF; ++i) q[i] = (i < D) ? row[i] : 0.f;
-        float c = 0.f;
-        if (t >= 1) {
-            c = waypoint_cost<true>(G, q, dq);
-        } else {
+    for (int i = 0; i < MPB_MAX_DOF; ++i) carry[i] = 0.f;
+    for (int base = 0; base < H; base += 64) {
+        const int t = base + lane;
+        const bool active = t < H;
+        const float* row = x + ((size_t)b * H + (active ? t : 0)) * dim;
+        float q[MPB_MAX_DOF], dq[MPB_MAX_DOF], gnext[MPB_MAX_DOF];
 #pragma unroll
-            for (int i = 0; i < MPB_MAX_DOF; ++i) dq[i] = 0.f;
+        for (int i = 0; i < MPB_MAX_DOF; ++i) {
+            q[i] = (i < D) ? row[i] : 0.f;
+            dq[i] = 0.f;
+            gnext[i] = 0.f;
         }
-        float* o = jac + ((size_t)b * H + t) * (D + 1);
+        float c = 0.f;
+        if (active && t >= 1) c = waypoint_cost<true>(G, q, dq);
+        if (n_interp > 0) {
+            if (active && t + 1 < H) {
+                float qn[MPB_MAX_DOF];
 #pragma unroll
-        for (int i = 0; i < MPB_MAX_DOF; ++i)
-            if (i < D) o[i] = -dq[i];
-        o[D] = c;
+                for (int i = 0; i < MPB_MAX_DOF; ++i) qn[i] = (i < D) ? row[dim + i] : 0.f;
+                for (int k = 1; k <= n_interp; ++k) {
+                    const float al = (float)k / (float)(n_interp + 1);
+                    float qi[MPB_MAX_DOF], dqi[MPB_MAX_DOF];
+#pragma unroll
+                    for (int i = 0; i < MPB_MAX_DOF; ++i) qi[i] = q[i] + al * (qn[i] - q[i]);
+                    waypoint_cost<true>(G, qi, dqi);
+#pragma unroll
+                    for (int i = 0; i < MPB_MAX_DOF; ++i) {
+                        dq[i] = fmaf(1.f - al, dqi[i], dq[i]);
+                        gnext[i] = fmaf(al, dqi[i], gnext[i]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MPB_MAX_DOF; ++i) {
+                const float up = __shfl_up(gnext[i], 1, 64);
+                dq[i] += (lane == 0) ? carry[i] : up;
+                carry[i] = __shfl(gnext[i], 63, 64);
+            }
+        }
+        if (active) {
+            float* o = jac + ((size_t)b * H + t) * (D + 1);
+#pragma unroll
+            for (int i = 0; i < MPB_MAX_DOF; ++i)
+                if (i < D) o[i] = -dq[i];
+            o[D] = c;
+        }
     }
 }
 
@@ -409,12 +446,14 @@ static GpWork gp_carve(void* ws, int B, int H, int D) {
     return w;
 }
 
-extern "C" int mpb_gpmp2_linearize(const float* x, const float* geom, void* workspace, int B, int H, int D, void* stream) {
+extern "C" int mpb_gpmp2_linearize(const float* x, const float* geom, void* workspace, int B, int H, int D, int n_interp,
+                                   void* stream) {
     if (!x || !geom || !workspace) return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_linearize: null pointer");
-    if (!gp_shape_ok(B, H, D)) return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_linearize: bad shape");
+    if (!gp_shape_ok(B, H, D) || n_interp < 0 || n_interp > 64) return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_linearize: bad shape");
     if (B == 0) return MPB_OK;
     GpWork w = gp_carve(workspace, B, H, D);
-    hipLaunchKernelGGL(gpmp2_linearize_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, geom, w.jac, B, H, D);
+    hipLaunchKernelGGL(gpmp2_linearize_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, geom, w.jac, B, H, D,
+                       n_interp);
     return mpb_check_launch("mpb_gpmp2_linearize");
 }
 
@@ -456,13 +495,13 @@ extern "C" int mpb_gpmp2_solve(float* x, const float* start, const float* goal, 
 extern "C" int mpb_gpmp2_step(float* x, const float* start, const float* goal, const float* geom, void* workspace,
                               float* costs_out, int B, int H, int D, float dt, float sigma_start, float sigma_gp,
                               float sigma_goal, float sigma_coll, float delta, int trust_region, float step_size,
-                              int n_iters, void* stream) {
+                              int n_iters, int n_interp, void* stream) {
     if (!x || !start || !goal || !geom || !workspace) return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_step: null pointer");
     if (!gp_shape_ok(B, H, D) || n_iters < 0) return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_step: bad shape");
     if (B == 0) return MPB_OK;
     GpWork w = gp_carve(workspace, B, H, D);
     for (int it = 0; it < n_iters; ++it) {
-        int rc = mpb_gpmp2_linearize(x, geom, workspace, B, H, D, stream);
+        int rc = mpb_gpmp2_linearize(x, geom, workspace, B, H, D, n_interp, stream);
         if (rc) return rc;
         if (trust_region) {
             rc = mpb_gpmp2_diag(workspace, nullptr, B, H, D, dt, sigma_start, sigma_gp, sigma_goal, sigma_coll, stream);

@@ -130,6 +130,26 @@ def cost_terms_eval(trajs, n_dof, dt=0.0, k_gp=0.0, vel_fd=False, k_start=0.0, s
     return out, jl_total
 
 
+def traj_interpolate(trajs, n_interp):
+    """(B,H,d) -> (B,(H-1)(n+1)+1,d): n evenly spaced joint-space points per segment (mpb_traj_interpolate)."""
+    B, H, d = trajs.shape
+    _chk(trajs, (B, H, d), 'trajs')
+    n = int(n_interp)
+    out = torch.empty(B, (H - 1) * (n + 1) + 1, d, device=trajs.device, dtype=torch.float32)
+    _lib.check(_lib.lib().mpb_traj_interpolate(_ptr(trajs), _ptr(out), B, H, d, n, _stream()), 'mpb_traj_interpolate')
+    return out
+
+
+def traj_finite_difference(pos, dt):
+    """(B,H,D) positions -> (B,H,2D) [pos, central-difference velocities] (mpb_traj_finite_difference)."""
+    B, H, D = pos.shape
+    _chk(pos, (B, H, D), 'pos')
+    out = torch.empty(B, H, 2 * D, device=pos.device, dtype=torch.float32)
+    _lib.check(_lib.lib().mpb_traj_finite_difference(_ptr(pos), _ptr(out), B, H, D, float(dt), _stream()),
+               'mpb_traj_finite_difference')
+    return out
+
+
 def stomp_step(means, eps, samples, costs, weights, L, Sigma, geom, S, D, k_sigma, weight, lr, temperature,
                n_iters=1, seed=0, iter0=0, particle_offset=0):
     P, H, d = means.shape
@@ -195,7 +215,8 @@ def gpmp2_workspace(B, H, D, device):
     return torch.empty(n, dtype=torch.uint8, device=device)
 
 
-def gpmp2_step(x, start, goal, geom, workspace, sigmas, dt, delta, trust_region, step_size, n_iters=1, costs_out=None):
+def gpmp2_step(x, start, goal, geom, workspace, sigmas, dt, delta, trust_region, step_size, n_iters=1, costs_out=None,
+               n_interp=0):
     """n_iters Gauss-Newton iterations on one GPU.  sigmas = (start, gp, goal, coll)."""
     B, H, dim = x.shape
     D = dim // 2
@@ -207,14 +228,14 @@ def gpmp2_step(x, start, goal, geom, workspace, sigmas, dt, delta, trust_region,
     _lib.check(_lib.lib().mpb_gpmp2_step(
         _ptr(x), _ptr(start), _ptr(goal), _ptr(geom.buf), _ptr(workspace), _ptr(costs_out), B, H, D, float(dt),
         float(sigmas[0]), float(sigmas[1]), float(sigmas[2]), float(sigmas[3]), float(delta), int(bool(trust_region)),
-        float(step_size), int(n_iters), _stream()), 'mpb_gpmp2_step')
+        float(step_size), int(n_iters), int(n_interp or 0), _stream()), 'mpb_gpmp2_step')
 
 
-def gpmp2_linearize(x, geom, workspace):
+def gpmp2_linearize(x, geom, workspace, n_interp=0):
     B, H, dim = x.shape
     _chk(x, (B, H, dim), 'x')
-    _lib.check(_lib.lib().mpb_gpmp2_linearize(_ptr(x), _ptr(geom.buf), _ptr(workspace), B, H, dim // 2, _stream()),
-               'mpb_gpmp2_linearize')
+    _lib.check(_lib.lib().mpb_gpmp2_linearize(_ptr(x), _ptr(geom.buf), _ptr(workspace), B, H, dim // 2,
+                                              int(n_interp or 0), _stream()), 'mpb_gpmp2_linearize')
 
 
 def gpmp2_diag(workspace, B, H, D, sigmas, dt):

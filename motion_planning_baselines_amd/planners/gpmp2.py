@@ -36,8 +36,11 @@ class GPMP2(OptimizationPlanner):
                          multi_goal_states=multi_goal_states, sigma_start_init=sigma_start_init,
                          sigma_goal_init=sigma_goal_init, sigma_gp_init=sigma_gp_init, pos_only=False,
                          tensor_args=tensor_args)
-        if n_interpolated_points is not None:
-            raise NotImplementedError('trajectory interpolation for collision checking is SURVEY 8(f) rank 3 (next)')
+        # quirk Q13: the reference's GPMP2.__init__ accepts n_interpolated_points but never forwards it to the base
+        # class (gpmp2.py:94-131), so the attribute is None after construction (base.py:85) and the interpolated
+        # collision Jacobian (cost_functions.py:115-119) only runs when a caller sets the attribute afterwards.
+        # Same here: the ctor argument is ignored, the attribute is honoured by _step.
+        self.n_interpolated_points = None
         if not collision_fields or len(collision_fields) != 1:
             raise NotImplementedError('GPMP2 on the GPU takes exactly one CollisionField')
         solver_params = solver_params or dict(delta=1e-2, trust_region=True, method='cholesky')
@@ -94,7 +97,7 @@ class GPMP2(OptimizationPlanner):
         trust = self.solver_params.get('trust_region', False)
         x = self._particle_means
         if trust and self.process_group is not None and dist.get_world_size(self.process_group) > 1:
-            ops.gpmp2_linearize(x, self.geom, self._ws)
+            ops.gpmp2_linearize(x, self.geom, self._ws, n_interp=self.n_interpolated_points)
             dsum = ops.gpmp2_diag(self._ws, B, H, D, self.sigmas, self.dt)
             nb = torch.tensor([float(B)], device=self.device, dtype=torch.float64)
             dist.all_reduce(dsum, group=self.process_group)     # one H*2D fp64 vector per iteration
@@ -103,7 +106,7 @@ class GPMP2(OptimizationPlanner):
                             self.step_size, costs_out=self.costs)
         else:
             ops.gpmp2_step(x, self._start, self._goal, self.geom, self._ws, self.sigmas, self.dt, delta, trust,
-                           self.step_size, n_iters=1, costs_out=self.costs)
+                           self.step_size, n_iters=1, costs_out=self.costs, n_interp=self.n_interpolated_points)
 
     def optimize(self, opt_iters=None, debug=False, **observation):
         """gpmp2.py:273-306 incl. the optional relative-change stop criterion (:286-293)."""

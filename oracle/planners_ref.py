@@ -232,8 +232,18 @@ def cost_goal_prior_multi_eval(x, goal_states, trajs_per_goal, sigma_goal):
     return (err * err).sum(-1) / sigma_goal ** 2
 
 
+def interpolate_trajs(x, n):
+    """Build-defined stand-in for torch_robotics' interpolate_points_v1 (external; call site
+    cost_functions.py:118): n evenly spaced points between consecutive waypoints, linear in joint space,
+    (B,H,d) -> (B,(H-1)(n+1)+1,d); original waypoints keep their values."""
+    x0, x1 = x[:, :-1, None, :], x[:, 1:, None, :]
+    alpha = (torch.arange(n + 1, dtype=x.dtype) / (n + 1)).reshape(n + 1, 1)
+    seg = x0 + alpha * (x1 - x0)
+    return torch.cat((seg.flatten(1, 2), x[:, -1:]), dim=1)
+
+
 def gpmp2_linear_system(x, robot, field, start_state, goal_state, D, dt,
-                        sigma_start, sigma_gp, sigma_goal, sigma_coll, tensor_args):
+                        sigma_start, sigma_gp, sigma_goal, sigma_coll, tensor_args, n_interp=None):
     """Dense (A, b, K) exactly as CostComposite.get_linear_system stacks it (cost_functions.py:107-144)
     for the cost list of build_gpmp2_cost_composite (gpmp2.py:23-91): CostGP (:291-314), CostGoalPrior
     (:538-554), CostCollision (:191-231; Jacobian = -d err/d q by autograd, field_factor.py:41-57).
@@ -268,7 +278,12 @@ def gpmp2_linear_system(x, robot, field, start_state, goal_state, D, dt,
     q_pos = robot.get_position(xg)
     link_pos = robot.fk_map_collision(q_pos)
     err = field.compute_cost(q_pos[:, 1:], link_pos[:, 1:]).reshape(B, H - 1)
-    Hobst = -torch.autograd.grad(err.sum(), xg)[0][:, 1:, :D]                     # field_factor.py:54
+    err_j = err
+    if n_interp:        # Jacobian of the INTERPOLATED trajectory's error w.r.t. the support points; b keeps
+        xi = interpolate_trajs(xg, n_interp)                                      # the support-point error
+        qi = robot.get_position(xi)                                               # (field_factor.py:42-54,
+        err_j = field.compute_cost(qi[:, 1:], robot.fk_map_collision(qi)[:, 1:])  #  cost_functions.py:115-119)
+    Hobst = -torch.autograd.grad(err_j.sum(), xg)[0][:, 1:, :D]                   # field_factor.py:54
     A3 = torch.zeros(B, H - 1, N, **tensor_args)
     for i in range(H - 1):
         A3[:, i, (i + 1) * dim:(i + 1) * dim + D] = Hobst[:, i]
@@ -300,11 +315,11 @@ def gpmp2_normal_equations(A, b, K, delta, trust_region):
 
 
 def gpmp2_iteration(x, robot, field, start_state, goal_state, D, dt, sigma_start, sigma_gp, sigma_goal,
-                    sigma_coll, delta, trust_region, step_size, tensor_args):
+                    sigma_coll, delta, trust_region, step_size, tensor_args, n_interp=None):
     """One GPMP2._step (gpmp2.py:308-342) with method='cholesky' (:451-452) and cost b^T K b (:493-495)."""
     B, H, dim = x.shape
     A, b, K = gpmp2_linear_system(x, robot, field, start_state, goal_state, D, dt,
-                                  sigma_start, sigma_gp, sigma_goal, sigma_coll, tensor_args)
+                                  sigma_start, sigma_gp, sigma_goal, sigma_coll, tensor_args, n_interp=n_interp)
     JtJ, g = gpmp2_normal_equations(A, b, K, delta, trust_region)
     l, _ = torch.linalg.cholesky_ex(JtJ)
     dtheta = torch.cholesky_solve(g, l).view(B, H, dim)

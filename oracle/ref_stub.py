@@ -10,7 +10,9 @@ generating golden vectors (tests/golden/make_goldens.py).  Nothing here is copie
   batched_weighted_dot_prod(x, M, y) : per (batch, channel) x_c^T M y_c   -> (..., d)
   finite_difference_vector(x, dt)    : central difference along the horizon axis, zero at both ends
   TimerCUDA                          : wall-clock context manager
-  link_pos_from_link_tensor, interpolate_points_v1, tensor_linspace_v1, smoothen_trajectory :
+  interpolate_points_v1(x, n)        : n evenly spaced points inserted between every pair of consecutive
+                                       waypoints (linear, in joint space): (B,H,d) -> (B,(H-1)(n+1)+1,d)
+  link_pos_from_link_tensor, tensor_linspace_v1, smoothen_trajectory :
       imported by the reference but never executed on the paths in scope; they raise if called.
 """
 import sys
@@ -23,6 +25,14 @@ import torch
 def batched_weighted_dot_prod(x, M, y, with_einsum=False):
     r = x.transpose(-2, -1) @ M.unsqueeze(0) @ y
     return r.diagonal(dim1=-2, dim2=-1)
+
+
+def interpolate_points_v1(points, num_interpolated_points):
+    x0, x1 = points[..., :-1, None, :], points[..., 1:, None, :]
+    n = num_interpolated_points
+    alpha = (torch.arange(n + 1, dtype=points.dtype, device=points.device) / (n + 1)).reshape(n + 1, 1)
+    seg = x0 + alpha * (x1 - x0)                                   # (..., H-1, n+1, d): start point + n interior
+    return torch.cat((seg.flatten(-3, -2), points[..., -1:, :]), dim=-2)
 
 
 def finite_difference_vector(x, dt=1.0, method='central'):
@@ -78,7 +88,7 @@ def install():
         'torch_robotics.torch_planning_objectives': {},
         'torch_robotics.torch_planning_objectives.fields': {},
         'torch_robotics.torch_planning_objectives.fields.distance_fields': dict(
-            interpolate_points_v1=_not_in_scope('interpolate_points_v1')),
+            interpolate_points_v1=interpolate_points_v1),
     }
     for name, attrs in tree.items():
         m = types.ModuleType(name)

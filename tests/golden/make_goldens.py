@@ -161,7 +161,7 @@ def gen_chomp(name, robot, field, starts, goals, H, dt, sigma_coll, weight, iter
 
 
 def gen_gpmp2(name, robot, field, start, goal, B, H, dt, iters, seed, ta, sig=None, delta=1e-2,
-              trust_region=True, step_size=1.0, init_noise=0.02):
+              trust_region=True, step_size=1.0, init_noise=0.02, n_interp=None):
     sig = sig or dict(sigma_start=1e-5, sigma_gp=1e-2, sigma_coll=1e-5, sigma_goal_prior=1e-5)
     rr, rf = make_ref_geometry(robot, field, ta)
     start, goal = start.to(**ta), goal.to(**ta)
@@ -175,7 +175,12 @@ def gen_gpmp2(name, robot, field, start, goal, B, H, dt, iters, seed, ta, sig=No
                sigma_start_init=1e-3, sigma_goal_init=1e-3, sigma_gp_init=1.0,
                sigma_start_sample=1e-3, sigma_goal_sample=1e-3,
                solver_params=dict(delta=delta, trust_region=trust_region, method='cholesky'),
-               collision_fields=[rf], tensor_args=ta, **sig)
+               collision_fields=[rf], tensor_args=ta, n_interpolated_points=n_interp, **sig)
+    # quirk Q13: GPMP2.__init__ (gpmp2.py:94-131) swallows n_interpolated_points without forwarding it to the
+    # base class, which therefore stores None (base.py:85); the interpolated Jacobian only runs when the
+    # attribute is set on the instance afterwards
+    assert pl.n_interpolated_points is None
+    pl.n_interpolated_points = n_interp
     rec = dict(A=[], b=[], K=[], JtJ=[], g=[], means=[], costs=[])
     orig_ls = pl.cost.get_linear_system
     orig_gt = pl._get_grad_terms
@@ -211,6 +216,7 @@ def gen_gpmp2(name, robot, field, start, goal, B, H, dt, iters, seed, ta, sig=No
     np.savez_compressed(
         os.path.join(HERE, name + '.npz'),
         planner='gpmp2', B=B, H=H, D=robot.q_dim, dt=dt, delta=delta, trust_region=trust_region,
+        n_interp=0 if n_interp is None else n_interp,
         step_size=step_size, dtype=str(ta['dtype']), start=npf(start), goal=npf(goal), means0=npf(means0),
         **sig, **keep, **geom_arrays(robot, field))
     print(name, 'costs', rec['costs'][0][:3], '->', rec['costs'][-1][:3])
@@ -356,6 +362,14 @@ def gen_cost_terms(name, robot, D, H, G_, npg, S, dt, seed):
 
 def main():
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == 'gpmp2_interp':
+        gen_gpmp2('gpmp2_pm2d_h8_interp_f64', G.RobotPointMass(2, radius=0.01), G.env_dense_2d(),
+                  torch.tensor([-0.4, -0.4]), torch.tensor([0.4, 0.4]), B=3, H=8, dt=0.04, iters=3, seed=0, ta=TA64,
+                  n_interp=3)
+        qc = free_configs(G.RobotPanda(), G.env_spheres_3d(), 12, 11, TA32)     # pair (8, 9): the line crosses obstacles
+        gen_gpmp2('gpmp2_panda_h16_interp_f64', G.RobotPanda(), G.env_spheres_3d(), qc[8], qc[9], B=2, H=16, dt=5 / 16,
+                  iters=3, seed=1, ta=TA64, n_interp=2)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'cost_terms':
         gen_cost_terms('cost_terms_pm2d', G.RobotPointMass(2, radius=0.01), D=2, H=64, G_=2, npg=3, S=4, dt=0.04, seed=0)
         gen_cost_terms('cost_terms_panda', G.RobotPanda(), D=7, H=48, G_=1, npg=2, S=5, dt=0.1, seed=1)
@@ -402,6 +416,12 @@ def main():
     gen_gpmp2('gpmp2_pm2d_h8_notr_f64', pm, dense, s2 * 0.5, g2 * 0.5, B=3, H=8, dt=0.04, iters=3, seed=0, ta=TA64,
               trust_region=False)
     gen_gpmp2('gpmp2_panda_h16_f64', panda, sph3, q[0], q[1], B=2, H=16, dt=5 / 16, iters=3, seed=1, ta=TA64)
+    # with n_interpolated_points: collision Jacobian of the interpolated trajectory (build-defined interpolation)
+    gen_gpmp2('gpmp2_pm2d_h8_interp_f64', pm, dense, s2 * 0.5, g2 * 0.5, B=3, H=8, dt=0.04, iters=3, seed=0, ta=TA64,
+              n_interp=3)
+    qc = free_configs(panda, sph3, 12, 11, TA32)                                # pair (8, 9): the line crosses obstacles
+    gen_gpmp2('gpmp2_panda_h16_interp_f64', panda, sph3, qc[8], qc[9], B=2, H=16, dt=5 / 16, iters=3, seed=1, ta=TA64,
+              n_interp=2)
 
     # StochGPMP (fp64 reference run: its fp32 dense scale_tril is not reproducible)
     gen_stoch_gpmp('sgpmp_pm2d_h16_f64', pm, dense, s2 * 0.5, g2 * 0.5, P=3, S=8, H=16, dt=0.08, iters=3, seed=0, ta=TA64)

@@ -22,7 +22,7 @@ def dev_geom(g, device):
 
 
 @pytest.mark.parametrize('name', ['gpmp2_pm2d_h8_f64', 'gpmp2_pm2d_h8_notr_f64', 'gpmp2_panda_h16_f64',
-                                  'gpmp2_pm2d_h8_f32'])
+                                  'gpmp2_pm2d_h8_f32', 'gpmp2_pm2d_h8_interp_f64', 'gpmp2_panda_h16_interp_f64'])
 def test_gpmp2_vs_golden(gpu_device, name):
     """Teacher-forced Gauss-Newton steps.  The fp64 goldens are the reference run with
     tensor_args dtype=float64 (its fp32 dense Cholesky at kappa ~ 1e10+ is not reproducible: H4);
@@ -42,7 +42,8 @@ def test_gpmp2_vs_golden(gpu_device, name):
         x = prev.clone().to(dev)
         costs = torch.empty(B, device=dev)
         ops.gpmp2_step(x, start, goal, geom, ws, sig, float(g['dt']), float(g['delta']), bool(g['trust_region']),
-                       float(g['step_size']), n_iters=1, costs_out=costs)
+                       float(g['step_size']), n_iters=1, costs_out=costs,
+                       n_interp=int(g['n_interp']) if 'n_interp' in g else 0)
         torch.cuda.synchronize()
         ref = T(g['means'][it]).float()
         dref = ref - prev

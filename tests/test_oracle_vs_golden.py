@@ -55,7 +55,7 @@ def test_chomp_iterations(name):
 
 
 @pytest.mark.parametrize('name', ['gpmp2_pm2d_h8_f64', 'gpmp2_pm2d_h8_f32', 'gpmp2_pm2d_h8_notr_f64',
-                                  'gpmp2_panda_h16_f64'])
+                                  'gpmp2_panda_h16_f64', 'gpmp2_pm2d_h8_interp_f64', 'gpmp2_panda_h16_interp_f64'])
 def test_gpmp2_iterations(name):
     g = load_golden(name)
     dt64 = 'float64' in str(g['dtype'])
@@ -68,7 +68,8 @@ def test_gpmp2_iterations(name):
     x = T(g['means0']).to(**ta)
     for it in range(g['means'].shape[0]):
         kw = dict(D=D, dt=float(g['dt']), sigma_start=float(g['sigma_start']), sigma_gp=float(g['sigma_gp']),
-                  sigma_goal=float(g['sigma_goal_prior']), sigma_coll=float(g['sigma_coll']), tensor_args=ta)
+                  sigma_goal=float(g['sigma_goal_prior']), sigma_coll=float(g['sigma_coll']), tensor_args=ta,
+                  n_interp=int(g['n_interp']) if 'n_interp' in g else None)
         if 'A' in g:
             A, b, K = O.gpmp2_linear_system(x, robot, field, start, goal, **kw)
             np.testing.assert_allclose(A.numpy(), g['A'][it], rtol=1e-6 if dt64 else 1e-4, atol=1e-9 if dt64 else 1e-5)
