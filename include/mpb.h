@@ -92,14 +92,21 @@ int mpb_cost_terms_eval(const float *trajs, float *out, double *jl_total, const 
                         int accumulate, int broadcast_jlim, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Trajectory utilities either side of the loop (both external to the reference: torch_robotics).
+ * Trajectory utilities either side of the loop (all external to the reference: torch_robotics; build-defined).
  *   mpb_traj_interpolate       -- interpolate_points_v1 (call site cost_functions.py:118): n_interp evenly
  *                                 spaced points inserted between consecutive waypoints, linear in joint
  *                                 space: trajs (B,H,d) -> out (B,(H-1)*(n_interp+1)+1,d).
  *   mpb_traj_finite_difference -- finite_difference_vector(method='central') + the concatenation of
  *                                 OptimizationPlanner._get_traj (base.py:204-213): pos (B,H,D) ->
  *                                 out (B,H,2D) = [pos, (pos_{t+1}-pos_{t-1})/(2 dt)], zero end velocities.
+ *   mpb_traj_resample          -- the warm start of HybridPlanner.optimize (hybrid_planner.py:42-66, over the
+ *                                 external smoothen_trajectory / tensor_linspace_v1): N polylines of
+ *                                 lengths[n] <= Lmax waypoints (paths (N,Lmax,D), rows beyond the length
+ *                                 ignored) -> out (N,H,2D): H points uniform in arc length, linear in
+ *                                 between, velocity = (last - first)/((H-1) dt) on interior points, 0 at ends.
  * ------------------------------------------------------------------------------------------- */
+int mpb_traj_resample(const float *paths, const int *lengths, float *out, int N, int Lmax, int H, int D, float dt,
+                      void *stream);
 int mpb_traj_interpolate(const float *trajs, float *out, int B, int H, int d, int n_interp, void *stream);
 int mpb_traj_finite_difference(const float *pos, float *out, int B, int H, int D, float dt, void *stream);
 

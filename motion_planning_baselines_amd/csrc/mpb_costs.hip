@@ -213,3 +213,72 @@ extern "C" int mpb_traj_finite_difference(const float* pos, float* out, int B, i
                        1.f / (2.f * dt));
     return mpb_check_launch("mpb_traj_finite_difference");
 }
+
+// ------------------------------------------------------------------------------------------------
+// warm start of HybridPlanner (hybrid_planner.py:42-66): every sample-based path (a polyline with its own
+// number of waypoints) becomes H support points + velocities.  One wave per path: segment lengths ->
+// wave-wide inclusive scan into LDS (cumulative arc length) -> every output waypoint bisects its arc-length
+// target and interpolates linearly.  Ragged input: paths padded to Lmax rows, lengths[n] valid rows.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void traj_resample_kernel(const float* __restrict__ paths, const int* __restrict__ lengths,
+                                                           float* __restrict__ out, int Lmax, int H, int D, float dt) {
+    extern __shared__ double cum[];                        // cum[k] = arc length from waypoint 0 to waypoint k (fp64:
+    const int n = blockIdx.x, lane = threadIdx.x;          // hundreds of segments are summed)
+    const int L = min(max(lengths[n], 1), Lmax);
+    const float* P = paths + (size_t)n * Lmax * D;
+    double carry = 0.0;
+    for (int base = 0; base < L; base += 64) {
+        const int k = base + lane;
+        double seg = 0.0;
+        if (k >= 1 && k < L) {
+            double s2 = 0.0;
+            for (int i = 0; i < D; ++i) {
+                const double df = (double)P[(size_t)k * D + i] - (double)P[(size_t)(k - 1) * D + i];
+                s2 = fma(df, df, s2);
+            }
+            seg = sqrt(s2);
+        }
+        for (int off = 1; off < 64; off <<= 1) {           // inclusive scan over the wave
+            const double up = __shfl_up(seg, off, 64);
+            if (lane >= off) seg += up;
+        }
+        if (k < L) cum[k] = carry + seg;
+        carry += __shfl(seg, 63, 64);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const double total = cum[L - 1];
+    const float* p0 = P;
+    const float* p1 = P + (size_t)(L - 1) * D;
+    for (int h = lane; h < H; h += 64) {
+        float* o = out + ((size_t)n * H + h) * 2 * D;
+        const double target = total * ((double)h / (double)(H - 1));
+        // largest k with cum[k] <= target (cum is non-decreasing, cum[0] = 0)
+        int lo = 0, hi = L - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (cum[mid] <= target) lo = mid; else hi = mid - 1;
+        }
+        const int k0 = lo, k1 = min(lo + 1, L - 1);
+        const double span = cum[k1] - cum[k0];
+        const double a = span > 0.0 ? (target - cum[k0]) / span : 0.0;
+        const bool interior = h >= 1 && h + 1 < H;
+        for (int i = 0; i < D; ++i) {
+            const double x0 = P[(size_t)k0 * D + i], x1 = P[(size_t)k1 * D + i];
+            o[i] = (h == 0) ? p0[i] : (h == H - 1) ? p1[i] : (float)(x0 + a * (x1 - x0));
+            // average velocity of the whole motion on the interior points, rest at both ends
+            o[D + i] = interior ? (float)(((double)p1[i] - (double)p0[i]) / ((double)(H - 1) * (double)dt)) : 0.f;
+        }
+    }
+}
+
+extern "C" int mpb_traj_resample(const float* paths, const int* lengths, float* out, int N, int Lmax, int H, int D, float dt,
+                                 void* stream) {
+    if (N < 0 || Lmax < 1 || H < 2 || D < 1 || !(dt > 0.f)) return mpb_fail(MPB_E_INVALID, "mpb_traj_resample: bad shape or dt");
+    if ((size_t)Lmax * sizeof(double) > 150 * 1024) return mpb_fail(MPB_E_UNSUPPORTED, "mpb_traj_resample: Lmax too large for LDS");
+    if (N == 0) return MPB_OK;
+    if (!paths || !lengths || !out) return mpb_fail(MPB_E_INVALID, "mpb_traj_resample: null pointer");
+    hipLaunchKernelGGL(traj_resample_kernel, dim3(N), dim3(64), (size_t)Lmax * sizeof(double), (hipStream_t)stream, paths, lengths,
+                       out, Lmax, H, D, dt);
+    return mpb_check_launch("mpb_traj_resample");
+}

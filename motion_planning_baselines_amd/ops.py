@@ -140,6 +140,19 @@ def traj_interpolate(trajs, n_interp):
     return out
 
 
+def traj_resample(paths, lengths, H, dt):
+    """N padded polylines (N,Lmax,D) with `lengths` (N,) int32 valid rows -> (N,H,2D) support points uniform in
+    arc length + average-velocity channel (mpb_traj_resample)."""
+    N, Lmax, D = paths.shape
+    _chk(paths, (N, Lmax, D), 'paths')
+    if not (lengths.is_cuda and lengths.dtype == torch.int32 and lengths.is_contiguous() and tuple(lengths.shape) == (N,)):
+        raise ValueError('lengths must be a contiguous int32 GPU tensor of shape (N,)')
+    out = torch.empty(N, H, 2 * D, device=paths.device, dtype=torch.float32)
+    _lib.check(_lib.lib().mpb_traj_resample(_ptr(paths), _ptr(lengths), _ptr(out), N, Lmax, int(H), D, float(dt), _stream()),
+               'mpb_traj_resample')
+    return out
+
+
 def traj_finite_difference(pos, dt):
     """(B,H,D) positions -> (B,H,2D) [pos, central-difference velocities] (mpb_traj_finite_difference)."""
     B, H, D = pos.shape

@@ -437,3 +437,30 @@ def stoch_gpmp_iteration(means, eps, scale_tril, Sigma_inv, cost_fn, temperature
     w = torch.softmax(-costs / temperature, dim=1)
     grad = (w.reshape(P, S, 1, 1) * (samples - means.unsqueeze(1))).sum(1)
     return dict(samples=samples, costs=costs, weights=w, means=means + step_size * grad)
+
+
+# ------------------------------------------------------------------------------------------------
+# HybridPlanner warm start  (hybrid_planner.py:42-66)
+# ------------------------------------------------------------------------------------------------
+
+def resample_path(path, H, dt):
+    """Build-defined stand-in for torch_robotics' smoothen_trajectory(set_average_velocity=True) (external;
+    call site hybrid_planner.py:52-55): polyline (L,D) -> (H,2D); positions uniform in arc length and linear
+    within a segment, first/last point exact; velocity (last-first)/((H-1) dt) on interior points, 0 at ends."""
+    import numpy as np
+    P = np.asarray(path, dtype=np.float64)
+    L, D = P.shape
+    seg = np.sqrt(((P[1:] - P[:-1]) ** 2).sum(-1)) if L > 1 else np.zeros(0)
+    cum = np.concatenate([[0.0], np.cumsum(seg)])
+    out = np.zeros((H, 2 * D))
+    for h in range(H):
+        target = cum[-1] * h / (H - 1)
+        k0 = int(np.searchsorted(cum, target, side='right') - 1)
+        k0 = min(max(k0, 0), L - 1)
+        k1 = min(k0 + 1, L - 1)
+        span = cum[k1] - cum[k0]
+        a = (target - cum[k0]) / span if span > 0 else 0.0
+        out[h, :D] = P[k0] + a * (P[k1] - P[k0])
+    out[0, :D], out[-1, :D] = P[0], P[-1]
+    out[1:-1, D:] = (P[-1] - P[0]) / ((H - 1) * dt)
+    return torch.from_numpy(out)
