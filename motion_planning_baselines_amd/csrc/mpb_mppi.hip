@@ -1,10 +1,17 @@
-// mpb_mppi.hip -- MPPI on point-particle dynamics, one workgroup per problem, one thread per control sample.
+// mpb_mppi.hip -- MPPI on point-particle dynamics: one workgroup per problem, one WAVE per control sample,
+// one LANE per time step.
 //
 // Replaces MPPI.optimize's loop body (mppi.py:145-152): ControlTrajectoryGaussian.sample
-// (priors/gaussian.py:276-298: per control dim, mean + scale_tril @ eps), the sequential Euler rollout
+// (priors/gaussian.py:276-298: per control dim, mean + scale_tril @ eps), the Euler rollout
 // (mppi.py:205-209 over PointParticleDynamics.dynamics, point.py:102-140, deterministic), traj_cost
 // (point.py:154-226 incl. quirks Q6 / Q8), the importance-sampling term (mppi.py:125-128) and
 // update_controller (mppi.py:72-86).  All `n_iters` iterations run inside one launch.
+//
+// The reference walks the horizon in a Python loop (one dynamics + cost call per step).  Velocity-controlled
+// point dynamics are x_{t+1} = x_t + clamp(u_t) dt, i.e. a prefix sum over time, so here the horizon is the
+// lane axis: the T x T noise product is T fma per lane against an LDS-resident transposed scale_tril, the
+// rollout is a wave scan, the per-step costs (incl. the collision field) are evaluated by all lanes at once
+// and reduced with DPP; the sequential depth per iteration drops from O(T * (T + cost)) to O(T + log T).
 //
 // Only velocity control is served (state_dim == control_dim): with control_type='acceleration' the
 // reference's dynamics slices an empty tensor (point.py:114-118 uses the doubled self.state_dim) and
@@ -33,6 +40,25 @@ __device__ __forceinline__ float block_max(float v, float* red, int lane, int wa
     return t;
 }
 
+__device__ __forceinline__ float wave_scan_incl(float v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float up = __shfl_up(v, off, 64);
+        if (lane >= off) v += up;
+    }
+    return v;
+}
+
+struct MppiLds {
+    float* wvec;   // c*T   : Cov_inv[i] @ mean[:, i]
+    float* red;    // 64    : scratch of the block reductions
+    float* wts;    // S     : sample weights
+    float* cst;    // S     : sample costs
+    float* Us;     // S*c*T : controls of every sample, [s][i][t]
+    float* epsw;   // W*c*T : standard normals of the sample a wave is working on, [wave][i][t]
+    float* trilT;  // c*T*T : scale_tril transposed [i][k][t] (only when it fits)
+};
+
 __global__ __launch_bounds__(1024) void mppi_kernel(
     float* __restrict__ mean, const float* __restrict__ eps, const float* __restrict__ tril,
     const float* __restrict__ cov_inv, const float* __restrict__ state0, const float* __restrict__ goal,
@@ -40,135 +66,182 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
     const float* __restrict__ cw, const float* __restrict__ geom, float* __restrict__ controls,
     float* __restrict__ states, float* __restrict__ costs, float* __restrict__ weights, int S, int T, int c,
     float dt, float k_sigma, float weight, float temp, float step_size, int n_iters, uint32_t seed_lo,
-    uint32_t seed_hi, uint32_t iter0) {
+    uint32_t seed_hi, uint32_t iter0, int tril_in_lds) {
     extern __shared__ float lds[];
-    float* wvec = lds;           // c*T : Cov_inv[i] @ mean[:, i]
-    float* red = wvec + c * T;   // 32 floats of scratch for block reductions
-    float* wts = red + 32;       // S : sample weights
-    const int SP = blockDim.x;   // controls slab in LDS, sample index fastest: Us[(t*c + i)*SP + s] (conflict-free)
-    float* Us = wts + ((S + 3) & ~3);
+    const int nw = blockDim.x >> 6, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    MppiLds M;
+    M.wvec = lds;
+    M.red = M.wvec + c * T;
+    M.wts = M.red + 64;
+    M.cst = M.wts + ((S + 3) & ~3);
+    M.Us = M.cst + ((S + 3) & ~3);
+    M.epsw = M.Us + (size_t)S * c * T;
+    M.trilT = M.epsw + (size_t)nw * c * T;
     const int prob = blockIdx.x;
-    const int s = threadIdx.x;
-    const bool live = s < S;
-    const int lane = s & 63, wave = s >> 6, nw = blockDim.x >> 6;
     float* m = mean + (size_t)prob * T * c;
-    float* U = controls + ((size_t)prob * S + (live ? s : 0)) * T * c;
-    float* X = states + ((size_t)prob * S + (live ? s : 0)) * T * c;  // velocity control: state_dim == c
     const float w_pos = cw[0], w_ctrl = cw[2], w_posT = cw[3];
     GeomView G;
     if (geom != nullptr) G = geom_view(geom);
+    if (tril_in_lds) {
+        for (int e = threadIdx.x; e < c * T * T; e += blockDim.x) {       // coalesced read, transposed write
+            const int i = e / (T * T), r = e - i * T * T, t = r / T, k = r - t * T;
+            M.trilT[((size_t)i * T + k) * T + t] = tril[e];
+        }
+    }
+    float gl[MPPI_MAX_C], x0[MPPI_MAX_C], umin[MPPI_MAX_C], umax[MPPI_MAX_C];
+#pragma unroll
+    for (int i = 0; i < MPPI_MAX_C; ++i) {
+        const bool on = i < c;
+        gl[i] = on ? goal[(size_t)prob * c + i] : 0.f;
+        x0[i] = on ? state0[(size_t)prob * c + i] : 0.f;
+        umin[i] = on ? ctrl_min[i] : 0.f;
+        umax[i] = on ? ctrl_max[i] : 0.f;
+    }
+    float* ew = M.epsw + (size_t)wave * c * T;
 
     for (int it = 0; it < n_iters; ++it) {
+        const bool last = it == n_iters - 1;
         __syncthreads();
         // ---- w_i = Cov_inv[i] @ mean_i (vector of the importance-sampling term)
         for (int e = threadIdx.x; e < c * T; e += blockDim.x) {
             const int i = e / T, t = e - i * T;
             float a = 0.f;
             for (int k = 0; k < T; ++k) a = fmaf(cov_inv[((size_t)i * T + t) * T + k], m[k * c + i], a);
-            wvec[e] = a;
+            M.wvec[e] = a;
         }
         __syncthreads();
-        float cost = 0.f, coll = 0.f;
-        if (live) {
-            // ---- standard normals into this sample's controls slab, then U = mean + L eps in place
-            //      (L lower triangular: row t only needs eps[k <= t], so sweep t downwards)
+        float coll_wave = 0.f;                                  // this wave's share of the Q6 scalar
+        for (int s = wave; s < S; s += nw) {
+            // ---- standard normals of sample s: injected (reference draw order (c, S, T)) or Philox
             for (int i = 0; i < c; ++i) {
-                if (eps != nullptr) {
-                    const float* ep = eps + ((((size_t)it * gridDim.x + prob) * c + i) * S + s) * T;
-                    for (int t = 0; t < T; ++t) Us[(t * c + i) * SP + s] = ep[t];
-                } else {
-                    for (int t4 = 0; t4 < T; t4 += 4) {
+                for (int t = lane; t < T; t += 64) {
+                    float e;
+                    if (eps != nullptr) {
+                        e = eps[((((size_t)it * gridDim.x + prob) * c + i) * S + s) * T + t];
+                    } else {
                         const uint4 r = philox4x32_10(
-                            make_uint4((uint32_t)prob, (uint32_t)s, (uint32_t)(t4 >> 2) | ((uint32_t)i << 16), iter0 + (uint32_t)it),
+                            make_uint4((uint32_t)prob, (uint32_t)s, (uint32_t)(t >> 2) | ((uint32_t)i << 16), iter0 + (uint32_t)it),
                             make_uint2(seed_lo, seed_hi));
-                        float n[4];
-                        box_muller(r.x, r.y, n[0], n[1]);
-                        box_muller(r.z, r.w, n[2], n[3]);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            if (t4 + q < T) Us[((t4 + q) * c + i) * SP + s] = n[q];
+                        float n0, n1, n2, n3;
+                        box_muller(r.x, r.y, n0, n1);
+                        box_muller(r.z, r.w, n2, n3);
+                        const int q = t & 3;
+                        e = (q == 0) ? n0 : (q == 1) ? n1 : (q == 2) ? n2 : n3;
                     }
-                }
-                for (int t = T - 1; t >= 0; --t) {
-                    const float* trow = tril + ((size_t)i * T + t) * T;   // wave-uniform row: scalar loads
-                    float a = 0.f;
-#pragma unroll 8
-                    for (int k = 0; k <= t; ++k) a = fmaf(trow[k], Us[(k * c + i) * SP + s], a);
-                    const float u = m[t * c + i] + a;
-                    Us[(t * c + i) * SP + s] = u;
-                    U[t * c + i] = u;                                      // API-visible controls
+                    ew[i * T + t] = e;
                 }
             }
-            // ---- Euler rollout (mppi.py:205-209) + quadratic cost (point.py:198-226)
-            float x[MPPI_MAX_C], is_term[MPPI_MAX_C];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float carry[MPPI_MAX_C];
 #pragma unroll
-            for (int i = 0; i < MPPI_MAX_C; ++i) {
-                x[i] = (i < c) ? state0[(size_t)prob * c + i] : 0.f;
-                is_term[i] = 0.f;
-            }
-            float pos_cost = 0.f, ctl_cost = 0.f, term = 0.f;
-            for (int t = 0; t < T; ++t) {
-                float pc = 0.f, cc = 0.f, tc = 0.f;
+            for (int i = 0; i < MPPI_MAX_C; ++i) carry[i] = 0.f;
+            float pos_l = 0.f, ctl_l = 0.f, is_l = 0.f, term_l = 0.f, coll_l = 0.f;
+            for (int base = 0; base < T; base += 64) {
+                const int t = base + lane;
+                const bool on = t < T;
+                const int kend = min(base + 64, T);            // entries above the diagonal are zero: no lane mask
+                float u[MPPI_MAX_C], x[MPPI_MAX_C];
 #pragma unroll
                 for (int i = 0; i < MPPI_MAX_C; ++i) {
-                    if (i < c) {
-                        X[t * c + i] = x[i];
-                        const float dx = x[i] - goal[(size_t)prob * c + i];
-                        pc += dx * dx * w_pos;
-                        tc += dx * dx * w_posT;
-                        const float u = Us[(t * c + i) * SP + s];
-                        cc += u * u * w_ctrl;
-                        is_term[i] = fmaf(u, wvec[i * T + t], is_term[i]);
+                    u[i] = 0.f;
+                    if (i < c && on) {
+                        // U = mean + L eps (gaussian.py:276-298), ascending k like the matmul row
+                        float a = 0.f;
+                        if (tril_in_lds) {
+                            const float* col = M.trilT + (size_t)i * T * T + t;
+                            for (int k = 0; k < kend; ++k) a = fmaf(col[(size_t)k * T], ew[i * T + k], a);
+                        } else {
+                            const float* row = tril + ((size_t)i * T + t) * T;
+                            for (int k = 0; k < kend; ++k) a = fmaf(row[k], ew[i * T + k], a);
+                        }
+                        u[i] = m[t * c + i] + a;
+                        M.Us[((size_t)s * c + i) * T + t] = u[i];
                     }
                 }
-                pos_cost += pc * discount[t];
-                ctl_cost += cc * discount[t];
-                if (t == T - 1) term = tc * discount[T - 1];
-                if (geom != nullptr && t >= 1) {
-                    float q[MPB_MAX_DOF], dq[MPB_MAX_DOF];
+                // ---- Euler rollout (mppi.py:205-209, point.py:112, :139): x_t = x_0 + sum_{k<t} clamp(u_k) dt
 #pragma unroll
-                    for (int i = 0; i < MPB_MAX_DOF; ++i) q[i] = (i < MPPI_MAX_C && i < c) ? x[i < MPPI_MAX_C ? i : 0] : 0.f;
-                    coll += waypoint_cost<false>(G, q, dq);
+                for (int i = 0; i < MPPI_MAX_C; ++i) {
+                    const float v = (i < c && on) ? fminf(fmaxf(u[i], umin[i]), umax[i]) * dt : 0.f;
+                    const float inc = wave_scan_incl(v, lane);
+                    x[i] = x0[i] + (carry[i] + (inc - v));
+                    carry[i] += __shfl(inc, 63, 64);
                 }
-                if (t < T - 1) {
+                if (on) {
+                    // ---- quadratic cost terms of step t (point.py:198-226)
+                    float pc = 0.f, cc = 0.f, tc = 0.f, is = 0.f;
 #pragma unroll
                     for (int i = 0; i < MPPI_MAX_C; ++i) {
                         if (i < c) {
-                            const float u = fminf(fmaxf(Us[(t * c + i) * SP + s], ctrl_min[i]), ctrl_max[i]);  // point.py:112
-                            x[i] = x[i] + u * dt;                                                   // point.py:139
+                            const float dx = x[i] - gl[i];
+                            pc += dx * dx * w_pos;
+                            tc += dx * dx * w_posT;
+                            cc += u[i] * u[i] * w_ctrl;
+                            is = fmaf(u[i], M.wvec[i * T + t], is);
                         }
+                    }
+                    const float dsc = discount[t];
+                    pos_l += pc * dsc;
+                    ctl_l += cc * dsc;
+                    is_l += is;
+                    if (t == T - 1) term_l = tc * dsc;
+                    if (geom != nullptr && t >= 1) {
+                        float q[MPB_MAX_DOF], dq[MPB_MAX_DOF];
+#pragma unroll
+                        for (int i = 0; i < MPB_MAX_DOF; ++i) q[i] = (i < MPPI_MAX_C && i < c) ? x[i < MPPI_MAX_C ? i : 0] : 0.f;
+                        coll_l += waypoint_cost<false>(G, q, dq);
+                    }
+                    if (last) {                                 // API-visible outputs of the last iteration
+                        float* Ug = controls + (((size_t)prob * S + s) * T + t) * c;
+                        float* Xg = states + (((size_t)prob * S + s) * T + t) * c;   // velocity control: state_dim == c
+#pragma unroll
+                        for (int i = 0; i < MPPI_MAX_C; ++i)
+                            if (i < c) {
+                                Ug[i] = u[i];
+                                Xg[i] = x[i];
+                            }
                     }
                 }
             }
-            cost = pos_cost + 0.f /* vel_cost: empty slice, quirk Q8 */ + ctl_cost + term;
-#pragma unroll
-            for (int i = 0; i < MPPI_MAX_C; ++i)
-                if (i < c) cost += temp * is_term[i];
+            const float pos_cost = wave_sum_f32(pos_l), ctl_cost = wave_sum_f32(ctl_l), term = wave_sum_f32(term_l);
+            const float is_term = wave_sum_f32(is_l);
+            coll_wave += wave_sum_f32(coll_l);
+            if (lane == 0)
+                M.cst[s] = pos_cost + 0.f /* vel_cost: empty slice, quirk Q8 */ + ctl_cost + term + temp * is_term;
         }
         // ---- quirk Q6: the per-sample collision costs collapse into ONE scalar added to every sample
+        float total = 0.f;
         if (geom != nullptr) {
-            const float total = block_sum(live ? weight * (k_sigma * coll) : 0.f, red, lane, wave, nw);
-            cost += total;
+            __syncthreads();
+            if (lane == 0) M.red[wave] = weight * (k_sigma * coll_wave);
+            __syncthreads();
+            for (int i = 0; i < nw; ++i) total += M.red[i];
         }
-        // ---- softmax over samples (mppi.py:73-76)
-        const float xs = live ? -cost / temp : -3.0e38f;
-        const float mx = block_max(xs, red, lane, wave, nw);
-        const float ex = live ? expf(xs - mx) : 0.f;
-        const float z = block_sum(ex, red, lane, wave, nw);
-        const float w = ex / z;
-        if (live) {
-            wts[s] = w;
-            costs[(size_t)prob * S + s] = cost;
-            weights[(size_t)prob * S + s] = w;
-        }
-        __threadfence_block();
         __syncthreads();
-        // ---- mean += step * sum_s w_s (U_s - mean)   (mppi.py:79-84), one thread per (t, i)
+        // ---- softmax over samples (mppi.py:73-76)
+        float mx = -3.0e38f;
+        for (int ss = threadIdx.x; ss < S; ss += blockDim.x) mx = fmaxf(mx, -(M.cst[ss] + total) / temp);
+        mx = block_max(mx, M.red, lane, wave, nw);
+        float z = 0.f;
+        for (int ss = threadIdx.x; ss < S; ss += blockDim.x) z += expf(-(M.cst[ss] + total) / temp - mx);
+        z = block_sum(z, M.red, lane, wave, nw);
+        for (int ss = threadIdx.x; ss < S; ss += blockDim.x) {
+            const float cs = M.cst[ss] + total;
+            const float w = expf(-cs / temp - mx) / z;
+            M.wts[ss] = w;
+            if (last) {
+                costs[(size_t)prob * S + ss] = cs;
+                weights[(size_t)prob * S + ss] = w;
+            }
+        }
+        __syncthreads();
+        // ---- mean += step * sum_s w_s (U_s - mean)   (mppi.py:79-84), one thread per (i, t)
         for (int e = threadIdx.x; e < T * c; e += blockDim.x) {
-            const float mu = m[e];
+            const int i = e / T, t = e - i * T;
+            const float mu = m[t * c + i];
             float a = 0.f;
-            for (int ss = 0; ss < S; ++ss) a += wts[ss] * (Us[e * SP + ss] - mu);
-            m[e] = mu + step_size * a;
+            for (int ss = 0; ss < S; ++ss) a += M.wts[ss] * (M.Us[((size_t)ss * c + i) * T + t] - mu);
+            m[t * c + i] = mu + step_size * a;
         }
         __threadfence_block();
     }
@@ -189,11 +262,16 @@ extern "C" int mpb_mppi_step(float* mean, const float* eps, const float* scale_t
     if (control_type != 0)
         return mpb_fail(MPB_E_UNSUPPORTED, "mpb_mppi_step: only velocity control (the reference's acceleration mode cannot run)");
     if (NP == 0 || n_iters == 0) return MPB_OK;
-    const int threads = (S + 63) & ~63;
-    const size_t lds = ((size_t)c * T + 32 + ((S + 3) & ~3) + (size_t)T * c * threads) * sizeof(float);
-    if (lds > 150 * 1024) return mpb_fail(MPB_E_UNSUPPORTED, "mpb_mppi_step: S*T*c too large for the LDS controls slab");
-    hipLaunchKernelGGL(mppi_kernel, dim3(NP), dim3(threads), lds, (hipStream_t)stream, mean, eps, scale_tril, cov_inv,
+    const int nw = S < 16 ? S : 16;                                // one wave per sample, at most 16 waves per problem
+    const size_t base = (size_t)c * T + 64 + 2 * (size_t)((S + 3) & ~3) + (size_t)S * c * T + (size_t)nw * c * T;
+    const size_t with_tril = base + (size_t)c * T * T;
+    const size_t budget = 150 * 1024 / sizeof(float);
+    if (base > budget) return mpb_fail(MPB_E_UNSUPPORTED, "mpb_mppi_step: S*T*c too large for the LDS controls slab");
+    const int tril_in_lds = with_tril <= budget;
+    const size_t lds = (tril_in_lds ? with_tril : base) * sizeof(float);
+    hipLaunchKernelGGL(mppi_kernel, dim3(NP), dim3(64 * nw), lds, (hipStream_t)stream, mean, eps, scale_tril, cov_inv,
                        state0, goal, ctrl_min, ctrl_max, discount, c_weights, geom, controls, states, costs, weights, S, T,
-                       c, dt, k_sigma, weight, temp, step_size, n_iters, (uint32_t)seed, (uint32_t)(seed >> 32), iter0);
+                       c, dt, k_sigma, weight, temp, step_size, n_iters, (uint32_t)seed, (uint32_t)(seed >> 32), iter0,
+                       tril_in_lds);
     return mpb_check_launch("mpb_mppi_step");
 }
