@@ -387,29 +387,50 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
         }
         xr0 = xr1; xr1 = xr2; jr = jr1; jr1 = jr2;
     }
-    // ---- backward substitution and update: dtheta_t = z_t - W_t (U dtheta_{t+1})
+    // ---- backward substitution and update: dtheta_t = z_t - W_t (U dtheta_{t+1}).  Row `lane` of W_{t-1}, z_{t-1}
+    //      and x_{t-1} are fetched while step t runs: the workspace (B*H*2.2 KB) does not stay in cache, and an
+    //      un-prefetched global round trip per waypoint would sit on the sequential critical path
+    double wrow[GP_N], wnext[GP_N], zc = 0.0, zn = 0.0;
+    float xc = 0.f, xn = 0.f;
+    const bool rowlane = lane < dim;
+    {
+        const double* wt = wW + (size_t)(H - 1) * GP_WS_PER_T;
+#pragma unroll
+        for (int j = 0; j < GP_N; ++j) wrow[j] = rowlane ? wt[lane * GP_N + j] : 0.0;
+        zc = rowlane ? wt[GP_N * GP_N + lane] : 0.0;
+        xc = rowlane ? xb[(H - 1) * dim + lane] : 0.f;
+    }
     for (int t = H - 1; t >= 0; --t) {
-        const double* wt = wW + (size_t)t * GP_WS_PER_T;
-        double d = 0.0;
-        if (lane < dim) {
-            d = wt[GP_N * GP_N + lane];
-            if (t < H - 1) {
-                for (int j = 0; j < dim; ++j) d -= wt[lane * GP_N + j] * zv[j];   // zv holds U dtheta_{t+1}
-            }
+        if (t > 0) {
+            const double* wt = wW + (size_t)(t - 1) * GP_WS_PER_T;
+#pragma unroll
+            for (int j = 0; j < GP_N; ++j) wnext[j] = rowlane ? wt[lane * GP_N + j] : 0.0;
+            zn = rowlane ? wt[GP_N * GP_N + lane] : 0.0;
+            xn = rowlane ? xb[(t - 1) * dim + lane] : 0.f;
+        }
+        double d = zc;
+        if (rowlane && t < H - 1) {
+#pragma unroll
+            for (int j = 0; j < GP_N; ++j)
+                if (j < dim) d -= wrow[j] * zv[j];                               // zv holds U dtheta_{t+1}
         }
         wave_sync();
-        if (lane < dim) {
+        if (rowlane) {
             dth[lane] = d;
-            xb[t * dim + lane] = (float)((double)xb[t * dim + lane] + K.step * d);
+            xb[t * dim + lane] = (float)((double)xc + K.step * d);
         }
         wave_sync();
-        if (lane < dim) {   // v = U dtheta_t for the next (earlier) waypoint
+        if (rowlane) {   // v = U dtheta_t for the next (earlier) waypoint
             const bool ip = lane < D;
             const int ii = ip ? lane : lane - D;
             const double dp = dth[ii], dv = dth[ii + D];
             zv[lane] = ip ? u00 * dp + u01 * dv : u10 * dp + u11 * dv;
         }
         wave_sync();
+#pragma unroll
+        for (int j = 0; j < GP_N; ++j) wrow[j] = wnext[j];
+        zc = zn;
+        xc = xn;
     }
     cost = wave_sum_f64(cost);
     if (costs_out != nullptr && lane == 0) costs_out[b] = (float)cost;
