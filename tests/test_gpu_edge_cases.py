@@ -140,3 +140,63 @@ def test_empty_and_invalid_arguments(gpu_device):
     with pytest.raises(MPBError):
         ops.stomp_sample(big, None, torch.empty(1, S, 300, d, device=dev), torch.eye(300, device=dev), S)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('NP,S,Tn,c,with_geom', [
+    (3, 5, 48, 2, True),       # fewer samples than waves, horizon shorter than a wave
+    (2, 33, 64, 2, True),      # samples not a multiple of the 16 waves
+    (2, 100, 100, 3, False),   # ragged horizon across two 64-lane chunks, c = 3
+    (1, 20, 200, 2, False),    # scale_tril does not fit in LDS: global-memory path, four chunks
+    (4, 16, 64, 1, False),     # one control dimension
+    (2, 24, 96, 4, False),     # maximum control dimension
+])
+def test_mppi_shapes_vs_oracle(gpu_device, NP, S, Tn, c, with_geom):
+    """MPPI kernel (wave = sample, lane = time step) on ragged shapes against the oracle's sequential rollout."""
+    from motion_planning_baselines_amd import geometry as G, ops
+    from oracle import planners_ref as O
+    from oracle.geometry_ref import make_ref_geometry
+    dev = gpu_device
+    gen = torch.Generator().manual_seed(NP * 1000 + S + Tn + c)
+    ta = dict(device='cpu', dtype=torch.float32)
+    dt, temp, step = 0.05, 0.7, 0.8
+    Cov = O.mppi_covariance([0.2 + 0.05 * i for i in range(c)], Tn, c, 'const_ctrl', ta)          # (T,T,c)
+    Cov = Cov + 0.05 * torch.eye(Tn).unsqueeze(-1)
+    tril = torch.stack([torch.linalg.cholesky(Cov[..., i]) for i in range(c)]).contiguous()
+    cinv = torch.stack([torch.inverse(Cov[..., i]) for i in range(c)]).contiguous()
+    mean0 = 0.3 * torch.randn(NP, Tn, c, generator=gen)
+    state0 = 0.5 * torch.randn(NP, c, generator=gen)
+    goal = 0.5 * torch.randn(NP, c, generator=gen)
+    cmin, cmax = torch.full((c,), -0.6), torch.full((c,), 0.5)                                     # clamping is active
+    disc = 0.99 ** torch.arange(Tn, dtype=torch.float32)
+    cw = dict(pos=1.0, vel=0.5, ctrl=0.1, pos_T=20.0)
+    n_it = 2
+    eps = torch.randn(n_it, NP, c, S, Tn, generator=gen)
+    geom = rr = rf = None
+    if with_geom:
+        robot, field = G.RobotPointMass(2, radius=0.02), G.env_dense_2d()
+        geom = ops.DeviceGeometry(robot, field, dev)
+        rr, rf = make_ref_geometry(robot, field, ta)
+    f = lambda t: t.contiguous().to(dev)
+    mean = f(mean0.clone())
+    controls, states = torch.empty(NP, S, Tn, c, device=dev), torch.empty(NP, S, Tn, c, device=dev)
+    costs, weights = torch.empty(NP, S, device=dev), torch.empty(NP, S, device=dev)
+    ops.mppi_step(mean, f(eps), f(tril), f(cinv), f(state0), f(goal), f(cmin), f(cmax), f(disc),
+                  f(torch.tensor([cw['pos'], cw['vel'], cw['ctrl'], cw['pos_T']])), geom, controls, states, costs, weights,
+                  dt, k_sigma=4.0, weight=1.5, temp=temp, step_size=step, n_iters=n_it)
+    torch.cuda.synchronize()
+    for p in range(NP):
+        m = mean0[p].clone()
+        for it in range(n_it):
+            shift = 0.0
+            if with_geom:      # quirk Q6: the summed collision cost of ALL samples shifts every sample's cost
+                pre = O.mppi_iteration(m, eps[it, p], tril, cinv, state0[p], goal[p], dt, cmin, cmax, cw, disc, temp, step, c)
+                q = pre['states'][:, 1:, :2]
+                shift = 1.5 * 4.0 * float(rf.compute_cost(q, rr.fk_map_collision(q)).sum())
+            out = O.mppi_iteration(m, eps[it, p], tril, cinv, state0[p], goal[p], dt, cmin, cmax, cw, disc, temp, step, c,
+                                   shift_cost=shift)
+            m = out['mean']
+        assert rel_err(controls[p], out['controls']) < 1e-4
+        assert rel_err(states[p], out['states']) < 1e-4
+        np.testing.assert_allclose(costs[p].cpu().numpy(), out['costs'].reshape(-1).numpy(), rtol=2e-4)
+        np.testing.assert_allclose(weights[p].cpu().numpy(), out['weights'].reshape(-1).numpy(), rtol=5e-2, atol=1e-5)
+        assert rel_err(mean[p], m) < 2e-4
