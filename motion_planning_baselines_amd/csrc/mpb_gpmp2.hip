@@ -172,10 +172,14 @@ struct GpConst {
 
 #define GP_WS_PER_T (GP_N * GP_N + GP_N)   // workspace doubles per waypoint: W_t (16x16 row-major) + z_t
 
+// DT > 0: the number of degrees of freedom is a compile-time constant (loop bounds, pivot-block count and the
+// position/velocity index tests fold away); DT == 0: generic.
+template <int DT>
 __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, const float* __restrict__ start,
                                                          const float* __restrict__ goal, const float* __restrict__ jac,
                                                          const double* __restrict__ diag_mean, double* __restrict__ work,
-                                                         float* __restrict__ costs_out, int B, int H, int D, GpConst K) {
+                                                         float* __restrict__ costs_out, int B, int H, int Drt, GpConst K) {
+    const int D = DT ? DT : Drt;
     __shared__ double Sb[2][GP_N * GP_LD];  // ping-pong tile: Schur complement -> its inverse
     __shared__ double xs[2][GP_N];          // x_t, x_{t+1} (fp64 copies)
     __shared__ double rv[GP_N];             // r_t
@@ -508,8 +512,16 @@ extern "C" int mpb_gpmp2_solve(float* x, const float* start, const float* goal, 
     K.step = step_size;
     K.trust = trust_region;
     const double* dm = trust_region ? (diag_mean ? diag_mean : w.diag_mean) : nullptr;
-    hipLaunchKernelGGL(gpmp2_solve_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, x, start, goal, w.jac, dm, w.fz,
-                       costs_out, B, H, D, K);
+#define GP_LAUNCH(DT)                                                                                                   \
+    hipLaunchKernelGGL(gpmp2_solve_kernel<DT>, dim3(B), dim3(64), 0, (hipStream_t)stream, x, start, goal, w.jac, dm, w.fz, \
+                       costs_out, B, H, D, K)
+    switch (D) {
+        case 2: GP_LAUNCH(2); break;
+        case 3: GP_LAUNCH(3); break;
+        case 7: GP_LAUNCH(7); break;
+        default: GP_LAUNCH(0); break;
+    }
+#undef GP_LAUNCH
     return mpb_check_launch("mpb_gpmp2_solve");
 }
 
