@@ -299,25 +299,31 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
                 const double* A = Sb[cur];
                 double* Bn = Sb[cur ^ 1];
                 const int k0 = 4 * kb;
-                // pivot block inverse, redundantly in every lane (4x4 Gauss-Jordan in registers)
+                // pivot block inverse, redundantly in every lane.  The pivot block is a Schur complement of an SPD
+                // matrix, hence SPD: with P = [[A, B], [B^T, C]] in 2x2 blocks, X = A^-1 B, S = C - B^T X,
+                //   P^-1 = [[A^-1 + X S^-1 X^T, -X S^-1], [-(X S^-1)^T, S^-1]]      (2 reciprocals, ~50 fma)
                 double pv[4][4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int c2 = 0; c2 < 4; ++c2) pv[r][c2] = A[(k0 + r) * GP_LD + k0 + c2];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const double ip = fast_rcp(pv[k][k]);
-#pragma unroll
-                    for (int c2 = 0; c2 < 4; ++c2) pv[k][c2] = (c2 == k) ? ip : pv[k][c2] * ip;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (r != k) {
-                            const double f = pv[r][k];
-#pragma unroll
-                            for (int c2 = 0; c2 < 4; ++c2) pv[r][c2] = (c2 == k) ? -f * ip : pv[r][c2] - f * pv[k][c2];
-                        }
-                    }
+                {
+                    const double* Pk = A + k0 * GP_LD + k0;
+                    const double a00 = Pk[0], a01 = Pk[1], a11 = Pk[GP_LD + 1];
+                    const double b00 = Pk[2], b01 = Pk[3], b10 = Pk[GP_LD + 2], b11 = Pk[GP_LD + 3];
+                    const double c00 = Pk[2 * GP_LD + 2], c01 = Pk[2 * GP_LD + 3], c11 = Pk[3 * GP_LD + 3];
+                    const double ia = fast_rcp(fma(a00, a11, -a01 * a01));
+                    const double i00 = a11 * ia, i01 = -a01 * ia, i11 = a00 * ia;              // A^-1
+                    const double x00 = fma(i00, b00, i01 * b10), x01 = fma(i00, b01, i01 * b11);   // X = A^-1 B
+                    const double x10 = fma(i01, b00, i11 * b10), x11 = fma(i01, b01, i11 * b11);
+                    const double s00 = c00 - fma(b00, x00, b10 * x10), s01 = c01 - fma(b00, x01, b10 * x11);
+                    const double s11 = c11 - fma(b01, x01, b11 * x11);                          // S = C - B^T X
+                    const double is = fast_rcp(fma(s00, s11, -s01 * s01));
+                    const double t00 = s11 * is, t01 = -s01 * is, t11 = s00 * is;              // S^-1
+                    const double y00 = -fma(x00, t00, x01 * t01), y01 = -fma(x00, t01, x01 * t11);  // -X S^-1
+                    const double y10 = -fma(x10, t00, x11 * t01), y11 = -fma(x10, t01, x11 * t11);
+                    pv[0][0] = i00 - fma(y00, x00, y01 * x01);                                  // A^-1 + X S^-1 X^T
+                    pv[0][1] = pv[1][0] = i01 - fma(y00, x10, y01 * x11);
+                    pv[1][1] = i11 - fma(y10, x10, y11 * x11);
+                    pv[0][2] = pv[2][0] = y00; pv[0][3] = pv[3][0] = y01;
+                    pv[1][2] = pv[2][1] = y10; pv[1][3] = pv[3][1] = y11;
+                    pv[2][2] = t00; pv[2][3] = pv[3][2] = t01; pv[3][3] = t11;
                 }
                 // B operand: (Pinv * A'[K,:])[lk][li]
                 const bool jin = (li >= k0) && (li < k0 + 4);
