@@ -204,6 +204,46 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
     int cur = 0;  // Sb[cur] holds -(U^T W_{t-1} U) on entry to step t > 0
     double rcarry = 0.0;  // lane < dim: r_t contribution carried from step t-1 (gnext - U^T z)
 
+    // per-element constants of the S assembly (lane owns row ei, columns ej0 .. ej0+3)
+    double asm_g1[4], asm_g2[4], asm_dg[4], asm_pp[4], asm_id[4];
+    bool asm_in[4];
+    int asm_hj[4];
+    const int asm_di = (ei < dim) ? ei : 0, asm_hi = (ei < D) ? ei : 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = ei, j = ej0 + q;
+        const bool in = i < dim && j < dim;
+        const bool ip = i < D, jp = j < D;
+        const int ii = ip ? i : i - D, jj = jp ? j : j - D;
+        const bool same = in && ii == jj;
+        asm_in[q] = in;
+        asm_g1[q] = same ? (ip ? (jp ? p00 : p01) : (jp ? p01 : p11)) : 0.0;   // Phi^T Qi Phi block (t < H-1)
+        asm_g2[q] = same ? (ip ? (jp ? a : bq) : (jp ? bq : cq)) : 0.0;         // Qi block (t > 0)
+        asm_dg[q] = (in && i == j) ? 1.0 : 0.0;
+        asm_pp[q] = (in && ip && jp) ? 1.0 : 0.0;
+        asm_hj[q] = (j < D) ? j : 0;
+        asm_id[q] = (i == j) ? 1.0 : 0.0;
+    }
+
+    // per-element constants of the next-tile product -(U^T W U)
+    double nt_c[4][4];
+    int nt_off[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = ei, j = ej0 + q;
+        const bool in = i < dim && j < dim;
+        const bool ip = i < D, jp = j < D;
+        const int ii = in ? (ip ? i : i - D) : 0, jj = in ? (jp ? j : j - D) : 0;
+        const double uca0 = ip ? u00 : u01, uca1 = ip ? u10 : u11;   // U[c][a], c = 0,1
+        const double ueb0 = jp ? u00 : u01, ueb1 = jp ? u10 : u11;   // U[e][b], e = 0,1
+        const double m = in ? -1.0 : 0.0;
+        nt_c[q][0] = m * uca0 * ueb0;   // W[ii][jj]
+        nt_c[q][1] = m * uca0 * ueb1;   // W[ii][jj + D]
+        nt_c[q][2] = m * uca1 * ueb0;   // W[ii + D][jj]
+        nt_c[q][3] = m * uca1 * ueb1;   // W[ii + D][jj + D]
+        nt_off[q] = ii * GP_LD + jj;
+    }
+
     // software prefetch: rows t+1 of x and of the Jacobian are loaded one step ahead so that their global
     // latency hides behind the inverse of step t instead of sitting on the sequential critical path
     float xr0 = (lane < dim) ? xb[lane] : 0.f;
@@ -238,33 +278,25 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
                 cost += pos ? ep * qp : ev * qv;
             }
         }
-        // ---- S = D_t (+ Schur term already in the tile for t > 0); padding rows/cols = identity
+        // ---- S = D_t (+ Schur term already in the tile for t > 0); padding rows/cols = identity.  Branch-free: the
+        //      per-element coefficients (asm_*) were fixed before the loop, only the t-dependent selects remain
         const double ct = hv[D];
         double* S = Sb[cur];
+        {
+            const double first = (t == 0) ? 1.0 : 0.0, notfirst = 1.0 - first, notlast = (t < H - 1) ? 1.0 : 0.0;
+            const double dmp = K.trust ? K.delta * diag_mean[(size_t)t * dim + asm_di] : K.delta;   // (clamped index)
+            const double dg = dmp + first * K.ks + (1.0 - notlast) * K.kg;
+            const double hi = hv[asm_hi] * (K.kc * notfirst);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = ei, j = ej0 + q;
-            double v;
-            if (i < dim && j < dim) {
-                v = (t > 0) ? S[i * GP_LD + j] : 0.0;
-                const bool ip = i < D, jp = j < D;
-                const int ii = ip ? i : i - D, jj = jp ? j : j - D;
-                if (ii == jj) {
-                    double g = 0.0;
-                    if (t < H - 1) g += ip ? (jp ? p00 : p01) : (jp ? p01 : p11);
-                    if (t > 0) g += ip ? (jp ? a : bq) : (jp ? bq : cq);
-                    v += g;
-                }
-                if (i == j) {
-                    if (t == 0) v += K.ks;
-                    if (t == H - 1) v += K.kg;
-                    v += K.trust ? K.delta * diag_mean[(size_t)t * dim + i] : K.delta;
-                }
-                if (t > 0 && ip && jp) v += K.kc * hv[i] * hv[j];
-            } else {
-                v = (i == j) ? 1.0 : 0.0;
+            for (int q = 0; q < 4; ++q) {
+                const double prev = S[ei * GP_LD + ej0 + q];
+                double v = (t > 0) ? prev : 0.0;                    // t == 0: the tile holds nothing yet
+                v = fma(notlast, asm_g1[q], v);
+                v = fma(notfirst, asm_g2[q], v);
+                v = fma(asm_dg[q], dg, v);
+                v = fma(asm_pp[q] * hi, hv[asm_hj[q]], v);
+                S[ei * GP_LD + ej0 + q] = asm_in[q] ? v : asm_id[q];
             }
-            S[i * GP_LD + j] = v;
         }
         // ---- r_t
         double gnext = 0.0;
@@ -365,21 +397,16 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
         for (int q = 0; q < 4; ++q) wt[ei * GP_N + ej0 + q] = W[ei * GP_LD + ej0 + q];
         wave_sync();
         if (t < H - 1) {
-            // ---- next tile: -(U^T W U), block (a,b) (i',j') = -sum_{c,e} U[c][a] U[e][b] W[i'+cD][j'+eD]
+            // ---- next tile: -(U^T W U), block (a,b) (i',j') = -sum_{c,e} U[c][a] U[e][b] W[i'+cD][j'+eD]; the four
+            //      coefficient products and the element offsets are per-lane constants (nt_*), so 4 fma per element
             double newS[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int i = ei, j = ej0 + q;
-                double v = 0.0;
-                if (i < dim && j < dim) {
-                    const bool ip = i < D, jp = j < D;
-                    const int ii = ip ? i : i - D, jj = jp ? j : j - D;
-                    const double wpp = W[ii * GP_LD + jj], wpv = W[ii * GP_LD + jj + D];
-                    const double wvp = W[(ii + D) * GP_LD + jj], wvv = W[(ii + D) * GP_LD + jj + D];
-                    const double uca0 = ip ? u00 : u01, uca1 = ip ? u10 : u11;   // U[c][a], c = 0,1
-                    const double ueb0 = jp ? u00 : u01, ueb1 = jp ? u10 : u11;   // U[e][b], e = 0,1
-                    v = -(uca0 * (wpp * ueb0 + wpv * ueb1) + uca1 * (wvp * ueb0 + wvv * ueb1));
-                }
+                const double* Wq = W + nt_off[q];
+                double v = nt_c[q][0] * Wq[0];
+                v = fma(nt_c[q][1], Wq[D], v);
+                v = fma(nt_c[q][2], Wq[D * GP_LD], v);
+                v = fma(nt_c[q][3], Wq[D * GP_LD + D], v);
                 newS[q] = v;
             }
             // r_{t+1} carry = gnext - U^T z
