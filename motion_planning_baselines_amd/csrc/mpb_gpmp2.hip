@@ -327,6 +327,7 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
         //      C/D: column l&15, rows (l>>4) + 4*reg.
         {
             const int li = lane & 15, lk = lane >> 4;
+            const double rowsel[4] = {lk == 0 ? 1.0 : 0.0, lk == 1 ? 1.0 : 0.0, lk == 2 ? 1.0 : 0.0, lk == 3 ? 1.0 : 0.0};
             for (int kb = 0; 4 * kb < dim; ++kb) {
                 const double* A = Sb[cur];
                 double* Bn = Sb[cur ^ 1];
@@ -357,22 +358,31 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
                     pv[1][2] = pv[2][1] = y10; pv[1][3] = pv[3][1] = y11;
                     pv[2][2] = t00; pv[2][3] = pv[3][2] = t01; pv[3][3] = t11;
                 }
-                // B operand: (Pinv * A'[K,:])[lk][li]
+                // B operand: (Pinv * A'[K,:])[lk][li].  Lane-dependent choices (row lk of Pinv, identity columns of the
+                // pivot block) are done with 0/1 multipliers, not selects: hipcc lowers such selects around LDS loads
+                // to trees of exec-mask branches
                 const bool jin = (li >= k0) && (li < k0 + 4);
+                const double notj = jin ? 0.0 : 1.0;
                 double bop = 0.0;
+                {
+                    double am[4];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const double am = jin ? ((li - k0 == m) ? 1.0 : 0.0) : A[(k0 + m) * GP_LD + li];
-                    // Pinv[lk][m] with a lane-dependent row: select
-                    const double pm = (lk == 0) ? pv[0][m] : (lk == 1) ? pv[1][m] : (lk == 2) ? pv[2][m] : pv[3][m];
-                    bop = fma(pm, am, bop);
+                    for (int m = 0; m < 4; ++m)
+                        am[m] = fma(notj, A[(k0 + m) * GP_LD + li], (li - k0 == m) ? 1.0 : 0.0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        double rowdot = pv[r][0] * am[0];
+#pragma unroll
+                        for (int m = 1; m < 4; ++m) rowdot = fma(pv[r][m], am[m], rowdot);
+                        bop = fma(rowsel[r], rowdot, bop);
+                    }
                 }
                 // A operand: -A[li][k0 + lk]
                 const double aop = -A[li * GP_LD + k0 + lk];
                 // C in: rows lk + 4*reg, column li; columns of the pivot block start from zero
                 f64x4 cin;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) cin[q] = jin ? 0.0 : A[(lk + 4 * q) * GP_LD + li];
+                for (int q = 0; q < 4; ++q) cin[q] = notj * A[(lk + 4 * q) * GP_LD + li];
                 f64x4 dd = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, cin, 0, 0, 0);
                 // rows of the pivot block: row k0 + lk lives in register kb of lane (lk, li)
 #pragma unroll
