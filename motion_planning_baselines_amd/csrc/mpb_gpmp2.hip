@@ -440,20 +440,21 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
     double wrow[GP_N], wnext[GP_N], zc = 0.0, zn = 0.0;
     float xc = 0.f, xn = 0.f;
     const bool rowlane = lane < dim;
+    const int rl = rowlane ? lane : 0;          // idle lanes shadow row 0: unconditional loads, no exec-mask branches
     {
         const double* wt = wW + (size_t)(H - 1) * GP_WS_PER_T;
 #pragma unroll
-        for (int j = 0; j < GP_N; ++j) wrow[j] = rowlane ? wt[lane * GP_N + j] : 0.0;
-        zc = rowlane ? wt[GP_N * GP_N + lane] : 0.0;
-        xc = rowlane ? xb[(H - 1) * dim + lane] : 0.f;
+        for (int j = 0; j < GP_N; ++j) wrow[j] = wt[rl * GP_N + j];
+        zc = wt[GP_N * GP_N + rl];
+        xc = xb[(H - 1) * dim + rl];
     }
     for (int t = H - 1; t >= 0; --t) {
         if (t > 0) {
             const double* wt = wW + (size_t)(t - 1) * GP_WS_PER_T;
 #pragma unroll
-            for (int j = 0; j < GP_N; ++j) wnext[j] = rowlane ? wt[lane * GP_N + j] : 0.0;
-            zn = rowlane ? wt[GP_N * GP_N + lane] : 0.0;
-            xn = rowlane ? xb[(t - 1) * dim + lane] : 0.f;
+            for (int j = 0; j < GP_N; ++j) wnext[j] = wt[rl * GP_N + j];
+            zn = wt[GP_N * GP_N + rl];
+            xn = xb[(t - 1) * dim + rl];
         }
         double d = zc;
         if (rowlane && t < H - 1) {
