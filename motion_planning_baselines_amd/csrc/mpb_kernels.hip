@@ -89,102 +89,6 @@ extern "C" int mpb_geom_check(const float* g, int n_words) {
 #define MPB_MAX_D (2 * MPB_MAX_DOF)
 
 // ------------------------------------------------------------------------------------------------
-// STOMP kernel A: sample one rollout per wave, write it, evaluate its collision cost.
-//   noise[h][c] = sum_k L[h][k] eps[c][k]; rows 0 and H-1 zeroed; sample = mean + noise
-//   (stomp.py:97-108).  L^T is staged in LDS so lane h reads L[h][k] conflict-free; eps lives one
-//   value per lane (lane k) and is broadcast with v_readlane.
-// ------------------------------------------------------------------------------------------------
-template <bool WITH_COST>
-__global__ __launch_bounds__(256) void stomp_sample_cost_kernel(
-    const float* __restrict__ means, const float* __restrict__ eps, float* __restrict__ samples,
-    float* __restrict__ costs, const float* __restrict__ Lmat, const float* __restrict__ geom,
-    int P, int S, int H, int d, int D, float k_sigma, float weight,
-    uint32_t seed_lo, uint32_t seed_hi, uint32_t iter, uint32_t particle_offset) {
-    extern __shared__ float lds[];  // Lt[k*H + h]
-    for (int i = threadIdx.x; i < H * H; i += blockDim.x) {
-        const int h = i / H, k = i - h * H;
-        lds[k * H + h] = Lmat[i];
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int r = blockIdx.x * (blockDim.x >> 6) + wave;  // rollout index
-    if (r >= P * S) return;
-    const int p = r / S, s = r - p * S;
-    GeomView G;
-    if (WITH_COST) G = geom_view(geom);
-    double csum = 0.0;
-    const int nchunk = (H + 63) >> 6;
-    for (int hc = 0; hc < nchunk; ++hc) {
-        const int h = hc * 64 + lane;
-        float acc[MPB_MAX_D];
-#pragma unroll
-        for (int c = 0; c < MPB_MAX_D; ++c) acc[c] = 0.f;
-        // L is lower triangular: rows of this chunk only need k < (hc+1)*64
-        const int kend = min(H, (hc + 1) * 64);
-        for (int kc = 0; kc * 64 < kend; ++kc) {
-            const int k0 = kc * 64;
-            const int kl = k0 + lane;
-            // this lane's eps[c][kl] for every channel
-            float e[MPB_MAX_D];
-            if (eps != nullptr) {
-#pragma unroll
-                for (int c = 0; c < MPB_MAX_D; ++c)
-                    e[c] = (c < d && kl < H) ? eps[(((size_t)s * d + c) * P + p) * H + kl] : 0.f;
-            } else {
-#pragma unroll
-                for (int c4 = 0; c4 < MPB_MAX_D / 4; ++c4) {
-                    float n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
-                    if (c4 * 4 < d) {
-                        const uint4 rr = philox4x32_10(
-                            make_uint4(particle_offset + (uint32_t)p, (uint32_t)s, ((uint32_t)kl << 4) | (uint32_t)c4, iter),
-                            make_uint2(seed_lo, seed_hi));
-                        box_muller(rr.x, rr.y, n0, n1);
-                        box_muller(rr.z, rr.w, n2, n3);
-                    }
-                    e[c4 * 4 + 0] = n0; e[c4 * 4 + 1] = n1; e[c4 * 4 + 2] = n2; e[c4 * 4 + 3] = n3;
-                }
-            }
-            const int kn = min(64, kend - k0);
-            for (int kk = 0; kk < kn; ++kk) {
-                const float lv = (h < H) ? lds[(k0 + kk) * H + h] : 0.f;
-#pragma unroll
-                for (int c = 0; c < MPB_MAX_D; ++c) {
-                    if (c < d) {
-                        const float ev = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[c]), kk));
-                        acc[c] = fmaf(lv, ev, acc[c]);
-                    }
-                }
-            }
-        }
-        if (h < H) {
-            const bool edge = (h == 0) || (h == H - 1);
-            const float* mrow = means + ((size_t)p * H + h) * d;
-            float* srow = samples + (((size_t)p * S + s) * H + h) * d;
-            float q[MPB_MAX_DOF];
-#pragma unroll
-            for (int c = 0; c < MPB_MAX_D; ++c) {
-                if (c < d) {
-                    const float v = mrow[c] + (edge ? 0.f : acc[c]);
-                    srow[c] = v;
-                    if (c < MPB_MAX_DOF) q[c] = v;
-                } else if (c < MPB_MAX_DOF) {
-                    q[c] = 0.f;
-                }
-            }
-            if (WITH_COST && h >= 1) {
-                float dq[MPB_MAX_DOF];
-                csum += (double)waypoint_cost<false>(G, q, dq);
-            }
-        }
-    }
-    if (WITH_COST) {
-        csum = wave_sum_f64(csum);
-        if (lane == 0) costs[r] = weight * (k_sigma * (float)csum);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // STOMP kernel A, H = 64 fast path: the time-correlated noise  N = L * eps  (64x64 lower-triangular L,
 // the scale_tril of the precision matrix R; eps 64 x d) runs on the matrix cores as exact-fp32
 // v_mfma_f32_16x16x4_f32 tiles, one rollout per wave:
@@ -372,6 +276,160 @@ __global__ __launch_bounds__(256, 4) void stomp_sample_cost_h64_kernel(
         if (live && lane == 0) costs[r] = weight * (k_sigma * (float)csum);
     }
     MPB_STAMP(7);
+}
+
+// ------------------------------------------------------------------------------------------------
+// STOMP kernel A for any other horizon H <= 64*M (M = 1, 2, 4): the same wave-per-rollout / lane-per-waypoint
+// scheme with the horizon cut in 64-waypoint chunks.  noise[hc] = sum_{kc <= hc} L[hc][kc] * eps[kc] over
+// the 64 x 64 blocks of the lower-triangular scale_tril, each block product on the matrix cores exactly like
+// the H = 64 kernel (blocks are staged one at a time in the same 16 KB permuted LDS image, zero-padded past
+// H); the channel count is a run-time argument (the MFMA B operand always carries 16 columns).
+// ------------------------------------------------------------------------------------------------
+template <bool WITH_COST, int M>
+__global__ __launch_bounds__(256) void stomp_sample_cost_hx_kernel(
+    const float* __restrict__ means, const float* __restrict__ eps, float* __restrict__ samples,
+    float* __restrict__ costs, const float* __restrict__ Lmat, const float* __restrict__ geom,
+    int P, int S, int H, int d, float k_sigma, float weight, uint32_t seed_lo, uint32_t seed_hi, uint32_t iter,
+    uint32_t particle_offset) {
+    __shared__ __attribute__((aligned(16))) float Lp[64 * 64];
+    __shared__ __attribute__((aligned(16))) float Nt[4][64 * NT_STRIDE];
+    __shared__ float4 otab[MPB_GRID_MAX_SPH + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wave;
+    const bool live = r < P * S;
+    const int p = live ? r / S : 0, s = live ? r - p * S : 0;
+    const int j = lane & 15, g = lane >> 4;
+    const int Mc = (H + 63) >> 6;                                   // chunks in use (block-uniform)
+    const f32x4* Lp4 = reinterpret_cast<const f32x4*>(Lp);
+    float* nt = Nt[wave];
+    f32x4 acc[M][4];
+#pragma unroll
+    for (int hc = 0; hc < M; ++hc)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[hc][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < M; ++kc) {
+        if (kc < Mc) {
+            // ---- B operand of this column chunk: eps[c = j][k = 64 kc + 4 ks + g]
+            float e[16];
+            if (eps != nullptr) {
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+                    const int k = 64 * kc + 4 * ks + g;
+                    e[ks] = (j < d && k < H) ? eps[(((size_t)s * d + j) * P + p) * H + k] : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    float n[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (j < d)
+                        stomp_eps4(particle_offset + (uint32_t)p, (uint32_t)s, (uint32_t)j, (uint32_t)g,
+                                   (uint32_t)(kc << 4) | (uint32_t)q4, iter, seed_lo, seed_hi, n);
+                    e[4 * q4 + 0] = n[0]; e[4 * q4 + 1] = n[1]; e[4 * q4 + 2] = n[2]; e[4 * q4 + 3] = n[3];
+                }
+            }
+#pragma unroll
+            for (int hc = kc; hc < M; ++hc) {
+                if (hc < Mc) {
+                    // ---- stage block (hc, kc) of L in the permuted layout of the H = 64 kernel
+                    __syncthreads();
+                    for (int v = threadIdx.x; v < 64 * 64; v += 256) {
+                        const int row = v >> 6, col = v & 63;
+                        const int gr = 64 * hc + row, gc = 64 * kc + col;
+                        const float lv = (gr < H && gc < H) ? Lmat[(size_t)gr * H + gc] : 0.f;
+                        const int m = row >> 4, i = row & 15, ks = col >> 2, gg = col & 3;
+                        Lp[((((m * 4 + (ks >> 2)) * 4 + gg) * 16 + i) << 2) + (ks & 3)] = lv;
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+                        for (int ks4 = 0; ks4 < 4; ++ks4) {
+                            if (hc == kc && ks4 > m) continue;          // upper triangle of a diagonal block
+                            const f32x4 a = Lp4[((m * 4 + ks4) * 4 + g) * 16 + j];
+                            acc[hc][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], e[4 * ks4 + 0], acc[hc][m], 0, 0, 0);
+                            acc[hc][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], e[4 * ks4 + 1], acc[hc][m], 0, 0, 0);
+                            acc[hc][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], e[4 * ks4 + 2], acc[hc][m], 0, 0, 0);
+                            acc[hc][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], e[4 * ks4 + 3], acc[hc][m], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // ---- per chunk: transpose through the wave's tile, add the mean, store the samples, keep the positions
+    float q[M][MPB_MAX_DOF];
+    const bool vec_store = ((H * d) & 3) == 0;
+#pragma unroll
+    for (int hc = 0; hc < M; ++hc) {
+#pragma unroll
+        for (int i = 0; i < MPB_MAX_DOF; ++i) q[hc][i] = 0.f;
+        if (hc < Mc) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) nt[(16 * m + 4 * g + rr) * NT_STRIDE + j] = acc[hc][m][rr];
+            __syncthreads();                                       // written by lane = channel, read by lane = waypoint
+            const int h = 64 * hc + lane;
+            const bool on = h < H;
+            const bool edge = (h == 0) || (h == H - 1);
+            float x[16];
+            {
+                const f32x4* row = reinterpret_cast<const f32x4*>(nt + lane * NT_STRIDE);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const f32x4 t = row[v];
+                    x[4 * v + 0] = t[0]; x[4 * v + 1] = t[1]; x[4 * v + 2] = t[2]; x[4 * v + 3] = t[3];
+                }
+            }
+            const float* mrow = means + ((size_t)p * H + (on ? h : 0)) * d;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                if (c < d) {
+                    x[c] = mrow[c] + (edge ? 0.f : x[c]);
+                    if (c < MPB_MAX_DOF) q[hc][c < MPB_MAX_DOF ? c : 0] = x[c];
+                }
+            }
+            float* sbase = samples + (((size_t)p * S + s) * H + 64 * hc) * d;
+            const int nfl = (min(H - 64 * hc, 64)) * d;             // floats of this chunk
+            if (vec_store) {
+                // pack the (rows x d) chunk contiguously in the consumed tile, write 16-byte lanes
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+                    if (c < d && on) nt[lane * d + c] = x[c];
+                const f32x4* pk4 = reinterpret_cast<const f32x4*>(nt);
+                f32x4* out4 = reinterpret_cast<f32x4*>(sbase);
+                for (int idx = lane; 4 * idx < nfl; idx += 64)
+                    if (live) out4[idx] = pk4[idx];
+            } else if (on && live) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+                    if (c < d) sbase[lane * d + c] = x[c];
+            }
+            __syncthreads();                                       // tile reads done before the next chunk overwrites it
+        }
+    }
+    if (WITH_COST) {
+        const GeomView G = geom_view(geom);
+        float c = 0.f;
+        const bool use_grid = grid_usable(G);
+        unsigned* gridw = reinterpret_cast<unsigned*>(Lp);
+        if (use_grid) {
+            __syncthreads();
+            grid_stage(G, gridw, otab, threadIdx.x, 256);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int hc = 0; hc < M; ++hc) {
+            const int h = 64 * hc + lane;
+            if (hc < Mc && live && h >= 1 && h < H) {
+                float dq[MPB_MAX_DOF];
+                c += use_grid ? waypoint_cost_grid(G, gridw, otab, q[hc]) : waypoint_cost<false>(G, q[hc], dq);
+            }
+        }
+        const double csum = wave_sum_f64((double)c);
+        if (live && lane == 0) costs[r] = weight * (k_sigma * (float)csum);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -720,8 +778,16 @@ static void launch_sample(const float* means, const float* eps, float* samples, 
         }
     }
 #undef MPB_A_CASE
-    hipLaunchKernelGGL(stomp_sample_cost_kernel<WITH_COST>, grid, block, (size_t)H * H * 4, st, means, eps, samples,
-                       costs, L, geom, P, S, H, d, d, k_sigma, weight, lo, hi, iter, particle_offset);
+    // any other horizon / channel count (H <= MPB_MAX_H = 256, d <= MPB_MAX_D = 16): chunked MFMA kernel
+    {
+#define MPB_HX(M)                                                                                                   \
+    hipLaunchKernelGGL((stomp_sample_cost_hx_kernel<WITH_COST, M>), grid, block, 0, st, means, eps, samples, costs, L, \
+                       geom, P, S, H, d, k_sigma, weight, lo, hi, iter, particle_offset)
+        if (H <= 64) MPB_HX(1);
+        else if (H <= 128) MPB_HX(2);
+        else MPB_HX(4);
+#undef MPB_HX
+    }
 }
 
 static bool shape_ok(int H, int d, int D) {
@@ -757,7 +823,6 @@ extern "C" int mpb_stomp_sample(const float* means, const float* eps, float* sam
     if (!means || !samples || !L) return fail(MPB_E_INVALID, "%s: null pointer", __func__);
     if ((geom == nullptr) != (costs == nullptr)) return fail(MPB_E_INVALID, "%s: geom and costs must be given together", __func__);
     if (P < 0 || S < 1 || H < 3 || H > MPB_MAX_H || d < 1 || d > MPB_MAX_D) return fail(MPB_E_INVALID, "%s: bad shape", __func__);
-    if ((size_t)H * H * 4 > 160 * 1024) return fail(MPB_E_UNSUPPORTED, "%s: H too large for LDS staging of L", __func__);
     if (P == 0) return MPB_OK;
     if (geom)
         launch_sample<true>(means, eps, samples, costs, L, geom, P, S, H, d, k_sigma, weight, seed, iter,
@@ -789,7 +854,6 @@ extern "C" int mpb_stomp_step(float* means, const float* eps, float* samples, fl
     if (!means || !samples || !costs || !weights || !L || !Sigma || !geom) return fail(MPB_E_INVALID, "%s: null pointer", __func__);
     if (P < 0 || S < 1 || !shape_ok(H, d, D) || n_iters < 0) return fail(MPB_E_INVALID, "%s: bad shape", __func__);
     if (!(temperature > 0.f)) return fail(MPB_E_INVALID, "%s: temperature must be > 0", __func__);
-    if ((size_t)H * H * 4 > 160 * 1024) return fail(MPB_E_UNSUPPORTED, "%s: H too large for LDS staging of L", __func__);
     size_t lds_b;
     int sig_lds;
     if (!update_lds(S, H, d, lds_b, sig_lds)) return fail(MPB_E_UNSUPPORTED, "%s: S + H*d too large for LDS", __func__);

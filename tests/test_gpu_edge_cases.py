@@ -70,8 +70,13 @@ def test_cost_and_grad_vs_oracle(gpu_device, name, H):
     ('panda_boxes', 2, 8, 64, False),        # d = 14
     ('point3d', 5, 3, 64, False),            # d = 6
     ('point3d', 4, 7, 64, True),             # d = 3
-    ('panda_many', 2, 4, 80, True),          # generic-H kernel
-    ('point2d_boxes', 3, 9, 100, False),     # generic-H kernel, H > 64
+    ('panda_many', 2, 4, 80, True),          # chunked kernel: two chunks, ragged tail, odd d (scalar stores: 80*7 % 4 = 0 -> vector)
+    ('point2d_boxes', 3, 9, 100, False),     # chunked kernel, H > 64, d = 4
+    ('panda_crowded', 2, 5, 48, False),      # chunked kernel, one padded chunk (H < 64), d = 14
+    ('panda_boxes', 2, 3, 128, False),       # two full chunks
+    ('point3d', 3, 4, 150, True),            # three chunks of the M = 4 instance, d = 3, 150*3 % 4 != 0 -> scalar stores
+    ('point2d_boxes', 2, 4, 256, True),      # maximum horizon, d = 2
+    ('point3d', 2, 6, 61, True),             # odd horizon below one chunk, 61*3 % 4 != 0
 ])
 def test_stomp_iteration_vs_oracle(gpu_device, name, P, S, H, pos_only):
     from motion_planning_baselines_amd import ops
