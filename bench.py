@@ -173,7 +173,7 @@ def main():
                        'pos_only': bool(args.pos_only), 'noise': 'device philox', 'sigma_coll': wl['sigma_coll'],
                        'robot_collision_spheres': 31, 'obstacle_spheres': 16, 'parallelism': 'particles sharded x%d' % world,
                        'algorithmic_bytes_per_iter': stomp_algorithmic_bytes(P, S, H, d)},
-            'roofline': {'bound': 'hbm', 'kernel': 'stomp_sample_cost_kernel', 'achieved': achieved,
+            'roofline': {'bound': 'hbm', 'kernel': 'stomp_sample_cost_h64_kernel<14,true>', 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'kernel_ms': ka_ms, 'update_kernel_ms': kb_ms,
                          'algorithmic_bytes_per_launch': alg_bytes_a},
