@@ -549,12 +549,19 @@ __device__ __forceinline__ float waypoint_cost_grid(const GeomView& G, const uns
     for (int l0 = 0; l0 < G.n_links; l0 += N) {
         const int nl = min(N, G.n_links - l0);
         float x[N], y[N], z[N], rl[N];
+        // the N link records of the group are fetched together, so the scalar-load latency is paid once per group
+        // instead of once per sphere.  Records past n_links (last group) are read but never used: the words behind
+        // the link table are the sphere / cull tables of the same buffer, which exist whenever the grid path runs
+        float4 lkv[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            lkv[i] = *reinterpret_cast<const float4*>(G.links + 8 * (l0 + i));
+            rl[i] = G.links[8 * (l0 + i) + 4];
+        }
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             if (i < nl) {
-                const int li = l0 + i;
-                const float4 lk = *reinterpret_cast<const float4*>(G.links + 8 * li);  // frame, ox, oy, oz
-                rl[i] = G.links[8 * li + 4];
+                const float4 lk = lkv[i];                                              // frame, ox, oy, oz
                 const int f = __float_as_int(lk.x);
                 while (F.frame < f) fk_advance<false>(G, F, q);
                 x[i] = F.tx + (F.r00 * lk.y + F.r01 * lk.z + F.r02 * lk.w);
