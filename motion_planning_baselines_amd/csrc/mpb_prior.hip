@@ -11,6 +11,14 @@
 // (planners/base.py: gp_prior_factor); this kernel does the substitution, one thread per chain, in fp64.
 #include "mpb_common.h"
 
+// 1/x in fp64: v_rcp_f64 + two Newton steps (the IEEE division hipcc emits is ~40 instructions, twice per step)
+__device__ __forceinline__ double prior_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 __global__ __launch_bounds__(256) void gp_prior_sample_kernel(float* __restrict__ out, const double* __restrict__ means,
                                                               const double* __restrict__ eps,
                                                               const double* __restrict__ Udiag,
@@ -42,8 +50,8 @@ __global__ __launch_bounds__(256) void gp_prior_sample_kernel(float* __restrict_
             rv -= O[1] * yp + O[3] * yv;
         }
         const double* U = Udiag + (size_t)t * 3;              // u00, u01, u11  (U_tt = [[u00,u01],[0,u11]])
-        yp = rp / U[0];
-        yv = (rv - U[1] * yp) / U[2];
+        yp = rp * prior_rcp(U[0]);
+        yv = (rv - U[1] * yp) * prior_rcp(U[2]);
         o[t * dim + d] = (float)(mu[t * dim + d] + yp);
         o[t * dim + D + d] = (float)(mu[t * dim + D + d] + yv);
     }
