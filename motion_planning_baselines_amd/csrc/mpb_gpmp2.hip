@@ -163,6 +163,14 @@ __device__ __forceinline__ double fast_rcp(double x) {
     return r;
 }
 
+// broadcast of a double held by lane `l` (compile-time constant after unrolling): two v_readlane_b32
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
 struct GpConst {
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
                                                          const double* __restrict__ diag_mean, double* __restrict__ work,
                                                          float* __restrict__ costs_out, int B, int H, int Drt, GpConst K) {
     const int D = DT ? DT : Drt;
-    __shared__ double Sb[2][GP_N * GP_LD];  // ping-pong tile: Schur complement -> its inverse
+    __shared__ double Sb[1][GP_N * GP_LD];  // W_t for the matvec / next-tile reads (the inverse itself runs in registers)
     __shared__ double xs[2][GP_N];          // x_t, x_{t+1} (fp64 copies)
     __shared__ double rv[GP_N];             // r_t
     __shared__ double zv[GP_N];             // z_t / scratch vector
@@ -199,19 +207,21 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
     float* xb = x + (size_t)b * H * dim;
     const float* jb = jac + (size_t)b * H * (D + 1);
     double cost = 0.0;
-    // element ownership for the 16x16 tile: lane -> row i = lane >> 2, columns j0 .. j0+3 with j0 = 4 (lane & 3)
-    const int ei = lane >> 2, ej0 = (lane & 3) << 2;
-    int cur = 0;  // Sb[cur] holds -(U^T W_{t-1} U) on entry to step t > 0
+    // element ownership for the 16x16 tile = the C/D layout of v_mfma_f64_16x16x4_f64: lane (lk, li) holds rows
+    // lk + 4q (q = 0..3) of column li.  The tile stays in registers from its assembly through the whole inverse.
+    const int li = lane & 15, lk = lane >> 4;
+    f64x4 Snext = {0.0, 0.0, 0.0, 0.0};  // -(U^T W_{t-1} U) on entry to step t > 0, same layout
     double rcarry = 0.0;  // lane < dim: r_t contribution carried from step t-1 (gnext - U^T z)
 
-    // per-element constants of the S assembly (lane owns row ei, columns ej0 .. ej0+3)
+    // per-element constants of the S assembly (element q of this lane: row lk + 4q, column li)
     double asm_g1[4], asm_g2[4], asm_dg[4], asm_pp[4], asm_id[4];
     bool asm_in[4];
-    int asm_hj[4];
-    const int asm_di = (ei < dim) ? ei : 0, asm_hi = (ei < D) ? ei : 0;
+    int asm_hi[4];
+    const int asm_di = (li < dim) ? li : 0;    // the diagonal element of column li is row li
+    const int asm_hj = (li < D) ? li : 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int i = ei, j = ej0 + q;
+        const int i = lk + 4 * q, j = li;
         const bool in = i < dim && j < dim;
         const bool ip = i < D, jp = j < D;
         const int ii = ip ? i : i - D, jj = jp ? j : j - D;
@@ -221,7 +231,7 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
         asm_g2[q] = same ? (ip ? (jp ? a : bq) : (jp ? bq : cq)) : 0.0;         // Qi block (t > 0)
         asm_dg[q] = (in && i == j) ? 1.0 : 0.0;
         asm_pp[q] = (in && ip && jp) ? 1.0 : 0.0;
-        asm_hj[q] = (j < D) ? j : 0;
+        asm_hi[q] = (i < D) ? i : 0;
         asm_id[q] = (i == j) ? 1.0 : 0.0;
     }
 
@@ -230,7 +240,7 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
     int nt_off[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int i = ei, j = ej0 + q;
+        const int i = lk + 4 * q, j = li;
         const bool in = i < dim && j < dim;
         const bool ip = i < D, jp = j < D;
         const int ii = in ? (ip ? i : i - D) : 0, jj = in ? (jp ? j : j - D) : 0;
@@ -250,6 +260,8 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
     float xr1 = (lane < dim && H > 1) ? xb[dim + lane] : 0.f;
     float jr = 0.f;                                                   // row 0 takes no collision factor
     float jr1 = (lane <= D && H > 1) ? jb[(D + 1) + lane] : 0.f;
+    double dm0 = K.trust ? diag_mean[asm_di] : 0.0;
+    double dm1 = (K.trust && H > 1) ? diag_mean[dim + asm_di] : 0.0;
     for (int t = 0; t < H; ++t) {
         // ---- x_t, x_{t+1}, h_t from the prefetched registers; issue the loads of step t+1
         if (lane < dim) {
@@ -259,6 +271,7 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
         if (lane <= D) hv[lane] = (t > 0) ? (double)jr : 0.0;
         const float xr2 = (lane < dim && t + 2 < H) ? xb[(t + 2) * dim + lane] : 0.f;
         const float jr2 = (lane <= D && t + 2 < H) ? jb[(t + 2) * (D + 1) + lane] : 0.f;
+        const double dm2 = (K.trust && t + 2 < H) ? diag_mean[(size_t)(t + 2) * dim + asm_di] : 0.0;
         wave_sync();
         // ---- GP error of factor t: e = x_{t+1} - Phi x_t
         double e_i = 0.0;
@@ -278,24 +291,23 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
                 cost += pos ? ep * qp : ev * qv;
             }
         }
-        // ---- S = D_t (+ Schur term already in the tile for t > 0); padding rows/cols = identity.  Branch-free: the
+        // ---- S = D_t (+ Schur term carried in registers for t > 0); padding rows/cols = identity.  Branch-free: the
         //      per-element coefficients (asm_*) were fixed before the loop, only the t-dependent selects remain
         const double ct = hv[D];
-        double* S = Sb[cur];
+        f64x4 T;
         {
             const double first = (t == 0) ? 1.0 : 0.0, notfirst = 1.0 - first, notlast = (t < H - 1) ? 1.0 : 0.0;
-            const double dmp = K.trust ? K.delta * diag_mean[(size_t)t * dim + asm_di] : K.delta;   // (clamped index)
-            const double dg = dmp + first * K.ks + (1.0 - notlast) * K.kg;
-            const double hi = hv[asm_hi] * (K.kc * notfirst);
+            const double hj = hv[asm_hj] * (K.kc * notfirst);
+            // damping of the diagonal element of this lane's column (prefetched one step ahead, like x and h)
+            const double dg = (K.trust ? K.delta * dm0 : K.delta) + first * K.ks + (1.0 - notlast) * K.kg;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const double prev = S[ei * GP_LD + ej0 + q];
-                double v = (t > 0) ? prev : 0.0;                    // t == 0: the tile holds nothing yet
+                double v = (t > 0) ? Snext[q] : 0.0;
                 v = fma(notlast, asm_g1[q], v);
                 v = fma(notfirst, asm_g2[q], v);
                 v = fma(asm_dg[q], dg, v);
-                v = fma(asm_pp[q] * hi, hv[asm_hj[q]], v);
-                S[ei * GP_LD + ej0 + q] = asm_in[q] ? v : asm_id[q];
+                v = fma(asm_pp[q] * hj, hv[asm_hi[q]], v);
+                T[q] = asm_in[q] ? v : asm_id[q];
             }
         }
         // ---- r_t
@@ -319,82 +331,85 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
         }
         if (lane == 0 && t > 0) cost += K.kc * ct * ct;
         wave_sync();
-        // ---- W = S^-1 : blocked Gauss-Jordan with 4x4 pivot blocks; the rank-4 trailing update of the whole
-        //      16 x 16 tile is ONE v_mfma_f64_16x16x4_f64 per block step (4 steps, one synchronisation each):
+        // ---- W = S^-1 : blocked Gauss-Jordan with 4x4 pivot blocks, entirely in registers.  Per block step K:
         //        D = (-A[:,K]) * (Pinv * A'[K,:]) + C_in,  A'[K,K] := I,  C_in := A with columns K zeroed,
-        //      then rows K := Pinv * A'[K,:]  (which is exactly this lane's own B operand).
-        //      Lane maps (f64 16x16x4): A-op lane l -> [i = l&15][k = l>>4]; B-op [k = l>>4][j = l&15];
-        //      C/D: column l&15, rows (l>>4) + 4*reg.
+        //      one v_mfma_f64_16x16x4_f64, then rows K := Pinv * A'[K,:] (this lane's own B operand).
+        //      Lane maps (f64 16x16x4): A-op lane l -> [i = l&15][k = l>>4]; B-op [k = l>>4][j = l&15]; C/D: column
+        //      l&15, rows (l>>4) + 4*reg.  Nothing goes through LDS:
+        //        * the pivot block is broadcast with v_readlane (row k0+r lives in register kb of lanes (r, .));
+        //        * the B operand needs rows K of column li = register kb of lanes (m, li): four shuffles;
+        //        * the A operand -A[li][k0+lk] is this lane's OWN register kb up to a sign: the working matrix of
+        //          the Gauss-Jordan inverse of a symmetric matrix satisfies M[a][b] = s M[b][a] with s = -1 when
+        //          exactly one of a, b belongs to an already processed block, +1 otherwise (induction over the
+        //          block steps), and T[kb] = M[k0+lk][li].
         {
-            const int li = lane & 15, lk = lane >> 4;
             const double rowsel[4] = {lk == 0 ? 1.0 : 0.0, lk == 1 ? 1.0 : 0.0, lk == 2 ? 1.0 : 0.0, lk == 3 ? 1.0 : 0.0};
-            for (int kb = 0; 4 * kb < dim; ++kb) {
-                const double* A = Sb[cur];
-                double* Bn = Sb[cur ^ 1];
-                const int k0 = 4 * kb;
-                // pivot block inverse, redundantly in every lane.  The pivot block is a Schur complement of an SPD
-                // matrix, hence SPD: with P = [[A, B], [B^T, C]] in 2x2 blocks, X = A^-1 B, S = C - B^T X,
-                //   P^-1 = [[A^-1 + X S^-1 X^T, -X S^-1], [-(X S^-1)^T, S^-1]]      (2 reciprocals, ~50 fma)
-                double pv[4][4];
-                {
-                    const double* Pk = A + k0 * GP_LD + k0;
-                    const double a00 = Pk[0], a01 = Pk[1], a11 = Pk[GP_LD + 1];
-                    const double b00 = Pk[2], b01 = Pk[3], b10 = Pk[GP_LD + 2], b11 = Pk[GP_LD + 3];
-                    const double c00 = Pk[2 * GP_LD + 2], c01 = Pk[2 * GP_LD + 3], c11 = Pk[3 * GP_LD + 3];
-                    const double ia = fast_rcp(fma(a00, a11, -a01 * a01));
-                    const double i00 = a11 * ia, i01 = -a01 * ia, i11 = a00 * ia;              // A^-1
-                    const double x00 = fma(i00, b00, i01 * b10), x01 = fma(i00, b01, i01 * b11);   // X = A^-1 B
-                    const double x10 = fma(i01, b00, i11 * b10), x11 = fma(i01, b01, i11 * b11);
-                    const double s00 = c00 - fma(b00, x00, b10 * x10), s01 = c01 - fma(b00, x01, b10 * x11);
-                    const double s11 = c11 - fma(b01, x01, b11 * x11);                          // S = C - B^T X
-                    const double is = fast_rcp(fma(s00, s11, -s01 * s01));
-                    const double t00 = s11 * is, t01 = -s01 * is, t11 = s00 * is;              // S^-1
-                    const double y00 = -fma(x00, t00, x01 * t01), y01 = -fma(x00, t01, x01 * t11);  // -X S^-1
-                    const double y10 = -fma(x10, t00, x11 * t01), y11 = -fma(x10, t01, x11 * t11);
-                    pv[0][0] = i00 - fma(y00, x00, y01 * x01);                                  // A^-1 + X S^-1 X^T
-                    pv[0][1] = pv[1][0] = i01 - fma(y00, x10, y01 * x11);
-                    pv[1][1] = i11 - fma(y10, x10, y11 * x11);
-                    pv[0][2] = pv[2][0] = y00; pv[0][3] = pv[3][0] = y01;
-                    pv[1][2] = pv[2][1] = y10; pv[1][3] = pv[3][1] = y11;
-                    pv[2][2] = t00; pv[2][3] = pv[3][2] = t01; pv[3][3] = t11;
-                }
-                // B operand: (Pinv * A'[K,:])[lk][li].  Lane-dependent choices (row lk of Pinv, identity columns of the
-                // pivot block) are done with 0/1 multipliers, not selects: hipcc lowers such selects around LDS loads
-                // to trees of exec-mask branches
-                const bool jin = (li >= k0) && (li < k0 + 4);
-                const double notj = jin ? 0.0 : 1.0;
-                double bop = 0.0;
-                {
-                    double am[4];
 #pragma unroll
-                    for (int m = 0; m < 4; ++m)
-                        am[m] = fma(notj, A[(k0 + m) * GP_LD + li], (li - k0 == m) ? 1.0 : 0.0);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        double rowdot = pv[r][0] * am[0];
-#pragma unroll
-                        for (int m = 1; m < 4; ++m) rowdot = fma(pv[r][m], am[m], rowdot);
-                        bop = fma(rowsel[r], rowdot, bop);
+            for (int kb = 0; kb < 4; ++kb) {
+                if (4 * kb < dim) {
+                    const int k0 = 4 * kb;
+                    const double tk = T[kb];
+                    // pivot block (symmetric: upper triangle) from lanes (r, k0 + c)
+                    const double a00 = readlane_f64(tk, 0 * 16 + k0 + 0), a01 = readlane_f64(tk, 0 * 16 + k0 + 1);
+                    const double b00 = readlane_f64(tk, 0 * 16 + k0 + 2), b01 = readlane_f64(tk, 0 * 16 + k0 + 3);
+                    const double a11 = readlane_f64(tk, 1 * 16 + k0 + 1);
+                    const double b10 = readlane_f64(tk, 1 * 16 + k0 + 2), b11 = readlane_f64(tk, 1 * 16 + k0 + 3);
+                    const double c00 = readlane_f64(tk, 2 * 16 + k0 + 2), c01 = readlane_f64(tk, 2 * 16 + k0 + 3);
+                    const double c11 = readlane_f64(tk, 3 * 16 + k0 + 3);
+                    // SPD 4x4 inverse in 2x2 blocks: X = A^-1 B, S = C - B^T X,
+                    //   P^-1 = [[A^-1 + X S^-1 X^T, -X S^-1], [-(X S^-1)^T, S^-1]]      (2 reciprocals, ~50 fma)
+                    double pv[4][4];
+                    {
+                        const double ia = fast_rcp(fma(a00, a11, -a01 * a01));
+                        const double i00 = a11 * ia, i01 = -a01 * ia, i11 = a00 * ia;              // A^-1
+                        const double x00 = fma(i00, b00, i01 * b10), x01 = fma(i00, b01, i01 * b11);   // X = A^-1 B
+                        const double x10 = fma(i01, b00, i11 * b10), x11 = fma(i01, b01, i11 * b11);
+                        const double s00 = c00 - fma(b00, x00, b10 * x10), s01 = c01 - fma(b00, x01, b10 * x11);
+                        const double s11 = c11 - fma(b01, x01, b11 * x11);                          // S = C - B^T X
+                        const double is = fast_rcp(fma(s00, s11, -s01 * s01));
+                        const double t00 = s11 * is, t01 = -s01 * is, t11 = s00 * is;              // S^-1
+                        const double y00 = -fma(x00, t00, x01 * t01), y01 = -fma(x00, t01, x01 * t11);  // -X S^-1
+                        const double y10 = -fma(x10, t00, x11 * t01), y11 = -fma(x10, t01, x11 * t11);
+                        pv[0][0] = i00 - fma(y00, x00, y01 * x01);                                  // A^-1 + X S^-1 X^T
+                        pv[0][1] = pv[1][0] = i01 - fma(y00, x10, y01 * x11);
+                        pv[1][1] = i11 - fma(y10, x10, y11 * x11);
+                        pv[0][2] = pv[2][0] = y00; pv[0][3] = pv[3][0] = y01;
+                        pv[1][2] = pv[2][1] = y10; pv[1][3] = pv[3][1] = y11;
+                        pv[2][2] = t00; pv[2][3] = pv[3][2] = t01; pv[3][3] = t11;
                     }
-                }
-                // A operand: -A[li][k0 + lk]
-                const double aop = -A[li * GP_LD + k0 + lk];
-                // C in: rows lk + 4*reg, column li; columns of the pivot block start from zero
-                f64x4 cin;
+                    // B operand (Pinv * A'[K,:])[lk][li]; lane-dependent choices are 0/1 multipliers, not selects
+                    // (hipcc lowers such selects to trees of exec-mask branches)
+                    const bool jin = (li >= k0) && (li < k0 + 4);
+                    const double notj = jin ? 0.0 : 1.0;
+                    double bop = 0.0;
+                    {
+                        double am[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) cin[q] = notj * A[(lk + 4 * q) * GP_LD + li];
-                f64x4 dd = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, cin, 0, 0, 0);
-                // rows of the pivot block: row k0 + lk lives in register kb of lane (lk, li)
+                        for (int m = 0; m < 4; ++m)
+                            am[m] = fma(notj, __shfl(tk, m * 16 + li, 64), (li - k0 == m) ? 1.0 : 0.0);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const double v = (q == kb) ? bop : dd[q];
-                    Bn[(lk + 4 * q) * GP_LD + li] = v;
+                        for (int r = 0; r < 4; ++r) {
+                            double rowdot = pv[r][0] * am[0];
+#pragma unroll
+                            for (int m = 1; m < 4; ++m) rowdot = fma(pv[r][m], am[m], rowdot);
+                            bop = fma(rowsel[r], rowdot, bop);
+                        }
+                    }
+                    const double aop = (li < k0) ? tk : -tk;
+                    f64x4 cin;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) cin[q] = notj * T[q];
+                    T = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, cin, 0, 0, 0);
+                    T[kb] = bop;                                    // rows of the pivot block
                 }
-                cur ^= 1;
-                wave_sync();
             }
         }
-        const double* W = Sb[cur];
+        // W_t to LDS once (z = W r, the next Schur tile) and to the workspace straight from the registers
+        double* Wl = Sb[0];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Wl[(lk + 4 * q) * GP_LD + li] = T[q];
+        wave_sync();
+        const double* W = Wl;
         // ---- z = W r ; store W_t, z_t
         double* wt = wW + (size_t)t * GP_WS_PER_T;
         double zi = 0.0;
@@ -404,12 +419,11 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
             wt[GP_N * GP_N + lane] = zi;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) wt[ei * GP_N + ej0 + q] = W[ei * GP_LD + ej0 + q];
+        for (int q = 0; q < 4; ++q) wt[(lk + 4 * q) * GP_N + li] = T[q];
         wave_sync();
         if (t < H - 1) {
             // ---- next tile: -(U^T W U), block (a,b) (i',j') = -sum_{c,e} U[c][a] U[e][b] W[i'+cD][j'+eD]; the four
             //      coefficient products and the element offsets are per-lane constants (nt_*), so 4 fma per element
-            double newS[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const double* Wq = W + nt_off[q];
@@ -417,7 +431,7 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
                 v = fma(nt_c[q][1], Wq[D], v);
                 v = fma(nt_c[q][2], Wq[D * GP_LD], v);
                 v = fma(nt_c[q][3], Wq[D * GP_LD + D], v);
-                newS[q] = v;
+                Snext[q] = v;
             }
             // r_{t+1} carry = gnext - U^T z
             if (lane < dim) {
@@ -426,13 +440,9 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
                 const double zp = zv[ii], zvv = zv[ii + D];
                 rcarry = gnext - (ip ? u00 * zp + u10 * zvv : u01 * zp + u11 * zvv);
             }
-            wave_sync();
-            double* Sn = Sb[cur];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) Sn[ei * GP_LD + ej0 + q] = newS[q];
-            wave_sync();
+            wave_sync();                                           // W / zv reads done before the next step overwrites them
         }
-        xr0 = xr1; xr1 = xr2; jr = jr1; jr1 = jr2;
+        xr0 = xr1; xr1 = xr2; jr = jr1; jr1 = jr2; dm0 = dm1; dm1 = dm2;
     }
     // ---- backward substitution and update: dtheta_t = z_t - W_t (U dtheta_{t+1}).  Row `lane` of W_{t-1}, z_{t-1}
     //      and x_{t-1} are fetched while step t runs: the workspace (B*H*2.2 KB) does not stay in cache, and an
