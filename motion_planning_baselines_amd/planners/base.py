@@ -169,6 +169,19 @@ class OptimizationPlanner(MPPlanner):
         f64 = lambda a: torch.as_tensor(a, dtype=torch.float64).to(self.device).contiguous()
         return ops.gp_prior_sample(f64(means), eps, f64(Ud), f64(Uo), n, D, seed=seed)
 
+    def const_vel_trajectories(self, start_state, multi_goal_states):
+        """base.py:141-153, incl. its quirk: the velocity channel is (goal - start) / (H * dt), not / ((H-1) * dt).
+        One (H, 2D) straight line per goal; host-side set-up arithmetic (a few KB), placed on the planner's device."""
+        H, D = self.n_support_points, self.n_dof
+        start_state = torch.as_tensor(start_state, dtype=torch.float32).reshape(-1, start_state.shape[-1]).cpu()
+        goals = torch.as_tensor(multi_goal_states, dtype=torch.float32).cpu()
+        traj = torch.zeros(goals.shape[0], H, 2 * D)
+        mean_vel = (goals[:, :D] - start_state[:, :D]) / (H * self.dt)
+        for i in range(H):
+            traj[:, i, :D] = start_state[:, :D] * (H - i - 1) / (H - 1) + goals[:, :D] * i / (H - 1)
+        traj[:, :, D:] = mean_vel.unsqueeze(1).repeat(1, H, 1)
+        return traj.to(self.device)
+
     def _get_traj(self):
         trajs = self._particle_means.clone()
         if self.pos_only:

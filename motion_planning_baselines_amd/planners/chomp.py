@@ -53,6 +53,27 @@ class CHOMP(OptimizationPlanner):
     def _get_R_mat(cls, dt=0.01, n_support_points=64, tensor_args=None, **kwargs):
         return chomp_precision_matrix(dt=dt, n_support_points=n_support_points, tensor_args=tensor_args)
 
+    def _get_R_mat2(self):
+        """chomp.py:60-79: the STOMP-style second-difference precision (unused by optimize, kept for callers)."""
+        from .stomp import stomp_precision_matrix
+        return stomp_precision_matrix(self.n_support_points, self.dt, 1.0,
+                                      dict(device='cpu', dtype=torch.float32)).to(self.device)
+
+    def _eval(self, x, **observation):
+        """chomp.py:153-169: collision costs (B,) plus the smoothness prior -- the batch-wide scalar
+        weight_prior_cost * sum_{b,channel} x^T R x (quirk Q3) -- added to every entry."""
+        from .costs.cost_functions import CostSmoothnessCHOMP  # noqa: F401  (same kernel term)
+        fused = fusable_collision(self.cost)
+        if x.ndim == 2:
+            x = x.unsqueeze(0)
+        x = x.contiguous()
+        costs = torch.zeros(x.shape[0], device=x.device, dtype=torch.float32)
+        if fused is not None:
+            cc, weight = fused
+            costs = ops.cost_collision_eval(x, cc.device_geometry(x.device), cc.k_sigma, weight=weight)
+        smooth, _ = ops.cost_terms_eval(x, self.n_dof, dt=self.dt, k_smooth=1.0, terms={'smooth'})
+        return costs + self.weight_prior_cost * smooth.sum()
+
     def reset(self, initial_particle_means=None):
         """chomp.py:103-111."""
         if initial_particle_means is not None:

@@ -79,20 +79,34 @@ class StochGPMP(OptimizationPlanner):
         self._iter += 1
         return out.reshape(P, S, H, dim)
 
+    def sample_trajectories(self, **kwargs):
+        """stoch_gpmp.py:229-233: S fresh trajectories per particle from the sampling prior, (P, S, H, 2D)."""
+        self.state_samples = self._sample()
+        return self.state_samples
+
+    def sample_and_eval(self, **observation):
+        """stoch_gpmp.py:244-265: draw the samples and evaluate cost + importance term -> (costs (P,S), samples)."""
+        P, S, H, dim = self.num_particles, self.num_samples, self.n_support_points, self.d_state_opt
+        self.state_samples = self._sample()
+        flat = self.state_samples.reshape(P * S, H, dim)
+        ops.stoch_gpmp_costs(flat, self._particle_means, self._start, self._goal, self.geom, self.costs, S,
+                             self.sig_cost, self.sig_sample, self.dt, self.temperature)
+        return self.costs, self.state_samples
+
+    def _update_distribution(self, costs, traj_samples):
+        """stoch_gpmp.py:267-279: softmax weights over the samples, mean += step * sum_s w_s (x_s - mean)."""
+        ops.stomp_update(self._particle_means, traj_samples, costs, self._weights_buf, None, self.step_size,
+                         self.temperature)
+        self._weights = self._weights_buf.reshape(self.num_particles, self.num_samples, 1, 1)
+        self._recent_weights = self._weights
+
     def optimize(self, opt_iters=None, debug=False, **observation):
         """stoch_gpmp.py:281-313."""
         if opt_iters is None:
             opt_iters = self.opt_iters
-        P, S, H, dim = self.num_particles, self.num_samples, self.n_support_points, self.d_state_opt
         for _ in range(opt_iters):
-            self.state_samples = self._sample()
-            flat = self.state_samples.reshape(P * S, H, dim)
-            ops.stoch_gpmp_costs(flat, self._particle_means, self._start, self._goal, self.geom, self.costs, S,
-                                 self.sig_cost, self.sig_sample, self.dt, self.temperature)
-            ops.stomp_update(self._particle_means, self.state_samples, self.costs, self._weights_buf, None,
-                             self.step_size, self.temperature)
-        self._weights = self._weights_buf.reshape(P, S, 1, 1)
-        self._recent_weights = self._weights
+            costs, samples = self.sample_and_eval(**observation)
+            self._update_distribution(costs, samples)
         return self._get_traj()
 
     def get_recent_samples(self):

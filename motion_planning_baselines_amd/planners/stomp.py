@@ -81,6 +81,37 @@ class STOMP(OptimizationPlanner):
         self.reset(initial_particle_means=initial_particle_means)
         self.best_cost = torch.inf
 
+    # ---- constants ---------------------------------------------------------------------------
+    def _get_R_mat(self):
+        """stomp.py:68-86."""
+        return stomp_precision_matrix(self.n_support_points, self.dt, self.sigma_spectral,
+                                      dict(device='cpu', dtype=torch.float32)).to(self.device)
+
+    def set_noise_dist(self):
+        """stomp.py:88-95: the noise distribution is N(0, Sigma_inv^-1); here that is its scale_tril, derived exactly
+        as MultivariateNormal(precision_matrix=...) derives it."""
+        self.scale_tril = precision_to_scale_tril(self.Sigma_inv.detach().cpu().float()).to(self.device).contiguous()
+
+    def const_vel_trajectory(self, start_state, goal_state):
+        """stomp.py:122-135: straight line start -> goal, (H, d_state_opt)."""
+        H, D = self.n_support_points, self.n_dof
+        start_state, goal_state = start_state.detach().cpu().float(), goal_state.detach().cpu().float()
+        n = H - 1
+        traj = torch.zeros(H, self.d_state_opt)
+        for i in range(H):
+            traj[i, :D] = start_state[:D] * (n - i) * 1. / n + goal_state[:D] * i * 1. / n
+        if not self.pos_only:
+            traj[:, D:] = ((goal_state[:D] - start_state[:D]) / (n * self.dt)).unsqueeze(0)
+        return traj.to(self.device)
+
+    def _calc_sample_weights(self, costs):
+        """stomp.py:219-220: softmax(-costs / T) over the samples of each particle, (P, S, 1, 1).  Served by the
+        update kernel with a zero step (the means stay untouched)."""
+        costs = costs.reshape(self.num_particles, self.num_samples).to(torch.float32).contiguous()
+        w = torch.empty_like(costs)
+        ops.stomp_update(self._particle_means, self.state_particles, costs, w, self.Sigma, 0.0, self.temperature)
+        return w.reshape(self.num_particles, self.num_samples, 1, 1)
+
     # ---- noise -------------------------------------------------------------------------------
     def _draw_eps(self, n_iters):
         """Standard normals in the reference's draw order: one (S,d,P,H) block per iteration."""
