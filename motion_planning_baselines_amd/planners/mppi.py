@@ -113,9 +113,8 @@ class MPPI(MPPlanner):
         blocks = [torch.stack([torch.empty(S, T, device=dev).normal_() for _ in range(c)]) for _ in range(n_iters)]
         return torch.stack(blocks).reshape(n_iters, 1, c, S, T).to(self.device).contiguous()
 
-    def optimize(self, opt_iters=None, **observation):
-        if opt_iters is None:
-            opt_iters = self.opt_iters
+    def _problem(self, **observation):
+        """Device-side (state, goal, geometry, k_sigma, weight) of one optimize / rollout call."""
         c = self.control_dim
         state = observation['state'].to(device=self.device, dtype=torch.float32).reshape(1, c).contiguous()
         goal = observation.get('goal_state', self.system.goal_state)
@@ -128,15 +127,58 @@ class MPPI(MPPlanner):
                 raise NotImplementedError('MPPI fuses a single collision cost; other cost objects are not wired in')
             cc, weight = fused
             geom, k_sigma = cc.device_geometry(self.device), cc.k_sigma
-        mean = self._mean.reshape(1, self.rollout_steps, c)
-        ops.mppi_step(mean, self._draw_eps(opt_iters), self._scale_tril, self.Cov_inv, state, goal, self._cmin,
+        return state, goal, geom, k_sigma, weight
+
+    def _launch(self, n_iters, step_size, **observation):
+        state, goal, geom, k_sigma, weight = self._problem(**observation)
+        mean = self._mean.reshape(1, self.rollout_steps, self.control_dim)
+        ops.mppi_step(mean, self._draw_eps(n_iters), self._scale_tril, self.Cov_inv, state, goal, self._cmin,
                       self._cmax, self._disc, self._cw, geom, self._controls, self._states, self._costs, self._weights,
-                      self.system.dt, k_sigma=k_sigma, weight=weight, temp=self.temp, step_size=self.step_size,
-                      n_iters=opt_iters, seed=self.seed, iter0=self._iter)
-        self._iter += opt_iters
+                      self.system.dt, k_sigma=k_sigma, weight=weight, temp=self.temp, step_size=step_size,
+                      n_iters=n_iters, seed=self.seed, iter0=self._iter)
+        self._iter += n_iters
         self.costs = self._costs.reshape(-1, 1)
-        self.weights = self._weights.reshape(-1, 1)
         self.state_trajectories = self._states[0]
+
+    def update_ctrl_dist(self):
+        """mppi.py:68-70: the sampling distribution reads self._mean directly here; nothing to refresh."""
+
+    def sample_and_eval(self, **observation):
+        """mppi.py:88-134: sample controls, roll out, evaluate costs (incl. the importance term); the mean is left
+        untouched (one kernel iteration with a zero step)."""
+        self._launch(1, 0.0, **observation)
+        return self._controls[0], self._states[0], self.costs
+
+    def update_controller(self, costs, U_sampled):
+        """mppi.py:72-86: softmax weights over the samples and mean += step * sum_s w_s (U_s - mean) -- the STOMP
+        update kernel without a covariance product."""
+        S, T, c = self.num_ctrl_samples, self.rollout_steps, self.control_dim
+        ops.stomp_update(self._mean.reshape(1, T, c), U_sampled.reshape(1, S, T, c).contiguous(),
+                         costs.reshape(1, S).to(torch.float32).contiguous(), self._weights, None, self.step_size, self.temp)
+        self.weights = self._weights.reshape(-1, 1).clone()
+        self.update_ctrl_dist()
+
+    def get_state_trajectories_rollout(self, controls=None, num_ctrl_samples=None, **observation):
+        """mppi.py:190-210: Euler rollout of the given control sequences (default: the mean) from observation['state'].
+        Every sequence becomes a one-sample problem with zero noise, so the same kernel serves it."""
+        T, c = self.rollout_steps, self.control_dim
+        U = (self._mean.unsqueeze(0) if controls is None else controls).to(device=self.device, dtype=torch.float32)
+        U = U.reshape(-1, T, c).contiguous().clone()
+        n = U.shape[0]
+        state, goal, _, _, _ = self._problem(**{k: v for k, v in observation.items() if k != 'cost'})
+        eps = torch.zeros(1, n, c, 1, T, device=self.device)
+        ctr, st = torch.empty(n, 1, T, c, device=self.device), torch.empty(n, 1, T, c, device=self.device)
+        cs, ws = torch.empty(n, 1, device=self.device), torch.empty(n, 1, device=self.device)
+        ops.mppi_step(U, eps, self._scale_tril, self.Cov_inv, state.expand(n, c).contiguous(), goal.expand(n, c).contiguous(),
+                      self._cmin, self._cmax, self._disc, self._cw, None, ctr, st, cs, ws, self.system.dt, temp=self.temp,
+                      step_size=0.0, n_iters=1)
+        return st[:, 0]
+
+    def optimize(self, opt_iters=None, **observation):
+        if opt_iters is None:
+            opt_iters = self.opt_iters
+        self._launch(opt_iters, self.step_size, **observation)
+        self.weights = self._weights.reshape(-1, 1)
         self._save_best()
         self._recent_control_samples = self._controls[0]
         self._recent_state_trajectories = self._states[0]

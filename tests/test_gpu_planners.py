@@ -216,3 +216,29 @@ def test_planner_helper_methods(gpu_device):
     want = O.collision_cost(x64, rr, rf, float(g['sigma_coll'])) + 1e-6 * O.smoothness_sum(
         x64, O.chomp_precision(H, float(g['dt']), dict(device='cpu', dtype=torch.float64)))
     assert rel_err(got, want) < 1e-4
+
+
+def test_mppi_split_methods_equal_optimize(gpu_device):
+    """MPPI.sample_and_eval + update_controller (mppi.py:72-134) == one optimize() iteration; the rollout helper
+    reproduces the states of the sampled controls."""
+    from motion_planning_baselines_amd.planners.mppi import MPPI, PointParticleDynamics
+    dev = gpu_device
+    ta = dict(device=dev, dtype=torch.float32)
+    mk = lambda: MPPI(PointParticleDynamics(rollout_steps=64, goal_state=torch.tensor([0.8, 0.8]), dt=0.04,
+                                            ctrl_min=[-1, -1], ctrl_max=[1, 1], c_weights={'pos': 1., 'vel': 1., 'ctrl': 1., 'pos_T': 100.},
+                                            tensor_args=ta),
+                      num_ctrl_samples=32, rollout_steps=64, opt_iters=1, control_std=[0.3, 0.3], temp=1., step_size=0.7,
+                      cov_prior_type='const_ctrl', tensor_args=ta, noise='philox', seed=3)
+    obs = dict(state=torch.tensor([-0.8, -0.8], device=dev))
+    a, b = mk(), mk()
+    U, X, c = a.optimize(**obs)
+    U2, X2, c2 = b.sample_and_eval(**obs)
+    assert torch.equal(U, U2) and torch.equal(X, X2) and torch.equal(c, c2)
+    assert torch.equal(b.get_mean_controls(), torch.zeros(64, 2, device=dev))           # untouched so far
+    b.update_controller(c2, U2)
+    assert torch.allclose(a.get_mean_controls(), b.get_mean_controls(), rtol=1e-5, atol=1e-7)
+    assert torch.allclose(a.weights, b.weights, rtol=1e-5, atol=1e-8)
+    Xr = b.get_state_trajectories_rollout(controls=U2, num_ctrl_samples=32, **obs)
+    assert Xr.shape == (32, 64, 2) and torch.allclose(Xr, X2, rtol=1e-5, atol=1e-6)
+    Xm = b.get_state_trajectories_rollout(**obs)
+    assert Xm.shape == (1, 64, 2) and torch.equal(Xm[0, 0].cpu(), torch.tensor([-0.8, -0.8]))
