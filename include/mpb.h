@@ -187,20 +187,24 @@ int mpb_chomp_step(float *means, const float *R, const float *geom, float *costs
  *                         else delta * diag_mean (diag_mean NULL: workspace mean written by mpb_gpmp2_step).
  *                         costs_out (B) optional: b^T K b of the iterate BEFORE the update (gpmp2.py:493-495).
  *   mpb_gpmp2_step      : n_iters full iterations on one GPU (mean over the local B).
+ * n_fields = number of collision fields chained in `geom` (1..4; see mpb_geom_check): the reference stacks one
+ * block of H-1 collision rows per field (gpmp2.py:70-78, cost_functions.py:107-144), the workspace keeps one
+ * (h_t, c_t) set per field and the solve sums their rank-1 terms.
  * ------------------------------------------------------------------------------------------- */
 size_t mpb_gpmp2_workspace_bytes(int B, int H, int D);
 int mpb_gpmp2_linearize(const float *x, const float *geom, void *workspace, int B, int H, int D, int n_interp,
                         void *stream);
-int mpb_gpmp2_diag(void *workspace, double *diag_sum_out, int B, int H, int D, float dt,
+int mpb_gpmp2_diag(void *workspace, double *diag_sum_out, int B, int H, int D, int n_fields, float dt,
                    float sigma_start, float sigma_gp, float sigma_goal, float sigma_coll, void *stream);
 int mpb_gpmp2_solve(float *x, const float *start, const float *goal, const double *diag_mean, void *workspace,
-                    float *costs_out, int B, int H, int D, float dt,
+                    float *costs_out, int B, int H, int D, int n_fields, float dt,
                     float sigma_start, float sigma_gp, float sigma_goal, float sigma_coll,
                     float delta, int trust_region, float step_size, void *stream);
 int mpb_gpmp2_step(float *x, const float *start, const float *goal, const float *geom, void *workspace,
                    float *costs_out, int B, int H, int D, float dt,
                    float sigma_start, float sigma_gp, float sigma_goal, float sigma_coll,
-                   float delta, int trust_region, float step_size, int n_iters, int n_interp, void *stream);
+                   float delta, int trust_region, float step_size, int n_iters, int n_interp, int n_fields,
+                   void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * MPPI -- replaces MPPI.optimize's loop body (mppi.py:145-152): ControlTrajectoryGaussian.sample

@@ -21,7 +21,8 @@
 #include <type_traits>
 
 #define MPB_GEOM_MAGIC 0x4D504247
-#define MPB_GEOM_VERSION 3
+#define MPB_GEOM_VERSION 4
+#define MPB_MAX_FIELDS 4   // collision fields chained in one buffer (header word 27 = words to the next one)
 #define MPB_GEOM_HEADER_WORDS 32
 #define MPB_GRID_MAX_CELLS 4096
 #define MPB_GRID_MAX_SPH 63      // obstacle table in LDS: 63 spheres + one far-away dummy
@@ -55,7 +56,14 @@ struct GeomView {
     const unsigned* grid;
     int gnx, gny, gnz, n_cells;
     float glx, gly, glz, gix, giy, giz;  // origin, 1 / cell size
+    float fscale;                        // s_f: this field's share in  sum_f s_f * cost_f
 };
+
+// next field of the chain (the reference sums one CostCollision per field), nullptr after the last one
+__device__ __forceinline__ const float* geom_next(const float* __restrict__ g) {
+    const int off = reinterpret_cast<const int*>(g)[27];
+    return off ? g + off : nullptr;
+}
 
 __device__ __forceinline__ GeomView geom_view(const float* __restrict__ g) {
     const int* gi = reinterpret_cast<const int*>(g);
@@ -78,6 +86,7 @@ __device__ __forceinline__ GeomView geom_view(const float* __restrict__ g) {
     v.glx = g[20]; v.gly = g[21]; v.glz = g[22];
     v.gix = g[23]; v.giy = g[24]; v.giz = g[25];
     v.n_cells = gi[26];
+    v.fscale = g[28];
     return v;
 }
 
@@ -447,6 +456,25 @@ __device__ __forceinline__ float waypoint_cost(const GeomView& G, const float (&
 // all obstacles whenever the hinge is active, so the cost is bit-identical to the exhaustive loop.
 //   gridw : n_cells words in LDS;  otab : (cx,cy,cz,r) of the n_sph spheres + a far dummy at n_sph, in LDS.
 // ------------------------------------------------------------------------------------------------
+// sum_f s_f * cost_f(q) over the chained fields (exhaustive / gradient evaluator); dq accumulates the gradient
+template <bool GRAD>
+__device__ __forceinline__ float waypoint_cost_chain(const float* __restrict__ geom, const float (&q)[MPB_MAX_DOF],
+                                                    float (&dq)[MPB_MAX_DOF]) {
+    float c = 0.f;
+#pragma unroll
+    for (int i = 0; i < MPB_MAX_DOF; ++i) dq[i] = 0.f;
+    for (const float* gp = geom; gp != nullptr; gp = geom_next(gp)) {
+        const GeomView G = geom_view(gp);
+        float dqf[MPB_MAX_DOF];
+        c = fmaf(G.fscale, waypoint_cost<GRAD>(G, q, dqf), c);
+        if (GRAD) {
+#pragma unroll
+            for (int i = 0; i < MPB_MAX_DOF; ++i) dq[i] = fmaf(G.fscale, dqf[i], dq[i]);
+        }
+    }
+    return c;
+}
+
 __device__ __forceinline__ bool grid_usable(const GeomView& G) {
     return G.n_cells > 0 && G.n_cells <= MPB_GRID_MAX_CELLS && G.n_sph <= MPB_GRID_MAX_SPH;
 }

@@ -31,12 +31,18 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 // (t = 0 is excluded from the collision factor: traj_range [1, None]).  One wave per particle, lane = waypoint.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gpmp2_linearize_kernel(const float* __restrict__ x, const float* __restrict__ geom,
-                                                              float* __restrict__ jac, int B, int H, int D, int n_interp) {
+                                                              float* __restrict__ jac_all, int B, int H, int D, int n_interp) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (b >= B) return;
-    const GeomView G = geom_view(geom);
     const int dim = 2 * D;
+    // one (h_t, c_t) set per chained collision field f (the reference stacks one block of H-1 rows per field,
+    // cost_functions.py:107-144), scaled by sqrt(s_f) so that the solve kernel only has to sum kc h h^T, kc h c, kc c^2
+    int fidx = 0;
+    for (const float* gp = geom; gp != nullptr; gp = geom_next(gp), ++fidx) {
+    const GeomView G = geom_view(gp);
+    const float rs = __builtin_amdgcn_sqrtf(G.fscale);
+    float* jac = jac_all + (size_t)fidx * B * H * (D + 1);
     // n_interp > 0 (CostComposite.get_linear_system with n_interpolated_points, cost_functions.py:115-119;
     // field_factor.py:42-54): the Jacobian row of support point t is d/dq_t of the summed cost of the
     // INTERPOLATED trajectory, i.e. its own gradient plus (1-a) * grad of every interior point of segment
@@ -88,9 +94,10 @@ __global__ __launch_bounds__(256) void gpmp2_linearize_kernel(const float* __res
             float* o = jac + ((size_t)b * H + t) * (D + 1);
 #pragma unroll
             for (int i = 0; i < MPB_MAX_DOF; ++i)
-                if (i < D) o[i] = -dq[i];
-            o[D] = c;
+                if (i < D) o[i] = -rs * dq[i];
+            o[D] = rs * c;
         }
+    }
     }
 }
 
@@ -98,7 +105,7 @@ __global__ __launch_bounds__(256) void gpmp2_linearize_kernel(const float* __res
 // local SUM over particles of diag(A^T K A) (quirk Q9 needs its batch mean).  grid = H, block = 256.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gpmp2_diag_kernel(const float* __restrict__ jac, double* __restrict__ diag_sum,
-                                                         int B, int H, int D, double dt, double ks, double kgp,
+                                                         int B, int H, int D, int F, double dt, double ks, double kgp,
                                                          double kg, double kc) {
     const int t = blockIdx.x;
     const int dim = 2 * D;
@@ -106,12 +113,13 @@ __global__ __launch_bounds__(256) void gpmp2_diag_kernel(const float* __restrict
     double acc[MPB_MAX_DOF];
 #pragma unroll
     for (int i = 0; i < MPB_MAX_DOF; ++i) acc[i] = 0.0;
-    for (int b = threadIdx.x; b < B; b += blockDim.x) {
-        const float* o = jac + ((size_t)b * H + t) * (D + 1);
+    for (int f = 0; f < F; ++f)
+        for (int b = threadIdx.x; b < B; b += blockDim.x) {
+            const float* o = jac + (((size_t)f * B + b) * H + t) * (D + 1);
 #pragma unroll
-        for (int i = 0; i < MPB_MAX_DOF; ++i)
-            if (i < D) acc[i] += (double)o[i] * (double)o[i];
-    }
+            for (int i = 0; i < MPB_MAX_DOF; ++i)
+                if (i < D) acc[i] += (double)o[i] * (double)o[i];
+        }
 #pragma unroll
     for (int i = 0; i < MPB_MAX_DOF; ++i) acc[i] = wave_sum_f64(acc[i]);
     if ((threadIdx.x & 63) == 0) {
@@ -186,14 +194,14 @@ template <int DT>
 __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, const float* __restrict__ start,
                                                          const float* __restrict__ goal, const float* __restrict__ jac,
                                                          const double* __restrict__ diag_mean, double* __restrict__ work,
-                                                         float* __restrict__ costs_out, int B, int H, int Drt, GpConst K) {
+                                                         float* __restrict__ costs_out, int B, int H, int Drt, int F, GpConst K) {
     const int D = DT ? DT : Drt;
     __shared__ double Sb[1][GP_N * GP_LD];  // W_t for the matvec / next-tile reads (the inverse itself runs in registers)
     __shared__ double xs[2][GP_N];          // x_t, x_{t+1} (fp64 copies)
     __shared__ double rv[GP_N];             // r_t
     __shared__ double zv[GP_N];             // z_t / scratch vector
     __shared__ double dth[GP_N];            // dtheta_{t+1} during the backward pass
-    __shared__ double hv[GP_N];             // collision Jacobian h_t (D values) and cost c_t at [D]
+    __shared__ double hv[MPB_MAX_FIELDS][GP_N];   // per field: collision Jacobian h_t (D values) and cost c_t at [D]
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
     const int dim = 2 * D;
@@ -268,7 +276,11 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
             xs[0][lane] = (double)xr0;
             xs[1][lane] = (t + 1 < H) ? (double)xr1 : 0.0;
         }
-        if (lane <= D) hv[lane] = (t > 0) ? (double)jr : 0.0;
+        if (lane <= D) {
+            hv[0][lane] = (t > 0) ? (double)jr : 0.0;
+            for (int f = 1; f < F; ++f)      // further chained fields: not prefetched (the single-field path stays lean)
+                hv[f][lane] = (t > 0) ? (double)jb[(size_t)f * B * H * (D + 1) + t * (D + 1) + lane] : 0.0;
+        }
         const float xr2 = (lane < dim && t + 2 < H) ? xb[(t + 2) * dim + lane] : 0.f;
         const float jr2 = (lane <= D && t + 2 < H) ? jb[(t + 2) * (D + 1) + lane] : 0.f;
         const double dm2 = (K.trust && t + 2 < H) ? diag_mean[(size_t)(t + 2) * dim + asm_di] : 0.0;
@@ -293,11 +305,12 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
         }
         // ---- S = D_t (+ Schur term carried in registers for t > 0); padding rows/cols = identity.  Branch-free: the
         //      per-element coefficients (asm_*) were fixed before the loop, only the t-dependent selects remain
-        const double ct = hv[D];
         f64x4 T;
         {
             const double first = (t == 0) ? 1.0 : 0.0, notfirst = 1.0 - first, notlast = (t < H - 1) ? 1.0 : 0.0;
-            const double hj = hv[asm_hj] * (K.kc * notfirst);
+            double hj[MPB_MAX_FIELDS];
+#pragma unroll
+            for (int f = 0; f < MPB_MAX_FIELDS; ++f) hj[f] = (f < F) ? hv[f][asm_hj] * (K.kc * notfirst) : 0.0;
             // damping of the diagonal element of this lane's column (prefetched one step ahead, like x and h)
             const double dg = (K.trust ? K.delta * dm0 : K.delta) + first * K.ks + (1.0 - notlast) * K.kg;
 #pragma unroll
@@ -306,7 +319,9 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
                 v = fma(notlast, asm_g1[q], v);
                 v = fma(notfirst, asm_g2[q], v);
                 v = fma(asm_dg[q], dg, v);
-                v = fma(asm_pp[q] * hj, hv[asm_hi[q]], v);
+#pragma unroll
+                for (int f = 0; f < MPB_MAX_FIELDS; ++f)
+                    if (f < F) v = fma(asm_pp[q] * hj[f], hv[f][asm_hi[q]], v);
                 T[q] = asm_in[q] ? v : asm_id[q];
             }
         }
@@ -325,11 +340,13 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
                 cost += K.kg * eg * eg;
             }
             if (t < H - 1) r += pqe_i;
-            if (t > 0 && lane < D) r += K.kc * hv[lane] * ct;
+            if (t > 0 && lane < D)
+                for (int f = 0; f < F; ++f) r += K.kc * hv[f][lane] * hv[f][D];
             gnext = -qe_i;                                         // contribution of factor t to g_{t+1}
             rv[lane] = r;
         }
-        if (lane == 0 && t > 0) cost += K.kc * ct * ct;
+        if (lane == 0 && t > 0)
+            for (int f = 0; f < F; ++f) cost += K.kc * hv[f][D] * hv[f][D];
         wave_sync();
         // ---- W = S^-1 : blocked Gauss-Jordan with 4x4 pivot blocks, entirely in registers.  Per block step K:
         //        D = (-A[:,K]) * (Pinv * A'[K,:]) + C_in,  A'[K,K] := I,  C_in := A with columns K zeroed,
@@ -501,7 +518,7 @@ static bool gp_shape_ok(int B, int H, int D) { return B >= 0 && H >= 2 && H <= G
 
 extern "C" size_t mpb_gpmp2_workspace_bytes(int B, int H, int D) {
     if (!gp_shape_ok(B, H, D)) return 0;
-    const size_t jac = (size_t)B * H * (D + 1) * sizeof(float);
+    const size_t jac = (size_t)MPB_MAX_FIELDS * B * H * (D + 1) * sizeof(float);   // one (h, c) set per chained field
     const size_t diag = 2 * (size_t)H * 2 * D * sizeof(double);
     const size_t fz = (size_t)B * H * GP_WS_PER_T * sizeof(double);
     return ((jac + 255) / 256) * 256 + ((diag + 255) / 256) * 256 + fz;
@@ -517,7 +534,7 @@ static GpWork gp_carve(void* ws, int B, int H, int D) {
     GpWork w;
     char* p = (char*)ws;
     w.jac = (float*)p;
-    p += (((size_t)B * H * (D + 1) * sizeof(float)) + 255) / 256 * 256;
+    p += (((size_t)MPB_MAX_FIELDS * B * H * (D + 1) * sizeof(float)) + 255) / 256 * 256;
     w.diag_sum = (double*)p;
     w.diag_mean = w.diag_sum + (size_t)H * 2 * D;
     p += ((2 * (size_t)H * 2 * D * sizeof(double)) + 255) / 256 * 256;
@@ -536,24 +553,25 @@ extern "C" int mpb_gpmp2_linearize(const float* x, const float* geom, void* work
     return mpb_check_launch("mpb_gpmp2_linearize");
 }
 
-extern "C" int mpb_gpmp2_diag(void* workspace, double* diag_sum_out, int B, int H, int D, float dt, float sigma_start,
-                              float sigma_gp, float sigma_goal, float sigma_coll, void* stream) {
+extern "C" int mpb_gpmp2_diag(void* workspace, double* diag_sum_out, int B, int H, int D, int n_fields, float dt,
+                              float sigma_start, float sigma_gp, float sigma_goal, float sigma_coll, void* stream) {
     if (!workspace) return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_diag: null pointer");
-    if (!gp_shape_ok(B, H, D)) return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_diag: bad shape");
+    if (!gp_shape_ok(B, H, D) || n_fields < 1 || n_fields > MPB_MAX_FIELDS) return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_diag: bad shape");
     GpWork w = gp_carve(workspace, B, H, D);
     double* out = diag_sum_out ? diag_sum_out : w.diag_sum;
-    hipLaunchKernelGGL(gpmp2_diag_kernel, dim3(H), dim3(256), 0, (hipStream_t)stream, w.jac, out, B, H, D, (double)dt,
+    hipLaunchKernelGGL(gpmp2_diag_kernel, dim3(H), dim3(256), 0, (hipStream_t)stream, w.jac, out, B, H, D, n_fields,
+                       (double)dt,
                        1.0 / ((double)sigma_start * sigma_start), 1.0 / ((double)sigma_gp * sigma_gp),
                        1.0 / ((double)sigma_goal * sigma_goal), 1.0 / ((double)sigma_coll * sigma_coll));
     return mpb_check_launch("mpb_gpmp2_diag");
 }
 
 extern "C" int mpb_gpmp2_solve(float* x, const float* start, const float* goal, const double* diag_mean, void* workspace,
-                               float* costs_out, int B, int H, int D, float dt, float sigma_start, float sigma_gp,
-                               float sigma_goal, float sigma_coll, float delta, int trust_region, float step_size,
-                               void* stream) {
+                               float* costs_out, int B, int H, int D, int n_fields, float dt, float sigma_start,
+                               float sigma_gp, float sigma_goal, float sigma_coll, float delta, int trust_region,
+                               float step_size, void* stream) {
     if (!x || !start || !goal || !workspace) return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_solve: null pointer");
-    if (!gp_shape_ok(B, H, D)) return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_solve: bad shape");
+    if (!gp_shape_ok(B, H, D) || n_fields < 1 || n_fields > MPB_MAX_FIELDS) return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_solve: bad shape");
     if (B == 0) return MPB_OK;
     GpWork w = gp_carve(workspace, B, H, D);
     GpConst K;
@@ -568,7 +586,7 @@ extern "C" int mpb_gpmp2_solve(float* x, const float* start, const float* goal, 
     const double* dm = trust_region ? (diag_mean ? diag_mean : w.diag_mean) : nullptr;
 #define GP_LAUNCH(DT)                                                                                                   \
     hipLaunchKernelGGL(gpmp2_solve_kernel<DT>, dim3(B), dim3(64), 0, (hipStream_t)stream, x, start, goal, w.jac, dm, w.fz, \
-                       costs_out, B, H, D, K)
+                       costs_out, B, H, D, n_fields, K)
     switch (D) {
         case 2: GP_LAUNCH(2); break;
         case 3: GP_LAUNCH(3); break;
@@ -582,22 +600,23 @@ extern "C" int mpb_gpmp2_solve(float* x, const float* start, const float* goal, 
 extern "C" int mpb_gpmp2_step(float* x, const float* start, const float* goal, const float* geom, void* workspace,
                               float* costs_out, int B, int H, int D, float dt, float sigma_start, float sigma_gp,
                               float sigma_goal, float sigma_coll, float delta, int trust_region, float step_size,
-                              int n_iters, int n_interp, void* stream) {
+                              int n_iters, int n_interp, int n_fields, void* stream) {
     if (!x || !start || !goal || !geom || !workspace) return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_step: null pointer");
-    if (!gp_shape_ok(B, H, D) || n_iters < 0) return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_step: bad shape");
+    if (!gp_shape_ok(B, H, D) || n_iters < 0 || n_fields < 1 || n_fields > MPB_MAX_FIELDS)
+        return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_step: bad shape");
     if (B == 0) return MPB_OK;
     GpWork w = gp_carve(workspace, B, H, D);
     for (int it = 0; it < n_iters; ++it) {
         int rc = mpb_gpmp2_linearize(x, geom, workspace, B, H, D, n_interp, stream);
         if (rc) return rc;
         if (trust_region) {
-            rc = mpb_gpmp2_diag(workspace, nullptr, B, H, D, dt, sigma_start, sigma_gp, sigma_goal, sigma_coll, stream);
+            rc = mpb_gpmp2_diag(workspace, nullptr, B, H, D, n_fields, dt, sigma_start, sigma_gp, sigma_goal, sigma_coll, stream);
             if (rc) return rc;
             const int n = H * 2 * D;
             hipLaunchKernelGGL(gpmp2_scale_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, w.diag_sum,
                                w.diag_mean, n, 1.0 / (double)B);
         }
-        rc = mpb_gpmp2_solve(x, start, goal, nullptr, workspace, costs_out, B, H, D, dt, sigma_start, sigma_gp, sigma_goal,
+        rc = mpb_gpmp2_solve(x, start, goal, nullptr, workspace, costs_out, B, H, D, n_fields, dt, sigma_start, sigma_gp, sigma_goal,
                              sigma_coll, delta, trust_region, step_size, stream);
         if (rc) return rc;
     }

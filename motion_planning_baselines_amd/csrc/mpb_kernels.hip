@@ -41,16 +41,16 @@ static int check_launch(const char* what) {
 extern "C" int mpb_version(void) { return 1; }
 extern "C" const char* mpb_last_error(void) { return g_err; }
 
-extern "C" int mpb_geom_check(const float* g, int n_words) {
-    if (!g || n_words < MPB_GEOM_HEADER_WORDS) return fail(MPB_E_INVALID, "%s: geometry buffer too small", __func__);
+static int geom_check_one(const float* g, int n_words, const char* who) {
+    if (!g || n_words < MPB_GEOM_HEADER_WORDS) return fail(MPB_E_INVALID, "%s: geometry buffer too small", who);
     const int32_t* gi = reinterpret_cast<const int32_t*>(g);
-    if (gi[0] != MPB_GEOM_MAGIC || gi[1] != MPB_GEOM_VERSION) return fail(MPB_E_INVALID, "%s: bad magic/version", __func__);
+    if (gi[0] != MPB_GEOM_MAGIC || gi[1] != MPB_GEOM_VERSION) return fail(MPB_E_INVALID, "%s: bad magic/version", who);
     const int kind = gi[2], n_dof = gi[3], n_tf = gi[4], n_links = gi[5], n_sph = gi[6], n_box = gi[7];
-    if (kind != MPB_KIND_POINT && kind != MPB_KIND_CHAIN) return fail(MPB_E_INVALID, "%s: unknown robot kind", __func__);
-    if (n_dof < 1 || n_dof > MPB_MAX_DOF) return fail(MPB_E_INVALID, "%s: n_dof out of range", __func__);
-    if (kind == MPB_KIND_POINT && (n_dof < 2 || n_dof > 3 || n_links != 1)) return fail(MPB_E_INVALID, "%s: point robot must be 2-D/3-D with one sphere", __func__);
-    if (kind == MPB_KIND_CHAIN && n_tf != n_dof + 1) return fail(MPB_E_INVALID, "%s: chain needs n_dof+1 transforms", __func__);
-    if (n_links < 1 || n_sph < 0 || n_box < 0 || n_sph + n_box < 1) return fail(MPB_E_INVALID, "%s: empty link/obstacle set", __func__);
+    if (kind != MPB_KIND_POINT && kind != MPB_KIND_CHAIN) return fail(MPB_E_INVALID, "%s: unknown robot kind", who);
+    if (n_dof < 1 || n_dof > MPB_MAX_DOF) return fail(MPB_E_INVALID, "%s: n_dof out of range", who);
+    if (kind == MPB_KIND_POINT && (n_dof < 2 || n_dof > 3 || n_links != 1)) return fail(MPB_E_INVALID, "%s: point robot must be 2-D/3-D with one sphere", who);
+    if (kind == MPB_KIND_CHAIN && n_tf != n_dof + 1) return fail(MPB_E_INVALID, "%s: chain needs n_dof+1 transforms", who);
+    if (n_links < 1 || n_sph < 0 || n_box < 0 || n_sph + n_box < 1) return fail(MPB_E_INVALID, "%s: empty link/obstacle set", who);
     const int off_tf = gi[9], off_links = gi[10], off_sph = gi[11], off_box = gi[12], total = gi[13];
     const int off_cull = gi[14], off_fs = gi[15], off_grid = gi[16];
     const int gnx = gi[17], gny = gi[18], gnz = gi[19], n_cells = gi[26];
@@ -60,30 +60,50 @@ extern "C" int mpb_geom_check(const float* g, int n_words) {
     if (off_tf != MPB_GEOM_HEADER_WORDS || off_links != off_tf + 12 * n_tf || off_sph != off_links + 8 * n_links ||
         off_box != off_sph + 4 * n_sph || off_cull != off_box + 8 * n_box || off_fs != off_cull + 8 * n_sph_pad ||
         off_grid != off_fs + n_fs || total != off_grid + (n_cells + 3) / 4 * 4 || total > n_words)
-        return fail(MPB_E_INVALID, "%s: inconsistent section offsets", __func__);
-    if ((off_links | off_sph | off_box | off_cull | off_fs | off_grid) & 3) return fail(MPB_E_INVALID, "%s: sections must be 16-byte aligned", __func__);
+        return fail(MPB_E_INVALID, "%s: inconsistent section offsets", who);
+    if ((off_links | off_sph | off_box | off_cull | off_fs | off_grid) & 3) return fail(MPB_E_INVALID, "%s: sections must be 16-byte aligned", who);
     if (n_cells < 0 || (n_cells > 0 && (gnx < 1 || gny < 1 || gnz < 1 || gnx * gny * gnz != n_cells)))
-        return fail(MPB_E_INVALID, "%s: bad broad-phase grid dims", __func__);
+        return fail(MPB_E_INVALID, "%s: bad broad-phase grid dims", who);
     for (int i = 0; i < n_cells; ++i) {   // every packed obstacle index must exist
         const uint32_t w = (uint32_t)gi[off_grid + i];
         if (w == 0xFFFFFFFEu) continue;
         for (int k = 0; k < 4; ++k) {
             const uint32_t idx = (w >> (8 * k)) & 0xFFu;
-            if (idx != 0xFFu && (int)idx >= n_sph) return fail(MPB_E_INVALID, "%s: grid cell references a missing obstacle", __func__);
+            if (idx != 0xFFu && (int)idx >= n_sph) return fail(MPB_E_INVALID, "%s: grid cell references a missing obstacle", who);
         }
     }
     // frame -> link ranges must be monotone and end at n_links
     for (int j = 0; j < n_frames; ++j)
         if (gi[off_fs + j] < 0 || gi[off_fs + j] > gi[off_fs + j + 1] || gi[off_fs + j + 1] > n_links)
-            return fail(MPB_E_INVALID, "%s: bad frame_start table", __func__);
-    if (gi[off_fs] != 0 || gi[off_fs + n_frames] != n_links) return fail(MPB_E_INVALID, "%s: frame_start must cover all links", __func__);
+            return fail(MPB_E_INVALID, "%s: bad frame_start table", who);
+    if (gi[off_fs] != 0 || gi[off_fs + n_frames] != n_links) return fail(MPB_E_INVALID, "%s: frame_start must cover all links", who);
     int prev = 1;
     for (int l = 0; l < n_links; ++l) {
         const int f = gi[off_links + 8 * l];
-        if (kind == MPB_KIND_CHAIN && (f < prev || f > n_dof + 1)) return fail(MPB_E_INVALID, "%s: link frames must be sorted in [1, n_dof+1]", __func__);
+        if (kind == MPB_KIND_CHAIN && (f < prev || f > n_dof + 1)) return fail(MPB_E_INVALID, "%s: link frames must be sorted in [1, n_dof+1]", who);
         prev = f > prev ? f : prev;
     }
+    if (!(g[28] >= 0.f)) return fail(MPB_E_INVALID, "%s: field scale must be >= 0", who);
     return MPB_OK;
+}
+
+
+extern "C" int mpb_geom_check(const float* g, int n_words) {
+    // a buffer may chain up to MPB_MAX_FIELDS fields: header word 27 = words from this header to the next one
+    int off = 0;
+    for (int f = 0; f < MPB_MAX_FIELDS; ++f) {
+        if (!g || n_words - off < MPB_GEOM_HEADER_WORDS) return fail(MPB_E_INVALID, "%s: geometry buffer too small", __func__);
+        const int rc = geom_check_one(g + off, n_words - off, "mpb_geom_check");
+        if (rc) return rc;
+        const int32_t* gi = reinterpret_cast<const int32_t*>(g + off);
+        if (f > 0 && (gi[2] != reinterpret_cast<const int32_t*>(g)[2] || gi[3] != reinterpret_cast<const int32_t*>(g)[3]))
+            return fail(MPB_E_INVALID, "%s: chained fields must share the robot", __func__);
+        const int next = gi[27];
+        if (next == 0) return MPB_OK;
+        if (next < gi[13] || (next & 3)) return fail(MPB_E_INVALID, "%s: bad offset to the next field", __func__);
+        off += next;
+    }
+    return fail(MPB_E_INVALID, "%s: more than MPB_MAX_FIELDS chained fields", __func__);
 }
 
 #define MPB_MAX_D (2 * MPB_MAX_DOF)
@@ -255,22 +275,25 @@ __global__ __launch_bounds__(256, 4) void stomp_sample_cost_h64_kernel(
     (void)srow;
     MPB_STAMP(5);
     if (WITH_COST) {
-        const GeomView G = geom_view(geom);
         float q[MPB_MAX_DOF], dq[MPB_MAX_DOF];
 #pragma unroll
         for (int i = 0; i < MPB_MAX_DOF; ++i) q[i] = (i < DCH) ? x[i < DCH ? i : 0] : 0.f;
         float c = 0.f;
-        if (grid_usable(G)) {
-            // the permuted-L image is dead: its 16 KB now hold the broad-phase grid (all waves of the block
-            // take this branch together: G is wave- and block-uniform)
-            unsigned* gridw = reinterpret_cast<unsigned*>(Lp);
-            __syncthreads();
-            grid_stage(G, gridw, otab, threadIdx.x, 256);
-            __syncthreads();
-            MPB_STAMP(6);
-            if (live && h >= 1) c = waypoint_cost_grid(G, gridw, otab, q);
-        } else if (live && h >= 1) {
-            c = waypoint_cost<false>(G, q, dq);
+        // one pass per chained collision field (the reference sums one CostCollision per field)
+        for (const float* gp = geom; gp != nullptr; gp = geom_next(gp)) {
+            const GeomView G = geom_view(gp);
+            if (grid_usable(G)) {
+                // the permuted-L image is dead: its 16 KB now hold the broad-phase grid (all waves of the block
+                // take this branch together: G is wave- and block-uniform)
+                unsigned* gridw = reinterpret_cast<unsigned*>(Lp);
+                __syncthreads();
+                grid_stage(G, gridw, otab, threadIdx.x, 256);
+                __syncthreads();
+                MPB_STAMP(6);
+                if (live && h >= 1) c = fmaf(G.fscale, waypoint_cost_grid(G, gridw, otab, q), c);
+            } else if (live && h >= 1) {
+                c = fmaf(G.fscale, waypoint_cost<false>(G, q, dq), c);
+            }
         }
         const double csum = wave_sum_f64((double)c);
         if (live && lane == 0) costs[r] = weight * (k_sigma * (float)csum);
@@ -410,21 +433,23 @@ __global__ __launch_bounds__(256) void stomp_sample_cost_hx_kernel(
         }
     }
     if (WITH_COST) {
-        const GeomView G = geom_view(geom);
         float c = 0.f;
-        const bool use_grid = grid_usable(G);
         unsigned* gridw = reinterpret_cast<unsigned*>(Lp);
-        if (use_grid) {
-            __syncthreads();
-            grid_stage(G, gridw, otab, threadIdx.x, 256);
-            __syncthreads();
-        }
+        for (const float* gp = geom; gp != nullptr; gp = geom_next(gp)) {
+            const GeomView G = geom_view(gp);
+            const bool use_grid = grid_usable(G);
+            if (use_grid) {
+                __syncthreads();
+                grid_stage(G, gridw, otab, threadIdx.x, 256);
+                __syncthreads();
+            }
 #pragma unroll
-        for (int hc = 0; hc < M; ++hc) {
-            const int h = 64 * hc + lane;
-            if (hc < Mc && live && h >= 1 && h < H) {
-                float dq[MPB_MAX_DOF];
-                c += use_grid ? waypoint_cost_grid(G, gridw, otab, q[hc]) : waypoint_cost<false>(G, q[hc], dq);
+            for (int hc = 0; hc < M; ++hc) {
+                const int h = 64 * hc + lane;
+                if (hc < Mc && live && h >= 1 && h < H) {
+                    float dq[MPB_MAX_DOF];
+                    c = fmaf(G.fscale, use_grid ? waypoint_cost_grid(G, gridw, otab, q[hc]) : waypoint_cost<false>(G, q[hc], dq), c);
+                }
             }
         }
         const double csum = wave_sum_f64((double)c);
@@ -615,35 +640,58 @@ __global__ __launch_bounds__(256) void collision_cost_kernel(
     float weight) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const GeomView G = geom_view(geom);
-    const int D = G.n_dof;
+    const int D = reinterpret_cast<const int*>(geom)[3];
     __shared__ unsigned gridw[GRAD ? 1 : MPB_GRID_MAX_CELLS];
     __shared__ float4 otab[GRAD ? 1 : MPB_GRID_MAX_SPH + 1];
-    const bool use_grid = !GRAD && grid_usable(G);
-    if (use_grid) {
-        grid_stage(G, gridw, otab, threadIdx.x, blockDim.x);
-        __syncthreads();
-    }
-    if (b >= B) return;
+    const bool dead = b >= B;                                  // such waves still take part in the block barriers
     double csum = 0.0;
-    for (int h = lane; h < ((H + 63) & ~63); h += 64) {
-        float c = 0.f;
-        if (h < H) {
-            const float* row = trajs + ((size_t)b * H + h) * d;
-            float q[MPB_MAX_DOF], dq[MPB_MAX_DOF];
+    if (GRAD) {
+        // gradient path: exhaustive evaluator, all chained fields per waypoint
+        if (dead) return;
+        for (int h = lane; h < ((H + 63) & ~63); h += 64) {
+            float c = 0.f;
+            if (h < H) {
+                const float* row = trajs + ((size_t)b * H + h) * d;
+                float q[MPB_MAX_DOF], dq[MPB_MAX_DOF];
 #pragma unroll
-            for (int i = 0; i < MPB_MAX_DOF; ++i) q[i] = (i < D) ? row[i] : 0.f;
-            if (h >= h_begin) c = use_grid ? waypoint_cost_grid(G, gridw, otab, q) : waypoint_cost<GRAD>(G, q, dq);
-            if (per_wp) per_wp[(size_t)b * H + h] = c;
-            if (GRAD) {
+                for (int i = 0; i < MPB_MAX_DOF; ++i) q[i] = (i < D) ? row[i] : 0.f;
+                if (h >= h_begin) c = waypoint_cost_chain<true>(geom, q, dq);
+                if (per_wp) per_wp[(size_t)b * H + h] = c;
                 float* grow = grad + ((size_t)b * H + h) * d;
                 const float sc = weight * k_sigma;
 #pragma unroll
                 for (int i = 0; i < MPB_MAX_D; ++i)
                     if (i < d) grow[i] = (i < MPB_MAX_DOF && i < D && h >= h_begin) ? sc * dq[i < MPB_MAX_DOF ? i : 0] : 0.f;
             }
+            csum += (double)c;
         }
-        csum += (double)c;
+    } else {
+        // cost path: one pass over the trajectory per chained field (its broad-phase grid is staged in LDS)
+        const bool multi = geom_next(geom) != nullptr;
+        for (const float* gp = geom; gp != nullptr; gp = geom_next(gp)) {
+            const GeomView G = geom_view(gp);
+            const bool use_grid = grid_usable(G);
+            __syncthreads();
+            if (use_grid) grid_stage(G, gridw, otab, threadIdx.x, blockDim.x);
+            __syncthreads();
+            if (dead) continue;
+            for (int h = lane; h < ((H + 63) & ~63); h += 64) {
+                float c = 0.f;
+                if (h < H) {
+                    const float* row = trajs + ((size_t)b * H + h) * d;
+                    float q[MPB_MAX_DOF], dq[MPB_MAX_DOF];
+#pragma unroll
+                    for (int i = 0; i < MPB_MAX_DOF; ++i) q[i] = (i < D) ? row[i] : 0.f;
+                    if (h >= h_begin) c = G.fscale * (use_grid ? waypoint_cost_grid(G, gridw, otab, q) : waypoint_cost<false>(G, q, dq));
+                    if (per_wp) {
+                        float* pw = per_wp + (size_t)b * H + h;
+                        *pw = (multi && gp != geom) ? *pw + c : c;
+                    }
+                }
+                csum += (double)c;
+            }
+        }
+        if (dead) return;
     }
     csum = wave_sum_f64(csum);
     if (lane == 0) out[b] = weight * (k_sigma * (float)csum);
@@ -663,7 +711,6 @@ __global__ __launch_bounds__(256) void chomp_kernel(float* __restrict__ means, c
     const int b = blockIdx.x;
     const int h = threadIdx.x;
     const bool active = h < H;
-    const GeomView G = geom_view(geom);
     float x[MPB_MAX_D];
     float* row = means + ((size_t)b * H + (active ? h : 0)) * d;
 #pragma unroll
@@ -689,7 +736,7 @@ __global__ __launch_bounds__(256) void chomp_kernel(float* __restrict__ means, c
             float q[MPB_MAX_DOF];
 #pragma unroll
             for (int i = 0; i < MPB_MAX_DOF; ++i) q[i] = x[i];
-            cw = waypoint_cost<true>(G, q, dq);
+            cw = waypoint_cost_chain<true>(geom, q, dq);
         } else {
 #pragma unroll
             for (int i = 0; i < MPB_MAX_DOF; ++i) dq[i] = 0.f;

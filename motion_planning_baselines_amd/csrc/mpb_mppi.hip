@@ -80,8 +80,6 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
     const int prob = blockIdx.x;
     float* m = mean + (size_t)prob * T * c;
     const float w_pos = cw[0], w_ctrl = cw[2], w_posT = cw[3];
-    GeomView G;
-    if (geom != nullptr) G = geom_view(geom);
     if (tril_in_lds) {
         for (int e = threadIdx.x; e < c * T * T; e += blockDim.x) {       // coalesced read, transposed write
             const int i = e / (T * T), r = e - i * T * T, t = r / T, k = r - t * T;
@@ -189,7 +187,7 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
                         float q[MPB_MAX_DOF], dq[MPB_MAX_DOF];
 #pragma unroll
                         for (int i = 0; i < MPB_MAX_DOF; ++i) q[i] = (i < MPPI_MAX_C && i < c) ? x[i < MPPI_MAX_C ? i : 0] : 0.f;
-                        coll_l += waypoint_cost<false>(G, q, dq);
+                        coll_l += waypoint_cost_chain<false>(geom, q, dq);
                     }
                     if (last) {                                 // API-visible outputs of the last iteration
                         float* Ug = controls + (((size_t)prob * S + s) * T + t) * c;

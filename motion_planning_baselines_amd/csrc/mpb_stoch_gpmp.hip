@@ -26,13 +26,28 @@ __global__ __launch_bounds__(256) void stoch_gpmp_cost_kernel(const float* __res
     __shared__ float4 otab[MPB_GRID_MAX_SPH + 1];
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // sample index p*S + s
-    const GeomView G = geom_view(geom);
-    const bool use_grid = grid_usable(G);
-    if (use_grid) {
-        grid_stage(G, gridw, otab, threadIdx.x, blockDim.x);
+    const bool dead = r >= P * S;            // such waves still take part in the block barriers below
+    const int Dq = D;
+    // ---- collision (waypoint 0 excluded): one pass per chained field, its broad-phase grid staged in LDS
+    double acc = 0.0;
+    for (const float* gp = geom; gp != nullptr; gp = geom_next(gp)) {
+        const GeomView G = geom_view(gp);
+        const bool use_grid = grid_usable(G);
         __syncthreads();
+        if (use_grid) grid_stage(G, gridw, otab, threadIdx.x, blockDim.x);
+        __syncthreads();
+        if (dead) continue;
+        const float* xs0 = samples + (size_t)r * H * 2 * Dq;
+        for (int t = lane + 0; t < H; t += 64) {
+            if (t < 1) continue;
+            float q[MPB_MAX_DOF], dq[MPB_MAX_DOF];
+#pragma unroll
+            for (int i = 0; i < MPB_MAX_DOF; ++i) q[i] = (i < Dq) ? xs0[t * 2 * Dq + i] : 0.f;
+            const float c = use_grid ? waypoint_cost_grid(G, gridw, otab, q) : waypoint_cost<false>(G, q, dq);
+            acc += (double)K.kc * (double)(G.fscale * c);
+        }
     }
-    if (r >= P * S) return;
+    if (dead) return;
     const int p = r / S;
     const int dim = 2 * D;
     const float dt = K.dt;
@@ -40,19 +55,10 @@ __global__ __launch_bounds__(256) void stoch_gpmp_cost_kernel(const float* __res
     const float* us = means + (size_t)p * H * dim;
     // Qi = [[12/dt^3, -6/dt^2],[-6/dt^2, 4/dt]] (gp_factor.py:42-50), scaled per use
     const double qa = 12.0 / ((double)dt * dt * dt), qb = -6.0 / ((double)dt * dt), qc = 4.0 / (double)dt;
-    double acc = 0.0;
     for (int t = lane; t < ((H + 63) & ~63); t += 64) {
         if (t >= H) continue;
         const float* x0 = xs + t * dim;
         const float* u0 = us + t * dim;
-        // collision (waypoint 0 excluded)
-        if (t >= 1) {
-            float q[MPB_MAX_DOF], dq[MPB_MAX_DOF];
-#pragma unroll
-            for (int i = 0; i < MPB_MAX_DOF; ++i) q[i] = (i < D) ? x0[i] : 0.f;
-            const float c = use_grid ? waypoint_cost_grid(G, gridw, otab, q) : waypoint_cost<false>(G, q, dq);
-            acc += (double)K.kc * (double)c;
-        }
         for (int i = 0; i < D; ++i) {
             const double xp = x0[i], xv = x0[D + i], up = u0[i], uv = u0[D + i];
             if (t == 0) {   // start prior (unary_factor.py:24) and its bilinear twin

@@ -26,7 +26,8 @@ import numpy as np
 import torch
 
 GEOM_MAGIC = 0x4D504247  # 'MPBG'
-GEOM_VERSION = 3
+GEOM_VERSION = 4
+MAX_FIELDS = 4           # collision fields chained in one buffer (csrc/mpb_geom.h MPB_MAX_FIELDS)
 GEOM_HEADER_WORDS = 32
 GRID_MAX_DIM = 16       # cells per axis of the broad-phase grid (<= 4096 cells = 16 KB of LDS)
 GRID_CELL = 0.14        # target cell edge [m]
@@ -266,15 +267,21 @@ def build_grid(spheres, a_max, slack=1e-4):
                 stats=dict(mean=float(counts.mean()), max=int(counts.max()), overflow=int((counts > 4).sum())))
 
 
-def pack_geometry(robot, field):
-    """Pack robot + field into the flat fp32 word buffer the HIP kernels read.
+def pack_geometry(robot, field, scales=None):
+    """Pack robot + collision field(s) into the flat fp32 word buffer the HIP kernels read.
+
+    `field` may be a list of up to MAX_FIELDS CollisionFields (the reference builds one CostCollision per field,
+    gpmp2.py:70-78, and sums them): the per-field buffers are chained, header word [27] of each holding the word
+    offset to the next one (0 = last) and word [28] a per-field scale s_f -- every kernel evaluates
+    sum_f s_f * cost_f(q) (and its gradient) by walking the chain.
 
     Layout (32-bit words; ints stored bit-exact), mirrored by csrc/mpb_geom.h:
       [0] magic [1] version [2] kind [3] n_dof [4] n_frames_tf (0 or n_dof+1) [5] n_links
       [6] n_spheres [7] n_boxes [8] margin(f32) [9] off_tf [10] off_links [11] off_spheres
       [12] off_boxes [13] total_words [14] off_cull [15] off_frame_start
       [16] off_grid [17..19] grid dims nx,ny,nz [20..22] grid origin (f32) [23..25] 1/cell size (f32)
-      [26] n_cells (0: no grid) [27..31] reserved
+      [26] n_cells (0: no grid) [27] words to the next chained field (0: none) [28] field scale s_f (f32)
+      [29..31] reserved
       joint_tf    : n_frames_tf x 12   (row-major 3x4)
       links       : n_links x 8        (frame:int, ox, oy, oz, radius, 0, 0, 0)
       spheres     : n_spheres x 4      (cx, cy, cz, r)
@@ -290,6 +297,15 @@ def pack_geometry(robot, field):
                     A collision sphere at x can only be within its hinge threshold of the obstacles listed
                     in the cell containing x (none outside the grid), so per-LANE culling is exact.
     """
+    if isinstance(field, (list, tuple)):
+        fields = list(field)
+        assert 1 <= len(fields) <= MAX_FIELDS, f'1..{MAX_FIELDS} collision fields per geometry buffer'
+        scales = [1.0] * len(fields) if scales is None else [float(v) for v in scales]
+        assert len(scales) == len(fields)
+        parts = [pack_geometry(robot, f, scales=[sc]) for f, sc in zip(fields, scales)]
+        for i, part in enumerate(parts[:-1]):
+            part.view(np.int32)[27] = part.size
+        return np.concatenate(parts)
     rs, fs = robot.spec(), field.spec()
     n_tf = rs['joint_tf'].shape[0]
     n_links = len(rs['link_radius'])
@@ -357,7 +373,19 @@ def pack_geometry(robot, field):
     else:
         fstart[0], fstart[1:] = 0, n_links
     ibuf[off_fs:off_grid] = fstart
+    ibuf[27] = 0
+    buf[28] = 1.0 if scales is None else float(scales[0])
     return buf
+
+
+def count_fields(packed):
+    """Number of chained fields in a packed geometry buffer."""
+    gi = np.asarray(packed).view(np.int32)
+    n, off = 1, 0
+    while gi[off + 27] != 0:
+        off += int(gi[off + 27])
+        n += 1
+    return n
 
 
 # ----------------------------------------------------------------------------------------------

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .geometry import pack_geometry
+from .geometry import count_fields, pack_geometry
 
 
 def _stream():
@@ -38,12 +38,14 @@ def _chk(t, shape, name, allow_none=False):
 class DeviceGeometry:
     """Packed robot + field geometry resident in HBM (one small fp32 buffer)."""
 
-    def __init__(self, robot, field, device):
+    def __init__(self, robot, field, device, scales=None):
+        """`field`: one CollisionField or a list of up to 4 (evaluated as sum_f scales[f] * cost_f)."""
         self.robot, self.field = robot, field
-        host = pack_geometry(robot, field)
+        host = pack_geometry(robot, field, scales=scales)
         _lib.geom_check(host)
         self.host = host
         self.n_dof = robot.q_dim
+        self.n_fields = count_fields(host)
         self.buf = torch.from_numpy(host.copy()).to(device)
 
     @classmethod
@@ -54,6 +56,7 @@ class DeviceGeometry:
         self.robot = self.field = None
         self.host = host
         self.n_dof = int(host.view(np.int32)[3])
+        self.n_fields = count_fields(host)
         self.buf = torch.from_numpy(host.copy()).to(device)
         return self
 
@@ -241,7 +244,7 @@ def gpmp2_step(x, start, goal, geom, workspace, sigmas, dt, delta, trust_region,
     _lib.check(_lib.lib().mpb_gpmp2_step(
         _ptr(x), _ptr(start), _ptr(goal), _ptr(geom.buf), _ptr(workspace), _ptr(costs_out), B, H, D, float(dt),
         float(sigmas[0]), float(sigmas[1]), float(sigmas[2]), float(sigmas[3]), float(delta), int(bool(trust_region)),
-        float(step_size), int(n_iters), int(n_interp or 0), _stream()), 'mpb_gpmp2_step')
+        float(step_size), int(n_iters), int(n_interp or 0), int(geom.n_fields), _stream()), 'mpb_gpmp2_step')
 
 
 def gpmp2_linearize(x, geom, workspace, n_interp=0):
@@ -251,15 +254,16 @@ def gpmp2_linearize(x, geom, workspace, n_interp=0):
                                               int(n_interp or 0), _stream()), 'mpb_gpmp2_linearize')
 
 
-def gpmp2_diag(workspace, B, H, D, sigmas, dt):
+def gpmp2_diag(workspace, B, H, D, sigmas, dt, n_fields=1):
     """Local SUM over particles of diag(A^T K A) as an (H*2D,) fp64 tensor."""
     out = torch.empty(H * 2 * D, dtype=torch.float64, device=workspace.device)
-    _lib.check(_lib.lib().mpb_gpmp2_diag(_ptr(workspace), _ptr(out), B, H, D, float(dt), float(sigmas[0]),
+    _lib.check(_lib.lib().mpb_gpmp2_diag(_ptr(workspace), _ptr(out), B, H, D, int(n_fields), float(dt), float(sigmas[0]),
                                         float(sigmas[1]), float(sigmas[2]), float(sigmas[3]), _stream()), 'mpb_gpmp2_diag')
     return out
 
 
-def gpmp2_solve(x, start, goal, diag_mean, workspace, sigmas, dt, delta, trust_region, step_size, costs_out=None):
+def gpmp2_solve(x, start, goal, diag_mean, workspace, sigmas, dt, delta, trust_region, step_size, costs_out=None,
+                n_fields=1):
     B, H, dim = x.shape
     _chk(x, (B, H, dim), 'x')
     _chk(start, (B, dim), 'start')
@@ -267,8 +271,8 @@ def gpmp2_solve(x, start, goal, diag_mean, workspace, sigmas, dt, delta, trust_r
     if diag_mean is not None:
         assert diag_mean.dtype == torch.float64 and diag_mean.is_cuda and diag_mean.numel() == H * dim
     _lib.check(_lib.lib().mpb_gpmp2_solve(
-        _ptr(x), _ptr(start), _ptr(goal), _ptr(diag_mean), _ptr(workspace), _ptr(costs_out), B, H, dim // 2, float(dt),
-        float(sigmas[0]), float(sigmas[1]), float(sigmas[2]), float(sigmas[3]), float(delta), int(bool(trust_region)),
+        _ptr(x), _ptr(start), _ptr(goal), _ptr(diag_mean), _ptr(workspace), _ptr(costs_out), B, H, dim // 2, int(n_fields),
+        float(dt), float(sigmas[0]), float(sigmas[1]), float(sigmas[2]), float(sigmas[3]), float(delta), int(bool(trust_region)),
         float(step_size), _stream()), 'mpb_gpmp2_solve')
 
 

@@ -379,36 +379,83 @@ class CostComposite(Cost):
             o += m
         return A, b, K
 
+    def collision_terms(self):
+        """[(CostCollision, weight)] of the members that carry a field."""
+        return [(c, float(w)) for c, w in zip(self.cost_l, self.weight_cost_l)
+                if isinstance(c, CostCollision) and c.field is not None]
+
     def single_collision_term(self):
-        """(CostCollision, weight) if this composite is exactly one collision field -- the case the
-        planner kernels fuse; None otherwise."""
-        if len(self.cost_l) == 1 and isinstance(self.cost_l[0], CostCollision) and self.cost_l[0].field is not None:
-            return self.cost_l[0], float(self.weight_cost_l[0])
+        """(collision evaluator, weight) if this composite consists of collision fields only (1..4 of them) -- the
+        case the planner kernels fuse; None otherwise."""
+        terms = self.collision_terms()
+        if not terms or len(terms) != len(self.cost_l):
+            return None
+        return merge_collision_terms(terms)
+
+
+class MergedCollision:
+    """Several CostCollision members (same robot) as ONE chained geometry buffer: the kernels evaluate
+    weight * k_sigma * sum_f s_f cost_f with k_sigma, weight of the first member and
+    s_f = (w_f k_f) / (w_0 k_0).  Quacks like CostCollision where the planners need it."""
+
+    def __init__(self, terms):
+        (c0, w0) = terms[0]
+        assert all(c.robot is c0.robot for c, _ in terms), 'collision members must share the robot'
+        self.robot = c0.robot
+        self.fields = [c.field for c, _ in terms]
+        self.k_sigma = c0.k_sigma
+        self.weight = w0
+        self.scales = [(w * c.k_sigma) / (w0 * c0.k_sigma) for c, w in terms]
+        self._geom = None
+
+    def device_geometry(self, device):
+        if self._geom is None or self._geom.buf.device != torch.device(device):
+            self._geom = ops.DeviceGeometry(self.robot, self.fields, device, scales=self.scales)
+        return self._geom
+
+
+def merge_collision_terms(terms):
+    """[(CostCollision, weight)] -> (evaluator with device_geometry / k_sigma, weight) or None (too many fields)."""
+    if len(terms) == 1:
+        return terms[0]
+    if len(terms) > 4 or terms[0][1] == 0:
         return None
+    m = MergedCollision(terms)
+    return m, m.weight
 
 
 def fusable_collision(cost):
-    """Return (CostCollision, weight) when `cost` is a collision cost the kernels can fuse, else None."""
+    """Return (collision evaluator, weight) when `cost` is a collision cost the kernels can fuse, else None."""
     if isinstance(cost, CostCollision) and cost.field is not None:
         return cost, 1.0
     if isinstance(cost, CostComposite):
-        return cost.single_collision_term()
+        key = tuple((id(c), float(w)) for c, w in zip(cost.cost_l, cost.weight_cost_l))
+        cached = cost.__dict__.get('_fused_cache')
+        if cached is None or cached[0] != key:
+            cost.__dict__['_fused_cache'] = (key, cost.single_collision_term())
+        return cost.__dict__['_fused_cache'][1]
     return None
 
 
 def device_plan(cost, device):
-    """(collision member or None, its weight, merged trajectory-term specs) when every member of `cost` is
-    served by the HIP library and at most one collision field is involved -- the case a planner can run
-    as sample kernel -> term kernel -> update kernel with no host round trip; None otherwise."""
+    """(collision evaluator or None, its weight, merged trajectory-term specs) when every member of `cost` is
+    served by the HIP library (collision fields -- up to four, chained -- and trajectory-only terms): the case a
+    planner can run as sample kernel -> term kernel -> update kernel with no host round trip; None otherwise."""
     if isinstance(cost, CostComposite):
+        key = ('plan', str(device)) + tuple((id(c), float(w)) for c, w in zip(cost.cost_l, cost.weight_cost_l))
+        cached = cost.__dict__.get('_plan_cache')
+        if cached is not None and cached[0] == key:
+            return cached[1]
         coll, groups, other = cost.device_plan(device)
-    elif isinstance(cost, CostCollision):
-        coll, groups, other = ([(cost, 1.0)] if cost.field is not None else []), [], []
-    elif isinstance(cost, _TrajectoryTermCost):
-        coll, groups, other = [], _merge_term_specs([(cost.term_spec(device), 1.0)]), []
-    else:
-        return None
-    if other or len(coll) > 1 or (not coll and not groups):
-        return None
-    cc, w = coll[0] if coll else (None, 0.0)
-    return cc, w, groups
+        plan = None
+        if not other and (coll or groups):
+            merged = merge_collision_terms(coll) if coll else (None, 0.0)
+            if merged is not None:
+                plan = (merged[0], merged[1], groups)
+        cost.__dict__['_plan_cache'] = (key, plan)
+        return plan
+    if isinstance(cost, CostCollision):
+        return (cost, 1.0, []) if cost.field is not None else None
+    if isinstance(cost, _TrajectoryTermCost):
+        return None, 0.0, _merge_term_specs([(cost.term_spec(device), 1.0)])
+    return None

@@ -18,7 +18,8 @@ class GPMP2(OptimizationPlanner):
     sigma_goal_prior).
 
     Differences, all forced by the hot path living on the GPU:
-      * ``collision_fields`` must hold exactly one CollisionField (the fused kernels evaluate one field);
+      * ``collision_fields`` holds one to four CollisionFields (chained in one geometry buffer, one block of
+        collision rows per field like the reference);
       * ``solver_params['method']`` must be 'cholesky' (the reference's other methods solve the same system);
       * extra kwarg ``process_group``: when given, the trust-region damping's batch mean (quirk Q9,
         gpmp2.py:361-367) is all-reduced over the group so that sharded runs equal the unsharded one.
@@ -41,8 +42,8 @@ class GPMP2(OptimizationPlanner):
         # collision Jacobian (cost_functions.py:115-119) only runs when a caller sets the attribute afterwards.
         # Same here: the ctor argument is ignored, the attribute is honoured by _step.
         self.n_interpolated_points = None
-        if not collision_fields or len(collision_fields) != 1:
-            raise NotImplementedError('GPMP2 on the GPU takes exactly one CollisionField')
+        if not collision_fields or len(collision_fields) > 4:
+            raise NotImplementedError('GPMP2 on the GPU takes one to four CollisionFields')
         solver_params = solver_params or dict(delta=1e-2, trust_region=True, method='cholesky')
         if solver_params.get('method', 'cholesky') != 'cholesky':
             raise NotImplementedError("solver_params['method'] must be 'cholesky'")
@@ -56,7 +57,7 @@ class GPMP2(OptimizationPlanner):
         self.N = self.d_state_opt * n_support_points
         self.sigmas = (sigma_start, sigma_gp, sigma_goal_prior, sigma_coll)
         self.process_group = process_group
-        self.geom = ops.DeviceGeometry(robot, collision_fields[0], self.device)
+        self.geom = ops.DeviceGeometry(robot, list(collision_fields), self.device)   # one CostCollision per field (gpmp2.py:70-78)
         self.costs = None
         self._ws = None
         self.reset(initial_particle_means=initial_particle_means)
@@ -98,12 +99,12 @@ class GPMP2(OptimizationPlanner):
         x = self._particle_means
         if trust and self.process_group is not None and dist.get_world_size(self.process_group) > 1:
             ops.gpmp2_linearize(x, self.geom, self._ws, n_interp=self.n_interpolated_points)
-            dsum = ops.gpmp2_diag(self._ws, B, H, D, self.sigmas, self.dt)
+            dsum = ops.gpmp2_diag(self._ws, B, H, D, self.sigmas, self.dt, n_fields=self.geom.n_fields)
             nb = torch.tensor([float(B)], device=self.device, dtype=torch.float64)
             dist.all_reduce(dsum, group=self.process_group)     # one H*2D fp64 vector per iteration
             dist.all_reduce(nb, group=self.process_group)
             ops.gpmp2_solve(x, self._start, self._goal, dsum / nb, self._ws, self.sigmas, self.dt, delta, True,
-                            self.step_size, costs_out=self.costs)
+                            self.step_size, costs_out=self.costs, n_fields=self.geom.n_fields)
         else:
             ops.gpmp2_step(x, self._start, self._goal, self.geom, self._ws, self.sigmas, self.dt, delta, trust,
                            self.step_size, n_iters=1, costs_out=self.costs, n_interp=self.n_interpolated_points)

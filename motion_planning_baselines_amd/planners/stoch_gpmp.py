@@ -14,7 +14,7 @@ from .base import OptimizationPlanner, gp_prior_factor
 
 class StochGPMP(OptimizationPlanner):
     """Drop-in for mp_baselines.planners.stoch_gpmp.StochGPMP (ctor kwargs stoch_gpmp.py:16-38 plus the cost
-    kwargs of build_gpmp2_cost_composite: collision_fields (exactly one), sigma_start, sigma_gp, sigma_coll,
+    kwargs of build_gpmp2_cost_composite: collision_fields (one to four), sigma_start, sigma_gp, sigma_coll,
     sigma_goal_prior).  Extra kwargs: noise 'torch_cpu' | 'philox', seed."""
 
     def __init__(self, robot=None, n_dof=None, n_support_points=None, num_particles_per_goal=None, opt_iters=None,
@@ -29,8 +29,8 @@ class StochGPMP(OptimizationPlanner):
                          multi_goal_states=multi_goal_states, sigma_start_init=sigma_start_init,
                          sigma_goal_init=sigma_goal_init, sigma_gp_init=sigma_gp_init, pos_only=False,
                          tensor_args=tensor_args)
-        if not collision_fields or len(collision_fields) != 1:
-            raise NotImplementedError('StochGPMP on the GPU takes exactly one CollisionField')
+        if not collision_fields or len(collision_fields) > 4:
+            raise NotImplementedError('StochGPMP on the GPU takes one to four CollisionFields')
         assert multi_goal_states is not None, 'StochGPMP kernels need goal states'
         self.robot = robot
         self.d_state_opt = 2 * n_dof
@@ -40,7 +40,7 @@ class StochGPMP(OptimizationPlanner):
         self.sig_sample = (sigma_start_sample, sigma_gp_sample, sigma_goal_sample)
         self.sig_cost = (sigma_start, sigma_gp, sigma_goal_prior, sigma_coll)
         self.noise, self.seed, self._iter = noise, int(seed), 0
-        self.geom = ops.DeviceGeometry(robot, collision_fields[0], self.device)
+        self.geom = ops.DeviceGeometry(robot, list(collision_fields), self.device)
         H, D = n_support_points, n_dof
         Ud, Uo = gp_prior_factor(H, dt, sigma_start_sample, sigma_gp_sample, sigma_goal_sample)
         f64 = lambda a: torch.as_tensor(a, dtype=torch.float64).to(self.device).contiguous()

@@ -273,22 +273,30 @@ def gpmp2_linear_system(x, robot, field, start_state, goal_state, D, dt,
     A2[:, :, -dim:] = I
     b2 = (goal_state - x[:, -1]).reshape(B, dim, 1)
     K2 = (I / sigma_goal ** 2).expand(B, dim, dim)
-    # ---- collision (cost_functions.py:191-231)
-    xg = x.detach().clone().requires_grad_(True)
-    q_pos = robot.get_position(xg)
-    link_pos = robot.fk_map_collision(q_pos)
-    err = field.compute_cost(q_pos[:, 1:], link_pos[:, 1:]).reshape(B, H - 1)
-    err_j = err
-    if n_interp:        # Jacobian of the INTERPOLATED trajectory's error w.r.t. the support points; b keeps
-        xi = interpolate_trajs(xg, n_interp)                                      # the support-point error
-        qi = robot.get_position(xi)                                               # (field_factor.py:42-54,
-        err_j = field.compute_cost(qi[:, 1:], robot.fk_map_collision(qi)[:, 1:])  #  cost_functions.py:115-119)
-    Hobst = -torch.autograd.grad(err_j.sum(), xg)[0][:, 1:, :D]                   # field_factor.py:54
-    A3 = torch.zeros(B, H - 1, N, **tensor_args)
-    for i in range(H - 1):
-        A3[:, i, (i + 1) * dim:(i + 1) * dim + D] = Hobst[:, i]
-    b3 = err.detach().unsqueeze(-1)
-    K3 = (torch.eye(H - 1, **tensor_args) / sigma_coll ** 2).expand(B, H - 1, H - 1)
+    # ---- collision (cost_functions.py:191-231): one block of H-1 rows per collision field (gpmp2.py:70-78)
+    fields = list(field) if isinstance(field, (list, tuple)) else [field]
+    A3s, b3s, K3s = [], [], []
+    for fld in fields:
+        xg = x.detach().clone().requires_grad_(True)
+        q_pos = robot.get_position(xg)
+        link_pos = robot.fk_map_collision(q_pos)
+        err = fld.compute_cost(q_pos[:, 1:], link_pos[:, 1:]).reshape(B, H - 1)
+        err_j = err
+        if n_interp:        # Jacobian of the INTERPOLATED trajectory's error w.r.t. the support points; b keeps
+            xi = interpolate_trajs(xg, n_interp)                                      # the support-point error
+            qi = robot.get_position(xi)                                               # (field_factor.py:42-54,
+            err_j = fld.compute_cost(qi[:, 1:], robot.fk_map_collision(qi)[:, 1:])    #  cost_functions.py:115-119)
+        Hobst = -torch.autograd.grad(err_j.sum(), xg)[0][:, 1:, :D]                   # field_factor.py:54
+        A3f = torch.zeros(B, H - 1, N, **tensor_args)
+        for i in range(H - 1):
+            A3f[:, i, (i + 1) * dim:(i + 1) * dim + D] = Hobst[:, i]
+        A3s.append(A3f)
+        b3s.append(err.detach().unsqueeze(-1))
+        K3s.append((torch.eye(H - 1, **tensor_args) / sigma_coll ** 2).expand(B, H - 1, H - 1))
+    A3, b3 = torch.cat(A3s, 1), torch.cat(b3s, 1)
+    K3 = torch.zeros(B, A3.shape[1], A3.shape[1], **tensor_args)
+    for i, Kf in enumerate(K3s):
+        K3[:, i * (H - 1):(i + 1) * (H - 1), i * (H - 1):(i + 1) * (H - 1)] = Kf
     A = torch.cat([A1, A2, A3], 1)
     b = torch.cat([b1, b2, b3], 1)
     M = A.shape[1]

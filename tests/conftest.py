@@ -28,6 +28,11 @@ def ref_geometry_from_golden(g, dtype=torch.float32):
     robot = RefRobot(spec, tensor_args=ta)
     field = RefCollisionField(dict(spheres=g['spheres'], boxes=g['boxes'], margin=g['margin']),
                               g['link_radius'], tensor_args=ta)
+    n_extra = int(g['n_extra_fields']) if 'n_extra_fields' in g else 0
+    if n_extra:       # goldens with several collision fields: a list, first field first
+        field = [field] + [RefCollisionField(dict(spheres=g[f'extra{i}_spheres'], boxes=g[f'extra{i}_boxes'],
+                                                  margin=g[f'extra{i}_margin']), g['link_radius'], tensor_args=ta)
+                           for i in range(n_extra)]
     return robot, field
 
 
@@ -42,6 +47,11 @@ def product_geometry_from_golden(g):
                                    q_min=[-3.2] * D, q_max=[3.2] * D)
     field = G.CollisionField(spheres=g['spheres'] if len(g['spheres']) else None,
                              boxes=g['boxes'] if len(g['boxes']) else None, margin=float(g['margin']))
+    n_extra = int(g['n_extra_fields']) if 'n_extra_fields' in g else 0
+    if n_extra:
+        field = [field] + [G.CollisionField(spheres=g[f'extra{i}_spheres'] if len(g[f'extra{i}_spheres']) else None,
+                                            boxes=g[f'extra{i}_boxes'] if len(g[f'extra{i}_boxes']) else None,
+                                            margin=float(g[f'extra{i}_margin'])) for i in range(n_extra)]
     return robot, field
 
 

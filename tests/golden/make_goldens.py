@@ -161,9 +161,10 @@ def gen_chomp(name, robot, field, starts, goals, H, dt, sigma_coll, weight, iter
 
 
 def gen_gpmp2(name, robot, field, start, goal, B, H, dt, iters, seed, ta, sig=None, delta=1e-2,
-              trust_region=True, step_size=1.0, init_noise=0.02, n_interp=None):
+              trust_region=True, step_size=1.0, init_noise=0.02, n_interp=None, extra_fields=()):
     sig = sig or dict(sigma_start=1e-5, sigma_gp=1e-2, sigma_coll=1e-5, sigma_goal_prior=1e-5)
     rr, rf = make_ref_geometry(robot, field, ta)
+    rfs = [rf] + [make_ref_geometry(robot, f, ta)[1] for f in extra_fields]      # one CostCollision per field
     start, goal = start.to(**ta), goal.to(**ta)
     g = torch.Generator().manual_seed(seed + 1000)
     means0 = straight_line_means(start.float(), goal.float(), H, dt, B, False, noise=init_noise, gen=g).to(**ta)
@@ -175,7 +176,7 @@ def gen_gpmp2(name, robot, field, start, goal, B, H, dt, iters, seed, ta, sig=No
                sigma_start_init=1e-3, sigma_goal_init=1e-3, sigma_gp_init=1.0,
                sigma_start_sample=1e-3, sigma_goal_sample=1e-3,
                solver_params=dict(delta=delta, trust_region=trust_region, method='cholesky'),
-               collision_fields=[rf], tensor_args=ta, n_interpolated_points=n_interp, **sig)
+               collision_fields=rfs, tensor_args=ta, n_interpolated_points=n_interp, **sig)
     # quirk Q13: GPMP2.__init__ (gpmp2.py:94-131) swallows n_interpolated_points without forwarding it to the
     # base class, which therefore stores None (base.py:85); the interpolated Jacobian only runs when the
     # attribute is set on the instance afterwards
@@ -218,7 +219,10 @@ def gen_gpmp2(name, robot, field, start, goal, B, H, dt, iters, seed, ta, sig=No
         planner='gpmp2', B=B, H=H, D=robot.q_dim, dt=dt, delta=delta, trust_region=trust_region,
         n_interp=0 if n_interp is None else n_interp,
         step_size=step_size, dtype=str(ta['dtype']), start=npf(start), goal=npf(goal), means0=npf(means0),
-        **sig, **keep, **geom_arrays(robot, field))
+        **sig, **keep, **geom_arrays(robot, field),
+        **{f'extra{i}_{k}': v for i, f in enumerate(extra_fields) for k, v in
+           dict(spheres=f.spec()['spheres'], boxes=f.spec()['boxes'], margin=np.float32(f.spec()['margin'])).items()},
+        n_extra_fields=len(extra_fields))
     print(name, 'costs', rec['costs'][0][:3], '->', rec['costs'][-1][:3])
 
 
@@ -228,6 +232,7 @@ def gen_stoch_gpmp(name, robot, field, start, goal, P, S, H, dt, iters, seed, ta
     (GP + goal prior + collision) + importance term, softmax update without Sigma."""
     sig_cost = sig_cost or dict(sigma_start=1e-2, sigma_gp=1.0, sigma_coll=1e-1, sigma_goal_prior=1e-2)
     rr, rf = make_ref_geometry(robot, field, ta)
+    rfs = [rf] + [make_ref_geometry(robot, f, ta)[1] for f in extra_fields]      # one CostCollision per field
     start, goal = start.to(**ta), goal.to(**ta)
     g = torch.Generator().manual_seed(seed + 1000)
     means0 = straight_line_means(start.float(), goal.float(), H, dt, P, False, noise=init_noise, gen=g).to(**ta)
@@ -362,6 +367,11 @@ def gen_cost_terms(name, robot, D, H, G_, npg, S, dt, seed):
 
 def main():
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == 'gpmp2_fields':
+        gen_gpmp2('gpmp2_pm2d_h8_2fields_f64', G.RobotPointMass(2, radius=0.01), G.env_dense_2d(),
+                  torch.tensor([-0.4, -0.4]), torch.tensor([0.4, 0.4]), B=3, H=8, dt=0.04, iters=3, seed=0, ta=TA64,
+                  extra_fields=(G.env_grid_circles_2d(margin=0.03),))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'gpmp2_interp':
         gen_gpmp2('gpmp2_pm2d_h8_interp_f64', G.RobotPointMass(2, radius=0.01), G.env_dense_2d(),
                   torch.tensor([-0.4, -0.4]), torch.tensor([0.4, 0.4]), B=3, H=8, dt=0.04, iters=3, seed=0, ta=TA64,
@@ -416,6 +426,9 @@ def main():
     gen_gpmp2('gpmp2_pm2d_h8_notr_f64', pm, dense, s2 * 0.5, g2 * 0.5, B=3, H=8, dt=0.04, iters=3, seed=0, ta=TA64,
               trust_region=False)
     gen_gpmp2('gpmp2_panda_h16_f64', panda, sph3, q[0], q[1], B=2, H=16, dt=5 / 16, iters=3, seed=1, ta=TA64)
+    # two collision fields: one block of collision rows per field (gpmp2.py:70-78)
+    gen_gpmp2('gpmp2_pm2d_h8_2fields_f64', pm, dense, s2 * 0.5, g2 * 0.5, B=3, H=8, dt=0.04, iters=3, seed=0, ta=TA64,
+              extra_fields=(G.env_grid_circles_2d(margin=0.03),))
     # with n_interpolated_points: collision Jacobian of the interpolated trajectory (build-defined interpolation)
     gen_gpmp2('gpmp2_pm2d_h8_interp_f64', pm, dense, s2 * 0.5, g2 * 0.5, B=3, H=8, dt=0.04, iters=3, seed=0, ta=TA64,
               n_interp=3)

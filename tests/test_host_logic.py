@@ -120,7 +120,13 @@ def test_cost_term_specs_merge_into_one_launch():
     assert len(C.CostComposite(robot, H, [sm, gp_other_dt], tensor_args=ta).device_plan('cpu')[1]) == 2
     # what the planners can fuse
     assert C.device_plan(comp, 'cpu') is not None
-    assert C.device_plan(C.CostComposite(robot, H, [coll, coll], tensor_args=ta), 'cpu') is None      # two fields
+    # several collision members are chained into one evaluator: weight * k_0 * sum_f s_f cost_f
+    coll2 = C.CostCollision(robot, H, field=G.env_grid_circles_2d(), sigma_coll=0.2, tensor_args=ta)
+    plan = C.device_plan(C.CostComposite(robot, H, [coll, coll2], weights_cost_l=[2.0, 3.0], tensor_args=ta), 'cpu')
+    merged, w0, groups0 = plan
+    assert isinstance(merged, C.MergedCollision) and w0 == 2.0 and groups0 == []
+    assert merged.k_sigma == pytest.approx(100.0) and merged.scales == pytest.approx([1.0, (3.0 * 25.0) / (2.0 * 100.0)])
+    assert C.device_plan(C.CostComposite(robot, H, [coll] * 5, tensor_args=ta), 'cpu') is None      # more than four fields
     assert C.device_plan(lambda x: x, 'cpu') is None                                                   # user callable
     # no CPU fallback: evaluating on CPU tensors raises instead of computing
     with pytest.raises(ValueError, match='no CPU path'):
@@ -143,3 +149,38 @@ def test_oracle_trajectory_utilities():
     assert np.allclose(seg, 0.5)                                                               # uniform in arc length
     assert np.allclose(out[0, :2], path[0]) and np.allclose(out[-1, :2], path[-1])
     assert np.allclose(out[1:-1, 2:], (path[-1] - path[0]) / (8 * 0.5)) and np.all(out[[0, -1], 2:] == 0)
+
+
+def test_chained_geometry_buffers():
+    """Several collision fields in one buffer: header word 27 links them, word 28 carries the per-field scale;
+    the C-ABI validator walks the chain."""
+    from motion_planning_baselines_amd import geometry as G
+    from motion_planning_baselines_amd import _lib
+    from motion_planning_baselines_amd._lib import MPBError
+    robot = G.RobotPointMass(2, radius=0.01)
+    f1, f2 = G.env_dense_2d(), G.env_grid_circles_2d()
+    one = G.pack_geometry(robot, f1)
+    two = G.pack_geometry(robot, [f1, f2], scales=[1.0, 0.25])
+    assert G.count_fields(one) == 1 and G.count_fields(two) == 2
+    assert np.array_equal(two[:one.size].view(np.int32)[:27], one.view(np.int32)[:27])
+    assert two.view(np.int32)[27] == one.size and two[one.size + 28] == np.float32(0.25) and two[28] == 1.0
+    _lib.geom_check(one)
+    _lib.geom_check(two)
+    bad = two.copy()
+    bad.view(np.int32)[27] = one.size - 4          # next header inside the first field
+    with pytest.raises(MPBError):
+        _lib.geom_check(bad)
+    bad = two.copy()
+    bad[one.size + 28] = -1.0                      # negative scale
+    with pytest.raises(MPBError):
+        _lib.geom_check(bad)
+    with pytest.raises(MPBError):                  # second field for a different robot
+        _lib.geom_check(np.concatenate([_link(one), G.pack_geometry(G.RobotPointMass(3, radius=0.01), G.env_spheres_3d())]))
+    with pytest.raises(AssertionError):
+        G.pack_geometry(robot, [f1] * 5)
+
+
+def _link(buf):
+    b = buf.copy()
+    b.view(np.int32)[27] = b.size
+    return b

@@ -55,7 +55,8 @@ def test_chomp_iterations(name):
 
 
 @pytest.mark.parametrize('name', ['gpmp2_pm2d_h8_f64', 'gpmp2_pm2d_h8_f32', 'gpmp2_pm2d_h8_notr_f64',
-                                  'gpmp2_panda_h16_f64', 'gpmp2_pm2d_h8_interp_f64', 'gpmp2_panda_h16_interp_f64'])
+                                  'gpmp2_panda_h16_f64', 'gpmp2_pm2d_h8_interp_f64', 'gpmp2_panda_h16_interp_f64',
+                                  'gpmp2_pm2d_h8_2fields_f64'])
 def test_gpmp2_iterations(name):
     g = load_golden(name)
     dt64 = 'float64' in str(g['dtype'])
