@@ -190,12 +190,13 @@ struct GpConst {
 
 // DT > 0: the number of degrees of freedom is a compile-time constant (loop bounds, pivot-block count and the
 // position/velocity index tests fold away); DT == 0: generic.
-template <int DT>
+template <int DT, bool MULTI>
 __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, const float* __restrict__ start,
                                                          const float* __restrict__ goal, const float* __restrict__ jac,
                                                          const double* __restrict__ diag_mean, double* __restrict__ work,
-                                                         float* __restrict__ costs_out, int B, int H, int Drt, int F, GpConst K) {
+                                                         float* __restrict__ costs_out, int B, int H, int Drt, int Frt, GpConst K) {
     const int D = DT ? DT : Drt;
+    const int F = MULTI ? Frt : 1;       // MULTI == false: one collision field, the field loops fold away
     __shared__ double Sb[1][GP_N * GP_LD];  // W_t for the matvec / next-tile reads (the inverse itself runs in registers)
     __shared__ double xs[2][GP_N];          // x_t, x_{t+1} (fp64 copies)
     __shared__ double rv[GP_N];             // r_t
@@ -585,8 +586,12 @@ extern "C" int mpb_gpmp2_solve(float* x, const float* start, const float* goal, 
     K.trust = trust_region;
     const double* dm = trust_region ? (diag_mean ? diag_mean : w.diag_mean) : nullptr;
 #define GP_LAUNCH(DT)                                                                                                   \
-    hipLaunchKernelGGL(gpmp2_solve_kernel<DT>, dim3(B), dim3(64), 0, (hipStream_t)stream, x, start, goal, w.jac, dm, w.fz, \
-                       costs_out, B, H, D, n_fields, K)
+    if (n_fields == 1)                                                                                                  \
+        hipLaunchKernelGGL((gpmp2_solve_kernel<DT, false>), dim3(B), dim3(64), 0, (hipStream_t)stream, x, start, goal,  \
+                           w.jac, dm, w.fz, costs_out, B, H, D, n_fields, K);                                           \
+    else                                                                                                                \
+        hipLaunchKernelGGL((gpmp2_solve_kernel<DT, true>), dim3(B), dim3(64), 0, (hipStream_t)stream, x, start, goal,   \
+                           w.jac, dm, w.fz, costs_out, B, H, D, n_fields, K)
     switch (D) {
         case 2: GP_LAUNCH(2); break;
         case 3: GP_LAUNCH(3); break;
