@@ -258,6 +258,11 @@ int mpb_stoch_gpmp_costs(const float *samples, const float *means, const float *
  * ------------------------------------------------------------------------------------------- */
 int mpb_gp_prior_sample(float *out, const double *means, const double *eps, const double *Udiag,
                         const double *Uoff, int G, int n, int H, int D, uint64_t seed, void *stream);
+/* Same samples from the dense per-dof scale_tril (2H x 2H row-major fp64, index 2t + {0: position, 1: velocity};
+ * = U_dof^-T, what MultivariateNormal(precision_matrix=...) holds for one degree of freedom) as a GEMM on the
+ * matrix cores (v_mfma_f64_16x16x4_f64); H <= 128.  Same Philox stream as mpb_gp_prior_sample. */
+int mpb_gp_prior_sample_dense(float *out, const double *means, const double *eps, const double *scale_tril,
+                              int G, int n, int H, int D, uint64_t seed, void *stream);
 
 #ifdef __cplusplus
 }

@@ -32,16 +32,20 @@ __global__ __launch_bounds__(256) void gp_prior_sample_kernel(float* __restrict_
     const double* ep = eps ? eps + ((size_t)i * G + g) * H * dim : nullptr;
     float* o = out + ((size_t)g * n + i) * H * dim;           // particle index = mode * n + sample (base.py:202)
     double yp = 0.0, yv = 0.0;
+    float nrm[4] = {0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < H; ++t) {
         double ep_p, ep_v;
         if (ep) {
             ep_p = ep[t * dim + d];
             ep_v = ep[t * dim + D + d];
         } else {
-            const uint4 r = philox4x32_10(make_uint4((uint32_t)chain, (uint32_t)t, 0x6770u, 0u), make_uint2(seed_lo, seed_hi));
-            float a, b;
-            box_muller(r.x, r.y, a, b);
-            ep_p = a; ep_v = b;
+            // one Philox call per PAIR of time steps: (pos, vel) of t = 2 tp from (x, y), of t = 2 tp + 1 from (z, w)
+            if ((t & 1) == 0) {
+                const uint4 r = philox4x32_10(make_uint4((uint32_t)chain, (uint32_t)(t >> 1), 0x6770u, 0u), make_uint2(seed_lo, seed_hi));
+                box_muller(r.x, r.y, nrm[0], nrm[1]);
+                box_muller(r.z, r.w, nrm[2], nrm[3]);
+            }
+            ep_p = nrm[2 * (t & 1)]; ep_v = nrm[2 * (t & 1) + 1];
         }
         double rp = ep_p, rv = ep_v;
         if (t > 0) {   // rhs -= U_{t-1,t}^T y_{t-1}
@@ -55,6 +59,124 @@ __global__ __launch_bounds__(256) void gp_prior_sample_kernel(float* __restrict_
         o[t * dim + d] = (float)(mu[t * dim + d] + yp);
         o[t * dim + D + d] = (float)(mu[t * dim + D + d] + yv);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dense form on the matrix cores (H <= 128).  For one degree of freedom the map eps -> y is the 2H x 2H lower-
+// triangular scale_tril T = U_dof^-T of the reference's MultivariateNormal (the same for every chain), so
+// Y = T E with E the (2H x chains) block of standard normals is a GEMM: v_mfma_f64_16x16x4_f64, 16 chains per
+// wave.  A workgroup owns SB whole particles (SB * D <= 64 chains) so that its output is one contiguous slab:
+// T is streamed through LDS one 16-row tile at a time (shared by the four waves, odd row stride: conflict-free
+// A-operand reads), the B operand -- this lane's normals -- stays in registers, and every row tile of the result
+// is transposed through LDS and written with coalesced stores.  The sequential kernel above needs H dependent
+// steps per chain; here the depth is the MFMA chain of one row tile.
+// ------------------------------------------------------------------------------------------------
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+template <int KT>   // K tiles of 4: 2H <= 4 KT  (KT = 32: H <= 64, KT = 64: H <= 128)
+__global__ __launch_bounds__(256) void gp_prior_dense_kernel(float* __restrict__ out, const double* __restrict__ means,
+                                                             const double* __restrict__ eps, const double* __restrict__ T,
+                                                             int G, int n, int H, int D, int SB, uint32_t seed_lo,
+                                                             uint32_t seed_hi) {
+    constexpr int LD = 4 * KT + 1;                     // doubles per staged row (odd: distinct banks for 16 rows)
+    // T row tile; before the first tile the same memory carries the normals exchange (4 waves x 4 KT x 16 floats)
+    __shared__ double Tt[(16 * LD > 128 * KT) ? 16 * LD : 128 * KT];
+    extern __shared__ float Yt[];                      // SB x 8 x 2D: one row tile of the block's output, particle-major
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int c = wave * 16 + li;                      // chain slot of this lane (column of the MFMA tile)
+    const int sb = c / D, d = c - sb * D;
+    const int pidx = blockIdx.x * SB + sb;             // particle index = mode * n + sample (base.py:202)
+    const bool valid = sb < SB && pidx < G * n;
+    const int pp = valid ? pidx : 0;
+    const int g = pp / n, i = pp - g * n;
+    const int chain = (i * G + g) * D + d;             // Philox counter: same stream as the sequential kernel
+    const int dim = 2 * D, N2 = 2 * H;
+    // ---- B operand: eps[k = 4 kt + lk] of this chain, k = 2 t + s (s = 0 position, 1 velocity)
+    double e[KT];
+    if (eps != nullptr) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const int k = 4 * kt + lk, t = k >> 1, sv = k & 1;
+            e[kt] = (valid && t < H) ? eps[(((size_t)i * G + g) * H + t) * dim + (sv ? D + d : d)] : 0.0;
+        }
+    } else {
+        // one Philox call yields the four normals k = 4 tp .. 4 tp + 3 of a chain.  The four lanes that share a
+        // chain (lk = 0..3) split the calls (tp = 4 j + lk) and swap the results through LDS, so every call is
+        // made exactly once (Philox is 40 quarter-rate integer multiplies)
+        float* Ex = reinterpret_cast<float*>(Tt) + (size_t)wave * (4 * KT) * 16;     // [k][chain slot li]
+#pragma unroll
+        for (int j = 0; j < KT / 4; ++j) {
+            const int tp = 4 * j + lk;
+            float nrm[4] = {0.f, 0.f, 0.f, 0.f};
+            if (valid && 2 * tp < H) {
+                const uint4 r = philox4x32_10(make_uint4((uint32_t)chain, (uint32_t)tp, 0x6770u, 0u), make_uint2(seed_lo, seed_hi));
+                box_muller(r.x, r.y, nrm[0], nrm[1]);
+                box_muller(r.z, r.w, nrm[2], nrm[3]);
+                if (2 * tp + 1 >= H) nrm[2] = nrm[3] = 0.f;
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x) Ex[(4 * tp + x) * 16 + li] = nrm[x];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) e[kt] = (double)Ex[(4 * kt + lk) * 16 + li];
+    }
+    const int nsb = min(SB, G * n - blockIdx.x * SB);  // particles of this block
+#pragma unroll
+    for (int r = 0; r < KT / 4; ++r) {                 // 16-row tiles of T = 8 time steps x (pos, vel)
+        if (16 * r < N2) {
+            const int ncol = 16 * (r + 1);             // lower triangular: columns beyond the tile are zero
+            __syncthreads();
+            for (int idx = threadIdx.x; idx < 16 * ncol; idx += 256) {
+                const int row = idx / ncol, col = idx - row * ncol;
+                const int gr = 16 * r + row;
+                Tt[row * LD + col] = (gr < N2 && col < N2) ? T[(size_t)gr * N2 + col] : 0.0;
+            }
+            __syncthreads();
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kt = 0; kt < 4 * (r + 1); ++kt)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Tt[li * LD + 4 * kt + lk], e[kt], acc, 0, 0, 0);
+            // D layout: rows lk + 4 q of the tile, column (chain) li  ->  Yt[sb][t_local][channel]
+            if (sb < SB) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = lk + 4 * q, tl = row >> 1, sv = row & 1;
+                    Yt[(sb * 8 + tl) * dim + (sv ? D + d : d)] = (float)acc[q];
+                }
+            }
+            __syncthreads();
+            // coalesced write-out: per particle the 8 time steps x 2D channels of this tile are contiguous
+            const int t0 = 8 * r, nt = min(8, H - t0);
+            const int per = nt * dim;
+            for (int idx = threadIdx.x; idx < nsb * per; idx += 256) {
+                const int s2 = idx / per, rem = idx - s2 * per;
+                const int p2 = blockIdx.x * SB + s2, g2 = p2 / n;
+                const size_t off = (size_t)t0 * dim + rem;
+                out[(size_t)p2 * H * dim + off] = (float)(means[(size_t)g2 * H * dim + off] + (double)Yt[s2 * 8 * dim + rem]);
+            }
+        }
+    }
+}
+
+extern "C" int mpb_gp_prior_sample_dense(float* out, const double* means, const double* eps, const double* scale_tril,
+                                         int G, int n, int H, int D, uint64_t seed, void* stream) {
+    if (!out || !means || !scale_tril) return mpb_fail(MPB_E_INVALID, "mpb_gp_prior_sample_dense: null pointer");
+    if (G < 1 || n < 0 || H < 2 || D < 1 || D > 64) return mpb_fail(MPB_E_INVALID, "mpb_gp_prior_sample_dense: bad shape");
+    if (H > 128) return mpb_fail(MPB_E_UNSUPPORTED, "mpb_gp_prior_sample_dense: H > 128 (use mpb_gp_prior_sample)");
+    if (n == 0) return MPB_OK;
+    const int SB = 64 / D;                                      // whole particles per workgroup (SB * D <= 64 chains)
+    const dim3 grid((G * n + SB - 1) / SB), block(256);
+    const size_t lds = (size_t)SB * 8 * 2 * D * sizeof(float);
+    if (H <= 64)
+        hipLaunchKernelGGL(gp_prior_dense_kernel<32>, grid, block, lds, (hipStream_t)stream, out, means, eps, scale_tril, G,
+                           n, H, D, SB, (uint32_t)seed, (uint32_t)(seed >> 32));
+    else
+        hipLaunchKernelGGL(gp_prior_dense_kernel<64>, grid, block, lds, (hipStream_t)stream, out, means, eps, scale_tril, G,
+                           n, H, D, SB, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return mpb_check_launch("mpb_gp_prior_sample_dense");
 }
 
 extern "C" int mpb_gp_prior_sample(float* out, const double* means, const double* eps, const double* Udiag,

@@ -71,6 +71,20 @@ def gp_prior_factor(H, dt, sigma_start, sigma_gp, sigma_goal=None):
     return Ud, Uo
 
 
+def gp_prior_scale_tril(Ud, Uo):
+    """Dense per-dof scale_tril T = U_dof^-T (2H x 2H, index 2t + {0: pos, 1: vel}) from the bidiagonal factor of
+    gp_prior_factor -- what MultivariateNormal(precision_matrix=K^-1) derives (multivariate_normal.py:80-86),
+    restricted to one degree of freedom.  fp64 on the host; O(H^2) numbers."""
+    H = Ud.shape[0]
+    U = np.zeros((2 * H, 2 * H))
+    for t in range(H):
+        U[2 * t, 2 * t], U[2 * t, 2 * t + 1], U[2 * t + 1, 2 * t + 1] = Ud[t]
+        if t < H - 1:
+            U[2 * t:2 * t + 2, 2 * t + 2:2 * t + 4] = Uo[t].reshape(2, 2)
+    from scipy.linalg import solve_triangular
+    return np.ascontiguousarray(solve_triangular(U, np.eye(2 * H), lower=False).T)
+
+
 def const_vel_mean(start_pos, goal_pos, H, dt):
     """Straight line with constant velocity, zero velocity at both ends (mp_priors_multi.py:130-151)."""
     D = start_pos.shape[-1]
@@ -167,7 +181,8 @@ class OptimizationPlanner(MPPlanner):
         if noise != 'philox':
             eps = torch.empty(n, G, H * 2 * D, dtype=torch.float64).normal_().to(self.device)
         f64 = lambda a: torch.as_tensor(a, dtype=torch.float64).to(self.device).contiguous()
-        return ops.gp_prior_sample(f64(means), eps, f64(Ud), f64(Uo), n, D, seed=seed)
+        tril = f64(gp_prior_scale_tril(Ud, Uo)) if H <= 128 else None      # dense GEMM on the matrix cores
+        return ops.gp_prior_sample(f64(means), eps, f64(Ud), f64(Uo), n, D, seed=seed, scale_tril=tril)
 
     def const_vel_trajectories(self, start_state, multi_goal_states):
         """base.py:141-153, incl. its quirk: the velocity channel is (goal - start) / (H * dt), not / ((H-1) * dt).

@@ -9,7 +9,7 @@ evaluated factor-wise (csrc/mpb_stoch_gpmp.hip).
 import torch
 
 from .. import ops
-from .base import OptimizationPlanner, gp_prior_factor
+from .base import OptimizationPlanner, gp_prior_factor, gp_prior_scale_tril
 
 
 class StochGPMP(OptimizationPlanner):
@@ -45,6 +45,7 @@ class StochGPMP(OptimizationPlanner):
         Ud, Uo = gp_prior_factor(H, dt, sigma_start_sample, sigma_gp_sample, sigma_goal_sample)
         f64 = lambda a: torch.as_tensor(a, dtype=torch.float64).to(self.device).contiguous()
         self._Ud, self._Uo = f64(Ud), f64(Uo)
+        self._tril = f64(gp_prior_scale_tril(Ud, Uo)) if H <= 128 else None   # per-dof scale_tril: sampling as an MFMA GEMM
         self._weights = None
         self.reset(initial_particle_means=initial_particle_means)
 
@@ -75,7 +76,7 @@ class StochGPMP(OptimizationPlanner):
         if self.noise != 'philox':   # MultivariateNormal.sample((S,)) of batch shape (P,) and event shape (M,)
             eps = torch.empty(S, P, H * dim, dtype=torch.float64).normal_().to(self.device)
         out = ops.gp_prior_sample(self._particle_means.double().contiguous(), eps, self._Ud, self._Uo, S, self.n_dof,
-                                  seed=self.seed + self._iter)
+                                  seed=self.seed + self._iter, scale_tril=self._tril)
         self._iter += 1
         return out.reshape(P, S, H, dim)
 

@@ -229,3 +229,26 @@ def test_stoch_gpmp_class(gpu_device):
     assert traj.shape == (P, H, 2 * D) and torch.isfinite(traj).all()
     assert pl._weights.shape == (P, S, 1, 1)
     assert abs(float(pl._weights.sum()) - P) < 1e-4
+
+
+@pytest.mark.parametrize('H,D,G_,n', [(8, 2, 1, 6), (64, 7, 3, 40), (100, 3, 2, 17), (128, 7, 1, 64)])
+def test_gp_prior_dense_mfma_equals_chain(gpu_device, H, D, G_, n):
+    """The dense scale_tril GEMM on the matrix cores (mpb_gp_prior_sample_dense) == the per-chain forward
+    substitution (mpb_gp_prior_sample), with injected normals and with the device Philox stream."""
+    from motion_planning_baselines_amd import ops
+    from motion_planning_baselines_amd.planners.base import gp_prior_factor, gp_prior_scale_tril
+    dev = gpu_device
+    f64 = lambda a: torch.as_tensor(a, dtype=torch.float64).to(dev).contiguous()
+    Ud, Uo = gp_prior_factor(H, 5.0 / H, 1e-3, 0.5, 1e-3)
+    tril = f64(gp_prior_scale_tril(Ud, Uo))
+    gen = torch.Generator().manual_seed(H + D)
+    means = torch.randn(G_, H, 2 * D, generator=gen, dtype=torch.float64)
+    eps = torch.randn(n, G_, H * 2 * D, generator=gen, dtype=torch.float64)
+    a = ops.gp_prior_sample(f64(means), f64(eps), f64(Ud), f64(Uo), n, D)
+    b = ops.gp_prior_sample(f64(means), f64(eps), f64(Ud), f64(Uo), n, D, scale_tril=tril)
+    assert a.shape == b.shape == (G_ * n, H, 2 * D)
+    assert rel_err(b, a) < 2e-6                                       # fp32 outputs of two fp64 computations
+    a2 = ops.gp_prior_sample(f64(means), None, f64(Ud), f64(Uo), n, D, seed=9)
+    b2 = ops.gp_prior_sample(f64(means), None, f64(Ud), f64(Uo), n, D, seed=9, scale_tril=tril)
+    assert rel_err(b2, a2) < 2e-6                                     # same Philox stream in both kernels
+    assert float((a2 - f64(means).float().repeat_interleave(n, 0)).abs().max()) > 0

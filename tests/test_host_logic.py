@@ -184,3 +184,20 @@ def _link(buf):
     b = buf.copy()
     b.view(np.int32)[27] = b.size
     return b
+
+
+def test_gp_prior_scale_tril_matches_reference():
+    """Per-dof dense scale_tril from the bidiagonal factor == the sub-matrix of the reference's dense
+    MultivariateNormal scale_tril (golden from MultiMPPrior, fp64)."""
+    from conftest import load_golden
+    from motion_planning_baselines_amd.planners.base import gp_prior_factor, gp_prior_scale_tril
+    g = load_golden('gp_prior_d2_h8')
+    D, H = int(g['D']), int(g['H'])
+    Ud, Uo = gp_prior_factor(H, float(g['dt']), float(g['sigma_start']), float(g['sigma_gp']), float(g['sigma_goal']))
+    Tm = gp_prior_scale_tril(Ud, Uo)
+    assert Tm.shape == (2 * H, 2 * H) and np.allclose(np.triu(Tm, 1), 0.0)
+    full = g['scale_tril'][0]                                 # (2D*H, 2D*H), index t*2D + c
+    for d in range(D):
+        idx = np.array([[t * 2 * D + d, t * 2 * D + D + d] for t in range(H)]).reshape(-1)
+        sub = full[np.ix_(idx, idx)]
+        np.testing.assert_allclose(Tm, sub, rtol=1e-9, atol=1e-12 * np.abs(sub).max())
