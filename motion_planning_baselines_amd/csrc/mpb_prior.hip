@@ -124,6 +124,20 @@ __global__ __launch_bounds__(256) void gp_prior_dense_kernel(float* __restrict__
         for (int kt = 0; kt < KT; ++kt) e[kt] = (double)Ex[(4 * kt + lk) * 16 + li];
     }
     const int nsb = min(SB, G * n - blockIdx.x * SB);  // particles of this block
+    // write-out slots of this thread: flat index tid + 256 j over (particle of the block, 8 x 2D tile elements)
+    constexpr int WSLOTS = 4;                          // SB * 8 * 2D <= 64 * 16 = 1024 elements per tile
+    int w_s2[WSLOTS], w_rem[WSLOTS];
+    size_t w_out[WSLOTS], w_mu[WSLOTS];
+#pragma unroll
+    for (int j = 0; j < WSLOTS; ++j) {
+        const int idx = threadIdx.x + 256 * j;
+        const int s2 = idx / (8 * dim);
+        w_s2[j] = s2;
+        w_rem[j] = idx - s2 * 8 * dim;
+        const int p2 = min(blockIdx.x * SB + s2, G * n - 1);
+        w_out[j] = (size_t)p2 * H * dim;
+        w_mu[j] = (size_t)(p2 / n) * H * dim;
+    }
 #pragma unroll
     for (int r = 0; r < KT / 4; ++r) {                 // 16-row tiles of T = 8 time steps x (pos, vel)
         if (16 * r < N2) {
@@ -135,10 +149,15 @@ __global__ __launch_bounds__(256) void gp_prior_dense_kernel(float* __restrict__
                 Tt[row * LD + col] = (gr < N2 && col < N2) ? T[(size_t)gr * N2 + col] : 0.0;
             }
             __syncthreads();
-            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+            // two independent accumulation chains (even / odd K tiles) keep the MFMA pipe busy
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int kt = 0; kt < 4 * (r + 1); ++kt)
+            for (int kt = 0; kt < 4 * (r + 1); kt += 2) {
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Tt[li * LD + 4 * kt + lk], e[kt], acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Tt[li * LD + 4 * (kt + 1) + lk], e[kt + 1], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] += acc1[q];
             // D layout: rows lk + 4 q of the tile, column (chain) li  ->  Yt[sb][t_local][channel]
             if (sb < SB) {
 #pragma unroll
@@ -148,14 +167,15 @@ __global__ __launch_bounds__(256) void gp_prior_dense_kernel(float* __restrict__
                 }
             }
             __syncthreads();
-            // coalesced write-out: per particle the 8 time steps x 2D channels of this tile are contiguous
+            // coalesced write-out: per particle the 8 time steps x 2D channels of this tile are contiguous; the
+            // (particle, element) split of this thread's slots was fixed before the loop (no divisions here)
             const int t0 = 8 * r, nt = min(8, H - t0);
-            const int per = nt * dim;
-            for (int idx = threadIdx.x; idx < nsb * per; idx += 256) {
-                const int s2 = idx / per, rem = idx - s2 * per;
-                const int p2 = blockIdx.x * SB + s2, g2 = p2 / n;
-                const size_t off = (size_t)t0 * dim + rem;
-                out[(size_t)p2 * H * dim + off] = (float)(means[(size_t)g2 * H * dim + off] + (double)Yt[s2 * 8 * dim + rem]);
+#pragma unroll
+            for (int j = 0; j < WSLOTS; ++j) {
+                if (w_s2[j] < nsb && w_rem[j] < nt * dim) {
+                    const size_t off = (size_t)t0 * dim + w_rem[j];
+                    out[w_out[j] + off] = (float)(means[w_mu[j] + off] + (double)Yt[w_s2[j] * 8 * dim + w_rem[j]]);
+                }
             }
         }
     }

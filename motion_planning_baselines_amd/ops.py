@@ -302,7 +302,7 @@ def mppi_step(mean, eps, scale_tril, cov_inv, state0, goal, ctrl_min, ctrl_max, 
         float(step_size), int(n_iters), int(seed) & (2 ** 64 - 1), int(iter0), _stream()), 'mpb_mppi_step')
 
 
-def gp_prior_sample(means, eps, Udiag, Uoff, n, D, seed=0, scale_tril=None):
+def gp_prior_sample(means, eps, Udiag, Uoff, n, D, seed=0, scale_tril=None, out=None):
     """Initial particles from the GP prior: means (G,H,2D) fp64, eps None or (n,G,H*2D) fp64 -> (G*n,H,2D) fp32.
     With `scale_tril` (2H,2H fp64, planners.base.gp_prior_scale_tril) and H <= 128 the product runs as a GEMM on
     the matrix cores; otherwise as the per-chain forward substitution."""
@@ -314,7 +314,10 @@ def gp_prior_sample(means, eps, Udiag, Uoff, n, D, seed=0, scale_tril=None):
     if eps is not None:
         if not (eps.is_cuda and eps.dtype == torch.float64 and eps.is_contiguous() and tuple(eps.shape) == (n, G, H * dim)):
             raise ValueError('eps must be a contiguous CUDA float64 tensor of shape (n, G, H*2D)')
-    out = torch.empty(G * n, H, dim, device=means.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(G * n, H, dim, device=means.device, dtype=torch.float32)
+    else:
+        _chk(out, (G * n, H, dim), 'out')
     if scale_tril is not None and H <= 128:
         if not (scale_tril.is_cuda and scale_tril.dtype == torch.float64 and scale_tril.is_contiguous()
                 and tuple(scale_tril.shape) == (2 * H, 2 * H)):

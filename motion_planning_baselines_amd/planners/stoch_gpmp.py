@@ -75,8 +75,13 @@ class StochGPMP(OptimizationPlanner):
         eps = None
         if self.noise != 'philox':   # MultivariateNormal.sample((S,)) of batch shape (P,) and event shape (M,)
             eps = torch.empty(S, P, H * dim, dtype=torch.float64).normal_().to(self.device)
-        out = ops.gp_prior_sample(self._particle_means.double().contiguous(), eps, self._Ud, self._Uo, S, self.n_dof,
-                                  seed=self.seed + self._iter, scale_tril=self._tril)
+        # persistent buffers: no allocator traffic inside the iteration loop
+        if getattr(self, '_means64', None) is None or self._means64.shape != self._particle_means.shape:
+            self._means64 = torch.empty_like(self._particle_means, dtype=torch.float64)
+            self._samples_buf = torch.empty(P * S, H, dim, device=self.device, dtype=torch.float32)
+        self._means64.copy_(self._particle_means)
+        out = ops.gp_prior_sample(self._means64, eps, self._Ud, self._Uo, S, self.n_dof, seed=self.seed + self._iter,
+                                  scale_tril=self._tril, out=self._samples_buf)
         self._iter += 1
         return out.reshape(P, S, H, dim)
 
