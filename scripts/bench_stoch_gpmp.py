@@ -1,5 +1,6 @@
 """StochGPMP at a C3-like shape (P=128 particles x S=32 samples, H=64, D=7), device Philox noise."""
-import os, sys, time
+import gc, os, sys, time
+if os.environ.get("MPB_NOGC"): gc.disable()
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from motion_planning_baselines_amd import geometry as G, ops
