@@ -604,3 +604,177 @@ __device__ __forceinline__ float waypoint_cost_grid(const GeomView& G, const uns
     }
     return cost;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Broad-phase variant of the GRADIENT path: the same per-lane candidate lists, additionally tracking the
+// direction to the nearest obstacle (v, |v|) of every collision sphere; the hinge force -v/|v| of the spheres in
+// contact is pulled back through the kinematic chain (J^T f over the joints upstream of the sphere's frame).
+// The nearest obstacle among the candidates is the nearest overall whenever the hinge is active (first minimum in
+// obstacle-index order, like the exhaustive loop), so cost and gradient equal the exhaustive evaluator's.
+// ------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void spheres_nearest_grid(const GeomView& G, const unsigned* gridw, const float4* otab,
+                                                     const float (&x)[N], const float (&y)[N], const float (&z)[N],
+                                                     float (&best)[N], float (&vx)[N], float (&vy)[N], float (&vz)[N],
+                                                     float (&vn)[N]) {
+    unsigned w[N];
+    unsigned long long over = 0ull;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float fx = (x[i] - G.glx) * G.gix, fy = (y[i] - G.gly) * G.giy, fz = (z[i] - G.glz) * G.giz;
+        const int ix = (int)floorf(fx), iy = (int)floorf(fy), iz = (int)floorf(fz);
+        const bool inb = (unsigned)ix < (unsigned)G.gnx && (unsigned)iy < (unsigned)G.gny && (unsigned)iz < (unsigned)G.gnz;
+        const int cell = inb ? (iz * G.gny + iy) * G.gnx + ix : 0;
+        const unsigned wv = gridw[cell];
+        w[i] = inb ? wv : MPB_GRID_EMPTY;
+        best[i] = 3.0e38f;
+        vx[i] = vy[i] = vz[i] = 0.f;
+        vn[i] = 1.f;
+        over |= __ballot(w[i] == MPB_GRID_OVERFLOW);
+    }
+    auto visit = [&](int i, const float4 s) {
+        const float dx = x[i] - s.x, dy = y[i] - s.y, dz = z[i] - s.z;
+        const float d2 = fmaxf(dx * dx + dy * dy + dz * dz, 1e-30f);   // keeps 1/dist finite; the oracle clamps the same way
+        const float dist = fast_sqrt(d2);
+        const float sd = dist - s.w;
+        const bool better = sd < best[i];
+        vx[i] = better ? dx : vx[i];
+        vy[i] = better ? dy : vy[i];
+        vz[i] = better ? dz : vz[i];
+        vn[i] = better ? dist : vn[i];
+        best[i] = fminf(best[i], sd);
+    };
+    if (__builtin_expect(over != 0ull, 0)) {
+        for (int o = 0; o < G.n_sph; ++o) {
+            const float4 s = otab[o];
+#pragma unroll
+            for (int i = 0; i < N; ++i) visit(i, s);
+        }
+    } else {
+        for (;;) {
+            unsigned long long any = 0ull;
+#pragma unroll
+            for (int i = 0; i < N; ++i) any |= __ballot((w[i] & 0xFFu) != 0xFFu);
+            if (any == 0ull) break;
+            float4 s[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const unsigned idx = w[i] & 0xFFu;
+                w[i] = (w[i] >> 8) | 0xFF000000u;
+                s[i] = otab[idx == 0xFFu ? (unsigned)G.n_sph : idx];
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i) visit(i, s[i]);
+        }
+    }
+    // boxes are few: exhaustive (same direction rules as exact_box)
+    const float4* bp = reinterpret_cast<const float4*>(G.box);
+    for (int o = 0; o < G.n_box; ++o) {
+        const float4 c = bp[2 * o], h = bp[2 * o + 1];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const float px = x[i] - c.x, py = y[i] - c.y, pz = z[i] - c.z;
+            const float ax = fabsf(px) - h.x, ay = fabsf(py) - h.y, az = fabsf(pz) - h.z;
+            const float qx = fmaxf(ax, 0.f), qy = fmaxf(ay, 0.f), qz = fmaxf(az, 0.f);
+            const float outside = fast_sqrt(fmaxf(qx * qx + qy * qy + qz * qz, 1e-30f));
+            const float mx = fmaxf(ax, fmaxf(ay, az));
+            const float sd = outside + fminf(mx, 0.f);
+            const bool better = sd < best[i];
+            const bool out = mx > 0.f;
+            const bool ixm = (ax >= ay) && (ax >= az);
+            const bool iym = !ixm && (ay >= az);
+            const float nx = out ? copysignf(qx, px) : (ixm ? copysignf(1.f, px) : 0.f);
+            const float ny = out ? copysignf(qy, py) : (iym ? copysignf(1.f, py) : 0.f);
+            const float nz = out ? copysignf(qz, pz) : ((!ixm && !iym) ? copysignf(1.f, pz) : 0.f);
+            vx[i] = better ? nx : vx[i];
+            vy[i] = better ? ny : vy[i];
+            vz[i] = better ? nz : vz[i];
+            vn[i] = better ? (out ? outside : 1.f) : vn[i];
+            best[i] = fminf(best[i], sd);
+        }
+    }
+}
+
+// does the grid pay for the GRADIENT evaluators?  A point robot has ONE collision sphere per waypoint: against a
+// few dozen obstacles the straight SGPR-operand loop of point_cost is cheaper than a grid lookup (C2: 3.5 vs 4.3 us
+// per CHOMP iteration); articulated robots (tens of spheres per waypoint) always gain.
+__device__ __forceinline__ bool grid_usable_grad(const GeomView& G) {
+    return grid_usable(G) && (G.kind != MPB_KIND_POINT || G.n_sph > 48);
+}
+
+// cost and d cost / d q of one waypoint through the broad-phase grid (dq[i] for i < n_dof)
+__device__ __forceinline__ float waypoint_cost_grid_grad(const GeomView& G, const unsigned* gridw, const float4* otab,
+                                                         const float (&q)[MPB_MAX_DOF], float (&dq)[MPB_MAX_DOF]) {
+#pragma unroll
+    for (int i = 0; i < MPB_MAX_DOF; ++i) dq[i] = 0.f;
+    if (G.kind == MPB_KIND_POINT) {
+        const float x[1] = {q[0]}, y[1] = {q[1]}, z[1] = {(G.n_dof > 2) ? q[2] : 0.f};
+        float best[1], vx[1], vy[1], vz[1], vn[1];
+        spheres_nearest_grid<1>(G, gridw, otab, x, y, z, best, vx, vy, vz, vn);
+        const float h = fmaxf(G.margin + G.links[4] - best[0], 0.f);
+        const float sc = (h > 0.f) ? -1.0f / vn[0] : 0.f;
+        dq[0] = vx[0] * sc;
+        dq[1] = vy[0] * sc;
+        if (G.n_dof > 2) dq[2] = vz[0] * sc;
+        return h;
+    }
+    constexpr int N = 4;
+    constexpr float FAR = 1.0e9f;
+    FKState<true> F;
+    F.r00 = 1.f; F.r01 = 0.f; F.r02 = 0.f; F.r10 = 0.f; F.r11 = 1.f; F.r12 = 0.f; F.r20 = 0.f; F.r21 = 0.f; F.r22 = 1.f;
+    F.tx = F.ty = F.tz = 0.f;
+    F.frame = 0;
+#pragma unroll
+    for (int i = 0; i < MPB_MAX_DOF; ++i) { F.zx[i] = F.zy[i] = F.zz[i] = F.px[i] = F.py[i] = F.pz[i] = 0.f; }
+    float cost = 0.f;
+    for (int l0 = 0; l0 < G.n_links; l0 += N) {
+        const int nl = min(N, G.n_links - l0);
+        float x[N], y[N], z[N], rl[N];
+        int fr[N];
+        float4 lkv[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            lkv[i] = *reinterpret_cast<const float4*>(G.links + 8 * (l0 + i));
+            rl[i] = G.links[8 * (l0 + i) + 4];
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if (i < nl) {
+                const float4 lk = lkv[i];
+                const int f = __float_as_int(lk.x);
+                while (F.frame < f) fk_advance<true>(G, F, q);
+                x[i] = F.tx + (F.r00 * lk.y + F.r01 * lk.z + F.r02 * lk.w);
+                y[i] = F.ty + (F.r10 * lk.y + F.r11 * lk.z + F.r12 * lk.w);
+                z[i] = F.tz + (F.r20 * lk.y + F.r21 * lk.z + F.r22 * lk.w);
+                fr[i] = f;
+            } else {
+                rl[i] = 0.f;
+                x[i] = y[i] = z[i] = FAR;
+                fr[i] = 0;
+            }
+        }
+        float best[N], vx[N], vy[N], vz[N], vn[N];
+        spheres_nearest_grid<N>(G, gridw, otab, x, y, z, best, vx, vy, vz, vn);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const float h = fmaxf(G.margin + rl[i] - best[i], 0.f);   // parked slots: best = 3e38 -> 0
+            cost += h;
+            if (__any(h > 0.f)) {
+                const float sc = (h > 0.f) ? -1.0f / vn[i] : 0.f;
+                const float fx = vx[i] * sc, fy = vy[i] * sc, fz = vz[i] * sc;
+#pragma unroll
+                for (int ii = 0; ii < MPB_MAX_DOF; ++ii) {
+                    if (ii < fr[i] && ii < G.n_dof) {
+                        // d x / d q_ii = z_ii x (x - p_ii) for every joint upstream of the sphere's frame
+                        const float ex = x[i] - F.px[ii], ey = y[i] - F.py[ii], ez = z[i] - F.pz[ii];
+                        const float cx = F.zy[ii] * ez - F.zz[ii] * ey;
+                        const float cy = F.zz[ii] * ex - F.zx[ii] * ez;
+                        const float cz = F.zx[ii] * ey - F.zy[ii] * ex;
+                        dq[ii] += fx * cx + fy * cy + fz * cz;
+                    }
+                }
+            }
+        }
+    }
+    return cost;
+}

@@ -32,72 +32,80 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gpmp2_linearize_kernel(const float* __restrict__ x, const float* __restrict__ geom,
                                                               float* __restrict__ jac_all, int B, int H, int D, int n_interp) {
+    __shared__ unsigned gridw[MPB_GRID_MAX_CELLS];              // broad-phase grid of the field being linearised
+    __shared__ float4 otab[MPB_GRID_MAX_SPH + 1];
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (b >= B) return;
+    const bool dead = b >= B;                                   // such waves still take part in the block barriers
     const int dim = 2 * D;
     // one (h_t, c_t) set per chained collision field f (the reference stacks one block of H-1 rows per field,
     // cost_functions.py:107-144), scaled by sqrt(s_f) so that the solve kernel only has to sum kc h h^T, kc h c, kc c^2
     int fidx = 0;
     for (const float* gp = geom; gp != nullptr; gp = geom_next(gp), ++fidx) {
-    const GeomView G = geom_view(gp);
-    const float rs = __builtin_amdgcn_sqrtf(G.fscale);
-    float* jac = jac_all + (size_t)fidx * B * H * (D + 1);
-    // n_interp > 0 (CostComposite.get_linear_system with n_interpolated_points, cost_functions.py:115-119;
-    // field_factor.py:42-54): the Jacobian row of support point t is d/dq_t of the summed cost of the
-    // INTERPOLATED trajectory, i.e. its own gradient plus (1-a) * grad of every interior point of segment
-    // (t, t+1) plus a * grad of every interior point of segment (t-1, t); the error c_t stays the support
-    // point's own.  Lane t evaluates the interior points of ITS segment once and hands the a-weighted part
-    // to lane t+1 (carry across 64-waypoint chunks).
-    float carry[MPB_MAX_DOF];
+        const GeomView G = geom_view(gp);
+        const bool ug = grid_usable_grad(G);
+        __syncthreads();
+        if (ug) grid_stage(G, gridw, otab, threadIdx.x, blockDim.x);
+        __syncthreads();
+        if (dead) continue;
+        const float rs = __builtin_amdgcn_sqrtf(G.fscale);
+        float* jac = jac_all + (size_t)fidx * B * H * (D + 1);
+        // n_interp > 0 (CostComposite.get_linear_system with n_interpolated_points, cost_functions.py:115-119;
+        // field_factor.py:42-54): the Jacobian row of support point t is d/dq_t of the summed cost of the
+        // INTERPOLATED trajectory, i.e. its own gradient plus (1-a) * grad of every interior point of segment
+        // (t, t+1) plus a * grad of every interior point of segment (t-1, t); the error c_t stays the support
+        // point's own.  Lane t evaluates the interior points of ITS segment once and hands the a-weighted part
+        // to lane t+1 (carry across 64-waypoint chunks).
+        float carry[MPB_MAX_DOF];
 #pragma unroll
-    for (int i = 0; i < MPB_MAX_DOF; ++i) carry[i] = 0.f;
-    for (int base = 0; base < H; base += 64) {
-        const int t = base + lane;
-        const bool active = t < H;
-        const float* row = x + ((size_t)b * H + (active ? t : 0)) * dim;
-        float q[MPB_MAX_DOF], dq[MPB_MAX_DOF], gnext[MPB_MAX_DOF];
-#pragma unroll
-        for (int i = 0; i < MPB_MAX_DOF; ++i) {
-            q[i] = (i < D) ? row[i] : 0.f;
-            dq[i] = 0.f;
-            gnext[i] = 0.f;
-        }
-        float c = 0.f;
-        if (active && t >= 1) c = waypoint_cost<true>(G, q, dq);
-        if (n_interp > 0) {
-            if (active && t + 1 < H) {
-                float qn[MPB_MAX_DOF];
-#pragma unroll
-                for (int i = 0; i < MPB_MAX_DOF; ++i) qn[i] = (i < D) ? row[dim + i] : 0.f;
-                for (int k = 1; k <= n_interp; ++k) {
-                    const float al = (float)k / (float)(n_interp + 1);
-                    float qi[MPB_MAX_DOF], dqi[MPB_MAX_DOF];
-#pragma unroll
-                    for (int i = 0; i < MPB_MAX_DOF; ++i) qi[i] = q[i] + al * (qn[i] - q[i]);
-                    waypoint_cost<true>(G, qi, dqi);
-#pragma unroll
-                    for (int i = 0; i < MPB_MAX_DOF; ++i) {
-                        dq[i] = fmaf(1.f - al, dqi[i], dq[i]);
-                        gnext[i] = fmaf(al, dqi[i], gnext[i]);
-                    }
-                }
-            }
+        for (int i = 0; i < MPB_MAX_DOF; ++i) carry[i] = 0.f;
+        for (int base = 0; base < H; base += 64) {
+            const int t = base + lane;
+            const bool active = t < H;
+            const float* row = x + ((size_t)b * H + (active ? t : 0)) * dim;
+            float q[MPB_MAX_DOF], dq[MPB_MAX_DOF], gnext[MPB_MAX_DOF];
 #pragma unroll
             for (int i = 0; i < MPB_MAX_DOF; ++i) {
-                const float up = __shfl_up(gnext[i], 1, 64);
-                dq[i] += (lane == 0) ? carry[i] : up;
-                carry[i] = __shfl(gnext[i], 63, 64);
+                q[i] = (i < D) ? row[i] : 0.f;
+                dq[i] = 0.f;
+                gnext[i] = 0.f;
+            }
+            float c = 0.f;
+            if (active && t >= 1) c = ug ? waypoint_cost_grid_grad(G, gridw, otab, q, dq) : waypoint_cost<true>(G, q, dq);
+            if (n_interp > 0) {
+                if (active && t + 1 < H) {
+                    float qn[MPB_MAX_DOF];
+#pragma unroll
+                    for (int i = 0; i < MPB_MAX_DOF; ++i) qn[i] = (i < D) ? row[dim + i] : 0.f;
+                    for (int k = 1; k <= n_interp; ++k) {
+                        const float al = (float)k / (float)(n_interp + 1);
+                        float qi[MPB_MAX_DOF], dqi[MPB_MAX_DOF];
+#pragma unroll
+                        for (int i = 0; i < MPB_MAX_DOF; ++i) qi[i] = q[i] + al * (qn[i] - q[i]);
+                        if (ug) waypoint_cost_grid_grad(G, gridw, otab, qi, dqi);
+                        else waypoint_cost<true>(G, qi, dqi);
+#pragma unroll
+                        for (int i = 0; i < MPB_MAX_DOF; ++i) {
+                            dq[i] = fmaf(1.f - al, dqi[i], dq[i]);
+                            gnext[i] = fmaf(al, dqi[i], gnext[i]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < MPB_MAX_DOF; ++i) {
+                    const float up = __shfl_up(gnext[i], 1, 64);
+                    dq[i] += (lane == 0) ? carry[i] : up;
+                    carry[i] = __shfl(gnext[i], 63, 64);
+                }
+            }
+            if (active) {
+                float* o = jac + ((size_t)b * H + t) * (D + 1);
+#pragma unroll
+                for (int i = 0; i < MPB_MAX_DOF; ++i)
+                    if (i < D) o[i] = -rs * dq[i];
+                o[D] = rs * c;
             }
         }
-        if (active) {
-            float* o = jac + ((size_t)b * H + t) * (D + 1);
-#pragma unroll
-            for (int i = 0; i < MPB_MAX_DOF; ++i)
-                if (i < D) o[i] = -rs * dq[i];
-            o[D] = rs * c;
-        }
-    }
     }
 }
 
