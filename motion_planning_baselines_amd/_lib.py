@@ -60,6 +60,9 @@ def lib():
             f'{LIB_PATH} not found: the HIP extension is not built. Run '
             f'`python -c "import __graft_entry__ as g; g.build()"` (or motion_planning_baselines_amd/build.py). '
             f'There is no CPU fallback.')
+    # PyTorch-ROCm ships its own HIP runtime: it has to be in the process BEFORE this library is loaded, so that the
+    # library's libamdhip64 dependency resolves to the runtime torch initialises (a second copy would see no device)
+    import torch  # noqa: F401
     h = ctypes.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         try:

@@ -31,7 +31,7 @@ def precision_to_scale_tril(P):
     Lf = torch.linalg.cholesky(torch.flip(P, (-2, -1)))
     L_inv = torch.transpose(torch.flip(Lf, (-2, -1)), -2, -1)
     Id = torch.eye(P.shape[-1], dtype=P.dtype, device=P.device)
-    return torch.linalg.solve_triangular(L_inv, Id, upper=False)
+    return torch.linalg.solve_triangular(L_inv, Id, upper=False).contiguous()   # (some LAPACK back-ends hand back a transposed view)
 
 
 class STOMP(OptimizationPlanner):
