@@ -108,6 +108,8 @@ int mpb_cost_terms_eval(const float *trajs, float *out, double *jl_total, const 
 int mpb_traj_resample(const float *paths, const int *lengths, float *out, int N, int Lmax, int H, int D, float dt,
                       void *stream);
 int mpb_traj_interpolate(const float *trajs, float *out, int B, int H, int d, int n_interp, void *stream);
+/* GPFactor.get_error (costs/factors/gp_factor.py:52-56): err[b,t] = x[b,t+1] - Phi x[b,t]; x (B,H,2D) -> out (B,H-1,2D) */
+int mpb_gp_factor_error(const float *x, float *out, int B, int H, int D, float dt, void *stream);
 int mpb_traj_finite_difference(const float *pos, float *out, int B, int H, int D, float dt, void *stream);
 
 /* ---------------------------------------------------------------------------------------------

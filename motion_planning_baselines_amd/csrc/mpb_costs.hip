@@ -282,3 +282,28 @@ extern "C" int mpb_traj_resample(const float* paths, const int* lengths, float* 
                        out, Lmax, H, D, dt);
     return mpb_check_launch("mpb_traj_resample");
 }
+
+// ------------------------------------------------------------------------------------------------
+// GP factor error (gp_factor.py:52-56): err[b,t] = x[b,t+1] - Phi x[b,t], Phi = [[I, dt I],[0, I]]; (B,H,2D) -> (B,H-1,2D)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gp_factor_error_kernel(const float* __restrict__ x, float* __restrict__ out, size_t total,
+                                                              int H, int D, float dt) {
+    const int dim = 2 * D;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = e / dim;                       // b * (H-1) + t
+        const int c = (int)(e - row * dim);
+        const size_t b = row / (H - 1);
+        const int t = (int)(row - b * (H - 1));
+        const float* p = x + ((size_t)b * H + t) * dim;
+        out[e] = (c < D) ? p[dim + c] - (p[c] + dt * p[D + c]) : p[dim + c] - p[c];
+    }
+}
+
+extern "C" int mpb_gp_factor_error(const float* x, float* out, int B, int H, int D, float dt, void* stream) {
+    if (B < 0 || H < 2 || D < 1) return mpb_fail(MPB_E_INVALID, "mpb_gp_factor_error: bad shape");
+    if (B == 0) return MPB_OK;
+    if (!x || !out) return mpb_fail(MPB_E_INVALID, "mpb_gp_factor_error: null pointer");
+    const size_t total = (size_t)B * (H - 1) * 2 * D;
+    hipLaunchKernelGGL(gp_factor_error_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, x, out, total, H, D, dt);
+    return mpb_check_launch("mpb_gp_factor_error");
+}

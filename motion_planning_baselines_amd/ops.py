@@ -133,6 +133,15 @@ def cost_terms_eval(trajs, n_dof, dt=0.0, k_gp=0.0, vel_fd=False, k_start=0.0, s
     return out, jl_total
 
 
+def gp_factor_error(x, D, dt):
+    """(B,H,2D) -> (B,H-1,2D): x_{t+1} - Phi x_t (mpb_gp_factor_error)."""
+    B, H, dim = x.shape
+    _chk(x, (B, H, 2 * D), 'x')
+    out = torch.empty(B, H - 1, dim, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().mpb_gp_factor_error(_ptr(x), _ptr(out), B, H, D, float(dt), _stream()), 'mpb_gp_factor_error')
+    return out
+
+
 def traj_interpolate(trajs, n_interp):
     """(B,H,d) -> (B,(H-1)(n+1)+1,d): n evenly spaced joint-space points per segment (mpb_traj_interpolate)."""
     B, H, d = trajs.shape

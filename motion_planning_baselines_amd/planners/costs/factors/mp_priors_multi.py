@@ -1,0 +1,105 @@
+"""MultiMPPrior (mp_baselines/planners/costs/factors/mp_priors_multi.py:15-259): multi-modal constant-velocity GP
+trajectory prior.
+
+The reference materialises the dense M x M precision K^-1 = A^T Q^-1 A (M = state_dim * (num_steps+1)) in fp64 and
+hands it to MultivariateNormal.  With isotropic factors (K_s_inv = I/s_s^2, K_gp_inv = Q^-1(sigma_gp), K_g_inv =
+I/s_g^2 -- what every planner of the reference passes) the precision is block tridiagonal with (2x2) (x) I_dof
+blocks; this class keeps that structured form (planners.base.gp_prior_factor), samples on the GPU
+(mpb_gp_prior_sample / _dense) and builds the dense matrix only when `Sigma_inv` is actually read.
+"""
+import numpy as np
+import torch
+
+from .... import ops
+from ...base import const_vel_mean, gp_prior_factor, gp_prior_scale_tril, require_cuda
+
+
+class MultiMPPrior:
+
+    def __init__(self, num_steps, dt, state_dim, dof, K_s_inv, K_gp_inv, start_state, means=None, K_g_inv=None,
+                 goal_states=None, use_numpy=False, tensor_args=None, noise='torch_cpu', seed=0):
+        self.state_dim, self.dof, self.num_steps, self.dt = state_dim, dof, num_steps, dt
+        assert state_dim == 2 * dof
+        self.M = state_dim * (num_steps + 1)
+        self.tensor_args = tensor_args
+        self.device = require_cuda(dict(tensor_args, dtype=torch.float32))
+        self.goal_directed = goal_states is not None
+        self.noise, self.seed = noise, int(seed)
+        H = num_steps + 1
+        # isotropic factors only: recover the sigmas and check the structure
+        Ks = torch.as_tensor(K_s_inv).detach().cpu().double()
+        Kgp = torch.as_tensor(K_gp_inv).detach().cpu().double()
+        self.sigma_start = float(Ks[0, 0]) ** -0.5
+        self.sigma_gp = (float(Kgp[0, 0]) * dt ** 3 / 12.0) ** -0.5
+        I = torch.eye(dof, dtype=torch.float64)
+        qa, qb, qc = 12.0 / dt ** 3, -6.0 / dt ** 2, 4.0 / dt
+        Qi = torch.cat((torch.cat((qa * I, qb * I), 1), torch.cat((qb * I, qc * I), 1)), 0) / self.sigma_gp ** 2
+        ok = torch.allclose(Ks, torch.eye(state_dim, dtype=torch.float64) / self.sigma_start ** 2, rtol=1e-6) and \
+            torch.allclose(Kgp, Qi, rtol=1e-6, atol=1e-12 * float(Qi.abs().max()))
+        self.sigma_goal = None
+        if self.goal_directed:
+            Kg = torch.as_tensor(K_g_inv).detach().cpu().double()
+            self.sigma_goal = float(Kg[0, 0]) ** -0.5
+            ok = ok and torch.allclose(Kg, torch.eye(state_dim, dtype=torch.float64) / self.sigma_goal ** 2, rtol=1e-6)
+        if not ok:
+            raise NotImplementedError('MultiMPPrior on the GPU serves isotropic start / GP / goal factors '
+                                      '(K = I / sigma^2, Q_c = I / sigma_gp^2), the form every reference planner uses')
+        if means is None:
+            self.num_modes = goal_states.shape[0] if self.goal_directed else 1
+            s = torch.as_tensor(start_state).detach().cpu().double()
+            if self.goal_directed:
+                g = torch.as_tensor(goal_states).detach().cpu().double()
+                means = torch.stack([const_vel_mean(s[:dof], g[i, :dof], H, dt) for i in range(self.num_modes)])
+            else:
+                means = s.repeat(H, 1).unsqueeze(0)                     # mp_priors_multi.py:176
+        else:
+            self.num_modes = means.shape[0]
+        self.means = torch.as_tensor(means).detach().reshape(self.num_modes, -1).to(self.device, torch.float64)
+        self._Ud, self._Uo = gp_prior_factor(H, dt, self.sigma_start, self.sigma_gp, self.sigma_goal)
+        f64 = lambda a: torch.as_tensor(a, dtype=torch.float64).to(self.device).contiguous()
+        self._Ud_d, self._Uo_d = f64(self._Ud), f64(self._Uo)
+        self._tril = f64(gp_prior_scale_tril(self._Ud, self._Uo)) if H <= 128 else None
+        self._Sigma_inv = None
+        self._draws = 0
+
+    # ---- dense views (built on demand, fp64 on the host like the reference) --------------------------
+    @property
+    def Sigma_inv(self):
+        """Dense precision K^-1 (M x M), index t*state_dim + c (mp_priors_multi.py:213-251)."""
+        if self._Sigma_inv is None:
+            H, D = self.num_steps + 1, self.dof
+            U = np.zeros((2 * H, 2 * H))
+            for t in range(H):
+                U[2 * t, 2 * t], U[2 * t, 2 * t + 1], U[2 * t + 1, 2 * t + 1] = self._Ud[t]
+                if t < H - 1:
+                    U[2 * t:2 * t + 2, 2 * t + 2:2 * t + 4] = self._Uo[t].reshape(2, 2)
+            P1 = U @ U.T                                                # one degree of freedom, index 2t + {pos, vel}
+            K = np.zeros((self.M, self.M))
+            for d in range(D):
+                idx = np.array([[t * 2 * D + d, t * 2 * D + D + d] for t in range(H)]).reshape(-1)
+                K[np.ix_(idx, idx)] = P1
+            self._Sigma_inv = torch.from_numpy(K).to(**self.tensor_args)
+        return self._Sigma_inv
+
+    @property
+    def Sigma_invs(self):
+        return self.Sigma_inv.repeat(self.num_modes, 1, 1)
+
+    def get_mean(self, reshape=True):
+        m = self.means.clone().detach()
+        return m.reshape(self.num_modes, self.num_steps + 1, self.state_dim) if reshape else m
+
+    def set_mean(self, means_new):
+        assert means_new.shape == self.means.shape
+        self.means = means_new.clone().detach().to(self.device, torch.float64)
+
+    def sample(self, num_samples):
+        """(num_modes, num_samples, H, state_dim) like the reference's `.transpose(1, 0)` view (:253-256)."""
+        H, dim = self.num_steps + 1, self.state_dim
+        eps = None
+        if self.noise != 'philox':
+            eps = torch.empty(num_samples, self.num_modes, H * dim, dtype=torch.float64).normal_().to(self.device)
+        out = ops.gp_prior_sample(self.means.reshape(self.num_modes, H, dim).contiguous(), eps, self._Ud_d, self._Uo_d,
+                                  num_samples, self.dof, seed=self.seed + self._draws, scale_tril=self._tril)
+        self._draws += 1
+        return out.reshape(self.num_modes, num_samples, H, dim).to(self.tensor_args.get('dtype', torch.float32))
