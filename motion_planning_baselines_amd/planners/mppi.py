@@ -12,42 +12,8 @@ from .base import MPPlanner, require_cuda
 from .costs.cost_functions import fusable_collision
 
 
-def diag_Cov(sigma, length, ctrl_dim, tensor_args):
-    """Time-independent diagonal covariance (gaussian.py:143-163); (T,T,c)."""
-    Cov = torch.eye(length, **tensor_args).unsqueeze(-1).repeat(1, 1, ctrl_dim)
-    if isinstance(sigma, (list, tuple)):
-        return Cov * torch.Tensor(np.array(sigma)).to(**tensor_args) ** 2
-    return Cov * sigma ** 2
-
-
-def const_ctrl_Cov(sigma, length, ctrl_dim, tensor_args):
-    """Constant-control covariance prior (gaussian.py:166-198); (T,T,c)."""
-    if isinstance(sigma, (list, tuple)):
-        sigma = torch.from_numpy(np.array(sigma)).to(**tensor_args)
-    L = torch.tril(torch.ones(length, length - 1, **tensor_args), diagonal=-1)
-    LL_t = torch.matmul(L, L.transpose(0, 1)) + torch.ones(length, length, **tensor_args)
-    return LL_t.unsqueeze(-1).repeat(1, 1, ctrl_dim) * sigma ** 2
-
-
-class PointParticleDynamics:
-    """Parameters of the reference's point-particle system (dynamics/point.py:5-74); the dynamics and
-    trajectory cost themselves run inside the MPPI kernel."""
-
-    def __init__(self, rollout_steps=None, control_dim=2, state_dim=2, dt=0.01, discount=1.0, goal_state=None,
-                 ctrl_min=None, ctrl_max=None, control_type='velocity', c_weights=None, tensor_args=None, **kwargs):
-        if control_type != 'velocity':
-            raise IOError('only control_type "velocity" is served (the reference\'s acceleration mode cannot run)')
-        self.control_dim = control_dim
-        self.state_dim = state_dim
-        self.dt = dt
-        self.rollout_steps = rollout_steps
-        self.tensor_args = tensor_args
-        self._c_weights = c_weights or {'pos': 10., 'vel': 10., 'ctrl': 0., 'pos_T': 10., 'vel_T': 0.}
-        assert len(ctrl_min) == control_dim and len(ctrl_max) == control_dim
-        self.ctrl_min, self.ctrl_max = list(ctrl_min), list(ctrl_max)
-        self.goal_state = goal_state
-        seq = torch.cumprod(torch.ones(rollout_steps) * discount, dim=0) / discount   # point.py:145-152
-        self.discount_seq = seq
+from .dynamics.point import PointParticleDynamics  # noqa: F401  (import path of the reference kept: planners.dynamics.point)
+from .priors.gaussian import check_Cov_is_valid, const_ctrl_Cov, diag_Cov  # noqa: F401
 
 
 class MPPI(MPPlanner):
