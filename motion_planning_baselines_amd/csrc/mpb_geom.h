@@ -501,11 +501,13 @@ __device__ __forceinline__ void spheres_hinge_grid(const GeomView& G, const unsi
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const float fx = (x[i] - G.glx) * G.gix, fy = (y[i] - G.gly) * G.giy, fz = (z[i] - G.glz) * G.giz;
-        const int ix = (int)floorf(fx), iy = (int)floorf(fy), iz = (int)floorf(fz);
-        const bool inb = (unsigned)ix < (unsigned)G.gnx && (unsigned)iy < (unsigned)G.gny && (unsigned)iz < (unsigned)G.gnz;
-        const int cell = inb ? (iz * G.gny + iy) * G.gnx + ix : 0;
-        const unsigned wv = gridw[cell];
-        w[i] = inb ? wv : MPB_GRID_EMPTY;
+        // a point outside the grid box is farther than margin + r_l from every obstacle (the box is the bounding box
+        // of the inflated obstacles), so whatever candidates its CLAMPED cell lists all give hinge 0 exactly: no
+        // in-bounds test, three v_med3 + two 24-bit mads (the float -> int conversion saturates: parked slots at 1e9
+        // are safe)
+        const int ix = min(max((int)floorf(fx), 0), G.gnx - 1), iy = min(max((int)floorf(fy), 0), G.gny - 1),
+                  iz = min(max((int)floorf(fz), 0), G.gnz - 1);
+        w[i] = gridw[__mul24(__mul24(iz, G.gny) + iy, G.gnx) + ix];
         best[i] = 3.0e38f;
         over |= __ballot(w[i] == MPB_GRID_OVERFLOW);
     }
@@ -622,11 +624,10 @@ __device__ __forceinline__ void spheres_nearest_grid(const GeomView& G, const un
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const float fx = (x[i] - G.glx) * G.gix, fy = (y[i] - G.gly) * G.giy, fz = (z[i] - G.glz) * G.giz;
-        const int ix = (int)floorf(fx), iy = (int)floorf(fy), iz = (int)floorf(fz);
-        const bool inb = (unsigned)ix < (unsigned)G.gnx && (unsigned)iy < (unsigned)G.gny && (unsigned)iz < (unsigned)G.gnz;
-        const int cell = inb ? (iz * G.gny + iy) * G.gnx + ix : 0;
-        const unsigned wv = gridw[cell];
-        w[i] = inb ? wv : MPB_GRID_EMPTY;
+        // clamped cell index (exact: see spheres_hinge_grid)
+        const int ix = min(max((int)floorf(fx), 0), G.gnx - 1), iy = min(max((int)floorf(fy), 0), G.gny - 1),
+                  iz = min(max((int)floorf(fz), 0), G.gnz - 1);
+        w[i] = gridw[__mul24(__mul24(iz, G.gny) + iy, G.gnx) + ix];
         best[i] = 3.0e38f;
         vx[i] = vy[i] = vz[i] = 0.f;
         vn[i] = 1.f;
