@@ -113,6 +113,24 @@ int mpb_gp_factor_error(const float *x, float *out, int B, int H, int D, float d
 int mpb_traj_finite_difference(const float *pos, float *out, int B, int H, int D, float dt, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The robot / field API the reference's cost layer consumes (provider in the reference: torch_robotics), as separate
+ * device ops with vector-Jacobian products, so that the UNMODIFIED reference cost classes can run on this package's
+ * robot / field objects and torch.autograd can differentiate through them (field_factor.py:54):
+ *   mpb_fk_collision_points      robot.fk_map_collision (call site cost_functions.py:52): q (B,H,d) -> pts (B,H,L,3)
+ *   mpb_fk_collision_points_vjp  grad_q (B,H,n_dof) = J^T grad_pts
+ *   mpb_field_cost_points        field.compute_cost (call sites field_factor.py:39,52): pts (B,H,L,3) -> cost (B,H)
+ *                                = sum_l relu(margin + r_l - min_o sdf_o(pts_l))   (first field of `geom`)
+ *   mpb_field_cost_points_vjp    grad_pts (B,H,L,3) = grad_cost (B,H) * d cost / d pts
+ * The planners never call these (they use the fused evaluators); L = number of collision spheres of the robot.
+ * ------------------------------------------------------------------------------------------- */
+int mpb_fk_collision_points(const float *q, const float *geom, float *pts, int B, int H, int d, void *stream);
+int mpb_fk_collision_points_vjp(const float *q, const float *geom, const float *grad_pts, float *grad_q,
+                                int B, int H, int d, void *stream);
+int mpb_field_cost_points(const float *pts, const float *geom, float *cost, int B, int H, void *stream);
+int mpb_field_cost_points_vjp(const float *pts, const float *geom, const float *grad_cost, float *grad_pts,
+                              int B, int H, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * STOMP -- replaces STOMP._run_optimization's loop body (stomp.py:150-160):
  *   sample (stomp.py:97-108 + MultivariateNormal.rsample), _get_costs (base.py:218-223) with the
  *   collision cost above, _calc_sample_weights (stomp.py:219-220), _update_distribution (:199-211).

@@ -29,6 +29,10 @@ SIGNATURES = {
     'mpb_gp_factor_error': [_p, _p, _i, _i, _i, _f, _p],
     'mpb_traj_interpolate': [_p, _p, _i, _i, _i, _i, _p],
     'mpb_traj_finite_difference': [_p, _p, _i, _i, _i, _f, _p],
+    'mpb_fk_collision_points': [_p, _p, _p, _i, _i, _i, _p],
+    'mpb_fk_collision_points_vjp': [_p, _p, _p, _p, _i, _i, _i, _p],
+    'mpb_field_cost_points': [_p, _p, _p, _i, _i, _p],
+    'mpb_field_cost_points_vjp': [_p, _p, _p, _p, _i, _i, _p],
     'mpb_stomp_step': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _u64, _u32, _u32, _p],
     'mpb_stomp_sample': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _u64, _u32, _u32, _p],
     'mpb_stomp_update': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],

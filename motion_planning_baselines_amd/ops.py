@@ -133,6 +133,46 @@ def cost_terms_eval(trajs, n_dof, dt=0.0, k_gp=0.0, vel_fd=False, k_start=0.0, s
     return out, jl_total
 
 
+def fk_collision_points(q, geom):
+    """q (B,H,d) -> positions of the robot's collision spheres (B,H,L,3) (mpb_fk_collision_points)."""
+    B, H, d = q.shape
+    _chk(q, (B, H, d), 'q')
+    L = int(geom.host.view(np.int32)[5])
+    pts = torch.empty(B, H, L, 3, device=q.device, dtype=torch.float32)
+    _lib.check(_lib.lib().mpb_fk_collision_points(_ptr(q), _ptr(geom.buf), _ptr(pts), B, H, d, _stream()), 'mpb_fk_collision_points')
+    return pts
+
+
+def fk_collision_points_vjp(q, geom, grad_pts):
+    B, H, d = q.shape
+    L = int(geom.host.view(np.int32)[5])
+    _chk(q, (B, H, d), 'q')
+    _chk(grad_pts, (B, H, L, 3), 'grad_pts')
+    gq = torch.empty(B, H, geom.n_dof, device=q.device, dtype=torch.float32)
+    _lib.check(_lib.lib().mpb_fk_collision_points_vjp(_ptr(q), _ptr(geom.buf), _ptr(grad_pts), _ptr(gq), B, H, d, _stream()),
+               'mpb_fk_collision_points_vjp')
+    return gq
+
+
+def field_cost_points(pts, geom):
+    """Collision-sphere positions (B,H,L,3) -> hinge cost per waypoint (B,H) (mpb_field_cost_points)."""
+    B, H, L, _ = pts.shape
+    _chk(pts, (B, H, int(geom.host.view(np.int32)[5]), 3), 'pts')
+    cost = torch.empty(B, H, device=pts.device, dtype=torch.float32)
+    _lib.check(_lib.lib().mpb_field_cost_points(_ptr(pts), _ptr(geom.buf), _ptr(cost), B, H, _stream()), 'mpb_field_cost_points')
+    return cost
+
+
+def field_cost_points_vjp(pts, geom, grad_cost):
+    B, H, L, _ = pts.shape
+    _chk(pts, (B, H, int(geom.host.view(np.int32)[5]), 3), 'pts')
+    _chk(grad_cost, (B, H), 'grad_cost')
+    gp = torch.empty_like(pts)
+    _lib.check(_lib.lib().mpb_field_cost_points_vjp(_ptr(pts), _ptr(geom.buf), _ptr(grad_cost), _ptr(gp), B, H, _stream()),
+               'mpb_field_cost_points_vjp')
+    return gp
+
+
 def gp_factor_error(x, D, dt):
     """(B,H,2D) -> (B,H-1,2D): x_{t+1} - Phi x_t (mpb_gp_factor_error)."""
     B, H, dim = x.shape

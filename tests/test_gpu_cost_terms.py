@@ -376,3 +376,50 @@ def test_factor_classes(gpu_device):
     with pytest.raises(NotImplementedError):
         MultiMPPrior(H2n - 1, float(gp8['dt']), 2 * D2, D2, sK * torch.arange(1, 2 * D2 + 1).diag().double(), Qi,
                      T(gp8['start']), tensor_args=ta64d)
+
+
+@pytest.mark.parametrize('kind', ['pm2d', 'panda', 'panda_boxes_only'])
+def test_robot_field_api_with_autograd(gpu_device, kind):
+    """The duck-typed robot / field objects (fk_map_collision, compute_cost) drive the oracle's restatement of
+    CostCollision.eval -- written against that API exactly like the reference's cost layer -- on GPU tensors; values
+    and autograd gradients equal the fused kernels and the CPU oracle."""
+    from motion_planning_baselines_amd import geometry as G, ops
+    from motion_planning_baselines_amd.robot_field import device_robot_field
+    from oracle import planners_ref as O
+    from oracle.geometry_ref import make_ref_geometry
+    dev = gpu_device
+    if kind == 'pm2d':
+        robot, field = G.RobotPointMass(2, radius=0.02), G.env_dense_2d()
+    elif kind == 'panda':
+        robot, field = G.RobotPanda(), G.env_spheres_3d()
+    else:   # no spheres -> no broad-phase grid: exhaustive evaluator
+        robot, field = G.RobotPanda(), G.CollisionField(boxes=np.array([[0.4, 0.0, 0.4, 0.2, 0.6, 0.3]], np.float32), margin=0.05)
+    D, H, B = robot.q_dim, 24, 19
+    gen = torch.Generator().manual_seed(3)
+    qmin, qmax = torch.from_numpy(robot.q_min_np), torch.from_numpy(robot.q_max_np)
+    x = torch.cat([qmin + (qmax - qmin) * torch.rand(B, H, D, generator=gen), torch.randn(B, H, D, generator=gen)], -1)
+    drobot, dfield = device_robot_field(robot, field, dev)
+    xd = x.to(dev).requires_grad_(True)
+    cost = O.collision_cost(xd, drobot, dfield, 0.5)                      # oracle code, device objects
+    cost.sum().backward()
+    ta64 = dict(device='cpu', dtype=torch.float64)
+    rr, rf = make_ref_geometry(robot, field, ta64)
+    x64 = x.double().requires_grad_(True)
+    want = O.collision_cost(x64, rr, rf, 0.5)
+    want.sum().backward()
+    assert float(want.detach().max()) > 0
+    _close(cost.detach(), want.detach().numpy(), RTOL)
+    diff = (xd.grad.cpu().double() - x64.grad).abs()
+    tol = 3e-4 * x64.grad.abs().max() + 3e-4 * x64.grad.abs()
+    assert float((diff > tol).float().mean()) < 3e-3
+    assert float(xd.grad[..., D:].abs().max()) == 0.0                     # no dependence on the velocity channels
+    # the same numbers from the fused kernels
+    geom = ops.DeviceGeometry(robot, field, dev)
+    fused, fgrad = ops.cost_collision_grad(x.to(dev), geom, 1.0 / 0.5 ** 2)
+    _close(fused, cost.detach().cpu().double().numpy(), 1e-5)
+    assert torch.allclose(fgrad, xd.grad, rtol=1e-4, atol=1e-4 * float(xd.grad.abs().max()))
+    # FK positions themselves
+    pts = drobot.fk_map_collision(x.to(dev)[..., :D])
+    ref_pts = rr.fk_map_collision(x.double()[..., :D])
+    assert pts.shape == ref_pts.shape
+    _close(pts, ref_pts.numpy(), 1e-5)
