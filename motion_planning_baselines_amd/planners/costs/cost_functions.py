@@ -40,6 +40,20 @@ class Cost(ABC):
     def get_linear_system(self, trajs, **kwargs):
         pass
 
+    def get_q_pos_vel_and_fk_map(self, trajs, **kwargs):
+        """cost_functions.py:41-53: (trajs (B,H,d), q_pos, q_vel, H_positions) with H_positions = positions of the
+        robot's collision spheres (B,H,L,3), computed by the FK kernel (mpb_fk_collision_points)."""
+        trajs = self._as_3d(trajs)
+        q_pos = self.robot.get_position(trajs)
+        q_vel = self.robot.get_velocity(trajs)
+        geom = self.__dict__.get('_fk_geom')
+        if geom is None or geom.buf.device != trajs.device:
+            import numpy as np
+            from ...geometry import CollisionField
+            far = CollisionField(spheres=np.array([[1.0e6, 1.0e6, 1.0e6, 1.0]], np.float32))     # FK only: the field is unused
+            geom = self.__dict__['_fk_geom'] = ops.DeviceGeometry(self.robot, far, trajs.device)
+        return trajs, q_pos, q_vel, ops.fk_collision_points(trajs, geom)
+
     @staticmethod
     def _as_3d(trajs):
         """Accept (B,H,d) or (N,B,H,d) like get_q_pos_vel_and_fk_map (cost_functions.py:41-48)."""
