@@ -205,3 +205,32 @@ def test_mppi_shapes_vs_oracle(gpu_device, NP, S, Tn, c, with_geom):
         np.testing.assert_allclose(costs[p].cpu().numpy(), out['costs'].reshape(-1).numpy(), rtol=2e-4)
         np.testing.assert_allclose(weights[p].cpu().numpy(), out['weights'].reshape(-1).numpy(), rtol=5e-2, atol=1e-5)
         assert rel_err(mean[p], m) < 2e-4
+
+
+def test_new_entry_points_empty_and_invalid(gpu_device):
+    """Empty batches are accepted, wrong shapes / devices rejected on the host, for the round-1 late additions."""
+    from motion_planning_baselines_amd import geometry as G, ops
+    from motion_planning_baselines_amd._lib import MPBError
+    dev = gpu_device
+    robot, field = G.RobotPanda(), G.env_spheres_3d()
+    geom = ops.DeviceGeometry(robot, field, dev)
+    assert ops.fk_collision_points(torch.empty(0, 8, 7, device=dev), geom).shape == (0, 8, 31, 3)
+    assert ops.field_cost_points(torch.empty(0, 8, 31, 3, device=dev), geom).shape == (0, 8)
+    assert ops.gp_factor_error(torch.empty(0, 8, 14, device=dev), 7, 0.1).shape == (0, 7, 14)
+    assert ops.traj_resample(torch.empty(0, 5, 7, device=dev), torch.empty(0, dtype=torch.int32, device=dev), 16, 0.1).shape == (0, 16, 14)
+    with pytest.raises(ValueError):
+        ops.field_cost_points(torch.zeros(2, 8, 30, 3, device=dev), geom)            # wrong number of collision spheres
+    with pytest.raises(ValueError):
+        ops.fk_collision_points(torch.zeros(2, 8, 7), geom)                           # CPU tensor
+    with pytest.raises(ValueError):
+        ops.gp_factor_error(torch.zeros(2, 8, 13, device=dev), 7, 0.1)                # d != 2D
+    with pytest.raises(MPBError):
+        ops.traj_resample(torch.zeros(2, 5, 7, device=dev), torch.full((2,), 5, dtype=torch.int32, device=dev), 1, 0.1)   # H < 2
+    from motion_planning_baselines_amd import _lib
+    import ctypes
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    out = torch.empty(2, 200, 4, device=dev)
+    rc = _lib.lib().mpb_gp_prior_sample_dense(p(out), p(torch.zeros(1, 200, 4, dtype=torch.float64, device=dev)), ctypes.c_void_p(0),
+                                              p(torch.eye(400, dtype=torch.float64, device=dev)), 1, 2, 200, 2, 0, ctypes.c_void_p(0))
+    assert rc == 2 and b'H > 128' in _lib.lib().mpb_last_error()          # MPB_E_UNSUPPORTED, nothing launched
+    torch.cuda.synchronize()
