@@ -479,6 +479,27 @@ __device__ __forceinline__ bool grid_usable(const GeomView& G) {
     return G.n_cells > 0 && G.n_cells <= MPB_GRID_MAX_CELLS && G.n_sph <= MPB_GRID_MAX_SPH;
 }
 
+// clamped cell of a point, all in fp32: 3 fma + 3 floor + 3 med3 + 2 fma + 1 cvt (the integer formulation needs
+// floor-convert + min + max per axis and two integer mads, one of them quarter rate).  Cell coordinates and the
+// cell count stay below 2^24, so the float index arithmetic is exact; fma(x, inv, -lo * inv) differs from the
+// host's (x - lo) * inv by ~1e-6 cells, inside the 1e-5 m the host adds to the candidate radius for exactly this
+// (geometry.py build_grid).  NaN / inf coordinates land in some valid cell.
+// FP32 = false keeps the integer formulation: the gradient evaluators are register-bound, and the eight uniform float
+// constants of the fp32 form cost them more than the shorter index arithmetic saves (cost+grad +5 %, measured).
+template <bool FP32>
+__device__ __forceinline__ unsigned grid_cell(const GeomView& G, float x, float y, float z) {
+    if (!FP32) {
+        const float fx = (x - G.glx) * G.gix, fy = (y - G.gly) * G.giy, fz = (z - G.glz) * G.giz;
+        const int ix = min(max((int)floorf(fx), 0), G.gnx - 1), iy = min(max((int)floorf(fy), 0), G.gny - 1),
+                  iz = min(max((int)floorf(fz), 0), G.gnz - 1);
+        return (unsigned)(__mul24(__mul24(iz, G.gny) + iy, G.gnx) + ix);
+    }
+    const float fx = __builtin_amdgcn_fmed3f(floorf(fmaf(x, G.gix, -G.glx * G.gix)), 0.f, (float)(G.gnx - 1));
+    const float fy = __builtin_amdgcn_fmed3f(floorf(fmaf(y, G.giy, -G.gly * G.giy)), 0.f, (float)(G.gny - 1));
+    const float fz = __builtin_amdgcn_fmed3f(floorf(fmaf(z, G.giz, -G.glz * G.giz)), 0.f, (float)(G.gnz - 1));
+    return (unsigned)fmaf(fmaf(fz, (float)G.gny, fy), (float)G.gnx, fx);
+}
+
 // cooperative staging by `nthreads` threads (caller synchronises before and after)
 __device__ __forceinline__ void grid_stage(const GeomView& G, unsigned* gridw, float4* otab, int tid, int nthreads) {
     for (int i = tid; i < G.n_cells; i += nthreads) gridw[i] = G.grid[i];
@@ -500,14 +521,10 @@ __device__ __forceinline__ void spheres_hinge_grid(const GeomView& G, const unsi
     unsigned long long over = 0ull;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const float fx = (x[i] - G.glx) * G.gix, fy = (y[i] - G.gly) * G.giy, fz = (z[i] - G.glz) * G.giz;
         // a point outside the grid box is farther than margin + r_l from every obstacle (the box is the bounding box
         // of the inflated obstacles), so whatever candidates its CLAMPED cell lists all give hinge 0 exactly: no
-        // in-bounds test, three v_med3 + two 24-bit mads (the float -> int conversion saturates: parked slots at 1e9
-        // are safe)
-        const int ix = min(max((int)floorf(fx), 0), G.gnx - 1), iy = min(max((int)floorf(fy), 0), G.gny - 1),
-                  iz = min(max((int)floorf(fz), 0), G.gnz - 1);
-        w[i] = gridw[__mul24(__mul24(iz, G.gny) + iy, G.gnx) + ix];
+        // in-bounds test (parked slots at 1e9 clamp to the last cell)
+        w[i] = gridw[grid_cell<true>(G, x[i], y[i], z[i])];
         best[i] = 3.0e38f;
         over |= __ballot(w[i] == MPB_GRID_OVERFLOW);
     }
@@ -531,8 +548,8 @@ __device__ __forceinline__ void spheres_hinge_grid(const GeomView& G, const unsi
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 const unsigned idx = w[i] & 0xFFu;
-                w[i] = (w[i] >> 8) | 0xFF000000u;
-                s[i] = otab[idx == 0xFFu ? (unsigned)G.n_sph : idx];
+                w[i] = __builtin_amdgcn_alignbit(0xFFFFFFFFu, w[i], 8);   // (w >> 8) | 0xFF000000 in one instruction
+                s[i] = otab[min(idx, (unsigned)G.n_sph)];   // 0xFF (no candidate) -> the far dummy at n_sph
             }
 #pragma unroll
             for (int i = 0; i < N; ++i) {
@@ -623,11 +640,7 @@ __device__ __forceinline__ void spheres_nearest_grid(const GeomView& G, const un
     unsigned long long over = 0ull;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const float fx = (x[i] - G.glx) * G.gix, fy = (y[i] - G.gly) * G.giy, fz = (z[i] - G.glz) * G.giz;
-        // clamped cell index (exact: see spheres_hinge_grid)
-        const int ix = min(max((int)floorf(fx), 0), G.gnx - 1), iy = min(max((int)floorf(fy), 0), G.gny - 1),
-                  iz = min(max((int)floorf(fz), 0), G.gnz - 1);
-        w[i] = gridw[__mul24(__mul24(iz, G.gny) + iy, G.gnx) + ix];
+        w[i] = gridw[grid_cell<false>(G, x[i], y[i], z[i])];   // clamped cell index (exact: see spheres_hinge_grid)
         best[i] = 3.0e38f;
         vx[i] = vy[i] = vz[i] = 0.f;
         vn[i] = 1.f;
@@ -661,8 +674,8 @@ __device__ __forceinline__ void spheres_nearest_grid(const GeomView& G, const un
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 const unsigned idx = w[i] & 0xFFu;
-                w[i] = (w[i] >> 8) | 0xFF000000u;
-                s[i] = otab[idx == 0xFFu ? (unsigned)G.n_sph : idx];
+                w[i] = __builtin_amdgcn_alignbit(0xFFFFFFFFu, w[i], 8);   // (w >> 8) | 0xFF000000 in one instruction
+                s[i] = otab[min(idx, (unsigned)G.n_sph)];   // 0xFF (no candidate) -> the far dummy at n_sph
             }
 #pragma unroll
             for (int i = 0; i < N; ++i) visit(i, s[i]);
