@@ -15,8 +15,11 @@
 // Solve per particle by block elimination (block Thomas):
 //   S_0 = D_0, r_0 = g_0;   W_t = S_t^-1, z_t = W_t r_t;   S_{t+1} = D_{t+1} - U^T W_t U;  r_{t+1} = g_{t+1} - U^T z_t
 //   dtheta_{H-1} = z_{H-1};  dtheta_t = z_t - W_t U dtheta_{t+1}
-// One wave per particle; the 2D x 2D blocks live in LDS as 16 x 16 fp64 tiles; W_t, z_t go to a
-// caller-provided workspace.  All arithmetic is fp64: the weights reach 1/sigma^2 = 1e10 (gpmp2.py:32-35)
+// Two waves per particle: the elimination runs from BOTH ends of the chain towards the middle row m = (H-1)/2 (the
+// bottom-up wave is the same recursion on the reversed chain, whose coupling block is U^T), the merge row collects
+// both Schur complements and both right-hand-side carries, and the substitution runs outwards from it in both
+// directions at once -- half the sequential depth.  The 2D x 2D blocks are 16 x 16 fp64 tiles held in registers
+// (MFMA C layout); W_t (upper triangle: it is symmetric) and z_t go to a caller-provided workspace.  All arithmetic is fp64: the weights reach 1/sigma^2 = 1e10 (gpmp2.py:32-35)
 // and fp32 Cholesky at that conditioning is not reproducible; storage stays fp32.
 #include "mpb_common.h"
 #include "mpb_geom.h"
@@ -160,15 +163,16 @@ __global__ void gpmp2_scale_kernel(const double* __restrict__ in, double* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// block-tridiagonal solve + update, one wave per particle.
+// block-tridiagonal solve + update, two waves per particle (one when H < 4).
 //
 // U = -Phi^T Qi is (2x2) (x) I_D, so F_t = S_t^-1 U is a combination of column blocks of W_t = S_t^-1 and
 //   S_{t+1} = D_{t+1} - U^T W_t U,   z_t = W_t r_t,   r_{t+1} = g_{t+1} - U^T z_t,
-//   dtheta_t = z_t - W_t (U dtheta_{t+1}).
+//   dtheta_t = z_t - W_t (U dtheta_{t+1})
+// for the top-down wave (rows 0 .. m); the bottom-up wave (rows H-1 .. m+1) runs the same formulas with U^T in place
+// of U and t-1 in place of t+1.  Row m: S_m = D_m - U^T W_{m-1} U - U W_{m+1} U^T, r_m likewise, dtheta_m = S_m^-1 r_m.
 // The only dense operation per waypoint is the SPD inverse W_t: blocked Gauss-Jordan (no pivoting: the
 // pivot blocks of an SPD matrix are SPD) on a 16 x 16 fp64 tile with 4 x 4 pivot blocks; each block step is
-// one v_mfma_f64_16x16x4_f64 rank-4 update of the whole tile, ping-ponging between two LDS buffers
-// (4 wave-level synchronisations per inverse).
+// one v_mfma_f64_16x16x4_f64 rank-4 update of the whole tile, operands and result in registers.
 // ------------------------------------------------------------------------------------------------
 // 1/x in fp64: v_rcp_f64 (about 2^-26 accurate) + two Newton steps; the IEEE division hipcc emits costs
 // ~40 instructions and there are 16 of them per waypoint in the pivot-block inverses
@@ -194,32 +198,52 @@ struct GpConst {
     int trust;
 };
 
-#define GP_WS_PER_T (GP_N * GP_N + GP_N)   // workspace doubles per waypoint: W_t (16x16 row-major) + z_t
+// workspace doubles per waypoint: the upper triangle of the symmetric W_t (16x16 padded, row-major packed) + z_t.
+// The substitution pass is bound by this traffic at large B, so only the triangle is kept (152 instead of 272 words).
+#define GP_TRI (GP_N * (GP_N + 1) / 2)
+#define GP_WS_PER_T (GP_TRI + GP_N)
+__device__ __forceinline__ int gp_tri(int i, int j) { return i * GP_N - ((i * (i - 1)) >> 1) + (j - i); }   // i <= j
 
 // DT > 0: the number of degrees of freedom is a compile-time constant (loop bounds, pivot-block count and the
 // position/velocity index tests fold away); DT == 0: generic.
 template <int DT, bool MULTI>
-__global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, const float* __restrict__ start,
-                                                         const float* __restrict__ goal, const float* __restrict__ jac,
-                                                         const double* __restrict__ diag_mean, double* __restrict__ work,
-                                                         float* __restrict__ costs_out, int B, int H, int Drt, int Frt, GpConst K) {
+__global__ __launch_bounds__(128) void gpmp2_solve_kernel(float* __restrict__ x, const float* __restrict__ start,
+                                                          const float* __restrict__ goal, const float* __restrict__ jac,
+                                                          const double* __restrict__ diag_mean, double* __restrict__ work,
+                                                          float* __restrict__ costs_out, int B, int H, int Drt, int Frt, int split, GpConst K) {
     const int D = DT ? DT : Drt;
     const int F = MULTI ? Frt : 1;       // MULTI == false: one collision field, the field loops fold away
-    __shared__ double Sb[1][GP_N * GP_LD];  // W_t for the matvec / next-tile reads (the inverse itself runs in registers)
-    __shared__ double xs[2][GP_N];          // x_t, x_{t+1} (fp64 copies)
-    __shared__ double rv[GP_N];             // r_t
-    __shared__ double zv[GP_N];             // z_t / scratch vector
-    __shared__ double dth[GP_N];            // dtheta_{t+1} during the backward pass
-    __shared__ double hv[MPB_MAX_FIELDS][GP_N];   // per field: collision Jacobian h_t (D values) and cost c_t at [D]
-    const int lane = threadIdx.x;
+    // every wave owns a private set of the per-step LDS vectors; the ex_* words are the hand-over at the merge row
+    __shared__ double Sb_[2][GP_N * GP_LD];  // W_t for the matvec / next-tile reads (the inverse itself runs in registers)
+    __shared__ double xs_[2][2][GP_N];       // x_t and the neighbour row towards the merge row (fp64 copies)
+    __shared__ double rv_[2][GP_N];          // r_t
+    __shared__ double zv_[2][GP_N];          // z_t / scratch vector
+    __shared__ double dth_[2][GP_N];         // dtheta of the previous row during the substitution pass
+    __shared__ double hv_[2][MPB_MAX_FIELDS][GP_N];   // per field: collision Jacobian h_t (D values) and cost c_t at [D]
+    __shared__ double ex_S[4][64];           // wave 1 -> wave 0: its last Schur tile (C layout)
+    __shared__ double ex_r[GP_N];            // wave 1 -> wave 0: its last r carry
+    __shared__ double ex_d[GP_N];            // wave 0 -> wave 1: dtheta of the merge row
+    __shared__ double ex_cost;
+    const int lane = threadIdx.x & 63;
+    const int dir = threadIdx.x >> 6;        // 0: rows 0 .. m (top down, then the merge row m); 1: rows H-1 .. m+1 (bottom up)
     const int b = blockIdx.x;
     const int dim = 2 * D;
+    const int m = split ? (H - 1) >> 1 : H - 1;   // merge row; split == 0 (64-thread block): plain top-down sweep, nothing to merge
+    const int nst = dir ? (H - 1 - m) : m;   // plain elimination steps of this wave (wave 0 adds the merge step)
+    const int nrows = nst + 1;               // rows this wave touches: its own and, for wave 1, the merge row as neighbour
+    double (*xs)[GP_N] = xs_[dir];
+    double* rv = rv_[dir];
+    double* zv = zv_[dir];
+    double* dth = dth_[dir];
+    double (*hv)[GP_N] = hv_[dir];
     const double dt = K.dt;
     // 2x2 GP coefficient matrices (Kronecker with I_D)
     const double a = 12.0 / (dt * dt * dt) * K.kgp, bq = -6.0 / (dt * dt) * K.kgp, cq = 4.0 / dt * K.kgp;  // Qi
     const double p00 = a, p01 = 6.0 / (dt * dt) * K.kgp, p11 = cq;                                            // Phi^T Qi Phi
-    // U = -Phi^T Qi = -[[a, bq],[a dt + bq, bq dt + cq]]   (U[c][e]: c,e in {pos, vel})
-    const double u00 = -a, u01 = -bq, u10 = -(a * dt + bq), u11 = -(bq * dt + cq);
+    // U = -Phi^T Qi = -[[a, bq],[a dt + bq, bq dt + cq]]   (U[c][e]: c,e in {pos, vel}).  The bottom-up wave runs the
+    // same recursion on the reversed chain, whose super-diagonal block is U^T: it swaps the off-diagonal coefficients
+    const double u00 = -a, u11 = -(bq * dt + cq);
+    const double u01 = dir ? -(a * dt + bq) : -bq, u10 = dir ? -bq : -(a * dt + bq);
     double* wW = work + (size_t)b * H * GP_WS_PER_T;
     float* xb = x + (size_t)b * H * dim;
     const float* jb = jac + (size_t)b * H * (D + 1);
@@ -227,8 +251,8 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
     // element ownership for the 16x16 tile = the C/D layout of v_mfma_f64_16x16x4_f64: lane (lk, li) holds rows
     // lk + 4q (q = 0..3) of column li.  The tile stays in registers from its assembly through the whole inverse.
     const int li = lane & 15, lk = lane >> 4;
-    f64x4 Snext = {0.0, 0.0, 0.0, 0.0};  // -(U^T W_{t-1} U) on entry to step t > 0, same layout
-    double rcarry = 0.0;  // lane < dim: r_t contribution carried from step t-1 (gnext - U^T z)
+    f64x4 Snext = {0.0, 0.0, 0.0, 0.0};  // -(U^T W U) of the previous step, same layout
+    double rcarry = 0.0;  // lane < dim: r contribution carried from the previous step (gnext - U^T z)
 
     // per-element constants of the S assembly (element q of this lane: row lk + 4q, column li)
     double asm_g1[4], asm_g2[4], asm_dg[4], asm_pp[4], asm_id[4];
@@ -263,56 +287,74 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
         const int ii = in ? (ip ? i : i - D) : 0, jj = in ? (jp ? j : j - D) : 0;
         const double uca0 = ip ? u00 : u01, uca1 = ip ? u10 : u11;   // U[c][a], c = 0,1
         const double ueb0 = jp ? u00 : u01, ueb1 = jp ? u10 : u11;   // U[e][b], e = 0,1
-        const double m = in ? -1.0 : 0.0;
-        nt_c[q][0] = m * uca0 * ueb0;   // W[ii][jj]
-        nt_c[q][1] = m * uca0 * ueb1;   // W[ii][jj + D]
-        nt_c[q][2] = m * uca1 * ueb0;   // W[ii + D][jj]
-        nt_c[q][3] = m * uca1 * ueb1;   // W[ii + D][jj + D]
+        const double mm = in ? -1.0 : 0.0;
+        nt_c[q][0] = mm * uca0 * ueb0;   // W[ii][jj]
+        nt_c[q][1] = mm * uca0 * ueb1;   // W[ii][jj + D]
+        nt_c[q][2] = mm * uca1 * ueb0;   // W[ii + D][jj]
+        nt_c[q][3] = mm * uca1 * ueb1;   // W[ii + D][jj + D]
         nt_off[q] = ii * GP_LD + jj;
     }
 
-    // software prefetch: rows t+1 of x and of the Jacobian are loaded one step ahead so that their global
-    // latency hides behind the inverse of step t instead of sitting on the sequential critical path
-    float xr0 = (lane < dim) ? xb[lane] : 0.f;
-    float xr1 = (lane < dim && H > 1) ? xb[dim + lane] : 0.f;
-    float jr = 0.f;                                                   // row 0 takes no collision factor
-    float jr1 = (lane <= D && H > 1) ? jb[(D + 1) + lane] : 0.f;
-    double dm0 = K.trust ? diag_mean[asm_di] : 0.0;
-    double dm1 = (K.trust && H > 1) ? diag_mean[dim + asm_di] : 0.0;
-    for (int t = 0; t < H; ++t) {
-        // ---- x_t, x_{t+1}, h_t from the prefetched registers; issue the loads of step t+1
+    // packed-triangle offsets: the elements this lane stores (row lk + 4q <= column li), and row `lane` of W for the
+    // substitution pass (element (r, j) lives at (min, max))
+    int tri_st[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tri_st[q] = (lk + 4 * q <= li) ? gp_tri(lk + 4 * q, li) : 0;
+    // k-th row of this wave's sweep
+    const int t_first = dir ? H - 1 : 0, t_inc = dir ? -1 : 1;
+    // software prefetch: the rows of x, of the Jacobian and of the damping two steps ahead are loaded so that their
+    // global latency hides behind the inverse of the current step instead of sitting on the sequential critical path
+    float xr0 = (lane < dim) ? xb[t_first * dim + lane] : 0.f;
+    float xr1 = (lane < dim && nrows > 1) ? xb[(t_first + t_inc) * dim + lane] : 0.f;
+    float jr = (lane <= D) ? jb[t_first * (D + 1) + lane] : 0.f;
+    float jr1 = (lane <= D && nrows > 1) ? jb[(t_first + t_inc) * (D + 1) + lane] : 0.f;
+    double dm0 = K.trust ? diag_mean[(size_t)t_first * dim + asm_di] : 0.0;
+    double dm1 = (K.trust && nrows > 1) ? diag_mean[(size_t)(t_first + t_inc) * dim + asm_di] : 0.0;
+    const int ksteps = dir ? nst : nst + 1;              // wave 0 also runs the merge step
+    for (int k = 0; k < ksteps; ++k) {
+        const int t = t_first + t_inc * k;               // actual row
+        const bool merge = (dir == 0) && (k == m);       // wave-uniform
+        if (merge) __syncthreads();                      // wave 1 has published ex_S / ex_r (it passes this barrier after its loop)
+        // ---- x_t, the neighbour row, h_t from the prefetched registers; issue the loads of step k+2
         if (lane < dim) {
             xs[0][lane] = (double)xr0;
-            xs[1][lane] = (t + 1 < H) ? (double)xr1 : 0.0;
+            xs[1][lane] = (double)xr1;
         }
         if (lane <= D) {
-            hv[0][lane] = (t > 0) ? (double)jr : 0.0;
+            hv[0][lane] = (t > 0) ? (double)jr : 0.0;    // row 0 takes no collision factor
             for (int f = 1; f < F; ++f)      // further chained fields: not prefetched (the single-field path stays lean)
                 hv[f][lane] = (t > 0) ? (double)jb[(size_t)f * B * H * (D + 1) + t * (D + 1) + lane] : 0.0;
         }
-        const float xr2 = (lane < dim && t + 2 < H) ? xb[(t + 2) * dim + lane] : 0.f;
-        const float jr2 = (lane <= D && t + 2 < H) ? jb[(t + 2) * (D + 1) + lane] : 0.f;
-        const double dm2 = (K.trust && t + 2 < H) ? diag_mean[(size_t)(t + 2) * dim + asm_di] : 0.0;
+        const int t2 = t + 2 * t_inc;
+        const bool has2 = k + 2 < nrows;
+        const float xr2 = (lane < dim && has2) ? xb[t2 * dim + lane] : 0.f;
+        const float jr2 = (lane <= D && has2) ? jb[t2 * (D + 1) + lane] : 0.f;
+        const double dm2 = (K.trust && has2) ? diag_mean[(size_t)t2 * dim + asm_di] : 0.0;
         wave_sync();
-        // ---- GP error of factor t: e = x_{t+1} - Phi x_t
-        double e_i = 0.0;
-        if (lane < dim && t + 1 < H) {
-            const bool pos = lane < D;
-            e_i = pos ? xs[1][lane] - (xs[0][lane] + dt * xs[0][lane + D]) : xs[1][lane] - xs[0][lane];
-        }
-        double qe_i = 0.0, pqe_i = 0.0;
-        {
+        // ---- GP factor between this row and the neighbour: e = x_hi - Phi x_lo (hi = the later of the two rows).
+        //      Its gradient splits into Phi^T Qi e (row lo) and -Qi e (row hi): one part is this row's, the other is
+        //      carried to the neighbour.  The merge row receives both of its factors through the carries.
+        double own_i = 0.0, gnext = 0.0;
+        if (!merge) {
+            const int lo = dir ? 1 : 0, hi = 1 - lo;
+            double e_i = 0.0;
+            if (lane < dim) {
+                const bool pos = lane < D;
+                e_i = pos ? xs[hi][lane] - (xs[lo][lane] + dt * xs[lo][lane + D]) : xs[hi][lane] - xs[lo][lane];
+            }
             const double e_partner = __shfl(e_i, (lane < D) ? lane + D : lane - D, 64);
-            if (lane < dim && t + 1 < H) {
+            if (lane < dim) {
                 const bool pos = lane < D;
                 const double ep = pos ? e_i : e_partner, ev = pos ? e_partner : e_i;
                 const double qp = a * ep + bq * ev, qv = bq * ep + cq * ev;      // Qi e
-                qe_i = pos ? qp : qv;
-                pqe_i = pos ? qp : dt * qp + qv;                                 // Phi^T (Qi e)
+                const double qe_i = pos ? qp : qv;
+                const double pqe_i = pos ? qp : dt * qp + qv;                    // Phi^T (Qi e)
                 cost += pos ? ep * qp : ev * qv;
+                own_i = dir ? -qe_i : pqe_i;
+                gnext = dir ? pqe_i : -qe_i;
             }
         }
-        // ---- S = D_t (+ Schur term carried in registers for t > 0); padding rows/cols = identity.  Branch-free: the
+        // ---- S = D_t (+ Schur term carried in registers); padding rows/cols = identity.  Branch-free: the
         //      per-element coefficients (asm_*) were fixed before the loop, only the t-dependent selects remain
         f64x4 T;
         {
@@ -320,11 +362,12 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
             double hj[MPB_MAX_FIELDS];
 #pragma unroll
             for (int f = 0; f < MPB_MAX_FIELDS; ++f) hj[f] = (f < F) ? hv[f][asm_hj] * (K.kc * notfirst) : 0.0;
-            // damping of the diagonal element of this lane's column (prefetched one step ahead, like x and h)
+            // damping of the diagonal element of this lane's column (prefetched, like x and h)
             const double dg = (K.trust ? K.delta * dm0 : K.delta) + first * K.ks + (1.0 - notlast) * K.kg;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                double v = (t > 0) ? Snext[q] : 0.0;
+                double v = (k > 0) ? Snext[q] : 0.0;
+                if (merge && split) v += ex_S[q][lane];
                 v = fma(notlast, asm_g1[q], v);
                 v = fma(notfirst, asm_g2[q], v);
                 v = fma(asm_dg[q], dg, v);
@@ -335,9 +378,9 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
             }
         }
         // ---- r_t
-        double gnext = 0.0;
         if (lane < dim) {
-            double r = (t > 0) ? rcarry : 0.0;
+            double r = (k > 0) ? rcarry : 0.0;
+            if (merge && split) r += ex_r[lane];
             if (t == 0) {
                 const double es = (double)start[(size_t)b * dim + lane] - xs[0][lane];
                 r += K.ks * es;
@@ -348,10 +391,9 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
                 r += K.kg * eg;
                 cost += K.kg * eg * eg;
             }
-            if (t < H - 1) r += pqe_i;
+            r += own_i;
             if (t > 0 && lane < D)
                 for (int f = 0; f < F; ++f) r += K.kc * hv[f][lane] * hv[f][D];
-            gnext = -qe_i;                                         // contribution of factor t to g_{t+1}
             rv[lane] = r;
         }
         if (lane == 0 && t > 0)
@@ -411,13 +453,13 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
                     {
                         double am[4];
 #pragma unroll
-                        for (int m = 0; m < 4; ++m)
-                            am[m] = fma(notj, __shfl(tk, m * 16 + li, 64), (li - k0 == m) ? 1.0 : 0.0);
+                        for (int mi = 0; mi < 4; ++mi)
+                            am[mi] = fma(notj, __shfl(tk, mi * 16 + li, 64), (li - k0 == mi) ? 1.0 : 0.0);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             double rowdot = pv[r][0] * am[0];
 #pragma unroll
-                            for (int m = 1; m < 4; ++m) rowdot = fma(pv[r][m], am[m], rowdot);
+                            for (int mi = 1; mi < 4; ++mi) rowdot = fma(pv[r][mi], am[mi], rowdot);
                             bop = fma(rowsel[r], rowdot, bop);
                         }
                     }
@@ -431,7 +473,7 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
             }
         }
         // W_t to LDS once (z = W r, the next Schur tile) and to the workspace straight from the registers
-        double* Wl = Sb[0];
+        double* Wl = Sb_[dir];
 #pragma unroll
         for (int q = 0; q < 4; ++q) Wl[(lk + 4 * q) * GP_LD + li] = T[q];
         wave_sync();
@@ -442,12 +484,13 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
         if (lane < dim) {
             for (int j = 0; j < dim; ++j) zi = fma(W[lane * GP_LD + j], rv[j], zi);
             zv[lane] = zi;
-            wt[GP_N * GP_N + lane] = zi;
+            wt[GP_TRI + lane] = zi;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) wt[(lk + 4 * q) * GP_N + li] = T[q];
+        for (int q = 0; q < 4; ++q)
+            if (lk + 4 * q <= li) wt[tri_st[q]] = T[q];
         wave_sync();
-        if (t < H - 1) {
+        if (!merge) {
             // ---- next tile: -(U^T W U), block (a,b) (i',j') = -sum_{c,e} U[c][a] U[e][b] W[i'+cD][j'+eD]; the four
             //      coefficient products and the element offsets are per-lane constants (nt_*), so 4 fma per element
 #pragma unroll
@@ -459,7 +502,7 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
                 v = fma(nt_c[q][3], Wq[D * GP_LD + D], v);
                 Snext[q] = v;
             }
-            // r_{t+1} carry = gnext - U^T z
+            // carry to the neighbour's r = gnext - U^T z
             if (lane < dim) {
                 const bool ip = lane < D;
                 const int ii = ip ? lane : lane - D;
@@ -470,54 +513,86 @@ __global__ __launch_bounds__(64) void gpmp2_solve_kernel(float* __restrict__ x, 
         }
         xr0 = xr1; xr1 = xr2; jr = jr1; jr1 = jr2; dm0 = dm1; dm1 = dm2;
     }
-    // ---- backward substitution and update: dtheta_t = z_t - W_t (U dtheta_{t+1}).  Row `lane` of W_{t-1}, z_{t-1}
-    //      and x_{t-1} are fetched while step t runs: the workspace (B*H*2.2 KB) does not stay in cache, and an
-    //      un-prefetched global round trip per waypoint would sit on the sequential critical path
-    double wrow[GP_N], wnext[GP_N], zc = 0.0, zn = 0.0;
-    float xc = 0.f, xn = 0.f;
+    // ---- hand-over at the merge row: wave 1 publishes its last Schur tile and r carry (first barrier, taken by wave 0
+    //      at the top of its merge step); wave 0 publishes dtheta_m = z_m and updates x_m (second barrier).
+    if (dir) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ex_S[q][lane] = Snext[q];
+        if (lane < dim) ex_r[lane] = rcarry;
+        __syncthreads();
+    } else {
+        if (lane < dim) {
+            const double dm_ = zv[lane];
+            ex_d[lane] = dm_;
+            xb[m * dim + lane] = (float)(xs[0][lane] + K.step * dm_);   // xs[0] = x_m (fp64 copy of the fp32 row)
+        }
+    }
+    __syncthreads();
+    // ---- substitution away from the merge row and update: dtheta_t = z_t - W_t (U dtheta_prev), prev = the row one
+    //      step closer to the merge row.  Row `lane` of the next W, z and x are fetched while the current step runs:
+    //      the workspace (B*H*2.2 KB) does not stay in cache, and an un-prefetched global round trip per waypoint
+    //      would sit on the sequential critical path
     const bool rowlane = lane < dim;
     const int rl = rowlane ? lane : 0;          // idle lanes shadow row 0: unconditional loads, no exec-mask branches
-    {
-        const double* wt = wW + (size_t)(H - 1) * GP_WS_PER_T;
-#pragma unroll
-        for (int j = 0; j < GP_N; ++j) wrow[j] = wt[rl * GP_N + j];
-        zc = wt[GP_N * GP_N + rl];
-        xc = xb[(H - 1) * dim + rl];
+    if (rowlane) {   // v = U dtheta_m
+        const bool ip = lane < D;
+        const int ii = ip ? lane : lane - D;
+        const double dp = ex_d[ii], dv = ex_d[ii + D];
+        zv[lane] = ip ? u00 * dp + u01 * dv : u10 * dp + u11 * dv;
     }
-    for (int t = H - 1; t >= 0; --t) {
-        if (t > 0) {
-            const double* wt = wW + (size_t)(t - 1) * GP_WS_PER_T;
+    wave_sync();
+    if (nst > 0) {
+        int tri_ld[GP_N];
 #pragma unroll
-            for (int j = 0; j < GP_N; ++j) wnext[j] = wt[rl * GP_N + j];
-            zn = wt[GP_N * GP_N + rl];
-            xn = xb[(t - 1) * dim + rl];
-        }
-        double d = zc;
-        if (rowlane && t < H - 1) {
+        for (int j = 0; j < GP_N; ++j) tri_ld[j] = gp_tri(min(rl, j), max(rl, j));
+        double wrow[GP_N], wnext[GP_N], zc = 0.0, zn = 0.0;
+        float xc = 0.f, xn = 0.f;
+        {
+            const int t = t_first + t_inc * (nst - 1);
+            const double* wt = wW + (size_t)t * GP_WS_PER_T;
 #pragma unroll
-            for (int j = 0; j < GP_N; ++j)
-                if (j < dim) d -= wrow[j] * zv[j];                               // zv holds U dtheta_{t+1}
+            for (int j = 0; j < GP_N; ++j) wrow[j] = wt[tri_ld[j]];
+            zc = wt[GP_TRI + rl];
+            xc = xb[t * dim + rl];
         }
-        wave_sync();
-        if (rowlane) {
-            dth[lane] = d;
-            xb[t * dim + lane] = (float)((double)xc + K.step * d);
-        }
-        wave_sync();
-        if (rowlane) {   // v = U dtheta_t for the next (earlier) waypoint
-            const bool ip = lane < D;
-            const int ii = ip ? lane : lane - D;
-            const double dp = dth[ii], dv = dth[ii + D];
-            zv[lane] = ip ? u00 * dp + u01 * dv : u10 * dp + u11 * dv;
-        }
-        wave_sync();
+        for (int k = nst - 1; k >= 0; --k) {
+            const int t = t_first + t_inc * k;
+            if (k > 0) {
+                const double* wt = wW + (size_t)(t - t_inc) * GP_WS_PER_T;
 #pragma unroll
-        for (int j = 0; j < GP_N; ++j) wrow[j] = wnext[j];
-        zc = zn;
-        xc = xn;
+                for (int j = 0; j < GP_N; ++j) wnext[j] = wt[tri_ld[j]];
+                zn = wt[GP_TRI + rl];
+                xn = xb[(t - t_inc) * dim + rl];
+            }
+            double d = zc;
+            if (rowlane) {
+#pragma unroll
+                for (int j = 0; j < GP_N; ++j)
+                    if (j < dim) d -= wrow[j] * zv[j];                               // zv holds U dtheta_prev
+            }
+            wave_sync();
+            if (rowlane) {
+                dth[lane] = d;
+                xb[t * dim + lane] = (float)((double)xc + K.step * d);
+            }
+            wave_sync();
+            if (rowlane) {   // v = U dtheta_t for the next row
+                const bool ip = lane < D;
+                const int ii = ip ? lane : lane - D;
+                const double dp = dth[ii], dv = dth[ii + D];
+                zv[lane] = ip ? u00 * dp + u01 * dv : u10 * dp + u11 * dv;
+            }
+            wave_sync();
+#pragma unroll
+            for (int j = 0; j < GP_N; ++j) wrow[j] = wnext[j];
+            zc = zn;
+            xc = xn;
+        }
     }
     cost = wave_sum_f64(cost);
-    if (costs_out != nullptr && lane == 0) costs_out[b] = (float)cost;
+    if (dir && lane == 0) ex_cost = cost;
+    __syncthreads();
+    if (costs_out != nullptr && dir == 0 && lane == 0) costs_out[b] = (float)(split ? cost + ex_cost : cost);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -593,13 +668,18 @@ extern "C" int mpb_gpmp2_solve(float* x, const float* start, const float* goal, 
     K.step = step_size;
     K.trust = trust_region;
     const double* dm = trust_region ? (diag_mean ? diag_mean : w.diag_mean) : nullptr;
+    // two waves per particle (sweeps from both ends of the chain, see the kernel) halve the sequential chain: B = 256
+    // -32 %; at B = 2048 the instruction throughput is the bound and both forms take the same time (measured).  The
+    // one-wave form remains for chains too short to split
+    static const int force_split = getenv("MPB_GPMP2_SPLIT") ? atoi(getenv("MPB_GPMP2_SPLIT")) : -1;   // tuning aid
+    const int split = (H >= 4) && (force_split >= 0 ? force_split != 0 : 1);
 #define GP_LAUNCH(DT)                                                                                                   \
     if (n_fields == 1)                                                                                                  \
-        hipLaunchKernelGGL((gpmp2_solve_kernel<DT, false>), dim3(B), dim3(64), 0, (hipStream_t)stream, x, start, goal,  \
-                           w.jac, dm, w.fz, costs_out, B, H, D, n_fields, K);                                           \
+        hipLaunchKernelGGL((gpmp2_solve_kernel<DT, false>), dim3(B), dim3(split ? 128 : 64), 0, (hipStream_t)stream, x, \
+                           start, goal, w.jac, dm, w.fz, costs_out, B, H, D, n_fields, split, K);                       \
     else                                                                                                                \
-        hipLaunchKernelGGL((gpmp2_solve_kernel<DT, true>), dim3(B), dim3(64), 0, (hipStream_t)stream, x, start, goal,   \
-                           w.jac, dm, w.fz, costs_out, B, H, D, n_fields, K)
+        hipLaunchKernelGGL((gpmp2_solve_kernel<DT, true>), dim3(B), dim3(split ? 128 : 64), 0, (hipStream_t)stream, x,  \
+                           start, goal, w.jac, dm, w.fz, costs_out, B, H, D, n_fields, split, K)
     switch (D) {
         case 2: GP_LAUNCH(2); break;
         case 3: GP_LAUNCH(3); break;

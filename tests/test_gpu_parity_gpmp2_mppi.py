@@ -61,6 +61,76 @@ def test_gpmp2_vs_golden(gpu_device, name):
         prev = ref
 
 
+def _gpmp2_golden_step(name, dev):
+    from motion_planning_baselines_amd import ops
+    g = load_golden(name)
+    geom = dev_geom(g, dev)
+    B, H, D = int(g['B']), int(g['H']), int(g['D'])
+    sig = (float(g['sigma_start']), float(g['sigma_gp']), float(g['sigma_goal_prior']), float(g['sigma_coll']))
+    start = torch.cat([T(g['start']).float(), torch.zeros(D)]).repeat(B, 1).contiguous().to(dev)
+    goal = torch.cat([T(g['goal']).float(), torch.zeros(D)]).repeat(B, 1).contiguous().to(dev)
+    ws = ops.gpmp2_workspace(B, H, D, dev)
+    x = T(g['means0']).float().to(dev)
+    costs = torch.empty(B, device=dev)
+    ops.gpmp2_step(x, start, goal, geom, ws, sig, float(g['dt']), float(g['delta']), bool(g['trust_region']),
+                   float(g['step_size']), n_iters=1, costs_out=costs)
+    torch.cuda.synchronize()
+    return g, x.cpu(), costs.cpu()
+
+
+@pytest.mark.parametrize('name', ['gpmp2_pm2d_h8_notr_f64', 'gpmp2_panda_h16_f64'])
+def test_gpmp2_one_wave_and_two_wave_sweeps_agree(gpu_device, name, tmp_path):
+    """The solve kernel sweeps the chain from both ends with two waves per particle, and top-down with one wave when
+    the chain is too short to split (mpb_gpmp2.hip).  The one-wave form is forced on the same golden through the
+    library's tuning switch (read once per process, hence the child process) and compared with the two-wave run."""
+    import os, subprocess, sys
+    g, x2, c2 = _gpmp2_golden_step(name, gpu_device)
+    out = tmp_path / 'one_wave.npz'
+    code = ('import sys, numpy as np, torch; sys.path.insert(0, %r); sys.path.insert(0, %r);\n'
+            'import test_gpu_parity_gpmp2_mppi as M\n'
+            'g, x, c = M._gpmp2_golden_step(%r, torch.device("cuda:0"))\n'
+            'np.savez(%r, x=x.numpy(), c=c.numpy())\n') % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                           os.path.dirname(os.path.abspath(__file__)), name, str(out))
+    env = dict(os.environ, MPB_GPMP2_SPLIT='0')
+    subprocess.run([sys.executable, '-c', code], check=True, env=env, timeout=600)
+    z = np.load(out)
+    x1, c1 = torch.from_numpy(z['x']), torch.from_numpy(z['c'])
+    ref = T(g['means'][0]).float()
+    assert rel_err(x1, ref) < 1e-5 and rel_err(x2, ref) < 1e-5
+    # the two sweeps order the fp64 arithmetic differently: they agree to fp32 storage rounding of x, not bit for bit
+    assert float((x1 - x2).abs().max()) <= 4e-6 * float(ref.abs().max())
+    np.testing.assert_allclose(c1.numpy(), c2.numpy(), rtol=1e-6)
+
+
+@pytest.mark.parametrize('H', [2, 3, 4, 5])
+def test_gpmp2_short_chains(gpu_device, H):
+    """H = 2, 3 take the one-wave sweep, H = 4, 5 the shortest split chains (merge row 1 and 2): against the oracle's
+    dense restatement of the reference system (fp64)."""
+    from motion_planning_baselines_amd import geometry as G, ops
+    from oracle import planners_ref as O
+    from oracle.geometry_ref import make_ref_geometry
+    dev = gpu_device
+    robot, field = G.RobotPointMass(2, radius=0.01), G.env_grid_circles_2d()
+    geom = ops.DeviceGeometry(robot, field, dev)
+    B, D, dt = 3, 2, 0.1
+    gen = torch.Generator().manual_seed(H)
+    x0 = (0.5 * torch.randn(B, H, 2 * D, generator=gen)).float()
+    start, goal = x0[:, 0].clone(), x0[:, -1].clone()
+    start[:, D:] = 0
+    goal[:, D:] = 0
+    sig = (1e-3, 1.0, 1e-3, 1e-2)
+    x = x0.clone().to(dev)
+    ws = ops.gpmp2_workspace(B, H, D, dev)
+    ops.gpmp2_step(x, start.to(dev), goal.to(dev), geom, ws, sig, dt, 1e-2, False, 0.5)
+    torch.cuda.synchronize()
+    f64 = dict(device='cpu', dtype=torch.float64)
+    rrobot, rfield = make_ref_geometry(robot, field, f64)
+    ref = O.gpmp2_iteration(x0.double(), rrobot, rfield, start.double(), goal.double(), D=D, dt=dt, sigma_start=sig[0],
+                            sigma_gp=sig[1], sigma_goal=sig[2], sigma_coll=sig[3], delta=1e-2, trust_region=False,
+                            step_size=0.5, tensor_args=f64)
+    assert rel_err(x.cpu(), ref['means'].float()) < 1e-5
+
+
 def test_gpmp2_split_entry_points_equal_step(gpu_device):
     """linearize -> diag -> (host mean) -> solve == the single-call step: the sharded path's building blocks."""
     from motion_planning_baselines_amd import ops
