@@ -171,8 +171,8 @@ __global__ void gpmp2_scale_kernel(const double* __restrict__ in, double* __rest
 // for the top-down wave (rows 0 .. m); the bottom-up wave (rows H-1 .. m+1) runs the same formulas with U^T in place
 // of U and t-1 in place of t+1.  Row m: S_m = D_m - U^T W_{m-1} U - U W_{m+1} U^T, r_m likewise, dtheta_m = S_m^-1 r_m.
 // The only dense operation per waypoint is the SPD inverse W_t: blocked Gauss-Jordan (no pivoting: the
-// pivot blocks of an SPD matrix are SPD) on a 16 x 16 fp64 tile with 4 x 4 pivot blocks; each block step is
-// one v_mfma_f64_16x16x4_f64 rank-4 update of the whole tile, operands and result in registers.
+// pivot blocks of an SPD matrix are SPD) on a 16 x 16 fp64 tile with 2 x 2 pivot blocks; each block step is
+// one v_mfma_f64_16x16x4_f64 update of the whole tile, operands and result in registers.
 // ------------------------------------------------------------------------------------------------
 // 1/x in fp64: v_rcp_f64 (about 2^-26 accurate) + two Newton steps; the IEEE division hipcc emits costs
 // ~40 instructions and there are 16 of them per waypoint in the pivot-block inverses
@@ -206,8 +206,14 @@ __device__ __forceinline__ int gp_tri(int i, int j) { return i * GP_N - ((i * (i
 
 // DT > 0: the number of degrees of freedom is a compile-time constant (loop bounds, pivot-block count and the
 // position/velocity index tests fold away); DT == 0: generic.
+// two waves per SIMD: the kernel wants ~250 VGPRs (per-lane coefficient tables of the tile assembly in fp64), and
+// the compiler's default of one wave per SIMD leaves the matrix-core and LDS latencies of the pivot steps exposed
+// (measured at C4: 0.94 ms/iter with one wave, 0.63 with two; three or four only fit with spills and are slower)
+#ifndef MPB_GP_WAVES
+#define MPB_GP_WAVES 2
+#endif
 template <int DT, bool MULTI>
-__global__ __launch_bounds__(128) void gpmp2_solve_kernel(float* __restrict__ x, const float* __restrict__ start,
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVES))) void gpmp2_solve_kernel(float* __restrict__ x, const float* __restrict__ start,
                                                           const float* __restrict__ goal, const float* __restrict__ jac,
                                                           const double* __restrict__ diag_mean, double* __restrict__ work,
                                                           float* __restrict__ costs_out, int B, int H, int Drt, int Frt, int split, GpConst K) {
@@ -399,76 +405,45 @@ __global__ __launch_bounds__(128) void gpmp2_solve_kernel(float* __restrict__ x,
         if (lane == 0 && t > 0)
             for (int f = 0; f < F; ++f) cost += K.kc * hv[f][D] * hv[f][D];
         wave_sync();
-        // ---- W = S^-1 : blocked Gauss-Jordan with 4x4 pivot blocks, entirely in registers.  Per block step K:
+        // ---- W = S^-1 : blocked Gauss-Jordan with 2x2 pivot blocks, entirely in registers.  Per block step K:
         //        D = (-A[:,K]) * (Pinv * A'[K,:]) + C_in,  A'[K,K] := I,  C_in := A with columns K zeroed,
         //      one v_mfma_f64_16x16x4_f64, then rows K := Pinv * A'[K,:] (this lane's own B operand).
         //      Lane maps (f64 16x16x4): A-op lane l -> [i = l&15][k = l>>4]; B-op [k = l>>4][j = l&15]; C/D: column
         //      l&15, rows (l>>4) + 4*reg.  Nothing goes through LDS:
-        //        * the pivot block is broadcast with v_readlane (row k0+r lives in register kb of lanes (r, .));
-        //        * the B operand needs rows K of column li = register kb of lanes (m, li): four shuffles;
-        //        * the A operand -A[li][k0+lk] is this lane's OWN register kb up to a sign: the working matrix of
+        //        * rows k0, k0+1 are lanes lk = 2*half, 2*half+1 of register q = kb2 >> 1; the rank-2 update uses
+        //          those two of the four k-slots of the MFMA (the operands of the other two are zero);
+        //        * the pivot block is broadcast with v_readlane, the B operand needs rows K of column li: two shuffles;
+        //        * the A operand -A[li][k0+r] is this lane's OWN register q up to a sign: the working matrix of
         //          the Gauss-Jordan inverse of a symmetric matrix satisfies M[a][b] = s M[b][a] with s = -1 when
         //          exactly one of a, b belongs to an already processed block, +1 otherwise (induction over the
-        //          block steps), and T[kb] = M[k0+lk][li].
+        //          block steps), and T[q] = M[4q+lk][li].
+        //      Against 4x4 pivots (round-1 first version) this trades 7 instead of 4 MFMAs per tile for a pivot-block
+        //      inverse of 6 instead of ~60 fp64 operations that every lane repeats: the fp64 VALU (4.7 cycles per
+        //      wave instruction, scripts/microbench_valu.hip) is what bounds this kernel, not the matrix core.
         {
-            const double rowsel[4] = {lk == 0 ? 1.0 : 0.0, lk == 1 ? 1.0 : 0.0, lk == 2 ? 1.0 : 0.0, lk == 3 ? 1.0 : 0.0};
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                if (4 * kb < dim) {
-                    const int k0 = 4 * kb;
-                    const double tk = T[kb];
-                    // pivot block (symmetric: upper triangle) from lanes (r, k0 + c)
-                    const double a00 = readlane_f64(tk, 0 * 16 + k0 + 0), a01 = readlane_f64(tk, 0 * 16 + k0 + 1);
-                    const double b00 = readlane_f64(tk, 0 * 16 + k0 + 2), b01 = readlane_f64(tk, 0 * 16 + k0 + 3);
-                    const double a11 = readlane_f64(tk, 1 * 16 + k0 + 1);
-                    const double b10 = readlane_f64(tk, 1 * 16 + k0 + 2), b11 = readlane_f64(tk, 1 * 16 + k0 + 3);
-                    const double c00 = readlane_f64(tk, 2 * 16 + k0 + 2), c01 = readlane_f64(tk, 2 * 16 + k0 + 3);
-                    const double c11 = readlane_f64(tk, 3 * 16 + k0 + 3);
-                    // SPD 4x4 inverse in 2x2 blocks: X = A^-1 B, S = C - B^T X,
-                    //   P^-1 = [[A^-1 + X S^-1 X^T, -X S^-1], [-(X S^-1)^T, S^-1]]      (2 reciprocals, ~50 fma)
-                    double pv[4][4];
-                    {
-                        const double ia = fast_rcp(fma(a00, a11, -a01 * a01));
-                        const double i00 = a11 * ia, i01 = -a01 * ia, i11 = a00 * ia;              // A^-1
-                        const double x00 = fma(i00, b00, i01 * b10), x01 = fma(i00, b01, i01 * b11);   // X = A^-1 B
-                        const double x10 = fma(i01, b00, i11 * b10), x11 = fma(i01, b01, i11 * b11);
-                        const double s00 = c00 - fma(b00, x00, b10 * x10), s01 = c01 - fma(b00, x01, b10 * x11);
-                        const double s11 = c11 - fma(b01, x01, b11 * x11);                          // S = C - B^T X
-                        const double is = fast_rcp(fma(s00, s11, -s01 * s01));
-                        const double t00 = s11 * is, t01 = -s01 * is, t11 = s00 * is;              // S^-1
-                        const double y00 = -fma(x00, t00, x01 * t01), y01 = -fma(x00, t01, x01 * t11);  // -X S^-1
-                        const double y10 = -fma(x10, t00, x11 * t01), y11 = -fma(x10, t01, x11 * t11);
-                        pv[0][0] = i00 - fma(y00, x00, y01 * x01);                                  // A^-1 + X S^-1 X^T
-                        pv[0][1] = pv[1][0] = i01 - fma(y00, x10, y01 * x11);
-                        pv[1][1] = i11 - fma(y10, x10, y11 * x11);
-                        pv[0][2] = pv[2][0] = y00; pv[0][3] = pv[3][0] = y01;
-                        pv[1][2] = pv[2][1] = y10; pv[1][3] = pv[3][1] = y11;
-                        pv[2][2] = t00; pv[2][3] = pv[3][2] = t01; pv[3][3] = t11;
-                    }
-                    // B operand (Pinv * A'[K,:])[lk][li]; lane-dependent choices are 0/1 multipliers, not selects
-                    // (hipcc lowers such selects to trees of exec-mask branches)
-                    const bool jin = (li >= k0) && (li < k0 + 4);
+            for (int kb2 = 0; kb2 < 8; ++kb2) {
+                if (2 * kb2 < dim) {
+                    const int k0 = 2 * kb2, q = kb2 >> 1, half = kb2 & 1;
+                    const double tk = T[q];
+                    const double p00 = readlane_f64(tk, (2 * half) * 16 + k0), p01 = readlane_f64(tk, (2 * half) * 16 + k0 + 1);
+                    const double p11 = readlane_f64(tk, (2 * half + 1) * 16 + k0 + 1);
+                    const double id = fast_rcp(fma(p00, p11, -p01 * p01));
+                    const double i00 = p11 * id, i01 = -p01 * id, i11 = p00 * id;
+                    const bool jin = (li >= k0) && (li < k0 + 2);
                     const double notj = jin ? 0.0 : 1.0;
-                    double bop = 0.0;
-                    {
-                        double am[4];
-#pragma unroll
-                        for (int mi = 0; mi < 4; ++mi)
-                            am[mi] = fma(notj, __shfl(tk, mi * 16 + li, 64), (li - k0 == mi) ? 1.0 : 0.0);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            double rowdot = pv[r][0] * am[0];
-#pragma unroll
-                            for (int mi = 1; mi < 4; ++mi) rowdot = fma(pv[r][mi], am[mi], rowdot);
-                            bop = fma(rowsel[r], rowdot, bop);
-                        }
-                    }
-                    const double aop = (li < k0) ? tk : -tk;
+                    const double am0 = fma(notj, __shfl(tk, (2 * half) * 16 + li, 64), (li == k0) ? 1.0 : 0.0);
+                    const double am1 = fma(notj, __shfl(tk, (2 * half + 1) * 16 + li, 64), (li == k0 + 1) ? 1.0 : 0.0);
+                    const double sel0 = (lk == 2 * half) ? 1.0 : 0.0, sel1 = (lk == 2 * half + 1) ? 1.0 : 0.0;
+                    // row r of Pinv * A'[K,:] for the lanes of k-slot 2*half + r, zero in the two idle k-slots
+                    const double bop = fma(sel0 * i00 + sel1 * i01, am0, (sel0 * i01 + sel1 * i11) * am1);
+                    const double act = sel0 + sel1;
+                    const double aop = act * ((li < k0) ? tk : -tk);
                     f64x4 cin;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) cin[q] = notj * T[q];
+                    for (int qq = 0; qq < 4; ++qq) cin[qq] = notj * T[qq];
                     T = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, cin, 0, 0, 0);
-                    T[kb] = bop;                                    // rows of the pivot block
+                    T[q] = fma(act, bop, (1.0 - act) * T[q]);       // rows of the pivot block := bop (act is 0 or 1: exact)
                 }
             }
         }

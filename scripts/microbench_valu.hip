@@ -1,4 +1,5 @@
-// Micro-benchmark: sustained issue rate of v_fma_f32, v_pk_fma_f32, v_sqrt_f32, v_min_f32 per SIMD on gfx950.
+// Micro-benchmark: sustained issue rate of v_fma_f32, v_pk_fma_f32, v_sqrt_f32, v_min_f32, v_fma_f64, v_rcp_f64 and
+// v_mfma_f64_16x16x4_f64 per SIMD on gfx950.
 // hipcc --offload-arch=gfx950 -O3 scripts/microbench_valu.hip -o /tmp/mb && /tmp/mb
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -39,6 +40,30 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
             }
         }
     }
+    if (MODE >= 4) {
+        double d0 = a0, d1 = a1, d2 = a2, d3 = a3, d4 = a4, d5 = a5, d6 = a6, d7 = a7;
+        const double dm = 0.999, dc = 0.001;
+        typedef double d4v __attribute__((ext_vector_type(4)));
+        d4v acc0 = {d0, d1, d2, d3}, acc1 = {d4, d5, d6, d7};
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (MODE == 4) {
+                    d0 = __builtin_fma(d0, dm, dc); d1 = __builtin_fma(d1, dm, dc); d2 = __builtin_fma(d2, dm, dc); d3 = __builtin_fma(d3, dm, dc);
+                    d4 = __builtin_fma(d4, dm, dc); d5 = __builtin_fma(d5, dm, dc); d6 = __builtin_fma(d6, dm, dc); d7 = __builtin_fma(d7, dm, dc);
+                } else if (MODE == 5) {
+                    d0 = __builtin_amdgcn_rcp(d0); d1 = __builtin_amdgcn_rcp(d1); d2 = __builtin_amdgcn_rcp(d2); d3 = __builtin_amdgcn_rcp(d3);
+                    d4 = __builtin_amdgcn_rcp(d4); d5 = __builtin_amdgcn_rcp(d5); d6 = __builtin_amdgcn_rcp(d6); d7 = __builtin_amdgcn_rcp(d7);
+                } else {
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(d0, d1, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(d2, d3, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(d4, d5, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(d6, d7, acc1, 0, 0, 0);
+                }
+            }
+        }
+        a0 = (float)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7 + acc0[0] + acc0[1] + acc0[2] + acc0[3] + acc1[0] + acc1[1] + acc1[2] + acc1[3]);
+    }
     out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0[0] + p1[1] + p2[0] + p3[1] + p4[0] + p5[1] + p6[0] + p7[1];
 }
 
@@ -68,6 +93,9 @@ int main() {
         run<1>("v_pk_fma", w, out, 64);
         run<2>("v_sqrt", w, out, 64);
         run<3>("add+min", w, out, 128);
+        run<4>("v_fma_f64", w, out, 64);
+        run<5>("v_rcp_f64", w, out, 64);
+        run<6>("mfma_f64", w, out, 32);
     }
     return 0;
 }
