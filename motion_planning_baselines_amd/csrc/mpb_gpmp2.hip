@@ -209,6 +209,23 @@ __device__ __forceinline__ int gp_tri(int i, int j) { return i * GP_N - ((i * (i
 // two waves per SIMD: the kernel wants ~250 VGPRs (per-lane coefficient tables of the tile assembly in fp64), and
 // the compiler's default of one wave per SIMD leaves the matrix-core and LDS latencies of the pivot steps exposed
 // (measured at C4: 0.94 ms/iter with one wave, 0.63 with two; three or four only fit with spills and are slower)
+#ifdef MPB_GP_STAMPS   // diagnostic build only: cycles per phase of the elimination loop, wave 0 of block 0
+__device__ unsigned long long gp_phase_cycles[8];
+extern "C" int mpb_debug_read_gp_phases(unsigned long long* dst) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(gp_phase_cycles), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : 3;
+}
+#define GP_STAMP(i)                                                                       \
+    do {                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        unsigned long long t_;                                                            \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        ph[i] += t_ - tlast;                                                              \
+        tlast = t_;                                                                       \
+    } while (0)
+#else
+#define GP_STAMP(i)
+#endif
 #ifndef MPB_GP_WAVES
 #define MPB_GP_WAVES 2
 #endif
@@ -221,11 +238,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVE
     const int F = MULTI ? Frt : 1;       // MULTI == false: one collision field, the field loops fold away
     // every wave owns a private set of the per-step LDS vectors; the ex_* words are the hand-over at the merge row
     __shared__ double Sb_[2][GP_N * GP_LD];  // W_t for the matvec / next-tile reads (the inverse itself runs in registers)
-    __shared__ double xs_[2][2][GP_N];       // x_t and the neighbour row towards the merge row (fp64 copies)
-    __shared__ double rv_[2][GP_N];          // r_t
     __shared__ double zv_[2][GP_N];          // z_t / scratch vector
     __shared__ double dth_[2][GP_N];         // dtheta of the previous row during the substitution pass
-    __shared__ double hv_[2][MPB_MAX_FIELDS][GP_N];   // per field: collision Jacobian h_t (D values) and cost c_t at [D]
     __shared__ double ex_S[4][64];           // wave 1 -> wave 0: its last Schur tile (C layout)
     __shared__ double ex_r[GP_N];            // wave 1 -> wave 0: its last r carry
     __shared__ double ex_d[GP_N];            // wave 0 -> wave 1: dtheta of the merge row
@@ -237,11 +251,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVE
     const int m = split ? (H - 1) >> 1 : H - 1;   // merge row; split == 0 (64-thread block): plain top-down sweep, nothing to merge
     const int nst = dir ? (H - 1 - m) : m;   // plain elimination steps of this wave (wave 0 adds the merge step)
     const int nrows = nst + 1;               // rows this wave touches: its own and, for wave 1, the merge row as neighbour
-    double (*xs)[GP_N] = xs_[dir];
-    double* rv = rv_[dir];
     double* zv = zv_[dir];
     double* dth = dth_[dir];
-    double (*hv)[GP_N] = hv_[dir];
     const double dt = K.dt;
     // 2x2 GP coefficient matrices (Kronecker with I_D)
     const double a = 12.0 / (dt * dt * dt) * K.kgp, bq = -6.0 / (dt * dt) * K.kgp, cq = 4.0 / dt * K.kgp;  // Qi
@@ -317,41 +328,43 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVE
     double dm0 = K.trust ? diag_mean[(size_t)t_first * dim + asm_di] : 0.0;
     double dm1 = (K.trust && nrows > 1) ? diag_mean[(size_t)(t_first + t_inc) * dim + asm_di] : 0.0;
     const int ksteps = dir ? nst : nst + 1;              // wave 0 also runs the merge step
+#ifdef MPB_GP_STAMPS
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory");
+#endif
+    double z_last = 0.0, x_last = 0.0;                   // z and x of the last row this wave eliminated (the merge row for wave 0)
     for (int k = 0; k < ksteps; ++k) {
         const int t = t_first + t_inc * k;               // actual row
         const bool merge = (dir == 0) && (k == m);       // wave-uniform
         if (merge) __syncthreads();                      // wave 1 has published ex_S / ex_r (it passes this barrier after its loop)
-        // ---- x_t, the neighbour row, h_t from the prefetched registers; issue the loads of step k+2
-        if (lane < dim) {
-            xs[0][lane] = (double)xr0;
-            xs[1][lane] = (double)xr1;
-        }
-        if (lane <= D) {
-            hv[0][lane] = (t > 0) ? (double)jr : 0.0;    // row 0 takes no collision factor
-            for (int f = 1; f < F; ++f)      // further chained fields: not prefetched (the single-field path stays lean)
-                hv[f][lane] = (t > 0) ? (double)jb[(size_t)f * B * H * (D + 1) + t * (D + 1) + lane] : 0.0;
-        }
+        // ---- x_t, the neighbour row, h_t from the prefetched registers (lane < dim: x element `lane`; lane <= D: h_t and
+        //      c_t); issue the loads of step k+2.  Everything another lane needs of them travels through the lane
+        //      crossbar (ds_bpermute on the fp32 values) -- no LDS staging, no write -> read round trip on the chain
+        const double x0 = (double)xr0, x1 = (double)xr1;
+        float hf[MPB_MAX_FIELDS];
+        hf[0] = (t > 0) ? jr : 0.f;                      // row 0 takes no collision factor
+#pragma unroll
+        for (int f = 1; f < MPB_MAX_FIELDS; ++f)         // further chained fields: not prefetched (the single-field path stays lean)
+            hf[f] = (f < F && t > 0 && lane <= D) ? jb[(size_t)f * B * H * (D + 1) + t * (D + 1) + lane] : 0.f;
         const int t2 = t + 2 * t_inc;
         const bool has2 = k + 2 < nrows;
         const float xr2 = (lane < dim && has2) ? xb[t2 * dim + lane] : 0.f;
         const float jr2 = (lane <= D && has2) ? jb[t2 * (D + 1) + lane] : 0.f;
         const double dm2 = (K.trust && has2) ? diag_mean[(size_t)t2 * dim + asm_di] : 0.0;
-        wave_sync();
+        GP_STAMP(0);
         // ---- GP factor between this row and the neighbour: e = x_hi - Phi x_lo (hi = the later of the two rows).
         //      Its gradient splits into Phi^T Qi e (row lo) and -Qi e (row hi): one part is this row's, the other is
         //      carried to the neighbour.  The merge row receives both of its factors through the carries.
         double own_i = 0.0, gnext = 0.0;
         if (!merge) {
-            const int lo = dir ? 1 : 0, hi = 1 - lo;
-            double e_i = 0.0;
+            const int partner = (lane < D) ? lane + D : lane - D;    // position <-> velocity of the same dof
+            const double x0p = (double)__shfl(xr0, partner, 64), x1p = (double)__shfl(xr1, partner, 64);
             if (lane < dim) {
                 const bool pos = lane < D;
-                e_i = pos ? xs[hi][lane] - (xs[lo][lane] + dt * xs[lo][lane + D]) : xs[hi][lane] - xs[lo][lane];
-            }
-            const double e_partner = __shfl(e_i, (lane < D) ? lane + D : lane - D, 64);
-            if (lane < dim) {
-                const bool pos = lane < D;
-                const double ep = pos ? e_i : e_partner, ev = pos ? e_partner : e_i;
+                const double lo_o = dir ? x1 : x0, hi_o = dir ? x0 : x1;          // own element of the two rows
+                const double lo_p = dir ? x1p : x0p, hi_p = dir ? x0p : x1p;      // partner element
+                const double ep = pos ? hi_o - (lo_o + dt * lo_p) : hi_p - (lo_p + dt * lo_o);
+                const double ev = pos ? hi_p - lo_p : hi_o - lo_o;
                 const double qp = a * ep + bq * ev, qv = bq * ep + cq * ev;      // Qi e
                 const double qe_i = pos ? qp : qv;
                 const double pqe_i = pos ? qp : dt * qp + qv;                    // Phi^T (Qi e)
@@ -360,51 +373,56 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVE
                 gnext = dir ? pqe_i : -qe_i;
             }
         }
+        GP_STAMP(1);
         // ---- S = D_t (+ Schur term carried in registers); padding rows/cols = identity.  Branch-free: the
         //      per-element coefficients (asm_*) were fixed before the loop, only the t-dependent selects remain
         f64x4 T;
+        double r = 0.0;
         {
             const double first = (t == 0) ? 1.0 : 0.0, notfirst = 1.0 - first, notlast = (t < H - 1) ? 1.0 : 0.0;
-            double hj[MPB_MAX_FIELDS];
-#pragma unroll
-            for (int f = 0; f < MPB_MAX_FIELDS; ++f) hj[f] = (f < F) ? hv[f][asm_hj] * (K.kc * notfirst) : 0.0;
             // damping of the diagonal element of this lane's column (prefetched, like x and h)
             const double dg = (K.trust ? K.delta * dm0 : K.delta) + first * K.ks + (1.0 - notlast) * K.kg;
+            double v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                double v = (k > 0) ? Snext[q] : 0.0;
-                if (merge && split) v += ex_S[q][lane];
-                v = fma(notlast, asm_g1[q], v);
-                v = fma(notfirst, asm_g2[q], v);
-                v = fma(asm_dg[q], dg, v);
-#pragma unroll
-                for (int f = 0; f < MPB_MAX_FIELDS; ++f)
-                    if (f < F) v = fma(asm_pp[q] * hj[f], hv[f][asm_hi[q]], v);
-                T[q] = asm_in[q] ? v : asm_id[q];
+                v[q] = (k > 0) ? Snext[q] : 0.0;
+                if (merge && split) v[q] += ex_S[q][lane];
+                v[q] = fma(notlast, asm_g1[q], v[q]);
+                v[q] = fma(notfirst, asm_g2[q], v[q]);
+                v[q] = fma(asm_dg[q], dg, v[q]);
             }
-        }
-        // ---- r_t
-        if (lane < dim) {
-            double r = (k > 0) ? rcarry : 0.0;
-            if (merge && split) r += ex_r[lane];
-            if (t == 0) {
-                const double es = (double)start[(size_t)b * dim + lane] - xs[0][lane];
+            // ---- r_t (lane < dim)
+            r = (k > 0) ? rcarry : 0.0;
+            if (merge && split && lane < dim) r += ex_r[lane];
+            if (t == 0 && lane < dim) {
+                const double es = (double)start[(size_t)b * dim + lane] - x0;
                 r += K.ks * es;
                 cost += K.ks * es * es;
             }
-            if (t == H - 1) {
-                const double eg = (double)goal[(size_t)b * dim + lane] - xs[0][lane];
+            if (t == H - 1 && lane < dim) {
+                const double eg = (double)goal[(size_t)b * dim + lane] - x0;
                 r += K.kg * eg;
                 cost += K.kg * eg * eg;
             }
             r += own_i;
-            if (t > 0 && lane < D)
-                for (int f = 0; f < F; ++f) r += K.kc * hv[f][lane] * hv[f][D];
-            rv[lane] = r;
+            // collision factor(s): kc h h^T on the position block, kc h c on the right-hand side
+#pragma unroll
+            for (int f = 0; f < MPB_MAX_FIELDS; ++f) {
+                if (f < F) {
+                    const double hcol = (double)__shfl(hf[f], asm_hj, 64) * (K.kc * notfirst);
+                    const double cf = (double)__shfl(hf[f], D, 64);                           // c_t of this field
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        v[q] = fma(asm_pp[q] * hcol, (double)__shfl(hf[f], asm_hi[q], 64), v[q]);
+                    if (t > 0 && lane < D) r += K.kc * (double)hf[f] * cf;
+                    if (t > 0 && lane == 0) cost += K.kc * cf * cf;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) T[q] = asm_in[q] ? v[q] : asm_id[q];
+            if (lane >= dim) r = 0.0;
         }
-        if (lane == 0 && t > 0)
-            for (int f = 0; f < F; ++f) cost += K.kc * hv[f][D] * hv[f][D];
-        wave_sync();
+        GP_STAMP(2);
         // ---- W = S^-1 : blocked Gauss-Jordan with 2x2 pivot blocks, entirely in registers.  Per block step K:
         //        D = (-A[:,K]) * (Pinv * A'[K,:]) + C_in,  A'[K,K] := I,  C_in := A with columns K zeroed,
         //      one v_mfma_f64_16x16x4_f64, then rows K := Pinv * A'[K,:] (this lane's own B operand).
@@ -418,8 +436,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVE
         //          exactly one of a, b belongs to an already processed block, +1 otherwise (induction over the
         //          block steps), and T[q] = M[4q+lk][li].
         //      Against 4x4 pivots (round-1 first version) this trades 7 instead of 4 MFMAs per tile for a pivot-block
-        //      inverse of 6 instead of ~60 fp64 operations that every lane repeats: the fp64 VALU (4.7 cycles per
-        //      wave instruction, scripts/microbench_valu.hip) is what bounds this kernel, not the matrix core.
+        //      inverse of 6 instead of ~60 fp64 operations that every lane repeats.  Lane masks are 0/1 fp64 factors:
+        //      v_cndmask pairs in their place measured 8 % slower for the whole iteration.
         {
 #pragma unroll
             for (int kb2 = 0; kb2 < 8; ++kb2) {
@@ -435,7 +453,6 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVE
                     const double am0 = fma(notj, __shfl(tk, (2 * half) * 16 + li, 64), (li == k0) ? 1.0 : 0.0);
                     const double am1 = fma(notj, __shfl(tk, (2 * half + 1) * 16 + li, 64), (li == k0 + 1) ? 1.0 : 0.0);
                     const double sel0 = (lk == 2 * half) ? 1.0 : 0.0, sel1 = (lk == 2 * half + 1) ? 1.0 : 0.0;
-                    // row r of Pinv * A'[K,:] for the lanes of k-slot 2*half + r, zero in the two idle k-slots
                     const double bop = fma(sel0 * i00 + sel1 * i01, am0, (sel0 * i01 + sel1 * i11) * am1);
                     const double act = sel0 + sel1;
                     const double aop = act * ((li < k0) ? tk : -tk);
@@ -447,24 +464,32 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVE
                 }
             }
         }
-        // W_t to LDS once (z = W r, the next Schur tile) and to the workspace straight from the registers
+        GP_STAMP(3);
+        // W_t to LDS once (rows for z = W r, elements for the next Schur tile) and to the workspace straight from the
+        // registers.  One wave: its LDS accesses execute in order, the fence only pins the compiler's order.
         double* Wl = Sb_[dir];
 #pragma unroll
         for (int q = 0; q < 4; ++q) Wl[(lk + 4 * q) * GP_LD + li] = T[q];
         wave_sync();
         const double* W = Wl;
-        // ---- z = W r ; store W_t, z_t
+        // ---- z = W r (r_j broadcast with v_readlane); store W_t, z_t
         double* wt = wW + (size_t)t * GP_WS_PER_T;
         double zi = 0.0;
-        if (lane < dim) {
-            for (int j = 0; j < dim; ++j) zi = fma(W[lane * GP_LD + j], rv[j], zi);
-            zv[lane] = zi;
-            wt[GP_TRI + lane] = zi;
+        {
+            const int rowl = (lane < dim) ? lane : 0;
+            if (DT) {
+#pragma unroll
+                for (int j = 0; j < 2 * DT; ++j) zi = fma(W[rowl * GP_LD + j], readlane_f64(r, j), zi);
+            } else {
+                for (int j = 0; j < dim; ++j) zi = fma(W[rowl * GP_LD + j], readlane_f64(r, j), zi);
+            }
         }
+        if (lane < dim) wt[GP_TRI + lane] = zi;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             if (lk + 4 * q <= li) wt[tri_st[q]] = T[q];
-        wave_sync();
+        z_last = zi;
+        x_last = x0;
         if (!merge) {
             // ---- next tile: -(U^T W U), block (a,b) (i',j') = -sum_{c,e} U[c][a] U[e][b] W[i'+cD][j'+eD]; the four
             //      coefficient products and the element offsets are per-lane constants (nt_*), so 4 fma per element
@@ -477,17 +502,23 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVE
                 v = fma(nt_c[q][3], Wq[D * GP_LD + D], v);
                 Snext[q] = v;
             }
-            // carry to the neighbour's r = gnext - U^T z
-            if (lane < dim) {
+            // carry to the neighbour's r = gnext - U^T z (z of the partner lane through the crossbar)
+            {
                 const bool ip = lane < D;
-                const int ii = ip ? lane : lane - D;
-                const double zp = zv[ii], zvv = zv[ii + D];
+                const double zpart = __shfl(zi, ip ? lane + D : lane - D, 64);
+                const double zp = ip ? zi : zpart, zvv = ip ? zpart : zi;
                 rcarry = gnext - (ip ? u00 * zp + u10 * zvv : u01 * zp + u11 * zvv);
             }
-            wave_sync();                                           // W / zv reads done before the next step overwrites them
+            wave_sync();                                           // W reads stay ahead of the next step's tile write
         }
+        GP_STAMP(4);
         xr0 = xr1; xr1 = xr2; jr = jr1; jr1 = jr2; dm0 = dm1; dm1 = dm2;
+        GP_STAMP(5);
     }
+#ifdef MPB_GP_STAMPS
+    if (b == 0 && dir == 0 && lane == 0)
+        for (int i = 0; i < 8; ++i) gp_phase_cycles[i] = ph[i];
+#endif
     // ---- hand-over at the merge row: wave 1 publishes its last Schur tile and r carry (first barrier, taken by wave 0
     //      at the top of its merge step); wave 0 publishes dtheta_m = z_m and updates x_m (second barrier).
     if (dir) {
@@ -497,9 +528,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVE
         __syncthreads();
     } else {
         if (lane < dim) {
-            const double dm_ = zv[lane];
-            ex_d[lane] = dm_;
-            xb[m * dim + lane] = (float)(xs[0][lane] + K.step * dm_);   // xs[0] = x_m (fp64 copy of the fp32 row)
+            ex_d[lane] = z_last;                                        // dtheta_m = z_m
+            xb[m * dim + lane] = (float)(x_last + K.step * z_last);
         }
     }
     __syncthreads();
