@@ -150,8 +150,12 @@ __device__ __forceinline__ void stomp_eps4(uint32_t p_global, uint32_t s, uint32
 }
 #define NT_STRIDE 20  // floats per waypoint row of the noise tile: 80 B keeps ds_read_b128 conflict-free
 
+#ifndef MPB_A_WPB
+#define MPB_A_WPB 4      // waves (rollouts) per block of the H = 64 kernel.  Measured at C3 / P = 4096: 2 waves 42 / 878 us (the
+                         // L and grid staging is per block), 4 waves 30.0 / 638, 8 waves 29.6 / 670, 16 waves 30.0 / 779
+#endif
 template <int DCH, bool WITH_COST>
-__global__ __launch_bounds__(256, 4) void stomp_sample_cost_h64_kernel(
+__global__ __launch_bounds__(64 * MPB_A_WPB, 16 / MPB_A_WPB) void stomp_sample_cost_h64_kernel(
     const float* __restrict__ means, const float* __restrict__ eps, float* __restrict__ samples,
     float* __restrict__ costs, const float* __restrict__ Lmat, const float* __restrict__ geom,
     int P, int S, float k_sigma, float weight, uint32_t seed_lo, uint32_t seed_hi, uint32_t iter,
@@ -159,11 +163,11 @@ __global__ __launch_bounds__(256, 4) void stomp_sample_cost_h64_kernel(
     constexpr int H = 64;
     MPB_STAMP(0);
     __shared__ __attribute__((aligned(16))) float Lp[H * H];             // permuted L, 16 KB
-    __shared__ __attribute__((aligned(16))) float Nt[4][H * NT_STRIDE];  // per-wave noise tile, 4 x 5 KB
+    __shared__ __attribute__((aligned(16))) float Nt[MPB_A_WPB][H * NT_STRIDE];  // per-wave noise tile, 5 KB each
     __shared__ float4 otab[MPB_GRID_MAX_SPH + 1];                        // obstacle table of the broad phase
     // Lp[(((m*4 + ks4)*4 + g)*16 + i)*4 + kk] = L[16m+i][4*(4*ks4+kk) + g]; coalesced float4 reads of L,
     // scattered LDS writes
-    for (int v4 = threadIdx.x; v4 < H * H / 4; v4 += 256) {
+    for (int v4 = threadIdx.x; v4 < H * H / 4; v4 += 64 * MPB_A_WPB) {
         const f32x4 lv = reinterpret_cast<const f32x4*>(Lmat)[v4];
         const int row = v4 >> 4, col0 = (v4 & 15) << 2;
         const int m = row >> 4, i = row & 15;
@@ -182,13 +186,13 @@ __global__ __launch_bounds__(256, 4) void stomp_sample_cost_h64_kernel(
     // this kernel wrote still resident in that L2 instead of fetching them across the fabric.
     int lb = blockIdx.x;
     {
-        const int nb = S >> 2;                       // blocks per particle
-        if ((S & 3) == 0 && (P & 7) == 0) {
+        const int nb = S / MPB_A_WPB;                // blocks per particle
+        if ((S % MPB_A_WPB) == 0 && (P & 7) == 0) {
             const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
             lb = (8 * (q / nb) + x) * nb + (q % nb); // particle 8*(q/nb)+x, its (q%nb)-th block
         }
     }
-    const int r = lb * 4 + wave;  // rollout index
+    const int r = lb * MPB_A_WPB + wave;  // rollout index
     const bool live = r < P * S;
     const int p = live ? r / S : 0, s = live ? r - p * S : 0;
     const int j = lane & 15, g = lane >> 4;
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(256, 4) void stomp_sample_cost_h64_kernel(
                 // take this branch together: G is wave- and block-uniform)
                 unsigned* gridw = reinterpret_cast<unsigned*>(Lp);
                 __syncthreads();
-                grid_stage(G, gridw, otab, threadIdx.x, 256);
+                grid_stage(G, gridw, otab, threadIdx.x, 64 * MPB_A_WPB);
                 __syncthreads();
                 MPB_STAMP(6);
                 if (live && h >= 1) c = fmaf(G.fscale, waypoint_cost_grid(G, gridw, otab, q), c);
@@ -737,8 +741,9 @@ static void launch_sample(const float* means, const float* eps, float* samples, 
     const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
 #define MPB_A_CASE(DCH)                                                                                          \
     case DCH:                                                                                                    \
-        hipLaunchKernelGGL((stomp_sample_cost_h64_kernel<DCH, WITH_COST>), grid, block, 0, st, means, eps, samples, \
-                           costs, L, geom, P, S, k_sigma, weight, lo, hi, iter, particle_offset);                \
+        hipLaunchKernelGGL((stomp_sample_cost_h64_kernel<DCH, WITH_COST>), dim3((B + MPB_A_WPB - 1) / MPB_A_WPB),  \
+                           dim3(64 * MPB_A_WPB), 0, st, means, eps, samples, costs, L, geom, P, S, k_sigma, weight, \
+                           lo, hi, iter, particle_offset);                                                       \
         return;
     if (H == 64) {
         switch (d) {
