@@ -156,6 +156,16 @@ int mpb_stomp_step(float *means, const float *eps, float *samples, float *costs,
                    int P, int S, int H, int d, int D,
                    float k_sigma, float weight, float lr, float temperature,
                    int n_iters, uint64_t seed, uint32_t iter0, uint32_t particle_offset, void *stream);
+/* Measurement aid for bench.py: the n_iters (1..1024) iterations of mpb_stomp_step with device noise, every kernel
+ * launch carrying its own pair of HIP events on the dispatch (hipExtLaunchKernelGGL), then ONE stream synchronise.
+ * Writes the average duration in ms of the sample+cost kernel and of the update kernel, measured in the loop they
+ * run in (the per-kernel figure rocprofv3 --kernel-trace --stats reports for the same loop).  Host pointers. */
+int mpb_stomp_step_profile(float *means, float *samples, float *costs, float *weights,
+                           const float *L, const float *Sigma, const float *geom,
+                           int P, int S, int H, int d, int D,
+                           float k_sigma, float weight, float lr, float temperature,
+                           int n_iters, uint64_t seed, uint32_t iter0, uint32_t particle_offset, void *stream,
+                           float *sample_kernel_ms, float *update_kernel_ms);
 int mpb_stomp_sample(const float *means, const float *eps, float *samples, const float *L,
                      const float *geom, float *costs, /* both NULL: sample only; both set: fused cost */
                      int P, int S, int H, int d, float k_sigma, float weight,

@@ -34,6 +34,7 @@ SIGNATURES = {
     'mpb_field_cost_points': [_p, _p, _p, _i, _i, _p],
     'mpb_field_cost_points_vjp': [_p, _p, _p, _p, _i, _i, _p],
     'mpb_stomp_step': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _u64, _u32, _u32, _p],
+    'mpb_stomp_step_profile': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _u64, _u32, _u32, _p, _p, _p],
     'mpb_stomp_sample': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _u64, _u32, _u32, _p],
     'mpb_stomp_update': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     'mpb_chomp_step': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _p],

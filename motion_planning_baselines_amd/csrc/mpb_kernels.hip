@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include "mpb_common.h"
+#include <hip/hip_ext.h>
 #include "mpb_geom.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -107,6 +108,15 @@ extern "C" int mpb_geom_check(const float* g, int n_words) {
 }
 
 #define MPB_MAX_D (2 * MPB_MAX_DOF)
+
+// Measurement aid (mpb_stomp_step_profile): while these are set, the STOMP kernel launches record the pair on the
+// dispatch itself (hipExtLaunchKernelGGL: kernel begin / end timestamps, the quantity rocprofv3 --kernel-trace reports).
+static thread_local hipEvent_t t_ev0 = nullptr, t_ev1 = nullptr;
+#define MPB_LAUNCH(kernel, grid, block, lds, st, ...)                                                   \
+    do {                                                                                                \
+        if (t_ev0) hipExtLaunchKernelGGL(kernel, grid, block, lds, st, t_ev0, t_ev1, 0, __VA_ARGS__);   \
+        else hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                             \
+    } while (0)
 
 // ------------------------------------------------------------------------------------------------
 // STOMP kernel A, H = 64 fast path: the time-correlated noise  N = L * eps  (64x64 lower-triangular L,
@@ -719,14 +729,14 @@ static bool launch_update(float* means, const float* samples, const float* costs
         const int n4 = n >> 2;
         const int SG = (1024 / n4) < 4 ? (1024 / n4) : 4;
         const size_t lds = (size_t)n * 4 + (size_t)SG * n4 * 16;
-        hipLaunchKernelGGL(stomp_update_v4_kernel, dim3(P), dim3(1024), lds, st, means, samples, costs, weights, Sigma, P,
+        MPB_LAUNCH(stomp_update_v4_kernel, dim3(P), dim3(1024), lds, st, means, samples, costs, weights, Sigma, P,
                            S, H, d, lr, temperature);
         return true;
     }
     size_t lds;
     int sig_lds;
     if (!update_lds(S, H, d, lds, sig_lds)) return false;
-    hipLaunchKernelGGL(stomp_update_kernel, dim3(P), dim3(1024), lds, st, means, samples, costs, weights, Sigma, P, S, H,
+    MPB_LAUNCH(stomp_update_kernel, dim3(P), dim3(1024), lds, st, means, samples, costs, weights, Sigma, P, S, H,
                        d, lr, temperature, sig_lds);
     return true;
 }
@@ -741,7 +751,7 @@ static void launch_sample(const float* means, const float* eps, float* samples, 
     const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
 #define MPB_A_CASE(DCH)                                                                                          \
     case DCH:                                                                                                    \
-        hipLaunchKernelGGL((stomp_sample_cost_h64_kernel<DCH, WITH_COST>), dim3((B + MPB_A_WPB - 1) / MPB_A_WPB),  \
+        MPB_LAUNCH((stomp_sample_cost_h64_kernel<DCH, WITH_COST>), dim3((B + MPB_A_WPB - 1) / MPB_A_WPB),  \
                            dim3(64 * MPB_A_WPB), 0, st, means, eps, samples, costs, L, geom, P, S, k_sigma, weight, \
                            lo, hi, iter, particle_offset);                                                       \
         return;
@@ -755,7 +765,7 @@ static void launch_sample(const float* means, const float* eps, float* samples, 
     // any other horizon / channel count (H <= MPB_MAX_H = 256, d <= MPB_MAX_D = 16): chunked MFMA kernel
     {
 #define MPB_HX(M)                                                                                                   \
-    hipLaunchKernelGGL((stomp_sample_cost_hx_kernel<WITH_COST, M>), grid, block, 0, st, means, eps, samples, costs, L, \
+    MPB_LAUNCH((stomp_sample_cost_hx_kernel<WITH_COST, M>), grid, block, 0, st, means, eps, samples, costs, L, \
                        geom, P, S, H, d, k_sigma, weight, lo, hi, iter, particle_offset)
         if (H <= 64) MPB_HX(1);
         else if (H <= 128) MPB_HX(2);
@@ -856,5 +866,51 @@ extern "C" int mpb_stomp_step(float* means, const float* eps, float* samples, fl
     for (int k = 0; k < 2; ++k)
         if (ev[k]) (void)hipEventDestroy(ev[k]);
     return check_launch(__func__);
+}
+
+extern "C" int mpb_stomp_step_profile(float* means, float* samples, float* costs, float* weights, const float* L,
+                                      const float* Sigma, const float* geom, int P, int S, int H, int d, int D,
+                                      float k_sigma, float weight, float lr, float temperature, int n_iters, uint64_t seed,
+                                      uint32_t iter0, uint32_t particle_offset, void* stream, float* sample_kernel_ms,
+                                      float* update_kernel_ms) {
+    if (!means || !samples || !costs || !weights || !L || !Sigma || !geom || !sample_kernel_ms || !update_kernel_ms)
+        return fail(MPB_E_INVALID, "%s: null pointer", __func__);
+    if (P < 1 || S < 1 || !shape_ok(H, d, D) || n_iters < 1 || n_iters > 1024) return fail(MPB_E_INVALID, "%s: bad shape", __func__);
+    if (!(temperature > 0.f)) return fail(MPB_E_INVALID, "%s: temperature must be > 0", __func__);
+    size_t lds_b;
+    int sig_lds;
+    if (!update_lds(S, H, d, lds_b, sig_lds)) return fail(MPB_E_UNSUPPORTED, "%s: S + H*d too large for LDS", __func__);
+    hipEvent_t* ev = new hipEvent_t[4 * (size_t)n_iters];
+    for (int i = 0; i < 4 * n_iters; ++i)
+        if (hipEventCreate(&ev[i]) != hipSuccess) {
+            for (int k = 0; k < i; ++k) (void)hipEventDestroy(ev[k]);
+            delete[] ev;
+            return fail(MPB_E_HIP, "%s: hipEventCreate failed", __func__);
+        }
+    for (int it = 0; it < n_iters; ++it) {
+        t_ev0 = ev[4 * it + 0]; t_ev1 = ev[4 * it + 1];
+        launch_sample<true>(means, nullptr, samples, costs, L, geom, P, S, H, d, k_sigma, weight, seed, iter0 + (uint32_t)it,
+                            particle_offset, (hipStream_t)stream);
+        t_ev0 = ev[4 * it + 2]; t_ev1 = ev[4 * it + 3];
+        launch_update(means, samples, costs, weights, Sigma, P, S, H, d, lr, temperature, (hipStream_t)stream);
+    }
+    t_ev0 = t_ev1 = nullptr;
+    int rc = check_launch(__func__);
+    if (rc == MPB_OK && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) rc = fail(MPB_E_HIP, "%s: synchronize failed", __func__);
+    double sa = 0.0, sb = 0.0;
+    for (int it = 0; it < n_iters && rc == MPB_OK; ++it) {
+        float ma = 0.f, mb = 0.f;
+        if (hipEventElapsedTime(&ma, ev[4 * it + 0], ev[4 * it + 1]) != hipSuccess ||
+            hipEventElapsedTime(&mb, ev[4 * it + 2], ev[4 * it + 3]) != hipSuccess)
+            rc = fail(MPB_E_HIP, "%s: hipEventElapsedTime failed", __func__);
+        sa += ma;
+        sb += mb;
+    }
+    for (int i = 0; i < 4 * n_iters; ++i) (void)hipEventDestroy(ev[i]);
+    delete[] ev;
+    if (rc != MPB_OK) return rc;
+    *sample_kernel_ms = (float)(sa / n_iters);
+    *update_kernel_ms = (float)(sb / n_iters);
+    return MPB_OK;
 }
 

@@ -232,6 +232,27 @@ def stomp_step(means, eps, samples, costs, weights, L, Sigma, geom, S, D, k_sigm
         int(seed) & (2 ** 64 - 1), int(iter0), int(particle_offset), _stream()), 'mpb_stomp_step')
 
 
+def stomp_step_profile(means, samples, costs, weights, L, Sigma, geom, S, D, k_sigma, weight, lr, temperature,
+                       n_iters=50, seed=0, iter0=0, particle_offset=0):
+    """Measurement aid: n_iters iterations of stomp_step (device noise) with per-dispatch HIP events; returns the average
+    duration in ms of (sample+cost kernel, update kernel) inside that loop.  Synchronises the stream."""
+    P, H, d = means.shape
+    _chk(means, (P, H, d), 'means')
+    _chk(samples, (P, S, H, d), 'samples')
+    _chk(costs, (P, S), 'costs')
+    _chk(weights, (P, S), 'weights')
+    _chk(L, (H, H), 'L')
+    _chk(Sigma, (H, H), 'Sigma')
+    ka, kb = ctypes.c_float(0.0), ctypes.c_float(0.0)
+    _lib.check(_lib.lib().mpb_stomp_step_profile(
+        _ptr(means), _ptr(samples), _ptr(costs), _ptr(weights), _ptr(L), _ptr(Sigma), _ptr(geom.buf),
+        P, S, H, d, D, float(k_sigma), float(weight), float(lr), float(temperature), int(n_iters),
+        int(seed) & (2 ** 64 - 1), int(iter0), int(particle_offset), _stream(),
+        ctypes.cast(ctypes.pointer(ka), ctypes.c_void_p), ctypes.cast(ctypes.pointer(kb), ctypes.c_void_p)),
+        'mpb_stomp_step_profile')
+    return float(ka.value), float(kb.value)
+
+
 def stomp_sample(means, eps, samples, L, S, seed=0, it=0, particle_offset=0, geom=None, costs=None, k_sigma=0.0,
                  weight=1.0):
     """First kernel of an iteration: draw + write samples; with geom/costs also the fused collision cost."""

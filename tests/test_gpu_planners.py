@@ -242,3 +242,32 @@ def test_mppi_split_methods_equal_optimize(gpu_device):
     assert Xr.shape == (32, 64, 2) and torch.allclose(Xr, X2, rtol=1e-5, atol=1e-6)
     Xm = b.get_state_trajectories_rollout(**obs)
     assert Xm.shape == (1, 64, 2) and torch.equal(Xm[0, 0].cpu(), torch.tensor([-0.8, -0.8]))
+
+
+def test_stomp_step_profile_matches_step(gpu_device):
+    """The measurement entry point runs exactly the iterations of mpb_stomp_step (same kernels, same Philox counters)
+    and returns plausible per-kernel durations."""
+    from motion_planning_baselines_amd import ops, workloads
+    from motion_planning_baselines_amd.planners.stomp import precision_to_scale_tril, stomp_precision_matrix
+    dev = gpu_device
+    P, S, H = 8, 8, 64
+    wl = workloads.panda_spheres_stomp(P, dev, H=H, S=S)
+    d = wl['means0'].shape[-1]
+    R = stomp_precision_matrix(H, wl['params']['dt'], 0.1, dict(device='cpu', dtype=torch.float32))
+    Sigma, L = torch.inverse(R).contiguous().to(dev), precision_to_scale_tril(R).contiguous().to(dev)
+    geom = ops.DeviceGeometry(wl['robot'], wl['field'], dev)
+    outs = []
+    for prof in (False, True):
+        means = wl['means0'].clone()
+        samples, costs, weights = torch.empty(P, S, H, d, device=dev), torch.empty(P, S, device=dev), torch.empty(P, S, device=dev)
+        if prof:
+            ka, kb = ops.stomp_step_profile(means, samples, costs, weights, L, Sigma, geom, S, 7, 1e6, 1.0, 0.1, 1.0, n_iters=5,
+                                            seed=3, iter0=11)
+            assert 1e-4 < ka < 5.0 and 1e-4 < kb < 5.0
+        else:
+            ops.stomp_step(means, None, samples, costs, weights, L, Sigma, geom, S, 7, 1e6, 1.0, 0.1, 1.0, n_iters=5, seed=3,
+                           iter0=11)
+        torch.cuda.synchronize()
+        outs.append((means.clone(), samples.clone(), costs.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
