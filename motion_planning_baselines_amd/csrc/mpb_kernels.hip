@@ -558,7 +558,7 @@ __global__ __launch_bounds__(1024) void stomp_update_kernel(
 // Vectorised variant of kernel B for H*d divisible by 4, H*d <= 1024, H <= 64 and S <= 64, built for a
 // short critical path (the kernel is pure latency: ~900 VALU instructions per wave):
 //   * every load is issued in the first instructions: 8 float4 sample loads per thread (they do not
-//     depend on the weights), the thread's row of Sigma (registers, no LDS staging) and the costs;
+//     depend on the weights), the thread's float4 of Sigma (staged in LDS with padded rows) and the costs;
 //   * the softmax over S <= 64 is done redundantly by every wave with wave reductions -- no barriers;
 //   * two barriers in total (partial sums -> delta -> matvec); delta is kept transposed in LDS so the matvec reads
 //     float4s, and runs four independent accumulators with the learning rate applied once (8.2 -> 7.6 us).
@@ -573,6 +573,7 @@ __global__ __launch_bounds__(1024) void stomp_update_v4_kernel(
     const int spg = (S + SG - 1) / SG;                // samples per group
     float* delta = lds;                               // d rows of UPD_LD floats (transposed, padded)
     float4* part = reinterpret_cast<float4*>(delta + d * UPD_LD);  // SG * n4 float4
+    float* sig_l = reinterpret_cast<float*>(part + SG * n4);       // H rows of UPD_LD floats
     const int p = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const int sg = tid / n4, i4 = tid - sg * n4;
@@ -589,18 +590,30 @@ __global__ __launch_bounds__(1024) void stomp_update_v4_kernel(
             v[k] = (s0 + k < s1) ? smp4[(size_t)(s0 + k) * n4] : mu;
     }
     const float cst = (lane < S) ? costs[(size_t)p * S + lane] : 0.f;
-    // row of Sigma for the matvec output this thread owns (thread tid < n <-> element (h, c))
+    // the matvec output this thread owns (thread tid < n <-> element (h, c)); Sigma (H x H, the same for every block)
+    // is staged once in LDS with padded rows: one coalesced float4 per thread (H = 64) instead of a 64-float row per
+    // thread through the L1 (229 KB per block: 1.3 us of the kernel, measured by elimination)
     const int hh = (tid < n) ? tid / d : 0, cc = (tid < n) ? tid - hh * d : 0;
-    float4 srow[16];
+    float4 sg4[(64 * 64 / 4 + 1023) / 1024];
 #pragma unroll
-    for (int k = 0; k < 16; ++k)
-        srow[k] = (4 * k < H) ? reinterpret_cast<const float4*>(Sigma + (size_t)hh * H)[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < (64 * 64 / 4 + 1023) / 1024; ++u) {
+        const int v4 = tid + 1024 * u;
+        sg4[u] = (v4 < H * H / 4) ? reinterpret_cast<const float4*>(Sigma)[v4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     // ---- softmax over S (every wave, redundantly): w for sample `lane`
     const float xs = (lane < S) ? -cst / temperature : -3.0e38f;
     const float mx = wave_max_f32(xs);
     const float ex = (lane < S) ? expf(xs - mx) : 0.f;
     const float wl = ex / wave_sum_f32(ex);
     if (tid < S) weights[(size_t)p * S + tid] = wl;
+#pragma unroll
+    for (int u = 0; u < (64 * 64 / 4 + 1023) / 1024; ++u) {
+        const int v4 = tid + 1024 * u;
+        if (v4 < H * H / 4) {
+            const int row = (4 * v4) / H, col = 4 * v4 - row * H;
+            *reinterpret_cast<float4*>(sig_l + row * UPD_LD + col) = sg4[u];
+        }
+    }
     // ---- weighted noise reduce; the weight of sample s is broadcast from lane s
     if (worker) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -642,14 +655,15 @@ __global__ __launch_bounds__(1024) void stomp_update_v4_kernel(
     if (tid < n) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         const float4* dcol = reinterpret_cast<const float4*>(delta + cc * UPD_LD);
+        const float4* srow = reinterpret_cast<const float4*>(sig_l + hh * UPD_LD);
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             if (4 * k < H) {
-                const float4 dv = dcol[k];
-                acc[k & 3] = fmaf(srow[k].x, dv.x, acc[k & 3]);
-                acc[k & 3] = fmaf(srow[k].y, dv.y, acc[k & 3]);
-                acc[k & 3] = fmaf(srow[k].z, dv.z, acc[k & 3]);
-                acc[k & 3] = fmaf(srow[k].w, dv.w, acc[k & 3]);
+                const float4 dv = dcol[k], sv = srow[k];
+                acc[k & 3] = fmaf(sv.x, dv.x, acc[k & 3]);
+                acc[k & 3] = fmaf(sv.y, dv.y, acc[k & 3]);
+                acc[k & 3] = fmaf(sv.z, dv.z, acc[k & 3]);
+                acc[k & 3] = fmaf(sv.w, dv.w, acc[k & 3]);
             }
         }
         means[(size_t)p * n + tid] += lr * ((acc[0] + acc[1]) + (acc[2] + acc[3]));
@@ -740,7 +754,7 @@ static bool launch_update(float* means, const float* samples, const float* costs
     if (Sigma != nullptr && (n & 3) == 0 && n <= 1024 && H <= 64 && (H & 3) == 0 && S <= 64) {
         const int n4 = n >> 2;
         const int SG = (1024 / n4) < 4 ? (1024 / n4) : 4;
-        const size_t lds = (size_t)d * UPD_LD * 4 + (size_t)SG * n4 * 16;
+        const size_t lds = (size_t)d * UPD_LD * 4 + (size_t)SG * n4 * 16 + (size_t)H * UPD_LD * 4;
         MPB_LAUNCH(stomp_update_v4_kernel, dim3(P), dim3(1024), lds, st, means, samples, costs, weights, Sigma, P,
                            S, H, d, lr, temperature);
         return true;
