@@ -267,8 +267,48 @@ def build_grid(spheres, a_max, slack=1e-4):
                 stats=dict(mean=float(counts.mean()), max=int(counts.max()), overflow=int((counts > 4).sum())))
 
 
-def pack_geometry(robot, field, scales=None):
+def links_that_can_touch(rs, fs, slack=1e-4):
+    """Static broad phase at pack time (serial chains): a collision sphere riding on frame 1 moves on a circle about the
+    first joint axis whatever the trajectory does; when that circle keeps farther than margin + r_link (+ slack) from
+    every obstacle its hinge is exactly zero for every configuration, and the sphere can be left out of the link table
+    -- cost and gradient are unchanged bit for bit (x + 0).  Base links are the typical case (nothing is placed inside
+    the robot's pedestal).  Returns a boolean keep-mask over the robot's collision spheres; spheres on later frames are
+    always kept (their reach depends on several joints)."""
+    n_links = len(rs['link_radius'])
+    keep = np.ones(n_links, dtype=bool)
+    if rs['kind'] != KIND_CHAIN:
+        return keep
+    P0 = np.asarray(rs['joint_tf'][0], dtype=np.float64)            # frame 1 = P0 * Rz(q0)
+    R0, t0 = P0[:, :3], P0[:, 3]
+    n = R0[:, 2]                                                     # joint axis in the world
+    sph = np.asarray(fs['spheres'], dtype=np.float64).reshape(-1, 4)
+    box = np.asarray(fs['boxes'], dtype=np.float64).reshape(-1, 6)
+    cen = np.concatenate([sph[:, :3], box[:, :3]], 0)
+    rad = np.concatenate([sph[:, 3], np.linalg.norm(box[:, 3:6], axis=1)], 0)     # boxes: bounding sphere
+    for l in range(n_links):
+        if int(rs['link_frame'][l]) != 1:
+            continue
+        o = np.asarray(rs['link_offset'][l], dtype=np.float64)
+        a0 = t0 + R0 @ np.array([0.0, 0.0, o[2]])                   # centre of the circle
+        rho = float(np.hypot(o[0], o[1]))
+        v = cen - a0
+        h = v @ n
+        rperp = np.linalg.norm(v - h[:, None] * n[None, :], axis=1)
+        dist = np.sqrt((rperp - rho) ** 2 + h ** 2)                 # obstacle centre to the circle
+        thr = float(fs['margin']) + float(rs['link_radius'][l]) + slack
+        if np.all(dist - rad > thr):
+            keep[l] = False
+    if not keep.any():
+        keep[-1] = True                                              # the kernels want at least one link
+    return keep
+
+
+def pack_geometry(robot, field, scales=None, prune_static=True):
     """Pack robot + collision field(s) into the flat fp32 word buffer the HIP kernels read.
+
+    prune_static: leave out the collision spheres that can never come within their hinge threshold of this field's
+    obstacles (links_that_can_touch); the per-sphere entry points (mpb_fk_collision_points, mpb_field_cost_points) need
+    the full table: pack with prune_static=False for them.
 
     `field` may be a list of up to MAX_FIELDS CollisionFields (the reference builds one CostCollision per field,
     gpmp2.py:70-78, and sums them): the per-field buffers are chained, header word [27] of each holding the word
@@ -302,11 +342,16 @@ def pack_geometry(robot, field, scales=None):
         assert 1 <= len(fields) <= MAX_FIELDS, f'1..{MAX_FIELDS} collision fields per geometry buffer'
         scales = [1.0] * len(fields) if scales is None else [float(v) for v in scales]
         assert len(scales) == len(fields)
-        parts = [pack_geometry(robot, f, scales=[sc]) for f, sc in zip(fields, scales)]
+        parts = [pack_geometry(robot, f, scales=[sc], prune_static=prune_static) for f, sc in zip(fields, scales)]
         for i, part in enumerate(parts[:-1]):
             part.view(np.int32)[27] = part.size
         return np.concatenate(parts)
     rs, fs = robot.spec(), field.spec()
+    if prune_static and rs['kind'] == KIND_CHAIN:
+        keep = links_that_can_touch(rs, fs)
+        if not keep.all():
+            rs = dict(rs, link_frame=np.asarray(rs['link_frame'])[keep], link_offset=np.asarray(rs['link_offset'])[keep],
+                      link_radius=np.asarray(rs['link_radius'])[keep])
     n_tf = rs['joint_tf'].shape[0]
     n_links = len(rs['link_radius'])
     n_sph, n_box = len(fs['spheres']), len(fs['boxes'])

@@ -38,10 +38,15 @@ def _chk(t, shape, name, allow_none=False):
 class DeviceGeometry:
     """Packed robot + field geometry resident in HBM (one small fp32 buffer)."""
 
-    def __init__(self, robot, field, device, scales=None):
-        """`field`: one CollisionField or a list of up to 4 (evaluated as sum_f scales[f] * cost_f)."""
+    def __init__(self, robot, field, device, scales=None, keep_all_links=False):
+        """`field`: one CollisionField or a list of up to 4 (evaluated as sum_f scales[f] * cost_f).
+        keep_all_links: pack every collision sphere of the robot (needed by the per-sphere entry points
+        fk_collision_points / field_cost_points); by default spheres that can never reach an obstacle of the field are
+        left out of the link table (geometry.links_that_can_touch: exact, cost and gradient unchanged)."""
         self.robot, self.field = robot, field
-        host = pack_geometry(robot, field, scales=scales)
+        host = pack_geometry(robot, field, scales=scales, prune_static=not keep_all_links)
+        self.all_links = int(host.view(np.int32)[5]) == len(robot.spec()['link_radius']) and (
+            not isinstance(field, (list, tuple)) or keep_all_links or len(field) == 1)
         _lib.geom_check(host)
         self.host = host
         self.n_dof = robot.q_dim
@@ -54,6 +59,7 @@ class DeviceGeometry:
         host = np.ascontiguousarray(packed, dtype=np.float32)
         _lib.geom_check(host)
         self.robot = self.field = None
+        self.all_links = True
         self.host = host
         self.n_dof = int(host.view(np.int32)[3])
         self.n_fields = count_fields(host)
@@ -133,10 +139,17 @@ def cost_terms_eval(trajs, n_dof, dt=0.0, k_gp=0.0, vel_fd=False, k_start=0.0, s
     return out, jl_total
 
 
+def _need_all_links(geom):
+    if not getattr(geom, 'all_links', True):
+        raise ValueError('this geometry leaves out collision spheres that cannot reach an obstacle; the per-sphere entry '
+                         'points need DeviceGeometry(..., keep_all_links=True)')
+
+
 def fk_collision_points(q, geom):
     """q (B,H,d) -> positions of the robot's collision spheres (B,H,L,3) (mpb_fk_collision_points)."""
     B, H, d = q.shape
     _chk(q, (B, H, d), 'q')
+    _need_all_links(geom)
     L = int(geom.host.view(np.int32)[5])
     pts = torch.empty(B, H, L, 3, device=q.device, dtype=torch.float32)
     _lib.check(_lib.lib().mpb_fk_collision_points(_ptr(q), _ptr(geom.buf), _ptr(pts), B, H, d, _stream()), 'mpb_fk_collision_points')
@@ -145,6 +158,7 @@ def fk_collision_points(q, geom):
 
 def fk_collision_points_vjp(q, geom, grad_pts):
     B, H, d = q.shape
+    _need_all_links(geom)
     L = int(geom.host.view(np.int32)[5])
     _chk(q, (B, H, d), 'q')
     _chk(grad_pts, (B, H, L, 3), 'grad_pts')
@@ -157,6 +171,7 @@ def fk_collision_points_vjp(q, geom, grad_pts):
 def field_cost_points(pts, geom):
     """Collision-sphere positions (B,H,L,3) -> hinge cost per waypoint (B,H) (mpb_field_cost_points)."""
     B, H, L, _ = pts.shape
+    _need_all_links(geom)
     _chk(pts, (B, H, int(geom.host.view(np.int32)[5]), 3), 'pts')
     cost = torch.empty(B, H, device=pts.device, dtype=torch.float32)
     _lib.check(_lib.lib().mpb_field_cost_points(_ptr(pts), _ptr(geom.buf), _ptr(cost), B, H, _stream()), 'mpb_field_cost_points')
@@ -165,6 +180,7 @@ def field_cost_points(pts, geom):
 
 def field_cost_points_vjp(pts, geom, grad_cost):
     B, H, L, _ = pts.shape
+    _need_all_links(geom)
     _chk(pts, (B, H, int(geom.host.view(np.int32)[5]), 3), 'pts')
     _chk(grad_cost, (B, H), 'grad_cost')
     gp = torch.empty_like(pts)

@@ -51,7 +51,7 @@ class Cost(ABC):
             import numpy as np
             from ...geometry import CollisionField
             far = CollisionField(spheres=np.array([[1.0e6, 1.0e6, 1.0e6, 1.0]], np.float32))     # FK only: the field is unused
-            geom = self.__dict__['_fk_geom'] = ops.DeviceGeometry(self.robot, far, trajs.device)
+            geom = self.__dict__['_fk_geom'] = ops.DeviceGeometry(self.robot, far, trajs.device, keep_all_links=True)
         return trajs, q_pos, q_vel, ops.fk_collision_points(trajs, geom)
 
     @staticmethod

@@ -84,5 +84,5 @@ class DeviceField:
 
 def device_robot_field(robot, field, device):
     """(DeviceRobot, DeviceField) for one robot / collision field pair (geometry.Robot*, geometry.CollisionField)."""
-    geom = ops.DeviceGeometry(robot, field, device)
+    geom = ops.DeviceGeometry(robot, field, device, keep_all_links=True)
     return DeviceRobot(robot, geom, device), DeviceField(field, geom)

@@ -92,9 +92,37 @@ def test_product_geometry_round_trip():
     g = load_golden('chomp_panda')
     robot, field = product_geometry_from_golden(g)
     from motion_planning_baselines_amd import geometry as G
-    buf = G.pack_geometry(robot, field)
+    buf = G.pack_geometry(robot, field, prune_static=False)
     i = buf.view(np.int32)
     assert i[5] == len(g['link_radius']) and i[6] == len(g['spheres'])
+
+
+def test_static_link_pruning_is_conservative():
+    """pack_geometry leaves out only collision spheres whose hinge is zero for EVERY joint configuration: spheres on
+    frame 1 whose circle about the first joint axis stays clear of all obstacles.  Checked by brute force with the oracle's
+    FK over a dense sweep of q1 (the other joints cannot move frame 1) and random full configurations."""
+    from motion_planning_baselines_amd import geometry as G
+    from oracle.geometry_ref import make_ref_geometry
+    robot = G.RobotPanda()
+    for field in (G.env_spheres_3d(seed=0), G.env_spheres_3d(seed=3),
+                  G.CollisionField(spheres=np.array([[0.12, 0.05, 0.18, 0.05], [0.5, 0.0, 0.5, 0.1]]), margin=0.05),
+                  G.CollisionField(boxes=np.array([[0.2, 0.0, 0.1, 0.05, 0.05, 0.05]]), margin=0.05)):
+        rs, fs = robot.spec(), field.spec()
+        keep = G.links_that_can_touch(rs, fs)
+        assert keep[np.asarray(rs['link_frame']) != 1].all()                  # later frames are never dropped
+        rr, rf = make_ref_geometry(robot, field, dict(device='cpu', dtype=torch.float64))
+        q = torch.zeros(4096, 7, dtype=torch.float64)
+        q[:, 0] = torch.linspace(-3.2, 3.2, 4096)
+        q[:, 1:] = 6.0 * torch.rand(4096, 6, dtype=torch.float64, generator=torch.Generator().manual_seed(1)) - 3.0
+        pts = rr.fk_map_collision(q)                                          # (N, L, 3)
+        sd = rf.signed_distance(pts)                                          # (N, L)
+        hinge = (float(fs['margin']) + torch.as_tensor(rs['link_radius'], dtype=torch.float64) - sd).clamp_min(0)
+        worst = hinge.max(0).values.numpy()
+        assert (worst[~keep] == 0).all(), worst[~keep]
+        buf = G.pack_geometry(robot, field)
+        assert buf.view(np.int32)[5] == int(keep.sum())
+    # the synthetic C3 scene keeps obstacles off the base axis: the three base-link spheres go
+    assert int(G.links_that_can_touch(robot.spec(), G.env_spheres_3d(seed=0).spec()).sum()) == 28
 
 
 def test_cost_term_specs_merge_into_one_launch():
