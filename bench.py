@@ -194,7 +194,8 @@ def main():
             'config': {'workload': 'panda_spheres STOMP B=%d (P=%d particles x S=%d samples) H=%d D=%d d=%d per GPU'
                                    % (P * S, P, S, H, D, d),
                        'pos_only': bool(args.pos_only), 'noise': 'device philox', 'sigma_coll': wl['sigma_coll'],
-                       'robot_collision_spheres': 31, 'obstacle_spheres': 16, 'parallelism': 'particles sharded x%d' % world,
+                       'robot_collision_spheres': 31, 'collision_spheres_after_static_pruning': int(geom.host.view('int32')[5]),
+                       'obstacle_spheres': 16, 'parallelism': 'particles sharded x%d' % world,
                        'algorithmic_bytes_per_iter': stomp_algorithmic_bytes(P, S, H, d)},
             'roofline': {'bound': 'hbm', 'kernel': 'stomp_sample_cost_h64_kernel<14,true>', 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
