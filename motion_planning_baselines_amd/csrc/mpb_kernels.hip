@@ -175,19 +175,13 @@ __global__ __launch_bounds__(64 * MPB_A_WPB, 16 / MPB_A_WPB) void stomp_sample_c
     __shared__ __attribute__((aligned(16))) float Lp[H * H];             // permuted L, 16 KB
     __shared__ __attribute__((aligned(16))) float Nt[MPB_A_WPB][H * NT_STRIDE];  // per-wave noise tile, 5 KB each
     __shared__ float4 otab[MPB_GRID_MAX_SPH + 1];                        // obstacle table of the broad phase
-    // Lp[(((m*4 + ks4)*4 + g)*16 + i)*4 + kk] = L[16m+i][4*(4*ks4+kk) + g]; coalesced float4 reads of L,
-    // scattered LDS writes
-    for (int v4 = threadIdx.x; v4 < H * H / 4; v4 += 64 * MPB_A_WPB) {
-        const f32x4 lv = reinterpret_cast<const f32x4*>(Lmat)[v4];
-        const int row = v4 >> 4, col0 = (v4 & 15) << 2;
-        const int m = row >> 4, i = row & 15;
+    // L is read here (coalesced float4s, kept in registers) and written to LDS only after the noise has been drawn: the
+    // Philox + Box-Muller phase below needs neither L nor LDS, so the load latency (every block of the launch hits L2
+    // at the same moment) hides behind it
+    constexpr int L_PER_THREAD = H * H / 4 / (64 * MPB_A_WPB);
+    f32x4 lreg[L_PER_THREAD];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int col = col0 + e, ks = col >> 2, g = col & 3;
-            Lp[((((m * 4 + (ks >> 2)) * 4 + g) * 16 + i) << 2) + (ks & 3)] = lv[e];
-        }
-    }
-    __syncthreads();
+    for (int u = 0; u < L_PER_THREAD; ++u) lreg[u] = reinterpret_cast<const f32x4*>(Lmat)[threadIdx.x + 64 * MPB_A_WPB * u];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     // XCD-aware block -> rollout map (speed only, any map is correct): workgroups are dealt round-robin
@@ -225,6 +219,19 @@ __global__ __launch_bounds__(64 * MPB_A_WPB, 16 / MPB_A_WPB) void stomp_sample_c
         }
     }
     MPB_STAMP(2);
+    // Lp[(((m*4 + ks4)*4 + g)*16 + i)*4 + kk] = L[16m+i][4*(4*ks4+kk) + g] (scattered LDS writes)
+#pragma unroll
+    for (int u = 0; u < L_PER_THREAD; ++u) {
+        const int v4 = threadIdx.x + 64 * MPB_A_WPB * u;
+        const int row = v4 >> 4, col0 = (v4 & 15) << 2;
+        const int m = row >> 4, i = row & 15;
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+            const int col = col0 + e4, ks = col >> 2, gq = col & 3;
+            Lp[((((m * 4 + (ks >> 2)) * 4 + gq) * 16 + i) << 2) + (ks & 3)] = lreg[u][e4];
+        }
+    }
+    __syncthreads();
     // ---- N = L * eps on the matrix cores
     const f32x4* Lp4 = reinterpret_cast<const f32x4*>(Lp);
     float* nt = Nt[wave];
