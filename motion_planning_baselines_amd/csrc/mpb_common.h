@@ -45,8 +45,11 @@ __device__ __forceinline__ uint4 philox4x32(uint4 ctr, uint2 key) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
-        const uint32_t hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
-        const uint32_t hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
+        // one 32 x 32 -> 64 multiply per word pair (v_mad_u64_u32) instead of v_mul_hi_u32 + v_mul_lo_u32: both are
+        // quarter-rate instructions, and the multiplies are most of the generator
+        const uint64_t p0 = (uint64_t)M0 * ctr.x, p1 = (uint64_t)M1 * ctr.z;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
         key.x += W0;
         key.y += W1;
