@@ -185,3 +185,29 @@ def test_static_link_pruning_changes_nothing(gpu_device):
     torch.cuda.synchronize()
     assert float(c0.max()) > 0
     assert torch.equal(c0, c1) and torch.equal(pw0, pw1) and torch.equal(g0, g1)
+
+
+def test_bench_line_contract(gpu_device):
+    """bench.py prints ONE JSON line with the driver's fields, consistent with each other (child process: bench.py owns
+    its process group / device set-up)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '20', '--warmup', '3',
+                          '--no-cpu-baseline'], check=True, capture_output=True, text=True, timeout=600, cwd=root).stdout
+    lines = [l for l in out.splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline'):
+        assert k in j, k
+    assert j['metric'] == 'stomp_trajectory_update_iters_per_sec' and j['unit'] == 'iters/s'
+    assert j['n_gpus'] == 1 and j['steps'] == 20 and j['warmup'] == 3 and j['higher_is_better'] is True
+    assert j['scaling'] == 'weak' and j['vs_baseline'] is None and j['dtype'] == 'f32' and j['data'] == 'synthetic'
+    assert 'workload' in j['config'] and 'model' not in j['config']
+    assert abs(j['value'] * j['ms_per_step'] * 1e-3 - 1.0) < 1e-6              # value = steps / elapsed on one GPU
+    r = j['roofline']
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+    assert abs(r['achieved'] - r['algorithmic_bytes_per_launch'] / (r['kernel_ms'] * 1e-3) / 1e9) < 1e-6 * r['achieved']
+    assert 0.005 < r['kernel_ms_dispatch_events'] <= r['kernel_ms'] < 0.2      # execution <= back-to-back launch period
+    assert j['value'] > 10_000                                                  # north_star: >= 10k it/s at C3
