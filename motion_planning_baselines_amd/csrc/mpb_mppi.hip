@@ -101,11 +101,20 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
         const bool last = it == n_iters - 1;
         __syncthreads();
         // ---- w_i = Cov_inv[i] @ mean_i (vector of the importance-sampling term)
-        for (int e = threadIdx.x; e < c * T; e += blockDim.x) {
-            const int i = e / T, t = e - i * T;
+        // eight lanes per output row: each reads a contiguous eighth of the row (coalesced), the partial sums meet in
+        // a three-step lane exchange.  (One thread per row walked the row with T dependent, uncoalesced global loads.)
+        for (int e0 = 0; e0 < c * T; e0 += blockDim.x >> 3) {
+            const int e = e0 + (threadIdx.x >> 3), seg = threadIdx.x & 7;
             float a = 0.f;
-            for (int k = 0; k < T; ++k) a = fmaf(cov_inv[((size_t)i * T + t) * T + k], m[k * c + i], a);
-            M.wvec[e] = a;
+            if (e < c * T) {
+                const int i = e / T, t = e - i * T;
+                const float* row = cov_inv + ((size_t)i * T + t) * T;
+                for (int k = seg; k < T; k += 8) a = fmaf(row[k], m[k * c + i], a);
+            }
+            a += __shfl_xor(a, 1, 64);
+            a += __shfl_xor(a, 2, 64);
+            a += __shfl_xor(a, 4, 64);
+            if (e < c * T && seg == 0) M.wvec[e] = a;
         }
         __syncthreads();
         float coll_wave = 0.f;                                  // this wave's share of the Q6 scalar
@@ -147,8 +156,22 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
                         // U = mean + L eps (gaussian.py:276-298), ascending k like the matmul row
                         float a = 0.f;
                         if (tril_in_lds) {
+                            // eight LDS reads in flight per trip, then the eight fma in ascending k (the order is the
+                            // matmul row's; only the load latency is paid once per trip instead of once per term)
                             const float* col = M.trilT + (size_t)i * T * T + t;
-                            for (int k = 0; k < kend; ++k) a = fmaf(col[(size_t)k * T], ew[i * T + k], a);
+                            const float* er = ew + i * T;
+                            int k = 0;
+                            for (; k + 8 <= kend; k += 8) {
+                                float cv[8], ev[8];
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) {
+                                    cv[u] = col[(size_t)(k + u) * T];
+                                    ev[u] = er[k + u];
+                                }
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) a = fmaf(cv[u], ev[u], a);
+                            }
+                            for (; k < kend; ++k) a = fmaf(col[(size_t)k * T], er[k], a);
                         } else {
                             const float* row = tril + ((size_t)i * T + t) * T;
                             for (int k = 0; k < kend; ++k) a = fmaf(row[k], ew[i * T + k], a);
@@ -238,7 +261,18 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
             const int i = e / T, t = e - i * T;
             const float mu = m[t * c + i];
             float a = 0.f;
-            for (int ss = 0; ss < S; ++ss) a += M.wts[ss] * (M.Us[((size_t)ss * c + i) * T + t] - mu);
+            int ss = 0;
+            for (; ss + 8 <= S; ss += 8) {
+                float wv[8], uv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    wv[u] = M.wts[ss + u];
+                    uv[u] = M.Us[((size_t)(ss + u) * c + i) * T + t];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += wv[u] * (uv[u] - mu);
+            }
+            for (; ss < S; ++ss) a += M.wts[ss] * (M.Us[((size_t)ss * c + i) * T + t] - mu);
             m[t * c + i] = mu + step_size * a;
         }
         __threadfence_block();
