@@ -21,6 +21,11 @@ static inline int mpb_check_launch(const char* what) {
     return MPB_OK;
 }
 
+// Wave reductions on the DPP path (data-parallel primitives: the VALU reads a neighbouring lane directly) instead of
+// ds_bpermute shuffles through the LDS crossbar: four dependent full-rate instructions bring every 16-lane row to its
+// row total, the four row totals are read with v_readlane.  Callers are wave-uniform (all 64 lanes active).
+//   quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140
+#ifdef MPB_SHFL_REDUCE   // the former butterfly, kept for A/B measurements
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -36,6 +41,49 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
     return v;
 }
+#else
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ float readlane_f32(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ float wave_sum_f32(float v) {
+    v += dpp_f32<0xB1>(v);
+    v += dpp_f32<0x4E>(v);
+    v += dpp_f32<0x141>(v);
+    v += dpp_f32<0x140>(v);
+    return (readlane_f32(v, 0) + readlane_f32(v, 16)) + (readlane_f32(v, 32) + readlane_f32(v, 48));
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+    v = fmaxf(v, dpp_f32<0xB1>(v));
+    v = fmaxf(v, dpp_f32<0x4E>(v));
+    v = fmaxf(v, dpp_f32<0x141>(v));
+    v = fmaxf(v, dpp_f32<0x140>(v));
+    return fmaxf(fmaxf(readlane_f32(v, 0), readlane_f32(v, 16)), fmaxf(readlane_f32(v, 32), readlane_f32(v, 48)));
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    v += dpp_f64<0x141>(v);
+    v += dpp_f64<0x140>(v);
+    const unsigned long long u = __double_as_longlong(v);
+    double r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, 16 * k);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 16 * k);
+        r[k] = __longlong_as_double(((unsigned long long)hi << 32) | lo);
+    }
+    return (r[0] + r[1]) + (r[2] + r[3]);
+}
+#endif
 
 // Philox4x32-R (Salmon et al., SC'11), counter-based: no state, result depends only on (key, counter).
 // R = 10 is the library default; R = 7 is the smallest round count the authors report as passing

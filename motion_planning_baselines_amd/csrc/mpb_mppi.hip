@@ -40,12 +40,16 @@ __device__ __forceinline__ float block_max(float v, float* red, int lane, int wa
     return t;
 }
 
+// inclusive prefix sum over the 64 lanes on the DPP path: Hillis-Steele inside each 16-lane row (row_shr 1, 2, 4, 8,
+// zeros shifted in), then the totals of the earlier rows (row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3)
 __device__ __forceinline__ float wave_scan_incl(float v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const float up = __shfl_up(v, off, 64);
-        if (lane >= off) v += up;
-    }
+    (void)lane;
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));
     return v;
 }
 
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
                     const float v = (i < c && on) ? fminf(fmaxf(u[i], umin[i]), umax[i]) * dt : 0.f;
                     const float inc = wave_scan_incl(v, lane);
                     x[i] = x0[i] + (carry[i] + (inc - v));
-                    carry[i] += __shfl(inc, 63, 64);
+                    carry[i] += readlane_f32(inc, 63);
                 }
                 if (on) {
                     // ---- quadratic cost terms of step t (point.py:198-226)
