@@ -244,19 +244,35 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
         }
         __syncthreads();
         // ---- softmax over samples (mppi.py:73-76)
-        float mx = -3.0e38f;
-        for (int ss = threadIdx.x; ss < S; ss += blockDim.x) mx = fmaxf(mx, -(M.cst[ss] + total) / temp);
-        mx = block_max(mx, M.red, lane, wave, nw);
-        float z = 0.f;
-        for (int ss = threadIdx.x; ss < S; ss += blockDim.x) z += expf(-(M.cst[ss] + total) / temp - mx);
-        z = block_sum(z, M.red, lane, wave, nw);
-        for (int ss = threadIdx.x; ss < S; ss += blockDim.x) {
-            const float cs = M.cst[ss] + total;
-            const float w = expf(-cs / temp - mx) / z;
-            M.wts[ss] = w;
-            if (last) {
-                costs[(size_t)prob * S + ss] = cs;
-                weights[(size_t)prob * S + ss] = w;
+        if (S <= 64) {
+            // every wave repeats it on its own (lane = sample, wave reductions): no block-wide reduction, one barrier
+            const float cs = (lane < S) ? M.cst[lane] + total : 0.f;
+            const float xs = (lane < S) ? -cs / temp : -3.0e38f;
+            const float mx = wave_max_f32(xs);
+            const float ex = (lane < S) ? expf(xs - mx) : 0.f;
+            const float w = ex / wave_sum_f32(ex);
+            if (wave == 0 && lane < S) {
+                M.wts[lane] = w;
+                if (last) {
+                    costs[(size_t)prob * S + lane] = cs;
+                    weights[(size_t)prob * S + lane] = w;
+                }
+            }
+        } else {
+            float mx = -3.0e38f;
+            for (int ss = threadIdx.x; ss < S; ss += blockDim.x) mx = fmaxf(mx, -(M.cst[ss] + total) / temp);
+            mx = block_max(mx, M.red, lane, wave, nw);
+            float z = 0.f;
+            for (int ss = threadIdx.x; ss < S; ss += blockDim.x) z += expf(-(M.cst[ss] + total) / temp - mx);
+            z = block_sum(z, M.red, lane, wave, nw);
+            for (int ss = threadIdx.x; ss < S; ss += blockDim.x) {
+                const float cs = M.cst[ss] + total;
+                const float w = expf(-cs / temp - mx) / z;
+                M.wts[ss] = w;
+                if (last) {
+                    costs[(size_t)prob * S + ss] = cs;
+                    weights[(size_t)prob * S + ss] = w;
+                }
             }
         }
         __syncthreads();
