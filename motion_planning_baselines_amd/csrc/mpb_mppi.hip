@@ -124,22 +124,26 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
         float coll_wave = 0.f;                                  // this wave's share of the Q6 scalar
         for (int s = wave; s < S; s += nw) {
             // ---- standard normals of sample s: injected (reference draw order (c, S, T)) or Philox
-            for (int i = 0; i < c; ++i) {
-                for (int t = lane; t < T; t += 64) {
-                    float e;
-                    if (eps != nullptr) {
-                        e = eps[((((size_t)it * gridDim.x + prob) * c + i) * S + s) * T + t];
-                    } else {
-                        const uint4 r = philox4x32_10(
-                            make_uint4((uint32_t)prob, (uint32_t)s, (uint32_t)(t >> 2) | ((uint32_t)i << 16), iter0 + (uint32_t)it),
-                            make_uint2(seed_lo, seed_hi));
-                        float n0, n1, n2, n3;
-                        box_muller(r.x, r.y, n0, n1);
-                        box_muller(r.z, r.w, n2, n3);
-                        const int q = t & 3;
-                        e = (q == 0) ? n0 : (q == 1) ? n1 : (q == 2) ? n2 : n3;
-                    }
-                    ew[i * T + t] = e;
+            if (eps != nullptr) {
+                for (int i = 0; i < c; ++i)
+                    for (int t = lane; t < T; t += 64)
+                        ew[i * T + t] = eps[((((size_t)it * gridDim.x + prob) * c + i) * S + s) * T + t];
+            } else {
+                // one Philox call yields the normals of four consecutive time steps of one control dimension: the
+                // c * ceil(T/4) calls of the sample are spread over the lanes (counter = (problem, sample,
+                // step group | dim << 16, iteration), the same stream as one call per lane and step would give)
+                const int G4 = (T + 3) >> 2;
+                for (int l = lane; l < c * G4; l += 64) {
+                    const int i = l / G4, g4 = l - i * G4;
+                    const uint4 r = philox4x32_10(make_uint4((uint32_t)prob, (uint32_t)s, (uint32_t)g4 | ((uint32_t)i << 16),
+                                                             iter0 + (uint32_t)it),
+                                                  make_uint2(seed_lo, seed_hi));
+                    float n[4];
+                    box_muller(r.x, r.y, n[0], n[1]);
+                    box_muller(r.z, r.w, n[2], n[3]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (4 * g4 + q < T) ew[i * T + 4 * g4 + q] = n[q];
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
