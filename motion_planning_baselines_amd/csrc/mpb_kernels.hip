@@ -605,7 +605,7 @@ __global__ __launch_bounds__(1024) void stomp_update_v4_kernel(
 #pragma unroll
     for (int u = 0; u < (64 * 64 / 4 + 1023) / 1024; ++u) {
         const int v4 = tid + 1024 * u;
-        sg4[u] = (v4 < H * H / 4) ? reinterpret_cast<const float4*>(Sigma)[v4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        sg4[u] = (Sigma != nullptr && v4 < H * H / 4) ? reinterpret_cast<const float4*>(Sigma)[v4] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // ---- softmax over S (every wave, redundantly): w for sample `lane`
     const float xs = (lane < S) ? -cst / temperature : -3.0e38f;
@@ -659,7 +659,10 @@ __global__ __launch_bounds__(1024) void stomp_update_v4_kernel(
     __syncthreads();
     // ---- covariance-weighted step: mean += lr * (Sigma @ delta), Sigma row from registers; four independent partial
     //      sums (the kernel is a latency chain: one accumulator would serialise 64 dependent fma)
-    if (tid < n) {
+    if (tid < n && Sigma == nullptr) {
+        // update without the covariance product (StochGPMP, stoch_gpmp.py:272-275)
+        means[(size_t)p * n + tid] += lr * delta[cc * UPD_LD + hh];
+    } else if (tid < n) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         const float4* dcol = reinterpret_cast<const float4*>(delta + cc * UPD_LD);
         const float4* srow = reinterpret_cast<const float4*>(sig_l + hh * UPD_LD);
@@ -758,7 +761,7 @@ static bool update_lds(int S, int H, int d, size_t& bytes, int& sigma_in_lds) {
 static bool launch_update(float* means, const float* samples, const float* costs, float* weights, const float* Sigma,
                           int P, int S, int H, int d, float lr, float temperature, hipStream_t st) {
     const int n = H * d;
-    if (Sigma != nullptr && (n & 3) == 0 && n <= 1024 && H <= 64 && (H & 3) == 0 && S <= 64) {
+    if ((n & 3) == 0 && n <= 1024 && H <= 64 && (H & 3) == 0 && S <= 64) {   // Sigma may be NULL (no covariance product)
         const int n4 = n >> 2;
         const int SG = (1024 / n4) < 4 ? (1024 / n4) : 4;
         const size_t lds = (size_t)d * UPD_LD * 4 + (size_t)SG * n4 * 16 + (size_t)H * UPD_LD * 4;
