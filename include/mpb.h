@@ -278,6 +278,18 @@ int mpb_stoch_gpmp_costs(const float *samples, const float *means, const float *
                          float sigma_start_sample, float sigma_gp_sample, float sigma_goal_sample,
                          float temperature, void *stream);
 
+/* The whole loop, n_iters iterations enqueued by one call (device Philox noise, iteration i draws with seed + i exactly
+ * like n_iters single-iteration rounds of the three calls above): means (P,H,2D) in/out; means64 (P,H,2D) fp64 scratch;
+ * samples (P*S,H,2D), costs (P,S), weights (P,S): outputs of the last iteration; Udiag / Uoff / scale_tril: the sampling
+ * prior as for mpb_gp_prior_sample(_dense) (scale_tril NULL or H > 128: chain form). */
+int mpb_stoch_gpmp_step(float *means, double *means64, float *samples, float *costs, float *weights,
+                        const double *Udiag, const double *Uoff, const double *scale_tril,
+                        const float *start, const float *goal, const float *geom,
+                        int P, int S, int H, int D, float dt,
+                        float sigma_start, float sigma_gp, float sigma_goal, float sigma_coll,
+                        float sigma_start_sample, float sigma_gp_sample, float sigma_goal_sample,
+                        float temperature, float step_size, int n_iters, uint64_t seed, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * GP-prior initial particles -- replaces OptimizationPlanner.get_random_trajs (base.py:155-202) over
  * MultiMPPrior (costs/factors/mp_priors_multi.py:100-110, :213-256): x = mean + scale_tril @ eps with

@@ -105,3 +105,40 @@ extern "C" int mpb_stoch_gpmp_costs(const float* samples, const float* means, co
                        goal, geom, costs, P, S, H, D, K);
     return mpb_check_launch("mpb_stoch_gpmp_costs");
 }
+
+// ------------------------------------------------------------------------------------------------
+// The whole StochGPMP.optimize loop (stoch_gpmp.py:281-313) in one call: per iteration the fp64 copy of the means the
+// sampler starts from, the sampler (dense MFMA form when scale_tril is given and H <= 128, else the chain form), the
+// costs, and the update without covariance product -- the three entry points above, enqueued back to back.
+// ------------------------------------------------------------------------------------------------
+__global__ void sg_widen_kernel(const float* __restrict__ in, double* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (double)in[i];
+}
+
+extern "C" int mpb_stoch_gpmp_step(float* means, double* means64, float* samples, float* costs, float* weights,
+                                   const double* Udiag, const double* Uoff, const double* scale_tril, const float* start,
+                                   const float* goal, const float* geom, int P, int S, int H, int D, float dt,
+                                   float sigma_start, float sigma_gp, float sigma_goal, float sigma_coll,
+                                   float sigma_start_sample, float sigma_gp_sample, float sigma_goal_sample,
+                                   float temperature, float step_size, int n_iters, uint64_t seed, void* stream) {
+    if (!means || !means64 || !samples || !costs || !weights || !Udiag || !Uoff || !start || !goal || !geom)
+        return mpb_fail(MPB_E_INVALID, "mpb_stoch_gpmp_step: null pointer");
+    if (P < 0 || S < 1 || H < 2 || H > MPB_MAX_H || D < 1 || D > MPB_MAX_DOF || n_iters < 0)
+        return mpb_fail(MPB_E_INVALID, "mpb_stoch_gpmp_step: bad shape");
+    if (P == 0) return MPB_OK;
+    const size_t n = (size_t)P * H * 2 * D;
+    for (int it = 0; it < n_iters; ++it) {
+        hipLaunchKernelGGL(sg_widen_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, means, means64, n);
+        int rc = (scale_tril != nullptr && H <= 128)
+                     ? mpb_gp_prior_sample_dense(samples, means64, nullptr, scale_tril, P, S, H, D, seed + (uint64_t)it, stream)
+                     : mpb_gp_prior_sample(samples, means64, nullptr, Udiag, Uoff, P, S, H, D, seed + (uint64_t)it, stream);
+        if (rc) return rc;
+        rc = mpb_stoch_gpmp_costs(samples, means, start, goal, geom, costs, P, S, H, D, dt, sigma_start, sigma_gp, sigma_goal,
+                                  sigma_coll, sigma_start_sample, sigma_gp_sample, sigma_goal_sample, temperature, stream);
+        if (rc) return rc;
+        rc = mpb_stomp_update(means, samples, costs, weights, nullptr, P, S, H, 2 * D, step_size, temperature, stream);
+        if (rc) return rc;
+    }
+    return mpb_check_launch("mpb_stoch_gpmp_step");
+}

@@ -416,6 +416,29 @@ def gp_prior_sample(means, eps, Udiag, Uoff, n, D, seed=0, scale_tril=None, out=
     return out
 
 
+def stoch_gpmp_step(means, means64, samples, costs, weights, Udiag, Uoff, scale_tril, start, goal, geom, S, sig_cost,
+                    sig_sample, dt, temperature, step_size, n_iters=1, seed=0):
+    """n_iters StochGPMP iterations (device noise) enqueued by one C call: sample -> costs -> update."""
+    P, H, dim = means.shape
+    _chk(means, (P, H, dim), 'means')
+    _chk(samples, (P * S, H, dim), 'samples')
+    _chk(costs, (P, S), 'costs')
+    _chk(weights, (P, S), 'weights')
+    _chk(start, (P, dim), 'start')
+    _chk(goal, (P, dim), 'goal')
+    for t, nm, shp in ((means64, 'means64', (P, H, dim)), (Udiag, 'Udiag', (H, 3)), (Uoff, 'Uoff', (H - 1, 4))):
+        if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and tuple(t.shape) == shp):
+            raise ValueError(f'{nm} must be a contiguous CUDA float64 tensor of shape {shp}')
+    if scale_tril is not None and not (scale_tril.is_cuda and scale_tril.dtype == torch.float64 and scale_tril.is_contiguous()
+                                       and tuple(scale_tril.shape) == (2 * H, 2 * H)):
+        raise ValueError('scale_tril must be a contiguous CUDA float64 tensor of shape (2H, 2H)')
+    _lib.check(_lib.lib().mpb_stoch_gpmp_step(
+        _ptr(means), _ptr(means64), _ptr(samples), _ptr(costs), _ptr(weights), _ptr(Udiag), _ptr(Uoff), _ptr(scale_tril),
+        _ptr(start), _ptr(goal), _ptr(geom.buf), P, S, H, dim // 2, float(dt), float(sig_cost[0]), float(sig_cost[1]),
+        float(sig_cost[2]), float(sig_cost[3]), float(sig_sample[0]), float(sig_sample[1]), float(sig_sample[2]),
+        float(temperature), float(step_size), int(n_iters), int(seed) & (2 ** 64 - 1), _stream()), 'mpb_stoch_gpmp_step')
+
+
 def stoch_gpmp_costs(samples, means, start, goal, geom, costs, S, sig_cost, sig_sample, dt, temperature):
     """costs (P,S) of StochGPMP samples (P*S,H,2D): composite cost + importance term.
     sig_cost = (start, gp, goal_prior, coll); sig_sample = (start, gp, goal)."""

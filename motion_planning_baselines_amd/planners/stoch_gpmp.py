@@ -110,6 +110,21 @@ class StochGPMP(OptimizationPlanner):
         """stoch_gpmp.py:281-313."""
         if opt_iters is None:
             opt_iters = self.opt_iters
+        if self.noise == 'philox' and opt_iters > 0:
+            # device noise: the whole loop is one C call (mpb_stoch_gpmp_step) -- no per-iteration host work
+            P, S, H, dim = self.num_particles, self.num_samples, self.n_support_points, self.d_state_opt
+            if getattr(self, '_means64', None) is None or self._means64.shape != self._particle_means.shape:
+                self._means64 = torch.empty_like(self._particle_means, dtype=torch.float64)
+                self._samples_buf = torch.empty(P * S, H, dim, device=self.device, dtype=torch.float32)
+            ops.stoch_gpmp_step(self._particle_means, self._means64, self._samples_buf, self.costs, self._weights_buf,
+                                self._Ud, self._Uo, self._tril, self._start, self._goal, self.geom, S, self.sig_cost,
+                                self.sig_sample, self.dt, self.temperature, self.step_size, n_iters=opt_iters,
+                                seed=self.seed + self._iter)
+            self._iter += opt_iters
+            self.state_samples = self._samples_buf.reshape(P, S, H, dim)
+            self._weights = self._weights_buf.reshape(P, S, 1, 1)
+            self._recent_weights = self._weights
+            return self._get_traj()
         for _ in range(opt_iters):
             costs, samples = self.sample_and_eval(**observation)
             self._update_distribution(costs, samples)

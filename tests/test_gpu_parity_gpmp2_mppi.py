@@ -299,6 +299,26 @@ def test_stoch_gpmp_class(gpu_device):
     assert traj.shape == (P, H, 2 * D) and torch.isfinite(traj).all()
     assert pl._weights.shape == (P, S, 1, 1)
     assert abs(float(pl._weights.sum()) - P) < 1e-4
+    # optimize(opt_iters=5) is ONE C call (mpb_stoch_gpmp_step); the same five iterations driven from Python through the
+    # three entry points (sample -> costs -> update), same seeds, must give the same bits
+    import copy
+    pl2 = StochGPMP(robot=robot, n_dof=D, n_support_points=H, num_particles_per_goal=P, opt_iters=1, dt=float(g['dt']),
+                    start_state=T(g['start']).float().to(dev), step_size=float(g['step_size']),
+                    multi_goal_states=T(g['goal']).float().unsqueeze(0).to(dev),
+                    initial_particle_means=T(g['means0']).float().unsqueeze(0).to(dev),
+                    sigma_start_init=1e-3, sigma_goal_init=1e-3, sigma_gp_init=1.0,
+                    sigma_start_sample=float(g['sigma_start_sample']), sigma_goal_sample=float(g['sigma_goal_sample']),
+                    sigma_gp_sample=float(g['sigma_gp_sample']), num_samples=S, temperature=float(g['temperature']),
+                    collision_fields=[field], sigma_start=float(g['sigma_start']), sigma_gp=float(g['sigma_gp']),
+                    sigma_coll=float(g['sigma_coll']), sigma_goal_prior=float(g['sigma_goal_prior']),
+                    tensor_args=dict(device=dev, dtype=torch.float32), noise='philox', seed=3)
+    for _ in range(5):
+        costs, samples = pl2.sample_and_eval()
+        pl2._update_distribution(costs, samples)
+    torch.cuda.synchronize()
+    assert torch.equal(pl._particle_means, pl2._particle_means)
+    assert torch.equal(pl.state_samples, pl2.state_samples) and torch.equal(pl.costs, pl2.costs)
+    assert torch.equal(pl._weights, pl2._weights)
 
 
 @pytest.mark.parametrize('H,D,G_,n', [(8, 2, 1, 6), (64, 7, 3, 40), (100, 3, 2, 17), (128, 7, 1, 64)])
