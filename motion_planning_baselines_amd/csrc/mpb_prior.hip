@@ -75,6 +75,7 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 template <int KT>   // K tiles of 4: 2H <= 4 KT  (KT = 32: H <= 64, KT = 64: H <= 128)
 __global__ __launch_bounds__(256) void gp_prior_dense_kernel(float* __restrict__ out, const double* __restrict__ means,
+                                                             const float* __restrict__ means32,   // fp32 means instead (means == NULL)
                                                              const double* __restrict__ eps, const double* __restrict__ T,
                                                              int G, int n, int H, int D, int SB, uint32_t seed_lo,
                                                              uint32_t seed_hi) {
@@ -174,16 +175,19 @@ __global__ __launch_bounds__(256) void gp_prior_dense_kernel(float* __restrict__
             for (int j = 0; j < WSLOTS; ++j) {
                 if (w_s2[j] < nsb && w_rem[j] < nt * dim) {
                     const size_t off = (size_t)t0 * dim + w_rem[j];
-                    out[w_out[j] + off] = (float)(means[w_mu[j] + off] + (double)Yt[w_s2[j] * 8 * dim + w_rem[j]]);
+                    const double mu = means32 ? (double)means32[w_mu[j] + off] : means[w_mu[j] + off];
+                    out[w_out[j] + off] = (float)(mu + (double)Yt[w_s2[j] * 8 * dim + w_rem[j]]);
                 }
             }
         }
     }
 }
 
-extern "C" int mpb_gp_prior_sample_dense(float* out, const double* means, const double* eps, const double* scale_tril,
-                                         int G, int n, int H, int D, uint64_t seed, void* stream) {
-    if (!out || !means || !scale_tril) return mpb_fail(MPB_E_INVALID, "mpb_gp_prior_sample_dense: null pointer");
+// dense sampler, means in fp64 (C-ABI) or fp32 (means32; mpb_stoch_gpmp_step starts from the fp32 particle means and
+// needs no widened copy)
+int mpb_gp_prior_dense_launch(float* out, const double* means, const float* means32, const double* eps,
+                              const double* scale_tril, int G, int n, int H, int D, uint64_t seed, void* stream) {
+    if (!out || (!means && !means32) || !scale_tril) return mpb_fail(MPB_E_INVALID, "mpb_gp_prior_sample_dense: null pointer");
     if (G < 1 || n < 0 || H < 2 || D < 1 || D > 64) return mpb_fail(MPB_E_INVALID, "mpb_gp_prior_sample_dense: bad shape");
     if (H > 128) return mpb_fail(MPB_E_UNSUPPORTED, "mpb_gp_prior_sample_dense: H > 128 (use mpb_gp_prior_sample)");
     if (n == 0) return MPB_OK;
@@ -191,12 +195,18 @@ extern "C" int mpb_gp_prior_sample_dense(float* out, const double* means, const 
     const dim3 grid((G * n + SB - 1) / SB), block(256);
     const size_t lds = (size_t)SB * 8 * 2 * D * sizeof(float);
     if (H <= 64)
-        hipLaunchKernelGGL(gp_prior_dense_kernel<32>, grid, block, lds, (hipStream_t)stream, out, means, eps, scale_tril, G,
-                           n, H, D, SB, (uint32_t)seed, (uint32_t)(seed >> 32));
+        hipLaunchKernelGGL(gp_prior_dense_kernel<32>, grid, block, lds, (hipStream_t)stream, out, means, means32, eps,
+                           scale_tril, G, n, H, D, SB, (uint32_t)seed, (uint32_t)(seed >> 32));
     else
-        hipLaunchKernelGGL(gp_prior_dense_kernel<64>, grid, block, lds, (hipStream_t)stream, out, means, eps, scale_tril, G,
-                           n, H, D, SB, (uint32_t)seed, (uint32_t)(seed >> 32));
+        hipLaunchKernelGGL(gp_prior_dense_kernel<64>, grid, block, lds, (hipStream_t)stream, out, means, means32, eps,
+                           scale_tril, G, n, H, D, SB, (uint32_t)seed, (uint32_t)(seed >> 32));
     return mpb_check_launch("mpb_gp_prior_sample_dense");
+}
+
+extern "C" int mpb_gp_prior_sample_dense(float* out, const double* means, const double* eps, const double* scale_tril,
+                                         int G, int n, int H, int D, uint64_t seed, void* stream) {
+    if (!means) return mpb_fail(MPB_E_INVALID, "mpb_gp_prior_sample_dense: null pointer");
+    return mpb_gp_prior_dense_launch(out, means, nullptr, eps, scale_tril, G, n, H, D, seed, stream);
 }
 
 extern "C" int mpb_gp_prior_sample(float* out, const double* means, const double* eps, const double* Udiag,

@@ -111,6 +111,9 @@ extern "C" int mpb_stoch_gpmp_costs(const float* samples, const float* means, co
 // sampler starts from, the sampler (dense MFMA form when scale_tril is given and H <= 128, else the chain form), the
 // costs, and the update without covariance product -- the three entry points above, enqueued back to back.
 // ------------------------------------------------------------------------------------------------
+int mpb_gp_prior_dense_launch(float* out, const double* means, const float* means32, const double* eps,
+                              const double* scale_tril, int G, int n, int H, int D, uint64_t seed, void* stream);   // mpb_prior.hip
+
 __global__ void sg_widen_kernel(const float* __restrict__ in, double* __restrict__ out, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (double)in[i];
@@ -129,10 +132,14 @@ extern "C" int mpb_stoch_gpmp_step(float* means, double* means64, float* samples
     if (P == 0) return MPB_OK;
     const size_t n = (size_t)P * H * 2 * D;
     for (int it = 0; it < n_iters; ++it) {
-        hipLaunchKernelGGL(sg_widen_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, means, means64, n);
-        int rc = (scale_tril != nullptr && H <= 128)
-                     ? mpb_gp_prior_sample_dense(samples, means64, nullptr, scale_tril, P, S, H, D, seed + (uint64_t)it, stream)
-                     : mpb_gp_prior_sample(samples, means64, nullptr, Udiag, Uoff, P, S, H, D, seed + (uint64_t)it, stream);
+        int rc;
+        if (scale_tril != nullptr && H <= 128) {      // dense MFMA sampler: reads the fp32 means directly
+            rc = mpb_gp_prior_dense_launch(samples, nullptr, means, nullptr, scale_tril, P, S, H, D, seed + (uint64_t)it, stream);
+        } else {
+            hipLaunchKernelGGL(sg_widen_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, means,
+                               means64, n);
+            rc = mpb_gp_prior_sample(samples, means64, nullptr, Udiag, Uoff, P, S, H, D, seed + (uint64_t)it, stream);
+        }
         if (rc) return rc;
         rc = mpb_stoch_gpmp_costs(samples, means, start, goal, geom, costs, P, S, H, D, dt, sigma_start, sigma_gp, sigma_goal,
                                   sigma_coll, sigma_start_sample, sigma_gp_sample, sigma_goal_sample, temperature, stream);
