@@ -136,7 +136,7 @@ int mpb_field_cost_points_vjp(const float *pts, const float *geom, const float *
  *   collision cost above, _calc_sample_weights (stomp.py:219-220), _update_distribution (:199-211).
  *
  * means (P,H,d) in/out, updated in place n_iters times.
- * eps: NULL -> standard normals are generated on the device (Philox4x32-10 keyed by `seed`,
+ * eps: NULL -> standard normals are generated on the device (Philox4x32, 7 rounds, keyed by `seed`,
  *      counter = (particle_offset + p, s, waypoint, iter0 + i); result independent of sharding);
  *      else (n_iters, S, d, P, H): pre-drawn standard normals in the reference's draw order
  *      (one MultivariateNormal.sample((S,d)) of batch shape (P,) and event shape (H,) per iteration).
