@@ -252,11 +252,16 @@ int mpb_gpmp2_step(float *x, const float *start, const float *goal, const float 
  * geom optional (NULL = no collision term).  With geom, the reference's quirk Q6 is reproduced:
  * the per-sample collision costs are summed into ONE scalar that is added to every sample's cost.
  * Outputs of the last iteration: controls (NP,S,T,c), states (NP,S,T,c), costs (NP,S), weights (NP,S).
+ * best_cost (NP) in/out + best_states (NP,T,c) out, both or neither (NULL): MPPI._save_best
+ * (mppi.py:164-168, called every iteration, mppi.py:148): whenever an iteration's cheapest sample (first
+ * index on ties) beats best_cost[problem], its cost and state trajectory are stored.  Initialise
+ * best_cost to +inf; it carries over between calls like the reference's attribute.
  * ------------------------------------------------------------------------------------------- */
 int mpb_mppi_step(float *mean, const float *eps, const float *scale_tril, const float *cov_inv,
                   const float *state0, const float *goal, const float *ctrl_min, const float *ctrl_max,
                   const float *discount, const float *c_weights, const float *geom,
                   float *controls, float *states, float *costs, float *weights,
+                  float *best_cost, float *best_states,
                   int NP, int S, int T, int c, int control_type, float dt,
                   float k_sigma, float weight, float temp, float step_size,
                   int n_iters, uint64_t seed, uint32_t iter0, void *stream);

@@ -150,8 +150,8 @@ extern "C" int mpb_debug_read_stamps(unsigned long long* dst, int n) {
 #endif
 
 // Standard normals of the H = 64 fast path: one Philox4x32-7 call per (particle, sample, channel j,
-// k-group g, quarter q4) yields eps[j][k] for k = 16*q4 + 4*r + g, r = 0..3.  Shared by the sampling
-// kernel and the eps-space update kernel so both see the same noise without it ever touching memory.
+// k-group g, quarter q4) yields eps[j][k] for k = 16*q4 + 4*r + g, r = 0..3.  The counter holds the GLOBAL particle
+// id, so the noise does not depend on how the particles are sharded over GPUs.
 __device__ __forceinline__ void stomp_eps4(uint32_t p_global, uint32_t s, uint32_t j, uint32_t g, uint32_t q4,
                                            uint32_t iter, uint32_t seed_lo, uint32_t seed_hi, float (&n)[4]) {
     const uint4 rr = philox4x32<7>(make_uint4(p_global, s, (j << 16) | (g << 8) | q4, iter), make_uint2(seed_lo, seed_hi));
@@ -587,14 +587,15 @@ __global__ __launch_bounds__(1024) void stomp_update_v4_kernel(
     const bool worker = sg < SG;
     const int s0 = sg * spg, s1 = min(S, s0 + spg);
     const float4* smp4 = reinterpret_cast<const float4*>(samples) + (size_t)p * S * n4 + i4;
-    // ---- issue every load up front
+    // ---- issue every load up front.  Rows past the group's last sample are loaded from a clamped (valid) index and
+    //      never used: selecting between the load and a register copy of `mu` made hipcc spill `mu` to scratch and
+    //      load through a flat pointer (32 B / lane of scratch in a 6 us latency kernel)
     float4 v[8];
     float4 mu = make_float4(0.f, 0.f, 0.f, 0.f);
     if (worker) {
         mu = reinterpret_cast<const float4*>(means)[(size_t)p * n4 + i4];
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            v[k] = (s0 + k < s1) ? smp4[(size_t)(s0 + k) * n4] : mu;
+        for (int k = 0; k < 8; ++k) v[k] = smp4[(size_t)min(s0 + k, S - 1) * n4];
     }
     const float cst = (lane < S) ? costs[(size_t)p * S + lane] : 0.f;
     // the matvec output this thread owns (thread tid < n <-> element (h, c)); Sigma (H x H, the same for every block)
@@ -621,25 +622,32 @@ __global__ __launch_bounds__(1024) void stomp_update_v4_kernel(
             *reinterpret_cast<float4*>(sig_l + row * UPD_LD + col) = sg4[u];
         }
     }
-    // ---- weighted noise reduce; the weight of sample s is broadcast from lane s
+    // ---- weighted noise reduce; the weight of sample s is broadcast from lane s.  The broadcasts run with ALL 64 lanes
+    //      active (outside the `worker` branch, uniform trip counts): a wave straddling the worker boundary (H*d not a
+    //      multiple of 64) would otherwise shuffle from EXEC-disabled lanes, which return 0 on gfx950
+    float wk[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wk[k] = __shfl(wl, min(s0 + k, 63), 64);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (worker) {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float w = __shfl(wl, min(s0 + k, 63), 64);
             if (s0 + k < s1) {
-                acc.x += w * (v[k].x - mu.x); acc.y += w * (v[k].y - mu.y);
-                acc.z += w * (v[k].z - mu.z); acc.w += w * (v[k].w - mu.w);
+                acc.x += wk[k] * (v[k].x - mu.x); acc.y += wk[k] * (v[k].y - mu.y);
+                acc.z += wk[k] * (v[k].z - mu.z); acc.w += wk[k] * (v[k].w - mu.w);
             }
         }
-        for (int s = s0 + 8; s < s1; ++s) {
+    }
+    for (int k = 8; k < spg; ++k) {                      // S > 32: the rest of the group (block-uniform trip count)
+        const int s = s0 + k;
+        const float w = __shfl(wl, min(s, 63), 64);
+        if (worker && s < s1) {
             const float4 t = smp4[(size_t)s * n4];
-            const float w = __shfl(wl, s, 64);
             acc.x += w * (t.x - mu.x); acc.y += w * (t.y - mu.y);
             acc.z += w * (t.z - mu.z); acc.w += w * (t.w - mu.w);
         }
-        part[sg * n4 + i4] = acc;
     }
+    if (worker) part[sg * n4 + i4] = acc;
     __syncthreads();
     if (tid < n4) {
         float4 a = part[tid];

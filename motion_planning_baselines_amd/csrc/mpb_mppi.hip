@@ -68,7 +68,8 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
     const float* __restrict__ cov_inv, const float* __restrict__ state0, const float* __restrict__ goal,
     const float* __restrict__ ctrl_min, const float* __restrict__ ctrl_max, const float* __restrict__ discount,
     const float* __restrict__ cw, const float* __restrict__ geom, float* __restrict__ controls,
-    float* __restrict__ states, float* __restrict__ costs, float* __restrict__ weights, int S, int T, int c,
+    float* __restrict__ states, float* __restrict__ costs, float* __restrict__ weights,
+    float* __restrict__ best_cost, float* __restrict__ best_states, int S, int T, int c,
     float dt, float k_sigma, float weight, float temp, float step_size, int n_iters, uint32_t seed_lo,
     uint32_t seed_hi, uint32_t iter0, int tril_in_lds) {
     extern __shared__ float lds[];
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
         umax[i] = on ? ctrl_max[i] : 0.f;
     }
     float* ew = M.epsw + (size_t)wave * c * T;
+    float best_c = (best_cost != nullptr) ? best_cost[prob] : 0.f;   // running best over all iterations (and calls)
 
     for (int it = 0; it < n_iters; ++it) {
         const bool last = it == n_iters - 1;
@@ -247,6 +249,44 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
             for (int i = 0; i < nw; ++i) total += M.red[i];
         }
         __syncthreads();
+        // ---- MPPI._save_best (mppi.py:164-168), called every iteration before update_controller (mppi.py:148): the
+        //      cheapest sample so far (first index on ties, like torch.argmin) and its state trajectory.  The states of
+        //      every sample are not kept, so the winner's rollout is redone from its controls in LDS (same arithmetic
+        //      as above, bit-identical); only wave 0 works, the others go on to the softmax
+        if (best_cost != nullptr && wave == 0) {
+            float bv = 3.0e38f;
+            int bi = 0;
+            for (int ss = lane; ss < S; ss += 64) {
+                const float v = M.cst[ss] + total;
+                if (v < bv) { bv = v; bi = ss; }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float ov = __shfl_xor(bv, off, 64);
+                const int oi = __shfl_xor(bi, off, 64);
+                if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            if (bv < best_c) {                                   // wave-uniform
+                best_c = bv;
+                if (lane == 0) best_cost[prob] = bv;
+                float carry[MPPI_MAX_C];
+#pragma unroll
+                for (int i = 0; i < MPPI_MAX_C; ++i) carry[i] = 0.f;
+                for (int base = 0; base < T; base += 64) {
+                    const int t = base + lane;
+                    const bool on = t < T;
+#pragma unroll
+                    for (int i = 0; i < MPPI_MAX_C; ++i) {
+                        const float u = (i < c && on) ? M.Us[((size_t)bi * c + i) * T + t] : 0.f;
+                        const float v = (i < c && on) ? fminf(fmaxf(u, umin[i]), umax[i]) * dt : 0.f;
+                        const float inc = wave_scan_incl(v, lane);
+                        const float x = x0[i] + (carry[i] + (inc - v));
+                        carry[i] += readlane_f32(inc, 63);
+                        if (i < c && on) best_states[((size_t)prob * T + t) * c + i] = x;
+                    }
+                }
+            }
+        }
         // ---- softmax over samples (mppi.py:73-76)
         if (S <= 64) {
             // every wave repeats it on its own (lane = sample, wave reductions): no block-wide reduction, one barrier
@@ -306,7 +346,8 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
 extern "C" int mpb_mppi_step(float* mean, const float* eps, const float* scale_tril, const float* cov_inv,
                              const float* state0, const float* goal, const float* ctrl_min, const float* ctrl_max,
                              const float* discount, const float* c_weights, const float* geom, float* controls,
-                             float* states, float* costs, float* weights, int NP, int S, int T, int c, int control_type,
+                             float* states, float* costs, float* weights, float* best_cost, float* best_states,
+                             int NP, int S, int T, int c, int control_type,
                              float dt, float k_sigma, float weight, float temp, float step_size, int n_iters,
                              uint64_t seed, uint32_t iter0, void* stream) {
     if (!mean || !scale_tril || !cov_inv || !state0 || !goal || !ctrl_min || !ctrl_max || !discount || !c_weights ||
@@ -315,6 +356,8 @@ extern "C" int mpb_mppi_step(float* mean, const float* eps, const float* scale_t
     if (NP < 0 || S < 1 || S > 1024 || T < 2 || T > MPB_MAX_H || c < 1 || c > MPPI_MAX_C || n_iters < 0)
         return mpb_fail(MPB_E_INVALID, "mpb_mppi_step: bad shape");
     if (!(temp > 0.f)) return mpb_fail(MPB_E_INVALID, "mpb_mppi_step: temp must be > 0");
+    if ((best_cost == nullptr) != (best_states == nullptr))
+        return mpb_fail(MPB_E_INVALID, "mpb_mppi_step: best_cost and best_states must be given together");
     if (control_type != 0)
         return mpb_fail(MPB_E_UNSUPPORTED, "mpb_mppi_step: only velocity control (the reference's acceleration mode cannot run)");
     if (NP == 0 || n_iters == 0) return MPB_OK;
@@ -326,8 +369,8 @@ extern "C" int mpb_mppi_step(float* mean, const float* eps, const float* scale_t
     const int tril_in_lds = with_tril <= budget;
     const size_t lds = (tril_in_lds ? with_tril : base) * sizeof(float);
     hipLaunchKernelGGL(mppi_kernel, dim3(NP), dim3(64 * nw), lds, (hipStream_t)stream, mean, eps, scale_tril, cov_inv,
-                       state0, goal, ctrl_min, ctrl_max, discount, c_weights, geom, controls, states, costs, weights, S, T,
-                       c, dt, k_sigma, weight, temp, step_size, n_iters, (uint32_t)seed, (uint32_t)(seed >> 32), iter0,
+                       state0, goal, ctrl_min, ctrl_max, discount, c_weights, geom, controls, states, costs, weights,
+                       best_cost, best_states, S, T, c, dt, k_sigma, weight, temp, step_size, n_iters, (uint32_t)seed, (uint32_t)(seed >> 32), iter0,
                        tril_in_lds);
     return mpb_check_launch("mpb_mppi_step");
 }

@@ -4,6 +4,7 @@ csrc/*.hip.  Every wrapper validates device / dtype / contiguity / shape on the 
 launching (a kernel that faults can reset the whole GPU host).
 """
 import ctypes
+import functools
 
 import numpy as np
 import torch
@@ -13,7 +14,30 @@ from .geometry import count_fields, pack_geometry
 
 
 def _stream():
+    # called inside _on_tensor_device: the current device is the tensors' device
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _on_tensor_device(fn):
+    """Every wrapper launches on the device its tensors live on, on THAT device's current stream: all GPU tensor
+    arguments (a DeviceGeometry counts through its buffer) must share one device, which becomes the current device for
+    the duration of the call.  Without this a planner built for cuda:1 while cuda:0 is current would launch on GPU 0
+    with GPU-1 pointers."""
+    @functools.wraps(fn)
+    def run(*args, **kw):
+        dev = None
+        for a in list(args) + list(kw.values()):
+            t = a.buf if isinstance(a, DeviceGeometry) else a
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                if dev is None:
+                    dev = t.device
+                elif t.device != dev:
+                    raise ValueError(f'{fn.__name__}: tensor arguments live on different devices ({dev} and {t.device})')
+        if dev is None:
+            return fn(*args, **kw)       # no GPU tensor: the shape / device checks of the wrapper raise
+        with torch.cuda.device(dev):
+            return fn(*args, **kw)
+    return run
 
 
 def _ptr(t):
@@ -67,6 +91,7 @@ class DeviceGeometry:
         return self
 
 
+@_on_tensor_device
 def cost_collision_eval(trajs, geom, k_sigma, weight=1.0, h_begin=1, per_waypoint=False):
     B, H, d = trajs.shape
     _chk(trajs, (B, H, d), 'trajs')
@@ -77,6 +102,7 @@ def cost_collision_eval(trajs, geom, k_sigma, weight=1.0, h_begin=1, per_waypoin
     return (out, pw) if per_waypoint else out
 
 
+@_on_tensor_device
 def cost_collision_grad(trajs, geom, k_sigma, weight=1.0, h_begin=1):
     B, H, d = trajs.shape
     _chk(trajs, (B, H, d), 'trajs')
@@ -90,6 +116,7 @@ def cost_collision_grad(trajs, geom, k_sigma, weight=1.0, h_begin=1):
 TERM_GP, TERM_START, TERM_GOAL, TERM_SMOOTH, TERM_JLIM, TERM_VEL_FD = 1, 2, 4, 8, 16, 32   # include/mpb.h MPB_TERM_*
 
 
+@_on_tensor_device
 def cost_terms_eval(trajs, n_dof, dt=0.0, k_gp=0.0, vel_fd=False, k_start=0.0, start_state=None, k_goal=0.0,
                     goal_states=None, trajs_per_goal=1, k_smooth=0.0, k_jlim=0.0, q_min=None, q_max=None, jl_eps=0.0,
                     out=None, accumulate=False, broadcast_jlim=True, terms=None):
@@ -145,6 +172,7 @@ def _need_all_links(geom):
                          'points need DeviceGeometry(..., keep_all_links=True)')
 
 
+@_on_tensor_device
 def fk_collision_points(q, geom):
     """q (B,H,d) -> positions of the robot's collision spheres (B,H,L,3) (mpb_fk_collision_points)."""
     B, H, d = q.shape
@@ -156,6 +184,7 @@ def fk_collision_points(q, geom):
     return pts
 
 
+@_on_tensor_device
 def fk_collision_points_vjp(q, geom, grad_pts):
     B, H, d = q.shape
     _need_all_links(geom)
@@ -168,6 +197,7 @@ def fk_collision_points_vjp(q, geom, grad_pts):
     return gq
 
 
+@_on_tensor_device
 def field_cost_points(pts, geom):
     """Collision-sphere positions (B,H,L,3) -> hinge cost per waypoint (B,H) (mpb_field_cost_points)."""
     B, H, L, _ = pts.shape
@@ -178,6 +208,7 @@ def field_cost_points(pts, geom):
     return cost
 
 
+@_on_tensor_device
 def field_cost_points_vjp(pts, geom, grad_cost):
     B, H, L, _ = pts.shape
     _need_all_links(geom)
@@ -189,6 +220,7 @@ def field_cost_points_vjp(pts, geom, grad_cost):
     return gp
 
 
+@_on_tensor_device
 def gp_factor_error(x, D, dt):
     """(B,H,2D) -> (B,H-1,2D): x_{t+1} - Phi x_t (mpb_gp_factor_error)."""
     B, H, dim = x.shape
@@ -198,6 +230,7 @@ def gp_factor_error(x, D, dt):
     return out
 
 
+@_on_tensor_device
 def traj_interpolate(trajs, n_interp):
     """(B,H,d) -> (B,(H-1)(n+1)+1,d): n evenly spaced joint-space points per segment (mpb_traj_interpolate)."""
     B, H, d = trajs.shape
@@ -208,6 +241,7 @@ def traj_interpolate(trajs, n_interp):
     return out
 
 
+@_on_tensor_device
 def traj_resample(paths, lengths, H, dt):
     """N padded polylines (N,Lmax,D) with `lengths` (N,) int32 valid rows -> (N,H,2D) support points uniform in
     arc length + average-velocity channel (mpb_traj_resample)."""
@@ -221,6 +255,7 @@ def traj_resample(paths, lengths, H, dt):
     return out
 
 
+@_on_tensor_device
 def traj_finite_difference(pos, dt):
     """(B,H,D) positions -> (B,H,2D) [pos, central-difference velocities] (mpb_traj_finite_difference)."""
     B, H, D = pos.shape
@@ -231,6 +266,7 @@ def traj_finite_difference(pos, dt):
     return out
 
 
+@_on_tensor_device
 def stomp_step(means, eps, samples, costs, weights, L, Sigma, geom, S, D, k_sigma, weight, lr, temperature,
                n_iters=1, seed=0, iter0=0, particle_offset=0):
     P, H, d = means.shape
@@ -248,6 +284,7 @@ def stomp_step(means, eps, samples, costs, weights, L, Sigma, geom, S, D, k_sigm
         int(seed) & (2 ** 64 - 1), int(iter0), int(particle_offset), _stream()), 'mpb_stomp_step')
 
 
+@_on_tensor_device
 def stomp_step_profile(means, samples, costs, weights, L, Sigma, geom, S, D, k_sigma, weight, lr, temperature,
                        n_iters=50, seed=0, iter0=0, particle_offset=0):
     """Measurement aid: n_iters iterations of stomp_step (device noise) with per-dispatch HIP events; returns the average
@@ -269,6 +306,7 @@ def stomp_step_profile(means, samples, costs, weights, L, Sigma, geom, S, D, k_s
     return float(ka.value), float(kb.value)
 
 
+@_on_tensor_device
 def stomp_sample(means, eps, samples, L, S, seed=0, it=0, particle_offset=0, geom=None, costs=None, k_sigma=0.0,
                  weight=1.0):
     """First kernel of an iteration: draw + write samples; with geom/costs also the fused collision cost."""
@@ -288,6 +326,7 @@ def stomp_sample(means, eps, samples, L, S, seed=0, it=0, particle_offset=0, geo
                                           int(particle_offset), _stream()), 'mpb_stomp_sample')
 
 
+@_on_tensor_device
 def stomp_update(means, samples, costs, weights, Sigma, lr, temperature):
     P, S, H, d = samples.shape
     _chk(means, (P, H, d), 'means')
@@ -299,6 +338,7 @@ def stomp_update(means, samples, costs, weights, Sigma, lr, temperature):
                                           P, S, H, d, float(lr), float(temperature), _stream()), 'mpb_stomp_update')
 
 
+@_on_tensor_device
 def chomp_step(means, R, geom, D, k_sigma, weight, w_prior, lr, grad_clip, n_iters=1, B_global=None, costs_out=None):
     B, H, d = means.shape
     _chk(means, (B, H, d), 'means')
@@ -310,6 +350,7 @@ def chomp_step(means, R, geom, D, k_sigma, weight, w_prior, lr, grad_clip, n_ite
                'mpb_chomp_step')
 
 
+@_on_tensor_device
 def gpmp2_workspace(B, H, D, device):
     n = int(_lib.lib().mpb_gpmp2_workspace_bytes(B, H, D))
     if n == 0:
@@ -317,6 +358,7 @@ def gpmp2_workspace(B, H, D, device):
     return torch.empty(n, dtype=torch.uint8, device=device)
 
 
+@_on_tensor_device
 def gpmp2_step(x, start, goal, geom, workspace, sigmas, dt, delta, trust_region, step_size, n_iters=1, costs_out=None,
                n_interp=0):
     """n_iters Gauss-Newton iterations on one GPU.  sigmas = (start, gp, goal, coll)."""
@@ -333,6 +375,7 @@ def gpmp2_step(x, start, goal, geom, workspace, sigmas, dt, delta, trust_region,
         float(step_size), int(n_iters), int(n_interp or 0), int(geom.n_fields), _stream()), 'mpb_gpmp2_step')
 
 
+@_on_tensor_device
 def gpmp2_linearize(x, geom, workspace, n_interp=0):
     B, H, dim = x.shape
     _chk(x, (B, H, dim), 'x')
@@ -340,6 +383,26 @@ def gpmp2_linearize(x, geom, workspace, n_interp=0):
                                               int(n_interp or 0), _stream()), 'mpb_gpmp2_linearize')
 
 
+@_on_tensor_device
+def gpmp2_collision_rows(x, geom, n_interp=0):
+    """The collision factor's rows as the GPMP2 solve consumes them: (F, B, H, D+1) fp32 with [..., :D] = h_t =
+    -d c_t / d q_t (with n_interp > 0: of the INTERPOLATED trajectory's summed cost, cost_functions.py:115-119,
+    field_factor.py:42-54) and [..., D] = c_t, one set per chained field, each scaled by sqrt(s_f); row 0 is zero
+    (traj_range [1, None]).  Runs mpb_gpmp2_linearize into a scratch buffer that holds only the Jacobian section of
+    the GPMP2 workspace (the kernel writes nothing else)."""
+    B, H, dim = x.shape
+    D = dim // 2
+    _chk(x, (B, H, dim), 'x')
+    if _lib.lib().mpb_gpmp2_workspace_bytes(B, H, D) == 0:
+        raise ValueError(f'unsupported GPMP2 shape B={B} H={H} D={D}')
+    MAX_FIELDS = 4                                   # MPB_MAX_FIELDS: the section is laid out for four fields
+    jac = torch.zeros(MAX_FIELDS, B, H, D + 1, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().mpb_gpmp2_linearize(_ptr(x), _ptr(geom.buf), _ptr(jac), B, H, D, int(n_interp or 0), _stream()),
+               'mpb_gpmp2_linearize')
+    return jac[:geom.n_fields]
+
+
+@_on_tensor_device
 def gpmp2_diag(workspace, B, H, D, sigmas, dt, n_fields=1):
     """Local SUM over particles of diag(A^T K A) as an (H*2D,) fp64 tensor."""
     out = torch.empty(H * 2 * D, dtype=torch.float64, device=workspace.device)
@@ -348,6 +411,7 @@ def gpmp2_diag(workspace, B, H, D, sigmas, dt, n_fields=1):
     return out
 
 
+@_on_tensor_device
 def gpmp2_solve(x, start, goal, diag_mean, workspace, sigmas, dt, delta, trust_region, step_size, costs_out=None,
                 n_fields=1):
     B, H, dim = x.shape
@@ -362,8 +426,10 @@ def gpmp2_solve(x, start, goal, diag_mean, workspace, sigmas, dt, delta, trust_r
         float(step_size), _stream()), 'mpb_gpmp2_solve')
 
 
+@_on_tensor_device
 def mppi_step(mean, eps, scale_tril, cov_inv, state0, goal, ctrl_min, ctrl_max, discount, c_weights, geom, controls,
-              states, costs, weights, dt, k_sigma=0.0, weight=1.0, temp=1.0, step_size=1.0, n_iters=1, seed=0, iter0=0):
+              states, costs, weights, dt, k_sigma=0.0, weight=1.0, temp=1.0, step_size=1.0, n_iters=1, seed=0, iter0=0,
+              best_cost=None, best_states=None):
     NP, T, c = mean.shape
     S = controls.shape[1]
     _chk(mean, (NP, T, c), 'mean')
@@ -381,13 +447,19 @@ def mppi_step(mean, eps, scale_tril, cov_inv, state0, goal, ctrl_min, ctrl_max, 
     _chk(states, (NP, S, T, c), 'states')
     _chk(costs, (NP, S), 'costs')
     _chk(weights, (NP, S), 'weights')
+    if (best_cost is None) != (best_states is None):
+        raise ValueError('best_cost and best_states must be given together')
+    _chk(best_cost, (NP,), 'best_cost', allow_none=True)
+    _chk(best_states, (NP, T, c), 'best_states', allow_none=True)
     _lib.check(_lib.lib().mpb_mppi_step(
         _ptr(mean), _ptr(eps), _ptr(scale_tril), _ptr(cov_inv), _ptr(state0), _ptr(goal), _ptr(ctrl_min), _ptr(ctrl_max),
         _ptr(discount), _ptr(c_weights), _ptr(None if geom is None else geom.buf), _ptr(controls), _ptr(states),
-        _ptr(costs), _ptr(weights), NP, S, T, c, 0, float(dt), float(k_sigma), float(weight), float(temp),
+        _ptr(costs), _ptr(weights), _ptr(best_cost), _ptr(best_states), NP, S, T, c, 0, float(dt), float(k_sigma),
+        float(weight), float(temp),
         float(step_size), int(n_iters), int(seed) & (2 ** 64 - 1), int(iter0), _stream()), 'mpb_mppi_step')
 
 
+@_on_tensor_device
 def gp_prior_sample(means, eps, Udiag, Uoff, n, D, seed=0, scale_tril=None, out=None):
     """Initial particles from the GP prior: means (G,H,2D) fp64, eps None or (n,G,H*2D) fp64 -> (G*n,H,2D) fp32.
     With `scale_tril` (2H,2H fp64, planners.base.gp_prior_scale_tril) and H <= 128 the product runs as a GEMM on
@@ -416,6 +488,7 @@ def gp_prior_sample(means, eps, Udiag, Uoff, n, D, seed=0, scale_tril=None, out=
     return out
 
 
+@_on_tensor_device
 def stoch_gpmp_step(means, means64, samples, costs, weights, Udiag, Uoff, scale_tril, start, goal, geom, S, sig_cost,
                     sig_sample, dt, temperature, step_size, n_iters=1, seed=0):
     """n_iters StochGPMP iterations (device noise) enqueued by one C call: sample -> costs -> update."""
@@ -439,6 +512,7 @@ def stoch_gpmp_step(means, means64, samples, costs, weights, Udiag, Uoff, scale_
         float(temperature), float(step_size), int(n_iters), int(seed) & (2 ** 64 - 1), _stream()), 'mpb_stoch_gpmp_step')
 
 
+@_on_tensor_device
 def stoch_gpmp_costs(samples, means, start, goal, geom, costs, S, sig_cost, sig_sample, dt, temperature):
     """costs (P,S) of StochGPMP samples (P*S,H,2D): composite cost + importance term.
     sig_cost = (start, gp, goal_prior, coll); sig_sample = (start, gp, goal)."""

@@ -158,6 +158,15 @@ class OptimizationPlanner(MPPlanner):
         self.sigma_goal_init = sigma_goal_init
         self.sigma_gp_init = sigma_gp_init
 
+    def _full_state(self, state):
+        """A start / goal state for reset(): the reference stores what it is given (gpmp2.py:178-182,
+        stoch_gpmp.py:99-103), i.e. it expects the 2*n_dof-wide state the constructor built; a position-only
+        state (n_dof wide, what the constructor itself takes) gets its zero velocities appended here."""
+        if state.shape[-1] == self.n_dof:
+            return torch.cat([state, torch.zeros_like(state)], -1)
+        assert state.shape[-1] == 2 * self.n_dof, 'state must be n_dof or 2*n_dof wide'
+        return state.detach().clone()
+
     def get_random_trajs(self, noise='torch_cpu', seed=0):
         """Initial particles from the constant-velocity GP prior (base.py:155-202): num_particles_per_goal
         samples per goal around the straight line, returned as (num_goals * ppg, H, 2D) fp32 -- 2D wide
@@ -200,7 +209,8 @@ class OptimizationPlanner(MPPlanner):
     def _get_traj(self):
         trajs = self._particle_means.clone()
         if self.pos_only:
-            vels = finite_difference_vector(trajs, dt=self.dt)
+            # central-difference velocities by mpb_traj_finite_difference ([pos, vel] channels; the vel half is taken)
+            vels = ops.traj_finite_difference(trajs.contiguous(), self.dt)[..., self.n_dof:]
             trajs = torch.cat((trajs, vels), dim=1)   # quirk Q12: concatenated along the horizon axis
         return trajs
 
@@ -209,7 +219,7 @@ class OptimizationPlanner(MPPlanner):
 
     def _get_costs(self, state_trajectories, **observation):
         if self.cost is None:
-            return torch.zeros(state_trajectories.shape[0], device=state_trajectories.device)
+            return torch.zeros(self.num_particles, )     # quirk Q11 (base.py:219-220): CPU, default dtype
         return self.cost(state_trajectories, **observation)
 
     def render(self, ax, **kwargs):

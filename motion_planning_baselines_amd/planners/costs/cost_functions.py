@@ -95,19 +95,22 @@ class CostCollision(Cost):
         trajs = self._as_3d(trajs)
         return ops.cost_collision_grad(trajs, self.device_geometry(trajs.device), self.k_sigma, weight=weight)
 
-    def get_linear_system(self, trajs, **observation):
-        """Dense (A, b, K) rows of the collision factor (cost_functions.py:191-231), assembled from the
-        HIP per-waypoint cost and Jacobian.  Debug / inspection aid: GPMP2 itself never materialises it."""
+    def get_linear_system(self, trajs, n_interpolated_points=None, **observation):
+        """Dense (A, b, K) rows of the collision factor (cost_functions.py:191-231): row i has H_obst = -d err / d q at
+        columns (i+1)*dim .. +n_dof, b = the support points' errors, K = I / sigma^2.  With `n_interpolated_points`
+        (forwarded by CostComposite.get_linear_system, cost_functions.py:112-119) the Jacobian is that of the
+        INTERPOLATED trajectory's error w.r.t. the support points (field_factor.py:42-54) while b stays the support
+        points' own error.  Values come from the kernel GPMP2 itself uses (mpb_gpmp2_linearize); the dense form is
+        an inspection aid -- GPMP2 never materialises it."""
         trajs = self._as_3d(trajs)
         B, H, d = trajs.shape
-        geom = self.device_geometry(trajs.device)
-        _, pw = ops.cost_collision_eval(trajs, geom, 1.0, per_waypoint=True)
-        _, grad = ops.cost_collision_grad(trajs, geom, 1.0)
-        N = self.dim * H
+        assert d == self.dim, 'get_linear_system works on (B, H, 2*n_dof) trajectories'
+        rows = ops.gpmp2_collision_rows(trajs, self.device_geometry(trajs.device), n_interp=n_interpolated_points or 0)[0]
+        N, D = self.dim * H, self.n_dof
         A = torch.zeros(B, H - 1, N, device=trajs.device, dtype=trajs.dtype)
         for i in range(H - 1):
-            A[:, i, (i + 1) * self.dim:(i + 1) * self.dim + self.n_dof] = -grad[:, i + 1, :self.n_dof]
-        b = pw[:, 1:].unsqueeze(-1)
+            A[:, i, (i + 1) * self.dim:(i + 1) * self.dim + D] = rows[:, i + 1, :D]
+        b = rows[:, 1:, D].unsqueeze(-1).clone()
         K = self.k_sigma * torch.eye(H - 1, device=trajs.device, dtype=trajs.dtype).repeat(B, 1, 1)
         return A, b, K
 
@@ -377,13 +380,20 @@ class CostComposite(Cost):
                 other.append((cost, float(w)))
         return coll, _merge_term_specs(terms), other
 
-    def get_linear_system(self, trajs, **kwargs):
+    def get_linear_system(self, trajs, n_interpolated_points=None, **kwargs):
+        """cost_functions.py:107-144: row-concatenated A, b and block-diagonal K of the members that have a linear
+        system; `n_interpolated_points` reaches the collision members (their Jacobian is then the interpolated
+        trajectory's, :112-119).  Like the reference, a member whose get_linear_system returns None (the
+        reference's bare `pass`: CostGPTrajectory, CostSmoothnessCHOMP, CostJointLimits) raises TypeError at the
+        unpack (:122-126); (None, None, None) members are skipped (:129-130).  Composite weights do not enter
+        (the reference ignores weight_cost_l here)."""
+        trajs = self._as_3d(trajs)
         As, bs, Ks = [], [], []
         for cost in self.cost_l:
-            r = cost.get_linear_system(trajs, **kwargs)
-            if r is None or any(v is None for v in r):
+            A, b, K = cost.get_linear_system(trajs, n_interpolated_points=n_interpolated_points, **kwargs)
+            if A is None or b is None or K is None:
                 continue
-            As.append(r[0]); bs.append(r[1]); Ks.append(r[2])
+            As.append(A); bs.append(b); Ks.append(K)
         A, b = torch.cat(As, 1), torch.cat(bs, 1)
         K = torch.zeros(A.shape[0], A.shape[1], A.shape[1], device=A.device, dtype=A.dtype)
         o = 0

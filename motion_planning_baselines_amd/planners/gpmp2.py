@@ -10,6 +10,32 @@ import torch.distributed as dist
 
 from .. import ops
 from .base import OptimizationPlanner
+from .costs.cost_functions import CostCollision, CostComposite, CostGP, CostGoalPrior
+
+SOLVE_METHODS = ('cholesky', 'inverse', 'lstq')
+
+
+def build_gpmp2_cost_composite(robot=None, n_support_points=None, dt=None, start_state=None, multi_goal_states=None,
+                               num_particles_per_goal=None, collision_fields=None, extra_costs=[], sigma_start=1e-5,
+                               sigma_gp=1e-2, sigma_coll=1e-5, sigma_goal_prior=1e-5, num_samples=64, tensor_args=None,
+                               **kwargs):
+    """gpmp2.py:23-91: CostGP (start + GP prior), CostGoalPrior when there are goals, one CostCollision per field,
+    then the extra costs -- as a CostComposite (the object behind GPMP2.cost / StochGPMP.cost)."""
+    cost_func_list = []
+    start_zero_vel = torch.cat((start_state, torch.zeros_like(start_state)))
+    cost_func_list.append(CostGP(robot, n_support_points, start_zero_vel, dt,
+                                 dict(sigma_start=sigma_start, sigma_gp=sigma_gp), tensor_args=tensor_args))
+    if multi_goal_states is not None:
+        goals_zero_vel = torch.cat((multi_goal_states, torch.zeros_like(multi_goal_states)), dim=-1)
+        cost_func_list.append(CostGoalPrior(robot, n_support_points, multi_goal_states=goals_zero_vel,
+                                            num_particles_per_goal=num_particles_per_goal, num_samples=num_samples,
+                                            sigma_goal_prior=sigma_goal_prior, tensor_args=tensor_args))
+    for field in collision_fields:
+        cost_func_list.append(CostCollision(robot, n_support_points, field=field, sigma_coll=sigma_coll,
+                                            tensor_args=tensor_args))
+    if extra_costs:
+        cost_func_list.append(*extra_costs)          # gpmp2.py:82-84: works for exactly one extra cost, as there
+    return CostComposite(robot, n_support_points, cost_func_list, tensor_args=tensor_args)
 
 
 class GPMP2(OptimizationPlanner):
@@ -18,9 +44,13 @@ class GPMP2(OptimizationPlanner):
     sigma_goal_prior).
 
     Differences, all forced by the hot path living on the GPU:
-      * ``collision_fields`` holds one to four CollisionFields (chained in one geometry buffer, one block of
-        collision rows per field like the reference);
-      * ``solver_params['method']`` must be 'cholesky' (the reference's other methods solve the same system);
+      * ``collision_fields`` (+ a CostCollision given as ``extra_costs``) hold one to four CollisionFields in total
+        (chained in one geometry buffer, one block of collision rows per field like the reference); any other kind
+        of extra cost raises NotImplementedError (in the reference only costs with a real get_linear_system can be
+        extra costs at all: the others return None and fail at the unpack, cost_functions.py:122-126);
+      * ``solver_params['method']``: 'cholesky', 'inverse' and 'lstq' (gpmp2.py:432-491) all run the block solve --
+        they are three dense solvers of the same SPD system; 'cholesky-sparse' raises like the reference (:457);
+      * without goals (``multi_goal_states=None``, gpmp2.py:135-137) the goal factor is left out of the system;
       * extra kwarg ``process_group``: when given, the trust-region damping's batch mean (quirk Q9,
         gpmp2.py:361-367) is all-reduced over the group so that sharded runs equal the unsharded one.
     """
@@ -29,8 +59,8 @@ class GPMP2(OptimizationPlanner):
                  num_particles_per_goal=None, opt_iters=None, dt=None, start_state=None, step_size=1.,
                  multi_goal_states=None, initial_particle_means=None, sigma_start_init=None, sigma_start_sample=None,
                  sigma_goal_init=None, sigma_goal_sample=None, sigma_gp_init=None, solver_params=None,
-                 stop_criteria=None, collision_fields=None, sigma_start=1e-5, sigma_gp=1e-2, sigma_coll=1e-5,
-                 sigma_goal_prior=1e-5, tensor_args=None, process_group=None, **kwargs):
+                 stop_criteria=None, collision_fields=None, extra_costs=None, sigma_start=1e-5, sigma_gp=1e-2,
+                 sigma_coll=1e-5, sigma_goal_prior=1e-5, tensor_args=None, process_group=None, **kwargs):
         super().__init__(name='GPMP', n_dof=n_dof, n_support_points=n_support_points,
                          num_particles_per_goal=num_particles_per_goal, opt_iters=opt_iters, dt=dt,
                          start_state=start_state, initial_particle_means=initial_particle_means,
@@ -42,32 +72,62 @@ class GPMP2(OptimizationPlanner):
         # collision Jacobian (cost_functions.py:115-119) only runs when a caller sets the attribute afterwards.
         # Same here: the ctor argument is ignored, the attribute is honoured by _step.
         self.n_interpolated_points = None
+        collision_fields = list(collision_fields or [])
+        extra_costs = list(extra_costs or [])
+        scales = [1.0] * len(collision_fields)
+        for c in extra_costs:
+            # an extra CostCollision is one more block of collision rows with K = I / sigma_e^2: chained as a further
+            # field whose share is (sigma_coll / sigma_e)^2 of the common 1 / sigma_coll^2
+            if not isinstance(c, CostCollision) or c.field is None:
+                raise NotImplementedError('GPMP2 extra_costs: only CostCollision members are wired into the block solve')
+            collision_fields.append(c.field)
+            scales.append((sigma_coll / c.sigma_coll) ** 2)
         if not collision_fields or len(collision_fields) > 4:
             raise NotImplementedError('GPMP2 on the GPU takes one to four CollisionFields')
         solver_params = solver_params or dict(delta=1e-2, trust_region=True, method='cholesky')
-        if solver_params.get('method', 'cholesky') != 'cholesky':
-            raise NotImplementedError("solver_params['method'] must be 'cholesky'")
+        if solver_params.get('method', 'cholesky') not in SOLVE_METHODS:
+            raise NotImplementedError(f"solver_params['method'] must be one of {SOLVE_METHODS}")   # gpmp2.py:457, :489
         self.robot = robot
         self.d_state_opt = 2 * n_dof
         self.goal_directed = multi_goal_states is not None
-        assert self.goal_directed, 'GPMP2 kernels need goal states (CostGoalPrior)'
+        if not self.goal_directed:
+            self.num_goals = 1                                                                     # gpmp2.py:136-137
+        self._cost_kwargs = dict(robot=robot, n_support_points=n_support_points, dt=dt, start_state=start_state,
+                                 multi_goal_states=multi_goal_states, num_particles_per_goal=num_particles_per_goal,
+                                 collision_fields=collision_fields[:len(collision_fields) - len(extra_costs)],
+                                 extra_costs=extra_costs, sigma_start=sigma_start, sigma_gp=sigma_gp,
+                                 sigma_coll=sigma_coll, sigma_goal_prior=sigma_goal_prior, tensor_args=tensor_args)
+        self._cost = None
         self.step_size = step_size
         self.solver_params = solver_params
         self.stop_criteria = stop_criteria
         self.N = self.d_state_opt * n_support_points
-        self.sigmas = (sigma_start, sigma_gp, sigma_goal_prior, sigma_coll)
+        # no goals: 1 / sigma_goal^2 = 0 switches the goal factor off inside the kernels
+        self.sigmas = (sigma_start, sigma_gp, sigma_goal_prior if self.goal_directed else float('inf'), sigma_coll)
         self.process_group = process_group
-        self.geom = ops.DeviceGeometry(robot, list(collision_fields), self.device)   # one CostCollision per field (gpmp2.py:70-78)
+        self.geom = ops.DeviceGeometry(robot, collision_fields, self.device, scales=scales)   # one CostCollision per field (gpmp2.py:70-78)
         self.costs = None
         self._ws = None
         self.reset(initial_particle_means=initial_particle_means)
 
+    @property
+    def cost(self):
+        """The reference's GPMP2.cost (gpmp2.py:160-168): the CostComposite of the same factors, for callers that
+        evaluate it or read its dense get_linear_system; the planner's own step never goes through it."""
+        if self._cost is None and getattr(self, '_cost_kwargs', None) is not None:
+            self._cost = build_gpmp2_cost_composite(**self._cost_kwargs)
+        return self._cost
+
+    @cost.setter
+    def cost(self, value):
+        self._cost = value
+
     def reset(self, start_state=None, multi_goal_states=None, initial_particle_means=None):
         """gpmp2.py:172-199 (a leading goal dimension of the initial means is flattened, :199)."""
         if start_state is not None:
-            self.start_state = torch.cat([start_state, torch.zeros_like(start_state)], -1)
+            self.start_state = self._full_state(start_state)
         if multi_goal_states is not None:
-            self.multi_goal_states = torch.cat([multi_goal_states, torch.zeros_like(multi_goal_states)], -1)
+            self.multi_goal_states = self._full_state(multi_goal_states)
         if initial_particle_means is None:
             m = self.get_random_trajs()
         else:
@@ -80,9 +140,12 @@ class GPMP2(OptimizationPlanner):
         dim = self.d_state_opt
         ss = self.start_state.to(device=self.device, dtype=torch.float32).reshape(-1, dim)
         self._start = ss.expand(B, dim).contiguous() if ss.shape[0] == 1 else ss.contiguous()
-        gs = self.multi_goal_states.to(device=self.device, dtype=torch.float32).reshape(-1, dim)
-        # particles are ordered goal-major (num_goals x particles_per_goal), like the reference (:199)
-        self._goal = gs.repeat_interleave(self.num_particles_per_goal, 0).contiguous() if gs.shape[0] != B else gs.contiguous()
+        if self.goal_directed:
+            gs = self.multi_goal_states.to(device=self.device, dtype=torch.float32).reshape(-1, dim)
+            # particles are ordered goal-major (num_goals x particles_per_goal), like the reference (:199)
+            self._goal = gs.repeat_interleave(self.num_particles_per_goal, 0).contiguous() if gs.shape[0] != B else gs.contiguous()
+        else:
+            self._goal = self._start                 # never read: the goal factor's weight is zero
         self._ws = ops.gpmp2_workspace(B, self.n_support_points, self.n_dof, self.device)
         self.costs = torch.zeros(B, device=self.device, dtype=torch.float32)
 

@@ -59,7 +59,9 @@ class MPPI(MPPlanner):
         self._states = torch.empty(1, S, T, c, device=self.device)
         self._costs = torch.empty(1, S, device=self.device)
         self._weights = torch.empty(1, S, device=self.device)
-        self.best_cost = torch.inf
+        # MPPI._save_best state (mppi.py:164-168): kept on the device, updated inside the kernel every iteration
+        self._best_cost = torch.full((1,), float('inf'), device=self.device)
+        self._best_traj = torch.zeros(1, T, c, device=self.device)
         self.weights = None
         self.reset(initial_mean=initial_mean)
 
@@ -95,13 +97,25 @@ class MPPI(MPPlanner):
             geom, k_sigma = cc.device_geometry(self.device), cc.k_sigma
         return state, goal, geom, k_sigma, weight
 
-    def _launch(self, n_iters, step_size, **observation):
+    @property
+    def best_cost(self):
+        """Lowest sample cost seen by optimize() so far (inf before the first call), as a 0-dim tensor."""
+        return self._best_cost[0]
+
+    @property
+    def best_traj(self):
+        """State trajectory (T, state_dim) of that sample."""
+        return self._best_traj[0]
+
+    def _launch(self, n_iters, step_size, track_best=False, **observation):
         state, goal, geom, k_sigma, weight = self._problem(**observation)
         mean = self._mean.reshape(1, self.rollout_steps, self.control_dim)
         ops.mppi_step(mean, self._draw_eps(n_iters), self._scale_tril, self.Cov_inv, state, goal, self._cmin,
                       self._cmax, self._disc, self._cw, geom, self._controls, self._states, self._costs, self._weights,
                       self.system.dt, k_sigma=k_sigma, weight=weight, temp=self.temp, step_size=step_size,
-                      n_iters=n_iters, seed=self.seed, iter0=self._iter)
+                      n_iters=n_iters, seed=self.seed, iter0=self._iter,
+                      best_cost=self._best_cost if track_best else None,
+                      best_states=self._best_traj if track_best else None)
         self._iter += n_iters
         self.costs = self._costs.reshape(-1, 1)
         self.state_trajectories = self._states[0]
@@ -143,19 +157,20 @@ class MPPI(MPPlanner):
     def optimize(self, opt_iters=None, **observation):
         if opt_iters is None:
             opt_iters = self.opt_iters
-        self._launch(opt_iters, self.step_size, **observation)
+        # _save_best runs inside the kernel after every iteration's sample_and_eval, as in mppi.py:145-152
+        self._launch(opt_iters, self.step_size, track_best=True, **observation)
         self.weights = self._weights.reshape(-1, 1)
-        self._save_best()
         self._recent_control_samples = self._controls[0]
         self._recent_state_trajectories = self._states[0]
         self._recent_weights = self.weights
         return self._controls[0], self._states[0], self.costs
 
     def _save_best(self):
+        """mppi.py:164-168 for callers that drive sample_and_eval / update_controller themselves."""
         best_cost = torch.min(self.costs)
-        if best_cost < self.best_cost:
-            self.best_cost = best_cost
-            self.best_traj = self.state_trajectories[torch.argmin(self.costs)].clone()
+        if best_cost < self._best_cost[0]:
+            self._best_cost[0] = best_cost
+            self._best_traj[0] = self.state_trajectories[torch.argmin(self.costs)]
 
     def pop(self):
         action = self._mean[0, :].clone().detach()

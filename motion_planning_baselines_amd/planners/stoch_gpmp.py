@@ -50,7 +50,11 @@ class StochGPMP(OptimizationPlanner):
         self.reset(initial_particle_means=initial_particle_means)
 
     def reset(self, start_state=None, multi_goal_states=None, initial_particle_means=None):
-        """stoch_gpmp.py:97-141."""
+        """stoch_gpmp.py:97-141: new start / goal states re-target the planner (:99-103)."""
+        if start_state is not None:
+            self.start_state = self._full_state(start_state)
+        if multi_goal_states is not None:
+            self.multi_goal_states = self._full_state(multi_goal_states)
         if initial_particle_means is None:
             m = self.get_random_trajs()
         elif isinstance(initial_particle_means, str) and initial_particle_means == 'const_vel':

@@ -248,6 +248,7 @@ def gpmp2_linear_system(x, robot, field, start_state, goal_state, D, dt,
     for the cost list of build_gpmp2_cost_composite (gpmp2.py:23-91): CostGP (:291-314), CostGoalPrior
     (:538-554), CostCollision (:191-231; Jacobian = -d err/d q by autograd, field_factor.py:41-57).
     x (B,H,2D).  Returns A (B,M,N), b (B,M,1), K (B,M,M) with N = 2D*H, M = N + 2D + (H-1).
+    goal_state None: the composite has no CostGoalPrior (gpmp2.py:63-73, goal_directed False :135-137).
     """
     B, H, dim = x.shape
     N = dim * H
@@ -269,10 +270,14 @@ def gpmp2_linear_system(x, robot, field, start_state, goal_state, D, dt,
         K1[:, r, r] += Qi
     b1[:, dim:, 0] = e.reshape(B, -1)
     # ---- goal prior (cost_functions.py:538-554)
-    A2 = torch.zeros(B, dim, N, **tensor_args)
-    A2[:, :, -dim:] = I
-    b2 = (goal_state - x[:, -1]).reshape(B, dim, 1)
-    K2 = (I / sigma_goal ** 2).expand(B, dim, dim)
+    if goal_state is not None:
+        A2 = torch.zeros(B, dim, N, **tensor_args)
+        A2[:, :, -dim:] = I
+        b2 = (goal_state - x[:, -1]).reshape(B, dim, 1)
+        K2 = (I / sigma_goal ** 2).expand(B, dim, dim)
+    else:
+        A2, b2, K2 = (torch.zeros(B, 0, N, **tensor_args), torch.zeros(B, 0, 1, **tensor_args),
+                      torch.zeros(B, 0, 0, **tensor_args))
     # ---- collision (cost_functions.py:191-231): one block of H-1 rows per collision field (gpmp2.py:70-78)
     fields = list(field) if isinstance(field, (list, tuple)) else [field]
     A3s, b3s, K3s = [], [], []

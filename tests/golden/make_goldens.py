@@ -6,7 +6,8 @@ where it lies with a ``sys.modules`` stand-in for the absent ``torch_robotics`` 
 ``field`` (oracle/geometry_ref.py).  Only DATA is written (inputs, injected standard-normal draws,
 per-iteration outputs) as small .npz fixtures next to this script; no reference source is copied.
 
-    python tests/golden/make_goldens.py
+    python tests/golden/make_goldens.py            # every fixture
+    python tests/golden/make_goldens.py NAME ...   # only the named fixtures (e.g. stomp_panda_s32)
 """
 import os
 import sys
@@ -14,8 +15,10 @@ import sys
 import numpy as np
 import torch
 
-HERE = os.path.dirname(os.path.abspath(__file__))
-ROOT = os.path.dirname(os.path.dirname(HERE))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# output directory: next to this script, or MPB_GOLDEN_OUT (tests/test_goldens_regenerate.py writes to a temp dir and
+# compares with the committed fixtures bit for bit)
+HERE = os.environ.get('MPB_GOLDEN_OUT') or os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.dont_write_bytecode = True
 
@@ -41,6 +44,16 @@ from mp_baselines.planners.costs.factors.unary_factor import UnaryFactor  # noqa
 
 TA32 = dict(device='cpu', dtype=torch.float32)
 TA64 = dict(device='cpu', dtype=torch.float64)
+ONLY = set(sys.argv[1:])     # fixture names to (re)generate; empty = all.  Every generator seeds itself, so the
+                             # fixtures do not depend on which others were generated in the same run
+
+
+def fixture(fn):
+    def run(name, *a, **k):
+        if ONLY and name not in ONLY:
+            return
+        return fn(name, *a, **k)
+    return run
 
 
 class EpsRecorder:
@@ -100,6 +113,7 @@ def free_configs(robot, field, n, seed, ta):
 
 # ------------------------------------------------------------------------------------------------
 
+@fixture
 def gen_stomp(name, robot, field, start, goal, P, S, H, dt, sigma_coll, pos_only, iters, seed,
               lr=0.1, temperature=1.0, sigma_spectral=0.1, init_noise=0.0):
     ta = TA32
@@ -134,6 +148,7 @@ def gen_stomp(name, robot, field, start, goal, P, S, H, dt, sigma_coll, pos_only
     print(name, 'eps', eps.shape, 'final cost min/max', out['costs'][-1].min(), out['costs'][-1].max())
 
 
+@fixture
 def gen_chomp(name, robot, field, starts, goals, H, dt, sigma_coll, weight, iters, seed,
               w_prior=1e-4, lr=0.05, clip=0.05, pos_only=False, init_noise=0.01):
     ta = TA32
@@ -160,8 +175,9 @@ def gen_chomp(name, robot, field, starts, goals, H, dt, sigma_coll, weight, iter
     print(name, 'moved', np.abs(means[-1] - npf(means0)).max())
 
 
+@fixture
 def gen_gpmp2(name, robot, field, start, goal, B, H, dt, iters, seed, ta, sig=None, delta=1e-2,
-              trust_region=True, step_size=1.0, init_noise=0.02, n_interp=None, extra_fields=()):
+              trust_region=True, step_size=1.0, init_noise=0.02, n_interp=None, extra_fields=(), keep_band=True):
     sig = sig or dict(sigma_start=1e-5, sigma_gp=1e-2, sigma_coll=1e-5, sigma_goal_prior=1e-5)
     rr, rf = make_ref_geometry(robot, field, ta)
     rfs = [rf] + [make_ref_geometry(robot, f, ta)[1] for f in extra_fields]      # one CostCollision per field
@@ -205,7 +221,7 @@ def gen_gpmp2(name, robot, field, start, goal, B, H, dt, iters, seed, ta, sig=No
     rec.pop('_Kfull')
     small = H * robot.q_dim * 2 <= 64
     keep = {k: np.stack(v) for k, v in rec.items() if small or k in ('means', 'costs', 'g')}
-    if not small:   # keep the banded part of JtJ only (diagonal blocks + first off-diagonal blocks)
+    if not small and keep_band:   # keep the banded part of JtJ only (diagonal blocks + first off-diagonal blocks)
         dim = 2 * robot.q_dim
         J = np.stack(rec['JtJ'])
         keep['JtJ_diag'] = np.stack([J[:, :, t * dim:(t + 1) * dim, t * dim:(t + 1) * dim] for t in range(H)], 2)
@@ -226,13 +242,13 @@ def gen_gpmp2(name, robot, field, start, goal, B, H, dt, iters, seed, ta, sig=No
     print(name, 'costs', rec['costs'][0][:3], '->', rec['costs'][-1][:3])
 
 
+@fixture
 def gen_stoch_gpmp(name, robot, field, start, goal, P, S, H, dt, iters, seed, ta, temperature=1.0, step_size=0.5,
                    sig_sample=(1e-3, 1e-3, 0.5), sig_cost=None, init_noise=0.02):
     """StochGPMP (stoch_gpmp.py): samples from the full GP prior around each particle, composite cost
     (GP + goal prior + collision) + importance term, softmax update without Sigma."""
     sig_cost = sig_cost or dict(sigma_start=1e-2, sigma_gp=1.0, sigma_coll=1e-1, sigma_goal_prior=1e-2)
     rr, rf = make_ref_geometry(robot, field, ta)
-    rfs = [rf] + [make_ref_geometry(robot, f, ta)[1] for f in extra_fields]      # one CostCollision per field
     start, goal = start.to(**ta), goal.to(**ta)
     g = torch.Generator().manual_seed(seed + 1000)
     means0 = straight_line_means(start.float(), goal.float(), H, dt, P, False, noise=init_noise, gen=g).to(**ta)
@@ -269,6 +285,7 @@ def gen_stoch_gpmp(name, robot, field, start, goal, P, S, H, dt, iters, seed, ta
           'moved', np.abs(out['means'][-1] - npf(means0)).max())
 
 
+@fixture
 def gen_mppi(name, S, T, dt, iters, seed, cov_type='const_ctrl', control_std=(0.15, 0.15), temp=1.0,
              step_size=1.0, with_cost=False):
     ta = TA32
@@ -306,6 +323,7 @@ def gen_mppi(name, S, T, dt, iters, seed, cov_type='const_ctrl', control_std=(0.
     print(name, 'cost', out['costs'][0].min(), '->', out['costs'][-1].min())
 
 
+@fixture
 def gen_gp_prior(name, D, H, dt, seed):
     """MultiMPPrior precision / mean / samples as OptimizationPlanner.get_random_trajs builds them
     (base.py:155-202)."""
@@ -328,6 +346,7 @@ def gen_gp_prior(name, D, H, dt, seed):
     print(name, 'samples', smp.shape)
 
 
+@fixture
 def gen_cost_terms(name, robot, D, H, G_, npg, S, dt, seed):
     """The trajectory-only cost classes of cost_functions.py (CostGP :234-314, CostGPTrajectory :317-357,
     the position-only wrapper :360-368, CostSmoothnessCHOMP :371-390, CostJointLimits :393-429,
@@ -367,23 +386,6 @@ def gen_cost_terms(name, robot, D, H, G_, npg, S, dt, seed):
 
 def main():
     torch.set_num_threads(4)
-    if len(sys.argv) > 1 and sys.argv[1] == 'gpmp2_fields':
-        gen_gpmp2('gpmp2_pm2d_h8_2fields_f64', G.RobotPointMass(2, radius=0.01), G.env_dense_2d(),
-                  torch.tensor([-0.4, -0.4]), torch.tensor([0.4, 0.4]), B=3, H=8, dt=0.04, iters=3, seed=0, ta=TA64,
-                  extra_fields=(G.env_grid_circles_2d(margin=0.03),))
-        return
-    if len(sys.argv) > 1 and sys.argv[1] == 'gpmp2_interp':
-        gen_gpmp2('gpmp2_pm2d_h8_interp_f64', G.RobotPointMass(2, radius=0.01), G.env_dense_2d(),
-                  torch.tensor([-0.4, -0.4]), torch.tensor([0.4, 0.4]), B=3, H=8, dt=0.04, iters=3, seed=0, ta=TA64,
-                  n_interp=3)
-        qc = free_configs(G.RobotPanda(), G.env_spheres_3d(), 12, 11, TA32)     # pair (8, 9): the line crosses obstacles
-        gen_gpmp2('gpmp2_panda_h16_interp_f64', G.RobotPanda(), G.env_spheres_3d(), qc[8], qc[9], B=2, H=16, dt=5 / 16,
-                  iters=3, seed=1, ta=TA64, n_interp=2)
-        return
-    if len(sys.argv) > 1 and sys.argv[1] == 'cost_terms':
-        gen_cost_terms('cost_terms_pm2d', G.RobotPointMass(2, radius=0.01), D=2, H=64, G_=2, npg=3, S=4, dt=0.04, seed=0)
-        gen_cost_terms('cost_terms_panda', G.RobotPanda(), D=7, H=48, G_=1, npg=2, S=5, dt=0.1, seed=1)
-        return
     pm = G.RobotPointMass(2, radius=0.01)
     grid = G.env_grid_circles_2d()
     dense = G.env_dense_2d()
@@ -407,6 +409,14 @@ def main():
               pos_only=False, iters=6, seed=6, temperature=1.0, sigma_spectral=0.5)
     gen_stomp('stomp_pm2d_h48', pm, dense, s2, g2, P=3, S=5, H=48, dt=0.05, sigma_coll=0.1,
               pos_only=True, iters=3, seed=4, init_noise=0.01)
+    # C3's sample count (S = 32: the update kernel's register path is full) and S = 64 (its tail loop); H = 32 pos_only
+    # with S = 64: H*d = 224 is not a multiple of 64 (partial last worker wave of the update kernel)
+    gen_stomp('stomp_panda_s32', panda, sph3, q[0], q[1], P=2, S=32, H=64, dt=5 / 64, sigma_coll=1.0,
+              pos_only=False, iters=2, seed=7, temperature=1.0, sigma_spectral=0.5)
+    gen_stomp('stomp_panda_s64', panda, sph3, q[0], q[1], P=2, S=64, H=64, dt=5 / 64, sigma_coll=1.0,
+              pos_only=False, iters=1, seed=8, temperature=1.0, sigma_spectral=0.5)
+    gen_stomp('stomp_panda_h32_s64', panda, sph3, q[0], q[1], P=2, S=64, H=32, dt=5 / 32, sigma_coll=1.0,
+              pos_only=True, iters=2, seed=9, temperature=1.0, sigma_spectral=0.1)
 
     # CHOMP: dense 2-D with boxes (C2 parameters), Panda
     gs = torch.Generator().manual_seed(7)
@@ -426,13 +436,18 @@ def main():
     gen_gpmp2('gpmp2_pm2d_h8_notr_f64', pm, dense, s2 * 0.5, g2 * 0.5, B=3, H=8, dt=0.04, iters=3, seed=0, ta=TA64,
               trust_region=False)
     gen_gpmp2('gpmp2_panda_h16_f64', panda, sph3, q[0], q[1], B=2, H=16, dt=5 / 16, iters=3, seed=1, ta=TA64)
+    qc = free_configs(panda, sph3, 12, 11, TA32)                                # pair (8, 9): the line crosses obstacles
+    # C4's shape per particle (H = 128, D = 7: dense N = 1792) and H = 64, fp64 reference; means / costs / g only
+    gen_gpmp2('gpmp2_panda_h64_f64', panda, sph3, q[0], q[1], B=2, H=64, dt=5 / 64, iters=2, seed=2, ta=TA64,
+              keep_band=False)
+    gen_gpmp2('gpmp2_panda_h128_f64', panda, sph3, qc[8], qc[9], B=2, H=128, dt=5 / 128, iters=2, seed=3, ta=TA64,
+              keep_band=False)
     # two collision fields: one block of collision rows per field (gpmp2.py:70-78)
     gen_gpmp2('gpmp2_pm2d_h8_2fields_f64', pm, dense, s2 * 0.5, g2 * 0.5, B=3, H=8, dt=0.04, iters=3, seed=0, ta=TA64,
               extra_fields=(G.env_grid_circles_2d(margin=0.03),))
     # with n_interpolated_points: collision Jacobian of the interpolated trajectory (build-defined interpolation)
     gen_gpmp2('gpmp2_pm2d_h8_interp_f64', pm, dense, s2 * 0.5, g2 * 0.5, B=3, H=8, dt=0.04, iters=3, seed=0, ta=TA64,
               n_interp=3)
-    qc = free_configs(panda, sph3, 12, 11, TA32)                                # pair (8, 9): the line crosses obstacles
     gen_gpmp2('gpmp2_panda_h16_interp_f64', panda, sph3, qc[8], qc[9], B=2, H=16, dt=5 / 16, iters=3, seed=1, ta=TA64,
               n_interp=2)
 

@@ -114,13 +114,14 @@ def test_chomp_c2_fused_equals_stepwise(gpu_device):
     assert torch.equal(c, a[:512])
 
 
-def test_gpmp2_c4_solve_properties(gpu_device):
-    """C4 shape (H=128, D=7), B=256: the Gauss-Newton step must (i) be finite, (ii) leave trajectories that
+@pytest.mark.parametrize('B', [256, 2048])
+def test_gpmp2_c4_solve_properties(gpu_device, B):
+    """C4 (H=128, D=7) at its full batch B=2048 (352 MB workspace) and at B=256: the Gauss-Newton step must (i) be finite, (ii) leave trajectories that
     already satisfy all factors unchanged (fixed point: straight line, no collision, exact start/goal),
     (iii) reduce the cost b^T K b on colliding problems, (iv) split entry points == single call."""
     from motion_planning_baselines_amd import geometry as G, ops, workloads
     dev = gpu_device
-    B, H, D = 256, 128, 7
+    H, D = 128, 7
     robot, field = G.RobotPanda(), G.env_spheres_3d()
     geom = ops.DeviceGeometry(robot, field, dev)
     q = workloads.collision_free_configs(robot, field, 2 * B, 23, dev)
@@ -163,6 +164,35 @@ def test_gpmp2_c4_solve_properties(gpu_device):
     ops.gpmp2_solve(xb, start, goal, dsum / B, ws, sig, dt, 1e-2, True, 1.0)
     torch.cuda.synchronize()
     assert torch.equal(xa, xb)
+
+
+def test_stomp_c5_per_gpu_load(gpu_device):
+    """C5's per-GPU load: 4096 particles x 32 samples = 131 072 rollouts per iteration (470 MB of samples).  With the
+    device Philox stream keyed by the global particle id, the first 128 particles of the big launch must equal a
+    128-particle launch bit for bit (nothing depends on the grid size or on which block a particle lands in), the
+    weights are normalised and the costs equal the stand-alone cost kernel on the samples the big launch wrote."""
+    from motion_planning_baselines_amd import ops
+    dev = gpu_device
+    P, S, H = 4096, 32, 64
+    wl, Sigma, L, geom = _c3(dev, P, S)
+    d = wl['means0'].shape[-1]
+    mk = lambda p: (torch.empty(p, S, H, d, device=dev), torch.empty(p, S, device=dev), torch.empty(p, S, device=dev))
+    big = wl['means0'].clone()
+    s, c, w = mk(P)
+    ops.stomp_step(big, None, s, c, w, L, Sigma, geom, S, 7, 1.0, 1.0, 0.1, 1.0, n_iters=3, seed=5)
+    small = wl['means0'][:128].clone()
+    s2, c2, w2 = mk(128)
+    ops.stomp_step(small, None, s2, c2, w2, L, Sigma, geom, S, 7, 1.0, 1.0, 0.1, 1.0, n_iters=3, seed=5)
+    tail = wl['means0'][P - 64:].clone()
+    s3, c3, w3 = mk(64)
+    ops.stomp_step(tail, None, s3, c3, w3, L, Sigma, geom, S, 7, 1.0, 1.0, 0.1, 1.0, n_iters=3, seed=5, particle_offset=P - 64)
+    torch.cuda.synchronize()
+    assert torch.isfinite(big).all()
+    assert torch.equal(big[:128], small) and torch.equal(s[:128], s2) and torch.equal(c[:128], c2) and torch.equal(w[:128], w2)
+    assert torch.equal(big[P - 64:], tail) and torch.equal(s[P - 64:], s3)
+    assert torch.allclose(w.sum(1), torch.ones(P, device=dev), atol=1e-5)
+    cc = ops.cost_collision_eval(s.flatten(0, 1), geom, 1.0).reshape(P, S)
+    assert torch.equal(cc, c)
 
 
 def test_static_link_pruning_changes_nothing(gpu_device):

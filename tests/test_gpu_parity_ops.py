@@ -84,7 +84,10 @@ def test_collision_grad_vs_autograd(gpu_device, name, B, H, dd):
 
 
 STOMP_CASES = ['stomp_pm2d_stiff', 'stomp_pm2d_benign', 'stomp_pm2d_c1', 'stomp_panda_stiff',
-               'stomp_panda_benign', 'stomp_panda_t1', 'stomp_pm2d_h48']
+               'stomp_panda_benign', 'stomp_panda_t1', 'stomp_pm2d_h48',
+               'stomp_panda_s32',       # C3's S = 32: every register slot of the update kernel in use
+               'stomp_panda_s64',       # S = 64: the update kernel's tail loop
+               'stomp_panda_h32_s64']   # H*d = 224: partial last worker wave in the update kernel, chunked sampler
 
 
 def reference_fp32_envelope(g):
@@ -98,6 +101,17 @@ def reference_fp32_envelope(g):
                               lambda x: O.collision_cost(x, robot, field, float(g['sigma_coll'])),
                               float(g['lr']), float(g['temperature']))['means']
     return rel_err(T(g['means'][-1]), m)
+
+
+def reference_fp32_envelope_one_iteration(g, it):
+    """The same envelope for ONE teacher-forced pass of the loop body from the reference's own iterate."""
+    from oracle import planners_ref as O
+    robot, field = ref_geometry_from_golden(g, torch.float64)
+    prev = T(g['means0'] if it == 0 else g['means'][it - 1]).double()
+    m = O.stomp_iteration(prev, T(g['eps'][it]).double(), T(g['L']).double(), T(g['Sigma']).double(),
+                          lambda x: O.collision_cost(x, robot, field, float(g['sigma_coll'])),
+                          float(g['lr']), float(g['temperature']))['means']
+    return rel_err(T(g['means'][it]), m)
 
 
 def _stomp_bufs(g, dev):
@@ -132,7 +146,11 @@ def test_stomp_teacher_forced_vs_golden(gpu_device, name):
         cond = float(ksig) * 1e-6
         if cond < 1e-2:
             np.testing.assert_allclose(weights.cpu().numpy(), wref.numpy(), rtol=1e-3, atol=1e-5)
-        assert rel_err(means, T(g['means'][it])) < (REL if cond < 1e-2 else 5e-3), it
+        # means: north_star's 1e-4; where the softmax is ill-conditioned in the reference itself (costs carry a
+        # 1/sigma^2 = 1e6 factor: an fp32 rounding of the cost sum moves the logits by O(0.1)) the reference's fp32
+        # result is only defined up to its own fp32-vs-fp64 envelope, computed here on the same noise
+        bar = REL if cond < 1e-2 else max(REL, 2.0 * reference_fp32_envelope_one_iteration(g, it))
+        assert rel_err(means, T(g['means'][it])) < bar, (it, bar)
         prev = T(g['means'][it])
 
 
@@ -161,6 +179,43 @@ def test_stomp_free_running_vs_golden(gpu_device, name):
         assert err < REL
 
 
+@pytest.mark.parametrize('P,S,H,d', [
+    (3, 64, 32, 7),     # Panda pos_only H = 32: H*d = 224 = 3.5 waves, two samples per group beyond the registers
+    (2, 48, 16, 14),    # StochGPMP Panda H = 16 (dim 14)
+    (2, 40, 48, 14),    # H*d = 672 = 10.5 waves
+    (5, 24, 8, 2),      # H*d = 16: a quarter wave of workers
+    (2, 64, 64, 14),    # full waves, S = 64 (tail loop), C3's tile
+    (4, 32, 64, 14),    # C3's shape
+    (3, 33, 64, 7), (2, 9, 20, 3), (2, 70, 64, 4), (2, 5, 100, 4)])   # generic kernel: odd sizes / S > 64 / H > 64
+@pytest.mark.parametrize('with_sigma', [True, False])
+def test_stomp_update_vs_oracle_shapes(gpu_device, P, S, H, d, with_sigma):
+    """Kernel B alone (softmax weights + covariance-weighted update, stomp.py:199-220) against the oracle on random
+    samples / costs, over shapes that hit every dispatch path: full and partial worker waves, S <= 32, 32 < S <= 64
+    (tail loop), S > 64 and H > 64 (generic kernel), and the update without the covariance product (StochGPMP)."""
+    from motion_planning_baselines_amd import ops
+    from oracle import planners_ref as O
+    dev = gpu_device
+    gen = torch.Generator().manual_seed(100 * S + H + d)
+    means = torch.randn(P, H, d, generator=gen)
+    samples = means.unsqueeze(1) + 0.3 * torch.randn(P, S, H, d, generator=gen)
+    costs = 5.0 * torch.rand(P, S, generator=gen)
+    A = torch.randn(H, H, generator=gen) / H ** 0.5
+    Sigma = (A @ A.T + 0.1 * torch.eye(H)).contiguous()
+    lr, temp = 0.3, 0.7
+    w_ref = O.stomp_weights(costs.double(), temp)
+    if with_sigma:
+        m_ref = O.stomp_update(means.double(), samples.double(), w_ref, Sigma.double(), lr)
+    else:   # stoch_gpmp.py:272-275: no covariance product
+        m_ref = means.double() + lr * (w_ref.reshape(P, S, 1, 1) * (samples.double() - means.double().unsqueeze(1))).sum(1)
+    m = means.clone().to(dev)
+    w = torch.empty(P, S, device=dev)
+    ops.stomp_update(m, samples.to(dev), costs.to(dev), w, Sigma.to(dev) if with_sigma else None, lr, temp)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(w.cpu().numpy(), w_ref.float().numpy(), rtol=2e-5, atol=1e-8)
+    assert abs(float(w.sum(1).mean()) - 1.0) < 1e-5
+    assert rel_err(m, m_ref) < 2e-6
+
+
 def test_stomp_split_halves_equal_fused(gpu_device):
     """sample -> (cost) -> update through the split entry points == fused step (drop-in for a user cost)."""
     from motion_planning_baselines_amd import ops
@@ -179,9 +234,8 @@ def test_stomp_split_halves_equal_fused(gpu_device):
     ops.stomp_update(m2, s2, c2, w2, Sigma, 0.1, 0.1)
     torch.cuda.synchronize()
     assert torch.equal(s2, samples) and torch.equal(c2, costs) and torch.equal(w2, weights)
-    # the fused step updates in eps space (E = sum_s w_s eps_s, then Z L E), the split path from the samples:
-    # same mathematics, different fp32 summation order
-    assert rel_err(m1, m2) < 1e-5
+    # both paths run the same update kernel on the same samples / costs
+    assert torch.equal(m1, m2)
 
 
 def test_stomp_device_rng(gpu_device):

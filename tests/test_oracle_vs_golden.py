@@ -11,7 +11,8 @@ TA = dict(device='cpu', dtype=torch.float32)
 T = torch.from_numpy
 
 STOMP_CASES = ['stomp_pm2d_stiff', 'stomp_pm2d_benign', 'stomp_pm2d_c1', 'stomp_panda_stiff',
-               'stomp_panda_benign', 'stomp_panda_t1', 'stomp_pm2d_h48']
+               'stomp_panda_benign', 'stomp_panda_t1', 'stomp_pm2d_h48', 'stomp_panda_s32', 'stomp_panda_s64',
+               'stomp_panda_h32_s64']
 
 
 @pytest.mark.parametrize('name', STOMP_CASES)
@@ -56,7 +57,7 @@ def test_chomp_iterations(name):
 
 @pytest.mark.parametrize('name', ['gpmp2_pm2d_h8_f64', 'gpmp2_pm2d_h8_f32', 'gpmp2_pm2d_h8_notr_f64',
                                   'gpmp2_panda_h16_f64', 'gpmp2_pm2d_h8_interp_f64', 'gpmp2_panda_h16_interp_f64',
-                                  'gpmp2_pm2d_h8_2fields_f64'])
+                                  'gpmp2_pm2d_h8_2fields_f64', 'gpmp2_panda_h64_f64', 'gpmp2_panda_h128_f64'])
 def test_gpmp2_iterations(name):
     g = load_golden(name)
     dt64 = 'float64' in str(g['dtype'])
