@@ -140,7 +140,7 @@ def test_gpmp2_c4_shape_vs_oracle(gpu_device, H, trust, n_fields, n_interp):
     """One Gauss-Newton step at C4's per-particle shape (D = 7, H up to 128, C4's sigmas incl. 1/sigma^2 = 1e10) against
     the oracle's DENSE fp64 restatement of the reference system (N = 2*7*H up to 1792; gpmp2.py:308-368, :451-452):
     the two-ended sweep's merge row, the 64-waypoint chunk carry of the linearisation and the long elimination chain
-    at that conditioning.  Bars: d_theta 2e-3, x 1e-5 (x is stored in fp32)."""
+    at that conditioning.  Bars: d_theta 2e-3, x 1e-5 with the trust region (x is stored in fp32), 1e-4 without."""
     from motion_planning_baselines_amd import geometry as G, ops, workloads
     from oracle import planners_ref as O
     from oracle.geometry_ref import make_ref_geometry
@@ -187,7 +187,10 @@ def test_gpmp2_c4_shape_vs_oracle(gpu_device, H, trust, n_fields, n_interp):
     print(f'H={H} trust={trust} fields={n_fields} interp={n_interp}: step rel err {step_err:.2e}, x rel err {rel_err(x, xref):.2e}')
     assert float(cref.max()) > 1e3, 'the test problems must collide'
     assert step_err < 2e-3
-    assert rel_err(x, xref) < 1e-5
+    # with the trust region the step is small against x and x agrees to its fp32 storage rounding; without it the
+    # Gauss-Newton step is as large as x itself, so x inherits the step's error one for one (1.9e-5 measured: the
+    # linearisation's Jacobian is evaluated in fp32) and north_star's 1e-4 on the waypoints is the bar
+    assert rel_err(x, xref) < (1e-5 if trust else 1e-4)
     np.testing.assert_allclose(costs.cpu().numpy(), cref.numpy(), rtol=2e-3)
 
 
