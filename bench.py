@@ -1,19 +1,29 @@
 #!/usr/bin/env python
-"""Headline benchmark: STOMP trajectory-update iterations/sec on MI355X (BASELINE.json configs[2]).
+"""Headline benchmark: STOMP trajectory-update iterations/sec on MI355X (BASELINE.json configs[2], "C3").
 
     python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload ("C3", per GPU): panda_spheres STOMP, P=128 particles x S=32 samples = B=4096 rollouts,
-H=64 support points, D=7 (Panda FK + 31 robot collision spheres vs 16 obstacle spheres), reference
-example parameters (pos_only=False -> d=14, sigma_coll=1e-3, lr=0.1, T=1), on-device Philox noise.
-A "step" is one pass of the planner's loop body (stomp.py:157-160) over the whole batch.  Inputs are
-resident in HBM before the timed region.  N>1: every rank runs its own 128 independent start/goal
-problems (weak scaling, no data-path collective) and the final means are all-gathered over RCCL inside
-the timed region.  One JSON line is printed by rank 0.
+Main line (every N): per GPU, panda_spheres STOMP, P=128 particles x S=32 samples = B=4096 rollouts, H=64 support
+points, D=7 (Panda FK + 31 robot collision spheres vs 16 obstacle spheres), the reference example's parameters
+(pos_only=False -> d=14, sigma_coll=1e-3, lr=0.1, T=1), on-device Philox noise.  A "step" is one pass of the planner's
+loop body (stomp.py:157-160) over the whole batch; inputs are resident in HBM before the timed region.  The K steps
+are timed R times (--repeats, default 5), each block bracketed by barrier + synchronize and reduced with MAX over the
+ranks; `ms_per_step` / `value` are the MEDIAN block, min / max are reported next to it.  N > 1: every rank runs its own
+128 start/goal problems (weak scaling, no data-path collective), the final means are all-gathered over RCCL inside
+the timed region.
+
+Further entries of the same JSON line (the other BASELINE configs):
+  c5        BASELINE configs[4]'s per-GPU load: 4096 particles (131072 rollouts) per rank, same protocol, at every N
+            -- at N = 8 that is the 32768-problem job; compare c5.value across N for its weak scaling;
+  c2        pointmass_dense_2d CHOMP B=1024 (N = 1 only);
+  c4        panda_spheres GPMP2 B=2048, H=128, D=7 (N = 1 only; structured-FLOP roofline against the fp64 matrix peak,
+            CPU baseline on a small batch and extrapolated, as SURVEY 8d prescribes).
+One JSON line is printed by rank 0.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -24,7 +34,11 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# fp32 VALU issue peak: 1024 SIMDs x 2.4 GHz / 2 cycles per wave-instruction (MI355X_MICROARCH.md: v_fma_f32 wave64 =
+# 2 cycles on a SIMD-32) = 1228.8 G wave-instructions/s (x 64 lanes x 2 flop = the 157.3 TFLOP/s fp32 vector peak)
+VALU_PEAK_GINSTR = 1024 * 2.4 / 2.0
+FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X spec, v_mfma_f64_16x16x4_f64 at 64 cycles per SIMD
 
 
 def stomp_algorithmic_bytes(P, S, H, d):
@@ -33,15 +47,28 @@ def stomp_algorithmic_bytes(P, S, H, d):
     return 4 * (B * H * d + 2 * P * H * d + 2 * B)
 
 
-def cpu_baseline(wl, budget_s=12.0, max_iters=8):
-    """The oracle restatement of the reference loop (kind "port") on this host's cores, on a bounded
-    sample of the same workload: the FULL C3 batch (all P particles x S samples), as many iterations as
-    fit the time budget (at least 2 after one warm-up)."""
+def latest_profile(pattern):
+    """Newest committed profiles/<pattern> (rocprofv3 summaries are named per round), parsed, or None."""
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', pattern)))
+    if not files:
+        return None, None
+    with open(files[-1]) as fh:
+        return json.load(fh), os.path.relpath(files[-1], ROOT)
+
+
+def cpu_threads():
+    cores = min(os.cpu_count() or 1, 32)     # more intra-op threads than this only adds contention here
+    torch.set_num_threads(cores)
+    return cores
+
+
+def cpu_baseline_stomp(wl, budget_s=10.0, max_iters=8):
+    """The oracle restatement of the reference loop (kind "port") on this host's cores, on a bounded sample of the
+    same workload: the FULL C3 batch, as many iterations as fit the time budget (at least 2 after one warm-up)."""
     from oracle import planners_ref as O
     from oracle.geometry_ref import make_ref_geometry
     ta = dict(device='cpu', dtype=torch.float32)
-    cores = min(os.cpu_count() or 1, 32)     # more intra-op threads than this only adds contention here
-    torch.set_num_threads(cores)
+    cores = cpu_threads()
     prm = wl['params']
     H, S, d = prm['n_support_points'], prm['num_samples'], wl['means0'].shape[-1]
     P = wl['means0'].shape[0]
@@ -64,15 +91,213 @@ def cpu_baseline(wl, budget_s=12.0, max_iters=8):
     return times[len(times) // 2], cores, len(times)
 
 
+class Clock:
+    """R timed blocks of one callable, each bracketed by barrier + synchronize, MAX over the ranks."""
+
+    def __init__(self, dist, dev):
+        self.dist, self.dev = dist, dev
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def blocks(self, fn, repeats, before=None):
+        out = []
+        for _ in range(repeats):
+            if before is not None:
+                before()                 # untimed: every block starts from the same state
+            self.barrier()
+            t0 = time.perf_counter()
+            fn()
+            self.barrier()
+            el = time.perf_counter() - t0
+            if self.dist is not None:
+                t = torch.tensor([el], device=self.dev, dtype=torch.float64)
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+                el = float(t.item())
+            out.append(el)
+        return out
+
+
+def spread(blocks, steps):
+    b = sorted(blocks)
+    med = b[len(b) // 2]
+    return med, {'n': len(b), 'ms_per_step_median': 1e3 * med / steps, 'ms_per_step_min': 1e3 * b[0] / steps,
+                 'ms_per_step_max': 1e3 * b[-1] / steps}
+
+
+def make_stomp(P, S, dev, rank, pos_only=False):
+    from motion_planning_baselines_amd import workloads
+    from motion_planning_baselines_amd.planners.stomp import STOMP
+    from motion_planning_baselines_amd.planners.costs.cost_functions import CostCollision, CostComposite
+    wl = workloads.panda_spheres_stomp(P, dev, S=S, pos_only=pos_only, first_particle=rank * P)
+    prm = wl['params']
+    H = prm['n_support_points']
+    ta = dict(device=dev, dtype=torch.float32)
+    cost = CostComposite(wl['robot'], H, [CostCollision(wl['robot'], H, field=wl['field'],
+                                                        sigma_coll=wl['sigma_coll'], tensor_args=ta)], tensor_args=ta)
+    planner = STOMP(opt_iters=1, start_state=torch.from_numpy(wl['starts'][0]).to(dev), cost=cost,
+                    initial_particle_means=wl['means0'], tensor_args=ta, noise='philox', seed=0,
+                    particle_offset=rank * P, **prm)
+    return wl, cost, planner
+
+
+def run_stomp(planner, clock, dist, world, steps, warmup, repeats, preheat):
+    """W untimed steps, then R blocks of EXACTLY `steps` steps (one C-ABI call = 2K launches) + the final gather."""
+    gathered = [torch.empty_like(planner._particle_means) for _ in range(world)] if world > 1 else None
+    means_init = planner._particle_means.clone()
+    if preheat:   # device pre-heat (untimed set-up, not part of W or K): code objects loaded, clocks ramped
+        planner.optimize(opt_iters=preheat)
+        torch.cuda.synchronize()
+        planner._particle_means.copy_(means_init)
+    planner.optimize(opt_iters=warmup)
+    if dist is not None:                             # RCCL communicator / xGMI set-up is part of the warm-up
+        dist.all_gather(gathered, planner._particle_means)
+
+    def block():
+        planner.optimize(opt_iters=steps)
+        if dist is not None:
+            dist.all_gather(gathered, planner._particle_means)   # final gather of the (P,H,d) means over xGMI
+    blocks = clock.blocks(block, repeats, before=lambda: planner._particle_means.copy_(means_init))
+    assert torch.isfinite(planner._particle_means).all()
+    return blocks
+
+
+def bench_c2(dev, steps, with_cpu=True):
+    """BASELINE configs[1]: pointmass_dense_2d CHOMP, B=1024, H=64, D=2 (d=4): the whole loop is ONE launch."""
+    from motion_planning_baselines_amd import workloads
+    from motion_planning_baselines_amd.planners.chomp import CHOMP
+    from motion_planning_baselines_amd.planners.costs.cost_functions import CostCollision, CostComposite
+    B, H = 1024, 64
+    ta = dict(device=dev, dtype=torch.float32)
+    wl = workloads.pointmass_dense_chomp(B, dev)
+    cost = CostComposite(wl['robot'], H, [CostCollision(wl['robot'], H, field=wl['field'], sigma_coll=wl['sigma_coll'],
+                                                        tensor_args=ta)], weights_cost_l=[wl['weight']], tensor_args=ta)
+    pl = CHOMP(opt_iters=1, start_state=torch.from_numpy(wl['starts'][0]).to(dev), cost=cost,
+               initial_particle_means=wl['means0'], tensor_args=ta, **wl['params'])
+    pl.optimize(opt_iters=steps)
+    torch.cuda.synchronize()
+    blocks = []
+    for _ in range(5):
+        pl.reset(initial_particle_means=wl['means0'])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pl.optimize(opt_iters=steps)
+        torch.cuda.synchronize()
+        blocks.append(time.perf_counter() - t0)
+    med, sp = spread(blocks, steps)
+    d = wl['means0'].shape[-1]
+    alg_call = 4 * 2 * B * H * d                                   # the state is read and written once per CALL
+    out = {
+        'workload': 'pointmass_dense_2d CHOMP B=%d H=%d D=2 d=%d, %d iterations per launch' % (B, H, d, steps),
+        'metric': 'chomp_trajectory_update_iters_per_sec', 'value': steps / med, 'unit': 'iters/s',
+        'ms_per_step': 1e3 * med / steps, 'repeats': sp, 'dtype': 'f32',
+        'roofline': {'bound': 'valu/latency', 'note': 'one workgroup per particle keeps its trajectory in registers for the whole '
+                     'loop: HBM sees the state once per CALL, so the per-iteration HBM figure is not a bound',
+                     'algorithmic_bytes_per_call': alg_call, 'algorithmic_bytes_per_iter_survey': alg_call,
+                     'hbm_frac_if_streamed_every_iter': alg_call / (med / steps) / 1e9 / HBM_PEAK_GBS}}
+    if with_cpu:
+        # CPU: the oracle's autograd restatement of chomp.py:134-149 on the full batch
+        from oracle import planners_ref as O
+        from oracle.geometry_ref import make_ref_geometry
+        cores = cpu_threads()
+        cta = dict(device='cpu', dtype=torch.float32)
+        robot, field = make_ref_geometry(wl['robot'], wl['field'], cta)
+        R = O.chomp_precision(H, wl['params']['dt'], cta)
+        m = wl['means0'].cpu().clone()
+        ts = []
+        for it in range(13):
+            t0 = time.perf_counter()
+            m = O.chomp_iteration(m, R, lambda x: O.collision_cost(x, robot, field, wl['sigma_coll'], wl['weight']),
+                                  wl['params']['weight_prior_cost'], wl['params']['step_size'], wl['params']['grad_clip'])['means']
+            if it >= 3:
+                ts.append(time.perf_counter() - t0)
+        ts.sort()
+        cpu_med = ts[len(ts) // 2]
+        out['cpu_baseline'] = {'value': 1.0 / cpu_med, 'unit': 'iters/s', 'cores': cores, 'kind': 'port',
+                               'sample': 'oracle chomp_iteration (autograd restatement of chomp.py:134-149) on the full batch, '
+                                         'median of %d iterations = %.4f s' % (len(ts), cpu_med)}
+    return out
+
+
+def bench_c4(dev, steps, with_cpu=True):
+    """BASELINE configs[3]: panda_spheres GPMP2, B=2048, H=128, D=7 (fp64 block-tridiagonal solve)."""
+    from motion_planning_baselines_amd import geometry as G, workloads
+    from motion_planning_baselines_amd.planners.gpmp2 import GPMP2
+    B, H, D = 2048, 128, 7
+    ta = dict(device=dev, dtype=torch.float32)
+    robot, field = G.RobotPanda(), G.env_spheres_3d()
+    q = workloads.collision_free_configs(robot, field, 2 * B, 23, dev)
+    dt = 5.0 / H
+    means0 = workloads.straight_line_means(q[:B], q[B:], H, dt, False, dev)
+    means0[:, 0, D:] = 0
+    means0[:, -1, D:] = 0
+    sig = dict(sigma_start=1e-5, sigma_gp=1e-2, sigma_goal_prior=1e-5, sigma_coll=1e-5)
+    pl = GPMP2(robot=robot, n_dof=D, n_support_points=H, num_particles_per_goal=B, opt_iters=1, dt=dt,
+               start_state=torch.from_numpy(q[0]).to(dev), multi_goal_states=torch.from_numpy(q[B:B + 1]).to(dev),
+               initial_particle_means=means0, solver_params=dict(delta=1e-2, trust_region=True, method='cholesky'),
+               collision_fields=[field], tensor_args=ta, **sig)
+    pl.set_problem_states(torch.from_numpy(q[:B]).to(dev), torch.from_numpy(q[B:]).to(dev))
+    pl.optimize(opt_iters=3)
+    torch.cuda.synchronize()
+    blocks = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pl.optimize(opt_iters=steps)
+        torch.cuda.synchronize()
+        blocks.append(time.perf_counter() - t0)
+    med, sp = spread(blocks, steps)
+    assert torch.isfinite(pl._particle_means).all()
+    # structured flops (SURVEY 8d): per particle (H-1) block steps x (potrf 14^3/3 + trsm 14^3 + syrk/gemm 2*14^3)
+    n = 2 * D
+    flop_iter = B * (H - 1) * (n ** 3 / 3 + n ** 3 + 2 * n ** 3)
+    tflops = flop_iter / (med / steps) / 1e12
+    out = {
+        'workload': 'panda_spheres GPMP2 B=%d H=%d D=%d (N=%d unknowns per particle), trust region, fp64 solve' % (B, H, D, n * H),
+        'metric': 'gpmp2_trajectory_update_iters_per_sec', 'value': steps / med, 'unit': 'iters/s',
+        'ms_per_step': 1e3 * med / steps, 'repeats': sp, 'dtype': 'f64',
+        'roofline': {'bound': 'mfma', 'achieved': tflops, 'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': tflops / FP64_MATRIX_PEAK_TFLOPS, 'structured_flop_per_iter': flop_iter,
+                     'note': 'block-tridiagonal (14x14 blocks) elimination, sequential in t: a latency chain, not a GEMM'}}
+    if with_cpu:
+        # CPU: the oracle's DENSE restatement (gpmp2.py:308-368, :451-452) on a small batch; the dense system of the
+        # full batch needs > 150 GB (SURVEY 8d), so the figure is extrapolated linearly in B and says so
+        from oracle import planners_ref as O
+        from oracle.geometry_ref import make_ref_geometry
+        cores = cpu_threads()
+        f64 = dict(device='cpu', dtype=torch.float64)
+        rrobot, rfield = make_ref_geometry(robot, field, f64)
+        Bc = 4
+        x0 = means0[:Bc].cpu().double()
+        start = torch.cat([torch.from_numpy(q[0]).double(), torch.zeros(D, dtype=torch.float64)])
+        goal = torch.cat([torch.from_numpy(q[B]).double(), torch.zeros(D, dtype=torch.float64)])
+        ts = []
+        for it in range(3):
+            t0 = time.perf_counter()
+            O.gpmp2_iteration(x0, rrobot, rfield, start, goal, D=D, dt=dt, sigma_start=1e-5, sigma_gp=1e-2, sigma_goal=1e-5,
+                              sigma_coll=1e-5, delta=1e-2, trust_region=True, step_size=1.0, tensor_args=f64)
+            if it >= 1:
+                ts.append(time.perf_counter() - t0)
+        cpu_t = min(ts) * (B / Bc)
+        out['cpu_baseline'] = {'value': 1.0 / cpu_t, 'unit': 'iters/s', 'cores': cores, 'kind': 'port', 'extrapolated': True,
+                               'sample': 'oracle gpmp2_iteration (dense fp64 restatement) at B=%d: %.2f s per iteration, scaled x%d '
+                                         'to B=%d (the dense system of the full batch does not fit in memory)' % (Bc, min(ts), B // Bc, B)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--repeats', type=int, default=5)
     ap.add_argument('--particles', type=int, default=128)
     ap.add_argument('--samples', type=int, default=32)
     ap.add_argument('--pos-only', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true', help='main line only (profiling runs)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -93,51 +318,18 @@ def main():
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(backend)
+    clock = Clock(dist, dev)
 
-    from motion_planning_baselines_amd import ops, workloads
-    from motion_planning_baselines_amd.planners.stomp import STOMP
-    from motion_planning_baselines_amd.planners.costs.cost_functions import CostCollision, CostComposite
+    from motion_planning_baselines_amd import ops
 
     P, S = args.particles, args.samples
-    wl = workloads.panda_spheres_stomp(P, dev, S=S, pos_only=args.pos_only, first_particle=rank * P)
+    wl, cost, planner = make_stomp(P, S, dev, rank, args.pos_only)
     prm = wl['params']
     H, d, D = prm['n_support_points'], wl['means0'].shape[-1], 7
-    ta = dict(device=dev, dtype=torch.float32)
-    cost = CostComposite(wl['robot'], H, [CostCollision(wl['robot'], H, field=wl['field'],
-                                                        sigma_coll=wl['sigma_coll'], tensor_args=ta)], tensor_args=ta)
-    planner = STOMP(opt_iters=1, start_state=torch.from_numpy(wl['starts'][0]).to(dev), cost=cost,
-                    initial_particle_means=wl['means0'], tensor_args=ta, noise='philox', seed=0,
-                    particle_offset=rank * P, **prm)
-    gathered = [torch.empty_like(planner._particle_means) for _ in range(world)] if world > 1 else None
+    blocks = run_stomp(planner, clock, dist, world, args.steps, args.warmup, args.repeats, preheat=500)
+    elapsed, sp = spread(blocks, args.steps)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # device pre-heat (untimed set-up, not part of W or K): code objects loaded, clocks ramped, allocator settled
-    # before the contract's warm-up and timed steps; the particle means are restored afterwards
-    means_init = planner._particle_means.clone()
-    planner.optimize(opt_iters=500)
-    torch.cuda.synchronize()
-    planner._particle_means.copy_(means_init)
-    planner.optimize(opt_iters=args.warmup)          # W untimed steps
-    if dist is not None:                             # RCCL communicator / xGMI set-up is part of the warm-up
-        dist.all_gather(gathered, planner._particle_means)
-    barrier()
-    t0 = time.perf_counter()
-    planner.optimize(opt_iters=args.steps)           # EXACTLY K steps: one C-ABI call, 2K launches
-    if dist is not None:
-        dist.all_gather(gathered, planner._particle_means)   # final gather of the (P,H,d) means over xGMI
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    assert torch.isfinite(planner._particle_means).all()
-
-    # ---- roofline of the dominant kernel (sample+cost), measured live with events on the launch stream
+    # ---- the dominant kernel (sample + cost), measured live with events on the launch stream
     geom = cost.cost_l[0].device_geometry(dev)
     n_prof = min(args.steps, 50)
 
@@ -177,19 +369,51 @@ def main():
                                           particle_offset=rank * P)
     planner._particle_means.copy_(means_keep)
     alg_bytes_a = 4 * (P * S * H * d + P * H * d + P * S)     # kernel A: samples written + means read + costs
-    achieved = alg_bytes_a / (ka_ms * 1e-3) / 1e9
+    hbm_gbs = alg_bytes_a / (ka_ms * 1e-3) / 1e9
+    # instruction counts and HBM-side bytes of kernel A: rocprofv3 PMC passes of this same workload, committed under
+    # profiles/ (counters cannot be read from inside the process being profiled)
+    pmc, pmc_file = latest_profile('r*_pmc_kernelA.json')
+    c3_shape = P == 128 and S == 32 and not args.pos_only
+    valu_per_wave = pmc.get('SQ_INSTS_VALU_per_wave') if (pmc and c3_shape) else None
+    traffic = pmc.get('hbm_bytes_per_launch') if (pmc and c3_shape) else None
+    if valu_per_wave:
+        ginstr = valu_per_wave * (P * S) / (ka_ms * 1e-3) / 1e9
+        roof = {'bound': 'valu', 'achieved': ginstr, 'peak': VALU_PEAK_GINSTR, 'unit': 'G wave-instr/s',
+                'frac': ginstr / VALU_PEAK_GINSTR, 'valu_instructions_per_wave': valu_per_wave, 'pmc_source': pmc_file,
+                'frac_dispatch_events': valu_per_wave * (P * S) / (ka_ev_ms * 1e-3) / 1e9 / VALU_PEAK_GINSTR}
+    else:   # no committed counter summary for this shape: the nominal bound
+        roof = {'bound': 'hbm', 'achieved': hbm_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': hbm_gbs / HBM_PEAK_GBS}
+    roof.update({'kernel': 'stomp_sample_cost kernel A (d=%d)' % d, 'traffic': traffic,
+                 'hbm': {'achieved': hbm_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': hbm_gbs / HBM_PEAK_GBS,
+                         'algorithmic_bytes_per_launch': alg_bytes_a},
+                 'kernel_ms': ka_ms, 'update_kernel_ms': kb_ms, 'kernel_ms_dispatch_events': ka_ev_ms,
+                 'update_kernel_ms_dispatch_events': kb_ev_ms})
 
-    traffic = None
-    tfile = os.path.join(ROOT, 'profiles', 'r01_traffic_kernelA.json')
-    if os.path.exists(tfile) and P == 128 and S == 32 and not args.pos_only:
-        with open(tfile) as fh:
-            traffic = json.load(fh).get('hbm_bytes_per_launch')   # rocprofv3 FETCH_SIZE/WRITE_SIZE passes, see the file
+    # ---- BASELINE configs[4]'s per-GPU load with the same protocol (every N)
+    c5 = None
+    if not args.no_other_configs:
+        del planner
+        torch.cuda.empty_cache()
+        P5 = 4096
+        k5 = max(1, min(args.steps, 50))
+        wl5, cost5, pl5 = make_stomp(P5, S, dev, rank, args.pos_only)
+        b5 = run_stomp(pl5, clock, dist, world, k5, max(1, min(args.warmup, 5)), args.repeats, preheat=10)
+        el5, sp5 = spread(b5, k5)
+        c5 = {'workload': 'panda_spheres STOMP, %d particles x S=%d = %d rollouts per GPU, %d particles in the job '
+                          '(BASELINE configs[4] is this load on 8 GPUs = 32768 problems)' % (P5, S, P5 * S, world * P5),
+              'metric': 'stomp_trajectory_update_iters_per_sec', 'value': world * k5 / el5, 'unit': 'iters/s',
+              'steps': k5, 'ms_per_step': 1e3 * el5 / k5, 'repeats': sp5, 'scaling': 'weak',
+              'particle_updates_per_sec': world * P5 * k5 / el5, 'rollouts_per_sec': world * P5 * S * k5 / el5,
+              'hbm_frac': stomp_algorithmic_bytes(P5, S, H, d) * k5 / el5 / 1e9 / HBM_PEAK_GBS}
+        del pl5, cost5, wl5
+        torch.cuda.empty_cache()
+
     if rank == 0:
         its = world * args.steps / elapsed
         line = {
             'metric': 'stomp_trajectory_update_iters_per_sec',
             'value': its, 'unit': 'iters/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': 1e3 * elapsed / args.steps, 'repeats': sp, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'panda_spheres STOMP B=%d (P=%d particles x S=%d samples) H=%d D=%d d=%d per GPU'
                                    % (P * S, P, S, H, D, d),
@@ -197,21 +421,23 @@ def main():
                        'robot_collision_spheres': 31, 'collision_spheres_after_static_pruning': int(geom.host.view('int32')[5]),
                        'obstacle_spheres': 16, 'parallelism': 'particles sharded x%d' % world,
                        'algorithmic_bytes_per_iter': stomp_algorithmic_bytes(P, S, H, d)},
-            'roofline': {'bound': 'hbm', 'kernel': 'stomp_sample_cost_h64_kernel<14,true>', 'achieved': achieved,
-                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel_ms': ka_ms, 'update_kernel_ms': kb_ms, 'kernel_ms_dispatch_events': ka_ev_ms,
-                         'update_kernel_ms_dispatch_events': kb_ev_ms,
-                         'algorithmic_bytes_per_launch': alg_bytes_a},
+            'roofline': roof,
         }
-        if not args.no_cpu_baseline and world == 1:
-            med, cores, n_it = cpu_baseline(wl)
+        if c5 is not None:
+            line['c5'] = c5
+        if world == 1 and not args.no_cpu_baseline:
+            med, cores, n_it = cpu_baseline_stomp(wl)
             line['cpu_baseline'] = {
                 'value': 1.0 / med, 'unit': 'iters/s', 'cores': cores, 'kind': 'port',
                 'sample': 'oracle/planners_ref.py stomp_iteration (PyTorch-CPU restatement of stomp.py:157-160 + build-defined '
                           'FK/SDF) on the full workload (P=%d x S=%d), median of %d iterations = %.3f s, %d intra-op threads'
                           % (P, S, n_it, med, cores)}
+        if world == 1 and not args.no_other_configs:
+            line['c2'] = bench_c2(dev, 500, with_cpu=not args.no_cpu_baseline)
+            line['c4'] = bench_c4(dev, 10, with_cpu=not args.no_cpu_baseline)
         print(json.dumps(line), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -45,6 +45,13 @@ const char *mpb_last_error(void);
 
 /* Validate a packed geometry buffer held in HOST memory (n_words 32-bit words). */
 int mpb_geom_check(const float *geom_host, int n_words);
+/* Properties of a (valid) packed geometry buffer, read from its HOST copy, that let a launcher pick a kernel
+ * instantiation without touching device memory.  *flags: bits 0-7 = id of the compile-time robot model
+ * (csrc/mpb_model_*.h) every chained field is tagged with AND whose cost-only kernels can run (every field has a
+ * usable broad-phase grid); 0 = generic table-driven kernels.  Entry points that take `geom_flags` expect the value
+ * computed from the host copy of the very buffer `geom` points to (0 is always valid); a kernel re-checks the tag
+ * against the device header and writes NaN costs if they disagree. */
+int mpb_geom_flags(const float *geom_host, int n_words, int *flags);
 
 /* ---------------------------------------------------------------------------------------------
  * Collision cost  -- replaces CostCollision.eval (costs/cost_functions.py:171-189) over
@@ -152,7 +159,7 @@ int mpb_field_cost_points_vjp(const float *pts, const float *geom, const float *
  * geom + costs given, mpb_stomp_sample is exactly the first kernel of mpb_stomp_step.
  * ------------------------------------------------------------------------------------------- */
 int mpb_stomp_step(float *means, const float *eps, float *samples, float *costs, float *weights,
-                   const float *L, const float *Sigma, const float *geom,
+                   const float *L, const float *Sigma, const float *geom, int geom_flags,
                    int P, int S, int H, int d, int D,
                    float k_sigma, float weight, float lr, float temperature,
                    int n_iters, uint64_t seed, uint32_t iter0, uint32_t particle_offset, void *stream);
@@ -161,13 +168,13 @@ int mpb_stomp_step(float *means, const float *eps, float *samples, float *costs,
  * Writes the average duration in ms of the sample+cost kernel and of the update kernel, measured in the loop they
  * run in (the per-kernel figure rocprofv3 --kernel-trace --stats reports for the same loop).  Host pointers. */
 int mpb_stomp_step_profile(float *means, float *samples, float *costs, float *weights,
-                           const float *L, const float *Sigma, const float *geom,
+                           const float *L, const float *Sigma, const float *geom, int geom_flags,
                            int P, int S, int H, int d, int D,
                            float k_sigma, float weight, float lr, float temperature,
                            int n_iters, uint64_t seed, uint32_t iter0, uint32_t particle_offset, void *stream,
                            float *sample_kernel_ms, float *update_kernel_ms);
 int mpb_stomp_sample(const float *means, const float *eps, float *samples, const float *L,
-                     const float *geom, float *costs, /* both NULL: sample only; both set: fused cost */
+                     const float *geom, int geom_flags, float *costs, /* geom, costs both NULL: sample only; both set: fused cost */
                      int P, int S, int H, int d, float k_sigma, float weight,
                      uint64_t seed, uint32_t iter, uint32_t particle_offset, void *stream);
 int mpb_stomp_update(float *means, const float *samples, const float *costs, float *weights,

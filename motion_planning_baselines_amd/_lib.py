@@ -22,6 +22,7 @@ SIGNATURES = {
     'mpb_version': [],
     'mpb_last_error': [],
     'mpb_geom_check': [_p, _i],
+    'mpb_geom_flags': [_p, _i, _p],
     'mpb_cost_collision_eval': [_p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     'mpb_cost_collision_grad': [_p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     'mpb_cost_terms_eval': [_p] * 7 + [_i] * 5 + [_u32] + [_f] * 7 + [_i, _i, _p],
@@ -33,9 +34,9 @@ SIGNATURES = {
     'mpb_fk_collision_points_vjp': [_p, _p, _p, _p, _i, _i, _i, _p],
     'mpb_field_cost_points': [_p, _p, _p, _i, _i, _p],
     'mpb_field_cost_points_vjp': [_p, _p, _p, _p, _i, _i, _p],
-    'mpb_stomp_step': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _u64, _u32, _u32, _p],
-    'mpb_stomp_step_profile': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _u64, _u32, _u32, _p, _p, _p],
-    'mpb_stomp_sample': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _u64, _u32, _u32, _p],
+    'mpb_stomp_step': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _u64, _u32, _u32, _p],
+    'mpb_stomp_step_profile': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _u64, _u32, _u32, _p, _p, _p],
+    'mpb_stomp_sample': [_p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _f, _f, _u64, _u32, _u32, _p],
     'mpb_stomp_update': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     'mpb_chomp_step': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _p],
     'mpb_gpmp2_workspace_bytes': [_i, _i, _i],
@@ -93,3 +94,12 @@ def geom_check(buf):
     """Validate a packed geometry buffer (numpy fp32) on the host side of the C-ABI."""
     buf = np.ascontiguousarray(buf, dtype=np.float32)
     check(lib().mpb_geom_check(buf.ctypes.data_as(ctypes.c_void_p), int(buf.size)), 'mpb_geom_check')
+
+
+def geom_flags(buf):
+    """mpb_geom_flags of a packed geometry buffer (numpy fp32, host): what lets a launcher pick its kernel."""
+    buf = np.ascontiguousarray(buf, dtype=np.float32)
+    out = ctypes.c_int(0)
+    check(lib().mpb_geom_flags(buf.ctypes.data_as(ctypes.c_void_p), int(buf.size), ctypes.cast(ctypes.pointer(out), ctypes.c_void_p)),
+          'mpb_geom_flags')
+    return int(out.value)

@@ -48,6 +48,11 @@ def build_variant(out, extra_flags, verbose=False):
 
 
 def build(force=False, verbose=True):
+    # the compile-time robot models (csrc/mpb_model_*.h) are generated from geometry.py, the single source of the numbers
+    from . import model_gen
+    for path in model_gen.write_headers():
+        if verbose:
+            print('regenerated', path, flush=True)
     if not force and not _stale():
         return OUT
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')

@@ -19,15 +19,18 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include <utility>
+
+#include "mpb_model_panda.h"
 
 #define MPB_GEOM_MAGIC 0x4D504247
-#define MPB_GEOM_VERSION 4
+#define MPB_GEOM_VERSION 5
 #define MPB_MAX_FIELDS 4   // collision fields chained in one buffer (header word 27 = words to the next one)
 #define MPB_GEOM_HEADER_WORDS 32
 #define MPB_GRID_MAX_CELLS 4096
+#define MPB_GRID_PAD 1024        // the grid section of a buffer is padded to a multiple of this many words
 #define MPB_GRID_MAX_SPH 63      // obstacle table in LDS: 63 spheres + one far-away dummy
-#define MPB_GRID_EMPTY 0xFFFFFFFFu
-#define MPB_GRID_OVERFLOW 0xFFFFFFFEu
+#define MPB_GRID_OVERFLOW 0xFFFFFFFEu   // a cell word packs four 8-bit obstacle indices; an unused slot holds n_sph (the far dummy)
 #define MPB_KIND_POINT 0
 #define MPB_KIND_CHAIN 1
 #define MPB_MAX_DOF 8
@@ -57,6 +60,8 @@ struct GeomView {
     int gnx, gny, gnz, n_cells;
     float glx, gly, glz, gix, giy, giz;  // origin, 1 / cell size
     float fscale;                        // s_f: this field's share in  sum_f s_f * cost_f
+    int model;                           // compile-time robot model the tables equal bit for bit (0: none), mpb_model_*.h
+    unsigned keep_mask;                  // bit l: the model's collision sphere l is in the link table (static pruning)
 };
 
 // next field of the chain (the reference sums one CostCollision per field), nullptr after the last one
@@ -87,6 +92,8 @@ __device__ __forceinline__ GeomView geom_view(const float* __restrict__ g) {
     v.gix = g[23]; v.giy = g[24]; v.giz = g[25];
     v.n_cells = gi[26];
     v.fscale = g[28];
+    v.model = gi[29];
+    v.keep_mask = (unsigned)gi[30];
     return v;
 }
 
@@ -243,6 +250,18 @@ __device__ __forceinline__ void chunk_vs_obstacles(const GeomView& G, LinkChunk<
     }
 }
 
+// The chain arithmetic is written with explicit fma sequences (no `a * b + c` left for the compiler to contract as it
+// pleases): the generic table-driven walk and the compile-time robot models (below) then execute the SAME operation
+// sequence -- a model merely drops the terms whose constant factor is an exact 0 and the products by an exact 1, which
+// changes no bit -- so both return identical results.
+//   mad3: t + a x + b y + c z (three fma);  dot3: a x + b y + c z (mul, two fma)
+__device__ __forceinline__ float mad3(float a, float x, float b, float y, float c, float z, float t) {
+    return fmaf(c, z, fmaf(b, y, fmaf(a, x, t)));
+}
+__device__ __forceinline__ float dot3(float a, float x, float b, float y, float c, float z) {
+    return fmaf(c, z, fmaf(b, y, a * x));
+}
+
 // forward-kinematics state: current frame transform (+ joint axes / origins for the gradient)
 template <bool GRAD>
 struct FKState {
@@ -259,16 +278,16 @@ __device__ __forceinline__ void fk_advance(const GeomView& G, FKState<GRAD>& F, 
     const int j = F.frame;
     const float4* P = reinterpret_cast<const float4*>(G.tf + 12 * j);
     const float4 p0 = P[0], p1 = P[1], p2 = P[2];  // rows of the 3x4 constant transform
-    const float ntx = F.tx + (F.r00 * p0.w + F.r01 * p1.w + F.r02 * p2.w);
-    const float nty = F.ty + (F.r10 * p0.w + F.r11 * p1.w + F.r12 * p2.w);
-    const float ntz = F.tz + (F.r20 * p0.w + F.r21 * p1.w + F.r22 * p2.w);
+    const float ntx = mad3(F.r00, p0.w, F.r01, p1.w, F.r02, p2.w, F.tx);
+    const float nty = mad3(F.r10, p0.w, F.r11, p1.w, F.r12, p2.w, F.ty);
+    const float ntz = mad3(F.r20, p0.w, F.r21, p1.w, F.r22, p2.w, F.tz);
     F.tx = ntx; F.ty = nty; F.tz = ntz;
-    float a00 = F.r00 * p0.x + F.r01 * p1.x + F.r02 * p2.x, a01 = F.r00 * p0.y + F.r01 * p1.y + F.r02 * p2.y,
-          a02 = F.r00 * p0.z + F.r01 * p1.z + F.r02 * p2.z;
-    float a10 = F.r10 * p0.x + F.r11 * p1.x + F.r12 * p2.x, a11 = F.r10 * p0.y + F.r11 * p1.y + F.r12 * p2.y,
-          a12 = F.r10 * p0.z + F.r11 * p1.z + F.r12 * p2.z;
-    float a20 = F.r20 * p0.x + F.r21 * p1.x + F.r22 * p2.x, a21 = F.r20 * p0.y + F.r21 * p1.y + F.r22 * p2.y,
-          a22 = F.r20 * p0.z + F.r21 * p1.z + F.r22 * p2.z;
+    float a00 = dot3(F.r00, p0.x, F.r01, p1.x, F.r02, p2.x), a01 = dot3(F.r00, p0.y, F.r01, p1.y, F.r02, p2.y),
+          a02 = dot3(F.r00, p0.z, F.r01, p1.z, F.r02, p2.z);
+    float a10 = dot3(F.r10, p0.x, F.r11, p1.x, F.r12, p2.x), a11 = dot3(F.r10, p0.y, F.r11, p1.y, F.r12, p2.y),
+          a12 = dot3(F.r10, p0.z, F.r11, p1.z, F.r12, p2.z);
+    float a20 = dot3(F.r20, p0.x, F.r21, p1.x, F.r22, p2.x), a21 = dot3(F.r20, p0.y, F.r21, p1.y, F.r22, p2.y),
+          a22 = dot3(F.r20, p0.z, F.r21, p1.z, F.r22, p2.z);
     if (j < G.n_dof) {
         // select chain on the wave-uniform j (7 v_cndmask); the empty asm keeps hipcc from turning it into a
         // scratch-memory array lookup
@@ -280,9 +299,9 @@ __device__ __forceinline__ void fk_advance(const GeomView& G, FKState<GRAD>& F, 
         }
         float sn, cs;
         fast_sincos(qj, sn, cs);
-        const float n00 = a00 * cs + a01 * sn, n01 = a01 * cs - a00 * sn;
-        const float n10 = a10 * cs + a11 * sn, n11 = a11 * cs - a10 * sn;
-        const float n20 = a20 * cs + a21 * sn, n21 = a21 * cs - a20 * sn;
+        const float n00 = fmaf(a01, sn, a00 * cs), n01 = fmaf(-a00, sn, a01 * cs);
+        const float n10 = fmaf(a11, sn, a10 * cs), n11 = fmaf(-a10, sn, a11 * cs);
+        const float n20 = fmaf(a21, sn, a20 * cs), n21 = fmaf(-a20, sn, a21 * cs);
         a00 = n00; a01 = n01; a10 = n10; a11 = n11; a20 = n20; a21 = n21;
         if (GRAD) {
 #pragma unroll
@@ -401,9 +420,9 @@ __device__ __forceinline__ float waypoint_cost(const GeomView& G, const float (&
                 } else {
                     const int f = __float_as_int(lk.x);
                     while (F.frame < f) fk_advance<GRAD>(G, F, q);
-                    C.x[i] = F.tx + (F.r00 * lk.y + F.r01 * lk.z + F.r02 * lk.w);
-                    C.y[i] = F.ty + (F.r10 * lk.y + F.r11 * lk.z + F.r12 * lk.w);
-                    C.z[i] = F.tz + (F.r20 * lk.y + F.r21 * lk.z + F.r22 * lk.w);
+                    C.x[i] = mad3(F.r00, lk.y, F.r01, lk.z, F.r02, lk.w, F.tx);
+                    C.y[i] = mad3(F.r10, lk.y, F.r11, lk.z, F.r12, lk.w, F.ty);
+                    C.z[i] = mad3(F.r20, lk.y, F.r21, lk.z, F.r22, lk.w, F.tz);
                     if (GRAD) fr[i] = f;
                 }
             } else {
@@ -539,18 +558,21 @@ __device__ __forceinline__ void spheres_hinge_grid(const GeomView& G, const unsi
             }
         }
     } else {
-        for (;;) {
-            unsigned long long any = 0ull;
+        // candidate slot k of every sphere of the group at once (an unused slot holds n_sph, the far dummy of the
+        // table: no index clamp); slot 0 is evaluated unconditionally (some lane of the wave always has a candidate),
+        // the later ones only while some lane still has one
+        const unsigned none = (unsigned)G.n_sph;
 #pragma unroll
-            for (int i = 0; i < N; ++i) any |= __ballot((w[i] & 0xFFu) != 0xFFu);
-            if (any == 0ull) break;
+        for (int k = 0; k < 4; ++k) {
+            if (k > 0) {
+                unsigned long long any = 0ull;
+#pragma unroll
+                for (int i = 0; i < N; ++i) any |= __ballot(((w[i] >> (8 * k)) & 0xFFu) != none);
+                if (any == 0ull) break;
+            }
             float4 s[N];
 #pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const unsigned idx = w[i] & 0xFFu;
-                w[i] = __builtin_amdgcn_alignbit(0xFFFFFFFFu, w[i], 8);   // (w >> 8) | 0xFF000000 in one instruction
-                s[i] = otab[min(idx, (unsigned)G.n_sph)];   // 0xFF (no candidate) -> the far dummy at n_sph
-            }
+            for (int i = 0; i < N; ++i) s[i] = otab[(w[i] >> (8 * k)) & 0xFFu];
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 const float dx = x[i] - s[i].x, dy = y[i] - s[i].y, dz = z[i] - s[i].z;
@@ -611,15 +633,123 @@ __device__ __forceinline__ float waypoint_cost_grid(const GeomView& G, const uns
                 const float4 lk = lkv[i];                                              // frame, ox, oy, oz
                 const int f = __float_as_int(lk.x);
                 while (F.frame < f) fk_advance<false>(G, F, q);
-                x[i] = F.tx + (F.r00 * lk.y + F.r01 * lk.z + F.r02 * lk.w);
-                y[i] = F.ty + (F.r10 * lk.y + F.r11 * lk.z + F.r12 * lk.w);
-                z[i] = F.tz + (F.r20 * lk.y + F.r21 * lk.z + F.r22 * lk.w);
+                x[i] = mad3(F.r00, lk.y, F.r01, lk.z, F.r02, lk.w, F.tx);
+                y[i] = mad3(F.r10, lk.y, F.r11, lk.z, F.r12, lk.w, F.ty);
+                z[i] = mad3(F.r20, lk.y, F.r21, lk.z, F.r22, lk.w, F.tz);
             } else {
                 rl[i] = 0.f;
                 x[i] = y[i] = z[i] = FAR;
             }
         }
         spheres_hinge_grid<N>(G, gridw, otab, x, y, z, rl, cost);
+    }
+    return cost;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Compile-time robot model (mpb_model_*.h, generated from geometry.py): the same chain walk and the same grid lookups
+// as waypoint_cost_grid, with the joint transforms and the collision-sphere table as constexpr data -- the chain is
+// unrolled, the exact 0 / +-1 entries of the modified-DH transforms and the zero components of the sphere offsets fold
+// away, and none of it is fetched through scalar loads.  Expression by expression the arithmetic is that of fk_advance /
+// waypoint_cost_grid (a product with an exact 0 or 1 is exact), so both evaluators return the same bits; the hinges are
+// added in sphere order like there.  Only taken when the geometry buffer carries the model's id, which pack_geometry
+// sets -- and mpb_geom_check verifies against these very constants -- when the robot's tables equal the model's.
+//   keep_mask: spheres riding on frame 1 that static pruning dropped are parked (their hinge is exactly 0); a group of
+//   frame-1 spheres with no survivor is skipped.
+// ------------------------------------------------------------------------------------------------
+struct ModelFK {
+    float r00, r01, r02, r10, r11, r12, r20, r21, r22, tx, ty, tz;
+};
+
+template <class M, int J>
+__device__ __forceinline__ void model_fk_advance(ModelFK& F, const float (&q)[MPB_MAX_DOF]) {
+    constexpr float p0x = M::TF[J][0], p0y = M::TF[J][1], p0z = M::TF[J][2], p0w = M::TF[J][3];
+    constexpr float p1x = M::TF[J][4], p1y = M::TF[J][5], p1z = M::TF[J][6], p1w = M::TF[J][7];
+    constexpr float p2x = M::TF[J][8], p2y = M::TF[J][9], p2z = M::TF[J][10], p2w = M::TF[J][11];
+    const float ntx = mad3(F.r00, p0w, F.r01, p1w, F.r02, p2w, F.tx);
+    const float nty = mad3(F.r10, p0w, F.r11, p1w, F.r12, p2w, F.ty);
+    const float ntz = mad3(F.r20, p0w, F.r21, p1w, F.r22, p2w, F.tz);
+    F.tx = ntx; F.ty = nty; F.tz = ntz;
+    float a00 = dot3(F.r00, p0x, F.r01, p1x, F.r02, p2x), a01 = dot3(F.r00, p0y, F.r01, p1y, F.r02, p2y),
+          a02 = dot3(F.r00, p0z, F.r01, p1z, F.r02, p2z);
+    float a10 = dot3(F.r10, p0x, F.r11, p1x, F.r12, p2x), a11 = dot3(F.r10, p0y, F.r11, p1y, F.r12, p2y),
+          a12 = dot3(F.r10, p0z, F.r11, p1z, F.r12, p2z);
+    float a20 = dot3(F.r20, p0x, F.r21, p1x, F.r22, p2x), a21 = dot3(F.r20, p0y, F.r21, p1y, F.r22, p2y),
+          a22 = dot3(F.r20, p0z, F.r21, p1z, F.r22, p2z);
+    if constexpr (J < M::N_DOF) {
+        float sn, cs;
+        fast_sincos(q[J], sn, cs);
+        const float n00 = fmaf(a01, sn, a00 * cs), n01 = fmaf(-a00, sn, a01 * cs);
+        const float n10 = fmaf(a11, sn, a10 * cs), n11 = fmaf(-a10, sn, a11 * cs);
+        const float n20 = fmaf(a21, sn, a20 * cs), n21 = fmaf(-a20, sn, a21 * cs);
+        a00 = n00; a01 = n01; a10 = n10; a11 = n11; a20 = n20; a21 = n21;
+    }
+    F.r00 = a00; F.r01 = a01; F.r02 = a02; F.r10 = a10; F.r11 = a11; F.r12 = a12;
+    F.r20 = a20; F.r21 = a21; F.r22 = a22;
+}
+
+// positions of the (up to four) collision spheres of group GRP, advancing the chain as far as they need.  Groups:
+// the spheres on frame 1 first (the only ones static pruning can drop), then the rest, four at a time.
+template <class M, int GRP>
+__device__ __forceinline__ bool model_group_positions(ModelFK& F, const float (&q)[MPB_MAX_DOF], unsigned keep,
+                                                      float (&x)[4], float (&y)[4], float (&z)[4], float (&rl)[4]) {
+    constexpr float FAR = 1.0e9f;   // parked slot: outside the grid, no candidates
+    constexpr int G1 = (M::N_FRAME1 + 3) / 4;
+    constexpr bool first = GRP < G1;
+    constexpr int lo = first ? 4 * GRP : M::N_FRAME1 + 4 * (GRP - G1);
+    constexpr int part_end = first ? M::N_FRAME1 : M::N_LINKS;
+    constexpr int hi = (lo + 4 < part_end) ? lo + 4 : part_end;
+    static_for<lo, hi>([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        constexpr int f = M::LINK_FRAME[l];
+        constexpr int fprev = (l == 0) ? 0 : M::LINK_FRAME[l > 0 ? l - 1 : 0];
+        static_for<fprev, f>([&](auto jc) { model_fk_advance<M, decltype(jc)::value>(F, q); });
+        constexpr int slot = l - lo;
+        constexpr float ox = M::LINK[l][0], oy = M::LINK[l][1], oz = M::LINK[l][2], rad = M::LINK[l][3];
+        const float px = mad3(F.r00, ox, F.r01, oy, F.r02, oz, F.tx);
+        const float py = mad3(F.r10, ox, F.r11, oy, F.r12, oz, F.ty);
+        const float pz = mad3(F.r20, ox, F.r21, oy, F.r22, oz, F.tz);
+        if constexpr (first) {
+            const bool on = (keep >> l) & 1u;                // wave-uniform
+            x[slot] = on ? px : FAR; y[slot] = on ? py : FAR; z[slot] = on ? pz : FAR; rl[slot] = on ? rad : 0.f;
+        } else {
+            x[slot] = px; y[slot] = py; z[slot] = pz; rl[slot] = rad;
+        }
+    });
+#pragma unroll
+    for (int i = hi - lo; i < 4; ++i) { x[i] = y[i] = z[i] = FAR; rl[i] = 0.f; }
+    if constexpr (first) {
+        constexpr unsigned gmask = ((hi >= 32) ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+        return (keep & gmask) != 0u;                         // a frame-1 group with no survivor is skipped
+    }
+    return true;
+}
+
+template <class M, int... GRPS>
+__device__ __forceinline__ bool model_group_dispatch(int grp, ModelFK& F, const float (&q)[MPB_MAX_DOF], unsigned keep,
+                                                     float (&x)[4], float (&y)[4], float (&z)[4], float (&rl)[4],
+                                                     std::integer_sequence<int, GRPS...>) {
+    bool run = false;
+    // one arm per group, selected by the wave-uniform group counter (scalar compares / branches)
+    ((grp == GRPS ? (void)(run = model_group_positions<M, GRPS>(F, q, keep, x, y, z, rl)) : (void)0), ...);
+    return run;
+}
+
+template <class M>
+__device__ __forceinline__ float waypoint_cost_grid_model(const GeomView& G, const unsigned* gridw, const float4* otab,
+                                                          const float (&q)[MPB_MAX_DOF]) {
+    constexpr int NG = (M::N_FRAME1 + 3) / 4 + (M::N_LINKS - M::N_FRAME1 + 3) / 4;
+    ModelFK F;
+    F.r00 = 1.f; F.r01 = 0.f; F.r02 = 0.f; F.r10 = 0.f; F.r11 = 1.f; F.r12 = 0.f; F.r20 = 0.f; F.r21 = 0.f; F.r22 = 1.f;
+    F.tx = F.ty = F.tz = 0.f;
+    float cost = 0.f;
+    const unsigned keep = G.keep_mask;
+    // a real loop over the groups with ONE instance of the grid look-up (unrolling it per group is 60 KB of code)
+#pragma nounroll
+    for (int grp = 0; grp < NG; ++grp) {
+        float x[4], y[4], z[4], rl[4];
+        const bool run = model_group_dispatch<M>(grp, F, q, keep, x, y, z, rl, std::make_integer_sequence<int, NG>{});
+        if (run) spheres_hinge_grid<4>(G, gridw, otab, x, y, z, rl, cost);
     }
     return cost;
 }
@@ -665,18 +795,18 @@ __device__ __forceinline__ void spheres_nearest_grid(const GeomView& G, const un
             for (int i = 0; i < N; ++i) visit(i, s);
         }
     } else {
-        for (;;) {
-            unsigned long long any = 0ull;
+        const unsigned none = (unsigned)G.n_sph;      // unused candidate slot: the far dummy of the table
 #pragma unroll
-            for (int i = 0; i < N; ++i) any |= __ballot((w[i] & 0xFFu) != 0xFFu);
-            if (any == 0ull) break;
+        for (int k = 0; k < 4; ++k) {
+            if (k > 0) {
+                unsigned long long any = 0ull;
+#pragma unroll
+                for (int i = 0; i < N; ++i) any |= __ballot(((w[i] >> (8 * k)) & 0xFFu) != none);
+                if (any == 0ull) break;
+            }
             float4 s[N];
 #pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const unsigned idx = w[i] & 0xFFu;
-                w[i] = __builtin_amdgcn_alignbit(0xFFFFFFFFu, w[i], 8);   // (w >> 8) | 0xFF000000 in one instruction
-                s[i] = otab[min(idx, (unsigned)G.n_sph)];   // 0xFF (no candidate) -> the far dummy at n_sph
-            }
+            for (int i = 0; i < N; ++i) s[i] = otab[(w[i] >> (8 * k)) & 0xFFu];
 #pragma unroll
             for (int i = 0; i < N; ++i) visit(i, s[i]);
         }
@@ -757,9 +887,9 @@ __device__ __forceinline__ float waypoint_cost_grid_grad(const GeomView& G, cons
                 const float4 lk = lkv[i];
                 const int f = __float_as_int(lk.x);
                 while (F.frame < f) fk_advance<true>(G, F, q);
-                x[i] = F.tx + (F.r00 * lk.y + F.r01 * lk.z + F.r02 * lk.w);
-                y[i] = F.ty + (F.r10 * lk.y + F.r11 * lk.z + F.r12 * lk.w);
-                z[i] = F.tz + (F.r20 * lk.y + F.r21 * lk.z + F.r22 * lk.w);
+                x[i] = mad3(F.r00, lk.y, F.r01, lk.z, F.r02, lk.w, F.tx);
+                y[i] = mad3(F.r10, lk.y, F.r11, lk.z, F.r12, lk.w, F.ty);
+                z[i] = mad3(F.r20, lk.y, F.r21, lk.z, F.r22, lk.w, F.tz);
                 fr[i] = f;
             } else {
                 rl[i] = 0.f;

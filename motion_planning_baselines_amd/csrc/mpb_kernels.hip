@@ -42,6 +42,38 @@ static int check_launch(const char* what) {
 extern "C" int mpb_version(void) { return 1; }
 extern "C" const char* mpb_last_error(void) { return g_err; }
 
+// A buffer tagged with a compile-time robot model (header word 29) must carry exactly that model's tables: the joint
+// transforms bit for bit, and as link table the model's collision spheres selected by the keep mask (word 30), of
+// which only spheres on frame 1 may be missing.  The model kernels never read these tables -- they trust the tag.
+template <class M>
+static int model_check_as(const float* g, const char* who) {
+    const int32_t* gi = reinterpret_cast<const int32_t*>(g);
+    const uint32_t keep = (uint32_t)gi[30];
+    if (gi[2] != MPB_KIND_CHAIN || gi[3] != M::N_DOF || gi[4] != M::N_TF) return fail(MPB_E_INVALID, "%s: model tag does not match the robot", who);
+    if (memcmp(g + gi[9], M::TF, sizeof(float) * 12 * M::N_TF) != 0) return fail(MPB_E_INVALID, "%s: joint transforms differ from the tagged model", who);
+    int n = 0;
+    for (int l = 0; l < M::N_LINKS; ++l) {
+        if (!((keep >> l) & 1u)) {
+            if (M::LINK_FRAME[l] != 1) return fail(MPB_E_INVALID, "%s: only frame-1 spheres of a model may be pruned", who);
+            continue;
+        }
+        if (n >= gi[5]) return fail(MPB_E_INVALID, "%s: keep mask and link table disagree", who);
+        const float* lk = g + gi[10] + 8 * n;
+        if (reinterpret_cast<const int32_t*>(lk)[0] != M::LINK_FRAME[l] || memcmp(lk + 1, M::LINK[l], 4 * sizeof(float)) != 0)
+            return fail(MPB_E_INVALID, "%s: link table differs from the tagged model", who);
+        ++n;
+    }
+    if (n != gi[5] || (M::N_LINKS < 32 && (keep >> M::N_LINKS) != 0u)) return fail(MPB_E_INVALID, "%s: keep mask and link table disagree", who);
+    return MPB_OK;
+}
+
+static int model_check(const float* g, const char* who) {
+    const int model = reinterpret_cast<const int32_t*>(g)[29];
+    if (model == 0) return MPB_OK;
+    if (model == PandaModel::ID) return model_check_as<PandaModel>(g, who);
+    return fail(MPB_E_INVALID, "%s: unknown robot model id", who);
+}
+
 static int geom_check_one(const float* g, int n_words, const char* who) {
     if (!g || n_words < MPB_GEOM_HEADER_WORDS) return fail(MPB_E_INVALID, "%s: geometry buffer too small", who);
     const int32_t* gi = reinterpret_cast<const int32_t*>(g);
@@ -60,7 +92,7 @@ static int geom_check_one(const float* g, int n_words, const char* who) {
     const int n_fs = (n_frames + 1 + 3) / 4 * 4;
     if (off_tf != MPB_GEOM_HEADER_WORDS || off_links != off_tf + 12 * n_tf || off_sph != off_links + 8 * n_links ||
         off_box != off_sph + 4 * n_sph || off_cull != off_box + 8 * n_box || off_fs != off_cull + 8 * n_sph_pad ||
-        off_grid != off_fs + n_fs || total != off_grid + (n_cells + 3) / 4 * 4 || total > n_words)
+        off_grid != off_fs + n_fs || total != off_grid + (n_cells + MPB_GRID_PAD - 1) / MPB_GRID_PAD * MPB_GRID_PAD || total > n_words)
         return fail(MPB_E_INVALID, "%s: inconsistent section offsets", who);
     if ((off_links | off_sph | off_box | off_cull | off_fs | off_grid) & 3) return fail(MPB_E_INVALID, "%s: sections must be 16-byte aligned", who);
     if (n_cells < 0 || (n_cells > 0 && (gnx < 1 || gny < 1 || gnz < 1 || gnx * gny * gnz != n_cells)))
@@ -69,8 +101,8 @@ static int geom_check_one(const float* g, int n_words, const char* who) {
         const uint32_t w = (uint32_t)gi[off_grid + i];
         if (w == 0xFFFFFFFEu) continue;
         for (int k = 0; k < 4; ++k) {
-            const uint32_t idx = (w >> (8 * k)) & 0xFFu;
-            if (idx != 0xFFu && (int)idx >= n_sph) return fail(MPB_E_INVALID, "%s: grid cell references a missing obstacle", who);
+            const uint32_t idx = (w >> (8 * k)) & 0xFFu;      // n_sph = unused slot (the far dummy the kernels append)
+            if ((int)idx > n_sph) return fail(MPB_E_INVALID, "%s: grid cell references a missing obstacle", who);
         }
     }
     // frame -> link ranges must be monotone and end at n_links
@@ -85,7 +117,7 @@ static int geom_check_one(const float* g, int n_words, const char* who) {
         prev = f > prev ? f : prev;
     }
     if (!(g[28] >= 0.f)) return fail(MPB_E_INVALID, "%s: field scale must be >= 0", who);
-    return MPB_OK;
+    return model_check(g, who);
 }
 
 
@@ -105,6 +137,24 @@ extern "C" int mpb_geom_check(const float* g, int n_words) {
         off += next;
     }
     return fail(MPB_E_INVALID, "%s: more than MPB_MAX_FIELDS chained fields", __func__);
+}
+
+extern "C" int mpb_geom_flags(const float* g, int n_words, int* flags) {
+    if (!flags) return fail(MPB_E_INVALID, "%s: null pointer", __func__);
+    *flags = 0;
+    const int rc = mpb_geom_check(g, n_words);
+    if (rc) return rc;
+    int model = -1;
+    for (int off = 0;;) {
+        const int32_t* gi = reinterpret_cast<const int32_t*>(g + off);
+        const bool grid_ok = gi[26] > 0 && gi[26] <= MPB_GRID_MAX_CELLS && gi[6] <= MPB_GRID_MAX_SPH;   // grid_usable()
+        const int m = grid_ok ? gi[29] : 0;
+        model = (model < 0 || model == m) ? m : 0;
+        if (gi[27] == 0) break;
+        off += gi[27];
+    }
+    *flags = model > 0 ? (model & 0xFF) : 0;
+    return MPB_OK;
 }
 
 #define MPB_MAX_D (2 * MPB_MAX_DOF)
@@ -164,24 +214,57 @@ __device__ __forceinline__ void stomp_eps4(uint32_t p_global, uint32_t s, uint32
 #define MPB_A_WPB 4      // waves (rollouts) per block of the H = 64 kernel.  Measured at C3 / P = 4096: 2 waves 42 / 878 us (the
                          // L and grid staging is per block), 4 waves 30.0 / 638, 8 waves 29.6 / 670, 16 waves 30.0 / 779
 #endif
-template <int DCH, bool WITH_COST>
+// LDS of one block: the permuted L image (16 KB), which is dead once the noise product is done and then holds the
+// per-wave transpose / pack tiles (5 KB per wave), and -- in a region of its own, so that it is staged at kernel entry
+// together with L instead of in a serial phase between two more barriers -- the broad-phase grid + obstacle table of
+// the (first) collision field.  37 KB per block: four blocks (16 waves) per CU, the whole C3 batch in one round.
+#define MPB_A_TILE_FLOATS (64 * NT_STRIDE * (MPB_A_WPB > 4 ? MPB_A_WPB : 4))
+#define MPB_A_GRID_ROUNDS (MPB_GRID_MAX_CELLS / 4 / (64 * MPB_A_WPB))   // uint4 per thread for the largest grid
+// MODEL: 0 = generic table-driven chain walk (any robot, grid or exhaustive obstacle loop per field); > 0 = the
+// compile-time robot model of that id (mpb_model_*.h) -- separate instantiations, because the register allocation of
+// one kernel holding all three evaluators spills.
+template <int DCH, bool WITH_COST, int MODEL>
 __global__ __launch_bounds__(64 * MPB_A_WPB, 16 / MPB_A_WPB) void stomp_sample_cost_h64_kernel(
     const float* __restrict__ means, const float* __restrict__ eps, float* __restrict__ samples,
     float* __restrict__ costs, const float* __restrict__ Lmat, const float* __restrict__ geom,
     int P, int S, float k_sigma, float weight, uint32_t seed_lo, uint32_t seed_hi, uint32_t iter,
     uint32_t particle_offset) {
     constexpr int H = 64;
+    constexpr int NTHR = 64 * MPB_A_WPB;
     MPB_STAMP(0);
-    __shared__ __attribute__((aligned(16))) float Lp[H * H];             // permuted L, 16 KB
-    __shared__ __attribute__((aligned(16))) float Nt[MPB_A_WPB][H * NT_STRIDE];  // per-wave noise tile, 5 KB each
-    __shared__ float4 otab[MPB_GRID_MAX_SPH + 1];                        // obstacle table of the broad phase
-    // L is read here (coalesced float4s, kept in registers) and written to LDS only after the noise has been drawn: the
-    // Philox + Box-Muller phase below needs neither L nor LDS, so the load latency (every block of the launch hits L2
-    // at the same moment) hides behind it
-    constexpr int L_PER_THREAD = H * H / 4 / (64 * MPB_A_WPB);
+    __shared__ __attribute__((aligned(16))) float Lp[MPB_A_TILE_FLOATS];  // permuted L (first 16 KB), then the wave tiles
+    __shared__ __attribute__((aligned(16))) unsigned gridw[WITH_COST ? MPB_GRID_MAX_CELLS : 4];   // broad-phase grid of the first field
+    __shared__ float4 otab[MPB_GRID_MAX_SPH + 1];                         // its obstacle table
+    // L and the grid are read here (coalesced, kept in registers) and written to LDS only after the noise has been
+    // drawn: the Philox + Box-Muller phase below needs neither, so the load latency (every block of the launch hits
+    // L2 at the same moment) hides behind it
+    constexpr int L_PER_THREAD = H * H / 4 / NTHR;
     f32x4 lreg[L_PER_THREAD];
 #pragma unroll
-    for (int u = 0; u < L_PER_THREAD; ++u) lreg[u] = reinterpret_cast<const f32x4*>(Lmat)[threadIdx.x + 64 * MPB_A_WPB * u];
+    for (int u = 0; u < L_PER_THREAD; ++u) lreg[u] = reinterpret_cast<const f32x4*>(Lmat)[threadIdx.x + NTHR * u];
+    static_assert(MPB_GRID_PAD % (4 * 64 * MPB_A_WPB) == 0, "the grid section is padded to whole rounds of the block's 16-byte loads");
+    float4 oreg = make_float4(-1.0e9f, -1.0e9f, -1.0e9f, 0.f);
+    bool grid0 = false;
+    int g_nsph = 0;
+    if (WITH_COST) {
+        const GeomView G0 = geom_view(geom);
+        grid0 = grid_usable(G0);
+        if (grid0) {
+            // the grid goes global -> LDS directly (global_load_lds_dwordx4: no VGPRs, no ds_write; LDS address = wave-uniform
+            // base + 16 * lane, i.e. a straight copy); the section is padded to whole rounds (MPB_GRID_PAD words): no tail.
+            // The loads are in flight during the Philox phase; the barrier behind the L image drains them (vmcnt(0)).
+            const int g_rounds = (G0.n_cells + 4 * NTHR - 1) / (4 * NTHR);
+            g_nsph = G0.n_sph;
+            const uint4* g4 = reinterpret_cast<const uint4*>(G0.grid);
+#pragma unroll
+            for (int u = 0; u < MPB_A_GRID_ROUNDS; ++u)
+                if (u < g_rounds)
+                    __builtin_amdgcn_global_load_lds(g4 + threadIdx.x + NTHR * u,
+                                                     (__attribute__((address_space(3))) unsigned*)(gridw + 4 * (NTHR * u + (threadIdx.x & ~63u))),
+                                                     16, 0, 0);
+            if ((int)threadIdx.x < g_nsph) oreg = reinterpret_cast<const float4*>(G0.sph)[threadIdx.x];
+        }
+    }
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     // XCD-aware block -> rollout map (speed only, any map is correct): workgroups are dealt round-robin
@@ -222,7 +305,7 @@ __global__ __launch_bounds__(64 * MPB_A_WPB, 16 / MPB_A_WPB) void stomp_sample_c
     // Lp[(((m*4 + ks4)*4 + g)*16 + i)*4 + kk] = L[16m+i][4*(4*ks4+kk) + g] (scattered LDS writes)
 #pragma unroll
     for (int u = 0; u < L_PER_THREAD; ++u) {
-        const int v4 = threadIdx.x + 64 * MPB_A_WPB * u;
+        const int v4 = threadIdx.x + NTHR * u;
         const int row = v4 >> 4, col0 = (v4 & 15) << 2;
         const int m = row >> 4, i = row & 15;
 #pragma unroll
@@ -231,28 +314,35 @@ __global__ __launch_bounds__(64 * MPB_A_WPB, 16 / MPB_A_WPB) void stomp_sample_c
             Lp[((((m * 4 + (ks >> 2)) * 4 + gq) * 16 + i) << 2) + (ks & 3)] = lreg[u][e4];
         }
     }
+    if (WITH_COST && grid0 && (int)threadIdx.x <= g_nsph && threadIdx.x <= MPB_GRID_MAX_SPH)
+        otab[threadIdx.x] = oreg;                                                            // entry n_sph: the far dummy
     __syncthreads();
     // ---- N = L * eps on the matrix cores
     const f32x4* Lp4 = reinterpret_cast<const f32x4*>(Lp);
-    float* nt = Nt[wave];
+    f32x4 acc[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks4 = 0; ks4 <= m; ++ks4) {
             const f32x4 a = Lp4[((m * 4 + ks4) * 4 + g) * 16 + j];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], e[4 * ks4 + 0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], e[4 * ks4 + 1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], e[4 * ks4 + 2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], e[4 * ks4 + 3], acc, 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], e[4 * ks4 + 0], acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], e[4 * ks4 + 1], acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], e[4 * ks4 + 2], acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], e[4 * ks4 + 3], acc[m], 0, 0, 0);
         }
-        // D[row = 4g + rr][col = j] -> noise tile [waypoint][channel]
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) nt[(16 * m + 4 * g + rr) * NT_STRIDE + j] = acc[rr];
     }
     MPB_STAMP(3);
-    __syncthreads();  // tile written by lane = channel, read by lane = waypoint
+    __syncthreads();  // every wave has read its A operands: the L image is dead, its space becomes the wave tiles
     MPB_STAMP(4);
+    float* nt = Lp + wave * (H * NT_STRIDE);
+    // D[row = 4g + rr][col = j] -> noise tile [waypoint][channel]; written by lane = channel and read back by lane =
+    // waypoint of the SAME wave (LDS operations of a wave complete in order: no barrier)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) nt[(16 * m + 4 * g + rr) * NT_STRIDE + j] = acc[m][rr];
+    __builtin_amdgcn_wave_barrier();
     // ---- lane = waypoint h
     const int h = lane;
     float nz[16];
@@ -264,9 +354,9 @@ __global__ __launch_bounds__(64 * MPB_A_WPB, 16 / MPB_A_WPB) void stomp_sample_c
             nz[4 * v + 0] = t[0]; nz[4 * v + 1] = t[1]; nz[4 * v + 2] = t[2]; nz[4 * v + 3] = t[3];
         }
     }
+    __builtin_amdgcn_wave_barrier();
     const bool edge = (h == 0) || (h == H - 1);
     const float* mrow = means + ((size_t)p * H + h) * DCH;
-    float* srow = samples + (((size_t)p * S + s) * H + h) * DCH;
     float x[DCH];
     if (DCH % 2 == 0) {
 #pragma unroll
@@ -285,6 +375,7 @@ __global__ __launch_bounds__(64 * MPB_A_WPB, 16 / MPB_A_WPB) void stomp_sample_c
         float* pk = nt;
 #pragma unroll
         for (int c = 0; c < DCH; ++c) pk[h * DCH + c] = x[c];
+        __builtin_amdgcn_wave_barrier();
         const f32x4* pk4 = reinterpret_cast<const f32x4*>(pk);
         f32x4* out4 = reinterpret_cast<f32x4*>(samples + ((size_t)p * S + s) * H * DCH);
 #pragma unroll
@@ -293,31 +384,45 @@ __global__ __launch_bounds__(64 * MPB_A_WPB, 16 / MPB_A_WPB) void stomp_sample_c
             if (idx < 16 * DCH && live) out4[idx] = pk4[idx];
         }
     }
-    (void)srow;
     MPB_STAMP(5);
     if (WITH_COST) {
         float q[MPB_MAX_DOF], dq[MPB_MAX_DOF];
 #pragma unroll
         for (int i = 0; i < MPB_MAX_DOF; ++i) q[i] = (i < DCH) ? x[i < DCH ? i : 0] : 0.f;
         float c = 0.f;
-        // one pass per chained collision field (the reference sums one CostCollision per field)
+        bool bad = false;   // geom_flags and the device header disagree: the cost is poisoned (NaN bits), never mis-read
+        // one pass per chained collision field (the reference sums one CostCollision per field); the first field's
+        // grid is already in LDS, a later field's replaces it (all waves of the block take the same branches: G is
+        // block-uniform)
         for (const float* gp = geom; gp != nullptr; gp = geom_next(gp)) {
             const GeomView G = geom_view(gp);
             if (grid_usable(G)) {
-                // the permuted-L image is dead: its 16 KB now hold the broad-phase grid (all waves of the block
-                // take this branch together: G is wave- and block-uniform)
-                unsigned* gridw = reinterpret_cast<unsigned*>(Lp);
-                __syncthreads();
-                grid_stage(G, gridw, otab, threadIdx.x, 64 * MPB_A_WPB);
-                __syncthreads();
+                if (gp != geom) {
+                    __syncthreads();
+                    grid_stage(G, gridw, otab, threadIdx.x, NTHR);
+                    __syncthreads();
+                }
                 MPB_STAMP(6);
-                if (live && h >= 1) c = fmaf(G.fscale, waypoint_cost_grid(G, gridw, otab, q), c);
+                if (live && h >= 1) {
+                    if (MODEL == PandaModel::ID) {
+                        // the launcher picked this instantiation from the caller's geom_flags; the device header has the
+                        // last word: a buffer that is not tagged with the model poisons the cost instead of being mis-read
+                        if (G.model == PandaModel::ID) c = fmaf(G.fscale, waypoint_cost_grid_model<PandaModel>(G, gridw, otab, q), c);
+                        else bad = true;
+                    } else {
+                        c = fmaf(G.fscale, waypoint_cost_grid(G, gridw, otab, q), c);
+                    }
+                }
             } else if (live && h >= 1) {
-                c = fmaf(G.fscale, waypoint_cost<false>(G, q, dq), c);
+                if (MODEL != 0) bad = true;                  // model instantiations are only launched for grid-backed fields
+                else c = fmaf(G.fscale, waypoint_cost<false>(G, q, dq), c);
             }
         }
         const double csum = wave_sum_f64((double)c);
-        if (live && lane == 0) costs[r] = weight * (k_sigma * (float)csum);
+        if (live && lane == 0) {
+            if (bad) reinterpret_cast<unsigned*>(costs)[r] = 0x7FC00000u;   // (the build is -ffinite-math-only: no NaN arithmetic)
+            else costs[r] = weight * (k_sigma * (float)csum);
+        }
     }
     MPB_STAMP(7);
 }
@@ -788,20 +893,26 @@ static bool launch_update(float* means, const float* samples, const float* costs
 // kernel A launcher: H = 64 takes the MFMA fast path for the channel counts of the reference's robots
 template <bool WITH_COST>
 static void launch_sample(const float* means, const float* eps, float* samples, float* costs, const float* L,
-                          const float* geom, int P, int S, int H, int d, float k_sigma, float weight, uint64_t seed,
-                          uint32_t iter, uint32_t particle_offset, hipStream_t st) {
+                          const float* geom, int geom_flags, int P, int S, int H, int d, float k_sigma, float weight,
+                          uint64_t seed, uint32_t iter, uint32_t particle_offset, hipStream_t st) {
     const int B = P * S;
     const dim3 grid((B + 3) / 4), block(256);
     const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
-#define MPB_A_CASE(DCH)                                                                                          \
+#define MPB_A_CASE(DCH, MODEL)                                                                                   \
     case DCH:                                                                                                    \
-        MPB_LAUNCH((stomp_sample_cost_h64_kernel<DCH, WITH_COST>), dim3((B + MPB_A_WPB - 1) / MPB_A_WPB),  \
+        MPB_LAUNCH((stomp_sample_cost_h64_kernel<DCH, WITH_COST, MODEL>), dim3((B + MPB_A_WPB - 1) / MPB_A_WPB),  \
                            dim3(64 * MPB_A_WPB), 0, st, means, eps, samples, costs, L, geom, P, S, k_sigma, weight, \
                            lo, hi, iter, particle_offset);                                                       \
         return;
+    if (H == 64 && WITH_COST && (geom_flags & 0xFF) == PandaModel::ID) {   // the Panda's channel counts (pos_only / not)
+        switch (d) {
+            MPB_A_CASE(7, (WITH_COST ? PandaModel::ID : 0)) MPB_A_CASE(14, (WITH_COST ? PandaModel::ID : 0))
+            default: break;
+        }
+    }
     if (H == 64) {
         switch (d) {
-            MPB_A_CASE(2) MPB_A_CASE(3) MPB_A_CASE(4) MPB_A_CASE(6) MPB_A_CASE(7) MPB_A_CASE(14)
+            MPB_A_CASE(2, 0) MPB_A_CASE(3, 0) MPB_A_CASE(4, 0) MPB_A_CASE(6, 0) MPB_A_CASE(7, 0) MPB_A_CASE(14, 0)
             default: break;
         }
     }
@@ -845,7 +956,7 @@ extern "C" int mpb_cost_collision_grad(const float* trajs, const float* geom, fl
 }
 
 extern "C" int mpb_stomp_sample(const float* means, const float* eps, float* samples, const float* L,
-                                const float* geom, float* costs, int P, int S, int H, int d, float k_sigma,
+                                const float* geom, int geom_flags, float* costs, int P, int S, int H, int d, float k_sigma,
                                 float weight, uint64_t seed, uint32_t iter, uint32_t particle_offset, void* stream) {
     if (P == 0) return MPB_OK;
     if (!means || !samples || !L) return fail(MPB_E_INVALID, "%s: null pointer", __func__);
@@ -853,10 +964,10 @@ extern "C" int mpb_stomp_sample(const float* means, const float* eps, float* sam
     if (P < 0 || S < 1 || H < 3 || H > MPB_MAX_H || d < 1 || d > MPB_MAX_D) return fail(MPB_E_INVALID, "%s: bad shape", __func__);
     if (P == 0) return MPB_OK;
     if (geom)
-        launch_sample<true>(means, eps, samples, costs, L, geom, P, S, H, d, k_sigma, weight, seed, iter,
+        launch_sample<true>(means, eps, samples, costs, L, geom, geom_flags, P, S, H, d, k_sigma, weight, seed, iter,
                             particle_offset, (hipStream_t)stream);
     else
-        launch_sample<false>(means, eps, samples, nullptr, L, nullptr, P, S, H, d, 0.f, 0.f, seed, iter,
+        launch_sample<false>(means, eps, samples, nullptr, L, nullptr, 0, P, S, H, d, 0.f, 0.f, seed, iter,
                              particle_offset, (hipStream_t)stream);
     return check_launch(__func__);
 }
@@ -875,7 +986,7 @@ extern "C" int mpb_stomp_update(float* means, const float* samples, const float*
 }
 
 extern "C" int mpb_stomp_step(float* means, const float* eps, float* samples, float* costs, float* weights,
-                              const float* L, const float* Sigma, const float* geom, int P, int S, int H, int d, int D,
+                              const float* L, const float* Sigma, const float* geom, int geom_flags, int P, int S, int H, int d, int D,
                               float k_sigma, float weight, float lr, float temperature, int n_iters, uint64_t seed,
                               uint32_t iter0, uint32_t particle_offset, void* stream) {
     if (P == 0) return MPB_OK;
@@ -902,7 +1013,7 @@ extern "C" int mpb_stomp_step(float* means, const float* eps, float* samples, fl
             if (ev[k]) (void)hipEventSynchronize(ev[k]);                 // chunk it/MPB_CHUNK - 2 has finished
             else (void)hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
         }
-        launch_sample<true>(means, eps ? eps + (size_t)it * eps_stride : nullptr, samples, costs, L, geom, P, S, H, d,
+        launch_sample<true>(means, eps ? eps + (size_t)it * eps_stride : nullptr, samples, costs, L, geom, geom_flags, P, S, H, d,
                             k_sigma, weight, seed, iter0 + (uint32_t)it, particle_offset, (hipStream_t)stream);
         launch_update(means, samples, costs, weights, Sigma, P, S, H, d, lr, temperature, (hipStream_t)stream);
         if (throttle && it % MPB_CHUNK == MPB_CHUNK - 1) (void)hipEventRecord(ev[(it / MPB_CHUNK) & 1], (hipStream_t)stream);
@@ -913,7 +1024,7 @@ extern "C" int mpb_stomp_step(float* means, const float* eps, float* samples, fl
 }
 
 extern "C" int mpb_stomp_step_profile(float* means, float* samples, float* costs, float* weights, const float* L,
-                                      const float* Sigma, const float* geom, int P, int S, int H, int d, int D,
+                                      const float* Sigma, const float* geom, int geom_flags, int P, int S, int H, int d, int D,
                                       float k_sigma, float weight, float lr, float temperature, int n_iters, uint64_t seed,
                                       uint32_t iter0, uint32_t particle_offset, void* stream, float* sample_kernel_ms,
                                       float* update_kernel_ms) {
@@ -933,7 +1044,7 @@ extern "C" int mpb_stomp_step_profile(float* means, float* samples, float* costs
         }
     for (int it = 0; it < n_iters; ++it) {
         t_ev0 = ev[4 * it + 0]; t_ev1 = ev[4 * it + 1];
-        launch_sample<true>(means, nullptr, samples, costs, L, geom, P, S, H, d, k_sigma, weight, seed, iter0 + (uint32_t)it,
+        launch_sample<true>(means, nullptr, samples, costs, L, geom, geom_flags, P, S, H, d, k_sigma, weight, seed, iter0 + (uint32_t)it,
                             particle_offset, (hipStream_t)stream);
         t_ev0 = ev[4 * it + 2]; t_ev1 = ev[4 * it + 3];
         launch_update(means, samples, costs, weights, Sigma, P, S, H, d, lr, temperature, (hipStream_t)stream);

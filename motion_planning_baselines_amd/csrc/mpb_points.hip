@@ -35,9 +35,9 @@ __global__ __launch_bounds__(256) void fk_points_kernel(const float* __restrict_
             const float4 lk = *reinterpret_cast<const float4*>(G.links + 8 * l);   // frame, ox, oy, oz
             const int f = __float_as_int(lk.x);
             while (F.frame < f) fk_advance<false>(G, F, q);
-            o[3 * l + 0] = F.tx + (F.r00 * lk.y + F.r01 * lk.z + F.r02 * lk.w);
-            o[3 * l + 1] = F.ty + (F.r10 * lk.y + F.r11 * lk.z + F.r12 * lk.w);
-            o[3 * l + 2] = F.tz + (F.r20 * lk.y + F.r21 * lk.z + F.r22 * lk.w);
+            o[3 * l + 0] = mad3(F.r00, lk.y, F.r01, lk.z, F.r02, lk.w, F.tx);
+            o[3 * l + 1] = mad3(F.r10, lk.y, F.r11, lk.z, F.r12, lk.w, F.ty);
+            o[3 * l + 2] = mad3(F.r20, lk.y, F.r21, lk.z, F.r22, lk.w, F.tz);
         }
     }
 }
@@ -74,9 +74,9 @@ __global__ __launch_bounds__(256) void fk_points_vjp_kernel(const float* __restr
                 const float4 lk = *reinterpret_cast<const float4*>(G.links + 8 * l);
                 const int f = __float_as_int(lk.x);
                 while (F.frame < f) fk_advance<true>(G, F, q);
-                const float x = F.tx + (F.r00 * lk.y + F.r01 * lk.z + F.r02 * lk.w);
-                const float y = F.ty + (F.r10 * lk.y + F.r11 * lk.z + F.r12 * lk.w);
-                const float z = F.tz + (F.r20 * lk.y + F.r21 * lk.z + F.r22 * lk.w);
+                const float x = mad3(F.r00, lk.y, F.r01, lk.z, F.r02, lk.w, F.tx);
+                const float y = mad3(F.r10, lk.y, F.r11, lk.z, F.r12, lk.w, F.ty);
+                const float z = mad3(F.r20, lk.y, F.r21, lk.z, F.r22, lk.w, F.tz);
                 const float fx = g[3 * l], fy = g[3 * l + 1], fz = g[3 * l + 2];
 #pragma unroll
                 for (int ii = 0; ii < MPB_MAX_DOF; ++ii) {

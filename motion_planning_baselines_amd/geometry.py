@@ -26,12 +26,12 @@ import numpy as np
 import torch
 
 GEOM_MAGIC = 0x4D504247  # 'MPBG'
-GEOM_VERSION = 4
+GEOM_VERSION = 5
 MAX_FIELDS = 4           # collision fields chained in one buffer (csrc/mpb_geom.h MPB_MAX_FIELDS)
 GEOM_HEADER_WORDS = 32
 GRID_MAX_DIM = 16       # cells per axis of the broad-phase grid (<= 4096 cells = 16 KB of LDS)
 GRID_CELL = 0.14        # target cell edge [m]
-GRID_EMPTY = 0xFFFFFFFF
+GRID_PAD = 1024         # the grid section is padded to a multiple of this many words (one round of a 256-thread block's uint4 loads)
 GRID_OVERFLOW = 0xFFFFFFFE  # more than 4 candidates in the cell: the kernel tests every obstacle
 KIND_POINT = 0
 KIND_CHAIN = 1
@@ -57,6 +57,10 @@ def _mdh(alpha, a, d):
     out = np.zeros((3, 4), dtype=np.float64)
     out[:, :3] = R
     out[:, 3] = t
+    # cos(+-pi/2) evaluates to 6.1e-17, not 0: the link twists of a modified-DH table are exact quarter turns, so such
+    # residues are rounding noise of the table's construction -- snapped to exact zeros (the compile-time robot models
+    # of model_gen.py then fold those terms away, and the generic kernels / the oracle see the same exact tables)
+    out[np.abs(out) < 1e-12] = 0.0
     return out
 
 
@@ -244,13 +248,12 @@ def build_grid(spheres, a_max, slack=1e-4):
     inv32 = (1.0 / cell).astype(np.float32)
     cell_eff = 1.0 / inv32.astype(np.float64)
     Rg = R + 1e-5 + 1e-6 * np.abs(np.concatenate([lo, hi])).max()
-    words = np.full(int(dims.prod()), GRID_EMPTY, dtype=np.uint32)
     ix = [np.arange(d) for d in dims]
     X, Y, Z = np.meshgrid(ix[0], ix[1], ix[2], indexing='ij')
     cmin = lo32.astype(np.float64) + np.stack([X, Y, Z], -1) * cell_eff          # (nx,ny,nz,3)
     cmax = cmin + cell_eff
     counts = np.zeros(dims, dtype=np.int64)
-    lists = np.full((*dims, 4), 0xFF, dtype=np.uint32)
+    lists = np.full((*dims, 4), n, dtype=np.uint32)      # empty slot = n: the far dummy the kernels append to the table
     for o in range(n):
         d = np.maximum(np.maximum(cmin - c[o], c[o] - cmax), 0.0)
         hit = (d * d).sum(-1) < Rg[o] ** 2
@@ -303,8 +306,11 @@ def links_that_can_touch(rs, fs, slack=1e-4):
     return keep
 
 
-def pack_geometry(robot, field, scales=None, prune_static=True):
+def pack_geometry(robot, field, scales=None, prune_static=True, use_model=True):
     """Pack robot + collision field(s) into the flat fp32 word buffer the HIP kernels read.
+
+    use_model: tag the buffer with the compile-time robot model its tables equal (model_gen.py), which lets the
+    kernels take their unrolled chain walk; False keeps the generic table-driven walk (same bits; tests compare them).
 
     prune_static: leave out the collision spheres that can never come within their hinge threshold of this field's
     obstacles (links_that_can_touch); the per-sphere entry points (mpb_fk_collision_points, mpb_field_cost_points) need
@@ -321,7 +327,8 @@ def pack_geometry(robot, field, scales=None, prune_static=True):
       [12] off_boxes [13] total_words [14] off_cull [15] off_frame_start
       [16] off_grid [17..19] grid dims nx,ny,nz [20..22] grid origin (f32) [23..25] 1/cell size (f32)
       [26] n_cells (0: no grid) [27] words to the next chained field (0: none) [28] field scale s_f (f32)
-      [29..31] reserved
+      [29] compile-time robot model id (model_gen.py; 0: none -- set only when the robot's tables equal the model's
+      bit for bit) [30] keep mask over the MODEL's collision spheres (bit l: sphere l is in the link table) [31] reserved
       joint_tf    : n_frames_tf x 12   (row-major 3x4)
       links       : n_links x 8        (frame:int, ox, oy, oz, radius, 0, 0, 0)
       spheres     : n_spheres x 4      (cx, cy, cz, r)
@@ -331,8 +338,8 @@ def pack_geometry(robot, field, scales=None, prune_static=True):
                     (3 fma + 1 compare per pair; the exact distance is evaluated only when a lane passes).
                     Padding entries never pass (rhs = -1e30).
       frame_start : n_frames + 1 ints (padded to 4): links [fs[j], fs[j+1]) ride on frame j+1
-      grid        : nx*ny*nz uint32 words, x fastest.  Broad phase for the obstacle spheres: a word packs up
-                    to four 8-bit obstacle indices (0xFF = none) -- exactly the obstacles whose ball inflated
+      grid        : nx*ny*nz uint32 words, x fastest (section zero-padded to a multiple of 1024 words).  Broad phase for the obstacle spheres: a word packs up
+                    to four 8-bit obstacle indices (n_spheres = none: the far dummy) -- exactly the obstacles whose ball inflated
                     by (margin + max_l r_l + slack) touches the cell; GRID_OVERFLOW when more than four do.
                     A collision sphere at x can only be within its hinge threshold of the obstacles listed
                     in the cell containing x (none outside the grid), so per-LANE culling is exact.
@@ -342,13 +349,23 @@ def pack_geometry(robot, field, scales=None, prune_static=True):
         assert 1 <= len(fields) <= MAX_FIELDS, f'1..{MAX_FIELDS} collision fields per geometry buffer'
         scales = [1.0] * len(fields) if scales is None else [float(v) for v in scales]
         assert len(scales) == len(fields)
-        parts = [pack_geometry(robot, f, scales=[sc], prune_static=prune_static) for f, sc in zip(fields, scales)]
+        parts = [pack_geometry(robot, f, scales=[sc], prune_static=prune_static, use_model=use_model)
+                 for f, sc in zip(fields, scales)]
         for i, part in enumerate(parts[:-1]):
             part.view(np.int32)[27] = part.size
         return np.concatenate(parts)
     rs, fs = robot.spec(), field.spec()
+    from . import model_gen
+    model_id, keep_mask = 0, 0
+    for name, mid in model_gen.MODEL_IDS.items():
+        if use_model and model_gen.matches_model(rs, name):
+            model_id, keep_mask = mid, (1 << len(rs['link_radius'])) - 1
     if prune_static and rs['kind'] == KIND_CHAIN:
         keep = links_that_can_touch(rs, fs)
+        if model_id:
+            keep_mask = int(sum(1 << l for l in range(len(keep)) if keep[l]))
+            if np.any(np.asarray(rs['link_frame'])[~keep] != 1):      # the model kernels only expect frame-1 spheres to go
+                model_id, keep_mask = 0, 0
         if not keep.all():
             rs = dict(rs, link_frame=np.asarray(rs['link_frame'])[keep], link_offset=np.asarray(rs['link_offset'])[keep],
                       link_radius=np.asarray(rs['link_radius'])[keep])
@@ -367,7 +384,7 @@ def pack_geometry(robot, field, scales=None, prune_static=True):
     off_grid = off_fs + n_fs
     grid = build_grid(fs['spheres'], float(fs['margin']) + float(np.max(rs['link_radius'])))
     n_cells = 0 if grid is None else int(grid['words'].size)
-    total = off_grid + (n_cells + 3) // 4 * 4
+    total = off_grid + (n_cells + GRID_PAD - 1) // GRID_PAD * GRID_PAD   # staged by the kernels in whole 16-byte rounds
     buf = np.zeros((total,), dtype=np.float32)
     ibuf = buf.view(np.int32)
     ibuf[0:8] = [GEOM_MAGIC, GEOM_VERSION, rs['kind'], rs['n_dof'], n_tf, n_links, n_sph, n_box]
@@ -420,6 +437,8 @@ def pack_geometry(robot, field, scales=None, prune_static=True):
     ibuf[off_fs:off_grid] = fstart
     ibuf[27] = 0
     buf[28] = 1.0 if scales is None else float(scales[0])
+    ibuf[29] = model_id
+    buf.view(np.uint32)[30] = keep_mask
     return buf
 
 

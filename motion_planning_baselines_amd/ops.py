@@ -62,16 +62,17 @@ def _chk(t, shape, name, allow_none=False):
 class DeviceGeometry:
     """Packed robot + field geometry resident in HBM (one small fp32 buffer)."""
 
-    def __init__(self, robot, field, device, scales=None, keep_all_links=False):
+    def __init__(self, robot, field, device, scales=None, keep_all_links=False, use_model=True):
         """`field`: one CollisionField or a list of up to 4 (evaluated as sum_f scales[f] * cost_f).
         keep_all_links: pack every collision sphere of the robot (needed by the per-sphere entry points
         fk_collision_points / field_cost_points); by default spheres that can never reach an obstacle of the field are
         left out of the link table (geometry.links_that_can_touch: exact, cost and gradient unchanged)."""
         self.robot, self.field = robot, field
-        host = pack_geometry(robot, field, scales=scales, prune_static=not keep_all_links)
+        host = pack_geometry(robot, field, scales=scales, prune_static=not keep_all_links, use_model=use_model)
         self.all_links = int(host.view(np.int32)[5]) == len(robot.spec()['link_radius']) and (
             not isinstance(field, (list, tuple)) or keep_all_links or len(field) == 1)
         _lib.geom_check(host)
+        self.flags = _lib.geom_flags(host)
         self.host = host
         self.n_dof = robot.q_dim
         self.n_fields = count_fields(host)
@@ -82,6 +83,7 @@ class DeviceGeometry:
         self = cls.__new__(cls)
         host = np.ascontiguousarray(packed, dtype=np.float32)
         _lib.geom_check(host)
+        self.flags = _lib.geom_flags(host)
         self.robot = self.field = None
         self.all_links = True
         self.host = host
@@ -280,7 +282,7 @@ def stomp_step(means, eps, samples, costs, weights, L, Sigma, geom, S, D, k_sigm
         _chk(eps, (n_iters, S, d, P, H), 'eps')
     _lib.check(_lib.lib().mpb_stomp_step(
         _ptr(means), _ptr(eps), _ptr(samples), _ptr(costs), _ptr(weights), _ptr(L), _ptr(Sigma), _ptr(geom.buf),
-        P, S, H, d, D, float(k_sigma), float(weight), float(lr), float(temperature), int(n_iters),
+        int(geom.flags), P, S, H, d, D, float(k_sigma), float(weight), float(lr), float(temperature), int(n_iters),
         int(seed) & (2 ** 64 - 1), int(iter0), int(particle_offset), _stream()), 'mpb_stomp_step')
 
 
@@ -298,7 +300,7 @@ def stomp_step_profile(means, samples, costs, weights, L, Sigma, geom, S, D, k_s
     _chk(Sigma, (H, H), 'Sigma')
     ka, kb = ctypes.c_float(0.0), ctypes.c_float(0.0)
     _lib.check(_lib.lib().mpb_stomp_step_profile(
-        _ptr(means), _ptr(samples), _ptr(costs), _ptr(weights), _ptr(L), _ptr(Sigma), _ptr(geom.buf),
+        _ptr(means), _ptr(samples), _ptr(costs), _ptr(weights), _ptr(L), _ptr(Sigma), _ptr(geom.buf), int(geom.flags),
         P, S, H, d, D, float(k_sigma), float(weight), float(lr), float(temperature), int(n_iters),
         int(seed) & (2 ** 64 - 1), int(iter0), int(particle_offset), _stream(),
         ctypes.cast(ctypes.pointer(ka), ctypes.c_void_p), ctypes.cast(ctypes.pointer(kb), ctypes.c_void_p)),
@@ -321,7 +323,8 @@ def stomp_sample(means, eps, samples, L, S, seed=0, it=0, particle_offset=0, geo
     if costs is not None:
         _chk(costs, (P, S), 'costs')
     _lib.check(_lib.lib().mpb_stomp_sample(_ptr(means), _ptr(eps), _ptr(samples), _ptr(L),
-                                          _ptr(None if geom is None else geom.buf), _ptr(costs), P, S, H, d,
+                                          _ptr(None if geom is None else geom.buf),
+                                          0 if geom is None else int(geom.flags), _ptr(costs), P, S, H, d,
                                           float(k_sigma), float(weight), int(seed) & (2 ** 64 - 1), int(it),
                                           int(particle_offset), _stream()), 'mpb_stomp_sample')
 

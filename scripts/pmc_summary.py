@@ -1,0 +1,85 @@
+"""Turn the rocprofv3 output of scripts/profile_round.sh into the summaries kept under profiles/:
+    profiles/<tag>_kernel_stats_bench.csv   (rocprofv3 --kernel-trace --stats of the bench command)
+    profiles/<tag>_pmc_per_wave.md          (every counter, per kernel, per launch and per wave)
+    profiles/<tag>_pmc_kernelA.json         (what bench.py reads: VALU instructions per wave, HBM-side bytes per launch)
+usage: python scripts/pmc_summary.py gpurun_out/prof_<tag> <tag>"""
+import csv, glob, json, os, shutil, sqlite3, sys
+from collections import defaultdict
+
+src, tag = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+prof = os.path.join(root, 'profiles')
+os.makedirs(prof, exist_ok=True)
+
+for f in glob.glob(os.path.join(src, 'stats', '**', '*kernel_stats.csv'), recursive=True):
+    shutil.copy(f, os.path.join(prof, f'{tag}_kernel_stats_bench.csv'))
+for f in glob.glob(os.path.join(src, 'stats', '**', '*_results.db'), recursive=True):   # rocprofv3's default output (rocpd)
+    db = sqlite3.connect(f)
+    per = defaultdict(list)
+    for name, dur in db.execute('select name, duration from kernels'):
+        per[name].append(dur)
+    tot = sum(sum(v) for v in per.values())
+    with open(os.path.join(prof, f'{tag}_kernel_stats_bench.csv'), 'w') as fh:
+        fh.write('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","MedianNs"\n')
+        for name, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+            v = sorted(v)
+            fh.write(f'"{name}",{len(v)},{sum(v)},{sum(v) / len(v):.1f},{100.0 * sum(v) / tot:.2f},{v[0]},{v[-1]},{v[len(v) // 2]}\n')
+b = os.path.join(src, 'bench_under_rocprof.json')
+if os.path.exists(b):
+    shutil.copy(b, os.path.join(prof, f'{tag}_bench_under_rocprof.json'))
+
+acc = defaultdict(lambda: defaultdict(list))     # kernel -> counter -> values per dispatch
+grid = {}
+for f in glob.glob(os.path.join(src, 'pmc*', '**', '*_results.db'), recursive=True):
+    db = sqlite3.connect(f)
+    q = ('select kernel_name, counter_name, value, grid_size, workgroup_size, vgpr_count, sgpr_count, lds_block_size, '
+         'scratch_size from counters_collection order by dispatch_id')
+    for k, c, v, g, wg, vg, sg, lds, scr in db.execute(q):
+        acc[k][c].append(float(v))
+        grid[k] = (int(g), int(wg), int(vg or 0), int(sg or 0), int(lds or 0), int(scr or 0))
+for f in glob.glob(os.path.join(src, 'pmc*', '**', '*counter_collection.csv'), recursive=True):
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            k = row['Kernel_Name']
+            acc[k][row['Counter_Name']].append(float(row['Counter_Value']))
+            grid[k] = (int(row['Grid_Size']), int(row['Workgroup_Size']), int(row.get('VGPR_Count', 0) or 0),
+                       int(row.get('SGPR_Count', 0) or 0), int(row.get('LDS_Block_Size', 0) or 0), int(row.get('Scratch_Size', 0) or 0))
+
+lines = [f'# rocprofv3 PMC, {tag}: scripts/profile_round.sh (separate --pmc passes of scripts/prof_stomp.py, C3 shape);',
+         '# per kernel: mean over its dispatches, per launch and per wave (grid / 64)', '']
+summary = {}
+for k in sorted(acc):
+    g, wg, vg, sg, lds, scr = grid[k]
+    waves = g // 64
+    lines.append(f'## {k}')
+    lines.append(f'grid {g} threads = {waves} waves, workgroup {wg}, VGPR {vg}, SGPR {sg}, LDS {lds} B, scratch {scr} B')
+    lines.append(f'{"counter":34s} {"per launch":>16s} {"per wave":>12s} {"dispatches":>10s}')
+    summary[k] = {}
+    for c in sorted(acc[k]):
+        v = acc[k][c]
+        v = v[len(v) // 4:]                      # drop the first quarter (warm-up dispatches)
+        m = sum(v) / len(v)
+        summary[k][c] = m
+        lines.append(f'{c:34s} {m:16.1f} {m / waves:12.1f} {len(v):10d}')
+    lines.append('')
+with open(os.path.join(prof, f'{tag}_pmc_per_wave.md'), 'w') as fh:
+    fh.write('\n'.join(lines))
+
+ka = [k for k in summary if 'stomp_sample_cost' in k and 'true' in k]
+if ka:
+    k = ka[0]
+    s = summary[k]
+    waves = grid[k][0] // 64
+    fetch_kb, write_kb = s.get('FETCH_SIZE'), s.get('WRITE_SIZE')
+    out = {'kernel': k, 'workload': 'C3 P=128 S=32 H=64 d=14 (scripts/prof_stomp.py)', 'waves_per_launch': waves,
+           'SQ_INSTS_VALU_per_wave': s.get('SQ_INSTS_VALU', 0) / waves if 'SQ_INSTS_VALU' in s else None,
+           'SQ_INSTS_SALU_per_wave': s.get('SQ_INSTS_SALU', 0) / waves if 'SQ_INSTS_SALU' in s else None,
+           'SQ_WAVE_CYCLES_per_wave_quads': s.get('SQ_WAVE_CYCLES', 0) / waves if 'SQ_WAVE_CYCLES' in s else None,
+           'FETCH_SIZE_KB_raw': fetch_kb, 'WRITE_SIZE_KB_raw': write_kb,
+           'note': 'gfx950: FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads (MI355X_MICROARCH.md, HBM) -> the read '
+                   'side is doubled; WRITE_SIZE is exact for 16-B-per-lane streaming stores',
+           'hbm_bytes_per_launch': (2 * fetch_kb + write_kb) * 1024 if fetch_kb is not None and write_kb is not None else None}
+    with open(os.path.join(prof, f'{tag}_pmc_kernelA.json'), 'w') as fh:
+        json.dump(out, fh, indent=1)
+    print(json.dumps(out, indent=1))
+print('\n'.join(lines[:60]))

@@ -75,6 +75,38 @@ def test_stomp_c3_kernels_consistent(gpu_device, pos_only):
     assert torch.equal(m3, means)
 
 
+@pytest.mark.parametrize('keep_all', [False, True])
+def test_panda_model_path_equals_generic_walk(gpu_device, keep_all):
+    """The compile-time Panda model (csrc/mpb_model_panda.h: unrolled chain, folded transforms) and the generic
+    table-driven chain walk return the same bits: fused STOMP cost and stand-alone cost on 131072 waypoints incl.
+    far-out-of-range angles, with the statically pruned link table and with the full one (frame-1 group live)."""
+    import numpy as np
+    from motion_planning_baselines_amd import ops
+    dev = gpu_device
+    P, S, H = 16, 32, 64
+    wl, Sigma, L, _ = _c3(dev, P, S)
+    gm = ops.DeviceGeometry(wl['robot'], wl['field'], dev, keep_all_links=keep_all)
+    gg = ops.DeviceGeometry(wl['robot'], wl['field'], dev, keep_all_links=keep_all, use_model=False)
+    assert int(gm.host.view(np.int32)[29]) == 1 and int(gg.host.view(np.int32)[29]) == 0
+    n_kept = int(gm.host.view(np.int32)[5])
+    assert int(gm.host.view(np.uint32)[30]) == ((1 << 31) - 1 if keep_all else ((1 << 31) - 1) & ~((1 << (31 - n_kept)) - 1))
+    d = wl['means0'].shape[-1]
+    out = []
+    for geom in (gm, gg):
+        means = wl['means0'].clone()
+        samples = torch.empty(P, S, H, d, device=dev)
+        costs = torch.empty(P, S, device=dev)
+        ops.stomp_sample(means, None, samples, L, S, seed=3, it=1, geom=geom, costs=costs, k_sigma=1e6)
+        g = torch.Generator().manual_seed(0)
+        x = ((torch.rand(2048, 64, 14, generator=g) * 2 - 1) * 6.0).to(dev)
+        alone, pw = ops.cost_collision_eval(x, geom, 1.0, per_waypoint=True)
+        torch.cuda.synchronize()
+        out.append((samples, costs, alone, pw))
+    assert float(out[0][1].max()) > 0 and float(out[0][2].max()) > 0
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+
+
 def test_collision_cost_grid_equals_exhaustive_at_scale(gpu_device):
     """Broad-phase grid (cost-only path) == exhaustive obstacle loop (gradient path's cost output), bit for
     bit, on 4096 x 64 random Panda configurations incl. far-out-of-workspace angles."""
@@ -236,8 +268,24 @@ def test_bench_line_contract(gpu_device):
     assert 'workload' in j['config'] and 'model' not in j['config']
     assert abs(j['value'] * j['ms_per_step'] * 1e-3 - 1.0) < 1e-6              # value = steps / elapsed on one GPU
     r = j['roofline']
-    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
+    # the binding roofline is the fp32 VALU issue rate when a committed rocprofv3 counter summary of this workload
+    # exists (profiles/r*_pmc_kernelA.json: instructions per wave), the nominal HBM bound of SURVEY 8d otherwise; the
+    # HBM figure is always reported next to it
+    assert r['bound'] in ('valu', 'hbm')
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
-    assert abs(r['achieved'] - r['algorithmic_bytes_per_launch'] / (r['kernel_ms'] * 1e-3) / 1e9) < 1e-6 * r['achieved']
+    if r['bound'] == 'valu':
+        assert r['unit'] == 'G wave-instr/s' and abs(r['peak'] - 1228.8) < 1e-6
+        assert abs(r['achieved'] - r['valu_instructions_per_wave'] * 4096 / (r['kernel_ms'] * 1e-3) / 1e9) < 1e-6 * r['achieved']
+    h = r['hbm']
+    assert h['unit'] == 'GB/s' and h['peak'] == 8000.0 and abs(h['frac'] - h['achieved'] / h['peak']) < 1e-9
+    assert abs(h['achieved'] - h['algorithmic_bytes_per_launch'] / (r['kernel_ms'] * 1e-3) / 1e9) < 1e-6 * h['achieved']
+    sp = j['repeats']
+    assert sp['n'] == 5 and sp['ms_per_step_min'] <= sp['ms_per_step_median'] <= sp['ms_per_step_max']
+    assert abs(sp['ms_per_step_median'] - j['ms_per_step']) < 1e-9
+    # the other BASELINE configs ride on the same line: C5's per-GPU load, C2 (CHOMP), C4 (GPMP2 at B = 2048)
+    for k in ('c5', 'c2', 'c4'):
+        assert j[k]['value'] > 0 and j[k]['unit'] == 'iters/s' and 'workload' in j[k], k
+    assert '4096 particles' in j['c5']['workload'] and 'B=1024' in j['c2']['workload'] and 'B=2048' in j['c4']['workload']
+    assert j['c4']['roofline']['bound'] == 'mfma' and j['c4']['dtype'] == 'f64'
     # timings are reported, not asserted against a bar: a rare ~70 ms device stall on this pool would fail it
     assert r['kernel_ms_dispatch_events'] > 0 and r['kernel_ms'] > 0 and j['value'] > 0
