@@ -35,10 +35,11 @@
 #define MPB_KIND_CHAIN 1
 #define MPB_MAX_DOF 8
 #define MPB_MAX_TF (MPB_MAX_DOF + 1)
-// collision spheres processed together (VGPR resident): 8 for the cost-only path, 4 when the gradient
-// state (direction + norm per sphere, joint axes/origins) also has to fit in the register file
+// collision spheres processed together (VGPR resident) by the exhaustive obstacle loop: 4.  (The cost-only path ran 8 at
+// a time in round 1; that evaluator is now the cold path -- fields without a usable broad-phase grid -- and at 8 it alone
+// pushed STOMP kernel A, which also holds the grid evaluator, over its 128 registers: 64 B / lane of scratch.)
 #ifndef MPB_LCH_COST
-#define MPB_LCH_COST 8
+#define MPB_LCH_COST 4
 #endif
 #define MPB_LCH_OF(GRAD) ((GRAD) ? 4 : MPB_LCH_COST)
 // conservative-test policy: 0 = adaptive (default), 1 = never test, 2 = always test (tuning builds only)
@@ -60,6 +61,7 @@ struct GeomView {
     int gnx, gny, gnz, n_cells;
     float glx, gly, glz, gix, giy, giz;  // origin, 1 / cell size
     float fscale;                        // s_f: this field's share in  sum_f s_f * cost_f
+    int next;                            // words from this header to the next chained field (0: last)
     int model;                           // compile-time robot model the tables equal bit for bit (0: none), mpb_model_*.h
     unsigned keep_mask;                  // bit l: the model's collision sphere l is in the link table (static pruning)
 };
@@ -92,6 +94,7 @@ __device__ __forceinline__ GeomView geom_view(const float* __restrict__ g) {
     v.gix = g[23]; v.giy = g[24]; v.giz = g[25];
     v.n_cells = gi[26];
     v.fscale = g[28];
+    v.next = gi[27];
     v.model = gi[29];
     v.keep_mask = (unsigned)gi[30];
     return v;

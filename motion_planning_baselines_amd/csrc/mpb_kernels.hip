@@ -13,6 +13,7 @@
 #include "mpb_common.h"
 #include <hip/hip_ext.h>
 #include "mpb_geom.h"
+#include "mpb_stomp_noise.h"
 
 // ------------------------------------------------------------------------------------------------
 // error plumbing
@@ -179,18 +180,20 @@ static thread_local hipEvent_t t_ev0 = nullptr, t_ev1 = nullptr;
 // The D tiles (lane = channel) go through a padded LDS tile to the lane = waypoint layout the
 // FK + SDF cost evaluation wants.  DCH = d is a compile-time channel count (no per-channel branches).
 // ------------------------------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #ifdef MPB_STAMPS  // diagnostic build only: per-wave s_memtime stamps of the phases of kernel A
-__device__ unsigned long long g_stamps[4096 * 8];
+__device__ unsigned long long g_stamps[4096 * 10];   // slots 0-7: s_memtime (shader clock) per phase; 8, 9: s_memrealtime (100 MHz) at entry / exit
 #define MPB_STAMP(k)                                                                              \
     do {                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                        \
         unsigned long long t_;                                                                    \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
         __builtin_amdgcn_sched_barrier(0);                                                        \
-        if ((threadIdx.x & 63) == 0 && blockIdx.x * 4 + (threadIdx.x >> 6) < 4096)                \
-            g_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = t_;                       \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x * 4 + (threadIdx.x >> 6) < 4096) {             \
+            g_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 10 + (k)] = t_;                      \
+            if ((k) == 0 || (k) == 7)                                                             \
+                g_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 10 + ((k) == 0 ? 8 : 9)] = __builtin_amdgcn_s_memrealtime(); \
+        }                                                                                         \
     } while (0)
 extern "C" int mpb_debug_read_stamps(unsigned long long* dst, int n) {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : 3;
@@ -198,17 +201,6 @@ extern "C" int mpb_debug_read_stamps(unsigned long long* dst, int n) {
 #else
 #define MPB_STAMP(k)
 #endif
-
-// Standard normals of the H = 64 fast path: one Philox4x32-7 call per (particle, sample, channel j,
-// k-group g, quarter q4) yields eps[j][k] for k = 16*q4 + 4*r + g, r = 0..3.  The counter holds the GLOBAL particle
-// id, so the noise does not depend on how the particles are sharded over GPUs.
-__device__ __forceinline__ void stomp_eps4(uint32_t p_global, uint32_t s, uint32_t j, uint32_t g, uint32_t q4,
-                                           uint32_t iter, uint32_t seed_lo, uint32_t seed_hi, float (&n)[4]) {
-    const uint4 rr = philox4x32<7>(make_uint4(p_global, s, (j << 16) | (g << 8) | q4, iter), make_uint2(seed_lo, seed_hi));
-    box_muller(rr.x, rr.y, n[0], n[1]);
-    box_muller(rr.z, rr.w, n[2], n[3]);
-}
-#define NT_STRIDE 20  // floats per waypoint row of the noise tile: 80 B keeps ds_read_b128 conflict-free
 
 #ifndef MPB_A_WPB
 #define MPB_A_WPB 4      // waves (rollouts) per block of the H = 64 kernel.  Measured at C3 / P = 4096: 2 waves 42 / 878 us (the
@@ -246,8 +238,12 @@ __global__ __launch_bounds__(64 * MPB_A_WPB, 16 / MPB_A_WPB) void stomp_sample_c
     float4 oreg = make_float4(-1.0e9f, -1.0e9f, -1.0e9f, 0.f);
     bool grid0 = false;
     int g_nsph = 0;
+    // the (first) field's header is read HERE, before this kernel's first global store: scalar loads into SGPRs that the
+    // cost section below reuses.  Re-reading it there, behind the sample stores, costs a chain of vector loads +
+    // v_readfirstlane (the compiler cannot use the scalar cache for memory the kernel may have written): ~3 k cycles
+    GeomView G0;
     if (WITH_COST) {
-        const GeomView G0 = geom_view(geom);
+        G0 = geom_view(geom);
         grid0 = grid_usable(G0);
         if (grid0) {
             // the grid goes global -> LDS directly (global_load_lds_dwordx4: no VGPRs, no ds_write; LDS address = wave-uniform
@@ -283,6 +279,22 @@ __global__ __launch_bounds__(64 * MPB_A_WPB, 16 / MPB_A_WPB) void stomp_sample_c
     const bool live = r < P * S;
     const int p = live ? r / S : 0, s = live ? r - p * S : 0;
     const int j = lane & 15, g = lane >> 4;
+    // the lane's row of the particle mean (lane = waypoint further down): fetched now, used after the noise product
+    // (the generic instantiation, which holds two evaluators, fetches it where it is used: it has no registers to spare)
+    float mu[DCH];
+    if (MODEL != 0) {
+        const float* mrow = means + ((size_t)p * H + lane) * DCH;
+        if (DCH % 2 == 0) {
+#pragma unroll
+            for (int c = 0; c < DCH; c += 2) {
+                const float2 mv = *reinterpret_cast<const float2*>(mrow + c);
+                mu[c] = mv.x; mu[c + 1] = mv.y;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < DCH; ++c) mu[c] = mrow[c];
+        }
+    }
 
     MPB_STAMP(1);
     // ---- B operand: eps[c=j][k=4ks+g], ks = 0..15
@@ -356,19 +368,14 @@ __global__ __launch_bounds__(64 * MPB_A_WPB, 16 / MPB_A_WPB) void stomp_sample_c
     }
     __builtin_amdgcn_wave_barrier();
     const bool edge = (h == 0) || (h == H - 1);
-    const float* mrow = means + ((size_t)p * H + h) * DCH;
-    float x[DCH];
-    if (DCH % 2 == 0) {
+    if (MODEL == 0) {
+        const float* mrow = means + ((size_t)p * H + h) * DCH;
 #pragma unroll
-        for (int c = 0; c < DCH; c += 2) {
-            const float2 mv = *reinterpret_cast<const float2*>(mrow + c);
-            x[c] = mv.x + (edge ? 0.f : nz[c]);
-            x[c + 1] = mv.y + (edge ? 0.f : nz[c + 1]);
-        }
-    } else {
-#pragma unroll
-        for (int c = 0; c < DCH; ++c) x[c] = mrow[c] + (edge ? 0.f : nz[c]);
+        for (int c = 0; c < DCH; ++c) mu[c] = mrow[c];
     }
+    float x[DCH];
+#pragma unroll
+    for (int c = 0; c < DCH; ++c) x[c] = mu[c] + (edge ? 0.f : nz[c]);
     // sample tile out through LDS: the wave's (64 x DCH) tile is contiguous in HBM, so pack it in the
     // (already consumed) noise tile and write 16-byte lanes, 1 KB per store instruction
     {
@@ -394,8 +401,8 @@ __global__ __launch_bounds__(64 * MPB_A_WPB, 16 / MPB_A_WPB) void stomp_sample_c
         // one pass per chained collision field (the reference sums one CostCollision per field); the first field's
         // grid is already in LDS, a later field's replaces it (all waves of the block take the same branches: G is
         // block-uniform)
-        for (const float* gp = geom; gp != nullptr; gp = geom_next(gp)) {
-            const GeomView G = geom_view(gp);
+        GeomView G = G0;
+        for (const float* gp = geom;;) {
             if (grid_usable(G)) {
                 if (gp != geom) {
                     __syncthreads();
@@ -417,6 +424,9 @@ __global__ __launch_bounds__(64 * MPB_A_WPB, 16 / MPB_A_WPB) void stomp_sample_c
                 if (MODEL != 0) bad = true;                  // model instantiations are only launched for grid-backed fields
                 else c = fmaf(G.fscale, waypoint_cost<false>(G, q, dq), c);
             }
+            if (G.next == 0) break;
+            gp += G.next;
+            G = geom_view(gp);
         }
         const double csum = wave_sum_f64((double)c);
         if (live && lane == 0) {

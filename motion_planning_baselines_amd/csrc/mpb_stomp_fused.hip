@@ -1,0 +1,351 @@
+// mpb_stomp_fused.hip -- the whole STOMP optimisation loop (stomp.py:150-160) as ONE persistent launch.
+//
+// The two-kernel path (mpb_kernels.hip) pays, per iteration, two dispatch ramps (a launch that fills the chip once
+// needs ~4.3 us to start its 4096 waves, measured: scripts/launch_ramp.hip), two dependent-dispatch gaps (~1.7 us
+// each) and re-stages its constants; at C3 that is ~40 % of a 25 us iteration.  Here a workgroup of 16 waves owns one
+// UNIT = (particle p, chunk of 16 of its S samples) for all n_iters iterations:
+//   * wave = rollout (sample), lane = waypoint, exactly the mapping of kernel A: noise product on the matrix cores,
+//     FK + SDF in registers, the per-rollout cost a wave reduction;
+//   * L (permuted MFMA image), Sigma, the broad-phase grid + obstacle table and the particle mean live in LDS for the
+//     whole launch; the samples of an iteration stay in the waves' LDS tiles for the weighted-noise reduction
+//     (stomp.py:199-211), which therefore reads LDS instead of re-reading the 14.7 MB of samples from L2;
+//   * a particle with S > 16 is shared by nc = ceil(S / 16) workgroups: each reduces its own 16 samples to
+//     (m_k = max logit, z_k = sum exp(logit - m_k), D_k = sum exp(logit - m_k) (sample - mean)), publishes that (3.6 KB)
+//     and combines the nc partials IN CHUNK ORDER -- every partner computes bit-identical new means, so the copies
+//     of the particle never drift apart.  Hand-off through global memory with agent-scope (sc1) stores / loads and a
+//     flag per unit (MI355X_MICROARCH.md, "Valid forms"); the noise of the NEXT iteration (Philox + MFMA, which does
+//     not depend on the means) is computed between publishing and polling, so the partner's latency is hidden;
+//   * softmax algebra: w_s = exp(x_s - m) / z with m = max_k m_k, z = sum_k exp(m_k - m) z_k -- the same weights as
+//     softmax(-c / T) up to rounding (the two-kernel path normalises before summing; both are within 1e-6 of fp64).
+// Every wait is bounded (s_memrealtime): a unit whose partner never shows up raises the error word and leaves.
+#include <hip/hip_runtime.h>
+
+#include "mpb_common.h"
+#include "mpb_geom.h"
+#include "mpb_stomp_noise.h"
+
+#define FUSED_WAVES 16
+#define FUSED_THREADS (64 * FUSED_WAVES)
+#define FUSED_LD 68                        // padded row (floats) of the Sigma image and of the transposed delta tile
+#define FUSED_XCHG 912                     // floats per published partial: m, z, pad(2), then H*d <= 896 values, padded to 16 B
+#define FUSED_MAX_CHUNKS 4                 // S <= 64
+#define FUSED_TIMEOUT_TICKS 200000000ull   // 2 s of s_memrealtime (100 MHz)
+
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent_u(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned ld_agent_u(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// workspace layout (floats): [0] error word, [16 .. 16 + P*nc) flags, then 2 parities x P x nc x FUSED_XCHG partials
+static inline size_t fused_ws_floats(int P, int nc) {
+    const size_t flags = ((size_t)P * nc + 15) / 16 * 16;
+    return 16 + flags + 2 * (size_t)P * nc * FUSED_XCHG;
+}
+
+template <int DCH, int MODEL>
+__global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
+    float* __restrict__ means, const float* __restrict__ eps, float* __restrict__ samples, float* __restrict__ costs,
+    float* __restrict__ weights, const float* __restrict__ Lmat, const float* __restrict__ Sigma,
+    const float* __restrict__ geom, float* __restrict__ ws, int P, int S, int nc, float k_sigma, float weight, float lr,
+    float temperature, int n_iters, uint32_t seed_lo, uint32_t seed_hi, uint32_t iter0, uint32_t particle_offset) {
+    constexpr int H = 64;
+    constexpr int N = H * DCH;                    // elements of a trajectory
+    static_assert(N <= FUSED_THREADS - 0 && N + 4 <= FUSED_XCHG, "one thread per trajectory element");
+    __shared__ __attribute__((aligned(16))) float Lp[H * H];                                  // 16 KB
+    __shared__ __attribute__((aligned(16))) float tiles[FUSED_WAVES * H * NT_STRIDE];         // 80 KB
+    __shared__ __attribute__((aligned(16))) unsigned gridw[MPB_GRID_MAX_CELLS];               // 16 KB
+    __shared__ float4 otab[MPB_GRID_MAX_SPH + 1];                                             //  1 KB
+    __shared__ __attribute__((aligned(16))) float sig_l[H * FUSED_LD];                        // 17 KB
+    __shared__ __attribute__((aligned(16))) float mean_l[N];                                  // 3.5 KB
+    __shared__ __attribute__((aligned(16))) float delta[DCH * FUSED_LD];                      // 3.7 KB (transposed)
+    __shared__ float cst[FUSED_WAVES];
+    __shared__ int s_abort;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // unit of this block.  XCD-aware (speed only): blocks are dealt round-robin over the 8 XCDs, so blocks b and b + 8
+    // share an L2 -- the nc chunks of a particle are given block indices 8 apart
+    int p, chunk;
+    if ((P & 7) == 0) {
+        const int grp = blockIdx.x / (8 * nc), x = blockIdx.x & 7;
+        chunk = (blockIdx.x >> 3) % nc;
+        p = 8 * grp + x;
+    } else {
+        p = blockIdx.x / nc;
+        chunk = blockIdx.x - p * nc;
+    }
+    const int s = chunk * FUSED_WAVES + wave;           // this wave's sample
+    const bool live = s < S;
+    const int j = lane & 15, g = lane >> 4;
+    float* err_word = ws;
+    unsigned* flags = reinterpret_cast<unsigned*>(ws + 16);
+    float* xch = ws + 16 + ((size_t)P * nc + 15) / 16 * 16;
+
+    // ---- constants into LDS (once)
+    GeomView G0 = geom_view(geom);
+    {
+        const int g_rounds = (G0.n_cells + 4 * FUSED_THREADS - 1) / (4 * FUSED_THREADS);   // MPB_GRID_PAD = 1024 words: whole rounds of 256 lanes
+        const uint4* g4 = reinterpret_cast<const uint4*>(G0.grid);
+        // 1024 threads x 16 B = 4 rounds' worth of the 256-thread padding unit per pass; lanes beyond the padded section stay out
+        const int n_pad16 = (G0.n_cells + MPB_GRID_PAD - 1) / MPB_GRID_PAD * (MPB_GRID_PAD / 4);   // uint4s in the padded section
+        for (int u = 0; u < (MPB_GRID_MAX_CELLS / 4 + FUSED_THREADS - 1) / FUSED_THREADS; ++u) {
+            const int i = tid + FUSED_THREADS * u;
+            if (u < g_rounds && i < n_pad16) reinterpret_cast<uint4*>(gridw)[i] = g4[i];
+        }
+        for (int i = tid; i <= G0.n_sph && i <= MPB_GRID_MAX_SPH; i += FUSED_THREADS)
+            otab[i] = (i < G0.n_sph) ? reinterpret_cast<const float4*>(G0.sph)[i] : make_float4(-1.0e9f, -1.0e9f, -1.0e9f, 0.f);
+        // permuted L image and padded Sigma image: one float4 per thread each
+        const f32x4 lv = reinterpret_cast<const f32x4*>(Lmat)[tid];
+        const f32x4 sv = reinterpret_cast<const f32x4*>(Sigma)[tid];
+        const int row = tid >> 4, col0 = (tid & 15) << 2;
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) Lp[stomp_l_image_index(row, col0 + e4)] = lv[e4];
+        *reinterpret_cast<f32x4*>(sig_l + row * FUSED_LD + col0) = sv;
+        if (tid < N) mean_l[tid] = means[(size_t)p * N + tid];
+        if (tid == 0) s_abort = 0;
+    }
+    __syncthreads();
+
+    // the matvec output this thread owns: element (hh, cc) of the trajectory
+    const int hh = (tid < N) ? tid / DCH : 0, cc = (tid < N) ? tid - hh * DCH : 0;
+    const size_t eps_stride = (size_t)S * DCH * P * H;
+
+    // ---- noise of iteration 0
+    f32x4 acc[4];
+    {
+        float e[16];
+        stomp_b_operand<DCH>(e, eps ? eps + (size_t)(live ? s : 0) * DCH * P * H : nullptr, P, p, j, g,
+                             particle_offset + (uint32_t)p, (uint32_t)s, iter0, seed_lo, seed_hi);
+        stomp_noise_product(Lp, e, j, g, acc);
+    }
+
+    float* nt = tiles + wave * (H * NT_STRIDE);
+    for (int it = 0; it < n_iters; ++it) {
+        // ============ A. samples of this iteration: x = mean + noise, stored, kept packed in the wave's tile
+        float nz[16];
+        stomp_noise_rows<DCH>(nt, acc, lane, nz);
+        const int h = lane;
+        const bool edge = (h == 0) || (h == H - 1);
+        float x[DCH];
+#pragma unroll
+        for (int c = 0; c < DCH; ++c) x[c] = mean_l[h * DCH + c] + (edge ? 0.f : nz[c]);
+#pragma unroll
+        for (int c = 0; c < DCH; ++c) nt[h * DCH + c] = x[c];
+        __builtin_amdgcn_wave_barrier();
+        if (live) {
+            const f32x4* pk4 = reinterpret_cast<const f32x4*>(nt);
+            f32x4* out4 = reinterpret_cast<f32x4*>(samples + ((size_t)p * S + s) * N);
+#pragma unroll
+            for (int k = 0; k < (16 * DCH + 63) / 64; ++k) {
+                const int idx = lane + 64 * k;
+                if (idx < 16 * DCH) out4[idx] = pk4[idx];
+            }
+        }
+        // ============ B. collision cost of the rollout
+        {
+            float q[MPB_MAX_DOF];
+#pragma unroll
+            for (int i = 0; i < MPB_MAX_DOF; ++i) q[i] = (i < DCH) ? x[i < DCH ? i : 0] : 0.f;
+            float c = 0.f;
+            bool bad = false;
+            GeomView G = G0;
+            for (const float* gp = geom;;) {
+                if (gp != geom) {     // a chained field: its grid replaces the first one's (restored before the next iteration)
+                    __syncthreads();
+                    grid_stage(G, gridw, otab, tid, FUSED_THREADS);
+                    __syncthreads();
+                }
+                if (live && h >= 1) {
+                    if (MODEL == PandaModel::ID) {
+                        if (G.model == PandaModel::ID) c = fmaf(G.fscale, waypoint_cost_grid_model<PandaModel>(G, gridw, otab, q), c);
+                        else bad = true;
+                    } else {
+                        c = fmaf(G.fscale, waypoint_cost_grid(G, gridw, otab, q), c);
+                    }
+                }
+                if (G.next == 0) break;
+                gp += G.next;
+                G = geom_view(gp);
+            }
+            if (G0.next != 0) {       // more than one field: put the first field's grid back for the next iteration
+                __syncthreads();
+                grid_stage(G0, gridw, otab, tid, FUSED_THREADS);
+            }
+            const double csum = wave_sum_f64((double)c);
+            const float cw = weight * (k_sigma * (float)csum);
+            if (lane == 0) {
+                cst[wave] = cw;
+                if (live) {
+                    if (bad) reinterpret_cast<unsigned*>(costs)[(size_t)p * S + s] = 0x7FC00000u;
+                    else costs[(size_t)p * S + s] = cw;
+                }
+            }
+        }
+        __syncthreads();                                                                        // (1) costs of the chunk
+        // ============ C. partial of this chunk: logits, local max, e_w, z, weighted (sample - mean)
+        const int sl = chunk * FUSED_WAVES + (lane & 15);                   // every wave redundantly, lanes 0-15 carry the chunk
+        const float xs = (lane < FUSED_WAVES && sl < S) ? -cst[lane & 15] / temperature : -3.0e38f;
+        const float mb = wave_max_f32(xs);
+        const float ex = (lane < FUSED_WAVES && sl < S) ? expf(xs - mb) : 0.f;
+        const float zb = wave_sum_f32(ex);
+        float dpart = 0.f;
+        if (tid < N) {
+            const float mu = mean_l[tid];
+#pragma unroll
+            for (int w = 0; w < FUSED_WAVES; ++w) {
+                const float ew = readlane_f32(ex, w);
+                dpart = fmaf(ew, tiles[w * (H * NT_STRIDE) + tid] - mu, dpart);
+            }
+        }
+        float m_all = mb, z_all = zb, f_own = 1.f;
+        if (nc > 1) {
+            // ============ D. publish (sc1 stores), flag, then -- before polling -- the noise of the next iteration
+            float* mine = xch + ((size_t)(it & 1) * P * nc + (size_t)p * nc + chunk) * FUSED_XCHG;
+            if (tid < N) st_agent(mine + 4 + tid, dpart);
+            if (tid == 0) { st_agent(mine + 0, mb); st_agent(mine + 1, zb); }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                                                    // (2) every store of the block is out
+            if (tid == 0) st_agent_u(flags + (size_t)p * nc + chunk, (unsigned)(it + 1));
+        }
+        if (it + 1 < n_iters) {
+            float e[16];
+            stomp_b_operand<DCH>(e, eps ? eps + (size_t)(it + 1) * eps_stride + (size_t)(live ? s : 0) * DCH * P * H : nullptr, P, p, j, g,
+                                 particle_offset + (uint32_t)p, (uint32_t)s, iter0 + (uint32_t)(it + 1), seed_lo, seed_hi);
+            stomp_noise_product(Lp, e, j, g, acc);
+        }
+        float dsum = dpart;
+        if (nc > 1) {
+            if (tid == 0) {
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                for (int k = 0; k < nc; ++k) {
+                    if (k == chunk) continue;
+                    while (ld_agent_u(flags + (size_t)p * nc + k) < (unsigned)(it + 1)) {
+                        __builtin_amdgcn_s_sleep(4);
+                        if (__builtin_amdgcn_s_memrealtime() - t0 > FUSED_TIMEOUT_TICKS) { s_abort = 1; break; }
+                    }
+                }
+            }
+            __syncthreads();                                                                    // (3) partners have published
+            if (s_abort) break;                                                                 // block-uniform
+            // combine the nc partials in chunk order (own partial from registers: the very bits the partners read)
+            float mk[FUSED_MAX_CHUNKS], zk[FUSED_MAX_CHUNKS], dk[FUSED_MAX_CHUNKS];
+#pragma unroll
+            for (int k = 0; k < FUSED_MAX_CHUNKS; ++k) {
+                mk[k] = -3.0e38f; zk[k] = 0.f; dk[k] = 0.f;
+                if (k < nc) {
+                    const float* theirs = xch + ((size_t)(it & 1) * P * nc + (size_t)p * nc + k) * FUSED_XCHG;
+                    mk[k] = (k == chunk) ? mb : ld_agent(theirs + 0);
+                    zk[k] = (k == chunk) ? zb : ld_agent(theirs + 1);
+                    dk[k] = (k == chunk) ? dpart : ((tid < N) ? ld_agent(theirs + 4 + tid) : 0.f);
+                }
+            }
+            m_all = mk[0];
+#pragma unroll
+            for (int k = 1; k < FUSED_MAX_CHUNKS; ++k) m_all = fmaxf(m_all, mk[k]);
+            z_all = 0.f;
+            dsum = 0.f;
+#pragma unroll
+            for (int k = 0; k < FUSED_MAX_CHUNKS; ++k) {
+                if (k < nc) {
+                    const float f = expf(mk[k] - m_all);
+                    z_all = fmaf(f, zk[k], z_all);
+                    dsum = fmaf(f, dk[k], dsum);
+                    if (k == chunk) f_own = f;
+                }
+            }
+        }
+        // ============ E. weights out, delta (transposed) -> mean += lr * Sigma @ delta
+        if (tid < FUSED_WAVES && sl < S) weights[(size_t)p * S + sl] = ex * f_own / z_all;
+        if (tid < N) delta[cc * FUSED_LD + hh] = dsum / z_all;
+        __syncthreads();                                                                        // (4) delta complete
+        if (tid < N) {
+            float a4[4] = {0.f, 0.f, 0.f, 0.f};
+            const float4* dcol = reinterpret_cast<const float4*>(delta + cc * FUSED_LD);
+            const float4* srow = reinterpret_cast<const float4*>(sig_l + hh * FUSED_LD);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float4 dv = dcol[k], sv = srow[k];
+                a4[k & 3] = fmaf(sv.x, dv.x, a4[k & 3]);
+                a4[k & 3] = fmaf(sv.y, dv.y, a4[k & 3]);
+                a4[k & 3] = fmaf(sv.z, dv.z, a4[k & 3]);
+                a4[k & 3] = fmaf(sv.w, dv.w, a4[k & 3]);
+            }
+            mean_l[tid] += lr * ((a4[0] + a4[1]) + (a4[2] + a4[3]));
+        }
+        __syncthreads();                                                                        // (5) new mean visible, tiles free
+    }
+    if (s_abort) {
+        if (tid == 0) st_agent(err_word, 1.0f);
+        return;
+    }
+    if (chunk == 0 && tid < N) means[(size_t)p * N + tid] = mean_l[tid];
+}
+
+// ------------------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" size_t mpb_stomp_workspace_bytes(int P, int S, int H, int d) {
+    (void)H; (void)d;
+    if (P < 1 || S < 1) return 0;
+    const int nc = (S + FUSED_WAVES - 1) / FUSED_WAVES;
+    return fused_ws_floats(P, nc) * sizeof(float);
+}
+
+// can the persistent kernel serve this call?  (geom_flags: bit 8 = every chained field has a usable broad-phase grid)
+static bool fused_applicable(int geom_flags, int S, int H, int d, size_t ws_bytes, int P) {
+    if (H != 64 || S > FUSED_WAVES * FUSED_MAX_CHUNKS || !(geom_flags & 0x100)) return false;
+    if (d != 2 && d != 3 && d != 4 && d != 6 && d != 7 && d != 14) return false;
+    const int nc = (S + FUSED_WAVES - 1) / FUSED_WAVES;
+    return ws_bytes >= fused_ws_floats(P, nc) * sizeof(float);
+}
+
+extern "C" int mpb_stomp_step(float* means, const float* eps, float* samples, float* costs, float* weights,
+                              const float* L, const float* Sigma, const float* geom, int geom_flags, int P, int S, int H, int d, int D,
+                              float k_sigma, float weight, float lr, float temperature, int n_iters, uint64_t seed,
+                              uint32_t iter0, uint32_t particle_offset, void* stream);
+
+extern "C" int mpb_stomp_run(float* means, const float* eps, float* samples, float* costs, float* weights,
+                             const float* L, const float* Sigma, const float* geom, int geom_flags, float* workspace,
+                             size_t workspace_bytes, int P, int S, int H, int d, int D, float k_sigma, float weight, float lr,
+                             float temperature, int n_iters, uint64_t seed, uint32_t iter0, uint32_t particle_offset,
+                             void* stream) {
+    if (P == 0 || n_iters == 0) return MPB_OK;
+    if (!workspace || !fused_applicable(geom_flags, S, H, d, workspace_bytes, P))
+        return mpb_stomp_step(means, eps, samples, costs, weights, L, Sigma, geom, geom_flags, P, S, H, d, D, k_sigma, weight, lr,
+                              temperature, n_iters, seed, iter0, particle_offset, stream);
+    if (!means || !samples || !costs || !weights || !L || !Sigma || !geom) return mpb_fail(MPB_E_INVALID, "mpb_stomp_run: null pointer");
+    if (P < 0 || S < 1 || n_iters < 0 || !(d == D || d == 2 * D)) return mpb_fail(MPB_E_INVALID, "mpb_stomp_run: bad shape");
+    if (!(temperature > 0.f)) return mpb_fail(MPB_E_INVALID, "mpb_stomp_run: temperature must be > 0");
+    const int nc = (S + FUSED_WAVES - 1) / FUSED_WAVES;
+    hipStream_t st = (hipStream_t)stream;
+    // error word + flags start at zero for every call
+    const size_t head = (16 + ((size_t)P * nc + 15) / 16 * 16) * sizeof(float);
+    if (hipMemsetAsync(workspace, 0, head, st) != hipSuccess) return mpb_fail(MPB_E_HIP, "mpb_stomp_run: hipMemsetAsync failed");
+    const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
+    const dim3 grid(P * nc), block(FUSED_THREADS);
+    const int model = geom_flags & 0xFF;
+#define MPB_F_CASE(DCH, MODEL)                                                                                        \
+    hipLaunchKernelGGL((stomp_fused_kernel<DCH, MODEL>), grid, block, 0, st, means, eps, samples, costs, weights, L, \
+                       Sigma, geom, workspace, P, S, nc, k_sigma, weight, lr, temperature, n_iters, lo, hi, iter0,      \
+                       particle_offset)
+    if (model == PandaModel::ID && d == 7) MPB_F_CASE(7, PandaModel::ID);
+    else if (model == PandaModel::ID && d == 14) MPB_F_CASE(14, PandaModel::ID);
+    else if (d == 2) MPB_F_CASE(2, 0);
+    else if (d == 3) MPB_F_CASE(3, 0);
+    else if (d == 4) MPB_F_CASE(4, 0);
+    else if (d == 6) MPB_F_CASE(6, 0);
+    else if (d == 7) MPB_F_CASE(7, 0);
+    else MPB_F_CASE(14, 0);
+#undef MPB_F_CASE
+    return mpb_check_launch("mpb_stomp_run");
+}
+
+/* error word of the last mpb_stomp_run on this workspace (host-side read: synchronises the stream) */
+extern "C" int mpb_stomp_run_status(const float* workspace, void* stream, int* timed_out) {
+    if (!workspace || !timed_out) return mpb_fail(MPB_E_INVALID, "mpb_stomp_run_status: null pointer");
+    float w = 0.f;
+    if (hipMemcpyAsync(&w, workspace, sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+        hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+        return mpb_fail(MPB_E_HIP, "mpb_stomp_run_status: copy failed");
+    *timed_out = (w != 0.f) ? 1 : 0;
+    return MPB_OK;
+}

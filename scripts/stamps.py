@@ -16,15 +16,22 @@ means = wl['means0'].clone()
 samples = torch.empty(P, S, H, d, device=dev); costs = torch.empty(P, S, device=dev); weights = torch.empty(P, S, device=dev)
 ops.stomp_step(means, None, samples, costs, weights, L, Sigma, geom, S, 7, 1e6, 1.0, 0.1, 1.0, n_iters=30)
 torch.cuda.synchronize()
-ops.stomp_sample(means, None, samples, L, S, seed=0, it=99, geom=geom, costs=costs, k_sigma=1e6)
+ka_ms, kb_ms = ops.stomp_step_profile(means, samples, costs, weights, L, Sigma, geom, S, 7, 1e6, 1.0, 0.1, 1.0, n_iters=1, seed=0, iter0=99)
 torch.cuda.synchronize()
 h = ctypes.CDLL(_lib.LIB_PATH)
-buf = np.zeros(4096 * 8, dtype=np.uint64)
+buf = np.zeros(4096 * 10, dtype=np.uint64)
 assert h.mpb_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.size) == 0
-t = buf.reshape(4096, 8).astype(np.int64)
+tt = buf.reshape(4096, 10).astype(np.int64)
+t = tt[:, :8]
+rt = tt[:, 8:]
 t0 = t[:, 0].min()
-names = ['entry', 'L staged + barrier', 'philox', 'mfma + tile write', 'barrier', 'row + store', 'grid staged (2 barriers)', 'cost + reduce']
-print('kernel span (cycles @100MHz ticks?):', t[:, 7].max() - t0)
+names = ['entry', 'L + grid loads issued', 'philox', 'L -> LDS, barrier, mfma', 'barrier', 'tile, row + store', 'to the cost loop', 'cost + reduce']
+life = (t[:, 7] - t[:, 0]).astype(np.float64)
+rl = (rt[:, 1] - rt[:, 0]).astype(np.float64)       # 100 MHz ticks
+print('dispatch-event duration %.2f us; wave life: median %.2f us, max %.2f us (s_memrealtime); kernel span first entry -> last exit %.2f us'
+      % (ka_ms * 1e3, np.median(rl) / 100, rl.max() / 100, (rt[:, 1].max() - rt[:, 0].min()) / 100))
+print('shader clock during the kernel: median %.3f GHz (d s_memtime / d s_memrealtime)' % np.median(life / rl * 0.1))
+print('entry skew (s_memrealtime): p50 %.2f us, p99 %.2f us, max %.2f us' % tuple(np.percentile(rt[:, 0] - rt[:, 0].min(), [50, 99, 100]) / 100))
 d_ = np.diff(t, axis=1)
 print('start skew: median', np.median(t[:, 0] - t0), 'max', (t[:, 0] - t0).max())
 for k in range(7):
