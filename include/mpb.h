@@ -48,7 +48,8 @@ int mpb_geom_check(const float *geom_host, int n_words);
 /* Properties of a (valid) packed geometry buffer, read from its HOST copy, that let a launcher pick a kernel
  * instantiation without touching device memory.  *flags: bits 0-7 = id of the compile-time robot model
  * (csrc/mpb_model_*.h) every chained field is tagged with AND whose cost-only kernels can run (every field has a
- * usable broad-phase grid); 0 = generic table-driven kernels.  Entry points that take `geom_flags` expect the value
+ * usable broad-phase grid); 0 = generic table-driven kernels; bit 8 = every chained field has a usable broad-phase
+ * grid (what the persistent STOMP kernel needs).  Entry points that take `geom_flags` expect the value
  * computed from the host copy of the very buffer `geom` points to (0 is always valid); a kernel re-checks the tag
  * against the device header and writes NaN costs if they disagree. */
 int mpb_geom_flags(const float *geom_host, int n_words, int *flags);
@@ -173,6 +174,22 @@ int mpb_stomp_step_profile(float *means, float *samples, float *costs, float *we
                            float k_sigma, float weight, float lr, float temperature,
                            int n_iters, uint64_t seed, uint32_t iter0, uint32_t particle_offset, void *stream,
                            float *sample_kernel_ms, float *update_kernel_ms);
+/* The same loop as ONE persistent launch (csrc/mpb_stomp_fused.hip): a workgroup of 16 waves owns (particle, chunk of 16
+ * samples) for all n_iters iterations -- constants, means and the iteration's samples stay in LDS, the partners of a
+ * particle (S > 16) exchange their 3.6 KB partial sums through `workspace`; no per-iteration launch ramps or dispatch
+ * gaps.  Same arguments and outputs as mpb_stomp_step plus the caller-allocated workspace
+ * (mpb_stomp_workspace_bytes; contents need not be initialised).  Served for H = 64, S <= 64, grid-backed fields
+ * (geom_flags bit 8); any other call -- or workspace == NULL -- runs mpb_stomp_step.  The softmax is evaluated as
+ * exp(x - m) / z over per-chunk partials, the same weights up to rounding.  mpb_stomp_run_status reads the error word
+ * (a partner workgroup that never arrived within 2 s; synchronises the stream). */
+size_t mpb_stomp_workspace_bytes(int P, int S, int H, int d);
+int mpb_stomp_run(float *means, const float *eps, float *samples, float *costs, float *weights,
+                  const float *L, const float *Sigma, const float *geom, int geom_flags,
+                  float *workspace, size_t workspace_bytes,
+                  int P, int S, int H, int d, int D,
+                  float k_sigma, float weight, float lr, float temperature,
+                  int n_iters, uint64_t seed, uint32_t iter0, uint32_t particle_offset, void *stream);
+int mpb_stomp_run_status(const float *workspace, void *stream, int *timed_out);
 int mpb_stomp_sample(const float *means, const float *eps, float *samples, const float *L,
                      const float *geom, int geom_flags, float *costs, /* geom, costs both NULL: sample only; both set: fused cost */
                      int P, int S, int H, int d, float k_sigma, float weight,

@@ -35,6 +35,9 @@ SIGNATURES = {
     'mpb_field_cost_points': [_p, _p, _p, _i, _i, _p],
     'mpb_field_cost_points_vjp': [_p, _p, _p, _p, _i, _i, _p],
     'mpb_stomp_step': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _u64, _u32, _u32, _p],
+    'mpb_stomp_workspace_bytes': [_i, _i, _i, _i],
+    'mpb_stomp_run': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, ctypes.c_size_t, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _u64, _u32, _u32, _p],
+    'mpb_stomp_run_status': [_p, _p, _p],
     'mpb_stomp_step_profile': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _u64, _u32, _u32, _p, _p, _p],
     'mpb_stomp_sample': [_p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _f, _f, _u64, _u32, _u32, _p],
     'mpb_stomp_update': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
@@ -79,7 +82,7 @@ def lib():
             raise MPBError(f'{LIB_PATH} does not export {name} (declared in include/mpb.h)') from e
         fn.argtypes = argtypes
         fn.restype = (ctypes.c_char_p if name == 'mpb_last_error' else
-                      ctypes.c_size_t if name == 'mpb_gpmp2_workspace_bytes' else ctypes.c_int)
+                      ctypes.c_size_t if name in ('mpb_gpmp2_workspace_bytes', 'mpb_stomp_workspace_bytes') else ctypes.c_int)
     _lib = h
     return h
 

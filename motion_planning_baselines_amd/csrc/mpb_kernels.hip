@@ -146,15 +146,17 @@ extern "C" int mpb_geom_flags(const float* g, int n_words, int* flags) {
     const int rc = mpb_geom_check(g, n_words);
     if (rc) return rc;
     int model = -1;
+    bool all_grids = true;
     for (int off = 0;;) {
         const int32_t* gi = reinterpret_cast<const int32_t*>(g + off);
         const bool grid_ok = gi[26] > 0 && gi[26] <= MPB_GRID_MAX_CELLS && gi[6] <= MPB_GRID_MAX_SPH;   // grid_usable()
+        all_grids = all_grids && grid_ok;
         const int m = grid_ok ? gi[29] : 0;
         model = (model < 0 || model == m) ? m : 0;
         if (gi[27] == 0) break;
         off += gi[27];
     }
-    *flags = model > 0 ? (model & 0xFF) : 0;
+    *flags = (model > 0 ? (model & 0xFF) : 0) | (all_grids ? 0x100 : 0);
     return MPB_OK;
 }
 

@@ -61,7 +61,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
     __shared__ float cst[FUSED_WAVES];
     __shared__ int s_abort;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the wave index as a SCALAR: everything derived from it (sample index, tile and output base addresses) then sits in
+    // SGPRs, and per-lane addresses are a 32-bit offset from a uniform base instead of hoisted 64-bit VGPR pairs (which spill)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // unit of this block.  XCD-aware (speed only): blocks are dealt round-robin over the 8 XCDs, so blocks b and b + 8
     // share an L2 -- the nc chunks of a particle are given block indices 8 apart
     int p, chunk;
@@ -105,24 +107,23 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
     }
     __syncthreads();
 
-    // the matvec output this thread owns: element (hh, cc) of the trajectory
-    const int hh = (tid < N) ? tid / DCH : 0, cc = (tid < N) ? tid - hh * DCH : 0;
     const size_t eps_stride = (size_t)S * DCH * P * H;
 
-    // ---- noise of iteration 0
-    f32x4 acc[4];
+    // ---- noise of iteration 0: straight into the wave's tile ([waypoint][channel], stride NT_STRIDE)
+    float* nt = tiles + wave * (H * NT_STRIDE);
     {
         float e[16];
+        f32x4 acc[4];
         stomp_b_operand<DCH>(e, eps ? eps + (size_t)(live ? s : 0) * DCH * P * H : nullptr, P, p, j, g,
                              particle_offset + (uint32_t)p, (uint32_t)s, iter0, seed_lo, seed_hi);
         stomp_noise_product(Lp, e, j, g, acc);
+        stomp_noise_to_tile(nt, acc, lane);
     }
 
-    float* nt = tiles + wave * (H * NT_STRIDE);
     for (int it = 0; it < n_iters; ++it) {
         // ============ A. samples of this iteration: x = mean + noise, stored, kept packed in the wave's tile
         float nz[16];
-        stomp_noise_rows<DCH>(nt, acc, lane, nz);
+        stomp_noise_row<DCH>(nt, lane, nz);
         const int h = lane;
         const bool edge = (h == 0) || (h == H - 1);
         float x[DCH];
@@ -133,11 +134,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         __builtin_amdgcn_wave_barrier();
         if (live) {
             const f32x4* pk4 = reinterpret_cast<const f32x4*>(nt);
-            f32x4* out4 = reinterpret_cast<f32x4*>(samples + ((size_t)p * S + s) * N);
+            f32x4* out4 = reinterpret_cast<f32x4*>(samples + ((size_t)p * S + s) * N);     // uniform
 #pragma unroll
             for (int k = 0; k < (16 * DCH + 63) / 64; ++k) {
-                const int idx = lane + 64 * k;
-                if (idx < 16 * DCH) out4[idx] = pk4[idx];
+                const unsigned idx = (unsigned)lane + 64u * k;
+                if (idx < 16u * DCH) out4[idx] = pk4[idx];
             }
         }
         // ============ B. collision cost of the rollout
@@ -182,39 +183,51 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         }
         __syncthreads();                                                                        // (1) costs of the chunk
         // ============ C. partial of this chunk: logits, local max, e_w, z, weighted (sample - mean)
-        const int sl = chunk * FUSED_WAVES + (lane & 15);                   // every wave redundantly, lanes 0-15 carry the chunk
-        const float xs = (lane < FUSED_WAVES && sl < S) ? -cst[lane & 15] / temperature : -3.0e38f;
+        // (thread-index arithmetic of the update phases is redone here from an opaque copy: hoisted out of the loop it
+        // would sit in registers through the cost phase, which has none to spare)
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+        const int lq = tq & 63;
+        const int hh = (tq < N) ? tq / DCH : 0, cc = (tq < N) ? tq - hh * DCH : 0;   // the trajectory element this thread owns
+        const int sl = chunk * FUSED_WAVES + (lq & 15);                     // every wave redundantly, lanes 0-15 carry the chunk
+        const float xs = (lq < FUSED_WAVES && sl < S) ? -cst[lq & 15] / temperature : -3.0e38f;
         const float mb = wave_max_f32(xs);
-        const float ex = (lane < FUSED_WAVES && sl < S) ? expf(xs - mb) : 0.f;
+        const float ex = (lq < FUSED_WAVES && sl < S) ? expf(xs - mb) : 0.f;
         const float zb = wave_sum_f32(ex);
         float dpart = 0.f;
-        if (tid < N) {
-            const float mu = mean_l[tid];
+        if (tq < N) {
+            const float mu = mean_l[tq];
 #pragma unroll
             for (int w = 0; w < FUSED_WAVES; ++w) {
                 const float ew = readlane_f32(ex, w);
-                dpart = fmaf(ew, tiles[w * (H * NT_STRIDE) + tid] - mu, dpart);
+                dpart = fmaf(ew, tiles[w * (H * NT_STRIDE) + tq] - mu, dpart);
             }
         }
         float m_all = mb, z_all = zb, f_own = 1.f;
         if (nc > 1) {
             // ============ D. publish (sc1 stores), flag, then -- before polling -- the noise of the next iteration
             float* mine = xch + ((size_t)(it & 1) * P * nc + (size_t)p * nc + chunk) * FUSED_XCHG;
-            if (tid < N) st_agent(mine + 4 + tid, dpart);
-            if (tid == 0) { st_agent(mine + 0, mb); st_agent(mine + 1, zb); }
+            if (tq < N) st_agent(mine + 4 + tq, dpart);
+            if (tq == 0) { st_agent(mine + 0, mb); st_agent(mine + 1, zb); }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                                                                    // (2) every store of the block is out
-            if (tid == 0) st_agent_u(flags + (size_t)p * nc + chunk, (unsigned)(it + 1));
         }
+        __syncthreads();                                                     // (2) every store of the block is out; tiles consumed
+        if (nc > 1 && tq == 0) st_agent_u(flags + (size_t)p * nc + chunk, (unsigned)(it + 1));
         if (it + 1 < n_iters) {
             float e[16];
-            stomp_b_operand<DCH>(e, eps ? eps + (size_t)(it + 1) * eps_stride + (size_t)(live ? s : 0) * DCH * P * H : nullptr, P, p, j, g,
+            f32x4 acc[4];
+            // (opaque copies: the first Philox round multiplies two counter words that do not change from one iteration to
+            // the next, and the compiler would hoist those products out of the loop and keep -- spill -- them)
+            int jv = j, gv = g;
+            asm volatile("" : "+v"(jv), "+v"(gv));
+            stomp_b_operand<DCH>(e, eps ? eps + (size_t)(it + 1) * eps_stride + (size_t)(live ? s : 0) * DCH * P * H : nullptr, P, p, jv, gv,
                                  particle_offset + (uint32_t)p, (uint32_t)s, iter0 + (uint32_t)(it + 1), seed_lo, seed_hi);
             stomp_noise_product(Lp, e, j, g, acc);
+            stomp_noise_to_tile(nt, acc, lane);           // (the samples packed in the tile were consumed before barrier 2)
         }
         float dsum = dpart;
         if (nc > 1) {
-            if (tid == 0) {
+            if (tq == 0) {
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 for (int k = 0; k < nc; ++k) {
                     if (k == chunk) continue;
@@ -235,7 +248,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
                     const float* theirs = xch + ((size_t)(it & 1) * P * nc + (size_t)p * nc + k) * FUSED_XCHG;
                     mk[k] = (k == chunk) ? mb : ld_agent(theirs + 0);
                     zk[k] = (k == chunk) ? zb : ld_agent(theirs + 1);
-                    dk[k] = (k == chunk) ? dpart : ((tid < N) ? ld_agent(theirs + 4 + tid) : 0.f);
+                    dk[k] = (k == chunk) ? dpart : ((tq < N) ? ld_agent(theirs + 4 + tq) : 0.f);
                 }
             }
             m_all = mk[0];
@@ -254,10 +267,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
             }
         }
         // ============ E. weights out, delta (transposed) -> mean += lr * Sigma @ delta
-        if (tid < FUSED_WAVES && sl < S) weights[(size_t)p * S + sl] = ex * f_own / z_all;
-        if (tid < N) delta[cc * FUSED_LD + hh] = dsum / z_all;
+        if (tq < FUSED_WAVES && sl < S) weights[(size_t)p * S + sl] = ex * f_own / z_all;
+        if (tq < N) delta[cc * FUSED_LD + hh] = dsum / z_all;
         __syncthreads();                                                                        // (4) delta complete
-        if (tid < N) {
+        if (tq < N) {
             float a4[4] = {0.f, 0.f, 0.f, 0.f};
             const float4* dcol = reinterpret_cast<const float4*>(delta + cc * FUSED_LD);
             const float4* srow = reinterpret_cast<const float4*>(sig_l + hh * FUSED_LD);
@@ -269,7 +282,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
                 a4[k & 3] = fmaf(sv.z, dv.z, a4[k & 3]);
                 a4[k & 3] = fmaf(sv.w, dv.w, a4[k & 3]);
             }
-            mean_l[tid] += lr * ((a4[0] + a4[1]) + (a4[2] + a4[3]));
+            mean_l[tq] += lr * ((a4[0] + a4[1]) + (a4[2] + a4[3]));
         }
         __syncthreads();                                                                        // (5) new mean visible, tiles free
     }
@@ -309,6 +322,8 @@ extern "C" int mpb_stomp_run(float* means, const float* eps, float* samples, flo
                              float temperature, int n_iters, uint64_t seed, uint32_t iter0, uint32_t particle_offset,
                              void* stream) {
     if (P == 0 || n_iters == 0) return MPB_OK;
+    if (workspace && workspace_bytes >= 64 && !fused_applicable(geom_flags, S, H, d, workspace_bytes, P))
+        (void)hipMemsetAsync(workspace, 0, 64, (hipStream_t)stream);       // the status word reads "ok" after the fallback too
     if (!workspace || !fused_applicable(geom_flags, S, H, d, workspace_bytes, P))
         return mpb_stomp_step(means, eps, samples, costs, weights, L, Sigma, geom, geom_flags, P, S, H, d, D, k_sigma, weight, lr,
                               temperature, n_iters, seed, iter0, particle_offset, stream);

@@ -85,3 +85,23 @@ __device__ __forceinline__ void stomp_noise_rows(float* __restrict__ nt, const f
     }
     __builtin_amdgcn_wave_barrier();
 }
+
+// the two halves of stomp_noise_rows for callers that park the noise in the tile between producing and consuming it
+__device__ __forceinline__ void stomp_noise_to_tile(float* __restrict__ nt, const f32x4 (&acc)[4], int lane) {
+    const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) nt[(16 * m + 4 * g + rr) * NT_STRIDE + j] = acc[m][rr];
+    __builtin_amdgcn_wave_barrier();
+}
+template <int DCH>
+__device__ __forceinline__ void stomp_noise_row(const float* __restrict__ nt, int lane, float (&nz)[16]) {
+    const f32x4* row = reinterpret_cast<const f32x4*>(nt + lane * NT_STRIDE);
+#pragma unroll
+    for (int v = 0; v < (DCH + 3) / 4; ++v) {
+        const f32x4 t = row[v];
+        nz[4 * v + 0] = t[0]; nz[4 * v + 1] = t[1]; nz[4 * v + 2] = t[2]; nz[4 * v + 3] = t[3];
+    }
+    __builtin_amdgcn_wave_barrier();
+}

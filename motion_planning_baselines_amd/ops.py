@@ -286,6 +286,44 @@ def stomp_step(means, eps, samples, costs, weights, L, Sigma, geom, S, D, k_sigm
         int(seed) & (2 ** 64 - 1), int(iter0), int(particle_offset), _stream()), 'mpb_stomp_step')
 
 
+def stomp_workspace(P, S, H, d, device):
+    """Exchange buffer of the persistent STOMP kernel (mpb_stomp_run); contents need not be initialised."""
+    n = int(_lib.lib().mpb_stomp_workspace_bytes(int(P), int(S), int(H), int(d)))
+    return torch.empty((n + 3) // 4, device=device, dtype=torch.float32)
+
+
+@_on_tensor_device
+def stomp_run(means, eps, samples, costs, weights, L, Sigma, geom, S, D, k_sigma, weight, lr, temperature, workspace,
+              n_iters=1, seed=0, iter0=0, particle_offset=0):
+    """stomp_step as ONE persistent launch where the shape allows it (H = 64, S <= 64, grid-backed fields), the
+    two-kernel loop otherwise (the C side decides)."""
+    P, H, d = means.shape
+    _chk(means, (P, H, d), 'means')
+    _chk(samples, (P, S, H, d), 'samples')
+    _chk(costs, (P, S), 'costs')
+    _chk(weights, (P, S), 'weights')
+    _chk(L, (H, H), 'L')
+    _chk(Sigma, (H, H), 'Sigma')
+    if eps is not None:
+        _chk(eps, (n_iters, S, d, P, H), 'eps')
+    if workspace is not None:
+        _chk(workspace, tuple(workspace.shape), 'workspace')
+    _lib.check(_lib.lib().mpb_stomp_run(
+        _ptr(means), _ptr(eps), _ptr(samples), _ptr(costs), _ptr(weights), _ptr(L), _ptr(Sigma), _ptr(geom.buf),
+        int(geom.flags), _ptr(workspace), 0 if workspace is None else workspace.numel() * 4,
+        P, S, H, d, D, float(k_sigma), float(weight), float(lr), float(temperature), int(n_iters),
+        int(seed) & (2 ** 64 - 1), int(iter0), int(particle_offset), _stream()), 'mpb_stomp_run')
+
+
+def stomp_run_timed_out(workspace):
+    """Did a workgroup of the last stomp_run on this workspace give up waiting for its partner?  (synchronises)"""
+    out = ctypes.c_int(0)
+    with torch.cuda.device(workspace.device):
+        _lib.check(_lib.lib().mpb_stomp_run_status(_ptr(workspace), _stream(), ctypes.cast(ctypes.pointer(out), ctypes.c_void_p)),
+                   'mpb_stomp_run_status')
+    return bool(out.value)
+
+
 @_on_tensor_device
 def stomp_step_profile(means, samples, costs, weights, L, Sigma, geom, S, D, k_sigma, weight, lr, temperature,
                        n_iters=50, seed=0, iter0=0, particle_offset=0):

@@ -43,13 +43,15 @@ class STOMP(OptimizationPlanner):
              reference's (S,d,P,H) order, so that `torch.manual_seed(s)` reproduces a CPU reference run
              bit for bit in the noise; 'torch' -- same draw on the planner's device.
       seed / particle_offset: Philox key and global index of this shard's first particle.
+      persistent: run a collision-only cost's loop as ONE persistent launch (mpb_stomp_run) where the shape allows it
+             (default); False keeps the two-kernels-per-iteration path (mpb_stomp_step).
     """
 
     def __init__(self, n_dof, n_support_points, num_particles_per_goal, num_samples, opt_iters, dt, start_state,
                  cost=None, initial_particle_means=None, multi_goal_states=None, sigma_start_init=0.001,
                  sigma_goal_init=0.001, sigma_gp_init=10., temperature=1., step_size=1., sigma_spectral=0.1,
                  goal_state=None, pos_only=True, tensor_args=None, noise='philox', seed=0, particle_offset=0,
-                 **kwargs):
+                 persistent=True, **kwargs):
         super().__init__(name='STOMP', n_dof=n_dof, n_support_points=n_support_points,
                          num_particles_per_goal=num_particles_per_goal, opt_iters=opt_iters, dt=dt,
                          start_state=start_state, cost=cost, initial_particle_means=initial_particle_means,
@@ -68,6 +70,8 @@ class STOMP(OptimizationPlanner):
         self.particle_offset = int(particle_offset)
         self._iter = 0
         self._weights = None
+        self._run_ws = None              # exchange buffer of the persistent kernel (allocated on first use)
+        self.persistent = bool(persistent)
         # constants on the CPU with the reference's own op sequence, then moved (H2)
         cpu = dict(device='cpu', dtype=torch.float32)
         R = stomp_precision_matrix(n_support_points, dt, sigma_spectral, cpu)
@@ -153,10 +157,16 @@ class STOMP(OptimizationPlanner):
         if fused is not None and not observation:
             cc, weight = fused
             eps = self._draw_eps(opt_iters)
-            ops.stomp_step(self._particle_means, eps, self.state_particles, self.costs, self._weights_buf,
-                           self.scale_tril, self.Sigma, cc.device_geometry(self.device), self.num_samples,
-                           self.n_dof, cc.k_sigma, weight, self.lr, self.temperature, n_iters=opt_iters,
-                           seed=self.seed, iter0=self._iter, particle_offset=self.particle_offset)
+            # the whole loop as one persistent launch where the shape allows it (H = 64, S <= 64, grid-backed fields);
+            # mpb_stomp_run falls back to the two-kernel loop by itself otherwise
+            if self._run_ws is None:
+                self._run_ws = ops.stomp_workspace(self.num_particles, self.num_samples, self.n_support_points,
+                                                   self.d_state_opt, self.device)
+            ops.stomp_run(self._particle_means, eps, self.state_particles, self.costs, self._weights_buf,
+                          self.scale_tril, self.Sigma, cc.device_geometry(self.device), self.num_samples,
+                          self.n_dof, cc.k_sigma, weight, self.lr, self.temperature,
+                          self._run_ws if self.persistent else None, n_iters=opt_iters,
+                          seed=self.seed, iter0=self._iter, particle_offset=self.particle_offset)
             self._iter += opt_iters
         elif not observation and device_plan(self.cost, self.device) is not None:
             # composite of HIP-served members: sample(+collision) kernel -> trajectory-terms kernel(s) -> update

@@ -1,0 +1,150 @@
+"""-m gpu: the persistent one-launch STOMP loop (csrc/mpb_stomp_fused.hip, mpb_stomp_run) against the reference-generated
+goldens, against the oracle, and against the two-kernel path (mpb_stomp_step) it replaces where the shape allows."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, ref_geometry_from_golden
+from test_gpu_parity_ops import (REL, STOMP_CASES, T, _stomp_bufs, dev_geom, reference_fp32_envelope,
+                                 reference_fp32_envelope_one_iteration, rel_err)
+
+pytestmark = pytest.mark.gpu
+
+
+def _ws(P, S, H, d, dev):
+    from motion_planning_baselines_amd import ops
+    return ops.stomp_workspace(P, S, H, d, dev)
+
+
+@pytest.mark.parametrize('name', STOMP_CASES)
+def test_stomp_run_teacher_forced_vs_golden(gpu_device, name):
+    """One pass of the loop body from the reference's own iterate, through mpb_stomp_run (H = 64 cases run the
+    persistent kernel, the others its two-kernel fallback): samples, costs, weights, means against the golden."""
+    from motion_planning_baselines_amd import ops
+    g = load_golden(name)
+    dev = gpu_device
+    P, S, H, d, samples, costs, weights = _stomp_bufs(g, dev)
+    geom = dev_geom(g, dev)
+    ws = _ws(P, S, H, d, dev)
+    L, Sigma = T(g['L']).to(dev), T(g['Sigma']).to(dev)
+    ksig = 1.0 / float(g['sigma_coll']) ** 2
+    prev = T(g['means0'])
+    for it in range(g['eps'].shape[0]):
+        means = prev.clone().to(dev)
+        eps = T(g['eps'][it:it + 1]).contiguous().to(dev)
+        ops.stomp_run(means, eps, samples, costs, weights, L, Sigma, geom, S, int(g['D']), ksig, 1.0,
+                      float(g['lr']), float(g['temperature']), ws)
+        torch.cuda.synchronize()
+        assert not ops.stomp_run_timed_out(ws)
+        assert rel_err(samples, T(g['samples'][it])) < 2e-5, it
+        np.testing.assert_allclose(costs.cpu().numpy(), T(g['costs'][it]).numpy(), rtol=5e-5, atol=1e-6 * ksig)
+        cond = float(ksig) * 1e-6
+        if cond < 1e-2:
+            np.testing.assert_allclose(weights.cpu().numpy(), T(g['weights'][it]).numpy(), rtol=1e-3, atol=1e-5)
+        bar = REL if cond < 1e-2 else max(REL, 2.0 * reference_fp32_envelope_one_iteration(g, it))
+        assert rel_err(means, T(g['means'][it])) < bar, (it, bar)
+        prev = T(g['means'][it])
+
+
+@pytest.mark.parametrize('name', STOMP_CASES)
+def test_stomp_run_free_running_vs_golden(gpu_device, name):
+    """All iterations in ONE launch from means0 on the reference's injected noise: north_star's criterion."""
+    from motion_planning_baselines_amd import ops
+    g = load_golden(name)
+    dev = gpu_device
+    P, S, H, d, samples, costs, weights = _stomp_bufs(g, dev)
+    n = g['eps'].shape[0]
+    ws = _ws(P, S, H, d, dev)
+    means = T(g['means0']).clone().to(dev)
+    ops.stomp_run(means, T(g['eps']).contiguous().to(dev), samples, costs, weights, T(g['L']).to(dev),
+                  T(g['Sigma']).to(dev), dev_geom(g, dev), S, int(g['D']), 1.0 / float(g['sigma_coll']) ** 2, 1.0,
+                  float(g['lr']), float(g['temperature']), ws, n_iters=n)
+    torch.cuda.synchronize()
+    assert not ops.stomp_run_timed_out(ws)
+    err = rel_err(means, T(g['means'][-1]))
+    env = reference_fp32_envelope(g)
+    print(name, 'final-waypoint rel err', err, 'reference fp32-vs-fp64 envelope', env)
+    assert err < max(REL, 2.0 * env)
+    if name != 'stomp_panda_benign':
+        assert err < REL
+
+
+@pytest.mark.parametrize('P,S,pos_only,n_iters', [
+    (128, 32, False, 4),     # C3: two workgroups per particle, the chip filled once
+    (8, 16, False, 3),       # one workgroup per particle: no exchange
+    (8, 64, True, 3),        # four workgroups per particle, d = 7
+    (3, 30, False, 3),       # the reference example's S = 30: a partial last chunk; P not a multiple of 8
+    (5, 5, True, 2),         # a quarter of one chunk
+    (300, 32, False, 2)])    # more units than CUs: workgroups run in rounds, partners are still co-scheduled
+def test_stomp_run_equals_two_kernel_path(gpu_device, P, S, pos_only, n_iters):
+    """Same device noise (Philox keyed by particle / sample / iteration), same geometry.
+    (a) One iteration: the persistent kernel and the two-kernel loop write the same samples and costs bit for bit and
+        agree on weights and means to rounding (the persistent kernel combines per-chunk softmax partials:
+        exp(x - m) / z in a different association).
+    (b) n iterations in ONE persistent launch == n launches of one iteration each, bit for bit: the in-launch
+        hand-off between the workgroups of a particle (parity buffers, flags, next-iteration noise drawn early)
+        changes nothing.  (Comparing n free-running iterations across the two PATHS is not a test of either: the loop
+        amplifies a 1e-6 difference of the weights ~1e3-fold per iteration at these cost scales.)"""
+    from motion_planning_baselines_amd import ops, workloads
+    from motion_planning_baselines_amd.planners.stomp import precision_to_scale_tril, stomp_precision_matrix
+    dev = gpu_device
+    H = 64
+    wl = workloads.panda_spheres_stomp(P, dev, H=H, S=S, pos_only=pos_only)
+    d = wl['means0'].shape[-1]
+    cpu = dict(device='cpu', dtype=torch.float32)
+    R = stomp_precision_matrix(H, wl['params']['dt'], 0.02, cpu)
+    Sigma, L = torch.inverse(R).to(dev).contiguous(), precision_to_scale_tril(R).to(dev).contiguous()
+    geom = ops.DeviceGeometry(wl['robot'], wl['field'], dev)
+    mk = lambda: (torch.empty(P, S, H, d, device=dev), torch.empty(P, S, device=dev), torch.empty(P, S, device=dev))
+    ws = _ws(P, S, H, d, dev)
+    args = (L, Sigma, geom, S, 7, 1e6, 1.0, 0.1, 1e5)
+    # (a)
+    mf, (sf, cf, wf) = wl['means0'].clone(), mk()
+    ops.stomp_run(mf, None, sf, cf, wf, *args, ws, n_iters=1, seed=11)
+    mt, (st, ct, wt) = wl['means0'].clone(), mk()
+    ops.stomp_step(mt, None, st, ct, wt, *args, n_iters=1, seed=11)
+    torch.cuda.synchronize()
+    assert not ops.stomp_run_timed_out(ws)
+    assert float(ct.max()) > 0
+    assert torch.equal(sf, st) and torch.equal(cf, ct)
+    np.testing.assert_allclose(wf.cpu().numpy(), wt.cpu().numpy(), rtol=2e-5, atol=1e-7)
+    assert rel_err(mf, mt) < 2e-6
+    # (b)
+    m1, (s1, c1, w1) = wl['means0'].clone(), mk()
+    ops.stomp_run(m1, None, s1, c1, w1, *args, ws, n_iters=n_iters, seed=11, iter0=5)
+    torch.cuda.synchronize()
+    assert not ops.stomp_run_timed_out(ws)
+    m2, (s2, c2, w2) = wl['means0'].clone(), mk()
+    for it in range(n_iters):
+        ops.stomp_run(m2, None, s2, c2, w2, *args, ws, n_iters=1, seed=11, iter0=5 + it)
+    torch.cuda.synchronize()
+    assert torch.equal(m1, m2) and torch.equal(s1, s2) and torch.equal(c1, c2) and torch.equal(w1, w2)
+    assert torch.isfinite(m1).all()
+
+
+def test_stomp_run_pointmass_generic_model(gpu_device):
+    """The generic (table-driven) instantiation: C1's point-mass problem, d = 4, S = 4 (a quarter chunk)."""
+    from motion_planning_baselines_amd import ops, workloads
+    from motion_planning_baselines_amd.planners.stomp import precision_to_scale_tril, stomp_precision_matrix
+    dev = gpu_device
+    wl = workloads.pointmass_grid_circles_stomp(dev)
+    P, H, d = wl['means0'].shape
+    S = wl['params']['num_samples']
+    cpu = dict(device='cpu', dtype=torch.float32)
+    R = stomp_precision_matrix(H, wl['params']['dt'], 0.1, cpu)
+    Sigma, L = torch.inverse(R).to(dev).contiguous(), precision_to_scale_tril(R).to(dev).contiguous()
+    geom = ops.DeviceGeometry(wl['robot'], wl['field'], dev)
+    res = []
+    for fused in (True, False):
+        means = wl['means0'].clone()
+        samples = torch.empty(P, S, H, d, device=dev)
+        costs, weights = torch.empty(P, S, device=dev), torch.empty(P, S, device=dev)
+        if fused:
+            ws = _ws(P, S, H, d, dev)
+            ops.stomp_run(means, None, samples, costs, weights, L, Sigma, geom, S, 2, 1e6, 1.0, 0.1, 1e5, ws, n_iters=5, seed=2)
+        else:
+            ops.stomp_step(means, None, samples, costs, weights, L, Sigma, geom, S, 2, 1e6, 1.0, 0.1, 1e5, n_iters=5, seed=2)
+        torch.cuda.synchronize()
+        res.append((means, samples, costs))
+    assert rel_err(res[0][0], res[1][0]) < 2e-5 and rel_err(res[0][1], res[1][1]) < 2e-5
+    np.testing.assert_allclose(res[0][2].cpu().numpy(), res[1][2].cpu().numpy(), rtol=1e-3, atol=1e-2)
