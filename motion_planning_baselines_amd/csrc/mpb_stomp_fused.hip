@@ -42,6 +42,25 @@ static inline size_t fused_ws_floats(int P, int nc) {
     return 16 + flags + 2 * (size_t)P * nc * FUSED_XCHG;
 }
 
+#ifdef MPB_STAMPS   // diagnostic build only: s_memtime per wave at the phase boundaries of iteration 2
+__device__ unsigned long long g_fstamps[256 * FUSED_WAVES * 12];
+#define FSTAMP(k)                                                                                   \
+    do {                                                                                            \
+        if (it == 2 && blockIdx.x < 256) {                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                      \
+            unsigned long long t_;                                                                  \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+            __builtin_amdgcn_sched_barrier(0);                                                      \
+            if ((threadIdx.x & 63) == 0) g_fstamps[(blockIdx.x * FUSED_WAVES + (threadIdx.x >> 6)) * 12 + (k)] = t_; \
+        }                                                                                           \
+    } while (0)
+extern "C" int mpb_debug_read_fstamps(unsigned long long* dst, int n) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_fstamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : 3;
+}
+#else
+#define FSTAMP(k)
+#endif
+
 template <int DCH, int MODEL>
 __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
     float* __restrict__ means, const float* __restrict__ eps, float* __restrict__ samples, float* __restrict__ costs,
@@ -122,6 +141,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
 
     for (int it = 0; it < n_iters; ++it) {
         // ============ A. samples of this iteration: x = mean + noise, stored, kept packed in the wave's tile
+        FSTAMP(0);
         float nz[16];
         stomp_noise_row<DCH>(nt, lane, nz);
         const int h = lane;
@@ -142,6 +162,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
             }
         }
         // ============ B. collision cost of the rollout
+        FSTAMP(1);
         {
             float q[MPB_MAX_DOF];
 #pragma unroll
@@ -181,7 +202,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
                 }
             }
         }
+        FSTAMP(2);
         __syncthreads();                                                                        // (1) costs of the chunk
+        FSTAMP(3);
         // ============ C. partial of this chunk: logits, local max, e_w, z, weighted (sample - mean)
         // (thread-index arithmetic of the update phases is redone here from an opaque copy: hoisted out of the loop it
         // would sit in registers through the cost phase, which has none to spare)
@@ -204,6 +227,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
             }
         }
         float m_all = mb, z_all = zb, f_own = 1.f;
+        FSTAMP(4);
         if (nc > 1) {
             // ============ D. publish (sc1 stores), flag, then -- before polling -- the noise of the next iteration
             float* mine = xch + ((size_t)(it & 1) * P * nc + (size_t)p * nc + chunk) * FUSED_XCHG;
@@ -213,7 +237,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         }
         __syncthreads();                                                     // (2) every store of the block is out; tiles consumed
         if (nc > 1 && tq == 0) st_agent_u(flags + (size_t)p * nc + chunk, (unsigned)(it + 1));
+        FSTAMP(5);
         if (it + 1 < n_iters) {
+            // the noise of the NEXT iteration (it does not depend on the means) is drawn here, between publishing and polling:
+            // the partner's latency.  (Drawing it before barrier 1, to fill the wait for the block's slowest rollout, was
+            // measured slower: the SIMD's VALU is the bottleneck there, the early waves only starve the late ones.)
             float e[16];
             f32x4 acc[4];
             // (opaque copies: the first Philox round multiplies two counter words that do not change from one iteration to
@@ -226,6 +254,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
             stomp_noise_to_tile(nt, acc, lane);           // (the samples packed in the tile were consumed before barrier 2)
         }
         float dsum = dpart;
+        FSTAMP(6);
         if (nc > 1) {
             if (tq == 0) {
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -238,17 +267,19 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
                 }
             }
             __syncthreads();                                                                    // (3) partners have published
+            FSTAMP(7);
             if (s_abort) break;                                                                 // block-uniform
-            // combine the nc partials in chunk order (own partial from registers: the very bits the partners read)
+            // combine the nc partials in chunk order; the own partial is read back like the partners' (the very bits they read)
             float mk[FUSED_MAX_CHUNKS], zk[FUSED_MAX_CHUNKS], dk[FUSED_MAX_CHUNKS];
+            const float* slot0 = xch + ((size_t)(it & 1) * P * nc + (size_t)p * nc) * FUSED_XCHG;
 #pragma unroll
             for (int k = 0; k < FUSED_MAX_CHUNKS; ++k) {
                 mk[k] = -3.0e38f; zk[k] = 0.f; dk[k] = 0.f;
                 if (k < nc) {
-                    const float* theirs = xch + ((size_t)(it & 1) * P * nc + (size_t)p * nc + k) * FUSED_XCHG;
-                    mk[k] = (k == chunk) ? mb : ld_agent(theirs + 0);
-                    zk[k] = (k == chunk) ? zb : ld_agent(theirs + 1);
-                    dk[k] = (k == chunk) ? dpart : ((tq < N) ? ld_agent(theirs + 4 + tq) : 0.f);
+                    const float* theirs = slot0 + (size_t)k * FUSED_XCHG;
+                    mk[k] = ld_agent(theirs + 0);
+                    zk[k] = ld_agent(theirs + 1);
+                    dk[k] = (tq < N) ? ld_agent(theirs + 4 + tq) : 0.f;
                 }
             }
             m_all = mk[0];
@@ -262,14 +293,16 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
                     const float f = expf(mk[k] - m_all);
                     z_all = fmaf(f, zk[k], z_all);
                     dsum = fmaf(f, dk[k], dsum);
-                    if (k == chunk) f_own = f;
                 }
             }
+            f_own = expf(mb - m_all);
         }
+        FSTAMP(8);
         // ============ E. weights out, delta (transposed) -> mean += lr * Sigma @ delta
         if (tq < FUSED_WAVES && sl < S) weights[(size_t)p * S + sl] = ex * f_own / z_all;
         if (tq < N) delta[cc * FUSED_LD + hh] = dsum / z_all;
         __syncthreads();                                                                        // (4) delta complete
+        FSTAMP(9);
         if (tq < N) {
             float a4[4] = {0.f, 0.f, 0.f, 0.f};
             const float4* dcol = reinterpret_cast<const float4*>(delta + cc * FUSED_LD);
@@ -284,7 +317,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
             }
             mean_l[tq] += lr * ((a4[0] + a4[1]) + (a4[2] + a4[3]));
         }
+        FSTAMP(10);
         __syncthreads();                                                                        // (5) new mean visible, tiles free
+        FSTAMP(11);
     }
     if (s_abort) {
         if (tid == 0) st_agent(err_word, 1.0f);

@@ -15,6 +15,11 @@ geom = ops.DeviceGeometry(wl['robot'], wl['field'], dev)
 means = wl['means0'].clone()
 samples = torch.empty(P, S, H, d, device=dev); costs = torch.empty(P, S, device=dev); weights = torch.empty(P, S, device=dev)
 n = int(os.environ.get('MPB_ITERS', 20))
-ops.stomp_step(means, None, samples, costs, weights, L, Sigma, geom, S, 7, 1e6, 1.0, 0.1, 1.0, n_iters=n)
+if os.environ.get('MPB_FUSED'):      # the persistent one-launch loop: a few launches of n iterations each
+    ws = ops.stomp_workspace(P, S, H, d, dev)
+    for _ in range(int(os.environ.get('MPB_LAUNCHES', 6))):
+        ops.stomp_run(means, None, samples, costs, weights, L, Sigma, geom, S, 7, 1e6, 1.0, 0.1, 1.0, ws, n_iters=n)
+else:
+    ops.stomp_step(means, None, samples, costs, weights, L, Sigma, geom, S, 7, 1e6, 1.0, 0.1, 1.0, n_iters=n)
 torch.cuda.synchronize()
 print('done', float(costs.mean()))
