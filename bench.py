@@ -8,7 +8,8 @@
 Main line (every N): per GPU, panda_spheres STOMP, P=128 particles x S=32 samples = B=4096 rollouts, H=64 support
 points, D=7 (Panda FK + 31 robot collision spheres vs 16 obstacle spheres), the reference example's parameters
 (pos_only=False -> d=14, sigma_coll=1e-3, lr=0.1, T=1), on-device Philox noise.  A "step" is one pass of the planner's
-loop body (stomp.py:157-160) over the whole batch; inputs are resident in HBM before the timed region.  The K steps
+loop body (stomp.py:157-160) over the whole batch -- all K steps run inside ONE persistent launch (mpb_stomp_run,
+csrc/mpb_stomp_fused.hip); inputs are resident in HBM before the timed region.  The K steps
 are timed R times (--repeats, default 5), each block bracketed by barrier + synchronize and reduced with MAX over the
 ranks; `ms_per_step` / `value` are the MEDIAN block, min / max are reported next to it.  N > 1: every rank runs its own
 128 start/goal problems (weak scaling, no data-path collective), the final means are all-gathered over RCCL inside
@@ -141,6 +142,15 @@ def make_stomp(P, S, dev, rank, pos_only=False):
                     initial_particle_means=wl['means0'], tensor_args=ta, noise='philox', seed=0,
                     particle_offset=rank * P, **prm)
     return wl, cost, planner
+
+
+def STOMP_two_kernel(wl, cost, dev, rank, P):
+    """The same planner on the two-kernels-per-iteration path (persistent=False), for the comparison entry."""
+    from motion_planning_baselines_amd.planners.stomp import STOMP
+    ta = dict(device=dev, dtype=torch.float32)
+    return STOMP(opt_iters=1, start_state=torch.from_numpy(wl['starts'][0]).to(dev), cost=cost,
+                 initial_particle_means=wl['means0'], tensor_args=ta, noise='philox', seed=0,
+                 particle_offset=rank * P, persistent=False, **wl['params'])
 
 
 def run_stomp(planner, clock, dist, world, steps, warmup, repeats, preheat):
@@ -320,8 +330,6 @@ def main():
             dist.init_process_group(backend)
     clock = Clock(dist, dev)
 
-    from motion_planning_baselines_amd import ops
-
     P, S = args.particles, args.samples
     wl, cost, planner = make_stomp(P, S, dev, rank, args.pos_only)
     prm = wl['params']
@@ -329,65 +337,60 @@ def main():
     blocks = run_stomp(planner, clock, dist, world, args.steps, args.warmup, args.repeats, preheat=500)
     elapsed, sp = spread(blocks, args.steps)
 
-    # ---- the dominant kernel (sample + cost), measured live with events on the launch stream
+    # ---- the dominant kernel, measured live with events on the launch stream.  The whole loop is ONE launch of the
+    # persistent kernel (csrc/mpb_stomp_fused.hip): its duration / K is the per-iteration kernel time; a launch of
+    # 2K iterations minus a launch of K removes the fixed part (launch + constants into LDS)
     geom = cost.cost_l[0].device_geometry(dev)
-    n_prof = min(args.steps, 50)
+    n_prof = max(args.steps, 50)
 
-    def launch_a(i):
-        ops.stomp_sample(planner._particle_means, None, planner.state_particles, planner.scale_tril, S, seed=0,
-                         it=10_000 + i, particle_offset=rank * P, geom=geom, costs=planner.costs,
-                         k_sigma=cost.cost_l[0].k_sigma, weight=1.0)
-
-    def launch_b():
-        ops.stomp_update(planner._particle_means, planner.state_particles, planner.costs, planner._weights_buf,
-                         planner.Sigma, planner.lr, planner.temperature)
-
-    # n back-to-back launches of ONE kernel between two events: the event / launch overhead (~4 us when a
-    # single launch is bracketed) is amortised, what remains per launch is the kernel plus its ~1 us gap
-    def timed(fn):
+    def launch_ms(k):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for i in range(5):
-            fn(i)
-        torch.cuda.synchronize()
-        e0.record()
-        for i in range(n_prof):
-            fn(i)
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / n_prof
+        ts = []
+        for _ in range(5):
+            planner._particle_means.copy_(means_init)
+            torch.cuda.synchronize()
+            e0.record()
+            planner.optimize(opt_iters=k)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        ts.sort()
+        return ts[len(ts) // 2]
 
-    ka_ms = timed(launch_a)
-    kb_ms = timed(lambda i: launch_b())
-    # the same two kernels inside the loop they run in (A, B, A, B, ...), each launch with its own pair of HIP events on
-    # the dispatch (hipExtLaunchKernelGGL): execution begin -> end without the ~2 us dispatch gap that the back-to-back
-    # figure above and rocprofv3's kernel-trace durations (profiles/) both include part of.  Reported next to
-    # `kernel_ms`, which stays the conservative back-to-back figure.  The particle means are restored afterwards.
-    means_keep = planner._particle_means.clone()
-    ka_ev_ms, kb_ev_ms = ops.stomp_step_profile(planner._particle_means, planner.state_particles, planner.costs, planner._weights_buf,
-                                          planner.scale_tril, planner.Sigma, geom, S, D, cost.cost_l[0].k_sigma, 1.0,
-                                          planner.lr, planner.temperature, n_iters=n_prof, seed=0, iter0=20_000,
-                                          particle_offset=rank * P)
-    planner._particle_means.copy_(means_keep)
-    alg_bytes_a = 4 * (P * S * H * d + P * H * d + P * S)     # kernel A: samples written + means read + costs
-    hbm_gbs = alg_bytes_a / (ka_ms * 1e-3) / 1e9
-    # instruction counts and HBM-side bytes of kernel A: rocprofv3 PMC passes of this same workload, committed under
-    # profiles/ (counters cannot be read from inside the process being profiled)
-    pmc, pmc_file = latest_profile('r*_pmc_kernelA.json')
+    means_init = wl['means0'].clone()
+    t1, t2 = launch_ms(n_prof), launch_ms(2 * n_prof)
+    k_ms = (t2 - t1) / n_prof                              # one iteration inside the persistent launch
+    launch_fixed_ms = max(t1 - k_ms * n_prof, 0.0)
+    # the two-kernel path (mpb_stomp_step: sample + cost kernel, update kernel per iteration) on the same problem
+    two = STOMP_two_kernel(wl, cost, dev, rank, P)
+    two.optimize(opt_iters=200)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    two.optimize(opt_iters=args.steps)
+    torch.cuda.synchronize()
+    two_ms = 1e3 * (time.perf_counter() - t0) / args.steps
+    del two
+    # algorithmic bytes of one iteration of the persistent kernel: samples written, costs + weights written; the means
+    # and every constant stay in LDS (SURVEY 8d's formula additionally counts the means read + written per iteration)
+    alg_bytes_k = 4 * (P * S * H * d + 2 * P * S)
+    hbm_gbs = alg_bytes_k / (k_ms * 1e-3) / 1e9
+    # instruction counts and HBM-side bytes: rocprofv3 PMC passes of this same workload, committed under profiles/
+    # (counters cannot be read from inside the process being profiled)
+    pmc, pmc_file = latest_profile('r*_pmc_stomp.json')
     c3_shape = P == 128 and S == 32 and not args.pos_only
-    valu_per_wave = pmc.get('SQ_INSTS_VALU_per_wave') if (pmc and c3_shape) else None
-    traffic = pmc.get('hbm_bytes_per_launch') if (pmc and c3_shape) else None
-    if valu_per_wave:
-        ginstr = valu_per_wave * (P * S) / (ka_ms * 1e-3) / 1e9
+    valu = pmc.get('SQ_INSTS_VALU_per_wave_iteration') if (pmc and c3_shape) else None
+    traffic = pmc.get('hbm_bytes_per_iteration') if (pmc and c3_shape) else None
+    if valu:
+        ginstr = valu * (P * S) / (k_ms * 1e-3) / 1e9
         roof = {'bound': 'valu', 'achieved': ginstr, 'peak': VALU_PEAK_GINSTR, 'unit': 'G wave-instr/s',
-                'frac': ginstr / VALU_PEAK_GINSTR, 'valu_instructions_per_wave': valu_per_wave, 'pmc_source': pmc_file,
-                'frac_dispatch_events': valu_per_wave * (P * S) / (ka_ev_ms * 1e-3) / 1e9 / VALU_PEAK_GINSTR}
+                'frac': ginstr / VALU_PEAK_GINSTR, 'valu_instructions_per_wave_iteration': valu, 'pmc_source': pmc_file}
     else:   # no committed counter summary for this shape: the nominal bound
         roof = {'bound': 'hbm', 'achieved': hbm_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': hbm_gbs / HBM_PEAK_GBS}
-    roof.update({'kernel': 'stomp_sample_cost kernel A (d=%d)' % d, 'traffic': traffic,
+    roof.update({'kernel': 'stomp_fused_kernel<%d, model> (persistent: one launch = all iterations)' % d, 'traffic': traffic,
                  'hbm': {'achieved': hbm_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': hbm_gbs / HBM_PEAK_GBS,
-                         'algorithmic_bytes_per_launch': alg_bytes_a},
-                 'kernel_ms': ka_ms, 'update_kernel_ms': kb_ms, 'kernel_ms_dispatch_events': ka_ev_ms,
-                 'update_kernel_ms_dispatch_events': kb_ev_ms})
+                         'algorithmic_bytes_per_launch': alg_bytes_k, 'note': 'per iteration of the persistent launch'},
+                 'kernel_ms': k_ms, 'launch_fixed_ms': launch_fixed_ms,
+                 'two_kernel_path_ms_per_step': two_ms, 'two_kernel_path_iters_per_sec': 1e3 / two_ms})
 
     # ---- BASELINE configs[4]'s per-GPU load with the same protocol (every N)
     c5 = None

@@ -65,6 +65,32 @@ for k in sorted(acc):
 with open(os.path.join(prof, f'{tag}_pmc_per_wave.md'), 'w') as fh:
     fh.write('\n'.join(lines))
 
+# the persistent STOMP kernel: one launch = MPB_ITERS iterations (scripts/profile_round.sh); per-iteration figures
+kf = [k for k in summary if 'stomp_fused_kernel' in k]
+if kf:
+    import re
+    k = kf[0]
+    s = summary[k]
+    waves = grid[k][0] // 64
+    iters = int(os.environ.get('MPB_ITERS', 50))
+    fetch_kb, write_kb = s.get('FETCH_SIZE'), s.get('WRITE_SIZE')
+    per = lambda c: (s[c] / waves / iters) if c in s else None
+    out = {'kernel': re.sub(r'\(.*', '', k), 'workload': 'C3 P=128 S=32 H=64 d=14 (scripts/prof_stomp.py, MPB_FUSED=1)',
+           'waves_per_launch': waves, 'iterations_per_launch': iters, 'vgpr': grid[k][2], 'sgpr': grid[k][3], 'lds_bytes': grid[k][4],
+           'scratch_bytes': grid[k][5],
+           'SQ_INSTS_VALU_per_wave_iteration': per('SQ_INSTS_VALU'), 'SQ_INSTS_SALU_per_wave_iteration': per('SQ_INSTS_SALU'),
+           'SQ_INSTS_LDS_per_wave_iteration': per('SQ_INSTS_LDS'), 'SQ_INSTS_MFMA_per_wave_iteration': per('SQ_INSTS_MFMA'),
+           'SQ_WAVE_CYCLES_quads_per_wave_iteration': per('SQ_WAVE_CYCLES'), 'SQ_WAIT_ANY_quads_per_wave_iteration': per('SQ_WAIT_ANY'),
+           'SQ_WAIT_INST_ANY_quads_per_wave_iteration': per('SQ_WAIT_INST_ANY'),
+           'FETCH_SIZE_KB_raw_per_iteration': fetch_kb / iters if fetch_kb is not None else None,
+           'WRITE_SIZE_KB_raw_per_iteration': write_kb / iters if write_kb is not None else None,
+           'note': 'gfx950: FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads (MI355X_MICROARCH.md, HBM) -> the read '
+                   'side is doubled; WRITE_SIZE is exact for 16-B-per-lane streaming stores',
+           'hbm_bytes_per_iteration': (2 * fetch_kb + write_kb) * 1024 / iters if fetch_kb is not None and write_kb is not None else None}
+    with open(os.path.join(prof, f'{tag}_pmc_stomp.json'), 'w') as fh:
+        json.dump(out, fh, indent=1)
+    print(json.dumps(out, indent=1))
+
 ka = [k for k in summary if 'stomp_sample_cost' in k and 'true' in k]
 if ka:
     k = ka[0]

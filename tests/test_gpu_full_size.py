@@ -269,13 +269,13 @@ def test_bench_line_contract(gpu_device):
     assert abs(j['value'] * j['ms_per_step'] * 1e-3 - 1.0) < 1e-6              # value = steps / elapsed on one GPU
     r = j['roofline']
     # the binding roofline is the fp32 VALU issue rate when a committed rocprofv3 counter summary of this workload
-    # exists (profiles/r*_pmc_kernelA.json: instructions per wave), the nominal HBM bound of SURVEY 8d otherwise; the
+    # exists (profiles/r*_pmc_stomp.json: instructions per wave and iteration of the persistent kernel), the nominal HBM bound of SURVEY 8d otherwise; the
     # HBM figure is always reported next to it
     assert r['bound'] in ('valu', 'hbm')
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
     if r['bound'] == 'valu':
         assert r['unit'] == 'G wave-instr/s' and abs(r['peak'] - 1228.8) < 1e-6
-        assert abs(r['achieved'] - r['valu_instructions_per_wave'] * 4096 / (r['kernel_ms'] * 1e-3) / 1e9) < 1e-6 * r['achieved']
+        assert abs(r['achieved'] - r['valu_instructions_per_wave_iteration'] * 4096 / (r['kernel_ms'] * 1e-3) / 1e9) < 1e-6 * r['achieved']
     h = r['hbm']
     assert h['unit'] == 'GB/s' and h['peak'] == 8000.0 and abs(h['frac'] - h['achieved'] / h['peak']) < 1e-9
     assert abs(h['achieved'] - h['algorithmic_bytes_per_launch'] / (r['kernel_ms'] * 1e-3) / 1e9) < 1e-6 * h['achieved']
@@ -288,4 +288,5 @@ def test_bench_line_contract(gpu_device):
     assert '4096 particles' in j['c5']['workload'] and 'B=1024' in j['c2']['workload'] and 'B=2048' in j['c4']['workload']
     assert j['c4']['roofline']['bound'] == 'mfma' and j['c4']['dtype'] == 'f64'
     # timings are reported, not asserted against a bar: a rare ~70 ms device stall on this pool would fail it
-    assert r['kernel_ms_dispatch_events'] > 0 and r['kernel_ms'] > 0 and j['value'] > 0
+    assert r['kernel_ms'] > 0 and r['two_kernel_path_iters_per_sec'] > 0 and j['value'] > 0
+    assert r['kernel_ms'] <= 1.25 * j['ms_per_step']        # the kernel's iteration cannot be slower than the step it is most of
