@@ -98,6 +98,19 @@ int mpb_cost_terms_eval(const float *trajs, float *out, double *jl_total, const 
                         int B, int H, int d, int n_dof, int trajs_per_goal, uint32_t flags, float dt,
                         float k_gp, float k_start, float k_goal, float k_smooth, float k_jlim, float jl_eps,
                         int accumulate, int broadcast_jlim, void *stream);
+/* Analytic gradient of the same terms -- what the reference obtains by autograd through CostComposite.eval when CHOMP
+ * differentiates costs.sum() (chomp.py:135-139) -- and, with apply != 0, CHOMP's update in the same pass (:141-147):
+ *   g = grad_in (may be NULL; e.g. mpb_cost_collision_grad's output) + d/dx [enabled terms, k_* as in
+ *       mpb_cost_terms_eval; the joint-limit term times jl_scale: its batch-global scalar sits in EVERY trajectory's
+ *       cost, so the gradient of costs.sum() carries the global batch size] + prior_bw * (R + R^T) x (CHOMP's
+ *       smoothness prior, prior_bw = B_global * weight_prior_cost: quirk Q3; R (H,H), only its tridiagonal band is read)
+ *   apply == 0: grad_out (B,H,d) = g;  apply != 0: trajs -= lr * mask(clamp(g, -grad_clip, grad_clip)) in place,
+ *   the mask zeroing rows 0 and H-1.  grad_in / grad_out may alias. */
+int mpb_cost_terms_grad(float *trajs, const float *grad_in, float *grad_out, const float *R,
+                        const float *start_state, const float *goal_states, const float *q_min, const float *q_max,
+                        int B, int H, int d, int n_dof, int trajs_per_goal, uint32_t flags, float dt,
+                        float k_gp, float k_start, float k_goal, float k_smooth, float k_jlim, float jl_eps,
+                        float jl_scale, float prior_bw, float lr, float grad_clip, int apply, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Trajectory utilities either side of the loop (all external to the reference: torch_robotics; build-defined).

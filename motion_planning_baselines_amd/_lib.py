@@ -26,6 +26,7 @@ SIGNATURES = {
     'mpb_cost_collision_eval': [_p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     'mpb_cost_collision_grad': [_p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     'mpb_cost_terms_eval': [_p] * 7 + [_i] * 5 + [_u32] + [_f] * 7 + [_i, _i, _p],
+    'mpb_cost_terms_grad': [_p] * 8 + [_i] * 5 + [_u32] + [_f] * 11 + [_i, _p],
     'mpb_traj_resample': [_p, _p, _p, _i, _i, _i, _i, _f, _p],
     'mpb_gp_factor_error': [_p, _p, _i, _i, _i, _f, _p],
     'mpb_traj_interpolate': [_p, _p, _i, _i, _i, _i, _p],

@@ -152,6 +152,168 @@ extern "C" int mpb_cost_terms_eval(const float* trajs, float* out, double* jl_to
 }
 
 // ------------------------------------------------------------------------------------------------
+// Analytic gradient of the same terms (what the reference obtains by autograd through CostComposite.eval:
+// chomp.py:135-139) and, optionally, the CHOMP update in the same pass (chomp.py:141-147).
+//   g[b,h,:] = grad_in[b,h,:]                                          (e.g. the collision gradient; may be NULL)
+//            + d/dx [ enabled terms of cost_terms_kernel ]              (joint limits times jl_scale: the batch-global
+//                                                                        scalar is added to EVERY trajectory's cost, so
+//                                                                        the gradient of costs.sum() carries the batch size)
+//            + prior_bw * (R + R^T) x                                   (CHOMP's smoothness prior incl. quirk Q3's batch
+//                                                                        factor; R's tridiagonal band is read from Rm)
+//   apply == 0: grad_out = g;   apply != 0: x -= lr * mask(clamp(g, -clip, clip)), mask zeroes rows 0 and H-1.
+// One wave per trajectory, lane = waypoint; the trajectory is staged once in LDS (every term's stencil reads its
+// neighbours' rows from there, and the update writes global memory only, so no wave races with another).
+// MPB_TERM_VEL_FD (velocities = central differences of the positions): the gradient with respect to the virtual
+// velocities goes through a second LDS tile and is pulled back onto the positions (v_h = (x_{h+1} - x_{h-1}) / 2dt).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * COSTS_WAVES) void cost_terms_grad_kernel(
+    float* __restrict__ trajs, const float* __restrict__ grad_in, float* __restrict__ grad_out,
+    const float* __restrict__ Rm, const float* __restrict__ start_state, const float* __restrict__ goal_states,
+    const float* __restrict__ q_min, const float* __restrict__ q_max, int B, int H, int d, int D, int trajs_per_goal,
+    uint32_t flags, float dt, float k_gp, float k_start, float k_goal, float k_smooth, float k_jlim, float jl_eps,
+    float jl_scale, float prior_bw, float lr, float grad_clip, int apply) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * COSTS_WAVES + wave;
+    if (b >= B) return;                                   // whole wave leaves together; no block barriers below
+    const int LD = d | 1;
+    float* X = lds + (size_t)wave * 2 * H * LD;           // trajectory tile
+    float* V = X + (size_t)H * LD;                        // VEL_FD: gradient w.r.t. the virtual velocities (H x D)
+    float* dst = trajs + (size_t)b * H * d;
+    const int n = H * d;
+    for (int e = lane; e < n; e += 64) {
+        const int r = e / d;
+        X[r * LD + (e - r * d)] = dst[e];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const bool vel_fd = flags & MPB_TERM_VEL_FD;
+    const double ddt = (double)dt;
+    const double q11 = 12.0 / (ddt * ddt * ddt), q12 = -6.0 / (ddt * ddt), q22 = 4.0 / ddt;
+    const double inv_dt4 = 1.0 / (ddt * ddt * ddt * ddt), inv_2dt = 1.0 / (2.0 * ddt);
+    // virtual velocity of row h, dof i (VEL_FD) or the stored one
+    auto vel = [&](int h, int i) -> double {
+        if (!vel_fd) return (double)X[h * LD + D + i];
+        return (h >= 1 && h + 1 < H) ? ((double)X[(h + 1) * LD + i] - (double)X[(h - 1) * LD + i]) * inv_2dt : 0.0;
+    };
+    // ---- pass 1 (VEL_FD only): d cost_gp / d v_h into V
+    if ((flags & MPB_TERM_GP) && vel_fd) {
+        for (int h = lane; h < H; h += 64) {
+            for (int i = 0; i < D; ++i) {
+                double gv = 0.0;
+                if (h + 1 < H) {
+                    const double ep = (double)X[(h + 1) * LD + i] - ((double)X[h * LD + i] + ddt * vel(h, i));
+                    const double ev = vel(h + 1, i) - vel(h, i);
+                    const double a = 2.0 * (q11 * ep + q12 * ev), bb = 2.0 * (q12 * ep + q22 * ev);
+                    gv -= ddt * a + bb;
+                }
+                if (h >= 1) {
+                    const double ep = (double)X[h * LD + i] - ((double)X[(h - 1) * LD + i] + ddt * vel(h - 1, i));
+                    const double ev = vel(h, i) - vel(h - 1, i);
+                    gv += 2.0 * (q12 * ep + q22 * ev);
+                }
+                V[h * D + i] = (float)((double)k_gp * gv);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    for (int h = lane; h < H; h += 64) {
+        const float* xh = X + h * LD;
+        for (int c = 0; c < d; ++c) {
+            double g = grad_in ? (double)grad_in[((size_t)b * H + h) * d + c] : 0.0;
+            const bool is_pos = c < D;
+            const int i = is_pos ? c : c - D;
+            // ---- GP prior factors (h-1, h) and (h, h+1)
+            if ((flags & MPB_TERM_GP) && i < D && (is_pos || (!vel_fd && c < 2 * D))) {
+                double gg = 0.0;
+                if (h + 1 < H) {
+                    const double ep = (double)X[(h + 1) * LD + i] - ((double)xh[i] + ddt * vel(h, i));
+                    const double ev = vel(h + 1, i) - vel(h, i);
+                    const double a = 2.0 * (q11 * ep + q12 * ev), bb = 2.0 * (q12 * ep + q22 * ev);
+                    gg += is_pos ? -a : -(ddt * a + bb);
+                }
+                if (h >= 1) {
+                    const double ep = (double)xh[i] - ((double)X[(h - 1) * LD + i] + ddt * vel(h - 1, i));
+                    const double ev = vel(h, i) - vel(h - 1, i);
+                    const double a = 2.0 * (q11 * ep + q12 * ev), bb = 2.0 * (q12 * ep + q22 * ev);
+                    gg += is_pos ? a : bb;
+                }
+                g += (double)k_gp * gg;
+                if (vel_fd) {   // pull the virtual-velocity gradient back: v_{h-1} and v_{h+1} depend on x_h
+                    if (h - 1 >= 1 && h < H) g += (double)V[(h - 1) * D + i] * inv_2dt;          // v_{h-1} = (x_h - x_{h-2}) / 2dt, h-1 interior
+                    if (h + 1 + 1 < H && h + 1 >= 1) g -= (double)V[(h + 1) * D + i] * inv_2dt;  // v_{h+1} = (x_{h+2} - x_h) / 2dt, h+1 interior
+                }
+            }
+            if ((flags & MPB_TERM_START) && h == 0 && c < 2 * D) g -= 2.0 * (double)k_start * ((double)start_state[c] - (double)xh[c]);
+            if ((flags & MPB_TERM_GOAL) && h == H - 1 && c < 2 * D)
+                g -= 2.0 * (double)k_goal * ((double)goal_states[(size_t)(b / trajs_per_goal) * 2 * D + c] - (double)xh[c]);
+            if (flags & MPB_TERM_SMOOTH) {
+                const double x = (double)xh[c];
+                const double df = (h >= 1) ? x - (double)xh[c - LD] : x;
+                double gs = 2.0 * df;
+                if (h + 1 < H) gs -= 2.0 * ((double)xh[c + LD] - x);
+                if (h == H - 1) gs += 2.0 * x;
+                g += (double)k_smooth * inv_dt4 * gs;
+            }
+            if ((flags & MPB_TERM_JLIM) && c < D) {
+                const double q = (double)xh[c];
+                const double lo = (double)q_min[c] + (double)jl_eps - q, hi = q - ((double)q_max[c] - (double)jl_eps);
+                double gj = 0.0;
+                if (lo > 0.0) gj -= 2.0 * lo;
+                if (hi > 0.0) gj += 2.0 * hi;
+                g += (double)jl_scale * (double)k_jlim * gj;
+            }
+            if (prior_bw != 0.f) {   // CHOMP prior: (B w) (R x + R^T x), R tridiagonal (chomp.py:81-101, :165)
+                const float xm = (h >= 1) ? xh[c - LD] : 0.f, xp = (h + 1 < H) ? xh[c + LD] : 0.f;
+                const float r_lo = (h >= 1) ? Rm[h * H + h - 1] : 0.f, r_di = Rm[h * H + h], r_up = (h + 1 < H) ? Rm[h * H + h + 1] : 0.f;
+                const float rx = r_lo * xm + r_di * xh[c] + r_up * xp;
+                g += (double)(prior_bw * (rx + rx));
+            }
+            if (apply) {
+                float gf = fminf(fmaxf((float)g, -grad_clip), grad_clip);
+                if (h == 0 || h == H - 1) gf = 0.f;
+                dst[(size_t)h * d + c] = xh[c] + (-lr * gf);
+            } else {
+                grad_out[((size_t)b * H + h) * d + c] = (float)g;
+            }
+        }
+    }
+}
+
+extern "C" int mpb_cost_terms_grad(float* trajs, const float* grad_in, float* grad_out, const float* R,
+                                   const float* start_state, const float* goal_states, const float* q_min,
+                                   const float* q_max, int B, int H, int d, int n_dof, int trajs_per_goal, uint32_t flags,
+                                   float dt, float k_gp, float k_start, float k_goal, float k_smooth, float k_jlim,
+                                   float jl_eps, float jl_scale, float prior_bw, float lr, float grad_clip, int apply,
+                                   void* stream) {
+    if (B < 0 || H < 2 || H > MPB_MAX_H || n_dof < 1 || d < 1) return mpb_fail(MPB_E_INVALID, "mpb_cost_terms_grad: bad shape");
+    if (flags & ~(uint32_t)MPB_TERM_ALL) return mpb_fail(MPB_E_INVALID, "mpb_cost_terms_grad: unknown term flag");
+    const bool fd = flags & MPB_TERM_VEL_FD;
+    if ((flags & (MPB_TERM_GP | MPB_TERM_JLIM)) && d < n_dof) return mpb_fail(MPB_E_INVALID, "mpb_cost_terms_grad: d < n_dof");
+    if ((flags & MPB_TERM_GP) && !fd && d != 2 * n_dof)
+        return mpb_fail(MPB_E_INVALID, "mpb_cost_terms_grad: the GP term needs d == 2*n_dof (or MPB_TERM_VEL_FD with d == n_dof)");
+    if (fd && d != n_dof) return mpb_fail(MPB_E_INVALID, "mpb_cost_terms_grad: MPB_TERM_VEL_FD needs d == n_dof");
+    if ((flags & (MPB_TERM_START | MPB_TERM_GOAL)) && d != 2 * n_dof)
+        return mpb_fail(MPB_E_INVALID, "mpb_cost_terms_grad: start / goal priors need d == 2*n_dof");
+    if ((flags & (MPB_TERM_GP | MPB_TERM_SMOOTH)) && !(dt > 0.f)) return mpb_fail(MPB_E_INVALID, "mpb_cost_terms_grad: dt must be > 0");
+    if (B == 0) return MPB_OK;
+    if (!trajs || (!apply && !grad_out)) return mpb_fail(MPB_E_INVALID, "mpb_cost_terms_grad: null pointer");
+    if ((flags & MPB_TERM_START) && !start_state) return mpb_fail(MPB_E_INVALID, "mpb_cost_terms_grad: start_state is NULL");
+    if ((flags & MPB_TERM_GOAL) && (!goal_states || trajs_per_goal < 1))
+        return mpb_fail(MPB_E_INVALID, "mpb_cost_terms_grad: goal_states NULL or trajs_per_goal < 1");
+    if ((flags & MPB_TERM_JLIM) && (!q_min || !q_max)) return mpb_fail(MPB_E_INVALID, "mpb_cost_terms_grad: joint-limit term needs q_min, q_max");
+    if (prior_bw != 0.f && !R) return mpb_fail(MPB_E_INVALID, "mpb_cost_terms_grad: the CHOMP prior needs R");
+    const size_t lds = (size_t)COSTS_WAVES * 2 * H * (d | 1) * sizeof(float);
+    if (lds > 150 * 1024) return mpb_fail(MPB_E_UNSUPPORTED, "mpb_cost_terms_grad: H*d too large for the LDS tiles");
+    hipLaunchKernelGGL(cost_terms_grad_kernel, dim3((B + COSTS_WAVES - 1) / COSTS_WAVES), dim3(64 * COSTS_WAVES), lds,
+                       (hipStream_t)stream, trajs, grad_in, grad_out, R, start_state, goal_states, q_min, q_max, B, H, d,
+                       n_dof, trajs_per_goal, flags, dt, k_gp, k_start, k_goal, k_smooth, k_jlim, jl_eps, jl_scale, prior_bw,
+                       lr, grad_clip, apply);
+    return mpb_check_launch("mpb_cost_terms_grad");
+}
+
+// ------------------------------------------------------------------------------------------------
 // trajectory utilities: streaming element-wise kernels, one thread per output word (coalesced stores)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void traj_interpolate_kernel(const float* __restrict__ x, float* __restrict__ out,

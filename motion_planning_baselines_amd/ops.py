@@ -105,11 +105,14 @@ def cost_collision_eval(trajs, geom, k_sigma, weight=1.0, h_begin=1, per_waypoin
 
 
 @_on_tensor_device
-def cost_collision_grad(trajs, geom, k_sigma, weight=1.0, h_begin=1):
+def cost_collision_grad(trajs, geom, k_sigma, weight=1.0, h_begin=1, grad=None):
     B, H, d = trajs.shape
     _chk(trajs, (B, H, d), 'trajs')
     out = torch.empty(B, device=trajs.device, dtype=torch.float32)
-    grad = torch.empty_like(trajs)
+    if grad is None:
+        grad = torch.empty_like(trajs)
+    else:
+        _chk(grad, (B, H, d), 'grad')
     _lib.check(_lib.lib().mpb_cost_collision_grad(_ptr(trajs), _ptr(geom.buf), _ptr(out), _ptr(grad), B, H, d, h_begin,
                                                  float(k_sigma), float(weight), _stream()), 'mpb_cost_collision_grad')
     return out, grad
@@ -230,6 +233,51 @@ def gp_factor_error(x, D, dt):
     out = torch.empty(B, H - 1, dim, device=x.device, dtype=torch.float32)
     _lib.check(_lib.lib().mpb_gp_factor_error(_ptr(x), _ptr(out), B, H, D, float(dt), _stream()), 'mpb_gp_factor_error')
     return out
+
+
+@_on_tensor_device
+def cost_terms_grad(trajs, n_dof, grad_in=None, grad_out=None, apply=False, R=None, prior_bw=0.0, lr=0.0, grad_clip=0.0,
+                    jl_scale=1.0, dt=0.0, k_gp=0.0, vel_fd=False, k_start=0.0, start_state=None, k_goal=0.0,
+                    goal_states=None, trajs_per_goal=1, k_smooth=0.0, k_jlim=0.0, q_min=None, q_max=None, jl_eps=0.0,
+                    terms=None):
+    """Analytic gradient of the trajectory-only cost terms (+ CHOMP's smoothness prior, + an incoming gradient such as
+    the collision one), written to grad_out or -- apply=True -- consumed by CHOMP's clamped, end-masked step on
+    `trajs` in place (mpb_cost_terms_grad).  Term arguments as cost_terms_eval."""
+    B, H, d = trajs.shape
+    _chk(trajs, (B, H, d), 'trajs')
+    terms = set(terms or ())
+    unknown = terms - {'gp', 'start', 'goal', 'smooth', 'jlim'}
+    if unknown:
+        raise ValueError(f'unknown cost terms {sorted(unknown)}')
+    flags = 0
+    if 'gp' in terms:
+        flags |= TERM_GP | (TERM_VEL_FD if vel_fd else 0)
+    if 'start' in terms:
+        flags |= TERM_START
+        _chk(start_state, (2 * n_dof,), 'start_state')
+    if 'goal' in terms:
+        flags |= TERM_GOAL
+        _chk(goal_states, (goal_states.shape[0], 2 * n_dof), 'goal_states')
+    if 'smooth' in terms:
+        flags |= TERM_SMOOTH
+    if 'jlim' in terms:
+        flags |= TERM_JLIM
+        _chk(q_min, (n_dof,), 'q_min')
+        _chk(q_max, (n_dof,), 'q_max')
+    if grad_in is not None:
+        _chk(grad_in, (B, H, d), 'grad_in')
+    if not apply:
+        if grad_out is None:
+            grad_out = torch.empty(B, H, d, device=trajs.device, dtype=torch.float32)
+        _chk(grad_out, (B, H, d), 'grad_out')
+    if prior_bw != 0.0:
+        _chk(R, (H, H), 'R')
+    _lib.check(_lib.lib().mpb_cost_terms_grad(
+        _ptr(trajs), _ptr(grad_in), _ptr(grad_out), _ptr(R), _ptr(start_state), _ptr(goal_states), _ptr(q_min), _ptr(q_max),
+        B, H, d, int(n_dof), int(trajs_per_goal), flags, float(dt), float(k_gp), float(k_start), float(k_goal),
+        float(k_smooth), float(k_jlim), float(jl_eps), float(jl_scale), float(prior_bw), float(lr), float(grad_clip),
+        int(bool(apply)), _stream()), 'mpb_cost_terms_grad')
+    return grad_out
 
 
 @_on_tensor_device

@@ -8,7 +8,7 @@ import torch
 
 from .. import ops
 from .base import OptimizationPlanner
-from .costs.cost_functions import fusable_collision
+from .costs.cost_functions import device_plan, fusable_collision
 
 
 def chomp_precision_matrix(dt=0.01, n_support_points=64, tensor_args=None):
@@ -91,11 +91,34 @@ class CHOMP(OptimizationPlanner):
         if opt_iters is None:
             opt_iters = self.opt_iters
         fused = fusable_collision(self.cost)
-        if fused is None:
+        B_global = self.global_batch or self.num_particles
+        if fused is not None:
+            cc, weight = fused
+            ops.chomp_step(self._particle_means, self.Sigma_inv, cc.device_geometry(self.device), self.n_dof,
+                           cc.k_sigma, weight, self.weight_prior_cost, self.lr, self.grad_clip, n_iters=opt_iters,
+                           B_global=B_global, costs_out=self.costs)
+            return
+        # any composite of HIP-served members (collision fields + GP / smoothness / joint-limit / start / goal terms): the
+        # reference differentiates it by autograd (chomp.py:135-139); here per iteration the collision gradient kernel
+        # (J^T grad sdf), then ONE pass that adds the closed-form gradients of the trajectory terms and of the
+        # smoothness prior, clamps, masks the end rows and steps (chomp.py:141-147)
+        plan = device_plan(self.cost, self.device) if self.cost is not None else None
+        if plan is None:
             raise NotImplementedError(
-                'CHOMP needs the analytic gradient of its cost: pass a CostCollision / single-field '
-                'CostComposite (the case every reference example uses)')
-        cc, weight = fused
-        ops.chomp_step(self._particle_means, self.Sigma_inv, cc.device_geometry(self.device), self.n_dof,
-                       cc.k_sigma, weight, self.weight_prior_cost, self.lr, self.grad_clip, n_iters=opt_iters,
-                       B_global=self.global_batch or self.num_particles, costs_out=self.costs)
+                'CHOMP needs the analytic gradient of its cost: a composite of CostCollision and the trajectory-term '
+                'costs of cost_functions.py (a user-defined Python cost has no gradient kernel)')
+        cc, weight, groups = plan
+        x = self._particle_means
+        grad = torch.empty_like(x) if (cc is not None or len(groups) > 1) else None
+        prior_bw = float(B_global) * float(self.weight_prior_cost)
+        for _ in range(opt_iters):
+            have = False
+            if cc is not None:
+                self.costs, _ = ops.cost_collision_grad(x, cc.device_geometry(self.device), cc.k_sigma, weight=weight, grad=grad)
+                have = True
+            for spec in groups[:-1]:     # term groups that could not be merged into one launch: accumulate
+                ops.cost_terms_grad(x, self.n_dof, grad_in=grad if have else None, grad_out=grad, jl_scale=float(B_global), **spec)
+                have = True
+            last = groups[-1] if groups else dict(terms=())
+            ops.cost_terms_grad(x, self.n_dof, grad_in=grad if have else None, apply=True, R=self.Sigma_inv, prior_bw=prior_bw,
+                                lr=self.lr, grad_clip=self.grad_clip, jl_scale=float(B_global), **last)
