@@ -42,6 +42,14 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     return v;
 }
 #else
+// debug builds (-DMPB_DEBUG): the DPP reductions read neighbouring lanes' registers directly, so every lane of the wave
+// must be active at the call site (a disabled lane contributes a stale register, not a neutral element)
+#ifdef MPB_DEBUG
+#include <assert.h>
+#define MPB_ASSERT_FULL_WAVE() assert(__builtin_amdgcn_read_exec() == ~0ull)
+#else
+#define MPB_ASSERT_FULL_WAVE()
+#endif
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
@@ -55,6 +63,7 @@ __device__ __forceinline__ double dpp_f64(double v) {
 }
 __device__ __forceinline__ float readlane_f32(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 __device__ __forceinline__ float wave_sum_f32(float v) {
+    MPB_ASSERT_FULL_WAVE();
     v += dpp_f32<0xB1>(v);
     v += dpp_f32<0x4E>(v);
     v += dpp_f32<0x141>(v);
@@ -62,6 +71,7 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
     return (readlane_f32(v, 0) + readlane_f32(v, 16)) + (readlane_f32(v, 32) + readlane_f32(v, 48));
 }
 __device__ __forceinline__ float wave_max_f32(float v) {
+    MPB_ASSERT_FULL_WAVE();
     v = fmaxf(v, dpp_f32<0xB1>(v));
     v = fmaxf(v, dpp_f32<0x4E>(v));
     v = fmaxf(v, dpp_f32<0x141>(v));
@@ -69,6 +79,7 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     return fmaxf(fmaxf(readlane_f32(v, 0), readlane_f32(v, 16)), fmaxf(readlane_f32(v, 32), readlane_f32(v, 48)));
 }
 __device__ __forceinline__ double wave_sum_f64(double v) {
+    MPB_ASSERT_FULL_WAVE();
     v += dpp_f64<0xB1>(v);
     v += dpp_f64<0x4E>(v);
     v += dpp_f64<0x141>(v);

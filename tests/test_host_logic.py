@@ -252,3 +252,51 @@ def test_ctypes_signatures_match_the_header():
     for name, params in protos:
         want = [t for t in (ctype_of(p) for p in params.split(',')) if t is not None]
         assert want == list(_lib.SIGNATURES[name]), (name, [t.__name__ for t in want], [t.__name__ for t in _lib.SIGNATURES[name]])
+
+
+def test_robot_model_header_is_generated_from_geometry():
+    """csrc/mpb_model_panda.h (the compile-time Panda tables the model kernels fold) is exactly what model_gen emits from
+    geometry.py -- the single source of the numbers -- and the DH tables carry exact zeros / ones (what folds)."""
+    import os
+    from motion_planning_baselines_amd import geometry as G, model_gen
+    path = os.path.join(os.path.dirname(G.__file__), 'csrc', 'mpb_model_panda.h')
+    assert open(path).read() == model_gen.header_text('panda')
+    tf = np.asarray(G.RobotPanda().spec()['joint_tf'])[:7, :, :3]
+    assert set(np.unique(np.abs(tf))) <= {0.0, 1.0}
+
+
+def test_geometry_model_tag_and_flags():
+    """pack_geometry tags a buffer with the robot model only when the tables match bit for bit; mpb_geom_flags reports it
+    (and the all-grids bit); mpb_geom_check refuses a forged tag."""
+    from motion_planning_baselines_amd import _lib, geometry as G
+    robot, field = G.RobotPanda(), G.env_spheres_3d()
+    buf = G.pack_geometry(robot, field)
+    gi = buf.view(np.int32)
+    assert gi[29] == 1 and int(buf.view(np.uint32)[30]) == ((1 << 31) - 1) & ~0b111      # the three base spheres are pruned here
+    _lib.geom_check(buf)
+    assert _lib.geom_flags(buf) == (1 | 0x100)
+    assert _lib.geom_flags(G.pack_geometry(robot, field, use_model=False)) == 0x100
+    full = G.pack_geometry(robot, field, prune_static=False)
+    assert int(full.view(np.uint32)[30]) == (1 << 31) - 1 and _lib.geom_flags(full) == (1 | 0x100)
+    # a robot that is not the Panda bit for bit is not tagged
+    other = G.RobotPanda()
+    other.link_offset[5, 1] += 1e-4
+    assert G.pack_geometry(other, field).view(np.int32)[29] == 0
+    # a forged tag on that buffer is refused
+    forged = G.pack_geometry(other, field, prune_static=False)
+    forged.view(np.int32)[29] = 1
+    forged.view(np.uint32)[30] = (1 << 31) - 1
+    with pytest.raises(_lib.MPBError):
+        _lib.geom_check(forged)
+    # point robot: no model, grid usable; box-only field: no grid at all
+    pm = G.pack_geometry(G.RobotPointMass(2, radius=0.01), G.env_grid_circles_2d())
+    assert _lib.geom_flags(pm) == 0x100
+    boxes = G.CollisionField(boxes=np.array([[0.2, 0.2, 0.1, 0.1]], np.float32), margin=0.01)
+    assert _lib.geom_flags(G.pack_geometry(G.RobotPointMass(2, radius=0.01), boxes)) == 0
+
+
+def test_stomp_workspace_size():
+    from motion_planning_baselines_amd import _lib
+    f = _lib.lib().mpb_stomp_workspace_bytes
+    assert f(128, 32, 64, 14) == 4 * (16 + 256 + 2 * 128 * 2 * 912)
+    assert f(3, 5, 64, 7) == 4 * (16 + 16 + 2 * 3 * 1 * 912) and f(0, 32, 64, 14) == 0
