@@ -21,6 +21,9 @@
 // directions at once -- half the sequential depth.  The 2D x 2D blocks are 16 x 16 fp64 tiles held in registers
 // (MFMA C layout); W_t (upper triangle: it is symmetric) and z_t go to a caller-provided workspace.  All arithmetic is fp64: the weights reach 1/sigma^2 = 1e10 (gpmp2.py:32-35)
 // and fp32 Cholesky at that conditioning is not reproducible; storage stays fp32.
+#include <stdlib.h>
+#include <string.h>
+
 #include "mpb_common.h"
 #include "mpb_geom.h"
 
