@@ -20,6 +20,9 @@
 // Every wait is bounded (s_memrealtime): a unit whose partner never shows up raises the error word and leaves.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <chrono>
+
 #include "mpb_common.h"
 #include "mpb_geom.h"
 #include "mpb_stomp_noise.h"
@@ -27,20 +30,24 @@
 #define FUSED_WAVES 16
 #define FUSED_THREADS (64 * FUSED_WAVES)
 #define FUSED_LD 68                        // padded row (floats) of the Sigma image and of the transposed delta tile
-#define FUSED_XCHG 912                     // floats per published partial: m, z, pad(2), then H*d <= 896 values, padded to 16 B
+#define FUSED_XCHG 912                     // granules per published partial: m, z, then H*d <= 896 values, padded
 #define FUSED_MAX_CHUNKS 4                 // S <= 64
 #define FUSED_TIMEOUT_TICKS 200000000ull   // 2 s of s_memrealtime (100 MHz)
 
 __device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent_u(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned ld_agent_u(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// workspace layout (floats): [0] error word, [16 .. 16 + P*nc) flags, then 2 parities x P x nc x FUSED_XCHG partials
-static inline size_t fused_ws_floats(int P, int nc) {
-    const size_t flags = ((size_t)P * nc + 15) / 16 * 16;
-    return 16 + flags + 2 * (size_t)P * nc * FUSED_XCHG;
+// one naturally aligned 8-byte granule {value, tag}, written by ONE agent-scope (sc1) store and read by ONE sc1 load: the
+// tag tells the reader which iteration of which call the value belongs to, so the payload needs no separate flag, no
+// drain of the stores and no fence (MI355X_MICROARCH.md: "handoff-1to1, data-tagged granules"; observed untorn)
+typedef unsigned long long granule_t;
+__device__ __forceinline__ void st_granule(granule_t* p, float v, unsigned tag) {
+    __hip_atomic_store(p, ((granule_t)tag << 32) | (granule_t)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ granule_t ld_granule(const granule_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// workspace layout: 16 floats of header ([0] = error word), then 2 parities x P x nc x FUSED_XCHG granules (8 B each):
+// granule 0 = m, 1 = z, 2 + t = partial sum of trajectory element t
+static inline size_t fused_ws_floats(int P, int nc) { return 16 + 2 * 2 * (size_t)P * nc * FUSED_XCHG; }
 
 #ifdef MPB_STAMPS   // diagnostic build only: s_memtime per wave at the phase boundaries of iteration 2
 __device__ unsigned long long g_fstamps[256 * FUSED_WAVES * 12];
@@ -66,10 +73,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
     float* __restrict__ means, const float* __restrict__ eps, float* __restrict__ samples, float* __restrict__ costs,
     float* __restrict__ weights, const float* __restrict__ Lmat, const float* __restrict__ Sigma,
     const float* __restrict__ geom, float* __restrict__ ws, int P, int S, int nc, float k_sigma, float weight, float lr,
-    float temperature, int n_iters, uint32_t seed_lo, uint32_t seed_hi, uint32_t iter0, uint32_t particle_offset) {
+    float temperature, int n_iters, uint32_t seed_lo, uint32_t seed_hi, uint32_t iter0, uint32_t particle_offset,
+    uint32_t tag0) {
     constexpr int H = 64;
     constexpr int N = H * DCH;                    // elements of a trajectory
-    static_assert(N <= FUSED_THREADS - 0 && N + 4 <= FUSED_XCHG, "one thread per trajectory element");
+    static_assert(N <= FUSED_THREADS && N + 2 <= FUSED_XCHG, "one thread per trajectory element");
     __shared__ __attribute__((aligned(16))) float Lp[H * H];                                  // 16 KB
     __shared__ __attribute__((aligned(16))) float tiles[FUSED_WAVES * H * NT_STRIDE];         // 80 KB
     __shared__ __attribute__((aligned(16))) unsigned gridw[MPB_GRID_MAX_CELLS];               // 16 KB
@@ -98,8 +106,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
     const bool live = s < S;
     const int j = lane & 15, g = lane >> 4;
     float* err_word = ws;
-    unsigned* flags = reinterpret_cast<unsigned*>(ws + 16);
-    float* xch = ws + 16 + ((size_t)P * nc + 15) / 16 * 16;
+    granule_t* xch = reinterpret_cast<granule_t*>(ws + 16);
 
     // ---- constants into LDS (once)
     GeomView G0 = geom_view(geom);
@@ -228,15 +235,15 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         }
         float m_all = mb, z_all = zb, f_own = 1.f;
         FSTAMP(4);
+        const unsigned tag = tag0 + (unsigned)it;                  // unique per (call, iteration): stale granules never match
         if (nc > 1) {
-            // ============ D. publish (sc1 stores), flag, then -- before polling -- the noise of the next iteration
-            float* mine = xch + ((size_t)(it & 1) * P * nc + (size_t)p * nc + chunk) * FUSED_XCHG;
-            if (tq < N) st_agent(mine + 4 + tq, dpart);
-            if (tq == 0) { st_agent(mine + 0, mb); st_agent(mine + 1, zb); }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // ============ D. publish the partial as tagged granules, then -- before reading the partners' -- the noise of
+            //              the next iteration: by then their granules have long landed
+            granule_t* mine = xch + ((size_t)(it & 1) * P * nc + (size_t)p * nc + chunk) * FUSED_XCHG;
+            if (tq < N) st_granule(mine + 2 + tq, dpart, tag);
+            if (tq == 0) { st_granule(mine + 0, mb, tag); st_granule(mine + 1, zb, tag); }
         }
-        __syncthreads();                                                     // (2) every store of the block is out; tiles consumed
-        if (nc > 1 && tq == 0) st_agent_u(flags + (size_t)p * nc + chunk, (unsigned)(it + 1));
+        __syncthreads();                                                     // (2) the samples in the tiles are consumed
         FSTAMP(5);
         if (it + 1 < n_iters) {
             // the noise of the NEXT iteration (it does not depend on the means) is drawn here, between publishing and polling:
@@ -248,6 +255,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
             // the next, and the compiler would hoist those products out of the loop and keep -- spill -- them)
             int jv = j, gv = g;
             asm volatile("" : "+v"(jv), "+v"(gv));
+            // (a k-block pipelined form -- Philox of block q+1 issued between the MFMAs of block q, straight-line code -- was
+            // measured 3 % slower: the waves of a SIMD already overlap one wave's matrix work with another's Philox)
             stomp_b_operand<DCH>(e, eps ? eps + (size_t)(it + 1) * eps_stride + (size_t)(live ? s : 0) * DCH * P * H : nullptr, P, p, jv, gv,
                                  particle_offset + (uint32_t)p, (uint32_t)s, iter0 + (uint32_t)(it + 1), seed_lo, seed_hi);
             stomp_noise_product(Lp, e, j, g, acc);
@@ -256,32 +265,31 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         float dsum = dpart;
         FSTAMP(6);
         if (nc > 1) {
-            if (tq == 0) {
-                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                for (int k = 0; k < nc; ++k) {
-                    if (k == chunk) continue;
-                    while (ld_agent_u(flags + (size_t)p * nc + k) < (unsigned)(it + 1)) {
-                        __builtin_amdgcn_s_sleep(4);
-                        if (__builtin_amdgcn_s_memrealtime() - t0 > FUSED_TIMEOUT_TICKS) { s_abort = 1; break; }
+            // every thread waits for ITS granules of every chunk (its own included: the very bits the partners read) --
+            // no block barrier, no flag; combined in chunk order so that all partners compute bit-identical means
+            float mk[FUSED_MAX_CHUNKS], zk[FUSED_MAX_CHUNKS], dk[FUSED_MAX_CHUNKS];
+            const granule_t* slot0 = xch + ((size_t)(it & 1) * P * nc + (size_t)p * nc) * FUSED_XCHG;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < FUSED_MAX_CHUNKS; ++k) {
+                    mk[k] = -3.0e38f; zk[k] = 0.f; dk[k] = 0.f;
+                    if (k < nc) {
+                        const granule_t* theirs = slot0 + (size_t)k * FUSED_XCHG;
+                        const granule_t gm = ld_granule(theirs + 0), gz = ld_granule(theirs + 1);
+                        const granule_t gd = ld_granule(theirs + 2 + (tq < N ? tq : 0));
+                        ok = ok && (unsigned)(gm >> 32) == tag && (unsigned)(gz >> 32) == tag && (unsigned)(gd >> 32) == tag;
+                        mk[k] = __uint_as_float((unsigned)gm);
+                        zk[k] = __uint_as_float((unsigned)gz);
+                        dk[k] = (tq < N) ? __uint_as_float((unsigned)gd) : 0.f;
                     }
                 }
+                if (ok) break;
+                __builtin_amdgcn_s_sleep(2);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > FUSED_TIMEOUT_TICKS) { s_abort = 1; break; }
             }
-            __syncthreads();                                                                    // (3) partners have published
             FSTAMP(7);
-            if (s_abort) break;                                                                 // block-uniform
-            // combine the nc partials in chunk order; the own partial is read back like the partners' (the very bits they read)
-            float mk[FUSED_MAX_CHUNKS], zk[FUSED_MAX_CHUNKS], dk[FUSED_MAX_CHUNKS];
-            const float* slot0 = xch + ((size_t)(it & 1) * P * nc + (size_t)p * nc) * FUSED_XCHG;
-#pragma unroll
-            for (int k = 0; k < FUSED_MAX_CHUNKS; ++k) {
-                mk[k] = -3.0e38f; zk[k] = 0.f; dk[k] = 0.f;
-                if (k < nc) {
-                    const float* theirs = slot0 + (size_t)k * FUSED_XCHG;
-                    mk[k] = ld_agent(theirs + 0);
-                    zk[k] = ld_agent(theirs + 1);
-                    dk[k] = (tq < N) ? ld_agent(theirs + 4 + tq) : 0.f;
-                }
-            }
             m_all = mk[0];
 #pragma unroll
             for (int k = 1; k < FUSED_MAX_CHUNKS; ++k) m_all = fmaxf(m_all, mk[k]);
@@ -303,6 +311,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         if (tq < N) delta[cc * FUSED_LD + hh] = dsum / z_all;
         __syncthreads();                                                                        // (4) delta complete
         FSTAMP(9);
+        if (s_abort) break;                                                                     // block-uniform (set before barrier 4)
         if (tq < N) {
             float a4[4] = {0.f, 0.f, 0.f, 0.f};
             const float4* dcol = reinterpret_cast<const float4*>(delta + cc * FUSED_LD);
@@ -367,16 +376,19 @@ extern "C" int mpb_stomp_run(float* means, const float* eps, float* samples, flo
     if (!(temperature > 0.f)) return mpb_fail(MPB_E_INVALID, "mpb_stomp_run: temperature must be > 0");
     const int nc = (S + FUSED_WAVES - 1) / FUSED_WAVES;
     hipStream_t st = (hipStream_t)stream;
-    // error word + flags start at zero for every call
-    const size_t head = (16 + ((size_t)P * nc + 15) / 16 * 16) * sizeof(float);
-    if (hipMemsetAsync(workspace, 0, head, st) != hipSuccess) return mpb_fail(MPB_E_HIP, "mpb_stomp_run: hipMemsetAsync failed");
+    // the error word starts at zero for every call; the granules need no initialisation: their tags carry a per-call
+    // epoch (process-wide counter scrambled over 32 bits), so whatever an earlier call -- or nobody -- left in the
+    // workspace does not match
+    if (hipMemsetAsync(workspace, 0, 64, st) != hipSuccess) return mpb_fail(MPB_E_HIP, "mpb_stomp_run: hipMemsetAsync failed");
+    static std::atomic<uint32_t> epoch{(uint32_t)std::chrono::steady_clock::now().time_since_epoch().count()};
+    const uint32_t tag0 = (epoch.fetch_add(1u) + 1u) * 0x9E3779B9u;
     const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
     const dim3 grid(P * nc), block(FUSED_THREADS);
     const int model = geom_flags & 0xFF;
 #define MPB_F_CASE(DCH, MODEL)                                                                                        \
     hipLaunchKernelGGL((stomp_fused_kernel<DCH, MODEL>), grid, block, 0, st, means, eps, samples, costs, weights, L, \
                        Sigma, geom, workspace, P, S, nc, k_sigma, weight, lr, temperature, n_iters, lo, hi, iter0,      \
-                       particle_offset)
+                       particle_offset, tag0)
     if (model == PandaModel::ID && d == 7) MPB_F_CASE(7, PandaModel::ID);
     else if (model == PandaModel::ID && d == 14) MPB_F_CASE(14, PandaModel::ID);
     else if (d == 2) MPB_F_CASE(2, 0);

@@ -298,5 +298,5 @@ def test_geometry_model_tag_and_flags():
 def test_stomp_workspace_size():
     from motion_planning_baselines_amd import _lib
     f = _lib.lib().mpb_stomp_workspace_bytes
-    assert f(128, 32, 64, 14) == 4 * (16 + 256 + 2 * 128 * 2 * 912)
-    assert f(3, 5, 64, 7) == 4 * (16 + 16 + 2 * 3 * 1 * 912) and f(0, 32, 64, 14) == 0
+    assert f(128, 32, 64, 14) == 4 * 16 + 8 * (2 * 128 * 2 * 912)          # header + 8-byte {value, tag} granules, two parities
+    assert f(3, 5, 64, 7) == 4 * 16 + 8 * (2 * 3 * 1 * 912) and f(0, 32, 64, 14) == 0
