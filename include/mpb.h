@@ -49,7 +49,8 @@ int mpb_geom_check(const float *geom_host, int n_words);
  * instantiation without touching device memory.  *flags: bits 0-7 = id of the compile-time robot model
  * (csrc/mpb_model_*.h) every chained field is tagged with AND whose cost-only kernels can run (every field has a
  * usable broad-phase grid); 0 = generic table-driven kernels; bit 8 = every chained field has a usable broad-phase
- * grid (what the persistent STOMP kernel needs).  Entry points that take `geom_flags` expect the value
+ * grid (what the persistent STOMP kernel needs); bit 9 = point robot with ONE field of at most 32 spheres and 8 boxes
+ * (CHOMP's four-lanes-per-waypoint kernel keeps such an obstacle set in registers).  Entry points that take `geom_flags` expect the value
  * computed from the host copy of the very buffer `geom` points to (0 is always valid); a kernel re-checks the tag
  * against the device header and writes NaN costs if they disagree. */
 int mpb_geom_flags(const float *geom_host, int n_words, int *flags);
@@ -221,7 +222,7 @@ int mpb_stomp_update(float *means, const float *samples, const float *costs, flo
  * only its tridiagonal band is read.  costs_out (B_local) optional: collision cost (scaled) of the
  * iterate BEFORE the last update, without the smoothness scalar.
  * ------------------------------------------------------------------------------------------- */
-int mpb_chomp_step(float *means, const float *R, const float *geom, float *costs_out,
+int mpb_chomp_step(float *means, const float *R, const float *geom, int geom_flags, float *costs_out,
                    int B_local, int B_global, int H, int d, int D,
                    float k_sigma, float weight, float w_prior, float lr, float grad_clip,
                    int n_iters, void *stream);

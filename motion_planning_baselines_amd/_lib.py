@@ -42,7 +42,7 @@ SIGNATURES = {
     'mpb_stomp_step_profile': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _u64, _u32, _u32, _p, _p, _p],
     'mpb_stomp_sample': [_p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _f, _f, _u64, _u32, _u32, _p],
     'mpb_stomp_update': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
-    'mpb_chomp_step': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _p],
+    'mpb_chomp_step': [_p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _p],
     'mpb_gpmp2_workspace_bytes': [_i, _i, _i],
     'mpb_gpmp2_linearize': [_p, _p, _p, _i, _i, _i, _i, _p],
     'mpb_gpmp2_diag': [_p, _p, _i, _i, _i, _i, _f, _f, _f, _f, _f, _p],

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64 * COSTS_WAVES) void cost_terms_grad_kernel(
             if (prior_bw != 0.f) {   // CHOMP prior: (B w) (R x + R^T x), R tridiagonal (chomp.py:81-101, :165)
                 const float xm = (h >= 1) ? xh[c - LD] : 0.f, xp = (h + 1 < H) ? xh[c + LD] : 0.f;
                 const float r_lo = (h >= 1) ? Rm[h * H + h - 1] : 0.f, r_di = Rm[h * H + h], r_up = (h + 1 < H) ? Rm[h * H + h + 1] : 0.f;
-                const float rx = r_lo * xm + r_di * xh[c] + r_up * xp;
+                const float rx = fmaf(r_up, xp, fmaf(r_di, xh[c], r_lo * xm));   // same association as the CHOMP kernels (mpb_chomp.hip)
                 g += (double)(prior_bw * (rx + rx));
             }
             if (apply) {

@@ -433,7 +433,7 @@ def chomp_step(means, R, geom, D, k_sigma, weight, w_prior, lr, grad_clip, n_ite
     _chk(means, (B, H, d), 'means')
     _chk(R, (H, H), 'R')
     _chk(costs_out, (B,), 'costs_out', allow_none=True)
-    _lib.check(_lib.lib().mpb_chomp_step(_ptr(means), _ptr(R), _ptr(geom.buf), _ptr(costs_out), B,
+    _lib.check(_lib.lib().mpb_chomp_step(_ptr(means), _ptr(R), _ptr(geom.buf), int(geom.flags), _ptr(costs_out), B,
                                         B if B_global is None else int(B_global), H, d, D, float(k_sigma), float(weight),
                                         float(w_prior), float(lr), float(grad_clip), int(n_iters), _stream()),
                'mpb_chomp_step')

@@ -122,6 +122,28 @@ def test_collision_cost_grid_equals_exhaustive_at_scale(gpu_device):
     assert torch.equal(a, b)
 
 
+def test_chomp_c2_quad_kernel_equals_lean_kernel(gpu_device):
+    """C2 runs on the four-lanes-per-waypoint kernel (obstacles in registers, nearest combined over the quad by (signed
+    distance, obstacle index)); with the geometry's flag bit 9 cleared the same call takes the one-lane-per-waypoint
+    kernel with its exhaustive loop: same arithmetic per obstacle, same first-minimum rule."""
+    from motion_planning_baselines_amd import ops, workloads
+    from motion_planning_baselines_amd.planners.chomp import chomp_precision_matrix
+    dev = gpu_device
+    wl = workloads.pointmass_dense_chomp(1024, dev)
+    R = chomp_precision_matrix(wl['params']['dt'], 64, dict(device='cpu', dtype=torch.float32)).to(dev).contiguous()
+    geom = ops.DeviceGeometry(wl['robot'], wl['field'], dev)
+    assert geom.flags & 0x200
+    kw = dict(D=2, k_sigma=1.0, weight=10.0, w_prior=1e-4, lr=0.05, grad_clip=0.05)
+    a, b = wl['means0'].clone(), wl['means0'].clone()
+    ca, cb = torch.empty(1024, device=dev), torch.empty(1024, device=dev)
+    ops.chomp_step(a, R, geom, n_iters=1, costs_out=ca, **kw)
+    geom.flags &= ~0x200
+    ops.chomp_step(b, R, geom, n_iters=1, costs_out=cb, **kw)
+    torch.cuda.synchronize()
+    assert float(ca.max()) > 0 and not torch.equal(a, wl['means0'])
+    assert torch.equal(ca, cb) and torch.equal(a, b)
+
+
 def test_chomp_c2_fused_equals_stepwise(gpu_device):
     """C2 (B=1024): 50 iterations inside one launch == 50 single-iteration calls, bit for bit; endpoints fixed."""
     from motion_planning_baselines_amd import ops, workloads

@@ -290,9 +290,10 @@ def test_geometry_model_tag_and_flags():
         _lib.geom_check(forged)
     # point robot: no model, grid usable; box-only field: no grid at all
     pm = G.pack_geometry(G.RobotPointMass(2, radius=0.01), G.env_grid_circles_2d())
-    assert _lib.geom_flags(pm) == 0x100
+    assert _lib.geom_flags(pm) == 0x100          # 49 circles: too many for the in-register CHOMP kernel (bit 9)
+    assert _lib.geom_flags(G.pack_geometry(G.RobotPointMass(2, radius=0.01), G.env_dense_2d())) == (0x100 | 0x200)
     boxes = G.CollisionField(boxes=np.array([[0.2, 0.2, 0.1, 0.1]], np.float32), margin=0.01)
-    assert _lib.geom_flags(G.pack_geometry(G.RobotPointMass(2, radius=0.01), boxes)) == 0
+    assert _lib.geom_flags(G.pack_geometry(G.RobotPointMass(2, radius=0.01), boxes)) == 0x200
 
 
 def test_stomp_workspace_size():
