@@ -171,6 +171,7 @@ def run_stomp(planner, clock, dist, world, steps, warmup, repeats, preheat):
             dist.all_gather(gathered, planner._particle_means)   # final gather of the (P,H,d) means over xGMI
     blocks = clock.blocks(block, repeats, before=lambda: planner._particle_means.copy_(means_init))
     assert torch.isfinite(planner._particle_means).all()
+    assert not planner.persistent_timed_out(), 'a workgroup of the persistent STOMP kernel gave up waiting for its partner'
     return blocks
 
 

@@ -193,6 +193,13 @@ class STOMP(OptimizationPlanner):
                 self._update_distribution(self.costs, self.state_particles)
         self._weights = self._weights_buf.reshape(self.num_particles, self.num_samples, 1, 1)
 
+    def persistent_timed_out(self):
+        """Did a workgroup of the last persistent launch give up waiting for the partner workgroups of its particle (they
+        exchange per-chunk partial sums every iteration; each wait is bounded at 2 s)?  That only happens when the
+        partners cannot be resident together -- e.g. another stream keeps most of the chip busy -- and leaves the
+        affected particles' means as they were.  Synchronises the stream; False when no persistent launch was made."""
+        return self._run_ws is not None and self.persistent and ops.stomp_run_timed_out(self._run_ws)
+
     def _sample_and_eval(self, **observation):
         """stomp.py:162-197."""
         self.state_particles = self.sample()
