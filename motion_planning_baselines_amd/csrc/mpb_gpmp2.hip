@@ -232,6 +232,9 @@ extern "C" int mpb_debug_read_gp_phases(unsigned long long* dst) {
 #ifndef MPB_GP_WAVES
 #define MPB_GP_WAVES 2
 #endif
+#ifndef GP_PF
+#define GP_PF 4            // register stages of the substitution pass's W_t prefetch ring (9 VGPRs each; C4: 4 stages 0.455 ms, 8: 0.476, 12: 0.488)
+#endif
 template <int DT, bool MULTI>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVES))) void gpmp2_solve_kernel(float* __restrict__ x, const float* __restrict__ start,
                                                           const float* __restrict__ goal, const float* __restrict__ jac,
@@ -487,10 +490,12 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVE
                 for (int j = 0; j < dim; ++j) zi = fma(W[rowl * GP_LD + j], readlane_f64(r, j), zi);
             }
         }
+#ifndef GP_T_SKIP_STORE   // (tuning builds: elimination without the workspace traffic)
         if (lane < dim) wt[GP_TRI + lane] = zi;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             if (lk + 4 * q <= li) wt[tri_st[q]] = T[q];
+#endif
         z_last = zi;
         x_last = x0;
         if (!merge) {
@@ -540,6 +545,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVE
     //      step closer to the merge row.  Row `lane` of the next W, z and x are fetched while the current step runs:
     //      the workspace (B*H*2.2 KB) does not stay in cache, and an un-prefetched global round trip per waypoint
     //      would sit on the sequential critical path
+#ifdef GP_T_SKIP_SUBST    // (tuning builds: elimination only)
+    if (costs_out != nullptr && dir == 0 && lane == 0) costs_out[b] = (float)cost;
+    return;
+#endif
     const bool rowlane = lane < dim;
     const int rl = rowlane ? lane : 0;          // idle lanes shadow row 0: unconditional loads, no exec-mask branches
     if (rowlane) {   // v = U dtheta_m
@@ -550,51 +559,63 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVE
     }
     wave_sync();
     if (nst > 0) {
-        int tri_ld[GP_N];
+        // The W_t records (152 doubles per waypoint and particle) do not stay in cache (352 MB at C4) and every step needs
+        // its own.  Round 1 had each lane gather its row of the packed triangle straight from global memory, one step
+        // ahead: 16 load instructions per step touching ~14 cache lines each -- the pass ran at 0.21 of the solve's
+        // 0.60 ms (measured by elimination), bound by the address coalescer and one HBM latency per waypoint.  Now the
+        // record is fetched as it lies (two 16-byte loads per lane, 1.2 KB contiguous), GP_PF steps ahead through a
+        // ring of register stages (the elimination's registers are dead here), dropped into the wave's LDS tile and
+        // the row is gathered from there.
+        constexpr int NW = DT ? 2 * DT : GP_N;                 // entries of a row of W actually used
+        int tri_ld[NW];
 #pragma unroll
-        for (int j = 0; j < GP_N; ++j) tri_ld[j] = gp_tri(min(rl, j), max(rl, j));
-        double wrow[GP_N], wnext[GP_N], zc = 0.0, zn = 0.0;
-        float xc = 0.f, xn = 0.f;
-        {
-            const int t = t_first + t_inc * (nst - 1);
-            const double* wt = wW + (size_t)t * GP_WS_PER_T;
-#pragma unroll
-            for (int j = 0; j < GP_N; ++j) wrow[j] = wt[tri_ld[j]];
-            zc = wt[GP_TRI + rl];
-            xc = xb[t * dim + rl];
-        }
-        for (int k = nst - 1; k >= 0; --k) {
+        for (int j = 0; j < NW; ++j) tri_ld[j] = gp_tri(min(rl, j), max(rl, j));
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        d2 sa[GP_PF], sb[GP_PF];
+        float xst[GP_PF];
+        constexpr int REC2 = GP_WS_PER_T / 2;                  // 76 16-byte words
+        auto fetch = [&](int k, d2& a0, d2& b0, float& xdst) {
             const int t = t_first + t_inc * k;
-            if (k > 0) {
-                const double* wt = wW + (size_t)(t - t_inc) * GP_WS_PER_T;
+            const d2* rec = reinterpret_cast<const d2*>(wW + (size_t)t * GP_WS_PER_T);
+            a0 = rec[lane];
+            b0 = rec[64 + (lane < REC2 - 64 ? lane : 0)];
+            xdst = xb[t * dim + rl];
+        };
 #pragma unroll
-                for (int j = 0; j < GP_N; ++j) wnext[j] = wt[tri_ld[j]];
-                zn = wt[GP_TRI + rl];
-                xn = xb[(t - t_inc) * dim + rl];
-            }
-            double d = zc;
-            if (rowlane) {
+        for (int u = 0; u < GP_PF; ++u)
+            if (nst - 1 - u >= 0) fetch(nst - 1 - u, sa[u], sb[u], xst[u]);
+        double* slot = Sb_[dir];                               // the wave's tile buffer (272 doubles), free in this pass
+        for (int kk = nst - 1; kk >= 0; kk -= GP_PF) {
 #pragma unroll
-                for (int j = 0; j < GP_N; ++j)
-                    if (j < dim) d -= wrow[j] * zv[j];                               // zv holds U dtheta_prev
-            }
-            wave_sync();
-            if (rowlane) {
-                dth[lane] = d;
-                xb[t * dim + lane] = (float)((double)xc + K.step * d);
-            }
-            wave_sync();
-            if (rowlane) {   // v = U dtheta_t for the next row
-                const bool ip = lane < D;
-                const int ii = ip ? lane : lane - D;
-                const double dp = dth[ii], dv = dth[ii + D];
-                zv[lane] = ip ? u00 * dp + u01 * dv : u10 * dp + u11 * dv;
-            }
-            wave_sync();
+            for (int u = 0; u < GP_PF; ++u) {
+                const int k = kk - u;
+                if (k < 0) break;                              // wave-uniform
+                const int t = t_first + t_inc * k;
+                reinterpret_cast<d2*>(slot)[lane] = sa[u];
+                if (lane < REC2 - 64) reinterpret_cast<d2*>(slot)[64 + lane] = sb[u];
+                const float xc = xst[u];
+                if (k - GP_PF >= 0) fetch(k - GP_PF, sa[u], sb[u], xst[u]);        // this stage's next occupant
+                wave_sync();
+                double d = slot[GP_TRI + rl];
+                if (rowlane) {
 #pragma unroll
-            for (int j = 0; j < GP_N; ++j) wrow[j] = wnext[j];
-            zc = zn;
-            xc = xn;
+                    for (int j = 0; j < NW; ++j)
+                        if (j < dim) d -= slot[tri_ld[j]] * zv[j];                 // zv holds U dtheta_prev
+                }
+                wave_sync();
+                if (rowlane) {
+                    dth[lane] = d;
+                    xb[t * dim + lane] = (float)((double)xc + K.step * d);
+                }
+                wave_sync();
+                if (rowlane) {   // v = U dtheta_t for the next row
+                    const bool ip = lane < D;
+                    const int ii = ip ? lane : lane - D;
+                    const double dp = dth[ii], dv = dth[ii + D];
+                    zv[lane] = ip ? u00 * dp + u01 * dv : u10 * dp + u11 * dv;
+                }
+                wave_sync();
+            }
         }
     }
     cost = wave_sum_f64(cost);
