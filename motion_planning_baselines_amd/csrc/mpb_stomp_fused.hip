@@ -154,10 +154,23 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         const int h = lane;
         const bool edge = (h == 0) || (h == H - 1);
         float x[DCH];
+        // (the 16 waves of the block do this at the same moment: the LDS pipe, not the VALU, paces this phase -- 8-byte
+        // accesses where the row length allows it: DCH even -> every row starts 8-byte aligned)
+        if (DCH % 2 == 0) {
 #pragma unroll
-        for (int c = 0; c < DCH; ++c) x[c] = mean_l[h * DCH + c] + (edge ? 0.f : nz[c]);
+            for (int c = 0; c < DCH; c += 2) {
+                const float2 mv = *reinterpret_cast<const float2*>(mean_l + h * DCH + c);
+                x[c] = mv.x + (edge ? 0.f : nz[c]);
+                x[c + 1] = mv.y + (edge ? 0.f : nz[c + 1]);
+            }
 #pragma unroll
-        for (int c = 0; c < DCH; ++c) nt[h * DCH + c] = x[c];
+            for (int c = 0; c < DCH; c += 2) *reinterpret_cast<float2*>(nt + h * DCH + c) = make_float2(x[c], x[c + 1]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < DCH; ++c) x[c] = mean_l[h * DCH + c] + (edge ? 0.f : nz[c]);
+#pragma unroll
+            for (int c = 0; c < DCH; ++c) nt[h * DCH + c] = x[c];
+        }
         __builtin_amdgcn_wave_barrier();
         if (live) {
             const f32x4* pk4 = reinterpret_cast<const f32x4*>(nt);
@@ -184,12 +197,16 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
                     __syncthreads();
                 }
                 if (live && h >= 1) {
+#ifdef FUSED_T_NOCOST   // (tuning builds)
+                    c = q[0] * 1e-3f;
+#else
                     if (MODEL == PandaModel::ID) {
                         if (G.model == PandaModel::ID) c = fmaf(G.fscale, waypoint_cost_grid_model<PandaModel>(G, gridw, otab, q), c);
                         else bad = true;
                     } else {
                         c = fmaf(G.fscale, waypoint_cost_grid(G, gridw, otab, q), c);
                     }
+#endif
                 }
                 if (G.next == 0) break;
                 gp += G.next;
@@ -257,9 +274,19 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
             asm volatile("" : "+v"(jv), "+v"(gv));
             // (a k-block pipelined form -- Philox of block q+1 issued between the MFMAs of block q, straight-line code -- was
             // measured 3 % slower: the waves of a SIMD already overlap one wave's matrix work with another's Philox)
+#ifdef FUSED_T_NOPHILOX
+#pragma unroll
+            for (int q = 0; q < 16; ++q) e[q] = 0.01f * (float)(jv + q + it);
+#else
             stomp_b_operand<DCH>(e, eps ? eps + (size_t)(it + 1) * eps_stride + (size_t)(live ? s : 0) * DCH * P * H : nullptr, P, p, jv, gv,
                                  particle_offset + (uint32_t)p, (uint32_t)s, iter0 + (uint32_t)(it + 1), seed_lo, seed_hi);
+#endif
+#ifdef FUSED_T_NOMFMA
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = f32x4{e[4 * m], e[4 * m + 1], e[4 * m + 2], e[4 * m + 3]};
+#else
             stomp_noise_product(Lp, e, j, g, acc);
+#endif
             stomp_noise_to_tile(nt, acc, lane);           // (the samples packed in the tile were consumed before barrier 2)
         }
         float dsum = dpart;
