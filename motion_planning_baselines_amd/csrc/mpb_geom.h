@@ -546,10 +546,20 @@ __device__ __forceinline__ void spheres_hinge_grid(const GeomView& G, const unsi
         // a point outside the grid box is farther than margin + r_l from every obstacle (the box is the bounding box
         // of the inflated obstacles), so whatever candidates its CLAMPED cell lists all give hinge 0 exactly: no
         // in-bounds test (parked slots at 1e9 clamp to the last cell)
+#ifdef GEOM_T_NOCELL   // (tuning builds: no cell index, no grid word)
+        w[i] = 0x01010101u * (unsigned)G.n_sph + (unsigned)(x[i] > 1.0e8f);
+#else
         w[i] = gridw[grid_cell<true>(G, x[i], y[i], z[i])];
+#endif
         best[i] = 3.0e38f;
         over |= __ballot(w[i] == MPB_GRID_OVERFLOW);
     }
+#ifdef GEOM_T_NOTRIPS     // (tuning builds: no candidate loop)
+    over = 0ull;
+#pragma unroll
+    for (int i = 0; i < N; ++i) best[i] = (w[i] == 12345u) ? 0.f : best[i];
+    if (false)
+#endif
     if (__builtin_expect(over != 0ull, 0)) {
         // some lane sits in a crowded cell: exhaustive exact loop for this group (rare)
         for (int o = 0; o < G.n_sph; ++o) {
@@ -660,6 +670,10 @@ __device__ __forceinline__ float waypoint_cost_grid(const GeomView& G, const uns
 //   keep_mask: spheres riding on frame 1 that static pruning dropped are parked (their hinge is exactly 0); a group of
 //   frame-1 spheres with no survivor is skipped.
 // ------------------------------------------------------------------------------------------------
+// issue priority of a wave with r groups of the model walk still to come after the current one (see model_group_positions)
+#ifndef MPB_COST_PRIO
+#define MPB_COST_PRIO(r) ((r) < 3 ? (r) : 3)
+#endif
 struct ModelFK {
     float r00, r01, r02, r10, r11, r12, r20, r21, r22, tx, ty, tz;
 };
@@ -702,6 +716,15 @@ __device__ __forceinline__ bool model_group_positions(ModelFK& F, const float (&
     constexpr int lo = first ? 4 * GRP : M::N_FRAME1 + 4 * (GRP - G1);
     constexpr int part_end = first ? M::N_FRAME1 : M::N_LINKS;
     constexpr int hi = (lo + 4 < part_end) ? lo + 4 : part_end;
+#ifndef MPB_NO_COST_PRIO
+    // issue priority by progress: the SIMD arbiter serves its oldest wave first, so without this the waves of a SIMD
+    // finish one after the other and the last one runs alone, latency-bound, at a fraction of the issue rate.  A wave
+    // that is behind (earlier group) outranks the ones ahead of it, which keeps all of them in flight to the end.
+    {
+        constexpr int NG_ = (M::N_FRAME1 + 3) / 4 + (M::N_LINKS - M::N_FRAME1 + 3) / 4;
+        __builtin_amdgcn_s_setprio(MPB_COST_PRIO(NG_ - 1 - GRP));
+    }
+#endif
     static_for<lo, hi>([&](auto lc) {
         constexpr int l = decltype(lc)::value;
         constexpr int f = M::LINK_FRAME[l];
@@ -754,6 +777,9 @@ __device__ __forceinline__ float waypoint_cost_grid_model(const GeomView& G, con
         const bool run = model_group_dispatch<M>(grp, F, q, keep, x, y, z, rl, std::make_integer_sequence<int, NG>{});
         if (run) spheres_hinge_grid<4>(G, gridw, otab, x, y, z, rl, cost);
     }
+#ifndef MPB_NO_COST_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     return cost;
 }
 

@@ -58,6 +58,11 @@ __device__ unsigned long long g_fstamps[256 * FUSED_WAVES * 12];
             unsigned long long t_;                                                                  \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
             __builtin_amdgcn_sched_barrier(0);                                                      \
+            if ((k) == 0) {   /* stamp 0 carries the SIMD the wave runs on in its top byte */        \
+                unsigned hw_;                                                                       \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 4, 2)" : "=s"(hw_));             \
+                t_ = (t_ & 0x00FFFFFFFFFFFFFFull) | ((unsigned long long)hw_ << 56);                \
+            }                                                                                       \
             if ((threadIdx.x & 63) == 0) g_fstamps[(blockIdx.x * FUSED_WAVES + (threadIdx.x >> 6)) * 12 + (k)] = t_; \
         }                                                                                           \
     } while (0)
@@ -264,8 +269,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         FSTAMP(5);
         if (it + 1 < n_iters) {
             // the noise of the NEXT iteration (it does not depend on the means) is drawn here, between publishing and polling:
-            // the partner's latency.  (Drawing it before barrier 1, to fill the wait for the block's slowest rollout, was
-            // measured slower: the SIMD's VALU is the bottleneck there, the early waves only starve the late ones.)
+            // the partner's latency.  (Drawing it before barrier 1 at the lowest issue priority, to fill the wait for the
+            // block's slowest rollout, was measured 15 % slower: the rollouts leave few issue slots free, and the matrix
+            // work that follows then runs with no Philox of another wave to overlap with.)
             float e[16];
             f32x4 acc[4];
             // (opaque copies: the first Philox round multiplies two counter words that do not change from one iteration to
@@ -278,7 +284,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
 #pragma unroll
             for (int q = 0; q < 16; ++q) e[q] = 0.01f * (float)(jv + q + it);
 #else
-            stomp_b_operand<DCH>(e, eps ? eps + (size_t)(it + 1) * eps_stride + (size_t)(live ? s : 0) * DCH * P * H : nullptr, P, p, jv, gv,
+#ifndef FUSED_NOISE_PRIO
+#define FUSED_NOISE_PRIO true
+#endif
+            stomp_b_operand<DCH, FUSED_NOISE_PRIO>(e, eps ? eps + (size_t)(it + 1) * eps_stride + (size_t)(live ? s : 0) * DCH * P * H : nullptr, P, p, jv, gv,
                                  particle_offset + (uint32_t)p, (uint32_t)s, iter0 + (uint32_t)(it + 1), seed_lo, seed_hi);
 #endif
 #ifdef FUSED_T_NOMFMA

@@ -28,6 +28,8 @@ print('200 iterations: %.2f us / iteration' % (e0.elapsed_time(e1) * 1e3 / 200))
 h = ctypes.CDLL(_lib.LIB_PATH)
 buf = np.zeros(256 * 16 * 12, dtype=np.uint64)
 assert h.mpb_debug_read_fstamps(buf.ctypes.data_as(ctypes.c_void_p), buf.size) == 0
+simd = (buf.reshape(256, 16, 12)[:, :, 0] >> np.uint64(56)).astype(np.int64)
+buf = buf & np.uint64(0x00FFFFFFFFFFFFFF)
 t = buf.reshape(256, 16, 12).astype(np.int64)
 names = ['A tile row, x = mean + noise, store', 'B cost (FK + SDF)', 'wait at barrier 1', 'C softmax stats + partial delta',
          'D publish + barrier 2 + flag', 'next noise (Philox + MFMA + tile)', 'poll + barrier 3', 'combine partials',
@@ -37,3 +39,8 @@ for k in range(11):
     print(f'{names[k]:40s} median {np.median(dd[:, k]):8.0f}  p90 {np.percentile(dd[:, k], 90):8.0f}  max {dd[:, k].max():8.0f}')
 tot = (t[:, :, 11] - t[:, :, 0]).reshape(-1)
 print('iteration (stamp 0 -> 11): median', np.median(tot), 'max', tot.max(), '(shader cycles; ~2.1 GHz)')
+for wg in (0, 1, 100):
+    t0 = t[wg, :, 0].min()
+    print(f'workgroup {wg}: wave simd | A start, B start, B end, barrier-1 release (cycles from the first wave\'s start)')
+    for w in np.argsort(simd[wg] * 100 + np.arange(16)):
+        print(f'   wave {w:2d} simd {simd[wg, w]} | {t[wg, w, 0] - t0:6d} {t[wg, w, 1] - t0:6d} {t[wg, w, 2] - t0:6d} {t[wg, w, 3] - t0:6d}')
