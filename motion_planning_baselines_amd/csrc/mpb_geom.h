@@ -497,6 +497,10 @@ __device__ __forceinline__ float waypoint_cost_chain(const float* __restrict__ g
     return c;
 }
 
+// issue priority of a wave with r groups of the chain walk still to come after the current one (see model_group_positions)
+#ifndef MPB_COST_PRIO
+#define MPB_COST_PRIO(r) ((r) < 3 ? (r) : 3)
+#endif
 __device__ __forceinline__ bool grid_usable(const GeomView& G) {
     return G.n_cells > 0 && G.n_cells <= MPB_GRID_MAX_CELLS && G.n_sph <= MPB_GRID_MAX_SPH;
 }
@@ -555,10 +559,10 @@ __device__ __forceinline__ void spheres_hinge_grid(const GeomView& G, const unsi
         over |= __ballot(w[i] == MPB_GRID_OVERFLOW);
     }
 #ifdef GEOM_T_NOTRIPS     // (tuning builds: no candidate loop)
-    over = 0ull;
+    if (true) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) best[i] = (w[i] == 12345u) ? 0.f : best[i];
-    if (false)
+        for (int i = 0; i < N; ++i) best[i] = (w[i] == 12345u) ? 0.f : best[i];
+    } else
 #endif
     if (__builtin_expect(over != 0ull, 0)) {
         // some lane sits in a crowded cell: exhaustive exact loop for this group (rare)
@@ -573,7 +577,8 @@ __device__ __forceinline__ void spheres_hinge_grid(const GeomView& G, const unsi
     } else {
         // candidate slot k of every sphere of the group at once (an unused slot holds n_sph, the far dummy of the
         // table: no index clamp); slot 0 is evaluated unconditionally (some lane of the wave always has a candidate),
-        // the later ones only while some lane still has one
+        // the later ones only while some lane still has one.  (Measured and rejected: the rare later slots sphere by
+        // sphere behind wave-uniform tests, +3 %; "slot in use" as one compare of w against a scalar threshold, +2 %.)
         const unsigned none = (unsigned)G.n_sph;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -630,6 +635,15 @@ __device__ __forceinline__ float waypoint_cost_grid(const GeomView& G, const uns
     float cost = 0.f;
     for (int l0 = 0; l0 < G.n_links; l0 += N) {
         const int nl = min(N, G.n_links - l0);
+#ifndef MPB_NO_COST_PRIO
+        // issue priority by the groups still to come (wave-uniform; see model_group_positions)
+        switch ((G.n_links - l0 - 1) / N) {
+            case 0: __builtin_amdgcn_s_setprio(MPB_COST_PRIO(0)); break;
+            case 1: __builtin_amdgcn_s_setprio(MPB_COST_PRIO(1)); break;
+            case 2: __builtin_amdgcn_s_setprio(MPB_COST_PRIO(2)); break;
+            default: __builtin_amdgcn_s_setprio(MPB_COST_PRIO(3)); break;
+        }
+#endif
         float x[N], y[N], z[N], rl[N];
         // the N link records of the group are fetched together, so the scalar-load latency is paid once per group
         // instead of once per sphere.  Records past n_links (last group) are read but never used: the words behind
@@ -656,6 +670,9 @@ __device__ __forceinline__ float waypoint_cost_grid(const GeomView& G, const uns
         }
         spheres_hinge_grid<N>(G, gridw, otab, x, y, z, rl, cost);
     }
+#ifndef MPB_NO_COST_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     return cost;
 }
 
@@ -670,10 +687,6 @@ __device__ __forceinline__ float waypoint_cost_grid(const GeomView& G, const uns
 //   keep_mask: spheres riding on frame 1 that static pruning dropped are parked (their hinge is exactly 0); a group of
 //   frame-1 spheres with no survivor is skipped.
 // ------------------------------------------------------------------------------------------------
-// issue priority of a wave with r groups of the model walk still to come after the current one (see model_group_positions)
-#ifndef MPB_COST_PRIO
-#define MPB_COST_PRIO(r) ((r) < 3 ? (r) : 3)
-#endif
 struct ModelFK {
     float r00, r01, r02, r10, r11, r12, r20, r21, r22, tx, ty, tz;
 };
@@ -902,6 +915,15 @@ __device__ __forceinline__ float waypoint_cost_grid_grad(const GeomView& G, cons
     float cost = 0.f;
     for (int l0 = 0; l0 < G.n_links; l0 += N) {
         const int nl = min(N, G.n_links - l0);
+#ifndef MPB_NO_COST_PRIO
+        // issue priority by the groups still to come (wave-uniform; see model_group_positions)
+        switch ((G.n_links - l0 - 1) / N) {
+            case 0: __builtin_amdgcn_s_setprio(MPB_COST_PRIO(0)); break;
+            case 1: __builtin_amdgcn_s_setprio(MPB_COST_PRIO(1)); break;
+            case 2: __builtin_amdgcn_s_setprio(MPB_COST_PRIO(2)); break;
+            default: __builtin_amdgcn_s_setprio(MPB_COST_PRIO(3)); break;
+        }
+#endif
         float x[N], y[N], z[N], rl[N];
         int fr[N];
         float4 lkv[N];
@@ -949,5 +971,8 @@ __device__ __forceinline__ float waypoint_cost_grid_grad(const GeomView& G, cons
             }
         }
     }
+#ifndef MPB_NO_COST_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     return cost;
 }

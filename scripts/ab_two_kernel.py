@@ -1,4 +1,3 @@
-"""Temporary A/B timer: per-iteration time of the persistent STOMP launch = (t(400) - t(200)) / 200, best of 5."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,14 +13,13 @@ Sigma, L = torch.inverse(R).to(dev).contiguous(), precision_to_scale_tril(R).to(
 geom = ops.DeviceGeometry(wl['robot'], wl['field'], dev)
 means0 = wl['means0'].clone()
 samples = torch.empty(P, S, H, d, device=dev); costs = torch.empty(P, S, device=dev); weights = torch.empty(P, S, device=dev)
-ws = ops.stomp_workspace(P, S, H, d, dev)
 def run(n):
     means = means0.clone()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    ops.stomp_run(means, None, samples, costs, weights, L, Sigma, geom, S, 7, 1e6, 1.0, 0.1, 1.0, ws, n_iters=n)
+    ops.stomp_step(means, None, samples, costs, weights, L, Sigma, geom, S, 7, 1e6, 1.0, 0.1, 1.0, n_iters=n)
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b)
-run(50)
-best = min((run(400) - run(200)) / 200 for _ in range(5))
-print('us/iter %.2f' % (best * 1e3), 'cost mean', float(costs.mean()))
+for _ in range(10): run(200)
+best = min(run(200) / 200 for _ in range(15))
+print('two-kernel us/iter %.2f' % (best * 1e3))

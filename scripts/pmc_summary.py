@@ -72,10 +72,10 @@ if kf:
     k = kf[0]
     s = summary[k]
     waves = grid[k][0] // 64
-    iters = int(os.environ.get('MPB_ITERS', 50))
+    iters = int(os.environ.get('MPB_ITERS', 200))
     fetch_kb, write_kb = s.get('FETCH_SIZE'), s.get('WRITE_SIZE')
     per = lambda c: (s[c] / waves / iters) if c in s else None
-    out = {'kernel': re.sub(r'\(.*', '', k), 'workload': 'C3 P=128 S=32 H=64 d=14 (scripts/prof_stomp.py, MPB_FUSED=1)',
+    out = {'kernel': re.sub(r'\(.*', '', k), 'workload': 'C3 P=128 S=32 H=64 d=14: bench.py\'s planner, launches of %d iterations from the initial means (scripts/prof_stomp.py, MPB_FUSED=1)' % iters,
            'waves_per_launch': waves, 'iterations_per_launch': iters, 'vgpr': grid[k][2], 'sgpr': grid[k][3], 'lds_bytes': grid[k][4],
            'scratch_bytes': grid[k][5],
            'SQ_INSTS_VALU_per_wave_iteration': per('SQ_INSTS_VALU'), 'SQ_INSTS_SALU_per_wave_iteration': per('SQ_INSTS_SALU'),

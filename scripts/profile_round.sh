@@ -11,7 +11,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-other-configs > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 echo "stats pass done"
-export MPB_ITERS=50 MPB_FUSED=1 MPB_LAUNCHES=6     # scripts/prof_stomp.py: the persistent kernel, 6 launches of 50 iterations
+export MPB_ITERS=200 MPB_FUSED=1 MPB_LAUNCHES=6     # scripts/prof_stomp.py: the persistent kernel, 6 launches of 200 iterations from the initial means = bench.py's timed launch
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $OUT/pmc1 -o p -- python3 scripts/prof_stomp.py > $OUT/pmc1.log 2>&1
 echo "pmc1 done"
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM SQ_INSTS_BRANCH SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA -d $OUT/pmc2 -o p -- python3 scripts/prof_stomp.py > $OUT/pmc2.log 2>&1
