@@ -21,6 +21,7 @@ Definitions (all fp32):
   * per-waypoint collision cost: sum_l relu(margin + r_l - min_o sdf_o(x_l)).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -29,8 +30,11 @@ GEOM_MAGIC = 0x4D504247  # 'MPBG'
 GEOM_VERSION = 5
 MAX_FIELDS = 4           # collision fields chained in one buffer (csrc/mpb_geom.h MPB_MAX_FIELDS)
 GEOM_HEADER_WORDS = 32
-GRID_MAX_DIM = 16       # cells per axis of the broad-phase grid (<= 4096 cells = 16 KB of LDS)
-GRID_CELL = 0.14        # target cell edge [m]
+GRID_MAX_DIM = 64       # cells per axis of the broad-phase grid
+GRID_MAX_CELLS = 4096   # = MPB_GRID_MAX_CELLS of csrc/mpb_geom.h: 16 KB of LDS
+GRID_CELL = 0.14        # coarsest target cell edge [m]; refined by GRID_REFINE steps down to GRID_CELL_MIN while the grid fits
+GRID_CELL_MIN = 0.05
+GRID_REFINE = 0.97
 GRID_PAD = 1024         # the grid section is padded to a multiple of this many words (one round of a 256-thread block's uint4 loads)
 GRID_OVERFLOW = 0xFFFFFFFE  # more than 4 candidates in the cell: the kernel tests every obstacle
 KIND_POINT = 0
@@ -237,10 +241,25 @@ def build_grid(spheres, a_max, slack=1e-4):
     lo = (c - R[:, None]).min(0)
     hi = (c + R[:, None]).max(0)
     ext = np.maximum(hi - lo, 1e-6)
-    dims = np.clip(np.ceil(ext / GRID_CELL).astype(np.int64), 1, GRID_MAX_DIM)
-    for ax in range(3):   # planar problems: one layer of cells along a degenerate axis
-        if np.ptp(c[:, ax]) == 0.0:
-            dims[ax] = 1
+    # the finest cubic cell, from GRID_CELL down to GRID_CELL_MIN, whose grid still fits GRID_MAX_CELLS words of LDS: finer
+    # cells list fewer obstacles each, and the kernels' candidate loop runs max-over-the-wave(candidates) times (C3: 0.14 m
+    # -> 1.36 trips per group of four collision spheres, 0.125 m = 17 x 15 x 16 cells -> 1.27; planar problems get one
+    # layer of cells along a degenerate axis)
+    def dims_for(edge):
+        dd = np.clip(np.ceil(ext / edge).astype(np.int64), 1, GRID_MAX_DIM)
+        for ax in range(3):
+            if np.ptp(c[:, ax]) == 0.0:
+                dd[ax] = 1
+        return dd
+    edge = GRID_CELL
+    dims = dims_for(edge)
+    while edge * GRID_REFINE >= GRID_CELL_MIN and dims_for(edge * GRID_REFINE).prod() <= GRID_MAX_CELLS:
+        edge *= GRID_REFINE
+        dims = dims_for(edge)
+    if dims.prod() > GRID_MAX_CELLS:          # (GRID_CELL itself too fine for a very large scene: coarsen)
+        while dims.prod() > GRID_MAX_CELLS:
+            edge /= GRID_REFINE
+            dims = dims_for(edge)
     cell = ext / dims
     # the kernel computes floor((x - lo32) * inv32) in fp32: keep lo / inv exactly as stored, and add the
     # worst-case fp32 index error (a point within 1e-5 of a cell face may land in the neighbour) to R

@@ -57,8 +57,10 @@ def stats(cell, maxdim, per_link=False):
     for gset in groups:
         trips.append(np.maximum(cnt[:, :, gset].max(axis=(1, 2)), 1))
     trips = np.stack(trips, 1)                                       # (waves, groups)
+    zero = np.stack([cnt[:, :, gset].max(axis=(1, 2)) == 0 for gset in groups], 1)
+    print('   fraction of (wave, group) pairs with NO candidate at all, by group:', np.round(zero.mean(0), 2), 'overall %.3f' % zero.mean())
     hist = np.bincount(cnt.reshape(-1), minlength=10) / cnt.size
     print(f'cell {cell:.3f} dims {dims} cells {dims.prod()} grid {g["stats"]}  lookup hist {np.round(hist[:6], 3)} overflow {hist[9]:.4f}'
           f'  mean trips/group {trips.mean():.3f}  (>=2: {np.mean(trips >= 2):.2f}, >=3: {np.mean(trips >= 3):.2f}, 4+: {np.mean(trips >= 4):.2f})')
-for cell, md in ((0.14, 16), (0.11, 20), (0.10, 24), (0.08, 32), (0.07, 32), (0.055, 40)):
+for cell, md in ((0.14, 16), (0.11, 20)):
     stats(cell, md)
