@@ -301,3 +301,56 @@ def test_stomp_workspace_size():
     f = _lib.lib().mpb_stomp_workspace_bytes
     assert f(128, 32, 64, 14) == 4 * 16 + 8 * (2 * 128 * 2 * 912)          # header + 8-byte {value, tag} granules, two parities
     assert f(3, 5, 64, 7) == 4 * 16 + 8 * (2 * 3 * 1 * 912) and f(0, 32, 64, 14) == 0
+
+
+@pytest.mark.parametrize('scene', ['spheres_3d', 'dense_2d', 'grid_circles_2d', 'large_3d'])
+def test_broad_phase_grid_is_conservative_and_fits(scene):
+    """geometry.build_grid: the grid fits the LDS image of the kernels (MPB_GRID_MAX_CELLS words), is refined below the
+    coarse target when there is room, and is conservative -- every obstacle within reach (r_o + a_max) of a point is listed
+    in the word of the point's cell (or the cell is marked overflow), with the cell index computed as the kernels do in fp32."""
+    from motion_planning_baselines_amd import geometry as G
+    rng = np.random.default_rng(5)
+    if scene == 'spheres_3d':
+        sph, a_max = G.env_spheres_3d().spheres, 0.13
+    elif scene == 'dense_2d':
+        sph, a_max = G.env_dense_2d().spheres, 0.02
+    elif scene == 'grid_circles_2d':
+        sph, a_max = G.env_grid_circles_2d().spheres, 0.015
+    else:   # a scene too large for the coarse target cell: the builder has to coarsen
+        c = rng.uniform(-6.0, 6.0, size=(40, 3))
+        sph, a_max = np.concatenate([c, rng.uniform(0.1, 0.4, size=(40, 1))], 1).astype(np.float32), 0.13
+    sph = np.asarray(sph, dtype=np.float32)
+    g = G.build_grid(sph, a_max)
+    dims, lo, inv, words = g['dims'].astype(np.int64), g['lo'], g['inv'], g['words']
+    n = len(sph)
+    assert dims.prod() == len(words) <= G.GRID_MAX_CELLS and (dims >= 1).all() and (dims <= G.GRID_MAX_DIM).all()
+    cell = 1.0 / inv.astype(np.float64)
+    if scene == 'large_3d':
+        assert cell.max() > G.GRID_CELL                      # coarsened
+    else:
+        assert cell[dims > 1].max() <= G.GRID_CELL * 1.0001  # never coarser than the target when it fits
+    planar = np.ptp(sph[:, 2]) == 0.0
+    assert (dims[2] == 1) == bool(planar)
+    # random points around the obstacles, cell index in fp32 exactly as grid_cell<true> (mpb_geom.h)
+    k = rng.integers(0, n, size=20000)
+    p = (sph[k, :3] + rng.normal(size=(20000, 3)).astype(np.float32) * (sph[k, 3:4] + a_max) * 1.2).astype(np.float32)
+    if planar:
+        p[:, 2] = sph[0, 2]
+    f = np.floor(p * inv + (-lo * inv).astype(np.float32)).astype(np.float32)     # fma vs mul+add: inside the 1e-5 m slack
+    f = np.clip(f, 0.0, (dims - 1).astype(np.float32))
+    idx = ((f[:, 2] * np.float32(dims[1]) + f[:, 1]) * np.float32(dims[0]) + f[:, 0]).astype(np.int64)
+    w = words[idx]
+    listed = np.stack([(w >> (8 * s)) & 0xFF for s in range(4)], 1)
+    d = np.linalg.norm(p[:, None, :3].astype(np.float64) - sph[None, :, :3].astype(np.float64), axis=2)
+    near = d < (sph[None, :, 3].astype(np.float64) + a_max)                       # obstacles that can matter at p
+    inside = ((p >= lo) & (p <= lo + dims / inv)).all(1)     # outside the grid box nothing is within reach by construction
+    assert not near[~inside].any()
+    for i in np.nonzero(near.any(1))[0]:
+        if w[i] == G.GRID_OVERFLOW:
+            continue
+        need = set(np.nonzero(near[i])[0].tolist())
+        assert need <= set(listed[i].tolist()), (scene, i, need, listed[i])
+    # slots fill in order and empty slots hold n (the far dummy of the obstacle table)
+    ok = w != G.GRID_OVERFLOW
+    used = listed[ok] != n
+    assert (listed[ok] <= n).all() and (used[:, 1:] <= used[:, :-1]).all()
