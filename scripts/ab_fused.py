@@ -1,4 +1,4 @@
-"""Tuning aid: per-iteration time of the persistent STOMP launch at C3 = (t(400) - t(200)) / 200, best of 15 after a warm-up; MPB_LIB_PATH selects the library build (scripts/ab_fused.sh alternates base and variants)."""
+"""Tuning aid: per-iteration time of the persistent STOMP launch at C3 = (t(400) - t(200)) / 200, min over 15 of each after a warm-up; MPB_LIB_PATH selects the library build (scripts/ab_fused.sh alternates base and variants)."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,5 +24,8 @@ def run(n):
     return a.elapsed_time(b)
 run(50)
 for _ in range(20): run(400)
-best = min((run(400) - run(200)) / 200 for _ in range(15))
+t4, t2 = [], []
+for _ in range(15):
+    t4.append(run(400)); t2.append(run(200))
+best = (min(t4) - min(t2)) / 200      # (min of each: a device stall in one run(200) must not shrink the difference)
 print('us/iter %.2f' % (best * 1e3), 'cost mean', float(costs.mean()))
