@@ -133,8 +133,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) Lp[stomp_l_image_index(row, col0 + e4)] = lv[e4];
         *reinterpret_cast<f32x4*>(sig_l + row * FUSED_LD + col0) = sv;
-        if (tid < N) mean_l[tid] = means[(size_t)p * N + tid];
+            if (tid < N) mean_l[tid] = means[(size_t)p * N + tid];
         if (tid == 0) s_abort = 0;
+        // header word 1 = this call's tag; word 0 (the error word) counts only when it equals it -- no memset per call
+        if (blockIdx.x == 0 && tid == 0) st_agent(ws + 1, __uint_as_float(tag0));
     }
     __syncthreads();
 
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         FSTAMP(11);
     }
     if (s_abort) {
-        if (tid == 0) st_agent(err_word, 1.0f);
+        if (tid == 0) st_agent(err_word, __uint_as_float(tag0));   // == header word 1 of THIS call: "timed out"
         return;
     }
     if (chunk == 0 && tid < N) means[(size_t)p * N + tid] = mean_l[tid];
@@ -412,12 +414,13 @@ extern "C" int mpb_stomp_run(float* means, const float* eps, float* samples, flo
     if (!(temperature > 0.f)) return mpb_fail(MPB_E_INVALID, "mpb_stomp_run: temperature must be > 0");
     const int nc = (S + FUSED_WAVES - 1) / FUSED_WAVES;
     hipStream_t st = (hipStream_t)stream;
-    // the error word starts at zero for every call; the granules need no initialisation: their tags carry a per-call
-    // epoch (process-wide counter scrambled over 32 bits), so whatever an earlier call -- or nobody -- left in the
-    // workspace does not match
-    if (hipMemsetAsync(workspace, 0, 64, st) != hipSuccess) return mpb_fail(MPB_E_HIP, "mpb_stomp_run: hipMemsetAsync failed");
+    // nothing in the workspace needs initialising: the granules' tags and the error word carry a per-call epoch
+    // (process-wide counter scrambled over 32 bits), so whatever an earlier call -- or nobody -- left there does not
+    // match.  Header: word 0 = tag of the call in which a workgroup timed out, word 1 = tag of the last call (written by
+    // block 0); "timed out" <=> word 0 == word 1 != 0.  (The memset this replaces was a dispatch of its own per call.)
     static std::atomic<uint32_t> epoch{(uint32_t)std::chrono::steady_clock::now().time_since_epoch().count()};
-    const uint32_t tag0 = (epoch.fetch_add(1u) + 1u) * 0x9E3779B9u;
+    uint32_t tag0 = (epoch.fetch_add(1u) + 1u) * 0x9E3779B9u;
+    if (tag0 == 0u) tag0 = 0x9E3779B9u;      // 0 is what the header holds after the two-kernel fallback
     const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
     const dim3 grid(P * nc), block(FUSED_THREADS);
     const int model = geom_flags & 0xFF;
@@ -440,10 +443,10 @@ extern "C" int mpb_stomp_run(float* means, const float* eps, float* samples, flo
 /* error word of the last mpb_stomp_run on this workspace (host-side read: synchronises the stream) */
 extern "C" int mpb_stomp_run_status(const float* workspace, void* stream, int* timed_out) {
     if (!workspace || !timed_out) return mpb_fail(MPB_E_INVALID, "mpb_stomp_run_status: null pointer");
-    float w = 0.f;
-    if (hipMemcpyAsync(&w, workspace, sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+    uint32_t w[2] = {0u, 0u};
+    if (hipMemcpyAsync(w, workspace, sizeof(w), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
         hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
         return mpb_fail(MPB_E_HIP, "mpb_stomp_run_status: copy failed");
-    *timed_out = (w != 0.f) ? 1 : 0;
+    *timed_out = (w[0] == w[1] && w[1] != 0u) ? 1 : 0;     // (after the two-kernel fallback both words are 0)
     return MPB_OK;
 }
