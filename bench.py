@@ -215,6 +215,12 @@ def bench_c2(dev, steps, with_cpu=True):
                      'loop: HBM sees the state once per CALL, so the per-iteration HBM figure is not a bound',
                      'algorithmic_bytes_per_call': alg_call, 'algorithmic_bytes_per_iter_survey': alg_call,
                      'hbm_frac_if_streamed_every_iter': alg_call / (med / steps) / 1e9 / HBM_PEAK_GBS}}
+    pmc, pmc_file = latest_profile('r*_pmc_chomp.json')
+    if pmc and pmc.get('SQ_INSTS_VALU_per_wave_iteration') and B == 1024:
+        ginstr = pmc['SQ_INSTS_VALU_per_wave_iteration'] * pmc['waves_per_launch'] / (med / steps) / 1e9
+        out['roofline'].update({'bound': 'valu', 'achieved': ginstr, 'peak': VALU_PEAK_GINSTR, 'unit': 'G wave-instr/s',
+                                'frac': ginstr / VALU_PEAK_GINSTR, 'pmc_source': pmc_file,
+                                'valu_instructions_per_wave_iteration': pmc['SQ_INSTS_VALU_per_wave_iteration']})
     if with_cpu:
         # CPU: the oracle's autograd restatement of chomp.py:134-149 on the full batch
         from oracle import planners_ref as O

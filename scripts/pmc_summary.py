@@ -3,7 +3,7 @@
     profiles/<tag>_pmc_per_wave.md          (every counter, per kernel, per launch and per wave)
     profiles/<tag>_pmc_kernelA.json         (what bench.py reads: VALU instructions per wave, HBM-side bytes per launch)
 usage: python scripts/pmc_summary.py gpurun_out/prof_<tag> <tag>"""
-import csv, glob, json, os, shutil, sqlite3, sys
+import csv, glob, json, os, re, shutil, sqlite3, sys
 from collections import defaultdict
 
 src, tag = sys.argv[1], sys.argv[2]
@@ -90,6 +90,20 @@ if kf:
     with open(os.path.join(prof, f'{tag}_pmc_stomp.json'), 'w') as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps(out, indent=1))
+
+kc = [k for k in summary if 'chomp_point4_kernel' in k]
+if kc:   # CHOMP C2 (scripts/prof_chomp.py: bench.py's c2 entry, MPB_CHOMP_ITERS iterations per launch)
+    k = kc[0]
+    s = summary[k]
+    waves = grid[k][0] // 64
+    iters = int(os.environ.get('MPB_CHOMP_ITERS', 500))
+    out = {'kernel': re.sub(r'\(.*', '', k) if 're' in dir() else k.split('(')[0], 'workload': 'C2 pointmass_dense_2d CHOMP B=1024 H=64 D=2, %d iterations per launch (scripts/prof_chomp.py)' % iters,
+           'waves_per_launch': waves, 'iterations_per_launch': iters, 'vgpr': grid[k][2], 'lds_bytes': grid[k][4], 'scratch_bytes': grid[k][5],
+           'SQ_INSTS_VALU_per_wave_iteration': s['SQ_INSTS_VALU'] / waves / iters if 'SQ_INSTS_VALU' in s else None,
+           'SQ_INSTS_SALU_per_wave_iteration': s['SQ_INSTS_SALU'] / waves / iters if 'SQ_INSTS_SALU' in s else None,
+           'SQ_INSTS_LDS_per_wave_iteration': s['SQ_INSTS_LDS'] / waves / iters if 'SQ_INSTS_LDS' in s else None}
+    with open(os.path.join(prof, f'{tag}_pmc_chomp.json'), 'w') as fh:
+        json.dump(out, fh, indent=1)
 
 ka = [k for k in summary if 'stomp_sample_cost' in k and 'true' in k]
 if ka:
