@@ -285,6 +285,20 @@ def bench_c4(dev, steps, with_cpu=True):
         'roofline': {'bound': 'mfma', 'achieved': tflops, 'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': tflops / FP64_MATRIX_PEAK_TFLOPS, 'structured_flop_per_iter': flop_iter,
                      'note': 'block-tridiagonal (14x14 blocks) elimination, sequential in t: a latency chain, not a GEMM'}}
+    pmc, pmc_file = latest_profile('r*_pmc_solve.json')
+    if pmc and pmc.get('SQ_INSTS_VALU_per_wave') and B == 2048:
+        # what actually binds the solve kernel (88 % of the iteration): fp64 VALU issue (4.7 cycles per wave-instruction,
+        # profiles/r01_microbench_valu.txt) and the W_t workspace stream; the whole iteration's time is used (conservative)
+        it_s = med / steps
+        ginstr = pmc['SQ_INSTS_VALU_per_wave'] * pmc['waves_per_launch'] / it_s / 1e9
+        peak64 = 1024 * 2.4 / 4.7
+        out['roofline']['valu_f64'] = {'achieved': ginstr, 'peak': peak64, 'unit': 'G wave-instr/s', 'frac': ginstr / peak64,
+                                       'valu_instructions_per_wave': pmc['SQ_INSTS_VALU_per_wave'], 'pmc_source': pmc_file}
+        if pmc.get('FETCH_SIZE_KB_raw_per_launch') and pmc.get('WRITE_SIZE_KB_raw_per_launch'):
+            traffic = (2 * pmc['FETCH_SIZE_KB_raw_per_launch'] + pmc['WRITE_SIZE_KB_raw_per_launch']) * 1024
+            out['roofline']['hbm'] = {'achieved': traffic / it_s / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                      'frac': traffic / it_s / 1e9 / HBM_PEAK_GBS, 'traffic': traffic,
+                                      'note': 'counter traffic of the solve kernel (FETCH_SIZE doubled per the guide + WRITE_SIZE): the W_t records written by the elimination and read back by the substitution'}
     if with_cpu:
         # CPU: the oracle's DENSE restatement (gpmp2.py:308-368, :451-452) on a small batch; the dense system of the
         # full batch needs > 150 GB, so the figure is extrapolated linearly in B and says so

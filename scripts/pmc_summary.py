@@ -91,6 +91,20 @@ if kf:
         json.dump(out, fh, indent=1)
     print(json.dumps(out, indent=1))
 
+kg = [k for k in summary if 'gpmp2_solve_kernel' in k]
+if kg:   # GPMP2 C4 (scripts/prof_gpmp2.py: one iteration per launch)
+    k = kg[0]
+    s = summary[k]
+    waves = grid[k][0] // 64
+    out = {'kernel': k.split('(')[0], 'workload': 'C4 panda_spheres GPMP2 B=2048 H=128 D=7, one iteration per launch (scripts/prof_gpmp2.py)',
+           'waves_per_launch': waves, 'vgpr': grid[k][2], 'lds_bytes': grid[k][4], 'scratch_bytes': grid[k][5]}
+    for c in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_INSTS_MFMA', 'SQ_INSTS_VMEM', 'SQ_WAVE_CYCLES', 'SQ_ACTIVE_INST_VALU',
+              'SQ_WAIT_INST_ANY', 'FETCH_SIZE', 'WRITE_SIZE'):
+        if c in s:
+            out[c + ('_KB_raw_per_launch' if c.endswith('SIZE') else '_per_wave')] = s[c] if c.endswith('SIZE') else s[c] / waves
+    with open(os.path.join(prof, f'{tag}_pmc_solve.json'), 'w') as fh:
+        json.dump(out, fh, indent=1)
+
 kc = [k for k in summary if 'chomp_point4_kernel' in k]
 if kc:   # CHOMP C2 (scripts/prof_chomp.py: bench.py's c2 entry, MPB_CHOMP_ITERS iterations per launch)
     k = kc[0]
