@@ -194,7 +194,9 @@ int mpb_stomp_step_profile(float *means, float *samples, float *costs, float *we
  * gaps.  Same arguments and outputs as mpb_stomp_step plus the caller-allocated workspace
  * (mpb_stomp_workspace_bytes; contents need not be initialised).  Served for H = 64, S <= 64, grid-backed fields
  * (geom_flags bit 8); any other call -- or workspace == NULL -- runs mpb_stomp_step.  The softmax is evaluated as
- * exp(x - m) / z over per-chunk partials, the same weights up to rounding.  mpb_stomp_run_status reads the error word
+ * exp(x - m) / z over per-chunk partials, the same weights up to rounding.  When the particles are at least as many as
+ * the CUs (and 16 < S <= 32) one workgroup per particle runs the samples as two batches of 16 instead -- no exchange, same
+ * bits (environment MPB_STOMP_BATCHES = 1 / 2 forces a layout; a test aid).  mpb_stomp_run_status reads the error word
  * (a partner workgroup that never arrived within 2 s; synchronises the stream). */
 size_t mpb_stomp_workspace_bytes(int P, int S, int H, int d);
 int mpb_stomp_run(float *means, const float *eps, float *samples, float *costs, float *weights,

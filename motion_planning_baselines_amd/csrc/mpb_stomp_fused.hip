@@ -18,7 +18,14 @@
 //   * softmax algebra: w_s = exp(x_s - m) / z with m = max_k m_k, z = sum_k exp(m_k - m) z_k -- the same weights as
 //     softmax(-c / T) up to rounding (the two-kernel path normalises before summing; both are within 1e-6 of fp64).
 // Every wait is bounded (s_memrealtime): a unit whose partner never shows up raises the error word and leaves.
+// With at least as many particles as CUs the launcher picks the other layout of the same kernel (template NB = 2): ONE
+// workgroup per particle runs the particle's S <= 32 samples as two batches of 16 and keeps the batches' partials in
+// registers -- no exchange, six instead of ten block barriers and one update instead of two per particle and iteration
+// (C5's per-GPU load: 0.531 -> 0.497 ms / iteration); the partials are combined with the expressions of the exchange
+// path, so both layouts produce the same bits (tests/test_gpu_stomp_fused.py).
 #include <hip/hip_runtime.h>
+
+#include <stdlib.h>
 
 #include <atomic>
 #include <chrono>
@@ -73,7 +80,12 @@ extern "C" int mpb_debug_read_fstamps(unsigned long long* dst, int n) {
 #define FSTAMP(k)
 #endif
 
-template <int DCH, int MODEL>
+// NB = 1: the unit is (particle, chunk of 16 samples), partners exchange partials through the workspace (above).
+// NB = 2: one workgroup per particle runs its S <= 32 samples as two batches of 16, one after the other, and keeps the
+//         batches' partials in registers -- no exchange, six instead of ten block barriers per particle and iteration, one
+//         update instead of two.  For loads with at least as many particles as CUs (C5); the partials are combined with
+//         the very expressions of the exchange path, so both layouts produce the same bits.
+template <int DCH, int MODEL, int NB>
 __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
     float* __restrict__ means, const float* __restrict__ eps, float* __restrict__ samples, float* __restrict__ costs,
     float* __restrict__ weights, const float* __restrict__ Lmat, const float* __restrict__ Sigma,
@@ -99,7 +111,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
     // unit of this block.  XCD-aware (speed only): blocks are dealt round-robin over the 8 XCDs, so blocks b and b + 8
     // share an L2 -- the nc chunks of a particle are given block indices 8 apart
     int p, chunk;
-    if ((P & 7) == 0) {
+    if (NB > 1) {
+        p = blockIdx.x;
+        chunk = 0;
+    } else if ((P & 7) == 0) {
         const int grp = blockIdx.x / (8 * nc), x = blockIdx.x & 7;
         chunk = (blockIdx.x >> 3) % nc;
         p = 8 * grp + x;
@@ -107,8 +122,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         p = blockIdx.x / nc;
         chunk = blockIdx.x - p * nc;
     }
-    const int s = chunk * FUSED_WAVES + wave;           // this wave's sample
-    const bool live = s < S;
+    int s = chunk * FUSED_WAVES + wave;                 // this wave's sample (NB > 1: of the current batch)
+    bool live = s < S;
     const int j = lane & 15, g = lane >> 4;
     float* err_word = ws;
     granule_t* xch = reinterpret_cast<granule_t*>(ws + 16);
@@ -154,6 +169,13 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
     }
 
     for (int it = 0; it < n_iters; ++it) {
+        // (NB > 1) partials of the batches, as the exchange path would publish them
+        float pm0 = -3.0e38f, pz0 = 0.f, pd0 = 0.f, pe0 = 0.f, pm1 = -3.0e38f, pz1 = 0.f, pd1 = 0.f, pe1 = 0.f;
+        float mb = 0.f, zb = 0.f, ex = 0.f, dpart = 0.f;
+        int tq = 0, hh = 0, cc = 0, sl = 0;
+#pragma nounroll
+        for (int bt = 0; bt < NB; ++bt) {
+        if (NB > 1) { s = bt * FUSED_WAVES + wave; live = s < S; }
         // ============ A. samples of this iteration: x = mean + noise, stored, kept packed in the wave's tile
         FSTAMP(0);
         float nz[16];
@@ -239,16 +261,16 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         // ============ C. partial of this chunk: logits, local max, e_w, z, weighted (sample - mean)
         // (thread-index arithmetic of the update phases is redone here from an opaque copy: hoisted out of the loop it
         // would sit in registers through the cost phase, which has none to spare)
-        int tq = tid;
+        tq = tid;
         asm volatile("" : "+v"(tq));
         const int lq = tq & 63;
-        const int hh = (tq < N) ? tq / DCH : 0, cc = (tq < N) ? tq - hh * DCH : 0;   // the trajectory element this thread owns
-        const int sl = chunk * FUSED_WAVES + (lq & 15);                     // every wave redundantly, lanes 0-15 carry the chunk
+        hh = (tq < N) ? tq / DCH : 0; cc = (tq < N) ? tq - hh * DCH : 0;   // the trajectory element this thread owns
+        sl = (NB > 1 ? bt : chunk) * FUSED_WAVES + (lq & 15);              // every wave redundantly, lanes 0-15 carry the chunk
         const float xs = (lq < FUSED_WAVES && sl < S) ? -cst[lq & 15] / temperature : -3.0e38f;
-        const float mb = wave_max_f32(xs);
-        const float ex = (lq < FUSED_WAVES && sl < S) ? expf(xs - mb) : 0.f;
-        const float zb = wave_sum_f32(ex);
-        float dpart = 0.f;
+        mb = wave_max_f32(xs);
+        ex = (lq < FUSED_WAVES && sl < S) ? expf(xs - mb) : 0.f;
+        zb = wave_sum_f32(ex);
+        dpart = 0.f;
         if (tq < N) {
             const float mu = mean_l[tq];
 #pragma unroll
@@ -257,10 +279,12 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
                 dpart = fmaf(ew, tiles[w * (H * NT_STRIDE) + tq] - mu, dpart);
             }
         }
-        float m_all = mb, z_all = zb, f_own = 1.f;
+        if (NB > 1) {            // (wave-uniform) keep this batch's partial
+            if (bt == 0) { pm0 = mb; pz0 = zb; pd0 = dpart; pe0 = ex; } else { pm1 = mb; pz1 = zb; pd1 = dpart; pe1 = ex; }
+        }
         FSTAMP(4);
         const unsigned tag = tag0 + (unsigned)it;                  // unique per (call, iteration): stale granules never match
-        if (nc > 1) {
+        if (NB == 1 && nc > 1) {
             // ============ D. publish the partial as tagged granules, then -- before reading the partners' -- the noise of
             //              the next iteration: by then their granules have long landed
             granule_t* mine = xch + ((size_t)(it & 1) * P * nc + (size_t)p * nc + chunk) * FUSED_XCHG;
@@ -269,7 +293,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         }
         __syncthreads();                                                     // (2) the samples in the tiles are consumed
         FSTAMP(5);
-        if (it + 1 < n_iters) {
+        const bool more_batches = NB > 1 && bt + 1 < NB;
+        const int it_n = more_batches ? it : it + 1;                       // (iteration, batch) whose noise is drawn now
+        const int s_n = NB > 1 ? (more_batches ? bt + 1 : 0) * FUSED_WAVES + wave : s;
+        if (it_n < n_iters) {
             // the noise of the NEXT iteration (it does not depend on the means) is drawn here, between publishing and polling:
             // the partner's latency.  (Drawing it before barrier 1 at the lowest issue priority, to fill the wait for the
             // block's slowest rollout, was measured 15 % slower: the rollouts leave few issue slots free, and the matrix
@@ -289,8 +316,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
 #ifndef FUSED_NOISE_PRIO
 #define FUSED_NOISE_PRIO true
 #endif
-            stomp_b_operand<DCH, FUSED_NOISE_PRIO>(e, eps ? eps + (size_t)(it + 1) * eps_stride + (size_t)(live ? s : 0) * DCH * P * H : nullptr, P, p, jv, gv,
-                                 particle_offset + (uint32_t)p, (uint32_t)s, iter0 + (uint32_t)(it + 1), seed_lo, seed_hi);
+            stomp_b_operand<DCH, FUSED_NOISE_PRIO>(e, eps ? eps + (size_t)it_n * eps_stride + (size_t)(s_n < S ? s_n : 0) * DCH * P * H : nullptr, P, p, jv, gv,
+                                 particle_offset + (uint32_t)p, (uint32_t)s_n, iter0 + (uint32_t)it_n, seed_lo, seed_hi);
 #endif
 #ifdef FUSED_T_NOMFMA
 #pragma unroll
@@ -300,9 +327,21 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
 #endif
             stomp_noise_to_tile(nt, acc, lane);           // (the samples packed in the tile were consumed before barrier 2)
         }
+        }   // batches
+        float m_all = mb, z_all = zb, f_own = 1.f, f_own0 = 1.f;
+        const unsigned tag = tag0 + (unsigned)it;
         float dsum = dpart;
         FSTAMP(6);
-        if (nc > 1) {
+        if (NB > 1) {
+            // the two batches combined in batch order with the expressions of the exchange path below
+            m_all = fmaxf(pm0, pm1);
+            const float f0 = expf(pm0 - m_all), f1 = expf(pm1 - m_all);
+            z_all = fmaf(f1, pz1, fmaf(f0, pz0, 0.f));
+            dsum = fmaf(f1, pd1, fmaf(f0, pd0, 0.f));
+            f_own0 = f0;
+            f_own = f1;
+        }
+        if (NB == 1 && nc > 1) {
             // every thread waits for ITS granules of every chunk (its own included: the very bits the partners read) --
             // no block barrier, no flag; combined in chunk order so that all partners compute bit-identical means
             float mk[FUSED_MAX_CHUNKS], zk[FUSED_MAX_CHUNKS], dk[FUSED_MAX_CHUNKS];
@@ -345,7 +384,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         }
         FSTAMP(8);
         // ============ E. weights out, delta (transposed) -> mean += lr * Sigma @ delta
-        if (tq < FUSED_WAVES && sl < S) weights[(size_t)p * S + sl] = ex * f_own / z_all;
+        if (NB > 1) {
+            const int sl0 = tq & 15;
+            if (tq < FUSED_WAVES && sl0 < S) weights[(size_t)p * S + sl0] = pe0 * f_own0 / z_all;
+            if (tq < FUSED_WAVES && sl < S) weights[(size_t)p * S + sl] = pe1 * f_own / z_all;
+        } else if (tq < FUSED_WAVES && sl < S) weights[(size_t)p * S + sl] = ex * f_own / z_all;
         if (tq < N) delta[cc * FUSED_LD + hh] = dsum / z_all;
         __syncthreads();                                                                        // (4) delta complete
         FSTAMP(9);
@@ -422,12 +465,30 @@ extern "C" int mpb_stomp_run(float* means, const float* eps, float* samples, flo
     uint32_t tag0 = (epoch.fetch_add(1u) + 1u) * 0x9E3779B9u;
     if (tag0 == 0u) tag0 = 0x9E3779B9u;      // 0 is what the header holds after the two-kernel fallback
     const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
-    const dim3 grid(P * nc), block(FUSED_THREADS);
+    // layout: one workgroup per (particle, chunk of 16 samples) with the exchange -- or, when there are at least as many
+    // particles as CUs and S <= 32, one workgroup per particle running two batches of 16 (no exchange; same bits).
+    // MPB_STOMP_BATCHES = 1 / 2 forces one or the other (2 only where it applies).
+    static const int force_nb = [] { const char* e = getenv("MPB_STOMP_BATCHES"); return e ? atoi(e) : 0; }();
+    int n_cu = 256;
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    }
+    // rounds of workgroups either layout needs on this chip: the two-batch workgroup takes ~1.88 x as long per iteration
+    const long r1 = (2L * P + n_cu - 1) / n_cu, r2 = ((long)P + n_cu - 1) / n_cu;
+    const bool two_batches = nc == 2 && force_nb != 1 && (force_nb == 2 || 188 * r2 < 100 * r1);
+    const dim3 grid(two_batches ? P : P * nc), block(FUSED_THREADS);
+    const int nc_k = two_batches ? 1 : nc;
     const int model = geom_flags & 0xFF;
-#define MPB_F_CASE(DCH, MODEL)                                                                                        \
-    hipLaunchKernelGGL((stomp_fused_kernel<DCH, MODEL>), grid, block, 0, st, means, eps, samples, costs, weights, L, \
-                       Sigma, geom, workspace, P, S, nc, k_sigma, weight, lr, temperature, n_iters, lo, hi, iter0,      \
+#define MPB_F_LAUNCH(DCH, MODEL, NB)                                                                                      \
+    hipLaunchKernelGGL((stomp_fused_kernel<DCH, MODEL, NB>), grid, block, 0, st, means, eps, samples, costs, weights, L, \
+                       Sigma, geom, workspace, P, S, nc_k, k_sigma, weight, lr, temperature, n_iters, lo, hi, iter0,        \
                        particle_offset, tag0)
+#define MPB_F_CASE(DCH, MODEL)                           \
+    do {                                                 \
+        if (two_batches) MPB_F_LAUNCH(DCH, MODEL, 2);    \
+        else MPB_F_LAUNCH(DCH, MODEL, 1);                \
+    } while (0)
     if (model == PandaModel::ID && d == 7) MPB_F_CASE(7, PandaModel::ID);
     else if (model == PandaModel::ID && d == 14) MPB_F_CASE(14, PandaModel::ID);
     else if (d == 2) MPB_F_CASE(2, 0);
@@ -437,6 +498,7 @@ extern "C" int mpb_stomp_run(float* means, const float* eps, float* samples, flo
     else if (d == 7) MPB_F_CASE(7, 0);
     else MPB_F_CASE(14, 0);
 #undef MPB_F_CASE
+#undef MPB_F_LAUNCH
     return mpb_check_launch("mpb_stomp_run");
 }
 

@@ -75,7 +75,9 @@ def test_stomp_run_free_running_vs_golden(gpu_device, name):
     (8, 64, True, 3),        # four workgroups per particle, d = 7
     (3, 30, False, 3),       # the reference example's S = 30: a partial last chunk; P not a multiple of 8
     (5, 5, True, 2),         # a quarter of one chunk
-    (300, 32, False, 2)])    # more units than CUs: workgroups run in rounds, partners are still co-scheduled
+    (300, 32, False, 2),     # more units than CUs: workgroups run in rounds, partners are still co-scheduled
+    (256, 32, False, 2),     # as many particles as CUs: one workgroup per particle, two batches of 16 samples (no exchange)
+    (260, 24, True, 2)])     # the same layout with a partial second batch, d = 7 (MPB_STOMP_BATCHES unset: chosen by the launcher)
 def test_stomp_run_equals_two_kernel_path(gpu_device, P, S, pos_only, n_iters):
     """Same device noise (Philox keyed by particle / sample / iteration), same geometry.
     (a) One iteration: the persistent kernel and the two-kernel loop write the same samples and costs bit for bit and
@@ -148,3 +150,47 @@ def test_stomp_run_pointmass_generic_model(gpu_device):
         res.append((means, samples, costs))
     assert rel_err(res[0][0], res[1][0]) < 2e-5 and rel_err(res[0][1], res[1][1]) < 2e-5
     np.testing.assert_allclose(res[0][2].cpu().numpy(), res[1][2].cpu().numpy(), rtol=1e-3, atol=1e-2)
+
+
+_LAYOUT_CHILD = r"""
+import sys, numpy as np, torch
+from motion_planning_baselines_amd import ops, workloads
+from motion_planning_baselines_amd.planners.stomp import precision_to_scale_tril, stomp_precision_matrix
+out, P, S, pos_only, n_iters = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), bool(int(sys.argv[4])), int(sys.argv[5])
+dev = torch.device('cuda:0')
+H = 64
+wl = workloads.panda_spheres_stomp(P, dev, H=H, S=S, pos_only=pos_only)
+d = wl['means0'].shape[-1]
+R = stomp_precision_matrix(H, wl['params']['dt'], 0.02, dict(device='cpu', dtype=torch.float32))
+Sigma, L = torch.inverse(R).to(dev).contiguous(), precision_to_scale_tril(R).to(dev).contiguous()
+geom = ops.DeviceGeometry(wl['robot'], wl['field'], dev)
+m = wl['means0'].clone()
+s, c, w = torch.empty(P, S, H, d, device=dev), torch.empty(P, S, device=dev), torch.empty(P, S, device=dev)
+ws = ops.stomp_workspace(P, S, H, d, dev)
+ops.stomp_run(m, None, s, c, w, L, Sigma, geom, S, 7, 1e6, 1.0, 0.1, 1e5, ws, n_iters=n_iters, seed=3, iter0=2)
+torch.cuda.synchronize()
+assert not ops.stomp_run_timed_out(ws)
+np.savez(out, means=m.cpu().numpy(), samples=s.cpu().numpy(), costs=c.cpu().numpy(), weights=w.cpu().numpy())
+"""
+
+
+@pytest.mark.parametrize('P,S,pos_only', [(6, 32, False), (5, 24, True), (9, 17, False)])
+def test_two_batch_layout_equals_exchange_layout(gpu_device, tmp_path, P, S, pos_only):
+    """The two work layouts of the persistent kernel -- two workgroups per particle exchanging their partials through the
+    workspace, or one workgroup running the particle's samples as two batches of 16 -- give the same bits: means,
+    samples, costs and weights after three iterations (MPB_STOMP_BATCHES forces the layout; one child process each)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    res = {}
+    for nb in (1, 2):
+        out = str(tmp_path / f'nb{nb}.npz')
+        env = dict(os.environ, MPB_STOMP_BATCHES=str(nb), PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
+        r = subprocess.run([sys.executable, '-c', _LAYOUT_CHILD, out, str(P), str(S), str(int(pos_only)), '3'],
+                           cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[nb] = np.load(out)
+    for k in ('samples', 'costs', 'weights', 'means'):
+        assert res[1][k].tobytes() == res[2][k].tobytes(), k
+    assert np.isfinite(res[1]['means']).all() and float(res[1]['costs'].max()) > 0
