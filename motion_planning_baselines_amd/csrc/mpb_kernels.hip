@@ -845,6 +845,8 @@ __global__ __launch_bounds__(256) void collision_cost_kernel(
                 if (h >= h_begin) {
                     if (GRAD)
                         c = G.fscale * (use_grid ? waypoint_cost_grid_grad(G, gridw, otab, q, dq) : waypoint_cost<true>(G, q, dq));
+                    else if (use_grid && G.model == PandaModel::ID)   // compile-time robot model (same bits as the table walk)
+                        c = G.fscale * waypoint_cost_grid_model<PandaModel>(G, gridw, otab, q);
                     else
                         c = G.fscale * (use_grid ? waypoint_cost_grid(G, gridw, otab, q) : waypoint_cost<false>(G, q, dq));
                 }

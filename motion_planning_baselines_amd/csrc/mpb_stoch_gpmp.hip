@@ -43,7 +43,11 @@ __global__ __launch_bounds__(256) void stoch_gpmp_cost_kernel(const float* __res
             float q[MPB_MAX_DOF], dq[MPB_MAX_DOF];
 #pragma unroll
             for (int i = 0; i < MPB_MAX_DOF; ++i) q[i] = (i < Dq) ? xs0[t * 2 * Dq + i] : 0.f;
-            const float c = use_grid ? waypoint_cost_grid(G, gridw, otab, q) : waypoint_cost<false>(G, q, dq);
+            // (the compile-time robot model where the geometry buffer carries its id -- set by pack_geometry, verified by
+            // mpb_geom_check against the model's constants; bit-identical to the table-driven walk)
+            float c;
+            if (use_grid && G.model == PandaModel::ID) c = waypoint_cost_grid_model<PandaModel>(G, gridw, otab, q);
+            else c = use_grid ? waypoint_cost_grid(G, gridw, otab, q) : waypoint_cost<false>(G, q, dq);
             acc += (double)K.kc * (double)(G.fscale * c);
         }
     }
