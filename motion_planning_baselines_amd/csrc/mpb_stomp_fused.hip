@@ -469,11 +469,11 @@ extern "C" int mpb_stomp_run(float* means, const float* eps, float* samples, flo
     // particles as CUs and S <= 32, one workgroup per particle running two batches of 16 (no exchange; same bits).
     // MPB_STOMP_BATCHES = 1 / 2 forces one or the other (2 only where it applies).
     static const int force_nb = [] { const char* e = getenv("MPB_STOMP_BATCHES"); return e ? atoi(e) : 0; }();
-    int n_cu = 256;
-    {
-        int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    }
+    static const int n_cu = [] {       // (every GPU of a node is the same part: asked once)
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
     // rounds of workgroups either layout needs on this chip: the two-batch workgroup takes ~1.88 x as long per iteration
     const long r1 = (2L * P + n_cu - 1) / n_cu, r2 = ((long)P + n_cu - 1) / n_cu;
     const bool two_batches = nc == 2 && force_nb != 1 && (force_nb == 2 || 188 * r2 < 100 * r1);
