@@ -249,6 +249,37 @@ def test_stomp_c5_per_gpu_load(gpu_device):
     assert torch.equal(cc, c)
 
 
+def test_stomp_c5_persistent_launch_matches_c3_layout(gpu_device):
+    """The persistent kernel at C5's per-GPU load (4096 particles: the launcher takes the one-workgroup-per-particle, two-batch
+    layout) against 128-particle launches of the same particles (two workgroups per particle exchanging their partials):
+    means, samples, costs and weights of those particles equal bit for bit after three iterations -- neither the layout, nor
+    the grid size, nor the block a particle lands in changes a result."""
+    from motion_planning_baselines_amd import ops
+    dev = gpu_device
+    P, S, H = 4096, 32, 64
+    wl, Sigma, L, geom = _c3(dev, P, S)
+    d = wl['means0'].shape[-1]
+    mk = lambda p: (torch.empty(p, S, H, d, device=dev), torch.empty(p, S, device=dev), torch.empty(p, S, device=dev))
+    args = (L, Sigma, geom, S, 7, 1e6, 1.0, 0.1, 1e5)
+    big = wl['means0'].clone()
+    s, c, w = mk(P)
+    ws = ops.stomp_workspace(P, S, H, d, dev)
+    ops.stomp_run(big, None, s, c, w, *args, ws, n_iters=3, seed=5)
+    torch.cuda.synchronize()
+    assert not ops.stomp_run_timed_out(ws)
+    assert torch.isfinite(big).all() and float(c.max()) > 0
+    assert torch.allclose(w.sum(1), torch.ones(P, device=dev), atol=1e-5)
+    ws2 = ops.stomp_workspace(128, S, H, d, dev)
+    for lo in (0, 1920, P - 128):
+        small = wl['means0'][lo:lo + 128].clone()
+        s2, c2, w2 = mk(128)
+        ops.stomp_run(small, None, s2, c2, w2, *args, ws2, n_iters=3, seed=5, particle_offset=lo)
+        torch.cuda.synchronize()
+        assert not ops.stomp_run_timed_out(ws2)
+        assert torch.equal(big[lo:lo + 128], small) and torch.equal(s[lo:lo + 128], s2), lo
+        assert torch.equal(c[lo:lo + 128], c2) and torch.equal(w[lo:lo + 128], w2), lo
+
+
 def test_static_link_pruning_changes_nothing(gpu_device):
     """The packed link table without the collision spheres that can never reach an obstacle (pack_geometry's static broad
     phase: 31 -> 28 for the C3 scene) gives bit-identical costs, per-waypoint costs and gradients at the C3 batch size."""
