@@ -447,7 +447,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVE
         {
 #pragma unroll
             for (int kb2 = 0; kb2 < 8; ++kb2) {
+#ifdef GP_T_GJ_STEPS   // (tuning builds: only the first GP_T_GJ_STEPS block steps -- wrong results, timing only)
+                if (2 * kb2 < dim && kb2 < GP_T_GJ_STEPS) {
+#else
                 if (2 * kb2 < dim) {
+#endif
                     const int k0 = 2 * kb2, q = kb2 >> 1, half = kb2 & 1;
                     const double tk = T[q];
                     const double p00 = readlane_f64(tk, (2 * half) * 16 + k0), p01 = readlane_f64(tk, (2 * half) * 16 + k0 + 1);
@@ -481,6 +485,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVE
         // ---- z = W r (r_j broadcast with v_readlane); store W_t, z_t
         double* wt = wW + (size_t)t * GP_WS_PER_T;
         double zi = 0.0;
+#ifdef GP_T_NO_Z       // (tuning builds: no z = W r -- wrong results, timing only)
+        zi = r * W[(lane < dim ? lane : 0) * GP_LD];
+        (void)wt;
+#else
         {
             const int rowl = (lane < dim) ? lane : 0;
             if (DT) {
@@ -490,6 +498,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVE
                 for (int j = 0; j < dim; ++j) zi = fma(W[rowl * GP_LD + j], readlane_f64(r, j), zi);
             }
         }
+#endif
 #ifndef GP_T_SKIP_STORE   // (tuning builds: elimination without the workspace traffic)
         if (lane < dim) wt[GP_TRI + lane] = zi;
 #pragma unroll
