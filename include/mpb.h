@@ -40,6 +40,8 @@ extern "C" {
 #define MPB_MAX_H 256
 #define MPB_MAX_DOF 8
 
+/* ABI version in the low bits; bit 30 set = a tuning build (compiled with wrong-result timing switches: never a product library) */
+#define MPB_VERSION_TUNING_BUILD 0x40000000
 int mpb_version(void);
 const char *mpb_last_error(void);
 
@@ -191,21 +193,52 @@ int mpb_stomp_step_profile(float *means, float *samples, float *costs, float *we
 /* The same loop as ONE persistent launch (csrc/mpb_stomp_fused.hip): a workgroup of 16 waves owns (particle, chunk of 16
  * samples) for all n_iters iterations -- constants, means and the iteration's samples stay in LDS, the partners of a
  * particle (S > 16) exchange their 3.6 KB partial sums through `workspace`; no per-iteration launch ramps or dispatch
- * gaps.  Same arguments and outputs as mpb_stomp_step plus the caller-allocated workspace
- * (mpb_stomp_workspace_bytes; contents need not be initialised).  Served for H = 64, S <= 64, grid-backed fields
- * (geom_flags bit 8); any other call -- or workspace == NULL -- runs mpb_stomp_step.  The softmax is evaluated as
- * exp(x - m) / z over per-chunk partials, the same weights up to rounding.  When the particles are at least as many as
- * the CUs (and 16 < S <= 32) one workgroup per particle runs the samples as two batches of 16 instead -- no exchange, same
- * bits (environment MPB_STOMP_BATCHES = 1 / 2 forces a layout; a test aid).  mpb_stomp_run_status reads the error word
- * (a partner workgroup that never arrived within 2 s; synchronises the stream). */
+ * gaps.  Same arguments and outputs as mpb_stomp_step plus the caller-allocated workspace (mpb_stomp_workspace_bytes;
+ * its first 64 bytes must be ZERO before the first call -- mpb_stomp_workspace_init -- and are maintained by the library
+ * afterwards; the rest need not be initialised; one workspace serves one call at a time).  Served for H = 64, S <= 64,
+ * grid-backed fields (geom_flags bit 8); any other call -- or workspace == NULL -- runs mpb_stomp_step
+ * (mpb_stomp_run_path tells which, without launching).  The softmax is evaluated as exp(x - m) / z over per-chunk
+ * partials, the same weights up to rounding.  When the particles are at least as many as the CUs (and 16 < S <= 32) one
+ * workgroup per particle runs the samples as two batches of 16 instead -- no exchange, same bits (environment
+ * MPB_STOMP_BATCHES = 1 / 2 forces a layout; a test aid).
+ *
+ * Failure contract.  The workgroups of a particle wait for each other's partial sums every iteration.  They are paired
+ * by a ticket drawn when a workgroup STARTS (not by block index), so partners are always workgroups that started next to
+ * each other and no dispatch order or co-residency is assumed; every wait is nevertheless bounded (2 s + 100 us per
+ * iteration; MPB_STOMP_TIMEOUT_US overrides, a test aid).  A workgroup whose partner does not arrive in time -- the
+ * device stopped starting this grid's workgroups for that long, e.g. another context holds every CU -- marks the call
+ * LOST: every workgroup leaves, the means of the affected particles are not written, samples / costs / weights are
+ * undefined.  The call still returns MPB_OK (it is asynchronous); the loss is reported
+ *   - by mpb_stomp_run_status (reads the workspace header; synchronises the stream): 0 fine, 1 lost, 2 header not zeroed;
+ *   - without synchronising, by mpb_stomp_run_checked's `status`: 4 words of pinned, device-mapped HOST memory
+ *     (hipHostMalloc), zero before the first call: [0] = tag of the last call that has completed, [1] = tag of the last
+ *     call that was lost (0: none), [2] = why (1 partner timed out, 2 header not zeroed); `tag_out` receives the tag
+ *     of this call (0 when it ran the two-kernel loop, which cannot be lost).  The caller compares [1] with the tags it
+ *     has issued whenever convenient -- planners/stomp.py raises at the next planner call.
+ * Not capturable in a HIP graph (the per-call tag is drawn on the host). */
+#define MPB_STOMP_PATH_TWO_KERNEL 0
+#define MPB_STOMP_PATH_PERSISTENT_EXCHANGE 1   /* one workgroup per (particle, chunk of 16 samples), partials exchanged */
+#define MPB_STOMP_PATH_PERSISTENT 2            /* one workgroup per particle (S <= 16, or two batches of 16), no exchange */
 size_t mpb_stomp_workspace_bytes(int P, int S, int H, int d);
+int mpb_stomp_workspace_init(float *workspace, size_t workspace_bytes, void *stream);
+int mpb_stomp_run_path(int geom_flags, size_t workspace_bytes, int P, int S, int H, int d);
 int mpb_stomp_run(float *means, const float *eps, float *samples, float *costs, float *weights,
                   const float *L, const float *Sigma, const float *geom, int geom_flags,
                   float *workspace, size_t workspace_bytes,
                   int P, int S, int H, int d, int D,
                   float k_sigma, float weight, float lr, float temperature,
                   int n_iters, uint64_t seed, uint32_t iter0, uint32_t particle_offset, void *stream);
+int mpb_stomp_run_checked(float *means, const float *eps, float *samples, float *costs, float *weights,
+                          const float *L, const float *Sigma, const float *geom, int geom_flags,
+                          float *workspace, size_t workspace_bytes,
+                          int P, int S, int H, int d, int D,
+                          float k_sigma, float weight, float lr, float temperature,
+                          int n_iters, uint64_t seed, uint32_t iter0, uint32_t particle_offset,
+                          uint32_t *status, uint32_t *tag_out, void *stream);
 int mpb_stomp_run_status(const float *workspace, void *stream, int *timed_out);
+/* Test aid: n_blocks workgroups that each take a whole CU's LDS and idle for `usec` microseconds (the "another stream
+ * keeps the chip busy" of the time-out tests); `sink` is one device word (never written in practice). */
+int mpb_debug_occupy(int n_blocks, uint64_t usec, uint32_t *sink, void *stream);
 int mpb_stomp_sample(const float *means, const float *eps, float *samples, const float *L,
                      const float *geom, int geom_flags, float *costs, /* geom, costs both NULL: sample only; both set: fused cost */
                      int P, int S, int H, int d, float k_sigma, float weight,

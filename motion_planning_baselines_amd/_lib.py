@@ -38,7 +38,11 @@ SIGNATURES = {
     'mpb_stomp_step': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _u64, _u32, _u32, _p],
     'mpb_stomp_workspace_bytes': [_i, _i, _i, _i],
     'mpb_stomp_run': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, ctypes.c_size_t, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _u64, _u32, _u32, _p],
+    'mpb_stomp_run_checked': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, ctypes.c_size_t, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _u64, _u32, _u32, _p, _p, _p],
     'mpb_stomp_run_status': [_p, _p, _p],
+    'mpb_stomp_workspace_init': [_p, ctypes.c_size_t, _p],
+    'mpb_stomp_run_path': [_i, ctypes.c_size_t, _i, _i, _i, _i],
+    'mpb_debug_occupy': [_i, _u64, _p, _p],
     'mpb_stomp_step_profile': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _u64, _u32, _u32, _p, _p, _p],
     'mpb_stomp_sample': [_p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _f, _f, _u64, _u32, _u32, _p],
     'mpb_stomp_update': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
@@ -84,6 +88,9 @@ def lib():
         fn.argtypes = argtypes
         fn.restype = (ctypes.c_char_p if name == 'mpb_last_error' else
                       ctypes.c_size_t if name in ('mpb_gpmp2_workspace_bytes', 'mpb_stomp_workspace_bytes') else ctypes.c_int)
+    if (h.mpb_version() & 0x40000000) and not os.environ.get('MPB_LIB_PATH'):
+        raise MPBError(f'{LIB_PATH} is a tuning build (compiled with wrong-result timing switches); rebuild with '
+                       f'motion_planning_baselines_amd.build.build(force=True)')
     _lib = h
     return h
 

@@ -31,7 +31,14 @@ def _stale():
 
 
 def build_variant(out, extra_flags, verbose=False):
-    """Tuning aid: build a variant of the library (extra -D flags) to another path."""
+    """Tuning aid: build a variant of the library (extra -D flags) to another path -- never to the product path.  The
+    wrong-result timing switches (GP_T_*) need -DMPB_TUNING_BUILD, added here; such a library reports itself through
+    mpb_version() and _lib.lib() only loads it when asked to by MPB_LIB_PATH."""
+    if os.path.abspath(out) == os.path.abspath(OUT):
+        raise ValueError('build_variant must not overwrite the product library')
+    extra_flags = list(extra_flags)
+    if any('_T_' in f for f in extra_flags) and '-DMPB_TUNING_BUILD' not in extra_flags:
+        extra_flags.append('-DMPB_TUNING_BUILD')
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     # per-file flags need per-file compiles
     objs = []
@@ -49,13 +56,20 @@ def build_variant(out, extra_flags, verbose=False):
 
 
 def build(force=False, verbose=True):
-    # the compile-time robot models (csrc/mpb_model_*.h) are generated from geometry.py, the single source of the numbers
+    """The product library.  Compiles with FLAGS + the per-file scheduling flags only: extra defines (HIPCC_FLAGS-style
+    environment hooks do not exist here) cannot reach it, and a tuning build is refused outright."""
+    # the compile-time robot models (csrc/mpb_model_*.h) are generated from geometry.py, the single source of the numbers.
+    # They are rewritten only when a build is going to run; on the fast path the committed header is only compared
+    # (ranks starting together must not write into the package, and it may be installed read-only)
     from . import model_gen
+    stale = force or _stale() or bool(model_gen.stale_headers())
+    if not stale:
+        return OUT
     for path in model_gen.write_headers():
         if verbose:
             print('regenerated', path, flush=True)
-    if not force and not _stale():
-        return OUT
+    if any('MPB_TUNING_BUILD' in f or '_T_' in f for f in FLAGS + [x for v in EXTRA.values() for x in v]):
+        raise RuntimeError('the product build must not carry tuning switches')
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     objs = []
     procs = []

@@ -6,6 +6,14 @@
 
 #include "../../include/mpb.h"
 
+// Wrong-result tuning switches (GP_T_*: by-elimination timing experiments on the GPMP2 solve) compile only with
+// -DMPB_TUNING_BUILD.  build.build() -- the product build -- refuses that flag, build.build_variant() adds it by
+// itself, and such a library says so in mpb_version() (bit 30), which _lib.lib() refuses unless it was asked for the
+// variant explicitly (MPB_LIB_PATH).
+#if !defined(MPB_TUNING_BUILD) && (defined(GP_T_GJ_STEPS) || defined(GP_T_NO_Z) || defined(GP_T_SKIP_STORE) || defined(GP_T_SKIP_SUBST))
+#error "a wrong-result tuning switch (GP_T_*) was defined without -DMPB_TUNING_BUILD"
+#endif
+
 // thread-local last-error string (defined in mpb_kernels.hip)
 char* mpb_err_buf();
 static inline int mpb_fail(int code, const char* msg) {

@@ -230,13 +230,8 @@ __device__ __forceinline__ void chunk_vs_obstacles(const GeomView& G, LinkChunk<
     const float4* cu = reinterpret_cast<const float4*>(G.cull);
     for (int ob = 0; ob < G.n_sph; ob += 4) {
         float4 k[8];
-#ifdef MPB_FAKE_OBST  // tuning experiment: no scalar loads in the obstacle loop (results are wrong)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) k[i] = make_float4(0.1f * i + 0.01f * ob, 0.2f * i, -0.1f * i, 0.05f + 0.01f * i);
-#else
 #pragma unroll
         for (int i = 0; i < 8; ++i) k[i] = cu[2 * ob + i];
-#endif
         if (MPB_CULL_MODE != 1 && cs.on) {
             const bool any = block_may_touch<GRAD>(C, k);
             cs.tested += 1;
@@ -550,20 +545,10 @@ __device__ __forceinline__ void spheres_hinge_grid(const GeomView& G, const unsi
         // a point outside the grid box is farther than margin + r_l from every obstacle (the box is the bounding box
         // of the inflated obstacles), so whatever candidates its CLAMPED cell lists all give hinge 0 exactly: no
         // in-bounds test (parked slots at 1e9 clamp to the last cell)
-#ifdef GEOM_T_NOCELL   // (tuning builds: no cell index, no grid word)
-        w[i] = 0x01010101u * (unsigned)G.n_sph + (unsigned)(x[i] > 1.0e8f);
-#else
         w[i] = gridw[grid_cell<true>(G, x[i], y[i], z[i])];
-#endif
         best[i] = 3.0e38f;
         over |= __ballot(w[i] == MPB_GRID_OVERFLOW);
     }
-#ifdef GEOM_T_NOTRIPS     // (tuning builds: no candidate loop)
-    if (true) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) best[i] = (w[i] == 12345u) ? 0.f : best[i];
-    } else
-#endif
     if (__builtin_expect(over != 0ull, 0)) {
         // some lane sits in a crowded cell: exhaustive exact loop for this group (rare)
         for (int o = 0; o < G.n_sph; ++o) {

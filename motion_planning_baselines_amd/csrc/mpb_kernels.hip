@@ -40,7 +40,11 @@ static int check_launch(const char* what) {
     return MPB_OK;
 }
 
-extern "C" int mpb_version(void) { return 1; }
+#ifdef MPB_TUNING_BUILD
+extern "C" int mpb_version(void) { return 2 | MPB_VERSION_TUNING_BUILD; }
+#else
+extern "C" int mpb_version(void) { return 2; }
+#endif
 extern "C" const char* mpb_last_error(void) { return g_err; }
 
 // A buffer tagged with a compile-time robot model (header word 29) must carry exactly that model's tables: the joint
@@ -333,21 +337,9 @@ __global__ __launch_bounds__(64 * MPB_A_WPB, 16 / MPB_A_WPB) void stomp_sample_c
     if (WITH_COST && grid0 && (int)threadIdx.x <= g_nsph && threadIdx.x <= MPB_GRID_MAX_SPH)
         otab[threadIdx.x] = oreg;                                                            // entry n_sph: the far dummy
     __syncthreads();
-    // ---- N = L * eps on the matrix cores
-    const f32x4* Lp4 = reinterpret_cast<const f32x4*>(Lp);
+    // ---- N = L * eps on the matrix cores (mpb_stomp_noise.h: the product the persistent kernel runs too)
     f32x4 acc[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks4 = 0; ks4 <= m; ++ks4) {
-            const f32x4 a = Lp4[((m * 4 + ks4) * 4 + g) * 16 + j];
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], e[4 * ks4 + 0], acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], e[4 * ks4 + 1], acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], e[4 * ks4 + 2], acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], e[4 * ks4 + 3], acc[m], 0, 0, 0);
-        }
-    }
+    stomp_noise_product(Lp, e, j, g, acc);
     MPB_STAMP(3);
     __syncthreads();  // every wave has read its A operands: the L image is dead, its space becomes the wave tiles
     MPB_STAMP(4);

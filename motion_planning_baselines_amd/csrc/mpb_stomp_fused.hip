@@ -17,7 +17,14 @@
 //     not depend on the means) is computed between publishing and polling, so the partner's latency is hidden;
 //   * softmax algebra: w_s = exp(x_s - m) / z with m = max_k m_k, z = sum_k exp(m_k - m) z_k -- the same weights as
 //     softmax(-c / T) up to rounding (the two-kernel path normalises before summing; both are within 1e-6 of fp64).
-// Every wait is bounded (s_memrealtime): a unit whose partner never shows up raises the error word and leaves.
+// Partners are paired by TICKET, not by block index: every workgroup of the exchange layout draws a ticket from a counter
+// in the workspace header when it starts, and consecutive tickets of a pool own the chunks of one particle.  Tickets are handed out
+// in the order the workgroups actually start, so the partners of a particle are always the workgroups that started next
+// to each other -- nothing is assumed about dispatch order or co-residency (HIP promises neither), and a grid of any
+// size makes progress as long as the device keeps starting its workgroups.  Every wait is still bounded
+// (s_memrealtime): a workgroup whose partner does not show up in time raises the error word -- in the workspace header
+// and, when the caller passed one, in a host-visible status block -- and every workgroup that starts afterwards leaves
+// at once; the caller (planners/stomp.py) turns that into an exception.  The last workgroup out resets the counters.
 // With at least as many particles as CUs the launcher picks the other layout of the same kernel (template NB = 2): ONE
 // workgroup per particle runs the particle's S <= 32 samples as two batches of 16 and keeps the batches' partials in
 // registers -- no exchange, six instead of ten block barriers and one update instead of two per particle and iteration
@@ -39,10 +46,25 @@
 #define FUSED_LD 68                        // padded row (floats) of the Sigma image and of the transposed delta tile
 #define FUSED_XCHG 912                     // granules per published partial: m, z, then H*d <= 896 values, padded
 #define FUSED_MAX_CHUNKS 4                 // S <= 64
-#define FUSED_TIMEOUT_TICKS 200000000ull   // 2 s of s_memrealtime (100 MHz)
+#define FUSED_TIMEOUT_TICKS 200000000ull   // 2 s of s_memrealtime (100 MHz) + FUSED_TIMEOUT_PER_ITER per iteration of the call
+#define FUSED_TIMEOUT_PER_ITER 10000ull    // 100 us: a workgroup whose partner starts a whole round of workgroups later waits that long
+// workspace header (16 words, zero before the first use: mpb_stomp_workspace_init; maintained by the kernel afterwards)
+#define FUSED_HDR_ERR 0      // tag of the call in which a workgroup gave up waiting (or found the header uninitialised)
+#define FUSED_HDR_TAG 1      // tag of the last call
+#define FUSED_HDR_DONE 2     // workgroups of the running call that have left; 0 between calls
+#define FUSED_HDR_WHY 3      // why FUSED_HDR_ERR was raised: 1 = partner timed out, 2 = header not initialised
+#define FUSED_HDR_TICKET 8   // words 8..15: next ticket of each of the 8 unit pools of the running call; 0 between calls
+// unit pools: pool x owns the particles p = x (mod FUSED_POOLS); a workgroup draws from the pool of the XCD it runs on
+// first (partners then share an L2: speed only), from the next pools once that one is exhausted
+#ifndef FUSED_POOLS
+#define FUSED_POOLS 8
+#endif
 
 __device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent_u(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned ld_agent_u(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_system_u(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 // one naturally aligned 8-byte granule {value, tag}, written by ONE agent-scope (sc1) store and read by ONE sc1 load: the
 // tag tells the reader which iteration of which call the value belongs to, so the payload needs no separate flag, no
 // drain of the stores and no fence (MI355X_MICROARCH.md: "handoff-1to1, data-tagged granules"; observed untorn)
@@ -91,7 +113,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
     float* __restrict__ weights, const float* __restrict__ Lmat, const float* __restrict__ Sigma,
     const float* __restrict__ geom, float* __restrict__ ws, int P, int S, int nc, float k_sigma, float weight, float lr,
     float temperature, int n_iters, uint32_t seed_lo, uint32_t seed_hi, uint32_t iter0, uint32_t particle_offset,
-    uint32_t tag0) {
+    uint32_t tag0, unsigned long long timeout_ticks, unsigned* __restrict__ status_host) {
     constexpr int H = 64;
     constexpr int N = H * DCH;                    // elements of a trajectory
     static_assert(N <= FUSED_THREADS && N + 2 <= FUSED_XCHG, "one thread per trajectory element");
@@ -104,28 +126,42 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
     __shared__ __attribute__((aligned(16))) float delta[DCH * FUSED_LD];                      // 3.7 KB (transposed)
     __shared__ float cst[FUSED_WAVES];
     __shared__ int s_abort;
+    __shared__ unsigned s_ticket;
 
     // the wave index as a SCALAR: everything derived from it (sample index, tile and output base addresses) then sits in
     // SGPRs, and per-lane addresses are a 32-bit offset from a uniform base instead of hoisted 64-bit VGPR pairs (which spill)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // unit of this block.  XCD-aware (speed only): blocks are dealt round-robin over the 8 XCDs, so blocks b and b + 8
-    // share an L2 -- the nc chunks of a particle are given block indices 8 apart
-    int p, chunk;
-    if (NB > 1) {
-        p = blockIdx.x;
-        chunk = 0;
-    } else if ((P & 7) == 0) {
-        const int grp = blockIdx.x / (8 * nc), x = blockIdx.x & 7;
-        chunk = (blockIdx.x >> 3) % nc;
-        p = 8 * grp + x;
-    } else {
-        p = blockIdx.x / nc;
-        chunk = blockIdx.x - p * nc;
+    unsigned* wsu = reinterpret_cast<unsigned*>(ws);
+    const bool exchange = NB == 1 && nc > 1;
+    // unit of this block: with partners to exchange with, by ticket (drawn here, read after the constants are staged);
+    // otherwise (one workgroup per particle) by block index
+    if (tid == 0) {
+        s_abort = 0;
+        unsigned u = blockIdx.x;
+        if (exchange) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+            bool got = false;
+            for (unsigned k = 0; k < FUSED_POOLS && !got; ++k) {
+                const unsigned pool = (xcc + k) % FUSED_POOLS;
+                const unsigned size = ((unsigned)P + FUSED_POOLS - 1u - pool) / FUSED_POOLS * (unsigned)nc;
+                if (size == 0u) continue;
+                const unsigned t = __hip_atomic_fetch_add(wsu + FUSED_HDR_TICKET + pool, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (t < size) {
+                    got = true;
+                    u = (FUSED_POOLS * (t / (unsigned)nc) + pool) * (unsigned)nc + t % (unsigned)nc;
+                }
+            }
+            // an earlier workgroup of this call has given up: the call is lost, leave at once
+            if (ld_agent_u(wsu + FUSED_HDR_ERR) == tag0) s_abort = 1;
+            if (!got) {       // (as many units as workgroups: only a header that was not zero before the call gets here)
+                s_abort = 2;
+                u = 0;
+            }
+        }
+        s_ticket = u;
     }
-    int s = chunk * FUSED_WAVES + wave;                 // this wave's sample (NB > 1: of the current batch)
-    bool live = s < S;
     const int j = lane & 15, g = lane >> 4;
-    float* err_word = ws;
     granule_t* xch = reinterpret_cast<granule_t*>(ws + 16);
 
     // ---- constants into LDS (once)
@@ -148,11 +184,16 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) Lp[stomp_l_image_index(row, col0 + e4)] = lv[e4];
         *reinterpret_cast<f32x4*>(sig_l + row * FUSED_LD + col0) = sv;
-            if (tid < N) mean_l[tid] = means[(size_t)p * N + tid];
-        if (tid == 0) s_abort = 0;
-        // header word 1 = this call's tag; word 0 (the error word) counts only when it equals it -- no memset per call
-        if (blockIdx.x == 0 && tid == 0) st_agent(ws + 1, __uint_as_float(tag0));
     }
+    __syncthreads();
+    const int ticket = __builtin_amdgcn_readfirstlane((int)s_ticket);
+    const int p = exchange ? ticket / nc : ticket;
+    const int chunk = exchange ? ticket - p * nc : 0;
+    int s = chunk * FUSED_WAVES + wave;                 // this wave's sample (NB > 1: of the current batch)
+    bool live = s < S;
+    if (tid < N) mean_l[tid] = means[(size_t)p * N + tid];
+    // header word 1 = this call's tag; word 0 (the error word) counts only when it equals it
+    if (ticket == 0 && tid == 0) st_agent_u(wsu + FUSED_HDR_TAG, tag0);    // (unit 0 is drawn exactly once)
     __syncthreads();
 
     const size_t eps_stride = (size_t)S * DCH * P * H;
@@ -168,7 +209,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         stomp_noise_to_tile(nt, acc, lane);
     }
 
-    for (int it = 0; it < n_iters; ++it) {
+    const int n_run = s_abort ? 0 : n_iters;          // (block-uniform: written before the barriers above)
+    for (int it = 0; it < n_run; ++it) {
         // (NB > 1) partials of the batches, as the exchange path would publish them
         float pm0 = -3.0e38f, pz0 = 0.f, pd0 = 0.f, pe0 = 0.f, pm1 = -3.0e38f, pz1 = 0.f, pd1 = 0.f, pe1 = 0.f;
         float mb = 0.f, zb = 0.f, ex = 0.f, dpart = 0.f;
@@ -226,16 +268,12 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
                     __syncthreads();
                 }
                 if (live && h >= 1) {
-#ifdef FUSED_T_NOCOST   // (tuning builds)
-                    c = q[0] * 1e-3f;
-#else
                     if (MODEL == PandaModel::ID) {
                         if (G.model == PandaModel::ID) c = fmaf(G.fscale, waypoint_cost_grid_model<PandaModel>(G, gridw, otab, q), c);
                         else bad = true;
                     } else {
                         c = fmaf(G.fscale, waypoint_cost_grid(G, gridw, otab, q), c);
                     }
-#endif
                 }
                 if (G.next == 0) break;
                 gp += G.next;
@@ -296,7 +334,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         const bool more_batches = NB > 1 && bt + 1 < NB;
         const int it_n = more_batches ? it : it + 1;                       // (iteration, batch) whose noise is drawn now
         const int s_n = NB > 1 ? (more_batches ? bt + 1 : 0) * FUSED_WAVES + wave : s;
-        if (it_n < n_iters) {
+        if (it_n < n_run) {
             // the noise of the NEXT iteration (it does not depend on the means) is drawn here, between publishing and polling:
             // the partner's latency.  (Drawing it before barrier 1 at the lowest issue priority, to fill the wait for the
             // block's slowest rollout, was measured 15 % slower: the rollouts leave few issue slots free, and the matrix
@@ -309,22 +347,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
             asm volatile("" : "+v"(jv), "+v"(gv));
             // (a k-block pipelined form -- Philox of block q+1 issued between the MFMAs of block q, straight-line code -- was
             // measured 3 % slower: the waves of a SIMD already overlap one wave's matrix work with another's Philox)
-#ifdef FUSED_T_NOPHILOX
-#pragma unroll
-            for (int q = 0; q < 16; ++q) e[q] = 0.01f * (float)(jv + q + it);
-#else
-#ifndef FUSED_NOISE_PRIO
-#define FUSED_NOISE_PRIO true
-#endif
-            stomp_b_operand<DCH, FUSED_NOISE_PRIO>(e, eps ? eps + (size_t)it_n * eps_stride + (size_t)(s_n < S ? s_n : 0) * DCH * P * H : nullptr, P, p, jv, gv,
-                                 particle_offset + (uint32_t)p, (uint32_t)s_n, iter0 + (uint32_t)it_n, seed_lo, seed_hi);
-#endif
-#ifdef FUSED_T_NOMFMA
-#pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m] = f32x4{e[4 * m], e[4 * m + 1], e[4 * m + 2], e[4 * m + 3]};
-#else
+            stomp_b_operand<DCH, true>(e, eps ? eps + (size_t)it_n * eps_stride + (size_t)(s_n < S ? s_n : 0) * DCH * P * H : nullptr, P, p, jv, gv,
+                                       particle_offset + (uint32_t)p, (uint32_t)s_n, iter0 + (uint32_t)it_n, seed_lo, seed_hi);
             stomp_noise_product(Lp, e, j, g, acc);
-#endif
             stomp_noise_to_tile(nt, acc, lane);           // (the samples packed in the tile were consumed before barrier 2)
         }
         }   // batches
@@ -364,7 +389,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
                 }
                 if (ok) break;
                 __builtin_amdgcn_s_sleep(2);
-                if (__builtin_amdgcn_s_memrealtime() - t0 > FUSED_TIMEOUT_TICKS) { s_abort = 1; break; }
+                if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) { s_abort = 1; break; }
             }
             FSTAMP(7);
             m_all = mk[0];
@@ -411,29 +436,102 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         __syncthreads();                                                                        // (5) new mean visible, tiles free
         FSTAMP(11);
     }
-    if (s_abort) {
-        if (tid == 0) st_agent(err_word, __uint_as_float(tag0));   // == header word 1 of THIS call: "timed out"
-        return;
+    const int aborted = s_abort;                        // (block-uniform: last written before a barrier every thread passed)
+    if (!aborted && chunk == 0 && tid < N) means[(size_t)p * N + tid] = mean_l[tid];
+    // ---- leaving: the error word (device header + the caller's host-visible status block), then the head count; the
+    //      last workgroup out re-arms the header for the next call and reports the call as completed
+    if (tid == 0) {
+        if (aborted) {
+            st_agent_u(wsu + FUSED_HDR_WHY, (unsigned)aborted);
+            st_agent_u(wsu + FUSED_HDR_ERR, tag0);   // == header word 1 of THIS call: "lost"
+            if (status_host) {
+                st_system_u(status_host + 2, (unsigned)aborted);
+                st_system_u(status_host + 1, tag0);
+                __threadfence_system();              // (rare path) visible to the host before the head count says "completed"
+            }
+        }
+        const unsigned left = __hip_atomic_fetch_add(wsu + FUSED_HDR_DONE, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (left == gridDim.x - 1u && aborted != 2) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) st_agent_u(wsu + FUSED_HDR_TICKET + k, 0u);
+            st_agent_u(wsu + FUSED_HDR_DONE, 0u);
+            if (status_host) st_system_u(status_host + 0, tag0);
+        }
     }
-    if (chunk == 0 && tid < N) means[(size_t)p * N + tid] = mean_l[tid];
 }
 
 // ------------------------------------------------------------------------------------------------
 // C-ABI
 // ------------------------------------------------------------------------------------------------
-extern "C" size_t mpb_stomp_workspace_bytes(int P, int S, int H, int d) {
-    (void)H; (void)d;
-    if (P < 1 || S < 1) return 0;
-    const int nc = (S + FUSED_WAVES - 1) / FUSED_WAVES;
-    return fused_ws_floats(P, nc) * sizeof(float);
+// test aid (mpb_debug_occupy): workgroups that each take a whole CU's LDS and spin for a given time -- the "other stream
+// keeps the chip busy" of the time-out tests
+__global__ __launch_bounds__(64) void occupy_kernel(unsigned long long ticks, unsigned* sink) {
+    __shared__ unsigned pad[150 * 256];                       // 150 KB: one such workgroup per CU
+    pad[threadIdx.x] = threadIdx.x;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    if (pad[(threadIdx.x + 1) & 63] == 0xFFFFFFFFu) sink[0] = 1u;   // (keeps the array)
 }
 
-// can the persistent kernel serve this call?  (geom_flags: bit 8 = every chained field has a usable broad-phase grid)
-static bool fused_applicable(int geom_flags, int S, int H, int d, size_t ws_bytes, int P) {
-    if (H != 64 || S > FUSED_WAVES * FUSED_MAX_CHUNKS || !(geom_flags & 0x100)) return false;
-    if (d != 2 && d != 3 && d != 4 && d != 6 && d != 7 && d != 14) return false;
-    const int nc = (S + FUSED_WAVES - 1) / FUSED_WAVES;
-    return ws_bytes >= fused_ws_floats(P, nc) * sizeof(float);
+extern "C" int mpb_debug_occupy(int n_blocks, uint64_t usec, uint32_t* sink, void* stream) {
+    if (n_blocks < 1 || !sink) return mpb_fail(MPB_E_INVALID, "mpb_debug_occupy: bad argument");
+    hipLaunchKernelGGL(occupy_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, usec * 100ull, sink);
+    return mpb_check_launch("mpb_debug_occupy");
+}
+
+static int device_cu_count() {       // (every GPU of a node is the same part: asked once)
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    return n_cu;
+}
+
+// which form of the loop serves a call, and the workspace it needs
+struct FusedPlan {
+    int path;            // MPB_STOMP_PATH_*: 0 two-kernel loop, 1 persistent with exchange, 2 persistent one workgroup per particle
+    int nc;              // workgroups per particle (exchange layout)
+    bool two_batches;    // one workgroup per particle runs two batches of 16 samples
+    size_t ws_bytes;     // workspace the persistent kernel needs (header only when nothing is exchanged)
+};
+static FusedPlan fused_plan(int geom_flags, int P, int S, int H, int d) {
+    FusedPlan f = {MPB_STOMP_PATH_TWO_KERNEL, 1, false, 0};
+    if (P < 1 || S < 1) return f;
+    if (H != 64 || S > FUSED_WAVES * FUSED_MAX_CHUNKS || !(geom_flags & 0x100)) return f;
+    if (d != 2 && d != 3 && d != 4 && d != 6 && d != 7 && d != 14) return f;
+    f.nc = (S + FUSED_WAVES - 1) / FUSED_WAVES;
+    // layout: one workgroup per (particle, chunk of 16 samples) with the exchange -- or, when there are at least as many
+    // particles as CUs and S <= 32, one workgroup per particle running two batches of 16 (no exchange; same bits).
+    // MPB_STOMP_BATCHES = 1 / 2 forces one or the other (2 only where it applies).
+    static const int force_nb = [] { const char* e = getenv("MPB_STOMP_BATCHES"); return e ? atoi(e) : 0; }();
+    const int n_cu = device_cu_count();
+    // rounds of workgroups either layout needs on this chip: the two-batch workgroup takes ~1.88 x as long per iteration
+    const long r1 = (2L * P + n_cu - 1) / n_cu, r2 = ((long)P + n_cu - 1) / n_cu;
+    f.two_batches = f.nc == 2 && force_nb != 1 && (force_nb == 2 || 188 * r2 < 100 * r1);
+    const bool exchange = f.nc > 1 && !f.two_batches;
+    f.path = exchange ? MPB_STOMP_PATH_PERSISTENT_EXCHANGE : MPB_STOMP_PATH_PERSISTENT;
+    f.ws_bytes = (exchange ? fused_ws_floats(P, f.nc) : 16) * sizeof(float);
+    return f;
+}
+
+extern "C" size_t mpb_stomp_workspace_bytes(int P, int S, int H, int d) {
+    if (P < 1 || S < 1) return 0;
+    // what the layout the launcher will pick needs (grid-backed fields assumed; a call the persistent kernel cannot
+    // serve needs none): the exchange area only when partner workgroups exchange partials, else just the header
+    const FusedPlan f = fused_plan(0x100, P, S, H, d);
+    return f.path == MPB_STOMP_PATH_TWO_KERNEL ? 16 * sizeof(float) : f.ws_bytes;
+}
+
+extern "C" int mpb_stomp_workspace_init(float* workspace, size_t workspace_bytes, void* stream) {
+    if (!workspace || workspace_bytes < 64) return mpb_fail(MPB_E_INVALID, "mpb_stomp_workspace_init: workspace too small");
+    if (hipMemsetAsync(workspace, 0, 64, (hipStream_t)stream) != hipSuccess) return mpb_fail(MPB_E_HIP, "mpb_stomp_workspace_init: memset failed");
+    return MPB_OK;
+}
+
+extern "C" int mpb_stomp_run_path(int geom_flags, size_t workspace_bytes, int P, int S, int H, int d) {
+    const FusedPlan f = fused_plan(geom_flags, P, S, H, d);
+    return (f.path != MPB_STOMP_PATH_TWO_KERNEL && workspace_bytes >= f.ws_bytes) ? f.path : MPB_STOMP_PATH_TWO_KERNEL;
 }
 
 extern "C" int mpb_stomp_step(float* means, const float* eps, float* samples, float* costs, float* weights,
@@ -441,52 +539,49 @@ extern "C" int mpb_stomp_step(float* means, const float* eps, float* samples, fl
                               float k_sigma, float weight, float lr, float temperature, int n_iters, uint64_t seed,
                               uint32_t iter0, uint32_t particle_offset, void* stream);
 
-extern "C" int mpb_stomp_run(float* means, const float* eps, float* samples, float* costs, float* weights,
-                             const float* L, const float* Sigma, const float* geom, int geom_flags, float* workspace,
-                             size_t workspace_bytes, int P, int S, int H, int d, int D, float k_sigma, float weight, float lr,
-                             float temperature, int n_iters, uint64_t seed, uint32_t iter0, uint32_t particle_offset,
-                             void* stream) {
+extern "C" int mpb_stomp_run_checked(float* means, const float* eps, float* samples, float* costs, float* weights,
+                                     const float* L, const float* Sigma, const float* geom, int geom_flags, float* workspace,
+                                     size_t workspace_bytes, int P, int S, int H, int d, int D, float k_sigma, float weight, float lr,
+                                     float temperature, int n_iters, uint64_t seed, uint32_t iter0, uint32_t particle_offset,
+                                     uint32_t* status, uint32_t* tag_out, void* stream) {
+    if (tag_out) *tag_out = 0u;
     if (P == 0 || n_iters == 0) return MPB_OK;
-    if (workspace && workspace_bytes >= 64 && !fused_applicable(geom_flags, S, H, d, workspace_bytes, P))
-        (void)hipMemsetAsync(workspace, 0, 64, (hipStream_t)stream);       // the status word reads "ok" after the fallback too
-    if (!workspace || !fused_applicable(geom_flags, S, H, d, workspace_bytes, P))
+    const FusedPlan f = fused_plan(geom_flags, P, S, H, d);
+    if (!workspace || f.path == MPB_STOMP_PATH_TWO_KERNEL || workspace_bytes < f.ws_bytes)
         return mpb_stomp_step(means, eps, samples, costs, weights, L, Sigma, geom, geom_flags, P, S, H, d, D, k_sigma, weight, lr,
                               temperature, n_iters, seed, iter0, particle_offset, stream);
     if (!means || !samples || !costs || !weights || !L || !Sigma || !geom) return mpb_fail(MPB_E_INVALID, "mpb_stomp_run: null pointer");
     if (P < 0 || S < 1 || n_iters < 0 || !(d == D || d == 2 * D)) return mpb_fail(MPB_E_INVALID, "mpb_stomp_run: bad shape");
     if (!(temperature > 0.f)) return mpb_fail(MPB_E_INVALID, "mpb_stomp_run: temperature must be > 0");
-    const int nc = (S + FUSED_WAVES - 1) / FUSED_WAVES;
     hipStream_t st = (hipStream_t)stream;
-    // nothing in the workspace needs initialising: the granules' tags and the error word carry a per-call epoch
-    // (process-wide counter scrambled over 32 bits), so whatever an earlier call -- or nobody -- left there does not
-    // match.  Header: word 0 = tag of the call in which a workgroup timed out, word 1 = tag of the last call (written by
-    // block 0); "timed out" <=> word 0 == word 1 != 0.  (The memset this replaces was a dispatch of its own per call.)
+    // the status block is host memory the device can write (pinned + mapped): its device address
+    unsigned* status_dev = nullptr;
+    if (status && hipHostGetDevicePointer(reinterpret_cast<void**>(&status_dev), status, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return mpb_fail(MPB_E_INVALID, "mpb_stomp_run: status is not pinned, device-mapped host memory");
+    }
+    // the granules' tags and the error word carry a per-call epoch (process-wide counter scrambled over 32 bits), so
+    // whatever an earlier call left in the exchange area does not match.  Header: word 0 = tag of the call in which a
+    // workgroup gave up, word 1 = tag of the last call; "lost" <=> word 0 == word 1 != 0.  Not capturable in a HIP
+    // graph: a replay would reuse the tag.
     static std::atomic<uint32_t> epoch{(uint32_t)std::chrono::steady_clock::now().time_since_epoch().count()};
     uint32_t tag0 = (epoch.fetch_add(1u) + 1u) * 0x9E3779B9u;
-    if (tag0 == 0u) tag0 = 0x9E3779B9u;      // 0 is what the header holds after the two-kernel fallback
+    if (tag0 == 0u) tag0 = 0x9E3779B9u;      // 0 means "none" in the header and the status block
+    if (tag_out) *tag_out = tag0;
     const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
-    // layout: one workgroup per (particle, chunk of 16 samples) with the exchange -- or, when there are at least as many
-    // particles as CUs and S <= 32, one workgroup per particle running two batches of 16 (no exchange; same bits).
-    // MPB_STOMP_BATCHES = 1 / 2 forces one or the other (2 only where it applies).
-    static const int force_nb = [] { const char* e = getenv("MPB_STOMP_BATCHES"); return e ? atoi(e) : 0; }();
-    static const int n_cu = [] {       // (every GPU of a node is the same part: asked once)
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        return n > 0 ? n : 256;
-    }();
-    // rounds of workgroups either layout needs on this chip: the two-batch workgroup takes ~1.88 x as long per iteration
-    const long r1 = (2L * P + n_cu - 1) / n_cu, r2 = ((long)P + n_cu - 1) / n_cu;
-    const bool two_batches = nc == 2 && force_nb != 1 && (force_nb == 2 || 188 * r2 < 100 * r1);
-    const dim3 grid(two_batches ? P : P * nc), block(FUSED_THREADS);
-    const int nc_k = two_batches ? 1 : nc;
+    // bound of every wait for a partner; MPB_STOMP_TIMEOUT_US overrides it (a test aid)
+    unsigned long long timeout = FUSED_TIMEOUT_TICKS + FUSED_TIMEOUT_PER_ITER * (unsigned long long)n_iters;
+    if (const char* e = getenv("MPB_STOMP_TIMEOUT_US")) { const long long us = atoll(e); if (us > 0) timeout = 100ull * (unsigned long long)us; }
+    const dim3 grid(f.two_batches ? P : P * f.nc), block(FUSED_THREADS);
+    const int nc_k = f.two_batches ? 1 : f.nc;
     const int model = geom_flags & 0xFF;
 #define MPB_F_LAUNCH(DCH, MODEL, NB)                                                                                      \
     hipLaunchKernelGGL((stomp_fused_kernel<DCH, MODEL, NB>), grid, block, 0, st, means, eps, samples, costs, weights, L, \
                        Sigma, geom, workspace, P, S, nc_k, k_sigma, weight, lr, temperature, n_iters, lo, hi, iter0,        \
-                       particle_offset, tag0)
+                       particle_offset, tag0, timeout, status_dev)
 #define MPB_F_CASE(DCH, MODEL)                           \
     do {                                                 \
-        if (two_batches) MPB_F_LAUNCH(DCH, MODEL, 2);    \
+        if (f.two_batches) MPB_F_LAUNCH(DCH, MODEL, 2);  \
         else MPB_F_LAUNCH(DCH, MODEL, 1);                \
     } while (0)
     if (model == PandaModel::ID && d == 7) MPB_F_CASE(7, PandaModel::ID);
@@ -502,13 +597,24 @@ extern "C" int mpb_stomp_run(float* means, const float* eps, float* samples, flo
     return mpb_check_launch("mpb_stomp_run");
 }
 
-/* error word of the last mpb_stomp_run on this workspace (host-side read: synchronises the stream) */
+extern "C" int mpb_stomp_run(float* means, const float* eps, float* samples, float* costs, float* weights,
+                             const float* L, const float* Sigma, const float* geom, int geom_flags, float* workspace,
+                             size_t workspace_bytes, int P, int S, int H, int d, int D, float k_sigma, float weight, float lr,
+                             float temperature, int n_iters, uint64_t seed, uint32_t iter0, uint32_t particle_offset,
+                             void* stream) {
+    return mpb_stomp_run_checked(means, eps, samples, costs, weights, L, Sigma, geom, geom_flags, workspace, workspace_bytes, P, S,
+                                 H, d, D, k_sigma, weight, lr, temperature, n_iters, seed, iter0, particle_offset, nullptr,
+                                 nullptr, stream);
+}
+
+/* state of the last persistent launch on this workspace (host-side read of the header: synchronises the stream):
+   0 = fine (or no persistent launch yet), 1 = a workgroup gave up waiting for its partner, 2 = header not initialised */
 extern "C" int mpb_stomp_run_status(const float* workspace, void* stream, int* timed_out) {
     if (!workspace || !timed_out) return mpb_fail(MPB_E_INVALID, "mpb_stomp_run_status: null pointer");
-    uint32_t w[2] = {0u, 0u};
+    uint32_t w[4] = {0u};
     if (hipMemcpyAsync(w, workspace, sizeof(w), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
         hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
         return mpb_fail(MPB_E_HIP, "mpb_stomp_run_status: copy failed");
-    *timed_out = (w[0] == w[1] && w[1] != 0u) ? 1 : 0;     // (after the two-kernel fallback both words are 0)
+    *timed_out = (w[FUSED_HDR_ERR] == w[FUSED_HDR_TAG] && w[FUSED_HDR_TAG] != 0u) ? (w[FUSED_HDR_WHY] == 2u ? 2 : 1) : 0;
     return MPB_OK;
 }

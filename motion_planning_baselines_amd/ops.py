@@ -335,16 +335,65 @@ def stomp_step(means, eps, samples, costs, weights, L, Sigma, geom, S, D, k_sigm
 
 
 def stomp_workspace(P, S, H, d, device):
-    """Exchange buffer of the persistent STOMP kernel (mpb_stomp_run); contents need not be initialised."""
+    """Exchange buffer of the persistent STOMP kernel (mpb_stomp_run): header zeroed (mpb_stomp_workspace_init), the
+    rest need not be initialised.  One workspace serves one call at a time."""
     n = int(_lib.lib().mpb_stomp_workspace_bytes(int(P), int(S), int(H), int(d)))
-    return torch.empty((n + 3) // 4, device=device, dtype=torch.float32)
+    ws = torch.empty((n + 3) // 4, device=device, dtype=torch.float32)
+    with torch.cuda.device(ws.device):
+        _lib.check(_lib.lib().mpb_stomp_workspace_init(_ptr(ws), ws.numel() * 4, _stream()), 'mpb_stomp_workspace_init')
+    return ws
+
+
+STOMP_PATH_TWO_KERNEL, STOMP_PATH_PERSISTENT_EXCHANGE, STOMP_PATH_PERSISTENT = 0, 1, 2
+
+
+def stomp_run_path(geom, workspace, P, S, H, d):
+    """Which form of the loop mpb_stomp_run takes for this call (STOMP_PATH_*), without launching anything."""
+    nbytes = 0 if workspace is None else workspace.numel() * 4
+    with torch.cuda.device(geom.buf.device):
+        return int(_lib.lib().mpb_stomp_run_path(int(geom.flags), nbytes, int(P), int(S), int(H), int(d)))
+
+
+class StompRunStatus:
+    """Host-visible status block of mpb_stomp_run_checked: 4 words of pinned host memory the kernel writes directly
+    ([0] tag of the last completed call, [1] tag of the last LOST call, [2] why), read here without synchronising."""
+
+    def __init__(self):
+        self.buf = torch.zeros(4, dtype=torch.int32).pin_memory()
+        self._view = self.buf.numpy().view(np.uint32)
+        self.issued = []             # tags of the persistent launches not yet known to be complete, in launch order
+        self.tag_c = ctypes.c_uint32(0)
+
+    def ptr(self):
+        return ctypes.c_void_p(self.buf.data_ptr())
+
+    def note_launch(self):
+        tag = int(self.tag_c.value)
+        if tag:
+            self.issued.append(tag)
+        return tag
+
+    def lost(self):
+        """(tag, why) of a lost call among the ones issued through this block, else None.  Reads host memory only."""
+        lost, done = int(self._view[1]), int(self._view[0])
+        if lost and lost in self.issued:
+            return lost, int(self._view[2])
+        if done in self.issued:      # calls complete in launch order: everything up to `done` is over, and was fine
+            del self.issued[:self.issued.index(done) + 1]
+        return None
+
+    def acknowledge(self, tag):
+        """Forget a lost call (after it has been reported)."""
+        if tag in self.issued:
+            del self.issued[:self.issued.index(tag) + 1]
 
 
 @_on_tensor_device
 def stomp_run(means, eps, samples, costs, weights, L, Sigma, geom, S, D, k_sigma, weight, lr, temperature, workspace,
-              n_iters=1, seed=0, iter0=0, particle_offset=0):
+              n_iters=1, seed=0, iter0=0, particle_offset=0, status=None):
     """stomp_step as ONE persistent launch where the shape allows it (H = 64, S <= 64, grid-backed fields), the
-    two-kernel loop otherwise (the C side decides)."""
+    two-kernel loop otherwise (the C side decides).  status: a StompRunStatus the kernel reports a lost call to
+    (include/mpb.h, "Failure contract"); returns the call's tag (0: two-kernel loop)."""
     P, H, d = means.shape
     _chk(means, (P, H, d), 'means')
     _chk(samples, (P, S, H, d), 'samples')
@@ -356,20 +405,37 @@ def stomp_run(means, eps, samples, costs, weights, L, Sigma, geom, S, D, k_sigma
         _chk(eps, (n_iters, S, d, P, H), 'eps')
     if workspace is not None:
         _chk(workspace, tuple(workspace.shape), 'workspace')
-    _lib.check(_lib.lib().mpb_stomp_run(
+    _lib.check(_lib.lib().mpb_stomp_run_checked(
         _ptr(means), _ptr(eps), _ptr(samples), _ptr(costs), _ptr(weights), _ptr(L), _ptr(Sigma), _ptr(geom.buf),
         int(geom.flags), _ptr(workspace), 0 if workspace is None else workspace.numel() * 4,
         P, S, H, d, D, float(k_sigma), float(weight), float(lr), float(temperature), int(n_iters),
-        int(seed) & (2 ** 64 - 1), int(iter0), int(particle_offset), _stream()), 'mpb_stomp_run')
+        int(seed) & (2 ** 64 - 1), int(iter0), int(particle_offset),
+        None if status is None else status.ptr(), None if status is None else ctypes.byref(status.tag_c), _stream()),
+        'mpb_stomp_run')
+    return 0 if status is None else status.note_launch()
 
 
-def stomp_run_timed_out(workspace):
-    """Did a workgroup of the last stomp_run on this workspace give up waiting for its partner?  (synchronises)"""
+def stomp_run_state(workspace):
+    """State of the last persistent stomp_run on this workspace (synchronises): 0 fine, 1 a workgroup gave up waiting
+    for its partner (the call is lost), 2 the workspace header was not zeroed."""
     out = ctypes.c_int(0)
     with torch.cuda.device(workspace.device):
         _lib.check(_lib.lib().mpb_stomp_run_status(_ptr(workspace), _stream(), ctypes.cast(ctypes.pointer(out), ctypes.c_void_p)),
                    'mpb_stomp_run_status')
-    return bool(out.value)
+    return int(out.value)
+
+
+def stomp_run_timed_out(workspace):
+    """Was the last persistent stomp_run on this workspace lost?  (synchronises)"""
+    return stomp_run_state(workspace) != 0
+
+
+def debug_occupy(n_blocks, usec, device):
+    """Test aid: n_blocks workgroups that each take a CU's LDS and idle for `usec` microseconds on the current stream."""
+    sink = torch.zeros(1, dtype=torch.int32, device=device)
+    with torch.cuda.device(sink.device):
+        _lib.check(_lib.lib().mpb_debug_occupy(int(n_blocks), int(usec), _ptr(sink), _stream()), 'mpb_debug_occupy')
+    return sink
 
 
 @_on_tensor_device

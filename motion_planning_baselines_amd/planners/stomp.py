@@ -9,6 +9,7 @@ bit-identical), buffer ownership, noise-source selection.  Device side: mpb_stom
 import torch
 
 from .. import ops
+from .._lib import MPBError
 from .base import OptimizationPlanner
 from .costs.cost_functions import device_plan, fusable_collision
 
@@ -34,6 +35,10 @@ def precision_to_scale_tril(P):
     return torch.linalg.solve_triangular(L_inv, Id, upper=False).contiguous()   # (some LAPACK back-ends hand back a transposed view)
 
 
+class PersistentLaunchLost(MPBError):
+    """A persistent (one-launch) optimisation loop was abandoned by the device side: see STOMP's `check` argument."""
+
+
 class STOMP(OptimizationPlanner):
     """Drop-in for mp_baselines.planners.stomp.STOMP (ctor kwargs stomp.py:10-32).
 
@@ -45,13 +50,21 @@ class STOMP(OptimizationPlanner):
       seed / particle_offset: Philox key and global index of this shard's first particle.
       persistent: run a collision-only cost's loop as ONE persistent launch (mpb_stomp_run) where the shape allows it
              (default); False keeps the two-kernels-per-iteration path (mpb_stomp_step).
+      check: what happens when a persistent launch is LOST (include/mpb.h, "Failure contract": its workgroups wait for
+             each other, every wait is bounded, and a wait that runs out -- the device stopped starting this launch's
+             workgroups for seconds, e.g. another context holds every CU -- abandons the call).  A lost call never
+             goes unnoticed: 'deferred' (default) raises PersistentLaunchLost at the next call into the planner
+             (optimize / reset / sample / get_traj / persistent_timed_out) -- the kernel reports into pinned host memory, so
+             the fast path has no synchronisation; 'sync' synchronises the stream at the end of optimize() and raises
+             there.  After the exception the means of the particles the lost call did not finish are the ones from before
+             that call; samples / costs / weights are undefined: reset() the planner (or re-run from saved means).
     """
 
     def __init__(self, n_dof, n_support_points, num_particles_per_goal, num_samples, opt_iters, dt, start_state,
                  cost=None, initial_particle_means=None, multi_goal_states=None, sigma_start_init=0.001,
                  sigma_goal_init=0.001, sigma_gp_init=10., temperature=1., step_size=1., sigma_spectral=0.1,
                  goal_state=None, pos_only=True, tensor_args=None, noise='philox', seed=0, particle_offset=0,
-                 persistent=True, **kwargs):
+                 persistent=True, check='deferred', **kwargs):
         super().__init__(name='STOMP', n_dof=n_dof, n_support_points=n_support_points,
                          num_particles_per_goal=num_particles_per_goal, opt_iters=opt_iters, dt=dt,
                          start_state=start_state, cost=cost, initial_particle_means=initial_particle_means,
@@ -59,6 +72,9 @@ class STOMP(OptimizationPlanner):
                          sigma_goal_init=sigma_goal_init, sigma_gp_init=sigma_gp_init, pos_only=pos_only,
                          tensor_args=tensor_args)
         assert noise in ('philox', 'torch', 'torch_cpu')
+        assert check in ('deferred', 'sync')
+        self.check = check
+        self._status = None              # host-visible status block of the persistent launches (allocated on first use)
         self.lr = step_size
         self.sigma_spectral = sigma_spectral
         self.start_state = start_state          # quirk Q10: overwrites the zero-velocity-extended state
@@ -128,6 +144,7 @@ class STOMP(OptimizationPlanner):
 
     def sample(self):
         """stomp.py:97-108: fresh state_particles (P,S,H,d) around the current means."""
+        self._raise_if_lost()
         eps = self._draw_eps(1)
         ops.stomp_sample(self._particle_means, None if eps is None else eps[0], self.state_particles,
                          self.scale_tril, self.num_samples, seed=self.seed, it=self._iter,
@@ -137,6 +154,7 @@ class STOMP(OptimizationPlanner):
 
     def reset(self, initial_particle_means=None):
         """stomp.py:110-120."""
+        self._raise_if_lost()
         if initial_particle_means is not None:
             m = initial_particle_means.clone()
         else:
@@ -148,25 +166,54 @@ class STOMP(OptimizationPlanner):
     def optimize(self, opt_iters=None, **observation):
         """stomp.py:137-148: run the iterations, return the current trajectory (P,H,d)."""
         self._run_optimization(opt_iters, **observation)
+        if self.check == 'sync':
+            self._raise_if_lost(synchronize=True)
         return self._get_traj()
+
+    def get_traj(self):
+        self._raise_if_lost()
+        return self._get_traj()
+
+    def _raise_if_lost(self, synchronize=False):
+        """Raise PersistentLaunchLost if a persistent launch issued by this planner has been abandoned (class docstring,
+        `check`).  Reads pinned host memory the kernel writes: no device synchronisation unless asked for."""
+        if self._status is None:
+            return
+        if synchronize:
+            torch.cuda.current_stream(self.device).synchronize()
+        lost = self._status.lost()
+        if lost is not None:
+            tag, why = lost
+            self._status.acknowledge(tag)
+            raise PersistentLaunchLost(
+                'the persistent STOMP launch (tag 0x%08x) was abandoned: %s.  The means of the particles it did not finish '
+                'are unchanged from before that optimize() call; samples, costs and weights are undefined.  reset() the '
+                'planner (or restore saved means) and run again; persistent=False selects the two-kernel path, which '
+                'has no inter-workgroup waits.' % (tag, {
+                    1: 'a workgroup waited longer than the bound for the partner workgroups of its particle (the device did '
+                       'not start them: is another context or stream holding the whole GPU?)',
+                    2: 'the workspace header was not zero before the first call'}.get(why, 'reason %d' % why)))
 
     def _run_optimization(self, opt_iters, **observation):
         if opt_iters is None:
             opt_iters = self.opt_iters
+        self._raise_if_lost()
         fused = fusable_collision(self.cost)
         if fused is not None and not observation:
             cc, weight = fused
             eps = self._draw_eps(opt_iters)
             # the whole loop as one persistent launch where the shape allows it (H = 64, S <= 64, grid-backed fields);
             # mpb_stomp_run falls back to the two-kernel loop by itself otherwise
-            if self._run_ws is None:
+            if self.persistent and self._run_ws is None:
                 self._run_ws = ops.stomp_workspace(self.num_particles, self.num_samples, self.n_support_points,
                                                    self.d_state_opt, self.device)
+                self._status = ops.StompRunStatus()
             ops.stomp_run(self._particle_means, eps, self.state_particles, self.costs, self._weights_buf,
                           self.scale_tril, self.Sigma, cc.device_geometry(self.device), self.num_samples,
                           self.n_dof, cc.k_sigma, weight, self.lr, self.temperature,
                           self._run_ws if self.persistent else None, n_iters=opt_iters,
-                          seed=self.seed, iter0=self._iter, particle_offset=self.particle_offset)
+                          seed=self.seed, iter0=self._iter, particle_offset=self.particle_offset,
+                          status=self._status if self.persistent else None)
             self._iter += opt_iters
         elif not observation and device_plan(self.cost, self.device) is not None:
             # composite of HIP-served members: sample(+collision) kernel -> trajectory-terms kernel(s) -> update
@@ -194,11 +241,28 @@ class STOMP(OptimizationPlanner):
         self._weights = self._weights_buf.reshape(self.num_particles, self.num_samples, 1, 1)
 
     def persistent_timed_out(self):
-        """Did a workgroup of the last persistent launch give up waiting for the partner workgroups of its particle (they
-        exchange per-chunk partial sums every iteration; each wait is bounded at 2 s)?  That only happens when the
-        partners cannot be resident together -- e.g. another stream keeps most of the chip busy -- and leaves the
-        affected particles' means as they were.  Synchronises the stream; False when no persistent launch was made."""
-        return self._run_ws is not None and self.persistent and ops.stomp_run_timed_out(self._run_ws)
+        """Was the last persistent launch lost (class docstring, `check`)?  Synchronises the stream and reads the
+        workspace header; False when no persistent launch was made.  Does not raise -- and a loss reported here is
+        not raised again later."""
+        if self._run_ws is None or not self.persistent:
+            return False
+        lost = ops.stomp_run_timed_out(self._run_ws)
+        if lost and self._status is not None:
+            hit = self._status.lost()
+            if hit is not None:
+                self._status.acknowledge(hit[0])
+        return lost
+
+    def run_path(self):
+        """Which form of the loop optimize() takes for this planner's shape and cost (ops.STOMP_PATH_*): the persistent
+        launch with or without an exchange between workgroups, or the two-kernel loop."""
+        fused = fusable_collision(self.cost)
+        if fused is None or not self.persistent:
+            return ops.STOMP_PATH_TWO_KERNEL
+        ws = self._run_ws if self._run_ws is not None else ops.stomp_workspace(
+            self.num_particles, self.num_samples, self.n_support_points, self.d_state_opt, self.device)
+        return ops.stomp_run_path(fused[0].device_geometry(self.device), ws, self.num_particles, self.num_samples,
+                                  self.n_support_points, self.d_state_opt)
 
     def _sample_and_eval(self, **observation):
         """stomp.py:162-197."""

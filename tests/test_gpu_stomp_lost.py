@@ -1,0 +1,178 @@
+"""-m gpu: the failure contract of the persistent STOMP launch (include/mpb.h, "Failure contract").
+
+The workgroups of a particle wait for each other every iteration.  These tests take the chip away from a launch
+(mpb_debug_occupy: workgroups that each hold a CU's LDS and idle) and check that
+  * a launch whose partners cannot start within the bound is LOST loudly -- STOMP raises, in both `check` modes, the
+    means are untouched, and the planner works again after reset();
+  * a launch that merely has to share the chip (fewer CUs, another persistent launch beside it) still computes exactly
+    what it computes alone: partners are paired by the order in which workgroups START, not by block index.
+The reference's loop always updates every particle (stomp.py:150-160): a call that returned stale means with no error
+would not be a drop-in."""
+import os
+import time
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _planner(dev, P=128, S=32, check='deferred', seed=3, persistent=True):
+    from motion_planning_baselines_amd import workloads
+    from motion_planning_baselines_amd.planners.costs.cost_functions import CostCollision, CostComposite
+    from motion_planning_baselines_amd.planners.stomp import STOMP
+    wl = workloads.panda_spheres_stomp(P, dev, S=S, pos_only=False)
+    prm = wl['params']
+    ta = dict(device=dev, dtype=torch.float32)
+    H = prm['n_support_points']
+    cost = CostComposite(wl['robot'], H, [CostCollision(wl['robot'], H, field=wl['field'], sigma_coll=wl['sigma_coll'],
+                                                        tensor_args=ta)], tensor_args=ta)
+    pl = STOMP(opt_iters=1, start_state=torch.from_numpy(wl['starts'][0]).to(dev), cost=cost,
+               initial_particle_means=wl['means0'], tensor_args=ta, noise='philox', seed=seed, check=check,
+               persistent=persistent, **prm)
+    return wl, pl
+
+
+@pytest.fixture
+def short_timeout():
+    os.environ['MPB_STOMP_TIMEOUT_US'] = '3000'          # read by mpb_stomp_run_checked at every call (a test aid)
+    yield
+    os.environ.pop('MPB_STOMP_TIMEOUT_US', None)
+
+
+def _occupy_all_but_one(dev, usec):
+    """Every CU but one held for `usec` on a side stream; returns once the holders are resident."""
+    from motion_planning_baselines_amd import ops
+    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        sink = ops.debug_occupy(n_cu - 1, usec, dev)
+    time.sleep(0.02)
+    return side, sink
+
+
+@pytest.mark.parametrize('check', ['deferred', 'sync'])
+def test_lost_launch_raises(gpu_device, short_timeout, check):
+    from motion_planning_baselines_amd import ops
+    from motion_planning_baselines_amd.planners.stomp import PersistentLaunchLost
+    dev = gpu_device
+    wl, pl = _planner(dev, check=check)
+    assert pl.run_path() == ops.STOMP_PATH_PERSISTENT_EXCHANGE
+    means0 = wl['means0'].clone()
+    torch.cuda.synchronize()
+    side, sink = _occupy_all_but_one(dev, 300_000)          # 0.3 s >> the 3 ms bound: the partner cannot start in time
+    if check == 'sync':
+        with pytest.raises(PersistentLaunchLost):
+            pl.optimize(opt_iters=5)
+    else:
+        out = pl.optimize(opt_iters=5)                      # asynchronous: nothing known yet
+        torch.cuda.synchronize()
+        assert out.shape == means0.shape
+        with pytest.raises(PersistentLaunchLost) as ei:
+            pl.optimize(opt_iters=1)                        # the next call into the planner reports it
+        assert 'abandoned' in str(ei.value)
+    torch.cuda.synchronize()
+    # no particle was half-updated: every workgroup left before writing its means
+    assert torch.equal(pl._particle_means, means0)
+    assert ops.stomp_run_state(pl._run_ws) == 1
+    # reported once; the planner is usable again (the header was re-armed by the last workgroup out)
+    os.environ.pop('MPB_STOMP_TIMEOUT_US', None)
+    pl.reset(initial_particle_means=means0)
+    pl._iter = 0
+    got = pl.optimize(opt_iters=5)
+    torch.cuda.synchronize()
+    assert not pl.persistent_timed_out()
+    _, fresh = _planner(dev, check=check)
+    fresh._iter = 0
+    want = fresh.optimize(opt_iters=5)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+
+
+def test_lost_launch_other_entry_points_raise(gpu_device, short_timeout):
+    """get_traj / reset / sample report a lost launch too, and persistent_timed_out() consumes it without raising."""
+    from motion_planning_baselines_amd.planners.stomp import PersistentLaunchLost
+    dev = gpu_device
+    for entry in ('get_traj', 'reset', 'sample', 'persistent_timed_out'):
+        wl, pl = _planner(dev, P=64, S=32)
+        torch.cuda.synchronize()
+        side, sink = _occupy_all_but_one(dev, 200_000)
+        pl.optimize(opt_iters=3)
+        torch.cuda.synchronize()
+        if entry == 'persistent_timed_out':
+            assert pl.persistent_timed_out()
+            pl.get_traj()                                    # reported: not raised again
+        else:
+            with pytest.raises(PersistentLaunchLost):
+                getattr(pl, entry)()
+            getattr(pl, entry)()                             # raised once
+
+
+def test_uninitialised_workspace_header_is_reported(gpu_device):
+    from motion_planning_baselines_amd import ops
+    dev = gpu_device
+    wl, pl = _planner(dev, P=16, S=32)
+    ws = torch.full((pl._run_ws.numel() if pl._run_ws is not None else
+                     ops.stomp_workspace(16, 32, 64, 14, dev).numel(),), 1.0e9, device=dev)     # garbage, header included
+    st = ops.StompRunStatus()
+    cc = pl.cost.cost_l[0]
+    means = wl['means0'].clone()
+    tag = ops.stomp_run(means, None, pl.state_particles, pl.costs, pl._weights_buf, pl.scale_tril, pl.Sigma,
+                        cc.device_geometry(dev), 32, 7, cc.k_sigma, 1.0, 0.1, 1.0, ws, n_iters=2, status=st)
+    torch.cuda.synchronize()
+    assert tag != 0 and st.lost() == (tag, 2)
+    assert ops.stomp_run_state(ws) == 2
+    assert torch.equal(means, wl['means0'])
+
+
+def test_shared_chip_same_results(gpu_device):
+    """Most of the chip held by something else for a while (default bound): the launch runs in rounds on what is left and
+    computes exactly what it computes on an idle chip."""
+    from motion_planning_baselines_amd import ops
+    dev = gpu_device
+    wl, pl = _planner(dev)
+    want = pl.optimize(opt_iters=20)
+    torch.cuda.synchronize()
+    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+    for held in (n_cu - 3, n_cu // 2 + 1, 7):                # odd numbers of free CUs: partners split across rounds
+        _, pl2 = _planner(dev)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(side):
+            sink = ops.debug_occupy(held, 20_000, dev)
+        time.sleep(0.005)
+        got = pl2.optimize(opt_iters=20)
+        torch.cuda.synchronize()
+        assert not pl2.persistent_timed_out()
+        assert torch.equal(got, want), held
+
+
+def test_two_planners_on_two_streams(gpu_device):
+    """Two persistent launches side by side (each wants the whole chip): each equals the same planner run alone -- or
+    raises; never silently stale."""
+    from motion_planning_baselines_amd.planners.stomp import PersistentLaunchLost
+    dev = gpu_device
+    alone = []
+    for seed in (1, 2):
+        _, pl = _planner(dev, seed=seed)
+        pl._iter = 0
+        alone.append(pl.optimize(opt_iters=60))
+    torch.cuda.synchronize()
+    planners = [_planner(dev, seed=seed)[1] for seed in (1, 2)]
+    streams = [torch.cuda.Stream(device=dev) for _ in planners]
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(3):                                      # interleaved launches, three rounds
+        outs = []
+        for pl, st in zip(planners, streams):
+            with torch.cuda.stream(st):
+                pl.reset(initial_particle_means=pl.initial_particle_means)
+                pl._iter = 0
+                outs.append(pl.optimize(opt_iters=60))
+        torch.cuda.synchronize()
+    for pl, got, want in zip(planners, outs, alone):
+        try:
+            pl.get_traj()
+        except PersistentLaunchLost:
+            continue                                          # loud is acceptable; stale is not
+        assert torch.equal(got, want)
