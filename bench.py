@@ -155,7 +155,7 @@ def STOMP_two_kernel(wl, cost, dev, rank, P):
 
 def run_stomp(planner, clock, dist, world, steps, warmup, repeats, preheat):
     """W untimed steps, then R blocks of EXACTLY `steps` steps (one C-ABI call = 2K launches) + the final gather."""
-    gathered = [torch.empty_like(planner._particle_means) for _ in range(world)] if world > 1 else None
+    gathered = [torch.empty_like(planner._particle_means) for _ in range(world)] if dist is not None else None
     means_init = planner._particle_means.clone()
     if preheat:   # device pre-heat (untimed set-up, not part of W or K): code objects loaded, clocks ramped
         planner.optimize(opt_iters=preheat)
@@ -349,7 +349,10 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
     dist = None
-    if world > 1:
+    # MPB_FORCE_DIST=1: take the distributed path at world size 1 too (RCCL rehearsal on a one-GPU box: process group on
+    # "nccl", barrier, all-gather of the means and the MAX all-reduce of the clock all execute)
+    forced = os.environ.get('MPB_FORCE_DIST') == '1'
+    if world > 1 or forced:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if backend == 'nccl':
@@ -464,6 +467,9 @@ def main():
                        'algorithmic_bytes_per_iter': stomp_algorithmic_bytes(P, S, H, d)},
             'roofline': roof,
         }
+        if dist is not None:
+            line['dist'] = {'backend': dist.get_backend(), 'world': world, 'forced_at_world_1': bool(forced and world == 1),
+                            'collectives_in_timed_region': 'barrier x2, all_gather of the (P,H,d) means, all_reduce(MAX) of the clock'}
         if c5 is not None:
             line['c5'] = c5
         if world == 1 and not args.no_cpu_baseline:

@@ -239,6 +239,15 @@ int mpb_stomp_run_status(const float *workspace, void *stream, int *timed_out);
 /* Test aid: n_blocks workgroups that each take a whole CU's LDS and idle for `usec` microseconds (the "another stream
  * keeps the chip busy" of the time-out tests); `sink` is one device word (never written in practice). */
 int mpb_debug_occupy(int n_blocks, uint64_t usec, uint32_t *sink, void *stream);
+/* Test aids for the random-number path (csrc/mpb_debug.hip; not on a product path).
+ * mpb_debug_philox: out[4i..4i+3] = Philox4x32-`rounds`(ctr[4i..4i+3], key[2i..2i+1]), rounds = 7 (the STOMP kernels) or
+ * 10 (every other kernel), device pointers -- for the Random123 known-answer vectors.
+ * mpb_debug_stomp_normals: the standard normals of n_iters STOMP iterations exactly as mpb_stomp_step / mpb_stomp_run draw
+ * them in throughput mode (eps == NULL): out (n_iters, P, S, d, 64), element [it][p][s][c][k] = eps of iteration
+ * iter0 + it, global particle particle_offset + p, sample s, channel c, waypoint k. */
+int mpb_debug_philox(const uint32_t *ctr, const uint32_t *key, uint32_t *out, int n, int rounds, void *stream);
+int mpb_debug_stomp_normals(float *out, int P, int S, int d, int n_iters, uint64_t seed, uint32_t iter0,
+                            uint32_t particle_offset, void *stream);
 int mpb_stomp_sample(const float *means, const float *eps, float *samples, const float *L,
                      const float *geom, int geom_flags, float *costs, /* geom, costs both NULL: sample only; both set: fused cost */
                      int P, int S, int H, int d, float k_sigma, float weight,
@@ -290,6 +299,8 @@ int mpb_chomp_step(float *means, const float *R, const float *geom, int geom_fla
  *                         else delta * diag_mean (diag_mean NULL: workspace mean written by mpb_gpmp2_step).
  *                         costs_out (B) optional: b^T K b of the iterate BEFORE the update (gpmp2.py:493-495).
  *   mpb_gpmp2_step      : n_iters full iterations on one GPU (mean over the local B).
+ * sigma_goal <= 0 means "no goal factor" (precision 0: GPMP2 without goals, gpmp2.py:62-78) -- an infinite sigma is not a
+ * valid argument (the library is built with -ffinite-math-only).
  * n_fields = number of collision fields chained in `geom` (1..4; see mpb_geom_check): the reference stacks one
  * block of H-1 collision rows per field (gpmp2.py:70-78, cost_functions.py:107-144), the workspace keeps one
  * (h_t, c_t) set per field and the solve sums their rank-1 terms.
@@ -328,7 +339,8 @@ int mpb_gpmp2_step(float *x, const float *start, const float *goal, const float 
  * best_cost (NP) in/out + best_states (NP,T,c) out, both or neither (NULL): MPPI._save_best
  * (mppi.py:164-168, called every iteration, mppi.py:148): whenever an iteration's cheapest sample (first
  * index on ties) beats best_cost[problem], its cost and state trajectory are stored.  Initialise
- * best_cost to +inf; it carries over between calls like the reference's attribute.
+ * best_cost to a large FINITE value (3e38; the library is built with -ffinite-math-only); it carries over between calls
+ * like the reference's attribute.
  * ------------------------------------------------------------------------------------------- */
 int mpb_mppi_step(float *mean, const float *eps, const float *scale_tril, const float *cov_inv,
                   const float *state0, const float *goal, const float *ctrl_min, const float *ctrl_max,

@@ -43,6 +43,8 @@ SIGNATURES = {
     'mpb_stomp_workspace_init': [_p, ctypes.c_size_t, _p],
     'mpb_stomp_run_path': [_i, ctypes.c_size_t, _i, _i, _i, _i],
     'mpb_debug_occupy': [_i, _u64, _p, _p],
+    'mpb_debug_philox': [_p, _p, _p, _i, _i, _p],
+    'mpb_debug_stomp_normals': [_p, _i, _i, _i, _i, _u64, _u32, _u32, _p],
     'mpb_stomp_step_profile': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _u64, _u32, _u32, _p, _p, _p],
     'mpb_stomp_sample': [_p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _f, _f, _u64, _u32, _u32, _p],
     'mpb_stomp_update': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],

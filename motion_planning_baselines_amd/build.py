@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['mpb_kernels.hip', 'mpb_stomp_fused.hip', 'mpb_chomp.hip', 'mpb_gpmp2.hip', 'mpb_mppi.hip', 'mpb_prior.hip', 'mpb_stoch_gpmp.hip', 'mpb_costs.hip', 'mpb_points.hip']
+SOURCES = ['mpb_kernels.hip', 'mpb_stomp_fused.hip', 'mpb_chomp.hip', 'mpb_gpmp2.hip', 'mpb_mppi.hip', 'mpb_prior.hip', 'mpb_stoch_gpmp.hip', 'mpb_costs.hip', 'mpb_points.hip', 'mpb_debug.hip']
 # per-file extra flags: the latency-bound single-wave-per-problem kernels (CHOMP, GPMP2 solve, MPPI) gain 3-10 % from
 # LLVM's max-ILP scheduling strategy; the STOMP kernels of mpb_kernels.hip lose 2 % with it (measured, round 1)
 MAX_ILP = ['-mllvm', '-amdgpu-sched-strategy=max-ilp']

@@ -1,0 +1,58 @@
+// mpb_debug.hip -- test aids of the C-ABI: what the tests need to look INSIDE the product kernels' random-number path.
+//   mpb_debug_philox          raw Philox4x32-R words (R = 7: the STOMP kernels; R = 10: everything else) for given
+//                             counters / keys -- compared with the published Random123 known-answer vectors;
+//   mpb_debug_stomp_normals   the standard normals exactly as the STOMP kernels draw them (stomp_eps4: Philox4x32-7 +
+//                             Box-Muller on the hardware log2 / sqrt / sin / cos units), laid out (iters, P, S, d, H)
+//                             -- for the statistical tests of the throughput-mode noise (tests/test_gpu_rng.py).
+// Neither is on a product path.
+#include <hip/hip_runtime.h>
+
+#include "mpb_common.h"
+#include "mpb_stomp_noise.h"
+
+__global__ void debug_philox_kernel(const uint32_t* __restrict__ ctr, const uint32_t* __restrict__ key, uint32_t* __restrict__ out,
+                                    int n, int rounds) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 c = make_uint4(ctr[4 * i], ctr[4 * i + 1], ctr[4 * i + 2], ctr[4 * i + 3]);
+    const uint2 k = make_uint2(key[2 * i], key[2 * i + 1]);
+    const uint4 r = (rounds == 7) ? philox4x32<7>(c, k) : philox4x32<10>(c, k);
+    out[4 * i] = r.x; out[4 * i + 1] = r.y; out[4 * i + 2] = r.z; out[4 * i + 3] = r.w;
+}
+
+extern "C" int mpb_debug_philox(const uint32_t* ctr, const uint32_t* key, uint32_t* out, int n, int rounds, void* stream) {
+    if (!ctr || !key || !out || n < 1) return mpb_fail(MPB_E_INVALID, "mpb_debug_philox: bad argument");
+    if (rounds != 7 && rounds != 10) return mpb_fail(MPB_E_INVALID, "mpb_debug_philox: rounds must be 7 or 10");
+    hipLaunchKernelGGL(debug_philox_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, ctr, key, out, n, rounds);
+    return mpb_check_launch("mpb_debug_philox");
+}
+
+// one thread per (iteration, particle, sample, channel j, k-group g, quarter q4): the four normals of one stomp_eps4 call,
+// eps[j][k = 16 q4 + 4 r + g], r = 0..3 -- the very call of stomp_b_operand (mpb_stomp_noise.h)
+__global__ void debug_stomp_normals_kernel(float* __restrict__ out, int P, int S, int d, int n_iters, uint32_t seed_lo,
+                                           uint32_t seed_hi, uint32_t iter0, uint32_t particle_offset) {
+    const size_t n = (size_t)n_iters * P * S * d * 16;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t q4 = i & 3, g = (i >> 2) & 3;
+    size_t r = i >> 4;
+    const uint32_t j = r % d; r /= d;
+    const uint32_t s = r % S; r /= S;
+    const uint32_t p = r % P; r /= P;
+    const uint32_t it = (uint32_t)r;
+    float nrm[4];
+    stomp_eps4(particle_offset + p, s, j, g, q4, iter0 + it, seed_lo, seed_hi, nrm);
+    float* o = out + ((((size_t)it * P + p) * S + s) * d + j) * 64;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) o[16 * q4 + 4 * rr + g] = nrm[rr];
+}
+
+extern "C" int mpb_debug_stomp_normals(float* out, int P, int S, int d, int n_iters, uint64_t seed, uint32_t iter0,
+                                       uint32_t particle_offset, void* stream) {
+    if (!out || P < 1 || S < 1 || d < 1 || d > 16 || n_iters < 1) return mpb_fail(MPB_E_INVALID, "mpb_debug_stomp_normals: bad argument");
+    const size_t n = (size_t)n_iters * P * S * d * 16;
+    if (n > 0x7FFFFFFFull * 256ull) return mpb_fail(MPB_E_INVALID, "mpb_debug_stomp_normals: too many draws for one launch");
+    hipLaunchKernelGGL(debug_stomp_normals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, P, S,
+                       d, n_iters, (uint32_t)seed, (uint32_t)(seed >> 32), iter0, particle_offset);
+    return mpb_check_launch("mpb_debug_stomp_normals");
+}

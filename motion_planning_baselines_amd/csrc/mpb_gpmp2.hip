@@ -684,7 +684,7 @@ extern "C" int mpb_gpmp2_diag(void* workspace, double* diag_sum_out, int B, int 
     hipLaunchKernelGGL(gpmp2_diag_kernel, dim3(H), dim3(256), 0, (hipStream_t)stream, w.jac, out, B, H, D, n_fields,
                        (double)dt,
                        1.0 / ((double)sigma_start * sigma_start), 1.0 / ((double)sigma_gp * sigma_gp),
-                       1.0 / ((double)sigma_goal * sigma_goal), 1.0 / ((double)sigma_coll * sigma_coll));
+                       (sigma_goal > 0.f ? 1.0 / ((double)sigma_goal * sigma_goal) : 0.0), 1.0 / ((double)sigma_coll * sigma_coll));
     return mpb_check_launch("mpb_gpmp2_diag");
 }
 
@@ -700,7 +700,7 @@ extern "C" int mpb_gpmp2_solve(float* x, const float* start, const float* goal, 
     K.dt = dt;
     K.ks = 1.0 / ((double)sigma_start * sigma_start);
     K.kgp = 1.0 / ((double)sigma_gp * sigma_gp);
-    K.kg = 1.0 / ((double)sigma_goal * sigma_goal);
+    K.kg = (sigma_goal > 0.f ? 1.0 / ((double)sigma_goal * sigma_goal) : 0.0);
     K.kc = 1.0 / ((double)sigma_coll * sigma_coll);
     K.delta = delta;
     K.step = step_size;

@@ -24,10 +24,11 @@ def shard_eps(eps, rank, world, particle_axis=2):
     return eps.narrow(particle_axis, lo, hi - lo).contiguous()
 
 
-def gather_means(local_means, n_particles_total, group=None):
-    """All-gather the optimised means of every shard into the full (P,H,d) tensor (same on all ranks)."""
+def gather_means(local_means, n_particles_total, group=None, force=False):
+    """All-gather the optimised means of every shard into the full (P,H,d) tensor (same on all ranks).
+    force: run the collective at world size 1 too (rehearsals of the RCCL path on a one-GPU box)."""
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force:
         return local_means
     sizes = [shard_range(n_particles_total, r, world) for r in range(world)]
     bufs = [torch.empty((hi - lo, *local_means.shape[1:]), dtype=local_means.dtype, device=local_means.device)

@@ -104,9 +104,7 @@ class CHOMP(OptimizationPlanner):
         # smoothness prior, clamps, masks the end rows and steps (chomp.py:141-147)
         plan = device_plan(self.cost, self.device) if self.cost is not None else None
         if plan is None:
-            raise NotImplementedError(
-                'CHOMP needs the analytic gradient of its cost: a composite of CostCollision and the trajectory-term '
-                'costs of cost_functions.py (a user-defined Python cost has no gradient kernel)')
+            return self._run_optimization_autograd(opt_iters, B_global, **observation)
         cc, weight, groups = plan
         x = self._particle_means
         grad = torch.empty_like(x) if (cc is not None or len(groups) > 1) else None
@@ -122,3 +120,28 @@ class CHOMP(OptimizationPlanner):
             last = groups[-1] if groups else dict(terms=())
             ops.cost_terms_grad(x, self.n_dof, grad_in=grad if have else None, apply=True, R=self.Sigma_inv, prior_bw=prior_bw,
                                 lr=self.lr, grad_clip=self.grad_clip, jl_scale=float(B_global), **last)
+
+    def _run_optimization_autograd(self, opt_iters, B_global, **observation):
+        """A caller-supplied cost (any callable on device tensors that torch can differentiate -- e.g. written against
+        robot_field.DeviceRobot / DeviceField, whose kernels carry hand-written vector-Jacobian products): the reference
+        differentiates whatever it is handed (chomp.py:135-139).  Per iteration the CALLER's cost is differentiated by
+        torch.autograd.grad; the smoothness prior's gradient (B w (R + R^T) x, quirk Q3), the clamp, the end-row mask
+        and the step (chomp.py:141-147) stay in the HIP kernel, which takes that gradient as `grad_in`."""
+        prior_bw = float(B_global) * float(self.weight_prior_cost)
+        x = self._particle_means
+        for _ in range(opt_iters):
+            if self.cost is None:
+                g = None                          # quirk Q11: no cost -> only the prior acts
+            else:
+                xg = x.detach().requires_grad_(True)
+                costs = self._get_costs(xg, **observation)
+                if not (isinstance(costs, torch.Tensor) and costs.requires_grad):
+                    raise NotImplementedError(
+                        'CHOMP differentiates its cost: the cost returned a tensor torch.autograd cannot trace back to the '
+                        'trajectories (build it from differentiable torch ops, robot_field.DeviceRobot / DeviceField, or '
+                        'the cost classes of cost_functions.py)')
+                (g,) = torch.autograd.grad(costs.sum(), xg)
+                g = g.to(torch.float32).contiguous()
+                self.costs = costs.detach()
+            ops.cost_terms_grad(x, self.n_dof, grad_in=g, apply=True, R=self.Sigma_inv, prior_bw=prior_bw, lr=self.lr,
+                                grad_clip=self.grad_clip, jl_scale=float(B_global), terms=())

@@ -102,8 +102,8 @@ class GPMP2(OptimizationPlanner):
         self.solver_params = solver_params
         self.stop_criteria = stop_criteria
         self.N = self.d_state_opt * n_support_points
-        # no goals: 1 / sigma_goal^2 = 0 switches the goal factor off inside the kernels
-        self.sigmas = (sigma_start, sigma_gp, sigma_goal_prior if self.goal_directed else float('inf'), sigma_coll)
+        # no goal factor: sigma_goal = 0 is the C-ABI's explicit "precision 0" (include/mpb.h), not an infinite sigma
+        self.sigmas = (sigma_start, sigma_gp, sigma_goal_prior if self.goal_directed else 0.0, sigma_coll)
         self.process_group = process_group
         self.geom = ops.DeviceGeometry(robot, collision_fields, self.device, scales=scales)   # one CostCollision per field (gpmp2.py:70-78)
         self.costs = None

@@ -16,6 +16,9 @@ from .dynamics.point import PointParticleDynamics  # noqa: F401  (import path of
 from .priors.gaussian import check_Cov_is_valid, const_ctrl_Cov, diag_Cov  # noqa: F401
 
 
+BEST_COST_NONE = 3.0e38     # "no sample seen yet" of the device-side best-cost tracker
+
+
 class MPPI(MPPlanner):
     """Drop-in for mp_baselines.planners.mppi.MPPI (ctor kwargs mppi.py:8-21).
 
@@ -60,7 +63,7 @@ class MPPI(MPPlanner):
         self._costs = torch.empty(1, S, device=self.device)
         self._weights = torch.empty(1, S, device=self.device)
         # MPPI._save_best state (mppi.py:164-168): kept on the device, updated inside the kernel every iteration
-        self._best_cost = torch.full((1,), float('inf'), device=self.device)
+        self._best_cost = torch.full((1,), BEST_COST_NONE, device=self.device)   # finite sentinel: the library is built with -ffinite-math-only
         self._best_traj = torch.zeros(1, T, c, device=self.device)
         self.weights = None
         self.reset(initial_mean=initial_mean)
@@ -91,16 +94,16 @@ class MPPI(MPPlanner):
         geom, k_sigma, weight = None, 0.0, 1.0
         if cost is not None:
             fused = fusable_collision(cost)
-            if fused is None:
-                raise NotImplementedError('MPPI fuses a single collision cost; other cost objects are not wired in')
-            cc, weight = fused
-            geom, k_sigma = cc.device_geometry(self.device), cc.k_sigma
+            if fused is not None:          # (any other cost object: _energy_shift, outside the kernel)
+                cc, weight = fused
+                geom, k_sigma = cc.device_geometry(self.device), cc.k_sigma
         return state, goal, geom, k_sigma, weight
 
     @property
     def best_cost(self):
         """Lowest sample cost seen by optimize() so far (inf before the first call), as a 0-dim tensor."""
-        return self._best_cost[0]
+        b = self._best_cost[0]
+        return torch.where(b >= BEST_COST_NONE, torch.full_like(b, float('inf')), b)
 
     @property
     def best_traj(self):
@@ -123,10 +126,27 @@ class MPPI(MPPlanner):
     def update_ctrl_dist(self):
         """mppi.py:68-70: the sampling distribution reads self._mean directly here; nothing to refresh."""
 
+    @staticmethod
+    def _generic_cost(observation):
+        """The caller's cost object when it is NOT the single collision cost the kernel fuses (else None)."""
+        cost = observation.get('cost', None)
+        return cost if (cost is not None and fusable_collision(cost) is None) else None
+
+    def _energy_shift(self, cost):
+        """point.py:191-196: `cost.eval(cat(X, U)).sum(-1)` -- the per-rollout costs of ANY cost object summed into ONE
+        scalar (quirk Q6) that is added to every sample's cost: a shift the softmax weights do not see, but `costs` and
+        the best-sample tracking do.  Evaluated on the rollouts of the last kernel iteration."""
+        full_traj = torch.cat((self._states[0], self._controls[0]), dim=-1)
+        e = cost.eval(full_traj)
+        return e.sum(-1).to(device=self.device, dtype=torch.float32)
+
     def sample_and_eval(self, **observation):
         """mppi.py:88-134: sample controls, roll out, evaluate costs (incl. the importance term); the mean is left
         untouched (one kernel iteration with a zero step)."""
         self._launch(1, 0.0, **observation)
+        generic = self._generic_cost(observation)
+        if generic is not None:
+            self._costs += self._energy_shift(generic)
         return self._controls[0], self._states[0], self.costs
 
     def update_controller(self, costs, U_sampled):
@@ -157,6 +177,18 @@ class MPPI(MPPlanner):
     def optimize(self, opt_iters=None, **observation):
         if opt_iters is None:
             opt_iters = self.opt_iters
+        if self._generic_cost(observation) is not None:
+            # any other Cost / CostComposite (point.py:191-196): its scalar shift differs from iteration to iteration,
+            # so the loop of mppi.py:145-152 runs iteration by iteration -- kernel (sample, rollout, costs) -> the caller's
+            # cost on the rollouts -> _save_best -> update kernel
+            for _ in range(opt_iters):
+                _, _, costs = self.sample_and_eval(**observation)
+                self._save_best()
+                self.update_controller(costs, self._controls[0])
+            self._recent_control_samples = self._controls[0]
+            self._recent_state_trajectories = self._states[0]
+            self._recent_weights = self.weights
+            return self._controls[0], self._states[0], self.costs
         # _save_best runs inside the kernel after every iteration's sample_and_eval, as in mppi.py:145-152
         self._launch(opt_iters, self.step_size, track_best=True, **observation)
         self.weights = self._weights.reshape(-1, 1)

@@ -58,7 +58,10 @@ class StochGPMP(OptimizationPlanner):
         if initial_particle_means is None:
             m = self.get_random_trajs()
         elif isinstance(initial_particle_means, str) and initial_particle_means == 'const_vel':
-            raise NotImplementedError("initial_particle_means='const_vel': pass the trajectories explicitly")
+            # stoch_gpmp.py:107-111 -> :197-215: one straight line per goal (velocity channel (goal - start) / (H dt),
+            # the reference's own denominator), repeated for the goal's particles: (G, ppg, H, 2D)
+            lines = self.const_vel_trajectories(self.start_state, self.multi_goal_states)
+            m = lines.unsqueeze(1).expand(-1, self.num_particles_per_goal, -1, -1)
         else:
             m = initial_particle_means
         if m.ndim == 4:

@@ -1,0 +1,201 @@
+"""-m gpu: the remaining holes of the planner API (VERDICT r02 "What's missing" 2, 3, 5).
+
+  * CHOMP differentiates whatever cost it is handed (chomp.py:135-139): a caller-supplied callable goes through the
+    caller's own torch.autograd.grad, the prior / clamp / mask / step stay in the HIP kernel -- checked against the
+    reference-generated CHOMP goldens (the caller's cost written on robot_field.DeviceRobot / DeviceField) and against
+    the oracle's autograd loop (a pure-torch cost);
+  * MPPI takes ANY cost object (point.py:191-196; quirk Q6: its per-rollout costs collapse into one scalar shift) --
+    checked against the reference-generated golden by handing the golden's collision cost over in a form the kernel
+    does not fuse, and against the oracle for a caller-defined cost class;
+  * StochGPMP(initial_particle_means='const_vel') (stoch_gpmp.py:107-111, :197-215)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, product_geometry_from_golden
+from test_gpu_planners import T, make_cost, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('name', ['chomp_pm2d_soft', 'chomp_panda'])
+def test_chomp_caller_supplied_cost_vs_golden(gpu_device, name):
+    """The golden's collision cost re-written as a CALLER's cost (not one of the package's Cost classes) on the
+    differentiable robot / field objects: CHOMP must reproduce the reference run."""
+    from motion_planning_baselines_amd.planners.chomp import CHOMP
+    from motion_planning_baselines_amd.robot_field import device_robot_field
+    g = load_golden(name)
+    dev = gpu_device
+    robot, field = product_geometry_from_golden(g)
+    drobot, dfield = device_robot_field(robot, field, dev)
+    k = float(g['weight']) / float(g['sigma_coll']) ** 2
+
+    calls = []
+
+    def caller_cost(x, **kw):
+        calls.append(x.shape)
+        q = drobot.get_position(x)
+        pts = drobot.fk_map_collision(q)
+        return k * dfield.compute_cost(q[:, 1:], pts[:, 1:]).sum(-1)          # cost_functions.py:171-189, quirk Q5
+
+    B = int(g['B'])
+    pl = CHOMP(n_dof=int(g['D']), n_support_points=int(g['H']), num_particles_per_goal=B, opt_iters=1,
+               dt=float(g['dt']), start_state=T(g['means0'][0, 0, :int(g['D'])]).to(dev), cost=caller_cost,
+               weight_prior_cost=float(g['w_prior']), initial_particle_means=T(g['means0']).to(dev),
+               step_size=float(g['lr']), grad_clip=float(g['clip']), pos_only=bool(g['pos_only']),
+               tensor_args=dict(device=dev, dtype=torch.float32))
+    for it in range(g['means'].shape[0]):
+        traj = pl.optimize()
+        assert rel_err(traj, T(g['traj'][it])) < 1e-4, it
+    assert len(calls) == g['means'].shape[0]
+
+
+def test_chomp_pure_torch_cost_vs_oracle(gpu_device):
+    """A cost written in plain torch ops (smooth attraction / repulsion terms): the product loop against the oracle's
+    autograd restatement of chomp.py:134-149 on the CPU."""
+    from motion_planning_baselines_amd.planners.chomp import CHOMP
+    from oracle import planners_ref as O
+    dev = gpu_device
+    B, H, D = 12, 64, 3
+    dt, w_prior, lr, clip = 0.04, 1e-3, 0.05, 0.3
+    gen = torch.Generator().manual_seed(5)
+    a, b = torch.rand(B, 1, D, generator=gen) * 2 - 1, torch.rand(B, 1, D, generator=gen) * 2 - 1
+    s = torch.linspace(0, 1, H).reshape(1, H, 1)
+    pos = a * (1 - s) + b * s + 0.01 * torch.randn(B, H, D, generator=gen)
+    means0 = torch.cat([pos, torch.zeros(B, H, D)], -1)
+    centre = torch.tensor([0.1, -0.2, 0.3])
+
+    def cost_fn(x, **kw):
+        c = centre.to(x.device)
+        d2 = ((x[..., :D] - c) ** 2).sum(-1)
+        return (3.0 * torch.exp(-4.0 * d2) + 0.05 * torch.sin(3.0 * x[..., D:]).sum(-1)).sum(-1) + 0.1 * (x[:, -1, :D] ** 2).sum(-1)
+
+    pl = CHOMP(n_dof=D, n_support_points=H, num_particles_per_goal=B, opt_iters=1, dt=dt, start_state=means0[0, 0, :D].to(dev),
+               cost=cost_fn, weight_prior_cost=w_prior, initial_particle_means=means0.to(dev), step_size=lr, grad_clip=clip,
+               pos_only=False, tensor_args=dict(device=dev, dtype=torch.float32))
+    cta = dict(device='cpu', dtype=torch.float32)
+    R = O.chomp_precision(H, dt, cta)
+    m = means0.clone()
+    for it in range(4):
+        m = O.chomp_iteration(m, R, cost_fn, w_prior, lr, clip)['means']
+        pl.optimize()
+        assert rel_err(pl._particle_means, m) < 1e-5, it
+    # a cost autograd cannot trace raises instead of stepping on a zero gradient
+    pl.cost = lambda x, **kw: torch.zeros(x.shape[0], device=x.device)
+    with pytest.raises(NotImplementedError):
+        pl.optimize()
+
+
+def _mppi(g, dev, noise='torch_cpu'):
+    from motion_planning_baselines_amd.planners.mppi import MPPI, PointParticleDynamics
+    ta = dict(device=dev, dtype=torch.float32)
+    S, Tn = int(g['S']), int(g['T'])
+    system = PointParticleDynamics(rollout_steps=Tn, control_dim=2, state_dim=2, dt=float(g['dt']), discount=1.,
+                                   goal_state=T(g['goal']).to(dev), ctrl_min=[-100, -100], ctrl_max=[100, 100],
+                                   c_weights={'pos': float(g['c_pos']), 'vel': float(g['c_vel']), 'ctrl': float(g['c_ctrl']),
+                                              'pos_T': float(g['c_pos_T']), 'vel_T': 0.}, tensor_args=ta)
+    return MPPI(system, num_ctrl_samples=S, rollout_steps=Tn, opt_iters=1, control_std=[float(v) for v in g['control_std']],
+                temp=float(g['temp']), step_size=float(g['step_size']), cov_prior_type=str(g['cov_type']), tensor_args=ta,
+                noise=noise)
+
+
+def test_mppi_any_cost_object_vs_golden(gpu_device):
+    """The golden's collision cost handed over inside a caller-defined class (not the single collision cost the kernel
+    fuses) takes the generic path -- cost.eval on the rollouts, outside the kernel -- and must
+    reproduce the reference run: costs, means, best sample."""
+    from motion_planning_baselines_amd.planners.costs.cost_functions import fusable_collision
+    name = 'mppi_pm2d_indep_cost'
+    g = load_golden(name)
+    assert bool(g['with_cost'])
+    dev = gpu_device
+    ta = dict(device=dev, dtype=torch.float32)
+    inner, _, _ = make_cost(g, dev)
+    Tn = int(g['T'])
+
+    class CallersCost:                 # not a class of cost_functions.py: the kernel cannot fuse it
+        def eval(self, trajs, **kw):
+            return inner.eval(trajs, **kw)
+
+    cost = CallersCost()
+    assert fusable_collision(cost) is None
+    torch.manual_seed(1)
+    pl = _mppi(g, dev)
+    obs = dict(state=T(g['start']).to(dev), goal_state=T(g['goal']).to(dev), cost=cost)
+    S = int(g['S'])
+    for it in range(g['eps'].shape[0]):
+        U, X, c = pl.optimize(**obs)
+        assert U.shape == (S, Tn, 2) and X.shape == (S, Tn, 2) and c.shape == (S, 1)
+        np.testing.assert_allclose(c.cpu().numpy(), g['costs'][it], rtol=5e-5)
+        assert rel_err(pl.get_mean_controls(), T(g['mean'][it])) < 1e-4, it
+        flat = np.stack([g['costs'][k].reshape(-1) for k in range(it + 1)])
+        it_b, s_b = np.unravel_index(np.argmin(flat), flat.shape)
+        np.testing.assert_allclose(float(pl.best_cost), flat[it_b, s_b], rtol=5e-5)
+        np.testing.assert_allclose(pl.best_traj.cpu().numpy(), g['states'][it_b][s_b], rtol=1e-4, atol=1e-5)
+
+
+def test_mppi_caller_defined_cost_vs_oracle(gpu_device):
+    """A caller's own cost class (only `.eval`): its scalar shift is added to every sample's cost -- against the oracle
+    loop fed the same noise."""
+    from oracle import planners_ref as O
+    g = load_golden('mppi_pm2d_const')
+    dev = gpu_device
+
+    class Energy:
+        def eval(self, full_traj, **kw):
+            assert full_traj.shape[-1] == 4                                   # cat(X, U), point.py:192
+            return (full_traj[..., :2] ** 2).sum(-1).sum(-1) * 0.3 + full_traj[..., 2:].abs().sum(-1).sum(-1) * 0.01
+
+    torch.manual_seed(0)
+    pl = _mppi(g, dev)
+    obs = dict(state=T(g['start']).to(dev), goal_state=T(g['goal']).to(dev), cost=Energy())
+    cpu = dict(device='cpu', dtype=torch.float32)
+    Tn, S = int(g['T']), int(g['S'])
+    mean = torch.zeros(Tn, 2)
+    cw = {'pos': float(g['c_pos']), 'vel': float(g['c_vel']), 'ctrl': float(g['c_ctrl']), 'pos_T': float(g['c_pos_T'])}
+    disc = torch.ones(Tn)
+    best = np.inf
+    for it in range(g['eps'].shape[0]):
+        eps = T(g['eps'][it]).reshape(2, S, Tn)
+        kw = dict(dt=float(g['dt']), ctrl_min=torch.tensor([-100., -100.]), ctrl_max=torch.tensor([100., 100.]), c_weights=cw,
+                  discount_seq=disc, temp=float(g['temp']), step_size=float(g['step_size']), state_dim=2)
+        dry = O.mppi_iteration(mean, eps, T(g['scale_tril']).float(), T(g['Cov_inv']).float(), T(g['start']), T(g['goal']), **kw)
+        shift = float(Energy().eval(torch.cat((dry['states'], dry['controls']), -1)).sum(-1))
+        ref = O.mppi_iteration(mean, eps, T(g['scale_tril']).float(), T(g['Cov_inv']).float(), T(g['start']), T(g['goal']), shift_cost=shift, **kw)
+        U, X, c = pl.optimize(**obs)
+        np.testing.assert_allclose(c.cpu().numpy(), ref['costs'].numpy(), rtol=5e-5)
+        assert rel_err(pl.get_mean_controls(), ref['mean']) < 1e-4, it
+        mean = ref['mean']
+        best = min(best, float(ref['costs'].min()))
+        np.testing.assert_allclose(float(pl.best_cost), best, rtol=5e-5)
+
+
+def test_stoch_gpmp_const_vel_initial_means(gpu_device):
+    from motion_planning_baselines_amd.planners.stoch_gpmp import StochGPMP
+    g = load_golden('sgpmp_panda_h16_f64')
+    dev = gpu_device
+    robot, field = product_geometry_from_golden(g)
+    S, H, D = int(g['S']), int(g['H']), int(g['D'])
+    ppg, dt = 3, float(g['dt'])
+    start = T(g['start']).float()
+    goals = torch.stack([T(g['goal']).float(), T(g['goal']).float() * 0.5 + 0.1])
+    pl = StochGPMP(robot=robot, n_dof=D, n_support_points=H, num_particles_per_goal=ppg, opt_iters=1, dt=dt,
+                   start_state=start.to(dev), step_size=float(g['step_size']), multi_goal_states=goals.to(dev),
+                   initial_particle_means='const_vel', sigma_start_init=1e-3, sigma_goal_init=1e-3, sigma_gp_init=1.0,
+                   sigma_start_sample=float(g['sigma_start_sample']), sigma_goal_sample=float(g['sigma_goal_sample']),
+                   sigma_gp_sample=float(g['sigma_gp_sample']), num_samples=S, temperature=float(g['temperature']),
+                   collision_fields=[field], sigma_start=float(g['sigma_start']), sigma_gp=float(g['sigma_gp']),
+                   sigma_coll=float(g['sigma_coll']), sigma_goal_prior=float(g['sigma_goal_prior']),
+                   tensor_args=dict(device=dev, dtype=torch.float32), noise='philox', seed=3)
+    # stoch_gpmp.py:197-215 restated: straight line per goal, velocity (goal - start) / (H dt), ppg copies
+    want = torch.zeros(2, ppg, H, 2 * D)
+    mean_vel = (goals[:, :D] - start[:D]) / (H * dt)
+    for i in range(H):
+        want[:, :, i, :D] = (start[:D] * (H - i - 1) / (H - 1) + goals[:, :D] * i / (H - 1)).unsqueeze(1)
+    want[:, :, :, D:] = mean_vel.unsqueeze(1).unsqueeze(1)
+    got = pl._particle_means.cpu()
+    assert got.shape == (2 * ppg, H, 2 * D)
+    assert torch.allclose(got, want.flatten(0, 1), rtol=1e-6, atol=1e-7)
+    traj = pl.optimize(opt_iters=2)
+    assert torch.isfinite(traj).all()
+    pl.reset(initial_particle_means='const_vel')
+    assert torch.allclose(pl._particle_means.cpu(), want.flatten(0, 1), rtol=1e-6, atol=1e-7)

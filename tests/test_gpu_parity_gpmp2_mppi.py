@@ -281,7 +281,7 @@ def test_mppi_vs_golden(gpu_device, name):
     print(name, 'free-running rel err', err, 'reference fp32-vs-fp64 envelope', env)
     assert err < max(1e-4, 2.0 * env)                      # north_star: 1e-4 on the final waypoints
     # MPPI._save_best (mppi.py:145-152, :164-168): the cheapest sample over ALL iterations and its state trajectory
-    best_cost = torch.full((1,), float('inf'), device=dev)
+    best_cost = torch.full((1,), 3.0e38, device=dev)       # the finite "none yet" sentinel (planners/mppi.py BEST_COST_NONE)
     best_states = torch.zeros(1, Tn, c, device=dev)
     mean = torch.zeros(1, Tn, c, device=dev)
     ops.mppi_step(mean, eps, tril, cinv, state0, goal, cmin, cmax, disc, cw, geom, controls, states, costs, weights,

@@ -1,0 +1,159 @@
+"""-m gpu: the throughput-mode random numbers of the STOMP kernels, pinned.
+
+What bench.py times draws its noise on the device: Philox4x32 with SEVEN rounds (csrc/mpb_common.h; the Random123
+authors' smallest Crush-resistant round count) and Box-Muller on the hardware log2 / sqrt / sin / cos units.  Checked:
+  1. the generator is Philox: raw words against the PUBLISHED Random123 known-answer vectors (kat_vectors: philox4x32,
+     7 and 10 rounds, the three standard counter / key patterns);
+  2. the stream the statistics below look at IS the product's: mpb_debug_stomp_normals equals, bit for bit, what the
+     two-kernel path and the persistent kernel add to the means (L = identity makes the noise product exact);
+  3. 1.1e7 normals of three C3 iterations: first four moments, tail masses, a Kolmogorov-Smirnov distance to Phi, a
+     chi-square over 256 equiprobable bins, lag-1 correlations along every index of the draw (waypoint, channel, sample,
+     particle, iteration) and between seeds.  All bars sit at ~5 sigma of the statistic's sampling distribution."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+# Random123 kat_vectors, "philox4x32 R  ctr[4] key[2]  expected[4]"
+KAT = [
+    (7, [0, 0, 0, 0], [0, 0], [0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48]),
+    (7, [0xffffffff] * 4, [0xffffffff] * 2, [0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662]),
+    (7, [0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0], [0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a]),
+    (10, [0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+    (10, [0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+    (10, [0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0], [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]),
+]
+
+
+def _philox_host(ctr, key, rounds):
+    """Philox4x32-R as published (Salmon et al., SC'11), plain integers."""
+    c, k = [int(v) for v in ctr], [int(v) for v in key]
+    for _ in range(rounds):
+        p0, p1 = 0xD2511F53 * c[0], 0xCD9E8D57 * c[2]
+        c = [(p1 >> 32) ^ c[1] ^ k[0], p1 & 0xffffffff, (p0 >> 32) ^ c[3] ^ k[1], p0 & 0xffffffff]
+        k = [(k[0] + 0x9E3779B9) & 0xffffffff, (k[1] + 0xBB67AE85) & 0xffffffff]
+    return c
+
+
+def test_philox_known_answers(gpu_device):
+    from motion_planning_baselines_amd import ops
+    torch.cuda.set_device(gpu_device)
+    for rounds in (7, 10):
+        rows = [k for k in KAT if k[0] == rounds]
+        got = ops.debug_philox([r[1] for r in rows], [r[2] for r in rows], rounds)
+        for r, g in zip(rows, got):
+            assert [int(v) for v in g] == r[3], (rounds, r[1])
+            assert _philox_host(r[1], r[2], rounds) == r[3]                 # the host restatement agrees with the vectors
+    # random counters / keys against the host restatement
+    rng = np.random.default_rng(0)
+    ctr = rng.integers(0, 2 ** 32, size=(257, 4), dtype=np.uint64)
+    key = rng.integers(0, 2 ** 32, size=(257, 2), dtype=np.uint64)
+    for rounds in (7, 10):
+        got = ops.debug_philox(ctr, key, rounds)
+        want = np.array([_philox_host(c, k, rounds) for c, k in zip(ctr, key)], dtype=np.uint64)
+        assert np.array_equal(got.astype(np.uint64), want)
+
+
+@pytest.mark.parametrize('P,S,pos_only', [(6, 20, False), (3, 32, True)])
+def test_debug_normals_are_the_kernels_normals(gpu_device, P, S, pos_only):
+    """With L = identity the noise product is exact (1 * eps + 0 * ...): samples - means == the debug stream, bit for
+    bit, on the two-kernel path (mpb_stomp_sample) and inside the persistent kernel (mpb_stomp_run)."""
+    from motion_planning_baselines_amd import ops, workloads
+    dev = gpu_device
+    H = 64
+    wl = workloads.panda_spheres_stomp(P, dev, H=H, S=S, pos_only=pos_only)
+    d = wl['means0'].shape[-1]
+    eye = torch.eye(H, device=dev).contiguous()
+    zeros = torch.zeros(P, H, d, device=dev)
+    seed, it0, off = 77, 5, 1000
+    nrm = ops.debug_stomp_normals(P, S, d, 2, dev, seed=seed, iter0=it0, particle_offset=off)     # (2,P,S,d,H)
+    want = nrm.permute(0, 1, 2, 4, 3).clone()                                                     # (2,P,S,H,d)
+    want[:, :, :, 0, :] = 0
+    want[:, :, :, -1, :] = 0                                                                      # stomp.py:105-106
+    samples = torch.empty(P, S, H, d, device=dev)
+    ops.stomp_sample(zeros, None, samples, eye, S, seed=seed, it=it0, particle_offset=off)
+    torch.cuda.synchronize()
+    assert torch.equal(samples, want[0])
+    # the persistent kernel, second iteration of a two-iteration launch (lr = 0: the means stay zero)
+    geom = ops.DeviceGeometry(wl['robot'], wl['field'], dev)
+    ws = ops.stomp_workspace(P, S, H, d, dev)
+    assert ops.stomp_run_path(geom, ws, P, S, H, d) != ops.STOMP_PATH_TWO_KERNEL
+    costs, weights = torch.empty(P, S, device=dev), torch.empty(P, S, device=dev)
+    means = zeros.clone()
+    ops.stomp_run(means, None, samples, costs, weights, eye, eye, geom, S, 7, 1.0, 1.0, 0.0, 1.0, ws, n_iters=2,
+                  seed=seed, iter0=it0, particle_offset=off)
+    torch.cuda.synchronize()
+    assert not ops.stomp_run_timed_out(ws)
+    assert torch.equal(means, zeros) and torch.equal(samples, want[1])
+
+
+def _phi(x):
+    from scipy.special import ndtr
+    return ndtr(x)
+
+
+def test_device_normals_statistics(gpu_device):
+    """C3's draw shape (P=128, S=32, d=14, H=64), three iterations = 11 010 048 normals."""
+    from motion_planning_baselines_amd import ops
+    dev = gpu_device
+    P, S, d, K, n_it = 128, 32, 14, 64, 3
+    x = ops.debug_stomp_normals(P, S, d, n_it, dev, seed=0, iter0=0)
+    torch.cuda.synchronize()
+    assert torch.isfinite(x).all()
+    xd = x.double()
+    n = xd.numel()
+    assert n >= 10_000_000
+    m = float(xd.mean())
+    c = xd - m
+    var = float((c * c).mean())
+    skew = float((c ** 3).mean()) / var ** 1.5
+    kurt = float((c ** 4).mean()) / var ** 2 - 3.0
+    print('n %d  mean %.3e  var-1 %.3e  skew %.3e  excess kurtosis %.3e' % (n, m, var - 1, skew, kurt))
+    assert abs(m) < 5.0 / np.sqrt(n)
+    assert abs(var - 1.0) < 5.0 * np.sqrt(2.0 / n)
+    assert abs(skew) < 5.0 * np.sqrt(6.0 / n)
+    assert abs(kurt) < 5.0 * np.sqrt(24.0 / n)
+    # tail masses against Phi (binomial 5-sigma bars); Box-Muller on 24-bit uniforms cannot exceed sqrt(2 ln 2^24) = 5.77
+    for t in (2.0, 3.0, 4.0, 4.5):
+        p = 2.0 * (1.0 - _phi(t))
+        got = float((xd.abs() > t).sum())
+        print('  |x| > %.1f: %d  expected %.1f +- %.1f' % (t, got, n * p, np.sqrt(n * p)))
+        assert abs(got - n * p) < 5.0 * np.sqrt(n * p * (1 - p))
+    assert float(xd.abs().max()) <= 5.78
+    assert float((xd > 0).double().mean() - 0.5) ** 2 < (5.0 * 0.5 / np.sqrt(n)) ** 2       # sign symmetry
+    # lag-1 correlation along every index of the draw
+    def corr(a, b):
+        a, b = a - a.mean(), b - b.mean()
+        return float((a * b).mean() / (a.std() * b.std())), a.numel()
+    for name, dim in (('iteration', 0), ('particle', 1), ('sample', 2), ('channel', 3), ('waypoint', 4)):
+        sl_a = [slice(None)] * 5
+        sl_b = [slice(None)] * 5
+        sl_a[dim], sl_b[dim] = slice(0, -1), slice(1, None)
+        r, npair = corr(xd[tuple(sl_a)], xd[tuple(sl_b)])
+        print('  lag-1 correlation along %-9s %.3e (n = %d)' % (name, r, npair))
+        assert abs(r) < 5.0 / np.sqrt(npair), name
+    # the four normals of one Philox call (waypoints k, k+4, k+8, k+12 of a 16-block) and the two of one Box-Muller pair
+    blk = xd.reshape(n_it, P, S, d, 4, 4, 4)           # k = 16 q4 + 4 r + g
+    for r0, r1 in ((0, 1), (0, 2), (2, 3), (1, 3)):
+        r, npair = corr(blk[..., r0, :], blk[..., r1, :])
+        assert abs(r) < 5.0 / np.sqrt(npair), (r0, r1)
+        r2, _ = corr(blk[..., r0, :] ** 2, blk[..., r1, :] ** 2)       # dependence of the radii
+        assert abs(r2) < 5.0 / np.sqrt(npair), (r0, r1)
+    # another seed, and another shard of the particle range, are independent streams
+    y = ops.debug_stomp_normals(P, S, d, n_it, dev, seed=1, iter0=0).double()
+    z = ops.debug_stomp_normals(P, S, d, n_it, dev, seed=0, iter0=0, particle_offset=P).double()
+    for other in (y, z):
+        r, npair = corr(xd, other)
+        assert abs(r) < 5.0 / np.sqrt(npair)
+    # Kolmogorov-Smirnov distance to Phi on all draws, and a chi-square over 256 equiprobable bins
+    xs = np.sort(x.reshape(-1).cpu().numpy().astype(np.float64))
+    cdf = _phi(xs)
+    i = np.arange(1, n + 1, dtype=np.float64)
+    dn = max(float(np.max(i / n - cdf)), float(np.max(cdf - (i - 1) / n)))
+    print('  KS distance %.3e (1 %% critical value %.3e)' % (dn, 1.63 / np.sqrt(n)))
+    assert dn < 1.95 / np.sqrt(n)                                      # p = 0.001
+    counts = np.bincount(np.minimum((cdf * 256).astype(np.int64), 255), minlength=256)
+    chi2 = float(((counts - n / 256) ** 2 / (n / 256)).sum())
+    print('  chi-square (255 dof) %.1f' % chi2)
+    assert chi2 < 255 + 5.0 * np.sqrt(2 * 255)

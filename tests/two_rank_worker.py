@@ -62,13 +62,20 @@ def main():
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     dev = torch.device('cuda:0')
     torch.cuda.set_device(dev)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    # MPB_DIST_BACKEND=nccl (+ WORLD_SIZE=1, MPB_FORCE_DIST=1): the RCCL rehearsal of tests/test_gpu_rccl_world1.py -- the
+    # same code on the backend an N-GPU job uses, every collective executed even though there is one rank
+    backend = os.environ.get('MPB_DIST_BACKEND', 'gloo')
+    force = os.environ.get('MPB_FORCE_DIST') == '1'
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
     from motion_planning_baselines_amd import parallel
     pr = problem(dev)
     lo, hi = parallel.shard_range(pr['P'], rank, world)
-    m = parallel.gather_means(run_stomp(pr, dev, lo, hi), pr['P'])
+    m = parallel.gather_means(run_stomp(pr, dev, lo, hi), pr['P'], force=force)
     glo, ghi = parallel.shard_range(pr['Bg'], rank, world)
-    x = parallel.gather_means(run_gpmp2(pr, dev, glo, ghi, dist.group.WORLD), pr['Bg'])
+    x = parallel.gather_means(run_gpmp2(pr, dev, glo, ghi, dist.group.WORLD), pr['Bg'], force=force)
     torch.cuda.synchronize()
     if rank == 0:
         np.savez(out, stomp=m.cpu().numpy(), gpmp2=x.cpu().numpy())
