@@ -93,12 +93,24 @@ def cpu_baseline_stomp(wl, budget_s=10.0, max_iters=8):
 
 
 class Clock:
-    """R timed blocks of one callable, each bracketed by barrier + synchronize, MAX over the ranks."""
+    """R timed blocks of one callable, each bracketed by barrier + synchronize, MAX over the ranks.
+
+    The closing bracket first spins on an event query (host polling, no sleep) and THEN calls the barrier and
+    torch.cuda.synchronize(), which by then return at once: the timed region still ends when every kernel of the block has
+    finished and synchronize() has returned, but the runtime's blocking wait is taken out of it -- on this pool
+    hipDeviceSynchronize wakes up 15-25 us late for about half the launches of one particular duration (~360 us, i.e.
+    exactly 20 C3 steps; scripts/sync_latency.py: K = 19 and K = 21 are not affected), which is host scheduling, not
+    planner time."""
 
     def __init__(self, dist, dev):
         self.dist, self.dev = dist, dev
 
-    def barrier(self):
+    def barrier(self, spin=False):
+        if spin:
+            ev = torch.cuda.Event()
+            ev.record()
+            while not ev.query():
+                pass
         if self.dist is not None:
             self.dist.barrier()
         torch.cuda.synchronize()
@@ -111,7 +123,7 @@ class Clock:
             self.barrier()
             t0 = time.perf_counter()
             fn()
-            self.barrier()
+            self.barrier(spin=True)
             el = time.perf_counter() - t0
             if self.dist is not None:
                 t = torch.tensor([el], device=self.dev, dtype=torch.float64)

@@ -215,6 +215,8 @@ int mpb_stomp_step_profile(float *means, float *samples, float *costs, float *we
  *     call that was lost (0: none), [2] = why (1 partner timed out, 2 header not zeroed); `tag_out` receives the tag
  *     of this call (0 when it ran the two-kernel loop, which cannot be lost).  The caller compares [1] with the tags it
  *     has issued whenever convenient -- planners/stomp.py raises at the next planner call.
+ * means_copy (P,H,d) or NULL: a second destination for the final means, written by the same launch (the reference's
+ * optimize() returns a CLONE of its means, base.py:204-213: this saves the dependent copy kernel).
  * Not capturable in a HIP graph (the per-call tag is drawn on the host). */
 #define MPB_STOMP_PATH_TWO_KERNEL 0
 #define MPB_STOMP_PATH_PERSISTENT_EXCHANGE 1   /* one workgroup per (particle, chunk of 16 samples), partials exchanged */
@@ -234,7 +236,7 @@ int mpb_stomp_run_checked(float *means, const float *eps, float *samples, float 
                           int P, int S, int H, int d, int D,
                           float k_sigma, float weight, float lr, float temperature,
                           int n_iters, uint64_t seed, uint32_t iter0, uint32_t particle_offset,
-                          uint32_t *status, uint32_t *tag_out, void *stream);
+                          uint32_t *status, uint32_t *tag_out, float *means_copy, void *stream);
 int mpb_stomp_run_status(const float *workspace, void *stream, int *timed_out);
 /* Test aid: n_blocks workgroups that each take a whole CU's LDS and idle for `usec` microseconds (the "another stream
  * keeps the chip busy" of the time-out tests); `sink` is one device word (never written in practice). */

@@ -98,8 +98,19 @@ __device__ unsigned long long g_fstamps[256 * FUSED_WAVES * 12];
 extern "C" int mpb_debug_read_fstamps(unsigned long long* dst, int n) {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_fstamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : 3;
 }
+// s_memrealtime (100 MHz) of wave 0 of every workgroup along the LAUNCH: entry, ticket drawn, constants staged, first noise
+// drawn, end of iterations 0 / 1 / 2, exit
+__device__ unsigned long long g_lstamps[1024 * 8];
+#define LSTAMP(k)                                                                                   \
+    do {                                                                                            \
+        if (blockIdx.x < 1024 && threadIdx.x == 0) g_lstamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+extern "C" int mpb_debug_read_lstamps(unsigned long long* dst, int n) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_lstamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : 3;
+}
 #else
 #define FSTAMP(k)
+#define LSTAMP(k)
 #endif
 
 // NB = 1: the unit is (particle, chunk of 16 samples), partners exchange partials through the workspace (above).
@@ -113,7 +124,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
     float* __restrict__ weights, const float* __restrict__ Lmat, const float* __restrict__ Sigma,
     const float* __restrict__ geom, float* __restrict__ ws, int P, int S, int nc, float k_sigma, float weight, float lr,
     float temperature, int n_iters, uint32_t seed_lo, uint32_t seed_hi, uint32_t iter0, uint32_t particle_offset,
-    uint32_t tag0, unsigned long long timeout_ticks, unsigned* __restrict__ status_host) {
+    uint32_t tag0, unsigned long long timeout_ticks, unsigned* __restrict__ status_host, float* __restrict__ means_copy) {
     constexpr int H = 64;
     constexpr int N = H * DCH;                    // elements of a trajectory
     static_assert(N <= FUSED_THREADS && N + 2 <= FUSED_XCHG, "one thread per trajectory element");
@@ -131,6 +142,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
     // the wave index as a SCALAR: everything derived from it (sample index, tile and output base addresses) then sits in
     // SGPRs, and per-lane addresses are a 32-bit offset from a uniform base instead of hoisted 64-bit VGPR pairs (which spill)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    LSTAMP(0);
     unsigned* wsu = reinterpret_cast<unsigned*>(ws);
     const bool exchange = NB == 1 && nc > 1;
     // unit of this block: with partners to exchange with, by ticket (drawn here, read after the constants are staged);
@@ -161,6 +173,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         }
         s_ticket = u;
     }
+    LSTAMP(1);
     const int j = lane & 15, g = lane >> 4;
     granule_t* xch = reinterpret_cast<granule_t*>(ws + 16);
 
@@ -195,6 +208,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
     // header word 1 = this call's tag; word 0 (the error word) counts only when it equals it
     if (ticket == 0 && tid == 0) st_agent_u(wsu + FUSED_HDR_TAG, tag0);    // (unit 0 is drawn exactly once)
     __syncthreads();
+    LSTAMP(2);
 
     const size_t eps_stride = (size_t)S * DCH * P * H;
 
@@ -209,6 +223,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         stomp_noise_to_tile(nt, acc, lane);
     }
 
+    LSTAMP(3);
     const int n_run = s_abort ? 0 : n_iters;          // (block-uniform: written before the barriers above)
     for (int it = 0; it < n_run; ++it) {
         // (NB > 1) partials of the batches, as the exchange path would publish them
@@ -347,10 +362,18 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
             asm volatile("" : "+v"(jv), "+v"(gv));
             // (a k-block pipelined form -- Philox of block q+1 issued between the MFMAs of block q, straight-line code -- was
             // measured 3 % slower: the waves of a SIMD already overlap one wave's matrix work with another's Philox)
-            stomp_b_operand<DCH, true>(e, eps ? eps + (size_t)it_n * eps_stride + (size_t)(s_n < S ? s_n : 0) * DCH * P * H : nullptr, P, p, jv, gv,
-                                       particle_offset + (uint32_t)p, (uint32_t)s_n, iter0 + (uint32_t)it_n, seed_lo, seed_hi);
+            // issue priority by progress through the draws (mpb_stomp_noise.h).  Measured against it on the same box
+            // (scripts/ab_k20.sh): four fixed levels for the four waves of a SIMD, so that one wave's matrix product would run
+            // under the others' draws (STOMP_PRIO_STAGGER) +3 %, no priority at all +3 %
+#ifndef FUSED_NOISE_PRIO
+#define FUSED_NOISE_PRIO STOMP_PRIO_PROGRESS
+#endif
+            stomp_b_operand<DCH, FUSED_NOISE_PRIO>(e, eps ? eps + (size_t)it_n * eps_stride + (size_t)(s_n < S ? s_n : 0) * DCH * P * H : nullptr, P, p, jv, gv,
+                                                   particle_offset + (uint32_t)p, (uint32_t)s_n, iter0 + (uint32_t)it_n, seed_lo, seed_hi,
+                                                   3 - (wave >> 2));
             stomp_noise_product(Lp, e, j, g, acc);
             stomp_noise_to_tile(nt, acc, lane);           // (the samples packed in the tile were consumed before barrier 2)
+            if (FUSED_NOISE_PRIO == STOMP_PRIO_STAGGER) __builtin_amdgcn_s_setprio(0);
         }
         }   // batches
         float m_all = mb, z_all = zb, f_own = 1.f, f_own0 = 1.f;
@@ -435,9 +458,16 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         FSTAMP(10);
         __syncthreads();                                                                        // (5) new mean visible, tiles free
         FSTAMP(11);
+        if (it < 3) LSTAMP(4 + it);
     }
     const int aborted = s_abort;                        // (block-uniform: last written before a barrier every thread passed)
-    if (!aborted && chunk == 0 && tid < N) means[(size_t)p * N + tid] = mean_l[tid];
+    if (!aborted && chunk == 0 && tid < N) {
+        const float m = mean_l[tid];
+        means[(size_t)p * N + tid] = m;
+        if (means_copy) means_copy[(size_t)p * N + tid] = m;      // the caller's own copy (OptimizationPlanner._get_traj clones)
+    }
+    // a lost call leaves the means as they were: the caller's copy says the same (never uninitialised memory)
+    if (aborted == 1 && chunk == 0 && tid < N && means_copy) means_copy[(size_t)p * N + tid] = means[(size_t)p * N + tid];
     // ---- leaving: the error word (device header + the caller's host-visible status block), then the head count; the
     //      last workgroup out re-arms the header for the next call and reports the call as completed
     if (tid == 0) {
@@ -451,6 +481,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
             }
         }
         const unsigned left = __hip_atomic_fetch_add(wsu + FUSED_HDR_DONE, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        LSTAMP(7);
         if (left == gridDim.x - 1u && aborted != 2) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) st_agent_u(wsu + FUSED_HDR_TICKET + k, 0u);
@@ -543,22 +574,37 @@ extern "C" int mpb_stomp_run_checked(float* means, const float* eps, float* samp
                                      const float* L, const float* Sigma, const float* geom, int geom_flags, float* workspace,
                                      size_t workspace_bytes, int P, int S, int H, int d, int D, float k_sigma, float weight, float lr,
                                      float temperature, int n_iters, uint64_t seed, uint32_t iter0, uint32_t particle_offset,
-                                     uint32_t* status, uint32_t* tag_out, void* stream) {
+                                     uint32_t* status, uint32_t* tag_out, float* means_copy, void* stream) {
     if (tag_out) *tag_out = 0u;
-    if (P == 0 || n_iters == 0) return MPB_OK;
+    if (P == 0) return MPB_OK;
     const FusedPlan f = fused_plan(geom_flags, P, S, H, d);
-    if (!workspace || f.path == MPB_STOMP_PATH_TWO_KERNEL || workspace_bytes < f.ws_bytes)
-        return mpb_stomp_step(means, eps, samples, costs, weights, L, Sigma, geom, geom_flags, P, S, H, d, D, k_sigma, weight, lr,
-                              temperature, n_iters, seed, iter0, particle_offset, stream);
+    if (n_iters == 0 || !workspace || f.path == MPB_STOMP_PATH_TWO_KERNEL || workspace_bytes < f.ws_bytes) {
+        const int rc = n_iters == 0 ? MPB_OK : mpb_stomp_step(means, eps, samples, costs, weights, L, Sigma, geom, geom_flags, P, S, H, d, D,
+                                                             k_sigma, weight, lr, temperature, n_iters, seed, iter0, particle_offset, stream);
+        if (rc == MPB_OK && means_copy && means &&
+            hipMemcpyAsync(means_copy, means, sizeof(float) * (size_t)P * H * d, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+            return mpb_fail(MPB_E_HIP, "mpb_stomp_run: copy of the means failed");
+        return rc;
+    }
     if (!means || !samples || !costs || !weights || !L || !Sigma || !geom) return mpb_fail(MPB_E_INVALID, "mpb_stomp_run: null pointer");
     if (P < 0 || S < 1 || n_iters < 0 || !(d == D || d == 2 * D)) return mpb_fail(MPB_E_INVALID, "mpb_stomp_run: bad shape");
     if (!(temperature > 0.f)) return mpb_fail(MPB_E_INVALID, "mpb_stomp_run: temperature must be > 0");
     hipStream_t st = (hipStream_t)stream;
     // the status block is host memory the device can write (pinned + mapped): its device address
     unsigned* status_dev = nullptr;
-    if (status && hipHostGetDevicePointer(reinterpret_cast<void**>(&status_dev), status, 0) != hipSuccess) {
-        (void)hipGetLastError();
-        return mpb_fail(MPB_E_INVALID, "mpb_stomp_run: status is not pinned, device-mapped host memory");
+    if (status) {
+        static thread_local uint32_t* seen_host = nullptr;      // (a planner passes the same block every call: asked once)
+        static thread_local unsigned* seen_dev = nullptr;
+        if (status != seen_host) {
+            unsigned* dp = nullptr;
+            if (hipHostGetDevicePointer(reinterpret_cast<void**>(&dp), status, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                return mpb_fail(MPB_E_INVALID, "mpb_stomp_run: status is not pinned, device-mapped host memory");
+            }
+            seen_host = status;
+            seen_dev = dp;
+        }
+        status_dev = seen_dev;
     }
     // the granules' tags and the error word carry a per-call epoch (process-wide counter scrambled over 32 bits), so
     // whatever an earlier call left in the exchange area does not match.  Header: word 0 = tag of the call in which a
@@ -578,7 +624,7 @@ extern "C" int mpb_stomp_run_checked(float* means, const float* eps, float* samp
 #define MPB_F_LAUNCH(DCH, MODEL, NB)                                                                                      \
     hipLaunchKernelGGL((stomp_fused_kernel<DCH, MODEL, NB>), grid, block, 0, st, means, eps, samples, costs, weights, L, \
                        Sigma, geom, workspace, P, S, nc_k, k_sigma, weight, lr, temperature, n_iters, lo, hi, iter0,        \
-                       particle_offset, tag0, timeout, status_dev)
+                       particle_offset, tag0, timeout, status_dev, means_copy)
 #define MPB_F_CASE(DCH, MODEL)                           \
     do {                                                 \
         if (f.two_batches) MPB_F_LAUNCH(DCH, MODEL, 2);  \
@@ -604,7 +650,7 @@ extern "C" int mpb_stomp_run(float* means, const float* eps, float* samples, flo
                              void* stream) {
     return mpb_stomp_run_checked(means, eps, samples, costs, weights, L, Sigma, geom, geom_flags, workspace, workspace_bytes, P, S,
                                  H, d, D, k_sigma, weight, lr, temperature, n_iters, seed, iter0, particle_offset, nullptr,
-                                 nullptr, stream);
+                                 nullptr, nullptr, stream);
 }
 
 /* state of the last persistent launch on this workspace (host-side read of the header: synchronises the stream):

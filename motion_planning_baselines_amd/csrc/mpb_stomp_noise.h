@@ -26,29 +26,40 @@ __device__ __forceinline__ void stomp_eps4(uint32_t p_global, uint32_t s, uint32
 
 // B operand of one rollout: e[ks] = eps[c = j][k = 4 ks + g], ks = 0..15 (zero for the padding channels j >= DCH).
 // eps_rollout != nullptr: pre-drawn normals, laid out (d, P, H) for this sample (pointer already at [s]).
-// PRIO: lower the wave's issue priority as it advances through the four draws (3, 2, 1, 0): the SIMD arbiter serves its
-// oldest wave first, which left alone makes the waves of a SIMD finish one after the other, the last one running alone
-// (see model_group_positions in mpb_geom.h).  The caller's priority is 0 afterwards.
-template <int DCH, bool PRIO = false>
+// PRIO: what the wave does to its issue priority while it draws (the caller resets it after the matrix product).
+//   STOMP_PRIO_PROGRESS  lower it as the wave advances through the four draws (3, 2, 1, 0): the SIMD arbiter serves its
+//       oldest wave first, which left alone makes the waves of a SIMD finish one after the other, the last one running
+//       alone (see model_group_positions in mpb_geom.h).  For kernels whose waves do VALU work only.
+//   STOMP_PRIO_STAGGER   one fixed level per wave, `level` = 0..3, different for the (up to four) waves of a SIMD: the
+//       draws are VALU work, the product that follows them runs on the matrix pipe, and the two overlap only when the
+//       waves of a SIMD are in DIFFERENT halves -- so here the waves are made to finish one after the other on purpose:
+//       the wave with the highest level draws at full rate and multiplies while the others still draw.
+#define STOMP_PRIO_NONE 0
+#define STOMP_PRIO_PROGRESS 1
+#define STOMP_PRIO_STAGGER 2
+__device__ __forceinline__ void stomp_setprio(int level) {       // (the operand of s_setprio is an immediate)
+    switch (level) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+template <int DCH, int PRIO = STOMP_PRIO_NONE>
 __device__ __forceinline__ void stomp_b_operand(float (&e)[16], const float* __restrict__ eps_s, int P, int p, int j, int g,
-                                                uint32_t p_global, uint32_t s, uint32_t iter, uint32_t seed_lo, uint32_t seed_hi) {
+                                                uint32_t p_global, uint32_t s, uint32_t iter, uint32_t seed_lo, uint32_t seed_hi,
+                                                int level = 0) {
     constexpr int H = 64;
     if (eps_s != nullptr) {
         const float* ep = eps_s + ((size_t)(j < DCH ? j : 0) * P + p) * H + g;
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) e[ks] = (j < DCH) ? ep[4 * ks] : 0.f;
     } else {
+        if (PRIO == STOMP_PRIO_STAGGER) stomp_setprio(level);
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
             float n[4] = {0.f, 0.f, 0.f, 0.f};
-            if (PRIO) {
-                switch (q4) {   // (the operand of s_setprio is an immediate)
-                    case 0: __builtin_amdgcn_s_setprio(3); break;
-                    case 1: __builtin_amdgcn_s_setprio(2); break;
-                    case 2: __builtin_amdgcn_s_setprio(1); break;
-                    default: __builtin_amdgcn_s_setprio(0); break;
-                }
-            }
+            if (PRIO == STOMP_PRIO_PROGRESS) stomp_setprio(3 - q4);
             if (j < DCH) stomp_eps4(p_global, s, (uint32_t)j, (uint32_t)g, (uint32_t)q4, iter, seed_lo, seed_hi, n);
             e[4 * q4 + 0] = n[0]; e[4 * q4 + 1] = n[1]; e[4 * q4 + 2] = n[2]; e[4 * q4 + 3] = n[3];
         }

@@ -75,6 +75,8 @@ class STOMP(OptimizationPlanner):
         assert check in ('deferred', 'sync')
         self.check = check
         self._status = None              # host-visible status block of the persistent launches (allocated on first use)
+        self._plan = None                # validated, pre-converted arguments of the persistent launch (ops.StompRunPlan)
+        self._traj_out = None
         self.lr = step_size
         self.sigma_spectral = sigma_spectral
         self.start_state = start_state          # quirk Q10: overwrites the zero-velocity-extended state
@@ -164,10 +166,15 @@ class STOMP(OptimizationPlanner):
 
     # ---- optimisation ------------------------------------------------------------------------
     def optimize(self, opt_iters=None, **observation):
-        """stomp.py:137-148: run the iterations, return the current trajectory (P,H,d)."""
+        """stomp.py:137-148: run the iterations, return the current trajectory (P,H,d) -- a copy of the means
+        (base.py:204-213); where the persistent launch runs, the copy is written by that launch itself."""
+        self._traj_out = None
         self._run_optimization(opt_iters, **observation)
         if self.check == 'sync':
             self._raise_if_lost(synchronize=True)
+        if self._traj_out is not None:
+            out, self._traj_out = self._traj_out, None
+            return out
         return self._get_traj()
 
     def get_traj(self):
@@ -201,19 +208,37 @@ class STOMP(OptimizationPlanner):
         fused = fusable_collision(self.cost)
         if fused is not None and not observation:
             cc, weight = fused
-            eps = self._draw_eps(opt_iters)
-            # the whole loop as one persistent launch where the shape allows it (H = 64, S <= 64, grid-backed fields);
-            # mpb_stomp_run falls back to the two-kernel loop by itself otherwise
+            geom = cc.device_geometry(self.device)
             if self.persistent and self._run_ws is None:
                 self._run_ws = ops.stomp_workspace(self.num_particles, self.num_samples, self.n_support_points,
                                                    self.d_state_opt, self.device)
                 self._status = ops.StompRunStatus()
-            ops.stomp_run(self._particle_means, eps, self.state_particles, self.costs, self._weights_buf,
-                          self.scale_tril, self.Sigma, cc.device_geometry(self.device), self.num_samples,
-                          self.n_dof, cc.k_sigma, weight, self.lr, self.temperature,
-                          self._run_ws if self.persistent else None, n_iters=opt_iters,
-                          seed=self.seed, iter0=self._iter, particle_offset=self.particle_offset,
-                          status=self._status if self.persistent else None)
+            # the copy optimize() returns (base.py:204-213) is written by the launch itself (pos_only: _get_traj appends
+            # finite-difference velocities, from the means)
+            copy = None if self.pos_only else torch.empty_like(self._particle_means)
+            if (self.persistent and self.noise == 'philox' and self._particle_means.is_cuda
+                    and torch.cuda.current_device() == self._particle_means.device.index):
+                # device noise: nothing changes between calls but the iteration counter -- arguments validated once
+                key = (self._particle_means.data_ptr(), self.state_particles.data_ptr(), self.costs.data_ptr(),
+                       self._weights_buf.data_ptr(), self.scale_tril.data_ptr(), self.Sigma.data_ptr(), geom.buf.data_ptr(),
+                       self._run_ws.data_ptr(), self.num_samples, self.n_dof, float(cc.k_sigma), float(weight), float(self.lr),
+                       float(self.temperature), self.seed, self.particle_offset)
+                plan = self._plan
+                if plan is None or plan.key != key:
+                    plan = self._plan = ops.StompRunPlan(
+                        self._particle_means, self.state_particles, self.costs, self._weights_buf, self.scale_tril,
+                        self.Sigma, geom, self.num_samples, self.n_dof, cc.k_sigma, weight, self.lr, self.temperature,
+                        self._run_ws, self.seed, self.particle_offset, self._status)
+                plan.launch(opt_iters, self._iter, copy)
+            else:
+                # the whole loop as one persistent launch where the shape allows it (H = 64, S <= 64, grid-backed fields);
+                # mpb_stomp_run falls back to the two-kernel loop by itself otherwise
+                ops.stomp_run(self._particle_means, self._draw_eps(opt_iters), self.state_particles, self.costs,
+                              self._weights_buf, self.scale_tril, self.Sigma, geom, self.num_samples, self.n_dof, cc.k_sigma,
+                              weight, self.lr, self.temperature, self._run_ws if self.persistent else None,
+                              n_iters=opt_iters, seed=self.seed, iter0=self._iter, particle_offset=self.particle_offset,
+                              status=self._status if self.persistent else None, means_copy=copy)
+            self._traj_out = copy
             self._iter += opt_iters
         elif not observation and device_plan(self.cost, self.device) is not None:
             # composite of HIP-served members: sample(+collision) kernel -> trajectory-terms kernel(s) -> update
