@@ -1,0 +1,88 @@
+// mpb_stomp_fused.h -- what the persistent STOMP kernels (mpb_stomp_fused.hip: the H = 64 kernel; mpb_stomp_fused_hx.hip:
+// any horizon up to 128, any channel count, any number of sample batches) share: the workspace header, the ticket pools,
+// the agent-scope accessors and the tagged granules of the exchange between the workgroups of a particle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define FUSED_WAVES 16
+#define FUSED_THREADS (64 * FUSED_WAVES)
+#define FUSED_LD 68                        // padded row (floats) of the Sigma image and of the transposed delta tile
+#define FUSED_XCHG 912                     // granules per published partial: m, z, then H*d <= 896 values, padded
+#define FUSED_MAX_CHUNKS 4                 // S <= 64
+#define FUSED_TIMEOUT_TICKS 200000000ull   // 2 s of s_memrealtime (100 MHz) + FUSED_TIMEOUT_PER_ITER per iteration of the call
+#define FUSED_TIMEOUT_PER_ITER 10000ull    // 100 us: a workgroup whose partner starts a whole round of workgroups later waits that long
+// workspace header (16 words, zero before the first use: mpb_stomp_workspace_init; maintained by the kernel afterwards)
+#define FUSED_HDR_ERR 0      // tag of the call in which a workgroup gave up waiting (or found the header uninitialised)
+#define FUSED_HDR_TAG 1      // tag of the last call
+#define FUSED_HDR_DONE 2     // workgroups of the running call that have left; 0 between calls
+#define FUSED_HDR_WHY 3      // why FUSED_HDR_ERR was raised: 1 = partner timed out, 2 = header not initialised
+#define FUSED_HDR_TICKET 8   // words 8..15: next ticket of each of the 8 unit pools of the running call; 0 between calls
+// unit pools: pool x owns the particles p = x (mod FUSED_POOLS); a workgroup draws from the pool of the XCD it runs on
+// first (partners then share an L2: speed only), from the next pools once that one is exhausted
+#ifndef FUSED_POOLS
+#define FUSED_POOLS 8
+#endif
+
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent_u(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned ld_agent_u(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_system_u(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// one naturally aligned 8-byte granule {value, tag}, written by ONE agent-scope (sc1) store and read by ONE sc1 load: the
+// tag tells the reader which iteration of which call the value belongs to, so the payload needs no separate flag, no
+// drain of the stores and no fence (MI355X_MICROARCH.md: "handoff-1to1, data-tagged granules"; observed untorn)
+typedef unsigned long long granule_t;
+__device__ __forceinline__ void st_granule(granule_t* p, float v, unsigned tag) {
+    __hip_atomic_store(p, ((granule_t)tag << 32) | (granule_t)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ granule_t ld_granule(const granule_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+
+// unit of a workgroup of the exchange layout, by ticket (see the header comment of mpb_stomp_fused.hip): returns the unit
+// index u = particle * nc + chunk, or sets `why` (1: an earlier workgroup of this call gave up; 2: header not zeroed)
+__device__ __forceinline__ unsigned fused_draw_unit(unsigned* wsu, int P, int nc, uint32_t tag0, int& why) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    const unsigned lost = ld_agent_u(wsu + FUSED_HDR_ERR);     // (in flight together with the first ticket draw)
+    unsigned u = 0;
+    bool got = false;
+    for (unsigned k = 0; k < FUSED_POOLS && !got; ++k) {
+        const unsigned pool = (xcc + k) % FUSED_POOLS;
+        const unsigned size = ((unsigned)P + FUSED_POOLS - 1u - pool) / FUSED_POOLS * (unsigned)nc;
+        if (size == 0u) continue;
+        const unsigned t = __hip_atomic_fetch_add(wsu + FUSED_HDR_TICKET + pool, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t < size) {
+            got = true;
+            u = (FUSED_POOLS * (t / (unsigned)nc) + pool) * (unsigned)nc + t % (unsigned)nc;
+        }
+    }
+    why = 0;
+    if (lost == tag0) why = 1;                 // the call is lost already: leave at once
+    if (!got) {                                // (as many units as workgroups: only a header that was not zero gets here)
+        why = 2;
+        u = 0;
+    }
+    return u;
+}
+
+// leaving: the error word (device header + the caller's host-visible status block), then the head count; the last
+// workgroup out re-arms the header for the next call and reports the call as completed.  One thread per workgroup.
+__device__ __forceinline__ void fused_leave(unsigned* wsu, unsigned* status_host, uint32_t tag0, int aborted) {
+    if (aborted) {
+        st_agent_u(wsu + FUSED_HDR_WHY, (unsigned)aborted);
+        st_agent_u(wsu + FUSED_HDR_ERR, tag0);   // == header word 1 of THIS call: "lost"
+        if (status_host) {
+            st_system_u(status_host + 2, (unsigned)aborted);
+            st_system_u(status_host + 1, tag0);
+            __threadfence_system();              // (rare path) visible to the host before the head count says "completed"
+        }
+    }
+    const unsigned left = __hip_atomic_fetch_add(wsu + FUSED_HDR_DONE, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (left == gridDim.x - 1u && aborted != 2) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) st_agent_u(wsu + FUSED_HDR_TICKET + k, 0u);
+        st_agent_u(wsu + FUSED_HDR_DONE, 0u);
+        if (status_host) st_system_u(status_host + 0, tag0);
+    }
+}

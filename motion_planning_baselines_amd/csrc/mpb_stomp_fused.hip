@@ -40,39 +40,7 @@
 #include "mpb_common.h"
 #include "mpb_geom.h"
 #include "mpb_stomp_noise.h"
-
-#define FUSED_WAVES 16
-#define FUSED_THREADS (64 * FUSED_WAVES)
-#define FUSED_LD 68                        // padded row (floats) of the Sigma image and of the transposed delta tile
-#define FUSED_XCHG 912                     // granules per published partial: m, z, then H*d <= 896 values, padded
-#define FUSED_MAX_CHUNKS 4                 // S <= 64
-#define FUSED_TIMEOUT_TICKS 200000000ull   // 2 s of s_memrealtime (100 MHz) + FUSED_TIMEOUT_PER_ITER per iteration of the call
-#define FUSED_TIMEOUT_PER_ITER 10000ull    // 100 us: a workgroup whose partner starts a whole round of workgroups later waits that long
-// workspace header (16 words, zero before the first use: mpb_stomp_workspace_init; maintained by the kernel afterwards)
-#define FUSED_HDR_ERR 0      // tag of the call in which a workgroup gave up waiting (or found the header uninitialised)
-#define FUSED_HDR_TAG 1      // tag of the last call
-#define FUSED_HDR_DONE 2     // workgroups of the running call that have left; 0 between calls
-#define FUSED_HDR_WHY 3      // why FUSED_HDR_ERR was raised: 1 = partner timed out, 2 = header not initialised
-#define FUSED_HDR_TICKET 8   // words 8..15: next ticket of each of the 8 unit pools of the running call; 0 between calls
-// unit pools: pool x owns the particles p = x (mod FUSED_POOLS); a workgroup draws from the pool of the XCD it runs on
-// first (partners then share an L2: speed only), from the next pools once that one is exhausted
-#ifndef FUSED_POOLS
-#define FUSED_POOLS 8
-#endif
-
-__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent_u(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned ld_agent_u(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_system_u(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-// one naturally aligned 8-byte granule {value, tag}, written by ONE agent-scope (sc1) store and read by ONE sc1 load: the
-// tag tells the reader which iteration of which call the value belongs to, so the payload needs no separate flag, no
-// drain of the stores and no fence (MI355X_MICROARCH.md: "handoff-1to1, data-tagged granules"; observed untorn)
-typedef unsigned long long granule_t;
-__device__ __forceinline__ void st_granule(granule_t* p, float v, unsigned tag) {
-    __hip_atomic_store(p, ((granule_t)tag << 32) | (granule_t)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ granule_t ld_granule(const granule_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#include "mpb_stomp_fused.h"
 
 // workspace layout: 16 floats of header ([0] = error word), then 2 parities x P x nc x FUSED_XCHG granules (8 B each):
 // granule 0 = m, 1 = z, 2 + t = partial sum of trajectory element t
@@ -151,25 +119,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         s_abort = 0;
         unsigned u = blockIdx.x;
         if (exchange) {
-            unsigned xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
-            bool got = false;
-            for (unsigned k = 0; k < FUSED_POOLS && !got; ++k) {
-                const unsigned pool = (xcc + k) % FUSED_POOLS;
-                const unsigned size = ((unsigned)P + FUSED_POOLS - 1u - pool) / FUSED_POOLS * (unsigned)nc;
-                if (size == 0u) continue;
-                const unsigned t = __hip_atomic_fetch_add(wsu + FUSED_HDR_TICKET + pool, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (t < size) {
-                    got = true;
-                    u = (FUSED_POOLS * (t / (unsigned)nc) + pool) * (unsigned)nc + t % (unsigned)nc;
-                }
-            }
-            // an earlier workgroup of this call has given up: the call is lost, leave at once
-            if (ld_agent_u(wsu + FUSED_HDR_ERR) == tag0) s_abort = 1;
-            if (!got) {       // (as many units as workgroups: only a header that was not zero before the call gets here)
-                s_abort = 2;
-                u = 0;
-            }
+            int why;
+            u = fused_draw_unit(wsu, P, nc, tag0, why);
+            s_abort = why;
         }
         s_ticket = u;
     }
@@ -471,23 +423,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
     // ---- leaving: the error word (device header + the caller's host-visible status block), then the head count; the
     //      last workgroup out re-arms the header for the next call and reports the call as completed
     if (tid == 0) {
-        if (aborted) {
-            st_agent_u(wsu + FUSED_HDR_WHY, (unsigned)aborted);
-            st_agent_u(wsu + FUSED_HDR_ERR, tag0);   // == header word 1 of THIS call: "lost"
-            if (status_host) {
-                st_system_u(status_host + 2, (unsigned)aborted);
-                st_system_u(status_host + 1, tag0);
-                __threadfence_system();              // (rare path) visible to the host before the head count says "completed"
-            }
-        }
-        const unsigned left = __hip_atomic_fetch_add(wsu + FUSED_HDR_DONE, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         LSTAMP(7);
-        if (left == gridDim.x - 1u && aborted != 2) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) st_agent_u(wsu + FUSED_HDR_TICKET + k, 0u);
-            st_agent_u(wsu + FUSED_HDR_DONE, 0u);
-            if (status_host) st_system_u(status_host + 0, tag0);
-        }
+        fused_leave(wsu, status_host, tag0, aborted);
     }
 }
 
@@ -519,24 +456,43 @@ static int device_cu_count() {       // (every GPU of a node is the same part: a
     return n_cu;
 }
 
+// the generalised kernel (mpb_stomp_fused_hx.hip): any H <= 128, d <= 16, S <= 128
+bool mpb_fused_hx_plan(int geom_flags, int n_cu, int P, int S, int H, int d, int* nc_out, int* nb_out, size_t* ws_bytes);
+int mpb_fused_hx_launch(float* means, const float* eps, float* samples, float* costs, float* weights, const float* L,
+                        const float* Sigma, const float* geom, int geom_flags, float* workspace, int P, int S, int H, int d, int nc,
+                        int nb, float k_sigma, float weight, float lr, float temperature, int n_iters, uint32_t lo, uint32_t hi,
+                        uint32_t iter0, uint32_t particle_offset, uint32_t tag0, unsigned long long timeout, unsigned* status_dev,
+                        float* means_copy, hipStream_t st);
+
 // which form of the loop serves a call, and the workspace it needs
 struct FusedPlan {
     int path;            // MPB_STOMP_PATH_*: 0 two-kernel loop, 1 persistent with exchange, 2 persistent one workgroup per particle
     int nc;              // workgroups per particle (exchange layout)
-    bool two_batches;    // one workgroup per particle runs two batches of 16 samples
+    bool two_batches;    // (H = 64 kernel) one workgroup per particle runs two batches of 16 samples
+    bool hx;             // served by the generalised kernel (any H <= 128, d <= 16, S <= 128)
+    int nb;              // (generalised kernel) passes per workgroup and iteration
     size_t ws_bytes;     // workspace the persistent kernel needs (header only when nothing is exchanged)
 };
 static FusedPlan fused_plan(int geom_flags, int P, int S, int H, int d) {
-    FusedPlan f = {MPB_STOMP_PATH_TWO_KERNEL, 1, false, 0};
+    FusedPlan f = {MPB_STOMP_PATH_TWO_KERNEL, 1, false, false, 1, 0};
     if (P < 1 || S < 1) return f;
-    if (H != 64 || S > FUSED_WAVES * FUSED_MAX_CHUNKS || !(geom_flags & 0x100)) return f;
-    if (d != 2 && d != 3 && d != 4 && d != 6 && d != 7 && d != 14) return f;
+    const int n_cu = device_cu_count();
+    // MPB_STOMP_HX = 1 sends every shape to the generalised kernel (a test aid: it is compared with the H = 64 kernel)
+    const char* hx_env = getenv("MPB_STOMP_HX");
+    const int force_hx = hx_env ? atoi(hx_env) : 0;
+    const bool v1 = !force_hx && H == 64 && S <= FUSED_WAVES * FUSED_MAX_CHUNKS && (geom_flags & 0x100) &&
+                    (d == 2 || d == 3 || d == 4 || d == 6 || d == 7 || d == 14);
+    if (!v1) {
+        if (!mpb_fused_hx_plan(geom_flags, n_cu, P, S, H, d, &f.nc, &f.nb, &f.ws_bytes)) return f;
+        f.hx = true;
+        f.path = f.nc > 1 ? MPB_STOMP_PATH_PERSISTENT_EXCHANGE : MPB_STOMP_PATH_PERSISTENT;
+        return f;
+    }
     f.nc = (S + FUSED_WAVES - 1) / FUSED_WAVES;
     // layout: one workgroup per (particle, chunk of 16 samples) with the exchange -- or, when there are at least as many
     // particles as CUs and S <= 32, one workgroup per particle running two batches of 16 (no exchange; same bits).
     // MPB_STOMP_BATCHES = 1 / 2 forces one or the other (2 only where it applies).
     static const int force_nb = [] { const char* e = getenv("MPB_STOMP_BATCHES"); return e ? atoi(e) : 0; }();
-    const int n_cu = device_cu_count();
     // rounds of workgroups either layout needs on this chip: the two-batch workgroup takes ~1.88 x as long per iteration
     const long r1 = (2L * P + n_cu - 1) / n_cu, r2 = ((long)P + n_cu - 1) / n_cu;
     f.two_batches = f.nc == 2 && force_nb != 1 && (force_nb == 2 || 188 * r2 < 100 * r1);
@@ -618,6 +574,10 @@ extern "C" int mpb_stomp_run_checked(float* means, const float* eps, float* samp
     // bound of every wait for a partner; MPB_STOMP_TIMEOUT_US overrides it (a test aid)
     unsigned long long timeout = FUSED_TIMEOUT_TICKS + FUSED_TIMEOUT_PER_ITER * (unsigned long long)n_iters;
     if (const char* e = getenv("MPB_STOMP_TIMEOUT_US")) { const long long us = atoll(e); if (us > 0) timeout = 100ull * (unsigned long long)us; }
+    if (f.hx)
+        return mpb_fused_hx_launch(means, eps, samples, costs, weights, L, Sigma, geom, geom_flags, workspace, P, S, H, d, f.nc, f.nb,
+                                   k_sigma, weight, lr, temperature, n_iters, lo, hi, iter0, particle_offset, tag0, timeout, status_dev,
+                                   means_copy, st);
     const dim3 grid(f.two_batches ? P : P * f.nc), block(FUSED_THREADS);
     const int nc_k = f.two_batches ? 1 : f.nc;
     const int model = geom_flags & 0xFF;

@@ -1,0 +1,524 @@
+// mpb_stomp_fused_hx.hip -- the persistent one-launch STOMP loop (stomp.py:150-160) for the shapes the H = 64 kernel of
+// mpb_stomp_fused.hip does not serve: any horizon up to 128 support points, any channel count d <= 16, any number of
+// samples per particle up to 128.  Same idea -- a workgroup of 16 waves owns (particle, chunk of its samples) for all
+// iterations, constants / means / the iteration's samples stay in LDS, the workgroups of a particle exchange per-chunk
+// softmax partials as tagged granules, paired by start-order tickets (mpb_stomp_fused.h) -- generalised along three axes:
+//   * horizon: a rollout is cut in HC = ceil(H / 64) chunks of 64 waypoints and a WAVE owns one chunk of one rollout
+//     (lane = waypoint of the chunk), so every per-wave phase is that of the H = 64 kernel; the noise of chunk hc is
+//     sum_{kc <= hc} L[hc][kc] eps[kc], block by block on the matrix cores (the blocks of the lower-triangular scale_tril
+//     sit in LDS as permuted images), and a wave of chunk hc draws eps[0..hc] itself (counter-based: no exchange);
+//     chunks are dealt to the waves so that every SIMD holds as many first as second chunks;
+//   * samples: a workgroup runs its RB = 16 / HC rollouts per pass, `nb` passes ("batches") per iteration, and folds each
+//     batch into a RUNNING softmax partial (m, z, sum e (x - mu)) -- the streaming form of the same algebra, any nb;
+//   * channels: d is a run-time value (DCH = 0) or a template constant (the Panda's 7 / 14).
+// The noise product is issued TRANSPOSED (A = eps, B = L^T image: D[channel][waypoint]) and brought to lane = waypoint
+// with v_permlane32_swap / v_permlane16_swap (a 4 x 4 block transpose across the four 16-lane rows) -- no LDS round trip;
+// the update  mean += lr * Sigma @ delta  runs on the matrix cores too (Sigma rows streamed from L2: a 128 x 128 Sigma
+// does not fit in LDS next to the tiles).  Results equal the two-kernel path (mpb_stomp_step) to rounding: samples and costs
+// of a 64-waypoint horizon bit for bit, weights / means within 1e-6 (tests/test_gpu_stomp_fused_hx.py).
+#include <hip/hip_runtime.h>
+
+#include <stdlib.h>
+
+#include "mpb_common.h"
+#include "mpb_geom.h"
+#include "mpb_stomp_noise.h"
+#include "mpb_stomp_fused.h"
+
+#define HX_XCHG 2064                       // granules per published partial: m, z, then H*d <= 2048 values, padded
+#define HX_MAX_NB 8
+
+static inline size_t hx_ws_floats(int P, int nc) { return 16 + 2 * 2 * (size_t)P * nc * HX_XCHG; }
+
+// acc[n] (lane (j, g): D[channel 4g + rr][waypoint 16 n + j]) -> nz[c] of THIS lane's waypoint (lane = 16 g + j): a 4 x 4
+// block transpose over the four 16-lane rows, per accumulator register rr
+__device__ __forceinline__ void hx_transpose_to_rows(const f32x4 (&acc)[4], float (&nz)[16]) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        unsigned x0 = __float_as_uint(acc[0][rr]), x1 = __float_as_uint(acc[1][rr]), x2 = __float_as_uint(acc[2][rr]),
+                 x3 = __float_as_uint(acc[3][rr]);
+        // stage 1: rows {2,3} of x0 / x1 <-> rows {0,1} of x2 / x3
+        auto a = __builtin_amdgcn_permlane32_swap(x0, x2, false, false);
+        auto b = __builtin_amdgcn_permlane32_swap(x1, x3, false, false);
+        // stage 2: odd rows of the first <-> even rows of the second
+        auto lo = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+        auto hi = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+        nz[0 + rr] = __uint_as_float(lo[0]);
+        nz[4 + rr] = __uint_as_float(lo[1]);
+        nz[8 + rr] = __uint_as_float(hi[0]);
+        nz[12 + rr] = __uint_as_float(hi[1]);
+    }
+}
+
+template <int DCH, int MODEL, int HC>
+__global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
+    float* __restrict__ means, const float* __restrict__ eps, float* __restrict__ samples, float* __restrict__ costs,
+    float* __restrict__ weights, const float* __restrict__ Lmat, const float* __restrict__ Sigma,
+    const float* __restrict__ geom, float* __restrict__ ws, int P, int S, int H, int d_rt, int nc, int nb, float k_sigma,
+    float weight, float lr, float temperature, int n_iters, uint32_t seed_lo, uint32_t seed_hi, uint32_t iter0,
+    uint32_t particle_offset, uint32_t tag0, unsigned long long timeout_ticks, unsigned* __restrict__ status_host,
+    float* __restrict__ means_copy) {
+    constexpr int DX = DCH ? DCH : 16;                 // channels held in registers / tile rows
+    constexpr int RB = FUSED_WAVES / HC;               // rollouts per pass
+    constexpr int HP = 64 * HC;                        // padded horizon
+    constexpr int NLB = HC * (HC + 1) / 2;             // 64 x 64 blocks of the lower triangle of L
+    constexpr int EPT = (HP * DX + FUSED_THREADS - 1) / FUSED_THREADS;   // trajectory elements per thread
+    constexpr int DLD = HP + 4;                        // row (floats) of the transposed delta tile
+    constexpr int TILE = 64 * DX;                      // floats of a wave's tile: its chunk of one rollout, rows packed
+    static_assert(HC == 1 || HC == 2, "horizons up to 128 support points");
+    static_assert(HP * DX + 2 <= HX_XCHG, "exchange slot too small");
+    __shared__ __attribute__((aligned(16))) float Lp[NLB * 4096];
+    __shared__ __attribute__((aligned(16))) float tiles[FUSED_WAVES * TILE];
+    __shared__ __attribute__((aligned(16))) unsigned gridw[MPB_GRID_MAX_CELLS];
+    __shared__ float4 otab[MPB_GRID_MAX_SPH + 1];
+    __shared__ __attribute__((aligned(16))) float mean_l[HP * DX];
+    __shared__ __attribute__((aligned(16))) float delta[16 * DLD];
+    __shared__ float cst[FUSED_WAVES];
+    __shared__ float ewl[HX_MAX_NB * FUSED_WAVES];     // exp(logit - batch max) of the unit's samples
+    __shared__ float mbl[HX_MAX_NB];                   // the batches' maxima
+    __shared__ int s_abort;
+    __shared__ unsigned s_ticket;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int d = DCH ? DCH : d_rt;
+    const int N = H * d;
+    unsigned* wsu = reinterpret_cast<unsigned*>(ws);
+    granule_t* xch = reinterpret_cast<granule_t*>(ws + 16);
+    const bool exchange = nc > 1;
+    if (tid == 0) {
+        s_abort = 0;
+        unsigned u = blockIdx.x;
+        if (exchange) {
+            int why;
+            u = fused_draw_unit(wsu, P, nc, tag0, why);
+            s_abort = why;
+        }
+        s_ticket = u;
+    }
+    // this wave's rollout slot and horizon chunk: with two chunks the waves of a SIMD (w, w + 4, w + 8, w + 12) hold two of each
+    const int hcw = (HC == 1) ? 0 : ((wave >> 2) & 1);
+    const int rw = (HC == 1) ? wave : ((wave & 3) | ((wave >> 3) << 2));
+    auto wave_of = [](int r, int hc) { return (HC == 1) ? r : ((r & 3) | (hc << 2) | ((r >> 2) << 3)); };
+    const int j = lane & 15, g = lane >> 4;
+
+    // ---- constants into LDS (once): the broad-phase grid + obstacle table, the blocks of L as permuted MFMA images
+    GeomView G0 = geom_view(geom);
+    grid_stage(G0, gridw, otab, tid, FUSED_THREADS);
+#pragma unroll
+    for (int b = 0; b < NLB; ++b) {
+        const int hc = (b == 0) ? 0 : 1, kc = (b == 2) ? 1 : 0;
+        for (int v = tid; v < 4096; v += FUSED_THREADS) {
+            const int row = v >> 6, col = v & 63;
+            const int gr = 64 * hc + row, gc = 64 * kc + col;
+            Lp[b * 4096 + stomp_l_image_index(row, col)] = (gr < H && gc < H) ? Lmat[(size_t)gr * H + gc] : 0.f;
+        }
+    }
+    for (int i = tid; i < 16 * DLD; i += FUSED_THREADS) delta[i] = 0.f;        // (padding rows / columns stay zero)
+    __syncthreads();
+    const int unit = __builtin_amdgcn_readfirstlane((int)s_ticket);
+    const int p = exchange ? unit / nc : unit;
+    const int chunk = exchange ? unit - p * nc : 0;
+    for (int e = tid; e < N; e += FUSED_THREADS) mean_l[e] = means[(size_t)p * N + e];
+    if (unit == 0 && tid == 0) st_agent_u(wsu + FUSED_HDR_TAG, tag0);
+    __syncthreads();
+    const int n_run = s_abort ? 0 : n_iters;
+
+    float* nt = tiles + wave * TILE;
+    const size_t eps_stride = (size_t)S * d * P * H;
+    const f32x4* Lp4 = reinterpret_cast<const f32x4*>(Lp);
+
+    // the noise rows of (iteration it_n, sample s_n) for this wave's chunk, parked in the wave's tile (rows packed, stride d).
+    // Block-uniform call sites only (two chunks: one workgroup barrier inside).
+    auto draw_noise = [&](int it_n, int s_n) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int jv = j, gv = g;
+        asm volatile("" : "+v"(jv), "+v"(gv));
+        // B... the eps columns of chunk kc as MFMA operand: e[ks] = eps[c = j][k = 64 kc + 4 ks + g]
+        auto operand = [&](int kc, float (&e)[16]) {
+            if (eps != nullptr) {
+                const float* ep = eps + (size_t)it_n * eps_stride + (((size_t)(s_n < S ? s_n : 0) * d + (jv < d ? jv : 0)) * P + p) * H;
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+                    const int k = 64 * kc + 4 * ks + gv;
+                    e[ks] = (jv < d && k < H) ? ep[k] : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    float n[4] = {0.f, 0.f, 0.f, 0.f};
+                    stomp_setprio(3 - q4);
+                    if (jv < d)
+                        stomp_eps4(particle_offset + (uint32_t)p, (uint32_t)s_n, (uint32_t)jv, (uint32_t)gv,
+                                   (uint32_t)(kc << 4) | (uint32_t)q4, iter0 + (uint32_t)it_n, seed_lo, seed_hi, n);
+                    e[4 * q4 + 0] = n[0]; e[4 * q4 + 1] = n[1]; e[4 * q4 + 2] = n[2]; e[4 * q4 + 3] = n[3];
+                }
+            }
+        };
+        auto product = [&](int b, bool diagonal, const float (&e)[16]) {      // acc += (block b of L) * e, transposed
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+#pragma unroll
+                for (int ks4 = 0; ks4 < 4; ++ks4) {
+                    if (diagonal && ks4 > m) continue;                      // upper triangle of a diagonal block
+                    const f32x4 a = Lp4[b * 1024 + ((m * 4 + ks4) * 4 + g) * 16 + j];
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(e[4 * ks4 + 0], a[0], acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(e[4 * ks4 + 1], a[1], acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(e[4 * ks4 + 2], a[2], acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(e[4 * ks4 + 3], a[3], acc[m], 0, 0, 0);
+                }
+            }
+        };
+        float e[16];
+        operand(hcw, e);                                   // every wave draws the columns of ITS chunk
+        if (HC == 1) {
+            product(0, true, e);
+        } else {
+            // the second-chunk wave of a rollout also needs the first chunk's columns: its partner has just drawn them and
+            // hands them over through the (free) tile of the second-chunk wave instead of both drawing them (device
+            // noise only; injected noise is simply loaded twice)
+            const bool share = eps == nullptr;
+            float* hand = tiles + wave_of(rw, 1) * TILE + (g * d + (j < d ? j : 0)) * 16;    // 4 d lanes x 16 floats = the tile
+            if (share && hcw == 0 && j < d) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) reinterpret_cast<f32x4*>(hand)[v] = f32x4{e[4 * v], e[4 * v + 1], e[4 * v + 2], e[4 * v + 3]};
+            }
+            if (share) __syncthreads();
+            if (hcw == 0) {
+                product(0, true, e);
+            } else {
+                float e0[16];
+                if (share) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const f32x4 t = (j < d) ? reinterpret_cast<const f32x4*>(hand)[v] : f32x4{0.f, 0.f, 0.f, 0.f};
+                        e0[4 * v] = t[0]; e0[4 * v + 1] = t[1]; e0[4 * v + 2] = t[2]; e0[4 * v + 3] = t[3];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                } else {
+                    operand(0, e0);
+                }
+                product(1, false, e0);                     // same accumulation order as the two-kernel path: kc = 0, then 1
+                product(2, true, e);
+            }
+        }
+        float nz[16];
+        hx_transpose_to_rows(acc, nz);
+        if (DCH != 0 && (DCH % 2) == 0) {
+#pragma unroll
+            for (int c = 0; c < DX; c += 2) *reinterpret_cast<float2*>(nt + lane * DX + c) = make_float2(nz[c], nz[c + 1]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < DX; ++c)
+                if (c < d) nt[lane * d + c] = nz[c];
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    if (n_run > 0) draw_noise(0, (chunk * nb) * RB + rw);
+
+    for (int it = 0; it < n_run; ++it) {
+        float m_run = -3.0e38f, z_run = 0.f, d_run[EPT];
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) d_run[u] = 0.f;
+#pragma nounroll
+        for (int bt = 0; bt < nb; ++bt) {
+            const int s = (chunk * nb + bt) * RB + rw;                       // this wave's sample in this batch
+            const bool live = s < S;
+            // ============ A. samples: x = mean + noise (zero at both ends, stomp.py:105-106), stored, kept packed in the tile
+            const int h = 64 * hcw + lane;
+            const bool on = h < H;
+            const bool edge = (h == 0) || (h == H - 1);
+            float x[DX];
+            if (DCH != 0 && (DCH % 2) == 0) {
+#pragma unroll
+                for (int c = 0; c < DX; c += 2) {
+                    const float2 nv = *reinterpret_cast<const float2*>(nt + lane * DX + c);
+                    const float2 mv = *reinterpret_cast<const float2*>(mean_l + (on ? h : 0) * DX + c);
+                    x[c] = mv.x + (edge ? 0.f : nv.x);
+                    x[c + 1] = mv.y + (edge ? 0.f : nv.y);
+                }
+#pragma unroll
+                for (int c = 0; c < DX; c += 2) *reinterpret_cast<float2*>(nt + lane * DX + c) = make_float2(x[c], x[c + 1]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < DX; ++c) x[c] = (c < d) ? mean_l[(on ? h : 0) * d + c] + (edge ? 0.f : nt[lane * d + c]) : 0.f;
+#pragma unroll
+                for (int c = 0; c < DX; ++c)
+                    if (c < d) nt[lane * d + c] = x[c];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (live) {
+                float* sbase = samples + (((size_t)p * S + s) * H + 64 * hcw) * d;       // uniform
+                const int nfl = min(H - 64 * hcw, 64) * d;                              // floats of this chunk (<= 0: none)
+                if (((H * d) & 3) == 0 && ((64 * d) & 3) == 0) {
+                    const f32x4* pk4 = reinterpret_cast<const f32x4*>(nt);
+                    f32x4* out4 = reinterpret_cast<f32x4*>(sbase);
+                    for (int idx = lane; 4 * idx < nfl; idx += 64) out4[idx] = pk4[idx];
+                } else {
+                    for (int idx = lane; idx < nfl; idx += 64) sbase[idx] = nt[idx];
+                }
+            }
+            // ============ B. collision cost of this chunk of the rollout
+            {
+                float q[MPB_MAX_DOF];
+#pragma unroll
+                for (int i = 0; i < MPB_MAX_DOF; ++i) q[i] = (i < DX) ? x[i < DX ? i : 0] : 0.f;
+                float c = 0.f;
+                bool bad = false;
+                GeomView G = G0;
+                for (const float* gp = geom;;) {
+                    if (gp != geom) {     // a chained field: its grid replaces the first one's (restored before the next pass)
+                        __syncthreads();
+                        grid_stage(G, gridw, otab, tid, FUSED_THREADS);
+                        __syncthreads();
+                    }
+                    if (live && on && h >= 1) {
+                        if (MODEL == PandaModel::ID) {
+                            if (G.model == PandaModel::ID) c = fmaf(G.fscale, waypoint_cost_grid_model<PandaModel>(G, gridw, otab, q), c);
+                            else bad = true;
+                        } else {
+                            c = fmaf(G.fscale, waypoint_cost_grid(G, gridw, otab, q), c);
+                        }
+                    }
+                    if (G.next == 0) break;
+                    gp += G.next;
+                    G = geom_view(gp);
+                }
+                if (G0.next != 0) {
+                    __syncthreads();
+                    grid_stage(G0, gridw, otab, tid, FUSED_THREADS);
+                }
+                const double csum = wave_sum_f64((double)c);
+                if (lane == 0) cst[wave] = bad ? __uint_as_float(0x7FC00000u) : (float)csum;
+            }
+            __syncthreads();                                                                    // (1) costs of the pass
+            // ============ C. fold this batch into the running partial: logits, batch max, e_w, z, weighted (sample - mean)
+            int tq = tid;
+            asm volatile("" : "+v"(tq));
+            const int lq = tq & 63;
+            const int rq = lq % RB;                                       // lanes 0..RB-1 carry the rollouts (every wave redundantly)
+            const float c0 = cst[wave_of(rq, 0)], c1 = (HC == 2) ? cst[wave_of(rq, 1)] : 0.f;
+            const bool poisoned = __float_as_uint(c0) == 0x7FC00000u;     // (geometry / kernel mismatch: see mpb_geom_flags)
+            const float cw = weight * (k_sigma * (poisoned ? 0.f : c0 + c1));
+            const int sl = (chunk * nb + bt) * RB + rq;
+            const bool carries = lq < RB && sl < S;
+            if (tq < RB && sl < S) reinterpret_cast<unsigned*>(costs)[(size_t)p * S + sl] = poisoned ? 0x7FC00000u : __float_as_uint(cw);
+            const float xs = carries ? -cw / temperature : -3.0e38f;
+            const float mb = wave_max_f32(xs);
+            const float ex = carries ? expf(xs - mb) : 0.f;
+            const float zb = wave_sum_f32(ex);
+            if (tq < RB) ewl[bt * RB + tq] = ex;
+            if (tq == 0) mbl[bt] = mb;
+            const float m_new = fmaxf(m_run, mb);
+            const float f_old = expf(m_run - m_new), f_b = expf(mb - m_new);
+            z_run = fmaf(zb, f_b, z_run * f_old);
+            m_run = m_new;
+#pragma unroll
+            for (int u = 0; u < EPT; ++u) {
+                const int e = tq + FUSED_THREADS * u;
+                if (e < N) {
+                    const int hc_e = (HC == 1) ? 0 : (e >= 64 * d ? 1 : 0);
+                    const int off = e - 64 * d * hc_e;                  // rows of a tile are packed with stride d
+                    const float mu = mean_l[e];
+                    float dp = 0.f;
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) {
+                        const float ew = readlane_f32(ex, r);
+                        dp = fmaf(ew, tiles[wave_of(r, hc_e) * TILE + off] - mu, dp);
+                    }
+                    d_run[u] = fmaf(dp, f_b, d_run[u] * f_old);
+                }
+            }
+            __syncthreads();                                                     // (2) the samples in the tiles are consumed
+            // ============ the noise of the next pass (next batch, or the first batch of the next iteration): independent of
+            //              the means, so it is drawn here, ahead of the exchange
+            const bool more = bt + 1 < nb;
+            const int it_n = more ? it : it + 1;
+            if (it_n < n_run) draw_noise(it_n, (chunk * nb + (more ? bt + 1 : 0)) * RB + rw);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+        // ============ D. exchange: publish this unit's partial, wait for the partners', combine in chunk order
+        float m_all = m_run, z_all = z_run, dsum[EPT];
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) dsum[u] = d_run[u];
+        const unsigned tag = tag0 + (unsigned)it;
+        if (exchange) {
+            granule_t* mine = xch + ((size_t)(it & 1) * P * nc + (size_t)p * nc + chunk) * HX_XCHG;
+#pragma unroll
+            for (int u = 0; u < EPT; ++u) {
+                const int e = tq + FUSED_THREADS * u;
+                if (e < N) st_granule(mine + 2 + e, d_run[u], tag);
+            }
+            if (tq == 0) { st_granule(mine + 0, m_run, tag); st_granule(mine + 1, z_run, tag); }
+            float mk[FUSED_MAX_CHUNKS], zk[FUSED_MAX_CHUNKS], dk[FUSED_MAX_CHUNKS][EPT];
+            const granule_t* slot0 = xch + ((size_t)(it & 1) * P * nc + (size_t)p * nc) * HX_XCHG;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < FUSED_MAX_CHUNKS; ++k) {
+                    mk[k] = -3.0e38f; zk[k] = 0.f;
+#pragma unroll
+                    for (int u = 0; u < EPT; ++u) dk[k][u] = 0.f;
+                    if (k < nc) {
+                        const granule_t* theirs = slot0 + (size_t)k * HX_XCHG;
+                        const granule_t gm = ld_granule(theirs + 0), gz = ld_granule(theirs + 1);
+                        ok = ok && (unsigned)(gm >> 32) == tag && (unsigned)(gz >> 32) == tag;
+                        mk[k] = __uint_as_float((unsigned)gm);
+                        zk[k] = __uint_as_float((unsigned)gz);
+#pragma unroll
+                        for (int u = 0; u < EPT; ++u) {
+                            const int e = tq + FUSED_THREADS * u;
+                            if (e < N) {
+                                const granule_t gd = ld_granule(theirs + 2 + e);
+                                ok = ok && (unsigned)(gd >> 32) == tag;
+                                dk[k][u] = __uint_as_float((unsigned)gd);
+                            }
+                        }
+                    }
+                }
+                if (ok) break;
+                __builtin_amdgcn_s_sleep(2);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) { s_abort = 1; break; }
+            }
+            m_all = mk[0];
+#pragma unroll
+            for (int k = 1; k < FUSED_MAX_CHUNKS; ++k) m_all = fmaxf(m_all, mk[k]);
+            z_all = 0.f;
+#pragma unroll
+            for (int u = 0; u < EPT; ++u) dsum[u] = 0.f;
+#pragma unroll
+            for (int k = 0; k < FUSED_MAX_CHUNKS; ++k) {
+                if (k < nc) {
+                    const float f = expf(mk[k] - m_all);
+                    z_all = fmaf(f, zk[k], z_all);
+#pragma unroll
+                    for (int u = 0; u < EPT; ++u) dsum[u] = fmaf(f, dk[k][u], dsum[u]);
+                }
+            }
+        }
+        // ============ E. weights out, delta (transposed) -> mean += lr * Sigma @ delta on the matrix cores
+        for (int i = tq; i < nb * RB; i += FUSED_THREADS) {
+            const int sl = chunk * nb * RB + i;
+            if (sl < S) weights[(size_t)p * S + sl] = ewl[i] * expf(mbl[i / RB] - m_all) / z_all;
+        }
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+            const int e = tq + FUSED_THREADS * u;
+            if (e < N) {
+                const int hh = e / d, cc = e - hh * d;
+                delta[cc * DLD + hh] = dsum[u] / z_all;
+            }
+        }
+        __syncthreads();                                                                        // (3) delta complete
+        if (s_abort) break;                                                                     // block-uniform (set before barrier 3)
+        // the rows of Sigma this wave's 16-row tile needs, all fetched up front (from L2: every workgroup reads the same
+        // H x H matrix every iteration).  (Fetched ahead of the exchange instead, so that the latency would run under the
+        // poll, the 32 registers spill: 232 B / lane of scratch.)
+        f32x4 sig_a[HP / 16];
+        if (wave < HP / 16) {
+            const int row = 16 * wave + j;
+            const bool vec = (H & 3) == 0;
+#pragma unroll
+            for (int ks4 = 0; ks4 < HP / 16; ++ks4) {
+                const int k0 = 16 * ks4 + 4 * g;
+                f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (row < H) {
+                    if (vec) {
+                        if (k0 < H) a = *reinterpret_cast<const f32x4*>(Sigma + (size_t)row * H + k0);
+                    } else {
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk)
+                            if (k0 + kk < H) a[kk] = Sigma[(size_t)row * H + k0 + kk];
+                    }
+                }
+                sig_a[ks4] = a;
+            }
+        }
+        if (wave < HP / 16) {
+            // row tile `wave` of Sigma @ delta: A = Sigma[16 w + i][k], B = delta[k][c = j];
+            // both operands deliver the k-set {16 ks4 + 4 g + kk} per step (any order of k is the same sum up to rounding)
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks4 = 0; ks4 < HP / 16; ++ks4) {
+                const f32x4 a = sig_a[ks4];
+                const f32x4 b = *reinterpret_cast<const f32x4*>(delta + j * DLD + 16 * ks4 + 4 * g);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int hh = 16 * wave + 4 * g + rr;
+                if (hh < H && j < d) mean_l[hh * d + j] += lr * acc[rr];
+            }
+        }
+        __syncthreads();                                                                        // (4) new mean visible, tiles free
+    }
+    const int aborted = s_abort;
+    if (!aborted && chunk == 0) {
+        for (int e = tid; e < N; e += FUSED_THREADS) {
+            const float m = mean_l[e];
+            means[(size_t)p * N + e] = m;
+            if (means_copy) means_copy[(size_t)p * N + e] = m;
+        }
+    }
+    if (aborted == 1 && chunk == 0 && means_copy)
+        for (int e = tid; e < N; e += FUSED_THREADS) means_copy[(size_t)p * N + e] = means[(size_t)p * N + e];
+    if (tid == 0) fused_leave(wsu, status_host, tag0, aborted);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launcher (called by mpb_stomp_run_checked, mpb_stomp_fused.hip)
+// ------------------------------------------------------------------------------------------------
+// can this kernel serve the shape, and with which split of the S samples over workgroups (nc) and passes (nb)?
+bool mpb_fused_hx_plan(int geom_flags, int n_cu, int P, int S, int H, int d, int* nc_out, int* nb_out, size_t* ws_bytes) {
+    if (P < 1 || S < 1 || S > 128 || H < 3 || H > 128 || d < 1 || d > 16 || !(geom_flags & 0x100)) return false;
+    const int HC = H > 64 ? 2 : 1, RB = FUSED_WAVES / HC;
+    const int passes = (S + RB - 1) / RB;                 // passes of RB rollouts a particle needs per iteration
+    // few particles: as many workgroups per particle as fit the chip in one round (and the exchange allows); many
+    // particles: one workgroup per particle running every pass itself (no exchange)
+    int nc = n_cu / P;
+    if (nc > FUSED_MAX_CHUNKS) nc = FUSED_MAX_CHUNKS;
+    if (nc > passes) nc = passes;
+    if (nc < 1) nc = 1;
+    int nb = (passes + nc - 1) / nc;
+    if (nb > HX_MAX_NB) {                                  // more passes than a workgroup may run: more workgroups
+        nc = (passes + HX_MAX_NB - 1) / HX_MAX_NB;
+        if (nc > FUSED_MAX_CHUNKS) return false;
+        nb = (passes + nc - 1) / nc;
+    }
+    *nc_out = nc;
+    *nb_out = nb;
+    *ws_bytes = (nc > 1 ? hx_ws_floats(P, nc) : 16) * sizeof(float);
+    return true;
+}
+
+int mpb_fused_hx_launch(float* means, const float* eps, float* samples, float* costs, float* weights, const float* L,
+                        const float* Sigma, const float* geom, int geom_flags, float* workspace, int P, int S, int H, int d, int nc,
+                        int nb, float k_sigma, float weight, float lr, float temperature, int n_iters, uint32_t lo, uint32_t hi,
+                        uint32_t iter0, uint32_t particle_offset, uint32_t tag0, unsigned long long timeout, unsigned* status_dev,
+                        float* means_copy, hipStream_t st) {
+    const dim3 grid(P * nc), block(FUSED_THREADS);
+    const int model = geom_flags & 0xFF;
+#define MPB_HX_LAUNCH(DCH, MODEL, HC)                                                                                          \
+    hipLaunchKernelGGL((stomp_fused_hx_kernel<DCH, MODEL, HC>), grid, block, 0, st, means, eps, samples, costs, weights, L,   \
+                       Sigma, geom, workspace, P, S, H, d, nc, nb, k_sigma, weight, lr, temperature, n_iters, lo, hi, iter0,    \
+                       particle_offset, tag0, timeout, status_dev, means_copy)
+    if (H > 64) {
+        if (model == PandaModel::ID && d == 7) MPB_HX_LAUNCH(7, PandaModel::ID, 2);
+        else if (model == PandaModel::ID && d == 14) MPB_HX_LAUNCH(14, PandaModel::ID, 2);
+        else MPB_HX_LAUNCH(0, 0, 2);
+    } else {
+        if (model == PandaModel::ID && d == 7) MPB_HX_LAUNCH(7, PandaModel::ID, 1);
+        else if (model == PandaModel::ID && d == 14) MPB_HX_LAUNCH(14, PandaModel::ID, 1);
+        else MPB_HX_LAUNCH(0, 0, 1);
+    }
+#undef MPB_HX_LAUNCH
+    return mpb_check_launch("mpb_stomp_run");
+}

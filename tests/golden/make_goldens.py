@@ -417,6 +417,9 @@ def main():
               pos_only=False, iters=1, seed=8, temperature=1.0, sigma_spectral=0.5)
     gen_stomp('stomp_panda_h32_s64', panda, sph3, q[0], q[1], P=2, S=64, H=32, dt=5 / 32, sigma_coll=1.0,
               pos_only=True, iters=2, seed=9, temperature=1.0, sigma_spectral=0.1)
+    # H = 128 (two 64-waypoint chunks per rollout), S = 32, d = 14: the shape of BASELINE config 4's horizon on STOMP
+    gen_stomp('stomp_panda_h128_s32', panda, sph3, q[0], q[1], P=1, S=32, H=128, dt=5 / 128, sigma_coll=1.0,
+              pos_only=False, iters=2, seed=10, temperature=1.0, sigma_spectral=0.5)
 
     # CHOMP: dense 2-D with boxes (C2 parameters), Panda
     gs = torch.Generator().manual_seed(7)

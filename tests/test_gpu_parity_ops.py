@@ -87,7 +87,8 @@ STOMP_CASES = ['stomp_pm2d_stiff', 'stomp_pm2d_benign', 'stomp_pm2d_c1', 'stomp_
                'stomp_panda_benign', 'stomp_panda_t1', 'stomp_pm2d_h48',
                'stomp_panda_s32',       # C3's S = 32: every register slot of the update kernel in use
                'stomp_panda_s64',       # S = 64: the update kernel's tail loop
-               'stomp_panda_h32_s64']   # H*d = 224: partial last worker wave in the update kernel, chunked sampler
+               'stomp_panda_h32_s64',   # H*d = 224: partial last worker wave in the update kernel, chunked sampler
+               'stomp_panda_h128_s32']  # H = 128: two horizon chunks per rollout (persistent: mpb_stomp_fused_hx.hip)
 
 
 def reference_fp32_envelope(g):

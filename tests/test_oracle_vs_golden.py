@@ -12,7 +12,7 @@ T = torch.from_numpy
 
 STOMP_CASES = ['stomp_pm2d_stiff', 'stomp_pm2d_benign', 'stomp_pm2d_c1', 'stomp_panda_stiff',
                'stomp_panda_benign', 'stomp_panda_t1', 'stomp_pm2d_h48', 'stomp_panda_s32', 'stomp_panda_s64',
-               'stomp_panda_h32_s64']
+               'stomp_panda_h32_s64', 'stomp_panda_h128_s32']
 
 
 @pytest.mark.parametrize('name', STOMP_CASES)
