@@ -65,10 +65,12 @@ int mpb_geom_flags(const float *geom_host, int n_words, int *flags);
  * mpb_cost_collision_grad additionally writes grad (B,H,d) = d out[b] / d trajs[b] (the quantity the
  * reference obtains by autograd: chomp.py:139, field_factor.py:54); velocity channels get 0.
  * per_waypoint (B,H) optional (may be NULL): un-scaled field cost of every waypoint (0 for h < h_begin).
+ * geom_flags = mpb_geom_flags(host copy of geom) lets the gradient evaluators pick the compile-time robot model's kernel
+ * (same bits as the table-driven walk, fewer instructions and registers); 0 is always valid (table-driven walk).
  * ------------------------------------------------------------------------------------------- */
 int mpb_cost_collision_eval(const float *trajs, const float *geom, float *out, float *per_waypoint,
                             int B, int H, int d, int h_begin, float k_sigma, float weight, void *stream);
-int mpb_cost_collision_grad(const float *trajs, const float *geom, float *out, float *grad,
+int mpb_cost_collision_grad(const float *trajs, const float *geom, int geom_flags, float *out, float *grad,
                             int B, int H, int d, int h_begin, float k_sigma, float weight, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -308,15 +310,15 @@ int mpb_chomp_step(float *means, const float *R, const float *geom, int geom_fla
  * (h_t, c_t) set per field and the solve sums their rank-1 terms.
  * ------------------------------------------------------------------------------------------- */
 size_t mpb_gpmp2_workspace_bytes(int B, int H, int D);
-int mpb_gpmp2_linearize(const float *x, const float *geom, void *workspace, int B, int H, int D, int n_interp,
-                        void *stream);
+int mpb_gpmp2_linearize(const float *x, const float *geom, int geom_flags, void *workspace, int B, int H, int D,
+                        int n_interp, void *stream);
 int mpb_gpmp2_diag(void *workspace, double *diag_sum_out, int B, int H, int D, int n_fields, float dt,
                    float sigma_start, float sigma_gp, float sigma_goal, float sigma_coll, void *stream);
 int mpb_gpmp2_solve(float *x, const float *start, const float *goal, const double *diag_mean, void *workspace,
                     float *costs_out, int B, int H, int D, int n_fields, float dt,
                     float sigma_start, float sigma_gp, float sigma_goal, float sigma_coll,
                     float delta, int trust_region, float step_size, void *stream);
-int mpb_gpmp2_step(float *x, const float *start, const float *goal, const float *geom, void *workspace,
+int mpb_gpmp2_step(float *x, const float *start, const float *goal, const float *geom, int geom_flags, void *workspace,
                    float *costs_out, int B, int H, int D, float dt,
                    float sigma_start, float sigma_gp, float sigma_goal, float sigma_coll,
                    float delta, int trust_region, float step_size, int n_iters, int n_interp, int n_fields,

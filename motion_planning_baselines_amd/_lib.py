@@ -24,7 +24,7 @@ SIGNATURES = {
     'mpb_geom_check': [_p, _i],
     'mpb_geom_flags': [_p, _i, _p],
     'mpb_cost_collision_eval': [_p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
-    'mpb_cost_collision_grad': [_p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
+    'mpb_cost_collision_grad': [_p, _p, _i, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     'mpb_cost_terms_eval': [_p] * 7 + [_i] * 5 + [_u32] + [_f] * 7 + [_i, _i, _p],
     'mpb_cost_terms_grad': [_p] * 8 + [_i] * 5 + [_u32] + [_f] * 11 + [_i, _p],
     'mpb_traj_resample': [_p, _p, _p, _i, _i, _i, _i, _f, _p],
@@ -50,10 +50,10 @@ SIGNATURES = {
     'mpb_stomp_update': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     'mpb_chomp_step': [_p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _p],
     'mpb_gpmp2_workspace_bytes': [_i, _i, _i],
-    'mpb_gpmp2_linearize': [_p, _p, _p, _i, _i, _i, _i, _p],
+    'mpb_gpmp2_linearize': [_p, _p, _i, _p, _i, _i, _i, _i, _p],
     'mpb_gpmp2_diag': [_p, _p, _i, _i, _i, _i, _f, _f, _f, _f, _f, _p],
     'mpb_gpmp2_solve': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _i, _f, _p],
-    'mpb_gpmp2_step': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _f, _f, _i, _f, _i, _i, _i, _p],
+    'mpb_gpmp2_step': [_p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _f, _f, _f, _f, _f, _f, _i, _f, _i, _i, _i, _p],
     'mpb_stoch_gpmp_costs': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i] + [_f] * 9 + [_p],
     'mpb_stoch_gpmp_step': [_p] * 11 + [_i] * 4 + [_f] * 10 + [_i, _u64, _p],
     'mpb_gp_prior_sample': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _u64, _p],

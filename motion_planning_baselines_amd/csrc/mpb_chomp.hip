@@ -242,6 +242,9 @@ __global__ __launch_bounds__(1024) void chomp_point4_kernel(float* __restrict__ 
 }
 
 // General variant (D > 3): broad-phase grid for the gradient evaluator, specialised loops per evaluator.
+// MODEL != 0: every chained field carries that compile-time robot model and a usable grid (launcher: geom_flags); the
+// tag is re-checked on the device (a mismatch poisons the trajectory with NaNs instead of mis-reading the buffer).
+template <int MODEL>
 __global__ __launch_bounds__(256) void chomp_kernel(float* __restrict__ means, const float* __restrict__ R,
                              const float* __restrict__ geom, float* __restrict__ costs_out, int B_global,
                              int H, int d, int D, float k_sigma, float weight, float w_prior, float lr,
@@ -299,7 +302,16 @@ __global__ __launch_bounds__(256) void chomp_kernel(float* __restrict__ means, c
         } else if constexpr (MODE == 1) {
             // single field through its broad-phase grid (staged once, before the loop)
             if (eval) {
-                cw = G0.fscale * waypoint_cost_grid_grad(G0, gridw, otab, q, dq);
+                if (MODEL == PandaModel::ID) {
+                    cw = (G0.model == PandaModel::ID) ? G0.fscale * waypoint_cost_grid_grad_model<PandaModel>(G0, gridw, otab, q, dq)
+                                                     : __uint_as_float(0x7FC00000u);
+                    if (G0.model != PandaModel::ID) {
+#pragma unroll
+                        for (int i = 0; i < MPB_MAX_DOF; ++i) dq[i] = cw;
+                    }
+                } else {
+                    cw = G0.fscale * waypoint_cost_grid_grad(G0, gridw, otab, q, dq);
+                }
 #pragma unroll
                 for (int i = 0; i < MPB_MAX_DOF; ++i) dq[i] *= G0.fscale;
             }
@@ -312,7 +324,19 @@ __global__ __launch_bounds__(256) void chomp_kernel(float* __restrict__ means, c
                 __syncthreads();
                 if (eval) {
                     float dqf[MPB_MAX_DOF];
-                    cw = fmaf(G.fscale, ug ? waypoint_cost_grid_grad(G, gridw, otab, q, dqf) : waypoint_cost<true>(G, q, dqf), cw);
+                    float cf;
+                    if (MODEL == PandaModel::ID) {
+                        if (ug && G.model == PandaModel::ID) {
+                            cf = waypoint_cost_grid_grad_model<PandaModel>(G, gridw, otab, q, dqf);
+                        } else {
+                            cf = __uint_as_float(0x7FC00000u);
+#pragma unroll
+                            for (int i = 0; i < MPB_MAX_DOF; ++i) dqf[i] = cf;
+                        }
+                    } else {
+                        cf = ug ? waypoint_cost_grid_grad(G, gridw, otab, q, dqf) : waypoint_cost<true>(G, q, dqf);
+                    }
+                    cw = fmaf(G.fscale, cf, cw);
 #pragma unroll
                     for (int i = 0; i < MPB_MAX_DOF; ++i) dq[i] = fmaf(G.fscale, dqf[i], dq[i]);
                 }
@@ -376,8 +400,11 @@ extern "C" int mpb_chomp_step(float* means, const float* R, const float* geom, i
     if (D <= 3)
         hipLaunchKernelGGL(chomp_lean_kernel, dim3(B_local), dim3(threads), (size_t)H * d * 4, (hipStream_t)stream, means,
                            R, geom, costs_out, B_global, H, d, D, k_sigma, weight, w_prior, lr, grad_clip, n_iters);
+    else if ((geom_flags & 0xFF) == PandaModel::ID && (geom_flags & 0x100) && D == PandaModel::N_DOF)
+        hipLaunchKernelGGL(chomp_kernel<PandaModel::ID>, dim3(B_local), dim3(threads), (size_t)H * d * 4, (hipStream_t)stream, means,
+                           R, geom, costs_out, B_global, H, d, D, k_sigma, weight, w_prior, lr, grad_clip, n_iters);
     else
-        hipLaunchKernelGGL(chomp_kernel, dim3(B_local), dim3(threads), (size_t)H * d * 4, (hipStream_t)stream, means,
+        hipLaunchKernelGGL(chomp_kernel<0>, dim3(B_local), dim3(threads), (size_t)H * d * 4, (hipStream_t)stream, means,
                            R, geom, costs_out, B_global, H, d, D, k_sigma, weight, w_prior, lr, grad_clip, n_iters);
     return mpb_check_launch("mpb_chomp_step");
 }

@@ -260,6 +260,17 @@ __device__ __forceinline__ float dot3(float a, float x, float b, float y, float 
     return fmaf(c, z, fmaf(b, y, a * x));
 }
 
+// d cost / d q_j contribution of one collision sphere at x with hinge force f: f . (z_j x (x - p_j)), written out as
+// explicit fma sequences so that the table-driven gradient walk and the compile-time models round alike
+__device__ __forceinline__ float joint_term(float zx, float zy, float zz, float px, float py, float pz, float x, float y,
+                                            float z, float fx, float fy, float fz) {
+    const float ex = x - px, ey = y - py, ez = z - pz;
+    const float cx = fmaf(zy, ez, -(zz * ey));
+    const float cy = fmaf(zz, ex, -(zx * ez));
+    const float cz = fmaf(zx, ey, -(zy * ex));
+    return fmaf(fz, cz, fmaf(fy, cy, fx * cx));
+}
+
 // forward-kinematics state: current frame transform (+ joint axes / origins for the gradient)
 template <bool GRAD>
 struct FKState {
@@ -447,11 +458,8 @@ __device__ __forceinline__ float waypoint_cost(const GeomView& G, const float (&
                         for (int ii = 0; ii < MPB_MAX_DOF; ++ii) {
                             if (ii < fr[i] && ii < G.n_dof) {
                                 // d x / d q_ii = z_ii x (x - p_ii) for every joint upstream of the sphere's frame
-                                const float ex = C.x[i] - F.px[ii], ey = C.y[i] - F.py[ii], ez = C.z[i] - F.pz[ii];
-                                const float cx = F.zy[ii] * ez - F.zz[ii] * ey;
-                                const float cy = F.zz[ii] * ex - F.zx[ii] * ez;
-                                const float cz = F.zx[ii] * ey - F.zy[ii] * ex;
-                                dq[ii] += fx * cx + fy * cy + fz * cz;
+                                dq[ii] += joint_term(F.zx[ii], F.zy[ii], F.zz[ii], F.px[ii], F.py[ii], F.pz[ii], C.x[i], C.y[i],
+                                                     C.z[i], fx, fy, fz);
                             }
                         }
                     }
@@ -946,11 +954,7 @@ __device__ __forceinline__ float waypoint_cost_grid_grad(const GeomView& G, cons
                 for (int ii = 0; ii < MPB_MAX_DOF; ++ii) {
                     if (ii < fr[i] && ii < G.n_dof) {
                         // d x / d q_ii = z_ii x (x - p_ii) for every joint upstream of the sphere's frame
-                        const float ex = x[i] - F.px[ii], ey = y[i] - F.py[ii], ez = z[i] - F.pz[ii];
-                        const float cx = F.zy[ii] * ez - F.zz[ii] * ey;
-                        const float cy = F.zz[ii] * ex - F.zx[ii] * ez;
-                        const float cz = F.zx[ii] * ey - F.zy[ii] * ex;
-                        dq[ii] += fx * cx + fy * cy + fz * cz;
+                        dq[ii] += joint_term(F.zx[ii], F.zy[ii], F.zz[ii], F.px[ii], F.py[ii], F.pz[ii], x[i], y[i], z[i], fx, fy, fz);
                     }
                 }
             }
@@ -960,4 +964,173 @@ __device__ __forceinline__ float waypoint_cost_grid_grad(const GeomView& G, cons
     __builtin_amdgcn_s_setprio(0);
 #endif
     return cost;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Compile-time robot model, GRADIENT path: waypoint_cost_grid_grad with the chain unrolled and the constant transforms /
+// sphere offsets folded (see waypoint_cost_grid_model).  The arithmetic is that of fk_advance<true> /
+// waypoint_cost_grid_grad expression by expression (products with exact 0 / 1 dropped), the hinges and the joint terms are
+// added in the same order -- both walks return the same bits (tests/test_gpu_parity_ops.py).  What the model saves
+// besides the folded arithmetic: no scalar loads on the chain, no `joint < frame` predicates (a sphere's frame is a
+// constant: its joint loop is exactly as long as its chain), no select chains for q_j and for the joint tables.
+// ------------------------------------------------------------------------------------------------
+template <class M>
+struct ModelFKGrad : ModelFK {
+    float zx[M::N_DOF], zy[M::N_DOF], zz[M::N_DOF], px[M::N_DOF], py[M::N_DOF], pz[M::N_DOF];
+};
+
+template <class M, int J>
+__device__ __forceinline__ void model_fk_advance_grad(ModelFKGrad<M>& F, const float (&q)[MPB_MAX_DOF]) {
+    constexpr float p0x = M::TF[J][0], p0y = M::TF[J][1], p0z = M::TF[J][2], p0w = M::TF[J][3];
+    constexpr float p1x = M::TF[J][4], p1y = M::TF[J][5], p1z = M::TF[J][6], p1w = M::TF[J][7];
+    constexpr float p2x = M::TF[J][8], p2y = M::TF[J][9], p2z = M::TF[J][10], p2w = M::TF[J][11];
+    const float ntx = mad3(F.r00, p0w, F.r01, p1w, F.r02, p2w, F.tx);
+    const float nty = mad3(F.r10, p0w, F.r11, p1w, F.r12, p2w, F.ty);
+    const float ntz = mad3(F.r20, p0w, F.r21, p1w, F.r22, p2w, F.tz);
+    F.tx = ntx; F.ty = nty; F.tz = ntz;
+    float a00 = dot3(F.r00, p0x, F.r01, p1x, F.r02, p2x), a01 = dot3(F.r00, p0y, F.r01, p1y, F.r02, p2y),
+          a02 = dot3(F.r00, p0z, F.r01, p1z, F.r02, p2z);
+    float a10 = dot3(F.r10, p0x, F.r11, p1x, F.r12, p2x), a11 = dot3(F.r10, p0y, F.r11, p1y, F.r12, p2y),
+          a12 = dot3(F.r10, p0z, F.r11, p1z, F.r12, p2z);
+    float a20 = dot3(F.r20, p0x, F.r21, p1x, F.r22, p2x), a21 = dot3(F.r20, p0y, F.r21, p1y, F.r22, p2y),
+          a22 = dot3(F.r20, p0z, F.r21, p1z, F.r22, p2z);
+    if constexpr (J < M::N_DOF) {
+        float sn, cs;
+        fast_sincos(q[J], sn, cs);
+        const float n00 = fmaf(a01, sn, a00 * cs), n01 = fmaf(-a00, sn, a01 * cs);
+        const float n10 = fmaf(a11, sn, a10 * cs), n11 = fmaf(-a10, sn, a11 * cs);
+        const float n20 = fmaf(a21, sn, a20 * cs), n21 = fmaf(-a20, sn, a21 * cs);
+        a00 = n00; a01 = n01; a10 = n10; a11 = n11; a20 = n20; a21 = n21;
+        F.zx[J] = a02; F.zy[J] = a12; F.zz[J] = a22;          // joint axis and origin in the base frame
+        F.px[J] = F.tx; F.py[J] = F.ty; F.pz[J] = F.tz;
+    }
+    F.r00 = a00; F.r01 = a01; F.r02 = a02; F.r10 = a10; F.r11 = a11; F.r12 = a12;
+    F.r20 = a20; F.r21 = a21; F.r22 = a22;
+}
+
+// positions of the collision spheres of group GRP (model_group_positions with the gradient state)
+template <class M, int GRP>
+__device__ __forceinline__ bool model_group_positions_grad(ModelFKGrad<M>& F, const float (&q)[MPB_MAX_DOF], unsigned keep,
+                                                           float (&x)[4], float (&y)[4], float (&z)[4], float (&rl)[4]) {
+    constexpr float FAR = 1.0e9f;
+    constexpr int G1 = (M::N_FRAME1 + 3) / 4;
+    constexpr bool first = GRP < G1;
+    constexpr int lo = first ? 4 * GRP : M::N_FRAME1 + 4 * (GRP - G1);
+    constexpr int part_end = first ? M::N_FRAME1 : M::N_LINKS;
+    constexpr int hi = (lo + 4 < part_end) ? lo + 4 : part_end;
+#ifndef MPB_NO_COST_PRIO
+    {
+        constexpr int NG_ = (M::N_FRAME1 + 3) / 4 + (M::N_LINKS - M::N_FRAME1 + 3) / 4;
+        __builtin_amdgcn_s_setprio(MPB_COST_PRIO(NG_ - 1 - GRP));
+    }
+#endif
+    static_for<lo, hi>([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        constexpr int f = M::LINK_FRAME[l];
+        constexpr int fprev = (l == 0) ? 0 : M::LINK_FRAME[l > 0 ? l - 1 : 0];
+        static_for<fprev, f>([&](auto jc) { model_fk_advance_grad<M, decltype(jc)::value>(F, q); });
+        constexpr int slot = l - lo;
+        constexpr float ox = M::LINK[l][0], oy = M::LINK[l][1], oz = M::LINK[l][2], rad = M::LINK[l][3];
+        const float px = mad3(F.r00, ox, F.r01, oy, F.r02, oz, F.tx);
+        const float py = mad3(F.r10, ox, F.r11, oy, F.r12, oz, F.ty);
+        const float pz = mad3(F.r20, ox, F.r21, oy, F.r22, oz, F.tz);
+        if constexpr (first) {
+            const bool on = (keep >> l) & 1u;                // wave-uniform
+            x[slot] = on ? px : FAR; y[slot] = on ? py : FAR; z[slot] = on ? pz : FAR; rl[slot] = on ? rad : 0.f;
+        } else {
+            x[slot] = px; y[slot] = py; z[slot] = pz; rl[slot] = rad;
+        }
+    });
+#pragma unroll
+    for (int i = hi - lo; i < 4; ++i) { x[i] = y[i] = z[i] = FAR; rl[i] = 0.f; }
+    if constexpr (first) {
+        constexpr unsigned gmask = ((hi >= 32) ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+        return (keep & gmask) != 0u;
+    }
+    return true;
+}
+
+// J^T f of the spheres of group GRP: slot i (sphere lo + i, on frame LINK_FRAME) pulls on the joints 0 .. frame - 1
+template <class M, int GRP>
+__device__ __forceinline__ void model_group_jtf(const ModelFKGrad<M>& F, const GeomView& G, const float (&x)[4],
+                                                const float (&y)[4], const float (&z)[4], const float (&rl)[4],
+                                                const float (&best)[4], const float (&vx)[4], const float (&vy)[4],
+                                                const float (&vz)[4], const float (&vn)[4], float& cost,
+                                                float (&dq)[MPB_MAX_DOF]) {
+    constexpr int G1 = (M::N_FRAME1 + 3) / 4;
+    constexpr bool first = GRP < G1;
+    constexpr int lo = first ? 4 * GRP : M::N_FRAME1 + 4 * (GRP - G1);
+    constexpr int part_end = first ? M::N_FRAME1 : M::N_LINKS;
+    constexpr int hi = (lo + 4 < part_end) ? lo + 4 : part_end;
+    static_for<0, 4>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const float h = fmaxf(G.margin + rl[i] - best[i], 0.f);   // parked slots: best = 3e38 -> 0
+        cost += h;
+        if constexpr (lo + i < hi) {
+            constexpr int fr = M::LINK_FRAME[lo + i];
+            constexpr int nj = fr < M::N_DOF ? fr : M::N_DOF;     // joints upstream of the sphere's frame
+            if (__any(h > 0.f)) {
+                const float sc = (h > 0.f) ? -1.0f / vn[i] : 0.f;
+                const float fx = vx[i] * sc, fy = vy[i] * sc, fz = vz[i] * sc;
+                static_for<0, nj>([&](auto jc) {
+                    constexpr int jj = decltype(jc)::value;
+                    dq[jj] += joint_term(F.zx[jj], F.zy[jj], F.zz[jj], F.px[jj], F.py[jj], F.pz[jj], x[i], y[i], z[i], fx, fy, fz);
+                });
+            }
+        }
+    });
+}
+
+template <class M, int... GRPS>
+__device__ __forceinline__ bool model_group_dispatch_grad(int grp, ModelFKGrad<M>& F, const float (&q)[MPB_MAX_DOF], unsigned keep,
+                                                          float (&x)[4], float (&y)[4], float (&z)[4], float (&rl)[4],
+                                                          std::integer_sequence<int, GRPS...>) {
+    bool run = false;
+    ((grp == GRPS ? (void)(run = model_group_positions_grad<M, GRPS>(F, q, keep, x, y, z, rl)) : (void)0), ...);
+    return run;
+}
+template <class M, int... GRPS>
+__device__ __forceinline__ void model_group_dispatch_jtf(int grp, const ModelFKGrad<M>& F, const GeomView& G, const float (&x)[4],
+                                                         const float (&y)[4], const float (&z)[4], const float (&rl)[4],
+                                                         const float (&best)[4], const float (&vx)[4], const float (&vy)[4],
+                                                         const float (&vz)[4], const float (&vn)[4], float& cost,
+                                                         float (&dq)[MPB_MAX_DOF], std::integer_sequence<int, GRPS...>) {
+    ((grp == GRPS ? model_group_jtf<M, GRPS>(F, G, x, y, z, rl, best, vx, vy, vz, vn, cost, dq) : (void)0), ...);
+}
+
+template <class M>
+__device__ __forceinline__ float waypoint_cost_grid_grad_model(const GeomView& G, const unsigned* gridw, const float4* otab,
+                                                               const float (&q)[MPB_MAX_DOF], float (&dq)[MPB_MAX_DOF]) {
+    constexpr int NG = (M::N_FRAME1 + 3) / 4 + (M::N_LINKS - M::N_FRAME1 + 3) / 4;
+#pragma unroll
+    for (int i = 0; i < MPB_MAX_DOF; ++i) dq[i] = 0.f;
+    ModelFKGrad<M> F;
+    F.r00 = 1.f; F.r01 = 0.f; F.r02 = 0.f; F.r10 = 0.f; F.r11 = 1.f; F.r12 = 0.f; F.r20 = 0.f; F.r21 = 0.f; F.r22 = 1.f;
+    F.tx = F.ty = F.tz = 0.f;
+#pragma unroll
+    for (int i = 0; i < M::N_DOF; ++i) { F.zx[i] = F.zy[i] = F.zz[i] = F.px[i] = F.py[i] = F.pz[i] = 0.f; }
+    float cost = 0.f;
+    const unsigned keep = G.keep_mask;
+#pragma nounroll
+    for (int grp = 0; grp < NG; ++grp) {
+        float x[4], y[4], z[4], rl[4];
+        const bool run = model_group_dispatch_grad<M>(grp, F, q, keep, x, y, z, rl, std::make_integer_sequence<int, NG>{});
+        if (run) {
+            float best[4], vx[4], vy[4], vz[4], vn[4];
+            spheres_nearest_grid<4>(G, gridw, otab, x, y, z, best, vx, vy, vz, vn);
+            model_group_dispatch_jtf<M>(grp, F, G, x, y, z, rl, best, vx, vy, vz, vn, cost, dq, std::make_integer_sequence<int, NG>{});
+        }
+    }
+#ifndef MPB_NO_COST_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    return cost;
+}
+
+// the gradient evaluator a kernel should call for this field: the compile-time model when the buffer carries its id
+__device__ __forceinline__ float waypoint_cost_grid_grad_any(const GeomView& G, const unsigned* gridw, const float4* otab,
+                                                             const float (&q)[MPB_MAX_DOF], float (&dq)[MPB_MAX_DOF]) {
+    if (G.model == PandaModel::ID) return waypoint_cost_grid_grad_model<PandaModel>(G, gridw, otab, q, dq);   // wave-uniform
+    return waypoint_cost_grid_grad(G, gridw, otab, q, dq);
 }

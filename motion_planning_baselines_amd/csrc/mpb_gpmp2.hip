@@ -36,8 +36,26 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 // linearisation of the collision factor: jac[b][t][0..D) = h_t = -d c_t/d q, jac[b][t][D] = c_t
 // (t = 0 is excluded from the collision factor: traj_range [1, None]).  One wave per particle, lane = waypoint.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gpmp2_linearize_kernel(const float* __restrict__ x, const float* __restrict__ geom,
-                                                              float* __restrict__ jac_all, int B, int H, int D, int n_interp) {
+// MODEL: compile-time robot model whose gradient walk the kernel runs (0: the table-driven walk); the geometry's tag is
+// re-checked on the device and a mismatch poisons the rows (NaN) instead of mis-reading the buffer.
+template <int MODEL>
+__device__ __forceinline__ float gp_point_grad(const GeomView& G, bool ug, const unsigned* gridw, const float4* otab,
+                                               const float (&q)[MPB_MAX_DOF], float (&dq)[MPB_MAX_DOF]) {
+    if (MODEL == PandaModel::ID) {
+        if (G.model == PandaModel::ID && ug) return waypoint_cost_grid_grad_model<PandaModel>(G, gridw, otab, q, dq);
+#pragma unroll
+        for (int i = 0; i < MPB_MAX_DOF; ++i) dq[i] = __uint_as_float(0x7FC00000u);
+        return __uint_as_float(0x7FC00000u);
+    }
+    return ug ? waypoint_cost_grid_grad(G, gridw, otab, q, dq) : waypoint_cost<true>(G, q, dq);
+}
+
+// INTERP: the interpolated-Jacobian path exists in the instantiation (its arrays cost ~40 registers the plain
+// linearisation does not need); WPE: waves per SIMD the register allocation aims at.
+template <int MODEL, bool INTERP, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void gpmp2_linearize_kernel(const float* __restrict__ x, const float* __restrict__ geom,
+                                                              float* __restrict__ jac_all, int B, int H, int D, int n_interp_rt) {
+    const int n_interp = INTERP ? n_interp_rt : 0;
     __shared__ unsigned gridw[MPB_GRID_MAX_CELLS];              // broad-phase grid of the field being linearised
     __shared__ float4 otab[MPB_GRID_MAX_SPH + 1];
     const int lane = threadIdx.x & 63;
@@ -77,7 +95,7 @@ __global__ __launch_bounds__(256) void gpmp2_linearize_kernel(const float* __res
                 gnext[i] = 0.f;
             }
             float c = 0.f;
-            if (active && t >= 1) c = ug ? waypoint_cost_grid_grad(G, gridw, otab, q, dq) : waypoint_cost<true>(G, q, dq);
+            if (active && t >= 1) c = gp_point_grad<MODEL>(G, ug, gridw, otab, q, dq);
             if (n_interp > 0) {
                 if (active && t + 1 < H) {
                     float qn[MPB_MAX_DOF];
@@ -88,8 +106,7 @@ __global__ __launch_bounds__(256) void gpmp2_linearize_kernel(const float* __res
                         float qi[MPB_MAX_DOF], dqi[MPB_MAX_DOF];
 #pragma unroll
                         for (int i = 0; i < MPB_MAX_DOF; ++i) qi[i] = q[i] + al * (qn[i] - q[i]);
-                        if (ug) waypoint_cost_grid_grad(G, gridw, otab, qi, dqi);
-                        else waypoint_cost<true>(G, qi, dqi);
+                        gp_point_grad<MODEL>(G, ug, gridw, otab, qi, dqi);
 #pragma unroll
                         for (int i = 0; i < MPB_MAX_DOF; ++i) {
                             dq[i] = fmaf(1.f - al, dqi[i], dq[i]);
@@ -664,14 +681,26 @@ static GpWork gp_carve(void* ws, int B, int H, int D) {
     return w;
 }
 
-extern "C" int mpb_gpmp2_linearize(const float* x, const float* geom, void* workspace, int B, int H, int D, int n_interp,
-                                   void* stream) {
+extern "C" int mpb_gpmp2_linearize(const float* x, const float* geom, int geom_flags, void* workspace, int B, int H, int D,
+                                   int n_interp, void* stream) {
     if (!x || !geom || !workspace) return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_linearize: null pointer");
     if (!gp_shape_ok(B, H, D) || n_interp < 0 || n_interp > 64) return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_linearize: bad shape");
     if (B == 0) return MPB_OK;
     GpWork w = gp_carve(workspace, B, H, D);
-    hipLaunchKernelGGL(gpmp2_linearize_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, geom, w.jac, B, H, D,
-                       n_interp);
+    // geom_flags (mpb_geom_flags of the host copy): low byte = compile-time robot model of EVERY chained field, bit 8 = all
+    // of them grid-backed -- the model kernel needs both
+#ifndef GP_LIN_WPE
+#define GP_LIN_WPE 3
+#endif
+    const bool model = (geom_flags & 0xFF) == PandaModel::ID && (geom_flags & 0x100) && D == PandaModel::N_DOF;
+#define GP_LIN(MODEL, INTERP, WPE)                                                                                           \
+    hipLaunchKernelGGL((gpmp2_linearize_kernel<MODEL, INTERP, WPE>), dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, \
+                       geom, w.jac, B, H, D, n_interp)
+    if (model && n_interp == 0) GP_LIN(PandaModel::ID, false, GP_LIN_WPE);
+    else if (model) GP_LIN(PandaModel::ID, true, 2);
+    else if (n_interp == 0) GP_LIN(0, false, 2);
+    else GP_LIN(0, true, 2);
+#undef GP_LIN
     return mpb_check_launch("mpb_gpmp2_linearize");
 }
 
@@ -728,7 +757,7 @@ extern "C" int mpb_gpmp2_solve(float* x, const float* start, const float* goal, 
     return mpb_check_launch("mpb_gpmp2_solve");
 }
 
-extern "C" int mpb_gpmp2_step(float* x, const float* start, const float* goal, const float* geom, void* workspace,
+extern "C" int mpb_gpmp2_step(float* x, const float* start, const float* goal, const float* geom, int geom_flags, void* workspace,
                               float* costs_out, int B, int H, int D, float dt, float sigma_start, float sigma_gp,
                               float sigma_goal, float sigma_coll, float delta, int trust_region, float step_size,
                               int n_iters, int n_interp, int n_fields, void* stream) {
@@ -738,7 +767,7 @@ extern "C" int mpb_gpmp2_step(float* x, const float* start, const float* goal, c
     if (B == 0) return MPB_OK;
     GpWork w = gp_carve(workspace, B, H, D);
     for (int it = 0; it < n_iters; ++it) {
-        int rc = mpb_gpmp2_linearize(x, geom, workspace, B, H, D, n_interp, stream);
+        int rc = mpb_gpmp2_linearize(x, geom, geom_flags, workspace, B, H, D, n_interp, stream);
         if (rc) return rc;
         if (trust_region) {
             rc = mpb_gpmp2_diag(workspace, nullptr, B, H, D, n_fields, dt, sigma_start, sigma_gp, sigma_goal, sigma_coll, stream);

@@ -802,7 +802,7 @@ __global__ __launch_bounds__(1024) void stomp_update_v4_kernel(
 // ------------------------------------------------------------------------------------------------
 // Stand-alone collision cost (and gradient): one wave per trajectory, lane = waypoint.
 // ------------------------------------------------------------------------------------------------
-template <bool GRAD>
+template <bool GRAD, int MODEL = 0>
 __global__ __launch_bounds__(256) void collision_cost_kernel(
     const float* __restrict__ trajs, const float* __restrict__ geom, float* __restrict__ out,
     float* __restrict__ per_wp, float* __restrict__ grad, int B, int H, int d, int h_begin, float k_sigma,
@@ -835,7 +835,15 @@ __global__ __launch_bounds__(256) void collision_cost_kernel(
                     dq[i] = 0.f;
                 }
                 if (h >= h_begin) {
-                    if (GRAD)
+                    if (GRAD && MODEL == PandaModel::ID) {     // compile-time model (launcher: geom_flags); tag re-checked here
+                        if (use_grid && G.model == PandaModel::ID) {
+                            c = G.fscale * waypoint_cost_grid_grad_model<PandaModel>(G, gridw, otab, q, dq);
+                        } else {
+                            c = __uint_as_float(0x7FC00000u);
+#pragma unroll
+                            for (int i = 0; i < MPB_MAX_DOF; ++i) dq[i] = c;
+                        }
+                    } else if (GRAD)
                         c = G.fscale * (use_grid ? waypoint_cost_grid_grad(G, gridw, otab, q, dq) : waypoint_cost<true>(G, q, dq));
                     else if (use_grid && G.model == PandaModel::ID)   // compile-time robot model (same bits as the table walk)
                         c = G.fscale * waypoint_cost_grid_model<PandaModel>(G, gridw, otab, q);
@@ -947,19 +955,23 @@ extern "C" int mpb_cost_collision_eval(const float* trajs, const float* geom, fl
     if (!trajs || !geom || !out) return fail(MPB_E_INVALID, "%s: null pointer", __func__);
     if (B < 0 || H < 1 || d < 1 || d > MPB_MAX_D || h_begin < 0) return fail(MPB_E_INVALID, "%s: bad shape", __func__);
     if (B == 0) return MPB_OK;
-    hipLaunchKernelGGL(collision_cost_kernel<false>, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, trajs, geom,
+    hipLaunchKernelGGL((collision_cost_kernel<false, 0>), dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, trajs, geom,
                        out, per_waypoint, (float*)nullptr, B, H, d, h_begin, k_sigma, weight);
     return check_launch(__func__);
 }
 
-extern "C" int mpb_cost_collision_grad(const float* trajs, const float* geom, float* out, float* grad, int B, int H,
-                                       int d, int h_begin, float k_sigma, float weight, void* stream) {
+extern "C" int mpb_cost_collision_grad(const float* trajs, const float* geom, int geom_flags, float* out, float* grad, int B,
+                                       int H, int d, int h_begin, float k_sigma, float weight, void* stream) {
     if (B == 0) return MPB_OK;
     if (!trajs || !geom || !out || !grad) return fail(MPB_E_INVALID, "%s: null pointer", __func__);
     if (B < 0 || H < 1 || d < 1 || d > MPB_MAX_D || h_begin < 0) return fail(MPB_E_INVALID, "%s: bad shape", __func__);
     if (B == 0) return MPB_OK;
-    hipLaunchKernelGGL(collision_cost_kernel<true>, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, trajs, geom,
-                       out, (float*)nullptr, grad, B, H, d, h_begin, k_sigma, weight);
+    if ((geom_flags & 0xFF) == PandaModel::ID && (geom_flags & 0x100))
+        hipLaunchKernelGGL((collision_cost_kernel<true, PandaModel::ID>), dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, trajs,
+                           geom, out, (float*)nullptr, grad, B, H, d, h_begin, k_sigma, weight);
+    else
+        hipLaunchKernelGGL((collision_cost_kernel<true, 0>), dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, trajs, geom,
+                           out, (float*)nullptr, grad, B, H, d, h_begin, k_sigma, weight);
     return check_launch(__func__);
 }
 

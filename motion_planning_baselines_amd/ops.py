@@ -113,7 +113,7 @@ def cost_collision_grad(trajs, geom, k_sigma, weight=1.0, h_begin=1, grad=None):
         grad = torch.empty_like(trajs)
     else:
         _chk(grad, (B, H, d), 'grad')
-    _lib.check(_lib.lib().mpb_cost_collision_grad(_ptr(trajs), _ptr(geom.buf), _ptr(out), _ptr(grad), B, H, d, h_begin,
+    _lib.check(_lib.lib().mpb_cost_collision_grad(_ptr(trajs), _ptr(geom.buf), int(geom.flags), _ptr(out), _ptr(grad), B, H, d, h_begin,
                                                  float(k_sigma), float(weight), _stream()), 'mpb_cost_collision_grad')
     return out, grad
 
@@ -597,7 +597,7 @@ def gpmp2_step(x, start, goal, geom, workspace, sigmas, dt, delta, trust_region,
     _chk(costs_out, (B,), 'costs_out', allow_none=True)
     assert workspace.numel() >= _lib.lib().mpb_gpmp2_workspace_bytes(B, H, D)
     _lib.check(_lib.lib().mpb_gpmp2_step(
-        _ptr(x), _ptr(start), _ptr(goal), _ptr(geom.buf), _ptr(workspace), _ptr(costs_out), B, H, D, float(dt),
+        _ptr(x), _ptr(start), _ptr(goal), _ptr(geom.buf), int(geom.flags), _ptr(workspace), _ptr(costs_out), B, H, D, float(dt),
         float(sigmas[0]), float(sigmas[1]), float(sigmas[2]), float(sigmas[3]), float(delta), int(bool(trust_region)),
         float(step_size), int(n_iters), int(n_interp or 0), int(geom.n_fields), _stream()), 'mpb_gpmp2_step')
 
@@ -606,7 +606,7 @@ def gpmp2_step(x, start, goal, geom, workspace, sigmas, dt, delta, trust_region,
 def gpmp2_linearize(x, geom, workspace, n_interp=0):
     B, H, dim = x.shape
     _chk(x, (B, H, dim), 'x')
-    _lib.check(_lib.lib().mpb_gpmp2_linearize(_ptr(x), _ptr(geom.buf), _ptr(workspace), B, H, dim // 2,
+    _lib.check(_lib.lib().mpb_gpmp2_linearize(_ptr(x), _ptr(geom.buf), int(geom.flags), _ptr(workspace), B, H, dim // 2,
                                               int(n_interp or 0), _stream()), 'mpb_gpmp2_linearize')
 
 
@@ -624,7 +624,7 @@ def gpmp2_collision_rows(x, geom, n_interp=0):
         raise ValueError(f'unsupported GPMP2 shape B={B} H={H} D={D}')
     MAX_FIELDS = 4                                   # MPB_MAX_FIELDS: the section is laid out for four fields
     jac = torch.zeros(MAX_FIELDS, B, H, D + 1, device=x.device, dtype=torch.float32)
-    _lib.check(_lib.lib().mpb_gpmp2_linearize(_ptr(x), _ptr(geom.buf), _ptr(jac), B, H, D, int(n_interp or 0), _stream()),
+    _lib.check(_lib.lib().mpb_gpmp2_linearize(_ptr(x), _ptr(geom.buf), int(geom.flags), _ptr(jac), B, H, D, int(n_interp or 0), _stream()),
                'mpb_gpmp2_linearize')
     return jac[:geom.n_fields]
 

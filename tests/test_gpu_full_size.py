@@ -107,6 +107,43 @@ def test_panda_model_path_equals_generic_walk(gpu_device, keep_all):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('keep_all', [False, True])
+def test_panda_model_gradient_walk_equals_generic_walk(gpu_device, keep_all):
+    """The compile-time Panda model of the GRADIENT evaluators (waypoint_cost_grid_grad_model: stand-alone cost + gradient,
+    GPMP2's linearisation incl. interpolated points, CHOMP's loop) and the table-driven walk return the same bits:
+    131072 waypoints incl. far-out-of-range angles, pruned and full link tables."""
+    import numpy as np
+    from motion_planning_baselines_amd import ops
+    dev = gpu_device
+    wl, _, _, _ = _c3(dev, 8, 4)
+    gm = ops.DeviceGeometry(wl['robot'], wl['field'], dev, keep_all_links=keep_all)
+    gg = ops.DeviceGeometry(wl['robot'], wl['field'], dev, keep_all_links=keep_all, use_model=False)
+    assert (gm.flags & 0xFF) == 1 and (gg.flags & 0xFF) == 0
+    g = torch.Generator().manual_seed(1)
+    x = ((torch.rand(2048, 64, 14, generator=g) * 2 - 1) * 6.0).to(dev)
+    x[:1024] *= 0.4                                          # half of them near the workspace centre: many contacts
+    outs = []
+    for geom in (gm, gg):
+        c, gr = ops.cost_collision_grad(x, geom, 1.0)
+        rows = ops.gpmp2_collision_rows(x[:256], geom, n_interp=0)
+        rows_i = ops.gpmp2_collision_rows(x[:64], geom, n_interp=2)
+        torch.cuda.synchronize()
+        outs.append((c, gr, rows, rows_i))
+    assert float(outs[0][0].max()) > 0 and float(outs[0][1].abs().max()) > 0
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    # CHOMP on the Panda: five iterations of the one-launch loop with either geometry
+    from motion_planning_baselines_amd.planners.chomp import chomp_precision_matrix
+    R = chomp_precision_matrix(dt=5 / 64, n_support_points=64, tensor_args=dict(device='cpu', dtype=torch.float32)).to(dev).contiguous()
+    res = []
+    for geom in (gm, gg):
+        m = (x[:512] * 0.3).contiguous().clone()
+        ops.chomp_step(m, R, geom, 7, 1.0, 10.0, 1e-6, 0.05, 0.05, n_iters=5)
+        torch.cuda.synchronize()
+        res.append(m)
+    assert torch.isfinite(res[0]).all() and torch.equal(res[0], res[1])
+
+
 def test_collision_cost_grid_equals_exhaustive_at_scale(gpu_device):
     """Broad-phase grid (cost-only path) == exhaustive obstacle loop (gradient path's cost output), bit for
     bit, on 4096 x 64 random Panda configurations incl. far-out-of-workspace angles."""
