@@ -212,9 +212,11 @@ int mpb_stomp_step_profile(float *means, float *samples, float *costs, float *we
  * LOST: every workgroup leaves, the means of the affected particles are not written, samples / costs / weights are
  * undefined.  The call still returns MPB_OK (it is asynchronous); the loss is reported
  *   - by mpb_stomp_run_status (reads the workspace header; synchronises the stream): 0 fine, 1 lost, 2 header not zeroed;
- *   - without synchronising, by mpb_stomp_run_checked's `status`: 4 words of pinned, device-mapped HOST memory
+ *   - without synchronising, by mpb_stomp_run_checked's `status`: 8 words of pinned, device-mapped HOST memory
  *     (hipHostMalloc), zero before the first call: [0] = tag of the last call that has completed, [1] = tag of the last
- *     call that was lost (0: none), [2] = why (1 partner timed out, 2 header not zeroed); `tag_out` receives the tag
+ *     call that was lost (0: none), [2] = why (1 partner timed out, 2 header not zeroed), [4..5] / [6..7] = the device's
+ *     100 MHz real-time counter when the launch's first unit started / when its last workgroup left (the launch's
+ *     duration as the device saw it: a measurement aid that costs nothing); `tag_out` receives the tag
  *     of this call (0 when it ran the two-kernel loop, which cannot be lost).  The caller compares [1] with the tags it
  *     has issued whenever convenient -- planners/stomp.py raises at the next planner call.
  * means_copy (P,H,d) or NULL: a second destination for the final means, written by the same launch (the reference's
@@ -240,6 +242,16 @@ int mpb_stomp_run_checked(float *means, const float *eps, float *samples, float 
                           int n_iters, uint64_t seed, uint32_t iter0, uint32_t particle_offset,
                           uint32_t *status, uint32_t *tag_out, float *means_copy, void *stream);
 int mpb_stomp_run_status(const float *workspace, void *stream, int *timed_out);
+/* Measurement aid (bench.py): mpb_stomp_run_checked with the persistent kernel's begin / end timestamps recorded on the
+ * dispatch itself (what rocprofv3 --kernel-trace reports); synchronises the stream; *kernel_ms = the kernel's duration in
+ * milliseconds (0 when the call ran the two-kernel loop). */
+int mpb_stomp_run_timed(float *means, const float *eps, float *samples, float *costs, float *weights,
+                        const float *L, const float *Sigma, const float *geom, int geom_flags,
+                        float *workspace, size_t workspace_bytes,
+                        int P, int S, int H, int d, int D,
+                        float k_sigma, float weight, float lr, float temperature,
+                        int n_iters, uint64_t seed, uint32_t iter0, uint32_t particle_offset,
+                        uint32_t *status, uint32_t *tag_out, float *means_copy, void *stream, float *kernel_ms);
 /* Test aid: n_blocks workgroups that each take a whole CU's LDS and idle for `usec` microseconds (the "another stream
  * keeps the chip busy" of the time-out tests); `sink` is one device word (never written in practice). */
 int mpb_debug_occupy(int n_blocks, uint64_t usec, uint32_t *sink, void *stream);

@@ -40,6 +40,7 @@ SIGNATURES = {
     'mpb_stomp_run': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, ctypes.c_size_t, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _u64, _u32, _u32, _p],
     'mpb_stomp_run_checked': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, ctypes.c_size_t, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _u64, _u32, _u32, _p, _p, _p, _p],
     'mpb_stomp_run_status': [_p, _p, _p],
+    'mpb_stomp_run_timed': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, ctypes.c_size_t, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _u64, _u32, _u32, _p, _p, _p, _p, _p],
     'mpb_stomp_workspace_init': [_p, ctypes.c_size_t, _p],
     'mpb_stomp_run_path': [_i, ctypes.c_size_t, _i, _i, _i, _i],
     'mpb_debug_occupy': [_i, _u64, _p, _p],

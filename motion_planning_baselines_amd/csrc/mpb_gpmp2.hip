@@ -271,6 +271,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVE
     const int dir = threadIdx.x >> 6;        // 0: rows 0 .. m (top down, then the merge row m); 1: rows H-1 .. m+1 (bottom up)
     const int b = blockIdx.x;
     const int dim = 2 * D;
+    const bool aug = DT ? (2 * DT <= 14) : (dim <= 14);   // room for the right-hand side as a column of the 16 x 16 tile
     const int m = split ? (H - 1) >> 1 : H - 1;   // merge row; split == 0 (64-thread block): plain top-down sweep, nothing to merge
     const int nst = dir ? (H - 1 - m) : m;   // plain elimination steps of this wave (wave 0 adds the merge step)
     const int nrows = nst + 1;               // rows this wave touches: its own and, for wave 1, the merge row as neighbour
@@ -444,6 +445,19 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVE
 #pragma unroll
             for (int q = 0; q < 4; ++q) T[q] = asm_in[q] ? v[q] : asm_id[q];
             if (lane >= dim) r = 0.0;
+            // the right-hand side rides along as column 14 of the tile (free whenever 2D <= 14): the row operations of the
+            // Gauss-Jordan steps below turn it into z = S^-1 r -- the update of the whole 16 x 16 tile is one MFMA per block
+            // step whatever its columns hold -- so z costs no instructions of its own (it used to be 14 fma with two
+            // v_readlane and an LDS read each, behind the tile's trip through LDS).  Row 14 of the tile collects
+            // meaningless values on the way (its A operand is read "by symmetry" from this column); nothing reads it.
+            if (aug) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = lk + 4 * q;
+                    const double rq = __shfl(r, row < dim ? row : 0, 64);
+                    if (li == 14 && row < dim) T[q] = rq;
+                }
+            }
         }
         GP_STAMP(2);
         // ---- W = S^-1 : blocked Gauss-Jordan with 2x2 pivot blocks, entirely in registers.  Per block step K:
@@ -508,7 +522,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVE
 #else
         {
             const int rowl = (lane < dim) ? lane : 0;
-            if (DT) {
+            if (aug) {
+                zi = (lane < dim) ? W[rowl * GP_LD + 14] : 0.0;      // column 14 of the tile: z = S^-1 r (see the assembly)
+            } else if (DT) {
 #pragma unroll
                 for (int j = 0; j < 2 * DT; ++j) zi = fma(W[rowl * GP_LD + j], readlane_f64(r, j), zi);
             } else {

@@ -3,6 +3,7 @@
 // the agent-scope accessors and the tagged granules of the exchange between the workgroups of a particle.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #define FUSED_WAVES 16
@@ -39,6 +40,15 @@ __device__ __forceinline__ void st_granule(granule_t* p, float v, unsigned tag) 
 __device__ __forceinline__ granule_t ld_granule(const granule_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 
+// Measurement aid (mpb_stomp_run_timed): while these are set, the persistent launch records the pair on the dispatch
+// itself (hipExtLaunchKernelGGL: kernel begin / end timestamps, the quantity rocprofv3 --kernel-trace reports).
+struct FusedProfile { hipEvent_t start, stop; };
+#define MPB_FUSED_LAUNCH(prof, kernel, grid, block, st, ...)                                                        \
+    do {                                                                                                            \
+        if ((prof) != nullptr) hipExtLaunchKernelGGL(kernel, grid, block, 0, st, (prof)->start, (prof)->stop, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, 0, st, __VA_ARGS__);                                           \
+    } while (0)
+
 // unit of a workgroup of the exchange layout, by ticket (see the header comment of mpb_stomp_fused.hip): returns the unit
 // index u = particle * nc + chunk, or sets `why` (1: an earlier workgroup of this call gave up; 2: header not zeroed)
 __device__ __forceinline__ unsigned fused_draw_unit(unsigned* wsu, int P, int nc, uint32_t tag0, int& why) {
@@ -66,6 +76,16 @@ __device__ __forceinline__ unsigned fused_draw_unit(unsigned* wsu, int P, int nc
     return u;
 }
 
+// the workgroup that owns unit 0 stamps the status block with the device's real-time counter (100 MHz) when it starts:
+// words 4, 5; together with words 6, 7 (fused_leave) the span of the launch as the device saw it
+__device__ __forceinline__ void fused_stamp_begin(unsigned* status_host) {
+    if (status_host) {
+        const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+        st_system_u(status_host + 4, (unsigned)t);
+        st_system_u(status_host + 5, (unsigned)(t >> 32));
+    }
+}
+
 // leaving: the error word (device header + the caller's host-visible status block), then the head count; the last
 // workgroup out re-arms the header for the next call and reports the call as completed.  One thread per workgroup.
 __device__ __forceinline__ void fused_leave(unsigned* wsu, unsigned* status_host, uint32_t tag0, int aborted) {
@@ -83,6 +103,11 @@ __device__ __forceinline__ void fused_leave(unsigned* wsu, unsigned* status_host
 #pragma unroll
         for (int k = 0; k < 8; ++k) st_agent_u(wsu + FUSED_HDR_TICKET + k, 0u);
         st_agent_u(wsu + FUSED_HDR_DONE, 0u);
-        if (status_host) st_system_u(status_host + 0, tag0);
+        if (status_host) {
+            const unsigned long long t = __builtin_amdgcn_s_memrealtime();     // words 6, 7: when the last workgroup left
+            st_system_u(status_host + 6, (unsigned)t);
+            st_system_u(status_host + 7, (unsigned)(t >> 32));
+            st_system_u(status_host + 0, tag0);
+        }
     }
 }

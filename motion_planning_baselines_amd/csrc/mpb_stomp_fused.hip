@@ -158,7 +158,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
     bool live = s < S;
     if (tid < N) mean_l[tid] = means[(size_t)p * N + tid];
     // header word 1 = this call's tag; word 0 (the error word) counts only when it equals it
-    if (ticket == 0 && tid == 0) st_agent_u(wsu + FUSED_HDR_TAG, tag0);    // (unit 0 is drawn exactly once)
+    if (ticket == 0 && tid == 0) {
+        st_agent_u(wsu + FUSED_HDR_TAG, tag0);    // (unit 0 is drawn exactly once)
+        fused_stamp_begin(status_host);
+    }
     __syncthreads();
     LSTAMP(2);
 
@@ -462,7 +465,7 @@ int mpb_fused_hx_launch(float* means, const float* eps, float* samples, float* c
                         const float* Sigma, const float* geom, int geom_flags, float* workspace, int P, int S, int H, int d, int nc,
                         int nb, float k_sigma, float weight, float lr, float temperature, int n_iters, uint32_t lo, uint32_t hi,
                         uint32_t iter0, uint32_t particle_offset, uint32_t tag0, unsigned long long timeout, unsigned* status_dev,
-                        float* means_copy, hipStream_t st);
+                        float* means_copy, hipStream_t st, const FusedProfile* prof);
 
 // which form of the loop serves a call, and the workspace it needs
 struct FusedPlan {
@@ -526,6 +529,8 @@ extern "C" int mpb_stomp_step(float* means, const float* eps, float* samples, fl
                               float k_sigma, float weight, float lr, float temperature, int n_iters, uint64_t seed,
                               uint32_t iter0, uint32_t particle_offset, void* stream);
 
+static thread_local const FusedProfile* t_prof = nullptr;      // set by mpb_stomp_run_timed around its launch
+
 extern "C" int mpb_stomp_run_checked(float* means, const float* eps, float* samples, float* costs, float* weights,
                                      const float* L, const float* Sigma, const float* geom, int geom_flags, float* workspace,
                                      size_t workspace_bytes, int P, int S, int H, int d, int D, float k_sigma, float weight, float lr,
@@ -577,14 +582,14 @@ extern "C" int mpb_stomp_run_checked(float* means, const float* eps, float* samp
     if (f.hx)
         return mpb_fused_hx_launch(means, eps, samples, costs, weights, L, Sigma, geom, geom_flags, workspace, P, S, H, d, f.nc, f.nb,
                                    k_sigma, weight, lr, temperature, n_iters, lo, hi, iter0, particle_offset, tag0, timeout, status_dev,
-                                   means_copy, st);
+                                   means_copy, st, t_prof);
     const dim3 grid(f.two_batches ? P : P * f.nc), block(FUSED_THREADS);
     const int nc_k = f.two_batches ? 1 : f.nc;
     const int model = geom_flags & 0xFF;
 #define MPB_F_LAUNCH(DCH, MODEL, NB)                                                                                      \
-    hipLaunchKernelGGL((stomp_fused_kernel<DCH, MODEL, NB>), grid, block, 0, st, means, eps, samples, costs, weights, L, \
-                       Sigma, geom, workspace, P, S, nc_k, k_sigma, weight, lr, temperature, n_iters, lo, hi, iter0,        \
-                       particle_offset, tag0, timeout, status_dev, means_copy)
+    MPB_FUSED_LAUNCH(t_prof, (stomp_fused_kernel<DCH, MODEL, NB>), grid, block, st, means, eps, samples, costs, weights, L, \
+                     Sigma, geom, workspace, P, S, nc_k, k_sigma, weight, lr, temperature, n_iters, lo, hi, iter0,          \
+                     particle_offset, tag0, timeout, status_dev, means_copy)
 #define MPB_F_CASE(DCH, MODEL)                           \
     do {                                                 \
         if (f.two_batches) MPB_F_LAUNCH(DCH, MODEL, 2);  \
@@ -611,6 +616,37 @@ extern "C" int mpb_stomp_run(float* means, const float* eps, float* samples, flo
     return mpb_stomp_run_checked(means, eps, samples, costs, weights, L, Sigma, geom, geom_flags, workspace, workspace_bytes, P, S,
                                  H, d, D, k_sigma, weight, lr, temperature, n_iters, seed, iter0, particle_offset, nullptr,
                                  nullptr, nullptr, stream);
+}
+
+/* measurement aid for bench.py: mpb_stomp_run_checked with the kernel's begin / end timestamps recorded on the dispatch
+   itself; synchronises the stream and returns the kernel's duration (0 when the call ran the two-kernel loop) */
+extern "C" int mpb_stomp_run_timed(float* means, const float* eps, float* samples, float* costs, float* weights,
+                                   const float* L, const float* Sigma, const float* geom, int geom_flags, float* workspace,
+                                   size_t workspace_bytes, int P, int S, int H, int d, int D, float k_sigma, float weight, float lr,
+                                   float temperature, int n_iters, uint64_t seed, uint32_t iter0, uint32_t particle_offset,
+                                   uint32_t* status, uint32_t* tag_out, float* means_copy, void* stream, float* kernel_ms) {
+    if (!kernel_ms) return mpb_fail(MPB_E_INVALID, "mpb_stomp_run_timed: null pointer");
+    *kernel_ms = 0.f;
+    FusedProfile pr = {nullptr, nullptr};
+    if (hipEventCreate(&pr.start) != hipSuccess || hipEventCreate(&pr.stop) != hipSuccess) {
+        if (pr.start) (void)hipEventDestroy(pr.start);
+        return mpb_fail(MPB_E_HIP, "mpb_stomp_run_timed: hipEventCreate failed");
+    }
+    uint32_t tag = 0;
+    t_prof = &pr;
+    int rc = mpb_stomp_run_checked(means, eps, samples, costs, weights, L, Sigma, geom, geom_flags, workspace, workspace_bytes, P, S, H,
+                                   d, D, k_sigma, weight, lr, temperature, n_iters, seed, iter0, particle_offset, status, &tag,
+                                   means_copy, stream);
+    t_prof = nullptr;
+    if (tag_out) *tag_out = tag;
+    if (rc == MPB_OK && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) rc = mpb_fail(MPB_E_HIP, "mpb_stomp_run_timed: synchronize failed");
+    if (rc == MPB_OK && tag != 0u && hipEventElapsedTime(kernel_ms, pr.start, pr.stop) != hipSuccess) {
+        (void)hipGetLastError();
+        rc = mpb_fail(MPB_E_HIP, "mpb_stomp_run_timed: hipEventElapsedTime failed");
+    }
+    (void)hipEventDestroy(pr.start);
+    (void)hipEventDestroy(pr.stop);
+    return rc;
 }
 
 /* state of the last persistent launch on this workspace (host-side read of the header: synchronises the stream):

@@ -119,7 +119,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
     const int p = exchange ? unit / nc : unit;
     const int chunk = exchange ? unit - p * nc : 0;
     for (int e = tid; e < N; e += FUSED_THREADS) mean_l[e] = means[(size_t)p * N + e];
-    if (unit == 0 && tid == 0) st_agent_u(wsu + FUSED_HDR_TAG, tag0);
+    if (unit == 0 && tid == 0) {
+        st_agent_u(wsu + FUSED_HDR_TAG, tag0);
+        fused_stamp_begin(status_host);
+    }
     __syncthreads();
     const int n_run = s_abort ? 0 : n_iters;
 
@@ -503,13 +506,13 @@ int mpb_fused_hx_launch(float* means, const float* eps, float* samples, float* c
                         const float* Sigma, const float* geom, int geom_flags, float* workspace, int P, int S, int H, int d, int nc,
                         int nb, float k_sigma, float weight, float lr, float temperature, int n_iters, uint32_t lo, uint32_t hi,
                         uint32_t iter0, uint32_t particle_offset, uint32_t tag0, unsigned long long timeout, unsigned* status_dev,
-                        float* means_copy, hipStream_t st) {
+                        float* means_copy, hipStream_t st, const FusedProfile* prof) {
     const dim3 grid(P * nc), block(FUSED_THREADS);
     const int model = geom_flags & 0xFF;
 #define MPB_HX_LAUNCH(DCH, MODEL, HC)                                                                                          \
-    hipLaunchKernelGGL((stomp_fused_hx_kernel<DCH, MODEL, HC>), grid, block, 0, st, means, eps, samples, costs, weights, L,   \
-                       Sigma, geom, workspace, P, S, H, d, nc, nb, k_sigma, weight, lr, temperature, n_iters, lo, hi, iter0,    \
-                       particle_offset, tag0, timeout, status_dev, means_copy)
+    MPB_FUSED_LAUNCH(prof, (stomp_fused_hx_kernel<DCH, MODEL, HC>), grid, block, st, means, eps, samples, costs, weights, L,   \
+                     Sigma, geom, workspace, P, S, H, d, nc, nb, k_sigma, weight, lr, temperature, n_iters, lo, hi, iter0,     \
+                     particle_offset, tag0, timeout, status_dev, means_copy)
     if (H > 64) {
         if (model == PandaModel::ID && d == 7) MPB_HX_LAUNCH(7, PandaModel::ID, 2);
         else if (model == PandaModel::ID && d == 14) MPB_HX_LAUNCH(14, PandaModel::ID, 2);

@@ -355,11 +355,12 @@ def stomp_run_path(geom, workspace, P, S, H, d):
 
 
 class StompRunStatus:
-    """Host-visible status block of mpb_stomp_run_checked: 4 words of pinned host memory the kernel writes directly
-    ([0] tag of the last completed call, [1] tag of the last LOST call, [2] why), read here without synchronising."""
+    """Host-visible status block of mpb_stomp_run_checked: 8 words of pinned host memory the kernel writes directly
+    ([0] tag of the last completed call, [1] tag of the last LOST call, [2] why, [4..7] device real-time stamps of the
+    launch's begin / end), read here without synchronising."""
 
     def __init__(self):
-        self.buf = torch.zeros(4, dtype=torch.int32).pin_memory()
+        self.buf = torch.zeros(8, dtype=torch.int32).pin_memory()
         self._view = self.buf.numpy().view(np.uint32)
         self.issued = []             # tags of the persistent launches not yet known to be complete, in launch order
         self.tag_c = ctypes.c_uint32(0)
@@ -381,6 +382,15 @@ class StompRunStatus:
         if done in self.issued:      # calls complete in launch order: everything up to `done` is over, and was fine
             del self.issued[:self.issued.index(done) + 1]
         return None
+
+    def device_span_ms(self):
+        """Duration of the last COMPLETED persistent launch as the device saw it (100 MHz real-time counter: first unit
+        started -> last workgroup left), in milliseconds; None if no launch has completed.  Host memory only."""
+        v = self._view
+        if int(v[0]) == 0:
+            return None
+        t0, t1 = int(v[4]) | (int(v[5]) << 32), int(v[6]) | (int(v[7]) << 32)
+        return (t1 - t0) * 1e-5 if t1 > t0 else None
 
     def acknowledge(self, tag):
         """Forget a lost call (after it has been reported)."""
@@ -453,6 +463,17 @@ class StompRunPlan:
         self._status_ptr = status.ptr()
         self._tag_ref = c.byref(status.tag_c)
         self._fn = _lib.lib().mpb_stomp_run_checked
+
+    def launch_timed(self, n_iters, iter0, means_copy=None):
+        """launch() with the kernel's own duration measured on the dispatch (mpb_stomp_run_timed): synchronises; returns ms."""
+        ms = ctypes.c_float(0.0)
+        rc = _lib.lib().mpb_stomp_run_timed(*self._head, int(n_iters), self._seed, int(iter0), self._poff, self._status_ptr,
+                                            self._tag_ref, None if means_copy is None else means_copy.data_ptr(),
+                                            torch.cuda.current_stream(self.device).cuda_stream, ctypes.byref(ms))
+        if rc != 0:
+            _lib.check(rc, 'mpb_stomp_run_timed')
+        self._status.note_launch()
+        return float(ms.value)
 
     def launch(self, n_iters, iter0, means_copy=None):
         """Enqueue the call on the current stream of the plan's device (which must be the current device)."""

@@ -278,6 +278,16 @@ class STOMP(OptimizationPlanner):
                 self._status.acknowledge(hit[0])
         return lost
 
+    def optimize_timed(self, opt_iters):
+        """Measurement aid (bench.py): optimize(opt_iters) on the persistent path with the kernel's own duration taken on the
+        dispatch (mpb_stomp_run_timed); synchronises and returns milliseconds (None when the planner is not on that path)."""
+        self._run_optimization(0)                      # builds the workspace / plan exactly as optimize() would
+        if self._plan is None:
+            return None
+        ms = self._plan.launch_timed(opt_iters, self._iter)
+        self._iter += opt_iters
+        return ms if ms > 0.0 else None
+
     def run_path(self):
         """Which form of the loop optimize() takes for this planner's shape and cost (ops.STOMP_PATH_*): the persistent
         launch with or without an exchange between workgroups, or the two-kernel loop."""

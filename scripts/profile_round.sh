@@ -1,17 +1,18 @@
 #!/bin/bash
 # rocprofv3 passes of one round (run on the GPU box from the repo root):  bash scripts/profile_round.sh r02
-#   1. kernel trace + stats of the bench command (main line only);
+#   1. kernel trace + stats of the bench command (main line only, the driver's --steps 20 --warmup 5);
 #   2.-6. PMC passes (each its own run, --kernel-trace only next to --pmc) of scripts/prof_stomp.py: the same C3 loop
 #         (one launch of the persistent kernel = MPB_ITERS iterations).
 # Raw output under gpurun_out/prof_<tag>/ (scratch); scripts/pmc_summary.py writes the summaries kept under profiles/.
 set -e
 TAG=${1:-rXX}
+ITERS=${2:-20}        # iterations per profiled launch: the driver times --steps 20
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-other-configs > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- python3 bench.py --steps $ITERS --warmup 5 --no-cpu-baseline --no-other-configs > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 echo "stats pass done"
-export MPB_ITERS=200 MPB_FUSED=1 MPB_LAUNCHES=6     # scripts/prof_stomp.py: the persistent kernel, 6 launches of 200 iterations from the initial means = bench.py's timed launch
+export MPB_ITERS=$ITERS MPB_FUSED=1 MPB_LAUNCHES=24     # scripts/prof_stomp.py: the persistent kernel, 6 launches of 200 iterations from the initial means = bench.py's timed launch
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $OUT/pmc1 -o p -- python3 scripts/prof_stomp.py > $OUT/pmc1.log 2>&1
 echo "pmc1 done"
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM SQ_INSTS_BRANCH SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA -d $OUT/pmc2 -o p -- python3 scripts/prof_stomp.py > $OUT/pmc2.log 2>&1
