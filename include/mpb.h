@@ -411,6 +411,12 @@ int mpb_gp_prior_sample(float *out, const double *means, const double *eps, cons
  * matrix cores (v_mfma_f64_16x16x4_f64); H <= 128.  Same Philox stream as mpb_gp_prior_sample. */
 int mpb_gp_prior_sample_dense(float *out, const double *means, const double *eps, const double *scale_tril,
                               int G, int n, int H, int D, uint64_t seed, void *stream);
+/* MultiMPPrior with ARBITRARY start / GP / goal precisions (mp_priors_multi.py:213-256 accepts any matrices; the planners
+ * of the reference pass isotropic ones, which the two entries above serve): x = mean + L eps from the dense M x M
+ * scale_tril L of the whole trajectory (M = 2D*H <= 4096), handed over TRANSPOSED (tril_t[k*M + m] = L[m][k], fp64).
+ * means (G,M) fp64; eps NULL (device Philox) or (n,G,M) fp64; out (G*n, M) fp32, index mode * n + sample. */
+int mpb_mvn_sample_dense(float *out, const double *means, const double *eps, const double *tril_t,
+                         int G, int n, int M, uint64_t seed, void *stream);
 
 #ifdef __cplusplus
 }

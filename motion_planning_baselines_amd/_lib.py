@@ -59,6 +59,7 @@ SIGNATURES = {
     'mpb_stoch_gpmp_step': [_p] * 11 + [_i] * 4 + [_f] * 10 + [_i, _u64, _p],
     'mpb_gp_prior_sample': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _u64, _p],
     'mpb_gp_prior_sample_dense': [_p, _p, _p, _p, _i, _i, _i, _i, _u64, _p],
+    'mpb_mvn_sample_dense': [_p, _p, _p, _p, _i, _i, _i, _u64, _p],
     'mpb_mppi_step': [_p] * 17 + [_i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _u64, _u32, _p],
 }
 

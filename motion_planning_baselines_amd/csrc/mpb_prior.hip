@@ -219,3 +219,54 @@ extern "C" int mpb_gp_prior_sample(float* out, const double* means, const double
                        eps, Udiag, Uoff, G, n, H, D, (uint32_t)seed, (uint32_t)(seed >> 32));
     return mpb_check_launch("mpb_gp_prior_sample");
 }
+
+// ------------------------------------------------------------------------------------------------
+// General multivariate normal from a DENSE scale_tril: x = mean + L eps (fp64), for MultiMPPrior with arbitrary
+// (non-isotropic) start / GP / goal precisions (mp_priors_multi.py:213-256 takes any matrices): the precision has no
+// (2x2) (x) I structure then and the host hands over the full M x M factor.  Set-up time only (M <= 4096): thread = row,
+// the factor is read transposed (coalesced), eps is staged through LDS in chunks of 256.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mvn_dense_sample_kernel(float* __restrict__ out, const double* __restrict__ means,
+                                                               const double* __restrict__ eps, const double* __restrict__ tril_t,
+                                                               int G, int n, int M, uint32_t seed_lo, uint32_t seed_hi) {
+    __shared__ double e_l[256];
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    const int sg = blockIdx.y;                     // sample * G + mode
+    const int smp = sg / G, mode = sg - smp * G;
+    double acc = 0.0;
+    const int k_end = min(M, (int)(blockIdx.x + 1) * 256);    // rows of this block only reach columns < k_end (lower triangular)
+    for (int k0 = 0; k0 < k_end; k0 += 256) {
+        __syncthreads();
+        const int k = k0 + threadIdx.x;
+        double ev = 0.0;
+        if (k < M) {
+            if (eps != nullptr) {
+                ev = eps[((size_t)smp * G + mode) * M + k];
+            } else {       // device noise: one Philox4x32-10 call per four consecutive k
+                const uint4 rr = philox4x32_10(make_uint4((uint32_t)smp, (uint32_t)mode, (uint32_t)(k >> 2), 0x4d564eu), make_uint2(seed_lo, seed_hi));
+                float n0, n1, n2, n3;
+                box_muller(rr.x, rr.y, n0, n1);
+                box_muller(rr.z, rr.w, n2, n3);
+                const int r = k & 3;
+                ev = (double)(r == 0 ? n0 : r == 1 ? n1 : r == 2 ? n2 : n3);
+            }
+        }
+        e_l[threadIdx.x] = ev;
+        __syncthreads();
+        if (m < M) {
+            const int kn = min(256, m + 1 - k0);     // columns k0 .. min(k0 + 255, m)
+            for (int t = 0; t < kn; ++t) acc = fma(tril_t[(size_t)(k0 + t) * M + m], e_l[t], acc);
+        }
+    }
+    if (m < M) out[((size_t)mode * n + smp) * M + m] = (float)(means[(size_t)mode * M + m] + acc);
+}
+
+extern "C" int mpb_mvn_sample_dense(float* out, const double* means, const double* eps, const double* tril_t, int G, int n, int M,
+                                    uint64_t seed, void* stream) {
+    if (!out || !means || !tril_t) return mpb_fail(MPB_E_INVALID, "mpb_mvn_sample_dense: null pointer");
+    if (G < 1 || n < 0 || M < 1 || M > 4096 || (long)n * G > 65535) return mpb_fail(MPB_E_INVALID, "mpb_mvn_sample_dense: bad shape");
+    if (n == 0) return MPB_OK;
+    hipLaunchKernelGGL(mvn_dense_sample_kernel, dim3((M + 255) / 256, n * G), dim3(256), 0, (hipStream_t)stream, out, means, eps, tril_t,
+                       G, n, M, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return mpb_check_launch("mpb_mvn_sample_dense");
+}

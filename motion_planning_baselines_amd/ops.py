@@ -708,6 +708,24 @@ def mppi_step(mean, eps, scale_tril, cov_inv, state0, goal, ctrl_min, ctrl_max, 
 
 
 @_on_tensor_device
+def mvn_sample_dense(means, eps, tril_t, n, seed=0):
+    """x = mean + L eps from a dense scale_tril handed over transposed (mpb_mvn_sample_dense): means (G,M) fp64, eps None or
+    (n,G,M) fp64, tril_t (M,M) fp64 with tril_t[k,m] = L[m,k] -> (G*n, M) fp32, row mode * n + sample."""
+    G, M = means.shape
+    for t, nm in ((means, 'means'), (tril_t, 'tril_t')):
+        if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
+            raise ValueError(f'{nm} must be a contiguous CUDA float64 tensor')
+    if tuple(tril_t.shape) != (M, M):
+        raise ValueError('tril_t must be (M, M)')
+    if eps is not None and not (eps.is_cuda and eps.dtype == torch.float64 and eps.is_contiguous() and tuple(eps.shape) == (n, G, M)):
+        raise ValueError('eps must be a contiguous CUDA float64 tensor of shape (n, G, M)')
+    out = torch.empty(G * n, M, device=means.device, dtype=torch.float32)
+    _lib.check(_lib.lib().mpb_mvn_sample_dense(_ptr(out), _ptr(means), _ptr(eps), _ptr(tril_t), G, n, M,
+                                              int(seed) & (2 ** 64 - 1), _stream()), 'mpb_mvn_sample_dense')
+    return out
+
+
+@_on_tensor_device
 def gp_prior_sample(means, eps, Udiag, Uoff, n, D, seed=0, scale_tril=None, out=None):
     """Initial particles from the GP prior: means (G,H,2D) fp64, eps None or (n,G,H*2D) fp64 -> (G*n,H,2D) fp32.
     With `scale_tril` (2H,2H fp64, planners.base.gp_prior_scale_tril) and H <= 128 the product runs as a GEMM on

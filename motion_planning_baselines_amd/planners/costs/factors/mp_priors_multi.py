@@ -41,9 +41,8 @@ class MultiMPPrior:
             Kg = torch.as_tensor(K_g_inv).detach().cpu().double()
             self.sigma_goal = float(Kg[0, 0]) ** -0.5
             ok = ok and torch.allclose(Kg, torch.eye(state_dim, dtype=torch.float64) / self.sigma_goal ** 2, rtol=1e-6)
-        if not ok:
-            raise NotImplementedError('MultiMPPrior on the GPU serves isotropic start / GP / goal factors '
-                                      '(K = I / sigma^2, Q_c = I / sigma_gp^2), the form every reference planner uses')
+        self._general = not ok
+        self._K = (Ks, Kgp, torch.as_tensor(K_g_inv).detach().cpu().double() if self.goal_directed else None)
         if means is None:
             self.num_modes = goal_states.shape[0] if self.goal_directed else 1
             s = torch.as_tensor(start_state).detach().cpu().double()
@@ -55,12 +54,49 @@ class MultiMPPrior:
         else:
             self.num_modes = means.shape[0]
         self.means = torch.as_tensor(means).detach().reshape(self.num_modes, -1).to(self.device, torch.float64)
+        self._Sigma_inv = None
+        self._draws = 0
+        if self._general:
+            # arbitrary precisions (mp_priors_multi.py:213-251 takes any matrices): no (2x2) (x) I structure -- the dense
+            # K^-1 = A^T Q^-1 A and its scale_tril (as MultivariateNormal(precision_matrix=...) derives it,
+            # multivariate_normal.py:80-86) are built once on the host in fp64, sampling is a dense product on the GPU
+            Kinv = self._dense_precision(dt)
+            self._Sigma_inv = torch.from_numpy(Kinv).to(**self.tensor_args)
+            from scipy.linalg import solve_triangular
+            Lf = np.linalg.cholesky(Kinv[::-1, ::-1])
+            L_inv = np.ascontiguousarray(Lf[::-1, ::-1].T)
+            tril = solve_triangular(L_inv, np.eye(self.M), lower=True)
+            self._tril_t = torch.from_numpy(np.ascontiguousarray(tril.T)).to(self.device)
+            return
         self._Ud, self._Uo = gp_prior_factor(H, dt, self.sigma_start, self.sigma_gp, self.sigma_goal)
         f64 = lambda a: torch.as_tensor(a, dtype=torch.float64).to(self.device).contiguous()
         self._Ud_d, self._Uo_d = f64(self._Ud), f64(self._Uo)
         self._tril = f64(gp_prior_scale_tril(self._Ud, self._Uo)) if H <= 128 else None
-        self._Sigma_inv = None
-        self._draws = 0
+
+    def _dense_precision(self, dt):
+        """K^-1 = A^T Q^-1 A (mp_priors_multi.py:213-251) for arbitrary K_s_inv / K_gp_inv / K_g_inv, block by block in fp64:
+        diag block t: [t=0] K_s + [t<H-1] Phi^T Q Phi + [t>0] Q + [t=H-1] K_g; block (t, t+1): -Phi^T Q."""
+        H, sd, D = self.num_steps + 1, self.state_dim, self.dof
+        Ks, Q, Kg = (None if k is None else k.numpy() for k in self._K)
+        Phi = np.eye(sd)
+        Phi[:D, D:] = np.eye(D) * dt
+        PQP, off = Phi.T @ Q @ Phi, -Phi.T @ Q
+        K = np.zeros((self.M, self.M))
+        for t in range(H):
+            blk = np.zeros((sd, sd))
+            if t == 0:
+                blk += Ks
+            if t < H - 1:
+                blk += PQP
+            if t > 0:
+                blk += Q
+            if t == H - 1 and Kg is not None:
+                blk += Kg
+            K[t * sd:(t + 1) * sd, t * sd:(t + 1) * sd] = blk
+            if t < H - 1:
+                K[t * sd:(t + 1) * sd, (t + 1) * sd:(t + 2) * sd] = off
+                K[(t + 1) * sd:(t + 2) * sd, t * sd:(t + 1) * sd] = off.T
+        return K
 
     # ---- dense views (built on demand, fp64 on the host like the reference) --------------------------
     @property
@@ -99,6 +135,10 @@ class MultiMPPrior:
         eps = None
         if self.noise != 'philox':
             eps = torch.empty(num_samples, self.num_modes, H * dim, dtype=torch.float64).normal_().to(self.device)
+        if self._general:
+            out = ops.mvn_sample_dense(self.means.contiguous(), eps, self._tril_t, num_samples, seed=self.seed + self._draws)
+            self._draws += 1
+            return out.reshape(self.num_modes, num_samples, H, dim).to(self.tensor_args.get('dtype', torch.float32))
         out = ops.gp_prior_sample(self.means.reshape(self.num_modes, H, dim).contiguous(), eps, self._Ud_d, self._Uo_d,
                                   num_samples, self.dof, seed=self.seed + self._draws, scale_tril=self._tril)
         self._draws += 1

@@ -375,6 +375,25 @@ def gp_prior_precision(H, dt, D, sigma_start, sigma_gp, sigma_goal, goal_directe
     return A.t() @ Qinv @ A
 
 
+def gp_prior_precision_general(H, dt, D, K_s_inv, K_gp_inv, K_g_inv=None):
+    """fp64 K^-1 = A^T Q^-1 A for ARBITRARY start / GP / goal precisions, assembled densely exactly as
+    MultiMPPrior.get_const_vel_covariance does (mp_priors_multi.py:213-251)."""
+    ta = dict(dtype=torch.float64, device='cpu')
+    dim = 2 * D
+    M = dim * H
+    Phi = gp_phi(D, dt, ta)
+    A = torch.eye(M, **ta)
+    for t in range(H - 1):
+        A[dim * (t + 1):dim * (t + 2), dim * t:dim * (t + 1)] += -Phi
+    blocks = [torch.as_tensor(K_s_inv, **ta)] + [torch.as_tensor(K_gp_inv, **ta)] * (H - 1)
+    if K_g_inv is not None:
+        bg = torch.zeros(dim, M, **ta)
+        bg[:, -dim:] = torch.eye(dim, **ta)
+        A = torch.cat((A, bg))
+        blocks.append(torch.as_tensor(K_g_inv, **ta))
+    return A.t() @ torch.block_diag(*blocks) @ A
+
+
 # ------------------------------------------------------------------------------------------------
 # MPPI on point-particle dynamics  (mppi.py, priors/gaussian.py, dynamics/point.py)
 # ------------------------------------------------------------------------------------------------

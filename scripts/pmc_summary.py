@@ -119,6 +119,20 @@ if kc:   # CHOMP C2 (scripts/prof_chomp.py: bench.py's c2 entry, MPB_CHOMP_ITERS
     with open(os.path.join(prof, f'{tag}_pmc_chomp.json'), 'w') as fh:
         json.dump(out, fh, indent=1)
 
+km = [k for k in summary if 'mppi_kernel' in k]
+if km:   # MPPI, NP = 1024 problems (scripts/prof_mppi.py: bench.py's mppi entry, 50 iterations per launch)
+    k = km[0]
+    s = summary[k]
+    waves = grid[k][0] // 64
+    iters = int(os.environ.get('MPB_MPPI_ITERS', 50))
+    out = {'kernel': k.split('(')[0], 'workload': 'MPPI point mass, 1024 problems x S=32 x T=64 x c=2, %d iterations per launch (scripts/prof_mppi.py)' % iters,
+           'waves_per_launch': waves, 'iterations_per_launch': iters, 'vgpr': grid[k][2], 'lds_bytes': grid[k][4], 'scratch_bytes': grid[k][5]}
+    for c in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_LDS_BANK_CONFLICT', 'SQ_LDS_IDX_ACTIVE'):
+        if c in s:
+            out[c + '_per_wave_iteration'] = s[c] / waves / iters
+    with open(os.path.join(prof, f'{tag}_pmc_mppi.json'), 'w') as fh:
+        json.dump(out, fh, indent=1)
+
 ka = [k for k in summary if 'stomp_sample_cost' in k and 'true' in k]
 if ka:
     k = ka[0]

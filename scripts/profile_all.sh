@@ -1,0 +1,34 @@
+#!/bin/bash
+# Everything kept under profiles/ for one round, in one go (run on the GPU box from the repo root; ~6 minutes):
+#     bash scripts/profile_all.sh r03
+#   * bench.py (the driver's command)                         -> profiles/<tag>_bench.json
+#   * rocprofv3 stats + PMC of the headline (profile_round.sh) -> <tag>_kernel_stats_bench.csv, <tag>_pmc_per_wave.md, <tag>_pmc_stomp.json
+#   * GPMP2 C4 (profile_gpmp2.sh), CHOMP C2, MPPI NP=1024      -> <tag>_gpmp2_*, <tag>_chomp_*, <tag>_mppi_*
+#   * large-B sweep                                             -> <tag>_large_b_sweep.txt
+#   * shapes beyond H = 64 / gradient evaluators                -> <tag>_other_shapes.txt
+# rocprofv3 counter passes run with --kernel-trace only (never with a sys / hip / hsa trace).
+set -e
+TAG=${1:-rXX}
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+python3 bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+cp gpurun_out/${TAG}_bench.json profiles/${TAG}_bench.json
+echo "bench done"
+bash scripts/profile_round.sh $TAG 20 > gpurun_out/${TAG}_profile_round.log 2>&1
+echo "headline passes done"
+bash scripts/profile_gpmp2.sh $TAG > gpurun_out/${TAG}_profile_gpmp2.log 2>&1
+python3 scripts/pmc_summary.py gpurun_out/prof_${TAG}_gpmp2 ${TAG}_gpmp2 > /dev/null
+echo "gpmp2 passes done"
+for drv in chomp mppi; do
+  OUT=gpurun_out/prof_${TAG}_$drv
+  mkdir -p $OUT
+  rocprofv3 --kernel-trace --stats -d $OUT/stats -o s -- python3 scripts/prof_$drv.py > $OUT/stats.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $OUT/pmc1 -o p -- python3 scripts/prof_$drv.py > $OUT/pmc1.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM SQ_INSTS_BRANCH SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA -d $OUT/pmc2 -o p -- python3 scripts/prof_$drv.py > $OUT/pmc2.log 2>&1
+  python3 scripts/pmc_summary.py $OUT ${TAG}_$drv > /dev/null
+  echo "$drv passes done"
+done
+python3 scripts/bench_large_b.py > profiles/${TAG}_large_b_sweep.txt 2> gpurun_out/${TAG}_large_b.err
+echo "large-B sweep done"
+( python3 scripts/bench_hx.py; python3 scripts/bench_grad.py ) > profiles/${TAG}_other_shapes.txt 2> gpurun_out/${TAG}_other.err
+echo "all done"

@@ -347,6 +347,34 @@ def gen_gp_prior(name, D, H, dt, seed):
 
 
 @fixture
+def gen_gp_prior_general(name, D, H, dt, seed):
+    """MultiMPPrior with NON-isotropic start / GP / goal precisions (mp_priors_multi.py:213-251 takes arbitrary matrices):
+    random SPD K_s_inv, K_gp_inv, K_g_inv; two goal modes."""
+    ta = TA64
+    g = torch.Generator().manual_seed(seed + 100)
+    def spd(n, lo, hi):
+        A = torch.randn(n, n, generator=g, dtype=torch.float64)
+        Q, _ = torch.linalg.qr(A)
+        ev = torch.exp(torch.linspace(np.log(lo), np.log(hi), n, dtype=torch.float64))
+        return (Q * ev) @ Q.t()
+    sd = 2 * D
+    sK, gK = spd(sd, 1e2, 1e6), spd(sd, 1e3, 1e5)
+    Qi = spd(sd, 1e-1, 1e3)
+    start = torch.cat([torch.linspace(-0.5, 0.3, D), torch.zeros(D)]).to(**ta)
+    goals = torch.stack([torch.cat([torch.linspace(0.4, -0.2, D), torch.zeros(D)]),
+                         torch.cat([torch.linspace(-0.1, 0.6, D), torch.zeros(D)])]).to(**ta)
+    torch.manual_seed(seed)
+    with EpsRecorder() as rec:
+        prior = MultiMPPrior(H - 1, dt, sd, D, sK, Qi, start, K_g_inv=gK, goal_states=goals, tensor_args=ta)
+        smp = prior.sample(5)
+    np.savez_compressed(
+        os.path.join(HERE, name + '.npz'), planner='gp_prior_general', D=D, H=H, dt=dt, start=npf(start), goals=npf(goals),
+        K_s_inv=npf(sK), K_gp_inv=npf(Qi), K_g_inv=npf(gK), Sigma_inv=npf(prior.Sigma_inv), mean=npf(prior.means),
+        scale_tril=npf(prior.dist._unbroadcasted_scale_tril), eps=npf(rec.draws[0]), samples=npf(smp))
+    print(name, 'samples', smp.shape)
+
+
+@fixture
 def gen_cost_terms(name, robot, D, H, G_, npg, S, dt, seed):
     """The trajectory-only cost classes of cost_functions.py (CostGP :234-314, CostGPTrajectory :317-357,
     the position-only wrapper :360-368, CostSmoothnessCHOMP :371-390, CostJointLimits :393-429,
@@ -465,6 +493,7 @@ def main():
 
     # GP-prior initial sampling
     gen_gp_prior('gp_prior_d2_h8', D=2, H=8, dt=0.04, seed=0)
+    gen_gp_prior_general('gp_prior_general_d2_h6', D=2, H=6, dt=0.05, seed=2)
 
     # trajectory-only cost classes
     gen_cost_terms('cost_terms_pm2d', pm, D=2, H=64, G_=2, npg=3, S=4, dt=0.04, seed=0)

@@ -373,9 +373,10 @@ def test_factor_classes(gpu_device):
     assert smp.shape == (1, 6, H2n, 2 * D2)
     # same torch seed -> same standard normals as the golden run (drawn on the CPU in the reference's order)
     _close(smp.reshape(1, 6, H2n, 2 * D2), gp8['samples'], 1e-5)
-    with pytest.raises(NotImplementedError):
-        MultiMPPrior(H2n - 1, float(gp8['dt']), 2 * D2, D2, sK * torch.arange(1, 2 * D2 + 1).diag().double(), Qi,
-                     T(gp8['start']), tensor_args=ta64d)
+    # non-isotropic precisions take the dense path (tests/test_gpu_api_holes.py checks it against a reference golden)
+    aniso = MultiMPPrior(H2n - 1, float(gp8['dt']), 2 * D2, D2, sK @ torch.arange(1, 2 * D2 + 1).diag().double(), Qi,
+                         T(gp8['start']), tensor_args=ta64d)
+    assert aniso._general and aniso.sample(3).shape == (1, 3, H2n, 2 * D2)
 
 
 @pytest.mark.parametrize('kind', ['pm2d', 'panda', 'panda_boxes_only'])

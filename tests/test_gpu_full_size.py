@@ -370,11 +370,14 @@ def test_bench_line_contract(gpu_device):
     assert h['unit'] == 'GB/s' and h['peak'] == 8000.0 and abs(h['frac'] - h['achieved'] / h['peak']) < 1e-9
     assert abs(h['achieved'] - h['algorithmic_bytes_per_launch'] / (r['kernel_ms'] * 1e-3) / 1e9) < 1e-6 * h['achieved']
     sp = j['repeats']
-    assert sp['n'] == 5 and sp['ms_per_step_min'] <= sp['ms_per_step_median'] <= sp['ms_per_step_max']
+    assert sp['n'] == 9 and sp['ms_per_step_min'] <= sp['ms_per_step_median'] <= sp['ms_per_step_max']
     assert abs(sp['ms_per_step_median'] - j['ms_per_step']) < 1e-9
     # the other BASELINE configs ride on the same line: C5's per-GPU load, C2 (CHOMP), C4 (GPMP2 at B = 2048)
-    for k in ('c5', 'c2', 'c4'):
+    for k in ('c5', 'c2', 'c4', 'h128'):
         assert j[k]['value'] > 0 and j[k]['unit'] == 'iters/s' and 'workload' in j[k], k
+    assert j['h128']['path'].startswith('persistent') and 'H=128' in j['h128']['workload']
+    assert j['mppi']['value'] > 0 and j['mppi']['unit'] == 'problem-iters/s'
+    assert r['kernel_ms'] <= j['ms_per_step']              # device-clock span of the timed launches themselves
     assert '4096 particles' in j['c5']['workload'] and 'B=1024' in j['c2']['workload'] and 'B=2048' in j['c4']['workload']
     assert j['c4']['roofline']['bound'] == 'mfma' and j['c4']['dtype'] == 'f64'
     # timings are reported, not asserted against a bar: a rare ~70 ms device stall on this pool would fail it

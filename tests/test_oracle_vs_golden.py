@@ -133,6 +133,21 @@ def test_gp_prior():
                                g['samples'], rtol=1e-9, atol=1e-12)
 
 
+def test_gp_prior_general_precisions():
+    """MultiMPPrior with non-isotropic K_s_inv / K_gp_inv / K_g_inv, two goal modes: precision, scale_tril, samples."""
+    g = load_golden('gp_prior_general_d2_h6')
+    D, H = int(g['D']), int(g['H'])
+    Kinv = O.gp_prior_precision_general(H, float(g['dt']), D, g['K_s_inv'], g['K_gp_inv'], g['K_g_inv'])
+    np.testing.assert_allclose(Kinv.numpy(), g['Sigma_inv'], rtol=1e-12, atol=1e-9 * np.abs(g['Sigma_inv']).max())
+    L = O.precision_to_scale_tril(Kinv)
+    np.testing.assert_allclose(L.numpy(), g['scale_tril'][0], rtol=1e-7, atol=1e-12)
+    mean = T(g['mean'])                                             # (modes, M)
+    eps = T(g['eps'])                                               # (n, modes, M)
+    smp = mean.unsqueeze(0) + torch.einsum('ij,nmj->nmi', L, eps)
+    want = T(g['samples'])                                          # (modes, n, H, 2D)
+    np.testing.assert_allclose(smp.transpose(0, 1).reshape(want.shape).numpy(), want.numpy(), rtol=1e-9, atol=1e-12)
+
+
 @pytest.mark.parametrize('name', ['sgpmp_pm2d_h16_f64', 'sgpmp_panda_h16_f64'])
 def test_stoch_gpmp_iterations(name):
     g = load_golden(name)
