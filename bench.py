@@ -444,6 +444,8 @@ def main():
     ap.add_argument('--pos-only', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true', help='main line only (profiling runs)')
+    ap.add_argument('--main-only', action='store_true', help='(rocprofv3 stats pass) no side measurements either: the only launches of the '
+                    'persistent kernel are the pre-heat, warm-up and timed K-step launches, so the trace\'s average is the timed launch')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -505,22 +507,24 @@ def main():
     # one iteration of the timed launch, its fixed part included: the device-clock span of the timed launches themselves
     # where the kernel reports it (persistent path), else the event figure
     k_ms = (span_ms if span_ms else timed_launch_ms) / args.steps
-    t2a, t2b = launch_ms(n_prof), launch_ms(2 * n_prof)
-    later_ms = (t2b - t2a) / n_prof                        # one of iterations n_prof .. 2 n_prof
-    l1, l2 = launch_ms(1), launch_ms(2)
-    launch_fixed_ms = max(2 * l1 - l2, 0.0)                # launch + constants into LDS + first draws: t(1) - (t(2) - t(1))
-    # the two-kernel path (mpb_stomp_step: sample + cost kernel, update kernel per iteration) on the same problem
-    two = STOMP_two_kernel(wl, cost, dev, rank, P)
-    two.optimize(opt_iters=200)
-    torch.cuda.synchronize()
-    tw = []
-    for _ in range(5):      # median of 5: a Python-driven loop of short launches occasionally catches a ~70 ms device stall
-        t0 = time.perf_counter()
-        two.optimize(opt_iters=args.steps)
+    later_ms = launch_fixed_ms = two_ms = None
+    if not args.main_only:
+        t2a, t2b = launch_ms(n_prof), launch_ms(2 * n_prof)
+        later_ms = (t2b - t2a) / n_prof                        # one of iterations n_prof .. 2 n_prof
+        l1, l2 = launch_ms(1), launch_ms(2)
+        launch_fixed_ms = max(2 * l1 - l2, 0.0)                # launch + constants into LDS + first draws: t(1) - (t(2) - t(1))
+        # the two-kernel path (mpb_stomp_step: sample + cost kernel, update kernel per iteration) on the same problem
+        two = STOMP_two_kernel(wl, cost, dev, rank, P)
+        two.optimize(opt_iters=200)
         torch.cuda.synchronize()
-        tw.append(time.perf_counter() - t0)
-    two_ms = 1e3 * sorted(tw)[2] / args.steps
-    del two
+        tw = []
+        for _ in range(5):      # median of 5: a Python-driven loop of short launches occasionally catches a ~70 ms device stall
+            t0 = time.perf_counter()
+            two.optimize(opt_iters=args.steps)
+            torch.cuda.synchronize()
+            tw.append(time.perf_counter() - t0)
+        two_ms = 1e3 * sorted(tw)[2] / args.steps
+        del two
     # algorithmic bytes of one iteration of the persistent kernel: samples written, costs + weights written; the means
     # and every constant stay in LDS (SURVEY 8d's formula additionally counts the means read + written per iteration)
     alg_bytes_k = 4 * (P * S * H * d + 2 * P * S)
@@ -549,11 +553,11 @@ def main():
                  'shows the kernels themselves longer: the profiled dispatch and the blocking wait behind it change the clock state)',
                  'launch_fixed_ms': launch_fixed_ms,
                  'kernel_ms_iterations_%d_to_%d' % (n_prof, 2 * n_prof): later_ms,
-                 'two_kernel_path_ms_per_step': two_ms, 'two_kernel_path_iters_per_sec': 1e3 / two_ms})
+                 'two_kernel_path_ms_per_step': two_ms, 'two_kernel_path_iters_per_sec': (1e3 / two_ms) if two_ms else None})
 
     # ---- BASELINE configs[4]'s per-GPU load with the same protocol (every N)
     c5 = None
-    if not args.no_other_configs:
+    if not args.no_other_configs and not args.main_only:
         del planner
         torch.cuda.empty_cache()
         P5 = 4096
@@ -597,7 +601,7 @@ def main():
                 'sample': 'oracle/planners_ref.py stomp_iteration (PyTorch-CPU restatement of stomp.py:157-160 + build-defined '
                           'FK/SDF) on the full workload (P=%d x S=%d), median of %d iterations = %.3f s, %d intra-op threads'
                           % (P, S, n_it, med, cores)}
-        if world == 1 and not args.no_other_configs:
+        if world == 1 and not args.no_other_configs and not args.main_only:
             line['c2'] = bench_c2(dev, 500, with_cpu=not args.no_cpu_baseline)
             line['c4'] = bench_c4(dev, 10, with_cpu=not args.no_cpu_baseline)
             line['h128'] = bench_h128(dev, 50)

@@ -31,4 +31,8 @@ done
 python3 scripts/bench_large_b.py > profiles/${TAG}_large_b_sweep.txt 2> gpurun_out/${TAG}_large_b.err
 echo "large-B sweep done"
 ( python3 scripts/bench_hx.py; python3 scripts/bench_grad.py ) > profiles/${TAG}_other_shapes.txt 2> gpurun_out/${TAG}_other.err
+# what travels back from the GPU box is gpurun_out/ (<= 64 MiB): the summaries, not the raw rocprofv3 databases
+mkdir -p gpurun_out/profiles_${TAG}
+cp profiles/${TAG}_* gpurun_out/profiles_${TAG}/
+rm -rf gpurun_out/prof_${TAG} gpurun_out/prof_${TAG}_gpmp2 gpurun_out/prof_${TAG}_chomp gpurun_out/prof_${TAG}_mppi
 echo "all done"

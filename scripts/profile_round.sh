@@ -10,7 +10,7 @@ ITERS=${2:-20}        # iterations per profiled launch: the driver times --steps
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- python3 bench.py --steps $ITERS --warmup 5 --no-cpu-baseline --no-other-configs > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- python3 bench.py --steps $ITERS --warmup 5 --no-cpu-baseline --main-only > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 echo "stats pass done"
 export MPB_ITERS=$ITERS MPB_FUSED=1 MPB_LAUNCHES=24     # scripts/prof_stomp.py: the persistent kernel, 6 launches of 200 iterations from the initial means = bench.py's timed launch
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $OUT/pmc1 -o p -- python3 scripts/prof_stomp.py > $OUT/pmc1.log 2>&1
