@@ -73,6 +73,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
     __shared__ float4 otab[MPB_GRID_MAX_SPH + 1];
     __shared__ __attribute__((aligned(16))) float mean_l[HP * DX];
     __shared__ __attribute__((aligned(16))) float delta[16 * DLD];
+    __shared__ __attribute__((aligned(16))) float sig_l[HC == 1 ? 64 * DLD : 4];   // H <= 64: Sigma stays in LDS (padded rows)
     __shared__ float cst[FUSED_WAVES];
     __shared__ float ewl[HX_MAX_NB * FUSED_WAVES];     // exp(logit - batch max) of the unit's samples
     __shared__ float mbl[HX_MAX_NB];                   // the batches' maxima
@@ -114,6 +115,12 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
         }
     }
     for (int i = tid; i < 16 * DLD; i += FUSED_THREADS) delta[i] = 0.f;        // (padding rows / columns stay zero)
+    if (HC == 1) {
+        for (int v = tid; v < 64 * 64; v += FUSED_THREADS) {
+            const int row = v >> 6, col = v & 63;
+            sig_l[row * DLD + col] = (row < H && col < H) ? Sigma[(size_t)row * H + col] : 0.f;
+        }
+    }
     __syncthreads();
     const int unit = __builtin_amdgcn_readfirstlane((int)s_ticket);
     const int p = exchange ? unit / nc : unit;
@@ -430,7 +437,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
             for (int ks4 = 0; ks4 < HP / 16; ++ks4) {
                 const int k0 = 16 * ks4 + 4 * g;
                 f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (row < H) {
+                if (HC == 1) {
+                    a = *reinterpret_cast<const f32x4*>(sig_l + row * DLD + k0);
+                } else if (row < H) {
                     if (vec) {
                         if (k0 < H) a = *reinterpret_cast<const f32x4*>(Sigma + (size_t)row * H + k0);
                     } else {
