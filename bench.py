@@ -104,15 +104,20 @@ class Clock:
 
     def __init__(self, dist, dev):
         self.dist, self.dev = dist, dev
+        self._flag = torch.zeros(1, device=dev) if dist is not None else None
 
     def barrier(self, spin=False):
-        if spin:
+        """Every rank has finished everything it enqueued.  Across ranks the barrier is an all_reduce of one element on
+        the process group's backend (on "nccl" that is what ProcessGroupNCCL.barrier itself runs before it blocks the host
+        in a device synchronize); here the host spins on an event behind it instead of sleeping, then calls
+        torch.cuda.synchronize(), which returns at once."""
+        if self.dist is not None:
+            self.dist.all_reduce(self._flag)
+        if spin or self.dist is not None:
             ev = torch.cuda.Event()
             ev.record()
             while not ev.query():
                 pass
-        if self.dist is not None:
-            self.dist.barrier()
         torch.cuda.synchronize()
 
     def blocks(self, fn, repeats, before=None):
@@ -167,7 +172,10 @@ def STOMP_two_kernel(wl, cost, dev, rank, P):
 
 def run_stomp(planner, clock, dist, world, steps, warmup, repeats, preheat):
     """W untimed steps, then R blocks of EXACTLY `steps` steps (one C-ABI call = 2K launches) + the final gather."""
-    gathered = [torch.empty_like(planner._particle_means) for _ in range(world)] if dist is not None else None
+    # the final gather's destination: one flat (world * P, H, d) tensor (all_gather_into_tensor: one RCCL kernel, no
+    # per-rank copy-out kernels)
+    gathered = (torch.empty((world * planner._particle_means.shape[0],) + tuple(planner._particle_means.shape[1:]),
+                            device=planner._particle_means.device) if dist is not None else None)
     means_init = planner._particle_means.clone()
     if preheat:
         # device pre-heat (untimed set-up, not part of W or K): `preheat` untimed blocks of the very shape that is timed below
@@ -182,13 +190,18 @@ def run_stomp(planner, clock, dist, world, steps, warmup, repeats, preheat):
             torch.cuda.synchronize()
         planner._particle_means.copy_(means_init)
     planner.optimize(opt_iters=warmup)
+    def gather():
+        if dist.get_backend() == 'nccl':
+            dist.all_gather_into_tensor(gathered, planner._particle_means)
+        else:                                        # (gloo rehearsals on a one-GPU box)
+            dist.all_gather(list(gathered.chunk(world)), planner._particle_means)
     if dist is not None:                             # RCCL communicator / xGMI set-up is part of the warm-up
-        dist.all_gather(gathered, planner._particle_means)
+        gather()
 
     def block():
         planner.optimize(opt_iters=steps)
         if dist is not None:
-            dist.all_gather(gathered, planner._particle_means)   # final gather of the (P,H,d) means over xGMI
+            gather()                                 # final gather of the (P,H,d) means over xGMI
     spans = []       # the timed launches' own duration on the device's clock (the kernel stamps its pinned status block: free)
 
     def reset():
@@ -591,7 +604,8 @@ def main():
         }
         if dist is not None:
             line['dist'] = {'backend': dist.get_backend(), 'world': world, 'forced_at_world_1': bool(forced and world == 1),
-                            'collectives_in_timed_region': 'barrier x2, all_gather of the (P,H,d) means, all_reduce(MAX) of the clock'}
+                            'collectives_in_timed_region': 'all_gather_into_tensor of the (P,H,d) means + the closing barrier (all_reduce of one element, host '
+                            'spinning on an event behind it); the opening barrier and the all_reduce(MAX) of the clock are outside'}
         if c5 is not None:
             line['c5'] = c5
         if world == 1 and not args.no_cpu_baseline:
