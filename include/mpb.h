@@ -312,7 +312,8 @@ int mpb_chomp_step(float *means, const float *R, const float *geom, int geom_fla
  *                         the sums and passes diag_mean = sum / B_global to mpb_gpmp2_solve;
  *   mpb_gpmp2_solve     : assemble + block-Cholesky solve + x += step_size * dtheta.
  *                         trust_region == 0: damping delta * I (diag_mean ignored);
- *                         else delta * diag_mean (diag_mean NULL: workspace mean written by mpb_gpmp2_step).
+ *                         else delta * diag_mean (diag_mean NULL: the LOCAL mean mpb_gpmp2_diag leaves in the workspace
+ *                         when it is called without diag_sum_out, as mpb_gpmp2_step does).
  *                         costs_out (B) optional: b^T K b of the iterate BEFORE the update (gpmp2.py:493-495).
  *   mpb_gpmp2_step      : n_iters full iterations on one GPU (mean over the local B).
  * sigma_goal <= 0 means "no goal factor" (precision 0: GPMP2 without goals, gpmp2.py:62-78) -- an infinite sigma is not a

@@ -136,8 +136,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void
 // local SUM over particles of diag(A^T K A) (quirk Q9 needs its batch mean).  grid = H, block = 256.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gpmp2_diag_kernel(const float* __restrict__ jac, double* __restrict__ diag_sum,
-                                                         int B, int H, int D, int F, double dt, double ks, double kgp,
-                                                         double kg, double kc) {
+                                                         double* __restrict__ diag_mean, int B, int H, int D, int F, double dt,
+                                                         double ks, double kgp, double kg, double kc) {
     const int t = blockIdx.x;
     const int dim = 2 * D;
     __shared__ double red[4][MPB_MAX_DOF];
@@ -174,12 +174,8 @@ __global__ __launch_bounds__(256) void gpmp2_diag_kernel(const float* __restrict
             s += kc * h2;
         }
         diag_sum[(size_t)t * dim + i] = s;
+        if (diag_mean != nullptr) diag_mean[(size_t)t * dim + i] = s * (1.0 / (double)B);   // (one GPU: the batch mean of quirk Q9 at once)
     }
-}
-
-__global__ void gpmp2_scale_kernel(const double* __restrict__ in, double* __restrict__ out, int n, double s) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = in[i] * s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -726,8 +722,10 @@ extern "C" int mpb_gpmp2_diag(void* workspace, double* diag_sum_out, int B, int 
     if (!gp_shape_ok(B, H, D) || n_fields < 1 || n_fields > MPB_MAX_FIELDS) return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_diag: bad shape");
     GpWork w = gp_carve(workspace, B, H, D);
     double* out = diag_sum_out ? diag_sum_out : w.diag_sum;
-    hipLaunchKernelGGL(gpmp2_diag_kernel, dim3(H), dim3(256), 0, (hipStream_t)stream, w.jac, out, B, H, D, n_fields,
-                       (double)dt,
+    // workspace mode (one GPU): the LOCAL mean goes to the workspace in the same pass (what mpb_gpmp2_solve reads when it is
+    // given no diag_mean); with diag_sum_out the host all-reduces the sums over the shards and passes the global mean itself
+    hipLaunchKernelGGL(gpmp2_diag_kernel, dim3(H), dim3(256), 0, (hipStream_t)stream, w.jac, out,
+                       diag_sum_out ? (double*)nullptr : w.diag_mean, B, H, D, n_fields, (double)dt,
                        1.0 / ((double)sigma_start * sigma_start), 1.0 / ((double)sigma_gp * sigma_gp),
                        (sigma_goal > 0.f ? 1.0 / ((double)sigma_goal * sigma_goal) : 0.0), 1.0 / ((double)sigma_coll * sigma_coll));
     return mpb_check_launch("mpb_gpmp2_diag");
@@ -781,16 +779,12 @@ extern "C" int mpb_gpmp2_step(float* x, const float* start, const float* goal, c
     if (!gp_shape_ok(B, H, D) || n_iters < 0 || n_fields < 1 || n_fields > MPB_MAX_FIELDS)
         return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_step: bad shape");
     if (B == 0) return MPB_OK;
-    GpWork w = gp_carve(workspace, B, H, D);
     for (int it = 0; it < n_iters; ++it) {
         int rc = mpb_gpmp2_linearize(x, geom, geom_flags, workspace, B, H, D, n_interp, stream);
         if (rc) return rc;
         if (trust_region) {
             rc = mpb_gpmp2_diag(workspace, nullptr, B, H, D, n_fields, dt, sigma_start, sigma_gp, sigma_goal, sigma_coll, stream);
             if (rc) return rc;
-            const int n = H * 2 * D;
-            hipLaunchKernelGGL(gpmp2_scale_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, w.diag_sum,
-                               w.diag_mean, n, 1.0 / (double)B);
         }
         rc = mpb_gpmp2_solve(x, start, goal, nullptr, workspace, costs_out, B, H, D, n_fields, dt, sigma_start, sigma_gp, sigma_goal,
                              sigma_coll, delta, trust_region, step_size, stream);

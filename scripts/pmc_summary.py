@@ -18,6 +18,31 @@ for f in glob.glob(os.path.join(src, 'stats', '**', '*_results.db'), recursive=T
     per = defaultdict(list)
     for name, dur in db.execute('select name, duration from kernels'):
         per[name].append(dur)
+    # every dispatch of the persistent STOMP kernel in launch order: the stats pass of profile_round.sh runs
+    # `bench.py --steps K --warmup 5 --main-only`, i.e. pre-heat blocks (untimed), ONE warm-up launch of 5 steps, the R timed
+    # K-step launches and the R launches with a HIP event pair on the dispatch
+    try:
+        seq = [(n, d) for n, d in db.execute('select name, duration from kernels order by start')]
+    except sqlite3.Error:
+        seq = [(n, d) for n, d in db.execute('select name, duration from kernels')]
+    fused = [d for n, d in seq if 'stomp_fused' in n]
+    if fused:
+        with open(os.path.join(prof, f'{tag}_fused_dispatches.txt'), 'w') as fh:
+            fh.write('# rocprofv3 --kernel-trace: duration (us) of every dispatch of the persistent STOMP kernel, in launch order, of\n'
+                     '# `bench.py --steps K --warmup 5 --main-only` (scripts/profile_round.sh): pre-heat blocks, one 5-step warm-up launch\n'
+                     '# (the short one), the R = 9 TIMED K-step launches, then the R = 9 launches with an event pair on the dispatch.\n')
+            fh.write(' '.join('%.1f' % (d / 1e3) for d in fused) + '\n')
+            short = [i for i, d in enumerate(fused) if d < 0.5 * sorted(fused)[len(fused) // 2]]
+            if short:
+                w = short[-1]
+                timed = fused[w + 1:w + 10]
+                prof_ = fused[w + 10:w + 19]
+                if timed:
+                    fh.write('timed launches (the 9 after the warm-up launch): mean %.1f us, median %.1f us\n'
+                             % (sum(timed) / len(timed) / 1e3, sorted(timed)[len(timed) // 2] / 1e3))
+                if prof_:
+                    fh.write('event-profiled launches (the next 9): mean %.1f us, median %.1f us\n'
+                             % (sum(prof_) / len(prof_) / 1e3, sorted(prof_)[len(prof_) // 2] / 1e3))
     tot = sum(sum(v) for v in per.values())
     with open(os.path.join(prof, f'{tag}_kernel_stats_bench.csv'), 'w') as fh:
         fh.write('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","MedianNs"\n')

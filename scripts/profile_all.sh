@@ -34,5 +34,6 @@ echo "large-B sweep done"
 # what travels back from the GPU box is gpurun_out/ (<= 64 MiB): the summaries, not the raw rocprofv3 databases
 mkdir -p gpurun_out/profiles_${TAG}
 cp profiles/${TAG}_* gpurun_out/profiles_${TAG}/
+cp gpurun_out/prof_${TAG}/stats/*_results.db gpurun_out/profiles_${TAG}/ 2>/dev/null || true
 rm -rf gpurun_out/prof_${TAG} gpurun_out/prof_${TAG}_gpmp2 gpurun_out/prof_${TAG}_chomp gpurun_out/prof_${TAG}_mppi
 echo "all done"
