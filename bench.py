@@ -554,6 +554,18 @@ def main():
                 'frac': ginstr / VALU_PEAK_GINSTR, 'valu_instructions_per_wave_iteration': valu, 'pmc_source': pmc_file}
     else:   # no committed counter summary for this shape: the nominal bound
         roof = {'bound': 'hbm', 'achieved': hbm_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': hbm_gbs / HBM_PEAK_GBS}
+    mfma = pmc.get('SQ_INSTS_MFMA_per_wave_iteration') if (pmc and c3_shape) else None
+    if valu and mfma is not None:
+        # v_mfma_f32_16x16x4_f32 does not run UNDER fp32 VALU work on gfx950 (profiles/r03_microbench_overlap.txt: an MFMA wave
+        # and an FMA wave on one SIMD take the SUM of their times, and so does one interleaved stream): the matrix product of
+        # the noise occupies the same fp32 pipe for 32 cycles per instruction.  Pipe cycles per wave-iteration =
+        # 2 x VALU + 32 x MFMA (quarter-rate VALU instructions counted at the full rate: a lower bound of the occupancy)
+        cyc = 2.0 * valu + 32.0 * mfma
+        pipe = cyc * (P * S) / (k_ms * 1e-3) / 1e9
+        roof['fp32_pipe'] = {'achieved': pipe, 'peak': 1024 * 2.4, 'unit': 'G SIMD-cycles/s', 'frac': pipe / (1024 * 2.4),
+                             'mfma_instructions_per_wave_iteration': mfma,
+                             'note': 'fp32 VALU issue (2 cycles per wave-instruction) + fp32 MFMA (32 cycles each) share one pipe per '
+                                     'SIMD; peak = 1024 SIMDs x 2.4 GHz; `frac` above counts the VALU instructions alone, as in rounds 1-2'}
     roof.update({'kernel': 'stomp_fused_kernel<%d, model> (persistent: one launch = all iterations)' % d, 'traffic': traffic,
                  'hbm': {'achieved': hbm_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': hbm_gbs / HBM_PEAK_GBS,
                          'algorithmic_bytes_per_launch': alg_bytes_k, 'note': 'per iteration of the persistent launch'},

@@ -11,9 +11,6 @@ set -e
 TAG=${1:-rXX}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-python3 bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
-cp gpurun_out/${TAG}_bench.json profiles/${TAG}_bench.json
-echo "bench done"
 bash scripts/profile_round.sh $TAG 20 > gpurun_out/${TAG}_profile_round.log 2>&1
 echo "headline passes done"
 bash scripts/profile_gpmp2.sh $TAG > gpurun_out/${TAG}_profile_gpmp2.log 2>&1
@@ -31,6 +28,10 @@ done
 python3 scripts/bench_large_b.py > profiles/${TAG}_large_b_sweep.txt 2> gpurun_out/${TAG}_large_b.err
 echo "large-B sweep done"
 ( python3 scripts/bench_hx.py; python3 scripts/bench_grad.py ) > profiles/${TAG}_other_shapes.txt 2> gpurun_out/${TAG}_other.err
+# the bench line LAST: it reads the instruction counts of the PMC summaries written above (profiles/<tag>_pmc_*.json)
+python3 bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+cp gpurun_out/${TAG}_bench.json profiles/${TAG}_bench.json
+echo "bench done"
 # what travels back from the GPU box is gpurun_out/ (<= 64 MiB): the summaries, not the raw rocprofv3 databases
 mkdir -p gpurun_out/profiles_${TAG}
 cp profiles/${TAG}_* gpurun_out/profiles_${TAG}/
