@@ -120,15 +120,31 @@ class Clock:
                 pass
         torch.cuda.synchronize()
 
+    def wait(self):
+        """This rank has finished everything it enqueued (host spin on an event, then synchronize)."""
+        ev = torch.cuda.Event()
+        ev.record()
+        while not ev.query():
+            pass
+        torch.cuda.synchronize()
+
     def blocks(self, fn, repeats, before=None):
+        """`fn` returns True when the LAST thing it enqueued is a collective that completes on no rank before every rank has
+        enqueued it behind its own steps (the final all-gather of the means): that collective IS the closing barrier of the
+        block -- no rank leaves it before all ranks have finished their K steps -- and the bracket is closed by waiting for
+        it; a second collective behind it would only add its own latency to the timed region.  Otherwise (single process,
+        or no such collective) the explicit barrier closes the block."""
         out = []
         for _ in range(repeats):
             if before is not None:
                 before()                 # untimed: every block starts from the same state
             self.barrier()
             t0 = time.perf_counter()
-            fn()
-            self.barrier(spin=True)
+            closed = fn()
+            if closed and self.dist is not None:
+                self.wait()
+            else:
+                self.barrier(spin=True)
             el = time.perf_counter() - t0
             if self.dist is not None:
                 t = torch.tensor([el], device=self.dev, dtype=torch.float64)
@@ -202,6 +218,7 @@ def run_stomp(planner, clock, dist, world, steps, warmup, repeats, preheat):
         planner.optimize(opt_iters=steps)
         if dist is not None:
             gather()                                 # final gather of the (P,H,d) means over xGMI
+        return dist is not None                      # (the all-gather closes the block: Clock.blocks)
     spans = []       # the timed launches' own duration on the device's clock (the kernel stamps its pinned status block: free)
 
     def reset():
@@ -616,8 +633,10 @@ def main():
         }
         if dist is not None:
             line['dist'] = {'backend': dist.get_backend(), 'world': world, 'forced_at_world_1': bool(forced and world == 1),
-                            'collectives_in_timed_region': 'all_gather_into_tensor of the (P,H,d) means + the closing barrier (all_reduce of one element, host '
-                            'spinning on an event behind it); the opening barrier and the all_reduce(MAX) of the clock are outside'}
+                            'collectives_in_timed_region': 'ONE: the final all_gather_into_tensor of the (P,H,d) means, which is also the closing barrier of the '
+                            'block (it completes on no rank before every rank has contributed, i.e. finished its K steps; the host spins on an '
+                            'event behind it, then synchronizes); the opening barrier (all_reduce of one element) and the all_reduce(MAX) of '
+                            'the clock are outside'}
         if c5 is not None:
             line['c5'] = c5
         if world == 1 and not args.no_cpu_baseline:
