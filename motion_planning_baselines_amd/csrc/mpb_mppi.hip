@@ -9,8 +9,8 @@
 //
 // The reference walks the horizon in a Python loop (one dynamics + cost call per step).  Velocity-controlled
 // point dynamics are x_{t+1} = x_t + clamp(u_t) dt, i.e. a prefix sum over time, so here the horizon is the
-// lane axis: the T x T noise product is T fma per lane against an LDS-resident transposed scale_tril, the
-// rollout is a wave scan, the per-step costs (incl. the collision field) are evaluated by all lanes at once
+// lane axis: the T x T noise product runs on the matrix pipe for all samples at once (T <= 64; beyond that T fma per
+// lane against an LDS-resident transposed scale_tril: see MPPI_NOISE_*), the rollout is a wave scan, the per-step costs (incl. the collision field) are evaluated by all lanes at once
 // and reduced with DPP; the sequential depth per iteration drops from O(T * (T + cost)) to O(T + log T).
 //
 // Only velocity control is served (state_dim == control_dim): with control_type='acceleration' the
@@ -18,6 +18,7 @@
 // cannot run, so there is nothing to match.
 #include "mpb_common.h"
 #include "mpb_geom.h"
+#include "mpb_stomp_noise.h"   // the permuted MFMA image of a 64 x 64 lower-triangular factor (stomp_l_image_index)
 
 #define MPPI_MAX_C 4
 
@@ -58,10 +59,24 @@ struct MppiLds {
     float* red;    // 64    : scratch of the block reductions
     float* wts;    // S     : sample weights
     float* cst;    // S     : sample costs
+    float* coll;   // S     : collision cost of every sample (summed into the Q6 scalar in sample order)
     float* Us;     // S*c*T : controls of every sample, [s][i][t]
     float* epsw;   // W*c*T : standard normals of the sample a wave is working on, [wave][i][t]
-    float* trilT;  // c*T*T : scale_tril transposed [i][k][t] (only when it fits)
+    float* trilT;  // c*T*T : scale_tril transposed [i][k][t] (only when it fits); matrix path: c*4096, the MFMA images
+    float* E;      // matrix path: c*Spad*64 standard normals of EVERY sample, [i][s][k & 3][k >> 2] (zero beyond T / S)
 };
+
+// How U = mean + scale_tril @ eps is formed (mpb_mppi_step picks):
+//   MPPI_NOISE_MATRIX  T <= 64 and everything fits LDS: the normals of all samples are drawn first, then the c products
+//                      (T x T lower triangular) x (T x S) run as v_mfma_f32_16x16x4_f32 tiles, one 16 x 16 tile of
+//                      (time steps x samples) per wave -- every word of the factor leaves LDS once per tile instead of once
+//                      per (sample, lane, k): the per-lane form below spends two LDS reads per multiply-add, ~420 LDS
+//                      instructions per wave and iteration at S = 32, T = 64, c = 2, and was LDS-bound;
+//   MPPI_NOISE_LDS     the per-lane product against the transposed factor in LDS;
+//   MPPI_NOISE_GLOBAL  the same against the factor in global memory (it does not fit).
+#define MPPI_NOISE_GLOBAL 0
+#define MPPI_NOISE_LDS 1
+#define MPPI_NOISE_MATRIX 2
 
 __global__ __launch_bounds__(1024) void mppi_kernel(
     float* __restrict__ mean, const float* __restrict__ eps, const float* __restrict__ tril,
@@ -71,7 +86,7 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
     float* __restrict__ states, float* __restrict__ costs, float* __restrict__ weights,
     float* __restrict__ best_cost, float* __restrict__ best_states, int S, int T, int c,
     float dt, float k_sigma, float weight, float temp, float step_size, int n_iters, uint32_t seed_lo,
-    uint32_t seed_hi, uint32_t iter0, int tril_in_lds) {
+    uint32_t seed_hi, uint32_t iter0, int noise_mode) {
     extern __shared__ float lds[];
     const int nw = blockDim.x >> 6, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     MppiLds M;
@@ -79,9 +94,16 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
     M.red = M.wvec + c * T;
     M.wts = M.red + 64;
     M.cst = M.wts + ((S + 3) & ~3);
-    M.Us = M.cst + ((S + 3) & ~3);
+    M.coll = M.cst + ((S + 3) & ~3);
+    M.Us = M.coll + ((S + 3) & ~3);
     M.epsw = M.Us + (size_t)S * c * T;
     M.trilT = M.epsw + (size_t)nw * c * T;
+    const bool tril_in_lds = noise_mode == MPPI_NOISE_LDS, matrix = noise_mode == MPPI_NOISE_MATRIX;
+    const int Spad = (S + 15) & ~15;
+    if (matrix) {                      // (no per-wave normals: the slab holds every sample's)
+        M.trilT = lds + (((M.epsw - lds) + 3) & ~(ptrdiff_t)3);                       // 16-byte rows for ds_read_b128
+        M.E = M.trilT + (size_t)c * 4096;
+    }
     const int prob = blockIdx.x;
     float* m = mean + (size_t)prob * T * c;
     const float w_pos = cw[0], w_ctrl = cw[2], w_posT = cw[3];
@@ -90,6 +112,13 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
             const int i = e / (T * T), r = e - i * T * T, t = r / T, k = r - t * T;
             M.trilT[((size_t)i * T + k) * T + t] = tril[e];
         }
+    }
+    if (matrix) {
+        for (int e = threadIdx.x; e < c * 4096; e += blockDim.x) {
+            const int i = e >> 12, row = (e >> 6) & 63, col = e & 63;
+            M.trilT[i * 4096 + stomp_l_image_index(row, col)] = (row < T && col < T) ? tril[((size_t)i * T + row) * T + col] : 0.f;
+        }
+        for (int e = threadIdx.x; e < c * Spad * 64; e += blockDim.x) M.E[e] = 0.f;      // padding samples / steps stay zero
     }
     float gl[MPPI_MAX_C], x0[MPPI_MAX_C], umin[MPPI_MAX_C], umax[MPPI_MAX_C];
 #pragma unroll
@@ -123,10 +152,60 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
             if (e < c * T && seg == 0) M.wvec[e] = a;
         }
         __syncthreads();
-        float coll_wave = 0.f;                                  // this wave's share of the Q6 scalar
+        if (matrix) {
+            // ---- the standard normals of EVERY sample (the same stream as below: one Philox call per (sample, dimension,
+            //      group of four steps)), then U = mean + L eps on the matrix pipe, one (16 steps x 16 samples) tile per wave
+            const int G4 = (T + 3) >> 2;
+            if (eps != nullptr) {
+                for (int e = threadIdx.x; e < c * S * T; e += blockDim.x) {
+                    const int i = e / (S * T), r = e - i * S * T, ss = r / T, t = r - ss * T;
+                    M.E[(((size_t)i * Spad + ss) * 4 + (t & 3)) * 16 + (t >> 2)] =
+                        eps[((((size_t)it * gridDim.x + prob) * c + i) * S + ss) * T + t];
+                }
+            } else {
+                for (int l = threadIdx.x; l < c * S * G4; l += blockDim.x) {
+                    const int i = l / (S * G4), r = l - i * S * G4, ss = r / G4, g4 = r - ss * G4;
+                    const uint4 rr = philox4x32_10(make_uint4((uint32_t)prob, (uint32_t)ss, (uint32_t)g4 | ((uint32_t)i << 16),
+                                                              iter0 + (uint32_t)it),
+                                                   make_uint2(seed_lo, seed_hi));
+                    float n[4];
+                    box_muller(rr.x, rr.y, n[0], n[1]);
+                    box_muller(rr.z, rr.w, n[2], n[3]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (4 * g4 + q < T) M.E[(((size_t)i * Spad + ss) * 4 + q) * 16 + g4] = n[q];
+                }
+            }
+            __syncthreads();
+            const int NT = Spad >> 4, j = lane & 15, g = lane >> 4;
+            const f32x4* L4 = reinterpret_cast<const f32x4*>(M.trilT);
+            for (int tile = wave; tile < c * 4 * NT; tile += nw) {
+                const int i = tile / (4 * NT), r = tile - i * 4 * NT, mt = r / NT, nt = r - mt * NT;
+                if (16 * mt >= T) continue;                                              // (wave-uniform)
+                const f32x4* e4 = reinterpret_cast<const f32x4*>(M.E + (((size_t)i * Spad + 16 * nt + j) * 4 + g) * 16);
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int ks4 = 0; ks4 <= mt; ++ks4) {
+                    const f32x4 a = L4[i * 1024 + ((mt * 4 + ks4) * 4 + g) * 16 + j];
+                    const f32x4 b = e4[ks4];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc, 0, 0, 0);
+                }
+                // acc[r] = (L eps)[t = 16 mt + 4 g + r][sample 16 nt + j]
+                const int ss = 16 * nt + j;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int t = 16 * mt + 4 * g + q;
+                    if (ss < S && t < T) M.Us[((size_t)ss * c + i) * T + t] = m[t * c + i] + acc[q];
+                }
+            }
+            __syncthreads();
+        }
         for (int s = wave; s < S; s += nw) {
             // ---- standard normals of sample s: injected (reference draw order (c, S, T)) or Philox
-            if (eps != nullptr) {
+            if (matrix) {
+            } else if (eps != nullptr) {
                 for (int i = 0; i < c; ++i)
                     for (int t = lane; t < T; t += 64)
                         ew[i * T + t] = eps[((((size_t)it * gridDim.x + prob) * c + i) * S + s) * T + t];
@@ -162,7 +241,9 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
 #pragma unroll
                 for (int i = 0; i < MPPI_MAX_C; ++i) {
                     u[i] = 0.f;
-                    if (i < c && on) {
+                    if (matrix) {
+                        if (i < c && on) u[i] = M.Us[((size_t)s * c + i) * T + t];
+                    } else if (i < c && on) {
                         // U = mean + L eps (gaussian.py:276-298), ascending k like the matmul row
                         float a = 0.f;
                         if (tril_in_lds) {
@@ -236,19 +317,23 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
             }
             const float pos_cost = wave_sum_f32(pos_l), ctl_cost = wave_sum_f32(ctl_l), term = wave_sum_f32(term_l);
             const float is_term = wave_sum_f32(is_l);
-            coll_wave += wave_sum_f32(coll_l);
-            if (lane == 0)
+            const float coll_s = wave_sum_f32(coll_l);
+            if (lane == 0) {
                 M.cst[s] = pos_cost + 0.f /* vel_cost: empty slice, quirk Q8 */ + ctl_cost + term + temp * is_term;
+                M.coll[s] = coll_s;
+            }
         }
         // ---- quirk Q6: the per-sample collision costs collapse into ONE scalar added to every sample
         float total = 0.f;
-        if (geom != nullptr) {
-            __syncthreads();
-            if (lane == 0) M.red[wave] = weight * (k_sigma * coll_wave);
-            __syncthreads();
-            for (int i = 0; i < nw; ++i) total += M.red[i];
-        }
         __syncthreads();
+        if (geom != nullptr) {
+            // summed by every wave for itself in an order that depends on S alone (lane-strided partial sums, then the
+            // wave reduction): the scalar -- and with it every cost and weight -- is the same however many waves the
+            // problem was given (mpb_mppi_step picks 8 or 16 by the number of problems)
+            float a = 0.f;
+            for (int ss = lane; ss < S; ss += 64) a += M.coll[ss];
+            total = weight * (k_sigma * wave_sum_f32(a));
+        }
         // ---- MPPI._save_best (mppi.py:164-168), called every iteration before update_controller (mppi.py:148): the
         //      cheapest sample so far (first index on ties, like torch.argmin) and its state trajectory.  The states of
         //      every sample are not kept, so the winner's rollout is redone from its controls in LDS (same arithmetic
@@ -361,16 +446,32 @@ extern "C" int mpb_mppi_step(float* mean, const float* eps, const float* scale_t
     if (control_type != 0)
         return mpb_fail(MPB_E_UNSUPPORTED, "mpb_mppi_step: only velocity control (the reference's acceleration mode cannot run)");
     if (NP == 0 || n_iters == 0) return MPB_OK;
-    const int nw = S < 16 ? S : 16;                                // one wave per sample, at most 16 waves per problem
-    const size_t base = (size_t)c * T + 64 + 2 * (size_t)((S + 3) & ~3) + (size_t)S * c * T + (size_t)nw * c * T;
+    static const int force_nw = getenv("MPB_MPPI_WAVES") ? atoi(getenv("MPB_MPPI_WAVES")) : 0;       // tuning aid
+    // one wave per sample, at most 16 waves per problem.  With at least two problems per CU, workgroups of 8 waves (two
+    // resident per CU: one problem's barriers and serial sections run under the other's rollouts) are 16 % faster than
+    // 16 (NP = 1 024, S = 32, T = 64: 68.7 against 81.5 us per iteration); a single problem is fastest on 16
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    int nw = S < 16 ? S : 16;
+    if (NP >= 2 * n_cu && S >= 16) nw = 8;
+    if (force_nw > 0 && force_nw <= 16 && force_nw <= S) nw = force_nw;
+    const size_t base = (size_t)c * T + 64 + 3 * (size_t)((S + 3) & ~3) + (size_t)S * c * T + (size_t)nw * c * T;
     const size_t with_tril = base + (size_t)c * T * T;
     const size_t budget = 150 * 1024 / sizeof(float);
     if (base > budget) return mpb_fail(MPB_E_UNSUPPORTED, "mpb_mppi_step: S*T*c too large for the LDS controls slab");
-    const int tril_in_lds = with_tril <= budget;
-    const size_t lds = (tril_in_lds ? with_tril : base) * sizeof(float);
+    // the matrix path swaps the per-wave normals + transposed factor for the MFMA images + every sample's normals
+    const size_t with_matrix = base - (size_t)nw * c * T + 4 + (size_t)c * 4096 + (size_t)c * ((S + 15) & ~15) * 64;
+    static const int force_mode = getenv("MPB_MPPI_NOISE") ? atoi(getenv("MPB_MPPI_NOISE")) : -1;     // tuning / tests: 0, 1, 2
+    int noise_mode = (T <= 64 && with_matrix <= budget) ? MPPI_NOISE_MATRIX : (with_tril <= budget ? MPPI_NOISE_LDS : MPPI_NOISE_GLOBAL);
+    if (force_mode == MPPI_NOISE_GLOBAL) noise_mode = MPPI_NOISE_GLOBAL;
+    if (force_mode == MPPI_NOISE_LDS && with_tril <= budget) noise_mode = MPPI_NOISE_LDS;
+    const size_t lds = (noise_mode == MPPI_NOISE_MATRIX ? with_matrix : noise_mode == MPPI_NOISE_LDS ? with_tril : base) * sizeof(float);
     hipLaunchKernelGGL(mppi_kernel, dim3(NP), dim3(64 * nw), lds, (hipStream_t)stream, mean, eps, scale_tril, cov_inv,
                        state0, goal, ctrl_min, ctrl_max, discount, c_weights, geom, controls, states, costs, weights,
                        best_cost, best_states, S, T, c, dt, k_sigma, weight, temp, step_size, n_iters, (uint32_t)seed, (uint32_t)(seed >> 32), iter0,
-                       tril_in_lds);
+                       noise_mode);
     return mpb_check_launch("mpb_mppi_step");
 }

@@ -236,3 +236,52 @@ def test_new_entry_points_empty_and_invalid(gpu_device):
                                               p(torch.eye(400, dtype=torch.float64, device=dev)), 1, 2, 200, 2, 0, ctypes.c_void_p(0))
     assert rc == 2 and b'H > 128' in _lib.lib().mpb_last_error()          # MPB_E_UNSUPPORTED, nothing launched
     torch.cuda.synchronize()
+
+
+_MPPI_WAVES_CHILD = r"""
+import sys, numpy as np, torch
+from motion_planning_baselines_amd import geometry as G, ops
+from motion_planning_baselines_amd.planners.priors.gaussian import const_ctrl_Cov
+out = sys.argv[1]
+dev = torch.device('cuda:0')
+NP, S, T, c = 3, 40, 64, 2
+f = lambda a: torch.as_tensor(a, dtype=torch.float32).contiguous().to(dev)
+Cov = const_ctrl_Cov([0.3, 0.3], T, c, dict(device='cpu', dtype=torch.float32))
+tril = torch.stack([torch.linalg.cholesky(Cov[..., i]) for i in range(c)]).contiguous().to(dev)
+cinv = torch.stack([torch.inverse(Cov[..., i]) for i in range(c)]).contiguous().to(dev)
+gen = torch.Generator().manual_seed(5)
+state0 = f(torch.rand(NP, c, generator=gen) * 0.2 - 0.9)
+goal = f(torch.rand(NP, c, generator=gen) * 0.2 + 0.7)
+geom = ops.DeviceGeometry(G.RobotPointMass(2, radius=0.01), G.env_grid_circles_2d(), dev)
+mean = torch.zeros(NP, T, c, device=dev)
+controls, states = torch.empty(NP, S, T, c, device=dev), torch.empty(NP, S, T, c, device=dev)
+costs, weights = torch.empty(NP, S, device=dev), torch.empty(NP, S, device=dev)
+ops.mppi_step(mean, None, tril, cinv, state0, goal, f([-1., -1.]), f([1., 1.]), torch.ones(T, device=dev),
+              f([1., 1., 1., 100.]), geom, controls, states, costs, weights, 0.04, k_sigma=1e3, weight=1.0, temp=1.0,
+              step_size=0.7, n_iters=3, seed=3)
+torch.cuda.synchronize()
+np.savez(out, mean=mean.cpu().numpy(), controls=controls.cpu().numpy(), states=states.cpu().numpy(),
+         costs=costs.cpu().numpy(), weights=weights.cpu().numpy())
+"""
+
+
+def test_mppi_same_bits_on_8_and_16_waves(gpu_device, tmp_path):
+    """mpb_mppi_step gives a problem 16 waves, or 8 when there are at least two problems per CU (two workgroups resident
+    per CU).  The choice must not show in the results: every per-sample quantity is computed by one wave, and the one
+    cross-sample sum (quirk Q6's collision scalar) is taken in an order that depends on S alone.  MPB_MPPI_WAVES forces the
+    workgroup size (read once per process: one child each)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    res = {}
+    for nw in (16, 8, 5):
+        out = str(tmp_path / f'nw{nw}.npz')
+        env = dict(os.environ, MPB_MPPI_WAVES=str(nw), PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
+        r = subprocess.run([sys.executable, '-c', _MPPI_WAVES_CHILD, out], cwd=ROOT, env=env, capture_output=True, text=True,
+                           timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[nw] = np.load(out)
+    for k in ('controls', 'states', 'costs', 'weights', 'mean'):
+        assert res[16][k].tobytes() == res[8][k].tobytes() == res[5][k].tobytes(), k
+    assert np.isfinite(res[16]['mean']).all() and float(np.abs(res[16]['mean']).max()) > 0
