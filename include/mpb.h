@@ -358,6 +358,8 @@ int mpb_gpmp2_step(float *x, const float *start, const float *goal, const float 
  * index on ties) beats best_cost[problem], its cost and state trajectory are stored.  Initialise
  * best_cost to a large FINITE value (3e38; the library is built with -ffinite-math-only); it carries over between calls
  * like the reference's attribute.
+ * How the work is laid out (T <= 64: mean + scale_tril @ eps of all samples on the matrix pipe; 8 or 16 waves per
+ * problem depending on NP) does not show in the results: a problem's outputs are the same bits whatever NP is.
  * ------------------------------------------------------------------------------------------- */
 int mpb_mppi_step(float *mean, const float *eps, const float *scale_tril, const float *cov_inv,
                   const float *state0, const float *goal, const float *ctrl_min, const float *ctrl_max,
