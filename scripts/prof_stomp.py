@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 import bench
 dev = torch.device('cuda:0')
 P = int(os.environ.get('MPB_P', 128))
-wl, cost, planner = bench.make_stomp(P, 32, dev, 0)
+wl, cost, planner = bench.make_stomp(P, 32, dev, 0, H=int(os.environ.get('MPB_H', 64)))    # MPB_H=128: the generalised kernel
 n = int(os.environ.get('MPB_ITERS', 200))
 means_init = wl['means0'].clone()
 if os.environ.get('MPB_FUSED'):
