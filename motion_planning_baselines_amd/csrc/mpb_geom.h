@@ -519,14 +519,42 @@ template <bool FP32>
 __device__ __forceinline__ unsigned grid_cell(const GeomView& G, float x, float y, float z) {
     if (!FP32) {
         const float fx = (x - G.glx) * G.gix, fy = (y - G.gly) * G.giy, fz = (z - G.glz) * G.giz;
+#ifdef MPB_GRID_CELL_FP32
         const int ix = min(max((int)floorf(fx), 0), G.gnx - 1), iy = min(max((int)floorf(fy), 0), G.gny - 1),
                   iz = min(max((int)floorf(fz), 0), G.gnz - 1);
         return (unsigned)(__mul24(__mul24(iz, G.gny) + iy, G.gnx) + ix);
+#else
+        // (one clamp of the linear index instead of two per axis: see below -- a point outside the box has hinge 0 and
+        // therefore gradient 0 whatever candidates it is given)
+        int ix, iy, iz;
+        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ix) : "v"(fx));
+        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iy) : "v"(fy));
+        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iz) : "v"(fz));
+        unsigned t, idx;
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(t) : "v"(iz), "s"(G.gny), "v"(iy));
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(idx) : "v"(t), "s"(G.gnx), "v"(ix));
+        return min(idx, (unsigned)(G.n_cells - 1));
+#endif
     }
+#ifdef MPB_GRID_CELL_FP32
     const float fx = __builtin_amdgcn_fmed3f(floorf(fmaf(x, G.gix, -G.glx * G.gix)), 0.f, (float)(G.gnx - 1));
     const float fy = __builtin_amdgcn_fmed3f(floorf(fmaf(y, G.giy, -G.gly * G.giy)), 0.f, (float)(G.gny - 1));
     const float fz = __builtin_amdgcn_fmed3f(floorf(fmaf(z, G.giz, -G.glz * G.giz)), 0.f, (float)(G.gnz - 1));
     return (unsigned)fmaf(fmaf(fz, (float)G.gny, fy), (float)G.gnx, fx);
+#else
+    // nine instructions instead of twelve: fma + v_cvt_flr_i32_f32 per axis, two v_mad_u32_u24, ONE clamp of the linear
+    // index.  No per-axis clamp: a point inside the box gets the cell it always got; a point outside it (or on its upper
+    // faces) lands in SOME valid cell, and whatever that cell lists gives hinge 0 exactly (the box bounds the inflated
+    // obstacles: see spheres_hinge_grid).  Saturated converts (parked slots at 1e9, inf) and NaN (-> 0) included.
+    int ix, iy, iz;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ix) : "v"(fmaf(x, G.gix, -G.glx * G.gix)));
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iy) : "v"(fmaf(y, G.giy, -G.gly * G.giy)));
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iz) : "v"(fmaf(z, G.giz, -G.glz * G.giz)));
+    unsigned t, idx;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(t) : "v"(iz), "s"(G.gny), "v"(iy));
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(idx) : "v"(t), "s"(G.gnx), "v"(ix));
+    return min(idx, (unsigned)(G.n_cells - 1));
+#endif
 }
 
 // cooperative staging by `nthreads` threads (caller synchronises before and after)
