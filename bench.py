@@ -576,7 +576,8 @@ def main():
         # v_mfma_f32_16x16x4_f32 does not run UNDER fp32 VALU work on gfx950 (profiles/r03_microbench_overlap.txt: an MFMA wave
         # and an FMA wave on one SIMD take the SUM of their times, and so does one interleaved stream): the matrix product of
         # the noise occupies the same fp32 pipe for 32 cycles per instruction.  Pipe cycles per wave-iteration =
-        # 2 x VALU + 32 x MFMA (quarter-rate VALU instructions counted at the full rate: a lower bound of the occupancy)
+        # 2 x VALU + 32 x MFMA (every VALU instruction counted at the full rate although v_min / v_max / v_cvt / 3-source v_fma / ... take 4 cycles and v_sqrt / v_sin 8,
+        # profiles/r03_microbench_rates.txt: a lower bound of the occupancy)
         cyc = 2.0 * valu + 32.0 * mfma
         pipe = cyc * (P * S) / (k_ms * 1e-3) / 1e9
         roof['fp32_pipe'] = {'achieved': pipe, 'peak': 1024 * 2.4, 'unit': 'G SIMD-cycles/s', 'frac': pipe / (1024 * 2.4),
