@@ -139,16 +139,35 @@ __global__ __launch_bounds__(256) void gp_prior_dense_kernel(float* __restrict__
         w_out[j] = (size_t)p2 * H * dim;
         w_mu[j] = (size_t)(p2 / n) * H * dim;
     }
+    // row tile r of T is 16 x 16 (r + 1) doubles (lower triangular: the columns beyond the tile are zero) = r + 1 per
+    // thread.  The NEXT tile is fetched into registers while the matrix instructions of the current one run: a tile's
+    // trip from L2 (every workgroup streams the whole factor) would otherwise sit between two barriers, sixteen times
+    double pf[KT / 4];
+    auto fetch = [&](int r, int cnt) {
+        const int ncol = 16 * (r + 1);
+#pragma unroll
+        for (int j = 0; j < KT / 4; ++j) {
+            if (j < cnt) {
+                const int idx = threadIdx.x + 256 * j;
+                const int row = idx / ncol, col = idx - row * ncol;
+                const int gr = 16 * r + row;
+                pf[j] = (gr < N2 && col < N2) ? T[(size_t)gr * N2 + col] : 0.0;
+            }
+        }
+    };
+    fetch(0, 1);
 #pragma unroll
     for (int r = 0; r < KT / 4; ++r) {                 // 16-row tiles of T = 8 time steps x (pos, vel)
         if (16 * r < N2) {
-            const int ncol = 16 * (r + 1);             // lower triangular: columns beyond the tile are zero
+            const int ncol = 16 * (r + 1);
             __syncthreads();
-            for (int idx = threadIdx.x; idx < 16 * ncol; idx += 256) {
+#pragma unroll
+            for (int j = 0; j <= r; ++j) {
+                const int idx = threadIdx.x + 256 * j;
                 const int row = idx / ncol, col = idx - row * ncol;
-                const int gr = 16 * r + row;
-                Tt[row * LD + col] = (gr < N2 && col < N2) ? T[(size_t)gr * N2 + col] : 0.0;
+                Tt[row * LD + col] = pf[j];
             }
+            if (r + 1 < KT / 4 && 16 * (r + 1) < N2) fetch(r + 1, r + 2);
             __syncthreads();
             // two independent accumulation chains (even / odd K tiles) keep the MFMA pipe busy
             f64x4 acc = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
