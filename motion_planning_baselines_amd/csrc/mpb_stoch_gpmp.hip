@@ -28,6 +28,19 @@ __global__ __launch_bounds__(256) void stoch_gpmp_cost_kernel(const float* __res
     const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // sample index p*S + s
     const bool dead = r >= P * S;            // such waves still take part in the block barriers below
     const int Dq = D;
+    const int dim = 2 * D;
+    // a lane's waypoint row (2D floats: positions, velocities) is fetched as D 8-byte pieces (rows start 8-byte aligned:
+    // 2D floats per row); one 4-byte load per element -- 8 per degree of freedom and lane in the factor terms below, each
+    // touching 28 cache lines per wave at D = 7 -- kept the memory pipe, not the arithmetic, busy
+    auto load_row = [&](const float* base, int t, float (&row)[2 * MPB_MAX_DOF]) {
+        const float2* p2 = reinterpret_cast<const float2*>(base + (size_t)t * dim);
+#pragma unroll
+        for (int i = 0; i < MPB_MAX_DOF; ++i) {
+            const float2 v = (i < D) ? p2[i] : make_float2(0.f, 0.f);
+            row[2 * i] = v.x;
+            row[2 * i + 1] = v.y;
+        }
+    };
     // ---- collision (waypoint 0 excluded): one pass per chained field, its broad-phase grid staged in LDS
     double acc = 0.0;
     for (const float* gp = geom; gp != nullptr; gp = geom_next(gp)) {
@@ -40,9 +53,11 @@ __global__ __launch_bounds__(256) void stoch_gpmp_cost_kernel(const float* __res
         const float* xs0 = samples + (size_t)r * H * 2 * Dq;
         for (int t = lane + 0; t < H; t += 64) {
             if (t < 1) continue;
+            float row[2 * MPB_MAX_DOF];
+            load_row(xs0, t, row);
             float q[MPB_MAX_DOF], dq[MPB_MAX_DOF];
 #pragma unroll
-            for (int i = 0; i < MPB_MAX_DOF; ++i) q[i] = (i < Dq) ? xs0[t * 2 * Dq + i] : 0.f;
+            for (int i = 0; i < MPB_MAX_DOF; ++i) q[i] = (i < Dq) ? row[i] : 0.f;
             // (the compile-time robot model where the geometry buffer carries its id -- set by pack_geometry, verified by
             // mpb_geom_check against the model's constants; bit-identical to the table-driven walk)
             float c;
@@ -53,16 +68,28 @@ __global__ __launch_bounds__(256) void stoch_gpmp_cost_kernel(const float* __res
     }
     if (dead) return;
     const int p = r / S;
-    const int dim = 2 * D;
     const float dt = K.dt;
     const float* xs = samples + (size_t)r * H * dim;
     const float* us = means + (size_t)p * H * dim;
     // Qi = [[12/dt^3, -6/dt^2],[-6/dt^2, 4/dt]] (gp_factor.py:42-50), scaled per use
     const double qa = 12.0 / ((double)dt * dt * dt), qb = -6.0 / ((double)dt * dt), qc = 4.0 / (double)dt;
-    for (int t = lane; t < ((H + 63) & ~63); t += 64) {
-        if (t >= H) continue;
-        const float* x0 = xs + t * dim;
-        const float* u0 = us + t * dim;
+    for (int base = 0; base < H; base += 64) {
+        const int t = base + lane;
+        const bool on = t < H;
+        float x0[2 * MPB_MAX_DOF], u0[2 * MPB_MAX_DOF], x1[2 * MPB_MAX_DOF], u1[2 * MPB_MAX_DOF];
+        load_row(xs, on ? t : 0, x0);
+        load_row(us, on ? t : 0, u0);
+        // row t + 1 is the next lane's row t (lane 63: the first row of the next 64-waypoint chunk, fetched by itself)
+#pragma unroll
+        for (int k = 0; k < 2 * MPB_MAX_DOF; ++k) {
+            x1[k] = (k < dim) ? __shfl_down(x0[k], 1, 64) : 0.f;
+            u1[k] = (k < dim) ? __shfl_down(u0[k], 1, 64) : 0.f;
+        }
+        if (lane == 63 && t + 1 < H) {
+            load_row(xs, t + 1, x1);
+            load_row(us, t + 1, u1);
+        }
+        if (!on) continue;
         for (int i = 0; i < D; ++i) {
             const double xp = x0[i], xv = x0[D + i], up = u0[i], uv = u0[D + i];
             if (t == 0) {   // start prior (unary_factor.py:24) and its bilinear twin
@@ -76,7 +103,7 @@ __global__ __launch_bounds__(256) void stoch_gpmp_cost_kernel(const float* __res
                 acc += (double)K.temperature * (double)K.sg * (xp * up + xv * uv);
             }
             if (t < H - 1) {   // GP factor t: e = x_{t+1} - Phi x_t (gp_factor.py:52-56)
-                const double xp1 = x0[dim + i], xv1 = x0[dim + D + i], up1 = u0[dim + i], uv1 = u0[dim + D + i];
+                const double xp1 = x1[i], xv1 = x1[D + i], up1 = u1[i], uv1 = u1[D + i];
                 const double exp_ = xp1 - (xp + (double)dt * xv), exv = xv1 - xv;
                 const double eup = up1 - (up + (double)dt * uv), euv = uv1 - uv;
                 acc += (double)K.kgp * (qa * exp_ * exp_ + 2.0 * qb * exp_ * exv + qc * exv * exv);
