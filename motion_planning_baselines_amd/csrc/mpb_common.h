@@ -133,3 +133,25 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, fl
     n0 = r * __builtin_amdgcn_cosf(u2);  // v_cos_f32 takes revolutions: cos(2*pi*u2)
     n1 = r * __builtin_amdgcn_sinf(u2);
 }
+
+// The first D floats of a waypoint row into q[0..D) (zero beyond): 8-byte loads when the row starts 8-byte aligned
+// (`even` = the row stride in floats is even and so is the base: wave-uniform), else element by element.  A lane's row is
+// 28-64 contiguous bytes, so every load instruction of a wave touches the same ~28 cache lines whatever its width:
+// halving the instruction count halves the work of the memory pipe.
+template <int MAXD>
+__device__ __forceinline__ void load_row_prefix(const float* __restrict__ row, int D, bool even, float (&q)[MAXD]) {
+    if (even) {
+        const float2* r2 = reinterpret_cast<const float2*>(row);
+#pragma unroll
+        for (int i = 0; i < MAXD; i += 2) {
+            float2 v = make_float2(0.f, 0.f);
+            if (i + 1 < D) v = r2[i >> 1];
+            else if (i < D) v.x = row[i];
+            q[i] = v.x;
+            if (i + 1 < MAXD) q[i + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MAXD; ++i) q[i] = (i < D) ? row[i] : 0.f;
+    }
+}

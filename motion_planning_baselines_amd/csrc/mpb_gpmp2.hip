@@ -88,9 +88,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void
             const bool active = t < H;
             const float* row = x + ((size_t)b * H + (active ? t : 0)) * dim;
             float q[MPB_MAX_DOF], dq[MPB_MAX_DOF], gnext[MPB_MAX_DOF];
+            load_row_prefix<MPB_MAX_DOF>(row, D, true, q);       // (rows of 2D floats: always 8-byte aligned)
 #pragma unroll
             for (int i = 0; i < MPB_MAX_DOF; ++i) {
-                q[i] = (i < D) ? row[i] : 0.f;
                 dq[i] = 0.f;
                 gnext[i] = 0.f;
             }
@@ -123,10 +123,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void
             }
             if (active) {
                 float* o = jac + ((size_t)b * H + t) * (D + 1);
+                if (D == 7) {             // 8 floats per row, 32-byte aligned: two 16-byte stores
+                    float4* o4 = reinterpret_cast<float4*>(o);
+                    o4[0] = make_float4(-rs * dq[0], -rs * dq[1], -rs * dq[2], -rs * dq[3]);
+                    o4[1] = make_float4(-rs * dq[4], -rs * dq[5], -rs * dq[6], rs * c);
+                } else {
 #pragma unroll
-                for (int i = 0; i < MPB_MAX_DOF; ++i)
-                    if (i < D) o[i] = -rs * dq[i];
-                o[D] = rs * c;
+                    for (int i = 0; i < MPB_MAX_DOF; ++i)
+                        if (i < D) o[i] = -rs * dq[i];
+                    o[D] = rs * c;
+                }
             }
         }
     }

@@ -829,11 +829,9 @@ __global__ __launch_bounds__(256) void collision_cost_kernel(
             if (h < H) {
                 const float* row = trajs + ((size_t)b * H + h) * d;
                 float q[MPB_MAX_DOF], dq[MPB_MAX_DOF];
+                load_row_prefix<MPB_MAX_DOF>(row, D, (d & 1) == 0, q);
 #pragma unroll
-                for (int i = 0; i < MPB_MAX_DOF; ++i) {
-                    q[i] = (i < D) ? row[i] : 0.f;
-                    dq[i] = 0.f;
-                }
+                for (int i = 0; i < MPB_MAX_DOF; ++i) dq[i] = 0.f;
                 if (h >= h_begin) {
                     if (GRAD && MODEL == PandaModel::ID) {     // compile-time model (launcher: geom_flags); tag re-checked here
                         if (use_grid && G.model == PandaModel::ID) {
@@ -857,11 +855,25 @@ __global__ __launch_bounds__(256) void collision_cost_kernel(
                 if (GRAD) {
                     float* grow = grad + ((size_t)b * H + h) * d;
                     const float sc = weight * k_sigma * G.fscale;
+                    if ((d & 1) == 0) {        // 8-byte pieces (rows start 8-byte aligned)
+                        float2* g2 = reinterpret_cast<float2*>(grow);
 #pragma unroll
-                    for (int i = 0; i < MPB_MAX_D; ++i) {
-                        if (i < d) {
-                            const float gi = (i < MPB_MAX_DOF && i < D && h >= h_begin) ? sc * dq[i < MPB_MAX_DOF ? i : 0] : 0.f;
-                            grow[i] = first ? gi : grow[i] + gi;
+                        for (int i = 0; i < MPB_MAX_D; i += 2) {
+                            if (i < d) {
+                                const float g0 = (i < MPB_MAX_DOF && i < D && h >= h_begin) ? sc * dq[i < MPB_MAX_DOF ? i : 0] : 0.f;
+                                const float g1 = (i + 1 < MPB_MAX_DOF && i + 1 < D && h >= h_begin) ? sc * dq[i + 1 < MPB_MAX_DOF ? i + 1 : 0] : 0.f;
+                                float2 o = make_float2(g0, g1);
+                                if (!first) { const float2 old = g2[i >> 1]; o.x = old.x + g0; o.y = old.y + g1; }
+                                g2[i >> 1] = o;
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < MPB_MAX_D; ++i) {
+                            if (i < d) {
+                                const float gi = (i < MPB_MAX_DOF && i < D && h >= h_begin) ? sc * dq[i < MPB_MAX_DOF ? i : 0] : 0.f;
+                                grow[i] = first ? gi : grow[i] + gi;
+                            }
                         }
                     }
                 }
