@@ -469,6 +469,7 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--repeats', type=int, default=9)
+    ap.add_argument('--preheat', type=int, default=-1, help='untimed K-step blocks before the warm-up (default: by K)')
     ap.add_argument('--particles', type=int, default=128)
     ap.add_argument('--samples', type=int, default=32)
     ap.add_argument('--pos-only', action='store_true')
@@ -505,7 +506,7 @@ def main():
     wl, cost, planner = make_stomp(P, S, dev, rank, args.pos_only)
     prm = wl['params']
     H, d, D = prm['n_support_points'], wl['means0'].shape[-1], 7
-    blocks = run_stomp(planner, clock, dist, world, args.steps, args.warmup, args.repeats, preheat=max(8, min(60, 1200 // max(args.steps, 1))))
+    blocks = run_stomp(planner, clock, dist, world, args.steps, args.warmup, args.repeats, preheat=args.preheat if args.preheat >= 0 else max(8, min(60, 1200 // max(args.steps, 1))))
     elapsed, sp = spread(blocks, args.steps)
     timed_launch_ms = run_stomp.launch_ms[len(run_stomp.launch_ms) // 2]    # median over the R event-timed launches
     span = run_stomp.device_span_ms
