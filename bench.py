@@ -401,8 +401,9 @@ def bench_h128(dev, steps):
     wl, cost, pl = make_stomp(128, 32, dev, 0, H=128)
     path = pl.run_path()
     m0 = pl._particle_means.clone()
-    pl.optimize(opt_iters=steps)
-    torch.cuda.synchronize()
+    for _ in range(12):     # (the CPU baselines before this entry leave the chip idle: untimed calls of the timed shape first,
+        pl.optimize(opt_iters=steps)   # as for the main line -- the first launches after an idle gap run ~10 % slow)
+        torch.cuda.synchronize()
 
     def timed(p, k):
         ts = []
@@ -452,7 +453,8 @@ def bench_mppi(dev, steps, NP=1024):
                       step_size=0.7, n_iters=k, seed=3)
         torch.cuda.synchronize()
         return time.perf_counter() - t0
-    run(steps)
+    for _ in range(6):      # (untimed calls of the timed shape first: see bench_h128)
+        run(steps)
     t = sorted(run(steps) for _ in range(5))[2]
     alg = 4 * (2 * S * T * c + 2 * T * c + 2 * S)          # bytes per problem and iteration
     return {'workload': 'MPPI point mass, %d problems x S=%d samples x T=%d steps x c=%d, %d iterations per launch' % (NP, S, T, c, steps),
