@@ -615,7 +615,10 @@ __device__ __forceinline__ void spheres_hinge_grid(const GeomView& G, const unsi
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 const float dx = x[i] - s[i].x, dy = y[i] - s[i].y, dz = z[i] - s[i].z;
-                best[i] = fminf(best[i], fast_sqrt(dx * dx + dy * dy + dz * dz) - s[i].w);
+                const float dist = fast_sqrt(dx * dx + dy * dy + dz * dz) - s[i].w;
+                // (slot 0 is always evaluated: min(3e38, dist) is dist -- v_min_f32 issues at half the rate of v_sub_f32 on
+                // gfx950, profiles/r03_microbench_rates.txt)
+                best[i] = (k == 0) ? dist : fminf(best[i], dist);
             }
         }
     }
