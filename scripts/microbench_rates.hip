@@ -38,6 +38,12 @@
 #define OP_CNDMASK_S(x) "v_cndmask_b32 " #x ", " #x ", %8, s[6:7]"
 #define OP_MADU64R(x) "v_mad_u64_u32 v[40:41], s[6:7], " #x ", %8, v[40:41]"
 #define OP_PKFMA(x) "v_mov_b32 " #x ", " #x
+#define OP_MULHI(x) "v_mul_hi_u32 " #x ", " #x ", %8"
+#define OP_MAD64(x) "v_mad_u64_u32 v[50:51], s[6:7], " #x ", %8, v[50:51]"
+#define OP_LOG(x) "v_log_f32 " #x ", " #x
+#define OP_EXP(x) "v_exp_f32 " #x ", " #x
+#define OP_RCP(x) "v_rcp_f32 " #x ", " #x
+#define OP_CMP(x) "v_cmp_lt_f32 vcc, " #x ", %8"
 #define OP_READLANE(x) "v_mov_b32_dpp " #x ", " #x " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
 
 template <int MODE>
@@ -76,6 +82,12 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
             if (MODE == 26) CHAIN8(OP_LSHL);
             if (MODE == 27) CHAIN8(OP_CNDMASK_S);
             if (MODE == 28) CHAIN8(OP_PKFMA);
+            if (MODE == 29) CHAIN8(OP_MULHI);
+            if (MODE == 30) CHAIN8(OP_MAD64);
+            if (MODE == 31) CHAIN8(OP_LOG);
+            if (MODE == 32) CHAIN8(OP_EXP);
+            if (MODE == 33) CHAIN8(OP_RCP);
+            if (MODE == 34) CHAIN8(OP_CMP);
         }
     }
     out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
@@ -112,6 +124,8 @@ int main() {
     run<20>("v_fma_f32 v,v,v,s", out); run<21>("v_fma_f32 x,x,x,v", out); run<22>("v_fmamk_f32", out); run<23>("v_add_u32", out);
     run<24>("v_and_b32", out); run<25>("v_xor_b32", out); run<26>("v_lshlrev_b32", out); run<27>("v_cndmask_b32 sgpr", out);
     run<28>("v_mov_b32", out);
+    run<29>("v_mul_hi_u32", out); run<30>("v_mad_u64_u32 (one acc)", out); run<34>("v_cmp_lt_f32", out);
+    run<31>("v_log_f32", out); run<32>("v_exp_f32", out); run<33>("v_rcp_f32", out);
     run<8>("v_sqrt_f32", out); run<14>("v_sin_f32", out); run<15>("v_mov_b32_dpp", out);
     return 0;
 }
