@@ -203,12 +203,20 @@ __global__ __launch_bounds__(256) void gpmp2_diag_kernel(const float* __restrict
 // pivot blocks of an SPD matrix are SPD) on a 16 x 16 fp64 tile with 2 x 2 pivot blocks; each block step is
 // one v_mfma_f64_16x16x4_f64 update of the whole tile, operands and result in registers.
 // ------------------------------------------------------------------------------------------------
-// 1/x in fp64: v_rcp_f64 (about 2^-26 accurate) + two Newton steps; the IEEE division hipcc emits costs
-// ~40 instructions and there are 16 of them per waypoint in the pivot-block inverses
+// 1/x in fp64: v_rcp_f64 (2^-24 accurate on gfx950) + ONE Newton step = at most 20 x 2^-53 relative error, 1.1 x 2^-53 on
+// average (scripts/rcp_accuracy.hip, profiles/r03_rcp_accuracy.txt; a second step brings the maximum to 1.0 x 2^-53).  The
+// IEEE division hipcc emits costs ~40 instructions and there are 7 reciprocals per waypoint in the pivot-block inverses,
+// each on the sequential chain of the block step: the second Newton step (two dependent fp64 fma) was 4 % of the whole
+// iteration at C4.  What the first step leaves reaches the result below the resolution of its fp32 storage: against two
+// steps the updated trajectories differ by 5e-11 of the step with the trust region and 7e-8 (one fp32 ulp) without it
+// (scripts/cmp_rcp_newton.py, B = 512, H = 128, D = 7).  -DGP_RCP_NEWTON=2 restores the second step.
+#ifndef GP_RCP_NEWTON
+#define GP_RCP_NEWTON 1
+#endif
 __device__ __forceinline__ double fast_rcp(double x) {
     double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
+#pragma unroll
+    for (int i = 0; i < GP_RCP_NEWTON; ++i) r = fma(fma(-x, r, 1.0), r, r);
     return r;
 }
 
@@ -497,13 +505,19 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVE
                     const double p00 = readlane_f64(tk, (2 * half) * 16 + k0), p01 = readlane_f64(tk, (2 * half) * 16 + k0 + 1);
                     const double p11 = readlane_f64(tk, (2 * half + 1) * 16 + k0 + 1);
                     const double id = fast_rcp(fma(p00, p11, -p01 * p01));
-                    const double i00 = p11 * id, i01 = -p01 * id, i11 = p00 * id;
                     const bool jin = (li >= k0) && (li < k0 + 2);
                     const double notj = jin ? 0.0 : 1.0;
+                    // (the two row fetches through v_permlane32_swap / v_permlane16_swap instead of the LDS crossbar: measured 2 %
+                    // slower, twice -- with the reciprocal chain as it was and as it is now)
                     const double am0 = fma(notj, __shfl(tk, (2 * half) * 16 + li, 64), (li == k0) ? 1.0 : 0.0);
                     const double am1 = fma(notj, __shfl(tk, (2 * half + 1) * 16 + li, 64), (li == k0 + 1) ? 1.0 : 0.0);
                     const double sel0 = (lk == 2 * half) ? 1.0 : 0.0, sel1 = (lk == 2 * half + 1) ? 1.0 : 0.0;
-                    const double bop = fma(sel0 * i00 + sel1 * i01, am0, (sel0 * i01 + sel1 * i11) * am1);
+                    // this lane's row of Pinv * A'[K,:] with the reciprocal of the determinant factored out: everything but the
+                    // last product is ready before the reciprocal is (Pinv = adj(P) / det: rows (p11, -p01) and (-p01, p00)),
+                    // so ONE multiply stands between the reciprocal and the matrix instruction instead of five dependent
+                    // operations (i00 = p11 id, sel0 i00 + sel1 i01, ... ): the block step is a latency chain
+                    const double u0 = fma(sel0, p11, -(sel1 * p01)), u1 = fma(sel1, p00, -(sel0 * p01));
+                    const double bop = fma(u0, am0, u1 * am1) * id;
                     const double act = sel0 + sel1;
                     const double aop = act * ((li < k0) ? tk : -tk);
                     f64x4 cin;
