@@ -587,6 +587,26 @@ def main():
                              'mfma_instructions_per_wave_iteration': mfma,
                              'note': 'fp32 VALU issue (2 cycles per wave-instruction) + fp32 MFMA (32 cycles each) share one pipe per '
                                      'SIMD; peak = 1024 SIMDs x 2.4 GHz; `frac` above counts the VALU instructions alone, as in rounds 1-2'}
+    cls = {c: pmc.get('SQ_INSTS_VALU_%s_per_wave_iteration' % c) for c in ('ADD_F32', 'MUL_F32', 'FMA_F32', 'TRANS_F32', 'INT32', 'INT64', 'CVT')} \
+        if (pmc and c3_shape) else {}
+    if valu and mfma is not None and all(v is not None for v in cls.values()) and cls:
+        # the same pipe with the instruction classes of the PMC passes priced by profiles/r03_microbench_rates.txt (architectural
+        # cycles per wave-instruction: add / mul 2, transcendental 8, convert 4, 64-bit integer multiply 4, matrix 32):
+        #   low : every class whose members issue at EITHER rate (fma: 2 with two distinct VGPR sources, 4 with three; 32-bit
+        #         integer: add / and / xor 2, shifts / bfe / 24-bit mad 4; the rest -- min, max, select, compare, move, lane ops)
+        #         at 2: a strict lower bound of the pipe occupancy;
+        #   mid : those classes at 3 (fma, int32) and 3.5 (the rest, mostly 4-cycle instructions).
+        other = valu - sum(cls.values())
+        fixed = 2.0 * (cls['ADD_F32'] + cls['MUL_F32']) + 8.0 * cls['TRANS_F32'] + 4.0 * (cls['INT64'] + cls['CVT']) + 32.0 * mfma
+        low = fixed + 2.0 * (cls['FMA_F32'] + cls['INT32'] + other)
+        mid = fixed + 3.0 * (cls['FMA_F32'] + cls['INT32']) + 3.5 * other
+        per_s = (P * S) / (k_ms * 1e-3) / 1e9 / (1024 * 2.4)
+        roof['fp32_pipe_by_class'] = {'frac_low': low * per_s, 'frac_mid': mid * per_s, 'cycles_per_wave_iteration_low': low,
+                                      'cycles_per_wave_iteration_mid': mid, 'instructions_per_wave_iteration': dict(cls, OTHER=other),
+                                      'mfma_valu_coexec_cycles_per_launch': pmc.get('SQ_VALU_MFMA_COEXEC_CYCLES_per_launch'),
+                                      'note': 'class counters SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32 / INT32 / INT64 / CVT of the PMC passes, '
+                                              'priced per profiles/r03_microbench_rates.txt; peak = 1024 SIMDs x 2.4 GHz; the hardware '
+                                              'counts 0 cycles in which a matrix and a vector instruction executed together'}
     roof.update({'kernel': 'stomp_fused_kernel<%d, model> (persistent: one launch = all iterations)' % d, 'traffic': traffic,
                  'hbm': {'achieved': hbm_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': hbm_gbs / HBM_PEAK_GBS,
                          'algorithmic_bytes_per_launch': alg_bytes_k, 'note': 'per iteration of the persistent launch'},

@@ -23,4 +23,8 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc4 -o p -- python3 scripts/p
 echo "pmc4 done"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 -d $OUT/pmc5 -o p -- python3 scripts/prof_stomp.py > $OUT/pmc5.log 2>&1
 echo "pmc5 done"
+# instruction classes of the VALU work (full-rate add / mul, fma, transcendental, integer, convert) and the cycles in which a
+# matrix instruction and a vector instruction of a SIMD were executing together
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_VALU_MFMA_COEXEC_CYCLES -d $OUT/pmc6 -o p -- python3 scripts/prof_stomp.py > $OUT/pmc6.log 2>&1
+echo "pmc6 done"
 python3 scripts/pmc_summary.py $OUT $TAG
