@@ -363,6 +363,21 @@ def bench_c4(dev, steps, with_cpu=True):
         peak64 = 1024 * 2.4 / 4.7
         out['roofline']['valu_f64'] = {'achieved': ginstr, 'peak': peak64, 'unit': 'G wave-instr/s', 'frac': ginstr / peak64,
                                        'valu_instructions_per_wave': pmc['SQ_INSTS_VALU_per_wave'], 'pmc_source': pmc_file}
+        cls = {c: pmc.get('SQ_INSTS_VALU_%s_per_wave' % c) for c in ('ADD_F64', 'MUL_F64', 'FMA_F64', 'TRANS_F64', 'INT32', 'INT64', 'CVT')}
+        if all(v is not None for v in cls.values()) and pmc.get('SQ_INSTS_MFMA_per_wave') is not None:
+            # the fp64 pipe of a SIMD by instruction class (architectural cycles per wave-instruction: fp64 add / mul / fma 4,
+            # v_rcp_f64 16, convert and 64-bit integer 4, v_mfma_f64_16x16x4_f64 64; matrix and vector instructions do not run
+            # together: profiles/r03_microbench_overlap.txt).  low: 32-bit integer and everything else (select, compare, move,
+            # lane operations) at 2 -- a strict lower bound; mid: those at 3 and 3.5.  The solve kernel's share of the iteration's
+            # time is used (conservative: the whole iteration)
+            other = pmc['SQ_INSTS_VALU_per_wave'] - sum(cls.values())
+            fixed = (4.0 * (cls['ADD_F64'] + cls['MUL_F64'] + cls['FMA_F64']) + 16.0 * cls['TRANS_F64'] + 4.0 * (cls['INT64'] + cls['CVT'])
+                     + 64.0 * pmc['SQ_INSTS_MFMA_per_wave'])
+            low, mid = fixed + 2.0 * (cls['INT32'] + other), fixed + 3.0 * cls['INT32'] + 3.5 * other
+            per_s = pmc['waves_per_launch'] / it_s / 1e9 / (1024 * 2.4)
+            out['roofline']['fp64_pipe_by_class'] = {'frac_low': low * per_s, 'frac_mid': mid * per_s, 'cycles_per_wave_low': low,
+                                                     'cycles_per_wave_mid': mid, 'instructions_per_wave': dict(cls, OTHER=other),
+                                                     'mfma_valu_coexec_cycles_per_launch': pmc.get('SQ_VALU_MFMA_COEXEC_CYCLES_per_wave')}
         if pmc.get('FETCH_SIZE_KB_raw_per_launch') and pmc.get('WRITE_SIZE_KB_raw_per_launch'):
             traffic = (2 * pmc['FETCH_SIZE_KB_raw_per_launch'] + pmc['WRITE_SIZE_KB_raw_per_launch']) * 1024
             out['roofline']['hbm'] = {'achieved': traffic / it_s / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

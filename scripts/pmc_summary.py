@@ -132,7 +132,9 @@ if kg:   # GPMP2 C4 (scripts/prof_gpmp2.py: one iteration per launch)
     out = {'kernel': k.split('(')[0], 'workload': 'C4 panda_spheres GPMP2 B=2048 H=128 D=7, one iteration per launch (scripts/prof_gpmp2.py)',
            'waves_per_launch': waves, 'vgpr': grid[k][2], 'lds_bytes': grid[k][4], 'scratch_bytes': grid[k][5]}
     for c in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_INSTS_MFMA', 'SQ_INSTS_VMEM', 'SQ_WAVE_CYCLES', 'SQ_ACTIVE_INST_VALU',
-              'SQ_WAIT_INST_ANY', 'FETCH_SIZE', 'WRITE_SIZE'):
+              'SQ_WAIT_INST_ANY', 'FETCH_SIZE', 'WRITE_SIZE', 'SQ_INSTS_VALU_ADD_F64', 'SQ_INSTS_VALU_MUL_F64', 'SQ_INSTS_VALU_FMA_F64',
+              'SQ_INSTS_VALU_TRANS_F64', 'SQ_INSTS_VALU_INT32', 'SQ_INSTS_VALU_INT64', 'SQ_INSTS_VALU_CVT', 'SQ_VALU_MFMA_COEXEC_CYCLES',
+              'SQ_VALU_MFMA_BUSY_CYCLES'):
         if c in s:
             out[c + ('_KB_raw_per_launch' if c.endswith('SIZE') else '_per_wave')] = s[c] if c.endswith('SIZE') else s[c] / waves
     with open(os.path.join(prof, f'{tag}_pmc_solve.json'), 'w') as fh:
