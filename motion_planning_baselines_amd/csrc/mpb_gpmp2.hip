@@ -313,8 +313,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVE
     double rcarry = 0.0;  // lane < dim: r contribution carried from the previous step (gnext - U^T z)
 
     // per-element constants of the S assembly (element q of this lane: row lk + 4q, column li)
-    double asm_g1[4], asm_g2[4], asm_dg[4], asm_pp[4], asm_id[4];
-    bool asm_in[4];
+    double asm_g1[4], asm_g2[4], asm_dg[4], asm_pp[4], asm_idpad[4];
     int asm_hi[4];
     const int asm_di = (li < dim) ? li : 0;    // the diagonal element of column li is row li
     const int asm_hj = (li < D) ? li : 0;
@@ -325,13 +324,12 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVE
         const bool ip = i < D, jp = j < D;
         const int ii = ip ? i : i - D, jj = jp ? j : j - D;
         const bool same = in && ii == jj;
-        asm_in[q] = in;
         asm_g1[q] = same ? (ip ? (jp ? p00 : p01) : (jp ? p01 : p11)) : 0.0;   // Phi^T Qi Phi block (t < H-1)
         asm_g2[q] = same ? (ip ? (jp ? a : bq) : (jp ? bq : cq)) : 0.0;         // Qi block (t > 0)
         asm_dg[q] = (in && i == j) ? 1.0 : 0.0;
         asm_pp[q] = (in && ip && jp) ? 1.0 : 0.0;
         asm_hi[q] = (i < D) ? i : 0;
-        asm_id[q] = (i == j) ? 1.0 : 0.0;
+        asm_idpad[q] = (!in && i == j) ? 1.0 : 0.0;   // the identity of the padding rows / columns
     }
 
     // per-element constants of the next-tile product -(U^T W U)
@@ -459,8 +457,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVE
                     if (t > 0 && lane == 0) cost += K.kc * cf * cf;
                 }
             }
+            // padding rows / columns = identity.  Outside the 2D x 2D block every term above is an exact zero (its
+            // coefficient is one: asm_g1, asm_g2, asm_dg, asm_pp and the next-tile coefficients all vanish there), so the
+            // tile is v plus the padding's diagonal ones -- one add per element instead of a select pair
 #pragma unroll
-            for (int q = 0; q < 4; ++q) T[q] = asm_in[q] ? v[q] : asm_id[q];
+            for (int q = 0; q < 4; ++q) T[q] = v[q] + asm_idpad[q];
             if (lane >= dim) r = 0.0;
             // the right-hand side rides along as column 14 of the tile (free whenever 2D <= 14): the row operations of the
             // Gauss-Jordan steps below turn it into z = S^-1 r -- the update of the whole 16 x 16 tile is one MFMA per block
@@ -470,9 +471,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVE
             if (aug) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
+                    // (lanes that do not hold an element of column 14 fetch lane 63, whose r is zero; column 14 itself
+                    // is zero before -- it lies outside the block -- so the insertion is an add, not a select)
                     const int row = lk + 4 * q;
-                    const double rq = __shfl(r, row < dim ? row : 0, 64);
-                    if (li == 14 && row < dim) T[q] = rq;
+                    const double rq = __shfl(r, (li == 14 && row < dim) ? row : 63, 64);
+                    T[q] += rq;
                 }
             }
         }
