@@ -379,7 +379,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVE
         // ---- x_t, the neighbour row, h_t from the prefetched registers (lane < dim: x element `lane`; lane <= D: h_t and
         //      c_t); issue the loads of step k+2.  Everything another lane needs of them travels through the lane
         //      crossbar (ds_bpermute on the fp32 values) -- no LDS staging, no write -> read round trip on the chain
-        const double x0 = (double)xr0, x1 = (double)xr1;
+        const double x0 = (double)xr0;
         float hf[MPB_MAX_FIELDS];
         hf[0] = (t > 0) ? jr : 0.f;                      // row 0 takes no collision factor
 #pragma unroll
@@ -397,11 +397,12 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVE
         double own_i = 0.0, gnext = 0.0;
         if (!merge) {
             const int partner = (lane < D) ? lane + D : lane - D;    // position <-> velocity of the same dof
-            const double x0p = (double)__shfl(xr0, partner, 64), x1p = (double)__shfl(xr1, partner, 64);
+            // (earlier / later of the two rows chosen on the fp32 values: two selects instead of eight on the doubles)
+            const float xlo_f = dir ? xr1 : xr0, xhi_f = dir ? xr0 : xr1;
+            const double lo_p = (double)__shfl(xlo_f, partner, 64), hi_p = (double)__shfl(xhi_f, partner, 64);   // partner element
             if (lane < dim) {
                 const bool pos = lane < D;
-                const double lo_o = dir ? x1 : x0, hi_o = dir ? x0 : x1;          // own element of the two rows
-                const double lo_p = dir ? x1p : x0p, hi_p = dir ? x0p : x1p;      // partner element
+                const double lo_o = (double)xlo_f, hi_o = (double)xhi_f;          // own element of the two rows
                 const double ep = pos ? hi_o - (lo_o + dt * lo_p) : hi_p - (lo_p + dt * lo_o);
                 const double ev = pos ? hi_p - lo_p : hi_o - lo_o;
                 const double qp = a * ep + bq * ev, qv = bq * ep + cq * ev;      // Qi e
