@@ -63,9 +63,11 @@ def cpu_threads():
     return cores
 
 
-def cpu_baseline_stomp(wl, budget_s=10.0, max_iters=8):
+def cpu_baseline_stomp(wl, L, Sigma, eps_parity, budget_s=10.0, max_iters=8):
     """The oracle restatement of the reference loop (kind "port") on this host's cores, on a bounded sample of the
-    same workload: the FULL C3 batch, as many iterations as fit the time budget (at least 2 after one warm-up)."""
+    same workload: the FULL C3 batch, as many iterations as fit the time budget (at least 2 after one warm-up).  Its first
+    len(eps_parity) iterations run on the injected noise the GPU side was fed (`stomp_parity_gpu`); their results are
+    returned for the `parity` object of the line."""
     from oracle import planners_ref as O
     from oracle.geometry_ref import make_ref_geometry
     ta = dict(device='cpu', dtype=torch.float32)
@@ -74,22 +76,79 @@ def cpu_baseline_stomp(wl, budget_s=10.0, max_iters=8):
     H, S, d = prm['n_support_points'], prm['num_samples'], wl['means0'].shape[-1]
     P = wl['means0'].shape[0]
     robot, field = make_ref_geometry(wl['robot'], wl['field'], ta)
-    R, Sigma, L = O.stomp_constants(H, prm['dt'], prm['sigma_spectral'], ta)
     means = wl['means0'].cpu().clone()
     cost_fn = lambda x: O.collision_cost(x, robot, field, wl['sigma_coll'])
-    times = []
+    times, kept = [], []
     t_start = time.perf_counter()
     for it in range(max_iters + 1):
         t0 = time.perf_counter()
-        eps = torch.empty(S, d, P, H).normal_()
+        eps = eps_parity[it] if it < len(eps_parity) else torch.empty(S, d, P, H).normal_()
         out = O.stomp_iteration(means, eps, L, Sigma, cost_fn, prm['step_size'], prm['temperature'])
         means = out['means']
+        if it < len(eps_parity):
+            kept.append(out)
         if it > 0:
             times.append(time.perf_counter() - t0)
         if len(times) >= 2 and time.perf_counter() - t_start > budget_s:
             break
     times.sort()
-    return times[len(times) // 2], cores, len(times)
+    return times[len(times) // 2], cores, len(times), kept
+
+
+def stomp_parity_gpu(wl, planner, cost, geom, eps_parity):
+    """GPU side of the line's `parity` object: the first len(eps_parity) iterations of the headline workload on INJECTED
+    noise (the reference's draw order) through mpb_stomp_run_checked -- the same persistent launch the timed region runs,
+    from the same initial means -- returned on the host.  Untimed."""
+    from motion_planning_baselines_amd import ops
+    dev = wl['means0'].device
+    P, H, d = wl['means0'].shape
+    S = wl['params']['num_samples']
+    ws = ops.stomp_workspace(P, S, H, d, dev)
+    path = ops.stomp_run_path(geom, ws, P, S, H, d)
+    means = wl['means0'].clone()
+    samples, costs, weights = torch.empty(P, S, H, d, device=dev), torch.empty(P, S, device=dev), torch.empty(P, S, device=dev)
+    cc = cost.cost_l[0]
+    ops.stomp_run(means, eps_parity.to(dev).contiguous(), samples, costs, weights, planner.scale_tril, planner.Sigma, geom, S, 7,
+                  cc.k_sigma, 1.0, planner.lr, planner.temperature, ws, n_iters=len(eps_parity))
+    torch.cuda.synchronize()
+    assert not ops.stomp_run_timed_out(ws)
+    return {'means': means.cpu(), 'costs': costs.cpu(), 'path': path}
+
+
+def stomp_parity(wl, L, Sigma, eps_parity, gpu, kept):
+    """`parity`: HIP path vs the oracle after len(eps_parity) free-running iterations on the same injected noise, full
+    headline workload.  rel_err_means: max|a-b| / max|b| over the final means; rel_err_means_per_waypoint: worst
+    ||a_ph - b_ph||_2 / ||b_ph||_2 over waypoints, position and velocity channels separately (1 % floor on the norm);
+    rel_err_costs: the last iteration's costs.  At sigma_coll = 1e-3 the reference's fp32 update is itself only defined up
+    to its fp32-vs-fp64 envelope (near-ties of a one-hot softmax), which is computed here by running the oracle in fp64 on
+    the same noise and reported next to the errors."""
+    from oracle import planners_ref as O
+    from oracle.geometry_ref import make_ref_geometry
+    f64 = dict(device='cpu', dtype=torch.float64)
+    robot, field = make_ref_geometry(wl['robot'], wl['field'], f64)
+    prm = wl['params']
+    m64 = wl['means0'].cpu().double()
+    for e in eps_parity:
+        m64 = O.stomp_iteration(m64, e.double(), L.double(), Sigma.double(), lambda x: O.collision_cost(x, robot, field, wl['sigma_coll']),
+                                prm['step_size'], prm['temperature'])['means']
+    ref = kept[-1]
+
+    def gmax(a, b):
+        return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-12))
+
+    def per_waypoint(a, b, n_pos=7):
+        worst = 0.0
+        for sl in (slice(0, n_pos), slice(n_pos, a.shape[-1])):
+            nb = b[..., sl].double().norm(dim=-1)
+            den = nb.clamp_min(1e-2 * float(nb.max()))
+            worst = max(worst, float(((a[..., sl].double() - b[..., sl].double()).norm(dim=-1) / den).max()))
+        return worst
+    return {'iters': len(eps_parity), 'rel_err_means': gmax(gpu['means'], ref['means']),
+            'rel_err_means_per_waypoint': per_waypoint(gpu['means'], ref['means']),
+            'rel_err_costs': gmax(gpu['costs'], ref['costs']),
+            'reference_fp32_vs_fp64_envelope_means': gmax(ref['means'], m64), 'bar': 1e-4,
+            'against': 'oracle/planners_ref.py stomp_iteration (fp32, CPU) on the same injected noise, free running from the initial means, '
+                       'the whole headline batch; GPU side: mpb_stomp_run_checked, persistent launch (path %d)' % gpu['path']}
 
 
 class Clock:
@@ -480,6 +539,24 @@ def bench_mppi(dev, steps, NP=1024):
                          'note': 'controls + states written per iteration; the kernel keeps a problem in one workgroup (wave = sample)'}}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` (N > 1) started bare, the way the driver starts the N = 1 line: this process has not touched
+    the GPU (no torch.cuda call, no library load) and never will -- it starts the N ranks as FRESH child processes through
+    `python -m torch.distributed.run` (one rank per GPU, rendezvous on 127.0.0.1), relays what they print (rank 0's JSON line)
+    and returns the launcher's exit code (non-zero if any rank failed)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 1) // n)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -496,10 +573,14 @@ def main():
                     'persistent kernel are the pre-heat, warm-up and timed K-step launches, so the trace\'s average is the timed launch')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args.gpus))     # (nothing has touched the GPU yet: the ranks are fresh child processes)
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if world != args.gpus:
+        sys.exit('bench.py: --gpus %d but WORLD_SIZE=%d (start it as `python bench.py --gpus N`, which launches its own N ranks, '
+                 'or under torch.distributed.run with --nproc-per-node N)' % (args.gpus, world))
     # one rank per GPU.  MPB_DIST_BACKEND=gloo (test aid) lets several ranks share one GPU to exercise this
     # path on a single-GPU box; the default is RCCL ("nccl") over xGMI
     backend = os.environ.get('MPB_DIST_BACKEND', 'nccl')
@@ -523,7 +604,8 @@ def main():
     wl, cost, planner = make_stomp(P, S, dev, rank, args.pos_only)
     prm = wl['params']
     H, d, D = prm['n_support_points'], wl['means0'].shape[-1], 7
-    blocks = run_stomp(planner, clock, dist, world, args.steps, args.warmup, args.repeats, preheat=args.preheat if args.preheat >= 0 else max(8, min(60, 1200 // max(args.steps, 1))))
+    preheat = args.preheat if args.preheat >= 0 else max(8, min(60, 1200 // max(args.steps, 1)))
+    blocks = run_stomp(planner, clock, dist, world, args.steps, args.warmup, args.repeats, preheat=preheat)
     elapsed, sp = spread(blocks, args.steps)
     timed_launch_ms = run_stomp.launch_ms[len(run_stomp.launch_ms) // 2]    # median over the R event-timed launches
     span = run_stomp.device_span_ms
@@ -636,6 +718,13 @@ def main():
                  'kernel_ms_iterations_%d_to_%d' % (n_prof, 2 * n_prof): later_ms,
                  'two_kernel_path_ms_per_step': two_ms, 'two_kernel_path_iters_per_sec': (1e3 / two_ms) if two_ms else None})
 
+    # ---- parity of the headline workload against the oracle (GPU side here, untimed; the oracle side rides on the CPU baseline)
+    par_gpu = eps_parity = None
+    consts = (planner.scale_tril.cpu(), planner.Sigma.cpu())
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.main_only:
+        eps_parity = torch.randn(2, S, d, P, H, generator=torch.Generator().manual_seed(1234))
+        par_gpu = stomp_parity_gpu(wl, planner, cost, geom, eps_parity)
+
     # ---- BASELINE configs[4]'s per-GPU load with the same protocol (every N)
     c5 = None
     if not args.no_other_configs and not args.main_only:
@@ -669,9 +758,15 @@ def main():
                        'obstacle_spheres': 16, 'parallelism': 'particles sharded x%d' % world,
                        'algorithmic_bytes_per_iter': stomp_algorithmic_bytes(P, S, H, d)},
             'roofline': roof,
+            'preheat': {'untimed_blocks': preheat, 'steps_per_block': args.steps,
+                        'note': 'untimed K-step blocks of the timed shape (synchronize between them) before the W warm-up steps: the '
+                                'chip is power-managed, the timed blocks measure the steady state of the protocol itself (DESIGN 6.2)'},
+            'scaling_note': 'weak scaling, 128 particles per GPU on this line at every N; its N-GPU ratio is capped at ~0.92 by the one '
+                            'fixed-cost collective (the final all-gather, ~26 us) inside a ~0.36 ms block at --steps 20.  The entry that '
+                            'answers ">= 6x at 8 GPUs" is `c5` (BASELINE configs[4]: 4096 particles per GPU, 25 ms blocks): compare c5.value across N',
         }
         if dist is not None:
-            line['dist'] = {'backend': dist.get_backend(), 'world': world, 'forced_at_world_1': bool(forced and world == 1),
+            line['dist'] = {'backend': dist.get_backend(), 'world': world, 'rccl_ranks_seen': dist.get_world_size(), 'forced_at_world_1': bool(forced and world == 1),
                             'collectives_in_timed_region': 'ONE: the final all_gather_into_tensor of the (P,H,d) means, which is also the closing barrier of the '
                             'block (it completes on no rank before every rank has contributed, i.e. finished its K steps; the host spins on an '
                             'event behind it, then synchronizes); the opening barrier (all_reduce of one element) and the all_reduce(MAX) of '
@@ -679,7 +774,9 @@ def main():
         if c5 is not None:
             line['c5'] = c5
         if world == 1 and not args.no_cpu_baseline:
-            med, cores, n_it = cpu_baseline_stomp(wl)
+            med, cores, n_it, kept = cpu_baseline_stomp(wl, consts[0], consts[1], eps_parity if eps_parity is not None else [])
+            if par_gpu is not None:
+                line['parity'] = stomp_parity(wl, consts[0], consts[1], eps_parity, par_gpu, kept)
             line['cpu_baseline'] = {
                 'value': 1.0 / med, 'unit': 'iters/s', 'cores': cores, 'kind': 'port',
                 'sample': 'oracle/planners_ref.py stomp_iteration (PyTorch-CPU restatement of stomp.py:157-160 + build-defined '

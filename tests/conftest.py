@@ -60,3 +60,22 @@ def gpu_device():
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     return torch.device('cuda:0')
+
+
+def rel_err_waypoint(a, b, n_pos=None, floor=1e-2):
+    """Per-waypoint L2-relative error (north_star: "1e-4 relative on final trajectory waypoints"), the stricter companion
+    of the global-max norm `max|a-b| / max|b|`: for every waypoint (p, h) and, separately, for its position channels
+    [:n_pos] and its velocity channels [n_pos:] (different units),  ||a_ph - b_ph||_2 / max(||b_ph||_2, floor * max_ph ||b_ph||_2);
+    the floor (1 % of the largest waypoint norm of that channel group) only keeps waypoints at the origin from dividing by
+    zero.  Returns the maximum over waypoints and channel groups."""
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    n_pos = a.shape[-1] if n_pos is None else n_pos
+    worst = 0.0
+    for sl in (slice(0, n_pos), slice(n_pos, a.shape[-1])):
+        if sl.start >= a.shape[-1]:
+            continue
+        nb = b[..., sl].norm(dim=-1)
+        den = nb.clamp_min(floor * float(nb.max().clamp_min(1e-12)))
+        worst = max(worst, float(((a[..., sl] - b[..., sl]).norm(dim=-1) / den).max()))
+    return worst

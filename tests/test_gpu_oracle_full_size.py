@@ -1,0 +1,168 @@
+"""-m gpu: the HIP path against the ORACLE at BASELINE's full sizes.
+
+The goldens generated from the reference hold P <= 4 particles (<= 8 workgroups): the ticket / pool / partner machinery of
+the persistent STOMP launch only becomes non-trivial at P >= 8.  The oracle restatement of the reference loop
+(oracle/planners_ref.py: stomp.py:150-160, chomp.py:127-151) runs the full C3 batch in about a second, so here it does:
+
+  * C3 (panda_spheres STOMP, P = 128 x S = 32, H = 64, d = 14, sigma_coll = 1e-3): two iterations on injected noise
+    through mpb_stomp_run_checked on the persistent exchange layout -- teacher forced and free running;
+  * the same at P = 256 (one workgroup per particle, two batches of 16 samples);
+  * C2 (pointmass_dense_2d CHOMP, B = 1024, H = 64): 20 iterations in one launch.
+
+Bars: samples 2e-5, costs 5e-5 (as in the golden tests); means 1e-4 in BOTH norms (global max and per-waypoint L2,
+conftest.rel_err_waypoint) for every particle whose update is well conditioned in the reference itself.  At sigma_coll =
+1e-3 the costs are ~1e6 and softmax(-c / T) is one-hot unless two samples tie to within fp32 rounding of the costs: a
+particle counts as ILL-conditioned when the oracle's own fp64 costs, perturbed by the fp32 cost resolution, move one of its
+weights by more than 1e-5 -- for those the reference fp32 result is only defined up to its fp32-vs-fp64 envelope and the
+bar is max(1e-4, 2 x envelope), as in the golden tests."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err_waypoint
+
+pytestmark = pytest.mark.gpu
+REL = 1e-4
+
+
+def _gmax(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def _c3(dev, P, S=32):
+    from motion_planning_baselines_amd import ops, workloads
+    from motion_planning_baselines_amd.planners.stomp import precision_to_scale_tril, stomp_precision_matrix
+    wl = workloads.panda_spheres_stomp(P, dev, S=S, pos_only=False)
+    prm = wl['params']
+    cpu = dict(device='cpu', dtype=torch.float32)
+    R = stomp_precision_matrix(64, prm['dt'], prm['sigma_spectral'], cpu)
+    return wl, torch.inverse(R).contiguous(), precision_to_scale_tril(R).contiguous(), ops.DeviceGeometry(wl['robot'], wl['field'], dev)
+
+
+def _oracle_iter(wl, means, eps, L, Sigma, dtype):
+    from oracle import planners_ref as O
+    from oracle.geometry_ref import make_ref_geometry
+    robot, field = make_ref_geometry(wl['robot'], wl['field'], dict(device='cpu', dtype=dtype))
+    prm = wl['params']
+    return O.stomp_iteration(means.to(dtype), eps.to(dtype), L.to(dtype), Sigma.to(dtype),
+                             lambda x: O.collision_cost(x, robot, field, wl['sigma_coll']), prm['step_size'], prm['temperature'])
+
+
+def _ill_conditioned(costs64, temperature):
+    """(P,) bool: particles whose softmax weights move by > 1e-5 under the fp32 resolution of their costs."""
+    c = costs64.double()
+    w = torch.softmax(-c / temperature, dim=1)
+    dc = 8.0 * 2.0 ** -24 * c.abs().max(dim=1, keepdim=True).values / temperature      # a few ulps of the largest cost
+    return ((w * (1.0 - w)) * dc).max(dim=1).values > 1e-5
+
+
+def _check_iteration(tag, got, ref32, ref64, n_pos, temperature):
+    means, samples, costs, weights = got
+    assert _gmax(samples, ref32['samples']) < 2e-5, tag
+    ksig_atol = 1e-6 * float(ref32['costs'].abs().max())
+    np.testing.assert_allclose(costs.cpu().numpy(), ref32['costs'].numpy(), rtol=5e-5, atol=ksig_atol)
+    ill = _ill_conditioned(ref64['costs'], temperature)
+    good = ~ill
+    assert int(good.sum()) >= 0.9 * good.numel(), (tag, int(ill.sum()))     # the bulk of the batch is checked at the strict bar
+    m, r32, r64 = means.cpu(), ref32['means'], ref64['means']
+    e_g, e_w = _gmax(m[good], r32[good]), rel_err_waypoint(m[good], r32[good], n_pos)
+    np.testing.assert_allclose(weights.cpu().numpy()[good.numpy()], ref32['weights'].numpy()[good.numpy()], rtol=1e-3, atol=1e-5)
+    env = _gmax(r32, r64)
+    e_all = _gmax(m, r32)
+    print('%s: %d / %d particles well conditioned: means global-max %.2e, per-waypoint %.2e; all particles %.2e (reference '
+          'fp32-vs-fp64 envelope %.2e)' % (tag, int(good.sum()), good.numel(), e_g, e_w, e_all, env))
+    assert e_g < REL and e_w < REL, (tag, e_g, e_w)
+    assert e_all < max(REL, 2.0 * env), (tag, e_all, env)
+    return e_g, e_w
+
+
+@pytest.mark.parametrize('P,path', [(128, 'exchange'), (256, 'two-batch')])
+def test_stomp_c3_persistent_vs_oracle_full_size(gpu_device, P, path):
+    from motion_planning_baselines_amd import ops
+    dev = gpu_device
+    S, H, n_it = 32, 64, 2
+    wl, Sigma, L, geom = _c3(dev, P, S)
+    prm = wl['params']
+    d = wl['means0'].shape[-1]
+    ksig = 1.0 / wl['sigma_coll'] ** 2
+    ws = ops.stomp_workspace(P, S, H, d, dev)
+    want = ops.STOMP_PATH_PERSISTENT_EXCHANGE if path == 'exchange' else ops.STOMP_PATH_PERSISTENT
+    assert ops.stomp_run_path(geom, ws, P, S, H, d) == want
+    eps = torch.randn(n_it, S, d, P, H, generator=torch.Generator().manual_seed(42))
+    eps_d = eps.to(dev)
+    samples, costs, weights = torch.empty(P, S, H, d, device=dev), torch.empty(P, S, device=dev), torch.empty(P, S, device=dev)
+    status = ops.StompRunStatus()
+
+    def run(m0, e, n):
+        means = m0.clone().to(dev)
+        ops.stomp_run(means, e.contiguous(), samples, costs, weights, L.to(dev), Sigma.to(dev), geom, S, 7, ksig, 1.0,
+                      prm['step_size'], prm['temperature'], ws, n_iters=n, status=status)
+        torch.cuda.synchronize()
+        assert not ops.stomp_run_timed_out(ws) and status.lost() is None
+        return means, samples.clone(), costs.clone(), weights.clone()
+
+    # teacher forced: every iteration from the oracle's own fp32 iterate
+    prev = wl['means0'].cpu()
+    refs = []
+    for it in range(n_it):
+        r32, r64 = _oracle_iter(wl, prev, eps[it], L, Sigma, torch.float32), _oracle_iter(wl, prev, eps[it], L, Sigma, torch.float64)
+        _check_iteration('C3 P=%d teacher-forced it %d' % (P, it), run(prev, eps_d[it:it + 1], 1), r32, r64, 7, prm['temperature'])
+        refs.append(r32)
+        prev = r32['means']
+    # free running: both iterations inside ONE persistent launch, against the oracle's free-running fp32 / fp64 runs
+    m64 = wl['means0'].cpu().double()
+    for it in range(n_it):
+        r64 = _oracle_iter(wl, m64, eps[it], L, Sigma, torch.float64)
+        m64 = r64['means']
+    got = run(wl['means0'].cpu(), eps_d, n_it)
+    env = _gmax(refs[-1]['means'], m64)
+    err, errw = _gmax(got[0], refs[-1]['means']), rel_err_waypoint(got[0], refs[-1]['means'], 7)
+    print('C3 P=%d free-running %d iterations: global-max %.2e per-waypoint %.2e (reference fp32-vs-fp64 envelope %.2e)' % (P, n_it, err, errw, env))
+    assert err < max(REL, 2.0 * env)
+
+
+def test_chomp_c2_vs_oracle_full_size(gpu_device):
+    """C2 at B = 1024: teacher-forced single iterations at the strict bar, then 20 iterations in ONE launch against the
+    oracle's autograd restatement (chomp.py:134-149); the clipped, B-scaled smoothness gradient (quirk Q3) makes the free
+    run ill-conditioned in the reference itself, hence the envelope."""
+    from motion_planning_baselines_amd import ops, workloads
+    from oracle import planners_ref as O
+    from oracle.geometry_ref import make_ref_geometry
+    dev = gpu_device
+    B, H, n_it = 1024, 64, 20
+    wl = workloads.pointmass_dense_chomp(B, dev)
+    prm = wl['params']
+    geom = ops.DeviceGeometry(wl['robot'], wl['field'], dev)
+    kw = dict(D=2, k_sigma=1.0 / wl['sigma_coll'] ** 2, weight=wl['weight'], w_prior=prm['weight_prior_cost'], lr=prm['step_size'],
+              grad_clip=prm['grad_clip'])
+
+    def oracle(m, dtype, n):
+        ta = dict(device='cpu', dtype=dtype)
+        robot, field = make_ref_geometry(wl['robot'], wl['field'], ta)
+        R = O.chomp_precision(H, prm['dt'], dict(device='cpu', dtype=torch.float32)).to(dtype)
+        m = m.to(dtype)
+        out = []
+        for _ in range(n):
+            m = O.chomp_iteration(m, R, lambda x: O.collision_cost(x, robot, field, wl['sigma_coll'], wl['weight']),
+                                  prm['weight_prior_cost'], prm['step_size'], prm['grad_clip'])['means']
+            out.append(m)
+        return out
+    R = O.chomp_precision(H, prm['dt'], dict(device='cpu', dtype=torch.float32)).to(dev)
+    ref32 = oracle(wl['means0'].cpu(), torch.float32, n_it)
+    ref64 = oracle(wl['means0'].cpu(), torch.float64, n_it)
+    prev = wl['means0'].cpu()
+    for it in (0, 1, n_it - 1):             # teacher forced from the oracle's own iterate
+        prev = wl['means0'].cpu() if it == 0 else ref32[it - 1]
+        m = prev.clone().to(dev)
+        ops.chomp_step(m, R, geom, n_iters=1, **kw)
+        torch.cuda.synchronize()
+        e, ew = _gmax(m, ref32[it]), rel_err_waypoint(m, ref32[it], 2)
+        assert e < 1e-5 and ew < REL, (it, e, ew)
+    m = wl['means0'].clone()
+    ops.chomp_step(m, R, geom, n_iters=n_it, **kw)
+    torch.cuda.synchronize()
+    env = _gmax(ref32[-1], ref64[-1])
+    err, errw = _gmax(m, ref32[-1]), rel_err_waypoint(m, ref32[-1], 2)
+    print('C2 B=%d free-running %d iterations: global-max %.2e per-waypoint %.2e (reference fp32-vs-fp64 envelope %.2e)' % (B, n_it, err, errw, env))
+    assert err < max(REL, 2.0 * env)
