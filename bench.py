@@ -232,7 +232,7 @@ def make_stomp(P, S, dev, rank, pos_only=False, H=64):
                                                         sigma_coll=wl['sigma_coll'], tensor_args=ta)], tensor_args=ta)
     planner = STOMP(opt_iters=1, start_state=torch.from_numpy(wl['starts'][0]).to(dev), cost=cost,
                     initial_particle_means=wl['means0'], tensor_args=ta, noise='philox', seed=0,
-                    particle_offset=rank * P, **prm)
+                    particle_offset=rank * P, check='deferred', **prm)   # (the timed region synchronises itself; loss checked after it)
     return wl, cost, planner
 
 
@@ -242,7 +242,7 @@ def STOMP_two_kernel(wl, cost, dev, rank, P):
     ta = dict(device=dev, dtype=torch.float32)
     return STOMP(opt_iters=1, start_state=torch.from_numpy(wl['starts'][0]).to(dev), cost=cost,
                  initial_particle_means=wl['means0'], tensor_args=ta, noise='philox', seed=0,
-                 particle_offset=rank * P, persistent=False, **wl['params'])
+                 particle_offset=rank * P, persistent=False, check='deferred', **wl['params'])
 
 
 def run_stomp(planner, clock, dist, world, steps, warmup, repeats, preheat):

@@ -40,7 +40,9 @@ extern "C" {
 #define MPB_MAX_H 256
 #define MPB_MAX_DOF 8
 
-/* ABI version in the low bits; bit 30 set = a tuning build (compiled with wrong-result timing switches: never a product library) */
+/* ABI version in the low 16 bits (MPB_ABI_VERSION: bumped whenever a signature of this header changes positionally; a
+ * binding must refuse a library that reports another number); bit 30 set = a tuning build (compiled with wrong-result timing switches: never a product library) */
+#define MPB_ABI_VERSION 3
 #define MPB_VERSION_TUNING_BUILD 0x40000000
 int mpb_version(void);
 const char *mpb_last_error(void);
@@ -252,18 +254,6 @@ int mpb_stomp_run_timed(float *means, const float *eps, float *samples, float *c
                         float k_sigma, float weight, float lr, float temperature,
                         int n_iters, uint64_t seed, uint32_t iter0, uint32_t particle_offset,
                         uint32_t *status, uint32_t *tag_out, float *means_copy, void *stream, float *kernel_ms);
-/* Test aid: n_blocks workgroups that each take a whole CU's LDS and idle for `usec` microseconds (the "another stream
- * keeps the chip busy" of the time-out tests); `sink` is one device word (never written in practice). */
-int mpb_debug_occupy(int n_blocks, uint64_t usec, uint32_t *sink, void *stream);
-/* Test aids for the random-number path (csrc/mpb_debug.hip; not on a product path).
- * mpb_debug_philox: out[4i..4i+3] = Philox4x32-`rounds`(ctr[4i..4i+3], key[2i..2i+1]), rounds = 7 (the STOMP kernels) or
- * 10 (every other kernel), device pointers -- for the Random123 known-answer vectors.
- * mpb_debug_stomp_normals: the standard normals of n_iters STOMP iterations exactly as mpb_stomp_step / mpb_stomp_run draw
- * them in throughput mode (eps == NULL): out (n_iters, P, S, d, 64), element [it][p][s][c][k] = eps of iteration
- * iter0 + it, global particle particle_offset + p, sample s, channel c, waypoint k. */
-int mpb_debug_philox(const uint32_t *ctr, const uint32_t *key, uint32_t *out, int n, int rounds, void *stream);
-int mpb_debug_stomp_normals(float *out, int P, int S, int d, int n_iters, uint64_t seed, uint32_t iter0,
-                            uint32_t particle_offset, void *stream);
 int mpb_stomp_sample(const float *means, const float *eps, float *samples, const float *L,
                      const float *geom, int geom_flags, float *costs, /* geom, costs both NULL: sample only; both set: fused cost */
                      int P, int S, int H, int d, float k_sigma, float weight,

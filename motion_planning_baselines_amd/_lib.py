@@ -43,9 +43,6 @@ SIGNATURES = {
     'mpb_stomp_run_timed': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, ctypes.c_size_t, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _u64, _u32, _u32, _p, _p, _p, _p, _p],
     'mpb_stomp_workspace_init': [_p, ctypes.c_size_t, _p],
     'mpb_stomp_run_path': [_i, ctypes.c_size_t, _i, _i, _i, _i],
-    'mpb_debug_occupy': [_i, _u64, _p, _p],
-    'mpb_debug_philox': [_p, _p, _p, _i, _i, _p],
-    'mpb_debug_stomp_normals': [_p, _i, _i, _i, _i, _u64, _u32, _u32, _p],
     'mpb_stomp_step_profile': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _u64, _u32, _u32, _p, _p, _p],
     'mpb_stomp_sample': [_p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _f, _f, _u64, _u32, _u32, _p],
     'mpb_stomp_update': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
@@ -63,7 +60,17 @@ SIGNATURES = {
     'mpb_mppi_step': [_p] * 17 + [_i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _u64, _u32, _p],
 }
 
+# test aids (include/mpb_debug.h): a separate library, csrc/libmpb_hip_debug.so
+DEBUG_SIGNATURES = {
+    'mpb_debug_last_error': [],
+    'mpb_debug_occupy': [_i, _u64, _p, _p],
+    'mpb_debug_philox': [_p, _p, _p, _i, _i, _p],
+    'mpb_debug_stomp_normals': [_p, _i, _i, _i, _i, _u64, _u32, _u32, _p],
+}
+ABI_VERSION = 3          # include/mpb.h MPB_ABI_VERSION
+
 _lib = None
+_debug_lib = None
 
 
 class MPBError(RuntimeError):
@@ -92,11 +99,39 @@ def lib():
         fn.argtypes = argtypes
         fn.restype = (ctypes.c_char_p if name == 'mpb_last_error' else
                       ctypes.c_size_t if name in ('mpb_gpmp2_workspace_bytes', 'mpb_stomp_workspace_bytes') else ctypes.c_int)
+    if (h.mpb_version() & 0xFFFF) != ABI_VERSION:
+        # signatures change positionally between ABI versions: calling across them would pass pointers as ints
+        raise MPBError(f'{LIB_PATH} reports ABI version {h.mpb_version() & 0xFFFF}, this binding is written for {ABI_VERSION} '
+                       f'(include/mpb.h MPB_ABI_VERSION); rebuild with motion_planning_baselines_amd.build.build(force=True)')
     if (h.mpb_version() & 0x40000000) and not os.environ.get('MPB_LIB_PATH'):
         raise MPBError(f'{LIB_PATH} is a tuning build (compiled with wrong-result timing switches); rebuild with '
                        f'motion_planning_baselines_amd.build.build(force=True)')
     _lib = h
     return h
+
+
+def debug_lib():
+    """The test-aid library (include/mpb_debug.h); never loaded by a product path."""
+    global _debug_lib
+    if _debug_lib is not None:
+        return _debug_lib
+    path = os.path.join(_HERE, 'csrc', 'libmpb_hip_debug.so')
+    if not os.path.exists(path):
+        raise MPBError(f'{path} not found: run motion_planning_baselines_amd.build.build()')
+    lib()                                        # (torch's HIP runtime first, as above)
+    h = ctypes.CDLL(path)
+    for name, argtypes in DEBUG_SIGNATURES.items():
+        fn = getattr(h, name)
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_char_p if name == 'mpb_debug_last_error' else ctypes.c_int
+    _debug_lib = h
+    return h
+
+
+def debug_check(code, what=''):
+    if code != 0:
+        msg = debug_lib().mpb_debug_last_error()
+        raise MPBError(f'{what} failed with code {code}: {msg.decode() if msg else "?"}')
 
 
 def check(code, what=''):

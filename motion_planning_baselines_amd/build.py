@@ -8,7 +8,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['mpb_kernels.hip', 'mpb_stomp_fused.hip', 'mpb_stomp_fused_hx.hip', 'mpb_chomp.hip', 'mpb_gpmp2.hip', 'mpb_mppi.hip', 'mpb_prior.hip', 'mpb_stoch_gpmp.hip', 'mpb_costs.hip', 'mpb_points.hip', 'mpb_debug.hip']
+SOURCES = ['mpb_kernels.hip', 'mpb_stomp_fused.hip', 'mpb_stomp_fused_hx.hip', 'mpb_chomp.hip', 'mpb_gpmp2.hip', 'mpb_mppi.hip', 'mpb_prior.hip', 'mpb_stoch_gpmp.hip', 'mpb_costs.hip', 'mpb_points.hip']
+# the test aids (include/mpb_debug.h) are a library of their own: the product library exports the product ABI only
+DEBUG_SOURCES = ['mpb_debug.hip']
 # per-file extra flags: the latency-bound single-wave-per-problem kernels (CHOMP, GPMP2 solve, MPPI) gain 3-10 % from
 # LLVM's max-ILP scheduling strategy; the STOMP kernels of mpb_kernels.hip lose 2 % with it (measured, round 1)
 MAX_ILP = ['-mllvm', '-amdgpu-sched-strategy=max-ilp']
@@ -18,16 +20,17 @@ EXTRA = {'mpb_chomp.hip': MAX_ILP, 'mpb_gpmp2.hip': MAX_ILP, 'mpb_mppi.hip': MAX
          'mpb_stomp_fused.hip': ['-mllvm', '-amdgpu-sched-strategy=iterative-ilp'],
          'mpb_stomp_fused_hx.hip': ['-mllvm', '-amdgpu-sched-strategy=iterative-ilp']}
 OUT = os.path.join(CSRC, 'libmpb_hip.so')
+DEBUG_OUT = os.path.join(CSRC, 'libmpb_hip_debug.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
          '-ffinite-math-only', '-fno-signed-zeros', '-fno-slp-vectorize']
 
 
 def _stale():
-    if not os.path.exists(OUT):
+    if not os.path.exists(OUT) or not os.path.exists(DEBUG_OUT):
         return True
-    t = os.path.getmtime(OUT)
+    t = min(os.path.getmtime(OUT), os.path.getmtime(DEBUG_OUT))
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h'))]
-    deps.append(os.path.join(os.path.dirname(HERE), 'include', 'mpb.h'))
+    deps += [os.path.join(os.path.dirname(HERE), 'include', h) for h in ('mpb.h', 'mpb_debug.h')]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -74,7 +77,7 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     objs = []
     procs = []
-    for src in SOURCES:
+    for src in SOURCES + DEBUG_SOURCES:
         obj = os.path.join(CSRC, src.replace('.hip', '.o'))
         objs.append(obj)
         cmd = [hipcc, *FLAGS, *EXTRA.get(src, []), '-c', os.path.join(CSRC, src), '-o', obj]
@@ -84,10 +87,12 @@ def build(force=False, verbose=True):
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError('hipcc failed: ' + ' '.join(cmd))
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', OUT]
-    if verbose:
-        print(' '.join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    n = len(SOURCES)
+    for out, o in ((OUT, objs[:n]), (DEBUG_OUT, objs[n:])):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *o, '-o', out]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
     return OUT
 
 

@@ -4,11 +4,19 @@
 //   mpb_debug_stomp_normals   the standard normals exactly as the STOMP kernels draw them (stomp_eps4: Philox4x32-7 +
 //                             Box-Muller on the hardware log2 / sqrt / sin / cos units), laid out (iters, P, S, d, H)
 //                             -- for the statistical tests of the throughput-mode noise (tests/test_gpu_rng.py).
-// Neither is on a product path.
+//   mpb_debug_occupy          workgroups that each hold a CU's LDS for a given time (the lost-launch tests).
+// None is on a product path: this file is the ONLY source of libmpb_hip_debug.so (include/mpb_debug.h), a library of its
+// own that the tests load next to the product library; it shares device code with the product through the headers only.
 #include <hip/hip_runtime.h>
 
 #include "mpb_common.h"
 #include "mpb_stomp_noise.h"
+#include "../../include/mpb_debug.h"
+
+// (this library's own last-error buffer: mpb_common.h's helpers write through mpb_err_buf())
+static thread_local char g_debug_err[512] = "";
+char* mpb_err_buf() { return g_debug_err; }
+extern "C" const char* mpb_debug_last_error(void) { return g_debug_err; }
 
 __global__ void debug_philox_kernel(const uint32_t* __restrict__ ctr, const uint32_t* __restrict__ key, uint32_t* __restrict__ out,
                                     int n, int rounds) {
@@ -55,4 +63,20 @@ extern "C" int mpb_debug_stomp_normals(float* out, int P, int S, int d, int n_it
     hipLaunchKernelGGL(debug_stomp_normals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, P, S,
                        d, n_iters, (uint32_t)seed, (uint32_t)(seed >> 32), iter0, particle_offset);
     return mpb_check_launch("mpb_debug_stomp_normals");
+}
+
+// test aid (mpb_debug_occupy): workgroups that each take a whole CU's LDS and spin for a given time -- the "other stream
+// keeps the chip busy" of the time-out tests
+__global__ __launch_bounds__(64) void occupy_kernel(unsigned long long ticks, unsigned* sink) {
+    __shared__ unsigned pad[150 * 256];                       // 150 KB: one such workgroup per CU
+    pad[threadIdx.x] = threadIdx.x;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    if (pad[(threadIdx.x + 1) & 63] == 0xFFFFFFFFu) sink[0] = 1u;   // (keeps the array)
+}
+
+extern "C" int mpb_debug_occupy(int n_blocks, uint64_t usec, uint32_t* sink, void* stream) {
+    if (n_blocks < 1 || !sink) return mpb_fail(MPB_E_INVALID, "mpb_debug_occupy: bad argument");
+    hipLaunchKernelGGL(occupy_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, usec * 100ull, sink);
+    return mpb_check_launch("mpb_debug_occupy");
 }

@@ -41,9 +41,9 @@ static int check_launch(const char* what) {
 }
 
 #ifdef MPB_TUNING_BUILD
-extern "C" int mpb_version(void) { return 2 | MPB_VERSION_TUNING_BUILD; }
+extern "C" int mpb_version(void) { return MPB_ABI_VERSION | MPB_VERSION_TUNING_BUILD; }
 #else
-extern "C" int mpb_version(void) { return 2; }
+extern "C" int mpb_version(void) { return MPB_ABI_VERSION; }
 #endif
 extern "C" const char* mpb_last_error(void) { return g_err; }
 

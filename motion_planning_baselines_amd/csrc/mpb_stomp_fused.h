@@ -18,6 +18,7 @@
 #define FUSED_HDR_TAG 1      // tag of the last call
 #define FUSED_HDR_DONE 2     // workgroups of the running call that have left; 0 between calls
 #define FUSED_HDR_WHY 3      // why FUSED_HDR_ERR was raised: 1 = partner timed out, 2 = header not initialised
+#define FUSED_HDR_BEGIN 4    // words 4, 5 (one 8-byte word): ~(earliest start of a workgroup of the running call); 0 between calls
 #define FUSED_HDR_TICKET 8   // words 8..15: next ticket of each of the 8 unit pools of the running call; 0 between calls
 // unit pools: pool x owns the particles p = x (mod FUSED_POOLS); a workgroup draws from the pool of the XCD it runs on
 // first (partners then share an L2: speed only), from the next pools once that one is exhausted
@@ -76,13 +77,14 @@ __device__ __forceinline__ unsigned fused_draw_unit(unsigned* wsu, int P, int nc
     return u;
 }
 
-// the workgroup that owns unit 0 stamps the status block with the device's real-time counter (100 MHz) when it starts:
-// words 4, 5; together with words 6, 7 (fused_leave) the span of the launch as the device saw it
-__device__ __forceinline__ void fused_stamp_begin(unsigned* status_host) {
+// every workgroup stamps the device's real-time counter (100 MHz) into header words 4, 5 when it starts -- an atomic MAX of
+// the INVERTED time, so that the zeroed header is the neutral element and the word ends up as ~(earliest start); the last
+// workgroup out copies it to words 4, 5 of the status block next to its own time (words 6, 7): the span of the launch as
+// the device saw it, from the FIRST workgroup to start (whichever unit it owns) to the last one to leave
+__device__ __forceinline__ void fused_stamp_begin(unsigned* wsu, unsigned* status_host) {
     if (status_host) {
         const unsigned long long t = __builtin_amdgcn_s_memrealtime();
-        st_system_u(status_host + 4, (unsigned)t);
-        st_system_u(status_host + 5, (unsigned)(t >> 32));
+        __hip_atomic_fetch_max(reinterpret_cast<unsigned long long*>(wsu + FUSED_HDR_BEGIN), ~t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -104,10 +106,17 @@ __device__ __forceinline__ void fused_leave(unsigned* wsu, unsigned* status_host
         for (int k = 0; k < 8; ++k) st_agent_u(wsu + FUSED_HDR_TICKET + k, 0u);
         st_agent_u(wsu + FUSED_HDR_DONE, 0u);
         if (status_host) {
+            unsigned long long* b64 = reinterpret_cast<unsigned long long*>(wsu + FUSED_HDR_BEGIN);
+            // (every workgroup's stamp precedes its own release increment of the head count, which this one has acquired)
+            const unsigned long long t0 = ~__hip_atomic_load(b64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(b64, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long t = __builtin_amdgcn_s_memrealtime();     // words 6, 7: when the last workgroup left
+            st_system_u(status_host + 4, (unsigned)t0);
+            st_system_u(status_host + 5, (unsigned)(t0 >> 32));
             st_system_u(status_host + 6, (unsigned)t);
             st_system_u(status_host + 7, (unsigned)(t >> 32));
-            st_system_u(status_host + 0, tag0);
+            // "completed" is published last, with release order: a host that reads the tag sees the stamps of THIS call
+            __hip_atomic_store(status_host + 0, tag0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }

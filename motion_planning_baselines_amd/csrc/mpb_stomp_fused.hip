@@ -117,6 +117,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
     // otherwise (one workgroup per particle) by block index
     if (tid == 0) {
         s_abort = 0;
+        fused_stamp_begin(wsu, status_host);
         unsigned u = blockIdx.x;
         if (exchange) {
             int why;
@@ -158,10 +159,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
     bool live = s < S;
     if (tid < N) mean_l[tid] = means[(size_t)p * N + tid];
     // header word 1 = this call's tag; word 0 (the error word) counts only when it equals it
-    if (ticket == 0 && tid == 0) {
-        st_agent_u(wsu + FUSED_HDR_TAG, tag0);    // (unit 0 is drawn exactly once)
-        fused_stamp_begin(status_host);
-    }
+    if (ticket == 0 && tid == 0) st_agent_u(wsu + FUSED_HDR_TAG, tag0);    // (unit 0 is drawn exactly once)
     __syncthreads();
     LSTAMP(2);
 
@@ -449,6 +447,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
     }
     // a lost call leaves the means as they were: the caller's copy says the same (never uninitialised memory)
     if (aborted == 1 && chunk == 0 && tid < N && means_copy) means_copy[(size_t)p * N + tid] = means[(size_t)p * N + tid];
+    // (header not zeroed: no unit was drawn -- the first P workgroups copy one particle each)
+    if (aborted == 2 && (int)blockIdx.x < P && tid < N && means_copy) means_copy[(size_t)blockIdx.x * N + tid] = means[(size_t)blockIdx.x * N + tid];
     // ---- leaving: the error word (device header + the caller's host-visible status block), then the head count; the
     //      last workgroup out re-arms the header for the next call and reports the call as completed
     if (tid == 0) {
@@ -460,22 +460,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
 // ------------------------------------------------------------------------------------------------
 // C-ABI
 // ------------------------------------------------------------------------------------------------
-// test aid (mpb_debug_occupy): workgroups that each take a whole CU's LDS and spin for a given time -- the "other stream
-// keeps the chip busy" of the time-out tests
-__global__ __launch_bounds__(64) void occupy_kernel(unsigned long long ticks, unsigned* sink) {
-    __shared__ unsigned pad[150 * 256];                       // 150 KB: one such workgroup per CU
-    pad[threadIdx.x] = threadIdx.x;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
-    if (pad[(threadIdx.x + 1) & 63] == 0xFFFFFFFFu) sink[0] = 1u;   // (keeps the array)
-}
-
-extern "C" int mpb_debug_occupy(int n_blocks, uint64_t usec, uint32_t* sink, void* stream) {
-    if (n_blocks < 1 || !sink) return mpb_fail(MPB_E_INVALID, "mpb_debug_occupy: bad argument");
-    hipLaunchKernelGGL(occupy_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, usec * 100ull, sink);
-    return mpb_check_launch("mpb_debug_occupy");
-}
-
 static int device_cu_count() {       // (every GPU of a node is the same part: asked once)
     static const int n_cu = [] {
         int dev = 0, n = 256;

@@ -88,6 +88,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
     const bool exchange = nc > 1;
     if (tid == 0) {
         s_abort = 0;
+        fused_stamp_begin(wsu, status_host);
         unsigned u = blockIdx.x;
         if (exchange) {
             int why;
@@ -126,10 +127,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
     const int p = exchange ? unit / nc : unit;
     const int chunk = exchange ? unit - p * nc : 0;
     for (int e = tid; e < N; e += FUSED_THREADS) mean_l[e] = means[(size_t)p * N + e];
-    if (unit == 0 && tid == 0) {
-        st_agent_u(wsu + FUSED_HDR_TAG, tag0);
-        fused_stamp_begin(status_host);
-    }
+    if (unit == 0 && tid == 0) st_agent_u(wsu + FUSED_HDR_TAG, tag0);
     __syncthreads();
     const int n_run = s_abort ? 0 : n_iters;
 
@@ -482,6 +480,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
     }
     if (aborted == 1 && chunk == 0 && means_copy)
         for (int e = tid; e < N; e += FUSED_THREADS) means_copy[(size_t)p * N + e] = means[(size_t)p * N + e];
+    if (aborted == 2 && (int)blockIdx.x < P && means_copy)       // (header not zeroed: no unit was drawn)
+        for (int e = tid; e < N; e += FUSED_THREADS) means_copy[(size_t)blockIdx.x * N + e] = means[(size_t)blockIdx.x * N + e];
     if (tid == 0) fused_leave(wsu, status_host, tag0, aborted);
 }
 

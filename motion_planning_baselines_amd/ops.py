@@ -509,7 +509,7 @@ def debug_philox(ctr, key, rounds):
     c = torch.from_numpy(ctr.view(np.int32)).to(dev)
     k = torch.from_numpy(key.view(np.int32)).to(dev)
     out = torch.empty(n, 4, dtype=torch.int32, device=dev)
-    _lib.check(_lib.lib().mpb_debug_philox(_ptr(c), _ptr(k), _ptr(out), n, int(rounds), _stream()), 'mpb_debug_philox')
+    _lib.debug_check(_lib.debug_lib().mpb_debug_philox(_ptr(c), _ptr(k), _ptr(out), n, int(rounds), _stream()), 'mpb_debug_philox')
     return out.cpu().numpy().view(np.uint32)
 
 
@@ -517,7 +517,7 @@ def debug_stomp_normals(P, S, d, n_iters, device, seed=0, iter0=0, particle_offs
     """Test aid: the standard normals the STOMP kernels draw in throughput mode, (n_iters, P, S, d, 64) fp32."""
     out = torch.empty(n_iters, P, S, d, 64, device=device, dtype=torch.float32)
     with torch.cuda.device(out.device):
-        _lib.check(_lib.lib().mpb_debug_stomp_normals(_ptr(out), int(P), int(S), int(d), int(n_iters),
+        _lib.debug_check(_lib.debug_lib().mpb_debug_stomp_normals(_ptr(out), int(P), int(S), int(d), int(n_iters),
                                                       int(seed) & (2 ** 64 - 1), int(iter0), int(particle_offset), _stream()),
                    'mpb_debug_stomp_normals')
     return out
@@ -527,7 +527,7 @@ def debug_occupy(n_blocks, usec, device):
     """Test aid: n_blocks workgroups that each take a CU's LDS and idle for `usec` microseconds on the current stream."""
     sink = torch.zeros(1, dtype=torch.int32, device=device)
     with torch.cuda.device(sink.device):
-        _lib.check(_lib.lib().mpb_debug_occupy(int(n_blocks), int(usec), _ptr(sink), _stream()), 'mpb_debug_occupy')
+        _lib.debug_check(_lib.debug_lib().mpb_debug_occupy(int(n_blocks), int(usec), _ptr(sink), _stream()), 'mpb_debug_occupy')
     return sink
 
 

@@ -52,19 +52,23 @@ class STOMP(OptimizationPlanner):
              (default); False keeps the two-kernels-per-iteration path (mpb_stomp_step).
       check: what happens when a persistent launch is LOST (include/mpb.h, "Failure contract": its workgroups wait for
              each other, every wait is bounded, and a wait that runs out -- the device stopped starting this launch's
-             workgroups for seconds, e.g. another context holds every CU -- abandons the call).  A lost call never
-             goes unnoticed: 'deferred' (default) raises PersistentLaunchLost at the next call into the planner
-             (optimize / reset / sample / get_traj / persistent_timed_out) -- the kernel reports into pinned host memory, so
-             the fast path has no synchronisation; 'sync' synchronises the stream at the end of optimize() and raises
-             there.  After the exception the means of the particles the lost call did not finish are the ones from before
-             that call; samples / costs / weights are undefined: reset() the planner (or re-run from saved means).
+             workgroups for seconds, e.g. another context holds every CU -- abandons the call).  'sync' (default):
+             optimize() waits for the launch (host spin on an event, no sleep) and raises PersistentLaunchLost before it
+             returns -- a caller never holds the result of a lost call.  'deferred' (opt-in, for callers that queue more
+             work behind optimize() and synchronise themselves, e.g. bench.py): optimize() returns without waiting and the
+             loss is raised at the NEXT call into the planner (optimize / reset / sample / get_traj / persistent_timed_out);
+             the kernel reports into pinned host memory, so that check costs no synchronisation -- but a program whose
+             LAST planner call is optimize() must call persistent_timed_out() (or get_traj()) itself before it trusts the
+             returned tensor, which after a lost call holds the means from BEFORE that call.
+             After the exception the means of the particles the lost call did not finish are the ones from before that
+             call; samples / costs / weights are undefined: reset() the planner (or re-run from saved means).
     """
 
     def __init__(self, n_dof, n_support_points, num_particles_per_goal, num_samples, opt_iters, dt, start_state,
                  cost=None, initial_particle_means=None, multi_goal_states=None, sigma_start_init=0.001,
                  sigma_goal_init=0.001, sigma_gp_init=10., temperature=1., step_size=1., sigma_spectral=0.1,
                  goal_state=None, pos_only=True, tensor_args=None, noise='philox', seed=0, particle_offset=0,
-                 persistent=True, check='deferred', **kwargs):
+                 persistent=True, check='sync', **kwargs):
         super().__init__(name='STOMP', n_dof=n_dof, n_support_points=n_support_points,
                          num_particles_per_goal=num_particles_per_goal, opt_iters=opt_iters, dt=dt,
                          start_state=start_state, cost=cost, initial_particle_means=initial_particle_means,
@@ -187,7 +191,10 @@ class STOMP(OptimizationPlanner):
         if self._status is None:
             return
         if synchronize:
-            torch.cuda.current_stream(self.device).synchronize()
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            while not ev.query():        # (host spin: the runtime's blocking wait wakes up tens of microseconds late)
+                pass
         lost = self._status.lost()
         if lost is not None:
             tag, why = lost

@@ -56,3 +56,26 @@ def test_bench_on_rccl_world1(gpu_device):
     if os.path.isdir(out_dir) and os.access(out_dir, os.W_OK):       # kept for profiles/r03_bench_nccl_world1.json
         with open(os.path.join(out_dir, 'r03_bench_nccl_world1.json'), 'w') as fh:
             fh.write(json.dumps(line) + '\n')
+
+
+def test_bench_bare_command_launches_its_own_ranks(gpu_device):
+    """`python bench.py --gpus N` started BARE (no torch.distributed.run around it, no WORLD_SIZE in the
+    environment) -- the driver's command form -- starts its N ranks itself as fresh child processes and relays rank 0's
+    line.  Two ranks share the box's one GPU here (MPB_DIST_BACKEND=gloo); on the 8-GPU node the same command runs on RCCL."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT',
+                                                             'MPB_FORCE_DIST')}
+    env.update(MPB_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '20', '--warmup', '5'],
+                       env=env, capture_output=True, text=True, timeout=1100)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['dist']['world'] == 2 and line['dist']['rccl_ranks_seen'] == 2
+    assert line['dist']['backend'] == 'gloo' and line['scaling'] == 'weak' and 'c5' in line['scaling_note']
+    assert line['metric'] == 'stomp_trajectory_update_iters_per_sec' and line['value'] > 1000
+    assert line['c5']['value'] > 0 and 'cpu_baseline' not in line
+    # a mismatch between --gpus and an existing WORLD_SIZE is an error message, not an assert
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1'],
+                         env=dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0'), capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and 'WORLD_SIZE' in bad.stderr

@@ -3,6 +3,7 @@ symbol include/mpb.h declares, geometry packing round-trips through the library'
 planner constants match the reference's (golden) R / Sigma / scale_tril bit for bit."""
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -19,7 +20,36 @@ def test_library_exports_every_declared_symbol():
     h = _lib.lib()
     for name in declared:
         assert hasattr(h, name)
-    assert h.mpb_version() >= 1
+    assert (h.mpb_version() & 0xFFFF) == _lib.ABI_VERSION == int(re.search(r'#define MPB_ABI_VERSION (\d+)', hdr).group(1))
+    # the product library exports the product ABI ONLY: the test aids live in a library of their own (include/mpb_debug.h)
+    assert not [n for n in declared if n.startswith('mpb_debug')]
+    import subprocess
+    syms = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r' T (mpb_[a-z0-9_]+)$', syms, flags=re.M))
+    assert exported == declared, exported ^ declared
+    dhdr = open(os.path.join(ROOT, 'include', 'mpb_debug.h')).read()
+    ddecl = set(re.findall(r'\b(mpb_[a-z0-9_]+)\s*\(', dhdr))
+    assert ddecl == set(_lib.DEBUG_SIGNATURES), ddecl ^ set(_lib.DEBUG_SIGNATURES)
+    dh = _lib.debug_lib()
+    for name in ddecl:
+        assert hasattr(dh, name)
+
+
+def test_binding_refuses_a_library_of_another_abi_version(tmp_path, monkeypatch):
+    """signatures change positionally between ABI versions -- a library that reports another MPB_ABI_VERSION (an
+    old build_variants/*.so through MPB_LIB_PATH) must be refused at load time, not called with shifted arguments."""
+    import subprocess
+    from motion_planning_baselines_amd import _lib
+    src = tmp_path / 'old.c'
+    names = [n for n in _lib.SIGNATURES if n not in ('mpb_version', 'mpb_last_error')]
+    src.write_text('int mpb_version(void) { return %d; }\nconst char *mpb_last_error(void) { return ""; }\n' % (_lib.ABI_VERSION - 1)
+                   + ''.join('int %s(void) { return 0; }\n' % n for n in names))
+    so = tmp_path / 'libold.so'
+    subprocess.check_call(['gcc', '-shared', '-fPIC', str(src), '-o', str(so)])
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(so))
+    monkeypatch.setattr(_lib, '_lib', None)
+    with pytest.raises(_lib.MPBError, match='ABI version'):
+        _lib.lib()
 
 
 def test_geometry_pack_validates_and_rejects_corruption():
@@ -365,3 +395,27 @@ def test_broad_phase_grid_is_conservative_and_fits(scene):
     ok = w != G.GRID_OVERFLOW
     used = listed[ok] != n
     assert (listed[ok] <= n).all() and (used[:, 1:] <= used[:, :-1]).all()
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """`python bench.py --gpus N` started bare hands its N ranks to torch.distributed.run as fresh child processes BEFORE any
+    GPU call, on 127.0.0.1, with the caller's own arguments, and returns the launcher's exit code."""
+    import subprocess
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen.update(cmd=cmd, env=env)
+        return subprocess.CompletedProcess(cmd, 3)
+    monkeypatch.setattr(subprocess, 'run', fake_run)
+    monkeypatch.setattr(torch.cuda, 'set_device', lambda *a, **k: (_ for _ in ()).throw(AssertionError('GPU touched before the launch')))
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '20', '--warmup', '5'])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 3
+    cmd = seen['cmd']
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and cmd[cmd.index('--nproc-per-node') + 1] == '4'
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and int(cmd[cmd.index('--master-port') + 1]) > 0
+    assert cmd[-6:] == ['--gpus', '4', '--steps', '20', '--warmup', '5'] and cmd[-7].endswith('bench.py')
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
