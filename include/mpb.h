@@ -306,6 +306,9 @@ int mpb_chomp_step(float *means, const float *R, const float *geom, int geom_fla
  *                         when it is called without diag_sum_out, as mpb_gpmp2_step does).
  *                         costs_out (B) optional: b^T K b of the iterate BEFORE the update (gpmp2.py:493-495).
  *   mpb_gpmp2_step      : n_iters full iterations on one GPU (mean over the local B).
+ * Alignment: x and geom 16-byte aligned, workspace 256-byte aligned (rows are moved as 8- / 16-byte pieces); a pointer
+ * that is not is refused with MPB_E_INVALID (allocations of hipMalloc / PyTorch-ROCm are 256-byte aligned; a VIEW with a
+ * storage offset may not be).
  * sigma_goal <= 0 means "no goal factor" (precision 0: GPMP2 without goals, gpmp2.py:62-78) -- an infinite sigma is not a
  * valid argument (the library is built with -ffinite-math-only).
  * n_fields = number of collision fields chained in `geom` (1..4; see mpb_geom_check): the reference stacks one

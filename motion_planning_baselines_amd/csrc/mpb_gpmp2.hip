@@ -727,6 +727,9 @@ static GpWork gp_carve(void* ws, int B, int H, int D) {
 extern "C" int mpb_gpmp2_linearize(const float* x, const float* geom, int geom_flags, void* workspace, int B, int H, int D,
                                    int n_interp, void* stream) {
     if (!x || !geom || !workspace) return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_linearize: null pointer");
+    // (waypoint rows are read as 8-byte pieces, the Jacobian rows written as 16-byte pieces)
+    if (((uintptr_t)x & 15u) || ((uintptr_t)workspace & 255u) || ((uintptr_t)geom & 15u))
+        return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_linearize: x / geom must be 16-byte aligned and the workspace 256-byte aligned");
     if (!gp_shape_ok(B, H, D) || n_interp < 0 || n_interp > 64) return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_linearize: bad shape");
     if (B == 0) return MPB_OK;
     GpWork w = gp_carve(workspace, B, H, D);
@@ -767,6 +770,8 @@ extern "C" int mpb_gpmp2_solve(float* x, const float* start, const float* goal, 
                                float sigma_gp, float sigma_goal, float sigma_coll, float delta, int trust_region,
                                float step_size, void* stream) {
     if (!x || !start || !goal || !workspace) return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_solve: null pointer");
+    if (((uintptr_t)x & 15u) || ((uintptr_t)workspace & 255u))
+        return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_solve: x must be 16-byte aligned and the workspace 256-byte aligned");
     if (!gp_shape_ok(B, H, D) || n_fields < 1 || n_fields > MPB_MAX_FIELDS) return mpb_fail(MPB_E_INVALID, "mpb_gpmp2_solve: bad shape");
     if (B == 0) return MPB_OK;
     GpWork w = gp_carve(workspace, B, H, D);
