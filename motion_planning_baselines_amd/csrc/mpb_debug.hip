@@ -36,7 +36,7 @@ extern "C" int mpb_debug_philox(const uint32_t* ctr, const uint32_t* key, uint32
 }
 
 // one thread per (iteration, particle, sample, channel j, k-group g, quarter q4): the four normals of one stomp_eps4 call,
-// eps[j][k = 16 q4 + 4 r + g], r = 0..3 -- the very call of stomp_b_operand (mpb_stomp_noise.h)
+// eps[j][k = stomp_eps_column(g, q4, r)], r = 0..3 -- the very call of stomp_eps8 (mpb_stomp_noise.h)
 __global__ void debug_stomp_normals_kernel(float* __restrict__ out, int P, int S, int d, int n_iters, uint32_t seed_lo,
                                            uint32_t seed_hi, uint32_t iter0, uint32_t particle_offset) {
     const size_t n = (size_t)n_iters * P * S * d * 16;
@@ -52,7 +52,7 @@ __global__ void debug_stomp_normals_kernel(float* __restrict__ out, int P, int S
     stomp_eps4(particle_offset + p, s, j, g, q4, iter0 + it, seed_lo, seed_hi, nrm);
     float* o = out + ((((size_t)it * P + p) * S + s) * d + j) * 64;
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) o[16 * q4 + 4 * rr + g] = nrm[rr];
+    for (int rr = 0; rr < 4; ++rr) o[stomp_eps_column((int)g, (int)q4, rr)] = nrm[rr];
 }
 
 extern "C" int mpb_debug_stomp_normals(float* out, int P, int S, int d, int n_iters, uint64_t seed, uint32_t iter0,

@@ -219,6 +219,7 @@ extern "C" int mpb_debug_read_stamps(unsigned long long* dst, int n) {
 // together with L instead of in a serial phase between two more barriers -- the broad-phase grid + obstacle table of
 // the (first) collision field.  37 KB per block: four blocks (16 waves) per CU, the whole C3 batch in one round.
 #define MPB_A_TILE_FLOATS (64 * NT_STRIDE * (MPB_A_WPB > 4 ? MPB_A_WPB : 4))
+static_assert(MPB_A_TILE_FLOATS >= STOMP_LIMG_WORDS, "the L image shares the tile region");
 #define MPB_A_GRID_ROUNDS (MPB_GRID_MAX_CELLS / 4 / (64 * MPB_A_WPB))   // uint4 per thread for the largest grid
 // MODEL: 0 = generic table-driven chain walk (any robot, grid or exhaustive obstacle loop per field); > 0 = the
 // compile-time robot model of that id (mpb_model_*.h) -- separate instantiations, because the register allocation of
@@ -305,41 +306,33 @@ __global__ __launch_bounds__(64 * MPB_A_WPB, 16 / MPB_A_WPB) void stomp_sample_c
     }
 
     MPB_STAMP(1);
-    // ---- B operand: eps[c=j][k=4ks+g], ks = 0..15
-    float e[16];
-    if (eps != nullptr) {
-        const float* ep = eps + (((size_t)s * DCH + (j < DCH ? j : 0)) * P + p) * H + g;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) e[ks] = (j < DCH) ? ep[4 * ks] : 0.f;
-    } else {
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            float n[4] = {0.f, 0.f, 0.f, 0.f};
-            if (j < DCH)
-                stomp_eps4(particle_offset + (uint32_t)p, (uint32_t)s, (uint32_t)j, (uint32_t)g, (uint32_t)q4, iter, seed_lo,
-                           seed_hi, n);
-            e[4 * q4 + 0] = n[0]; e[4 * q4 + 1] = n[1]; e[4 * q4 + 2] = n[2]; e[4 * q4 + 3] = n[3];
-        }
-    }
+    // ---- eps[c = j][k = 32 kb + 8 g + e] of both column blocks, drawn (or loaded) BEFORE L is needed
+    float ev[2][8];
+    const float* eps_s = eps ? eps + (size_t)s * DCH * P * H : nullptr;
+    stomp_eps8<DCH, 0, STOMP_PRIO_NONE>(ev[0], eps_s, P, p, j, g, particle_offset + (uint32_t)p, (uint32_t)s, iter, seed_lo, seed_hi);
+    stomp_eps8<DCH, 1, STOMP_PRIO_NONE>(ev[1], eps_s, P, p, j, g, particle_offset + (uint32_t)p, (uint32_t)s, iter, seed_lo, seed_hi);
     MPB_STAMP(2);
-    // Lp[(((m*4 + ks4)*4 + g)*16 + i)*4 + kk] = L[16m+i][4*(4*ks4+kk) + g] (scattered LDS writes)
+    // L as the three-component bf16 MFMA image (mpb_stomp_noise.h)
+    unsigned* Limg = reinterpret_cast<unsigned*>(Lp);
 #pragma unroll
     for (int u = 0; u < L_PER_THREAD; ++u) {
         const int v4 = threadIdx.x + NTHR * u;
-        const int row = v4 >> 4, col0 = (v4 & 15) << 2;
-        const int m = row >> 4, i = row & 15;
-#pragma unroll
-        for (int e4 = 0; e4 < 4; ++e4) {
-            const int col = col0 + e4, ks = col >> 2, gq = col & 3;
-            Lp[((((m * 4 + (ks >> 2)) * 4 + gq) * 16 + i) << 2) + (ks & 3)] = lreg[u][e4];
-        }
+        stomp_l_image_store(Limg, v4 >> 4, (v4 & 15) << 2, lreg[u]);
     }
     if (WITH_COST && grid0 && (int)threadIdx.x <= g_nsph && threadIdx.x <= MPB_GRID_MAX_SPH)
         otab[threadIdx.x] = oreg;                                                            // entry n_sph: the far dummy
     __syncthreads();
-    // ---- N = L * eps on the matrix cores (mpb_stomp_noise.h: the product the persistent kernel runs too)
+    // ---- N = L * eps on the matrix cores (mpb_stomp_noise.h: the product the persistent kernel runs too, same bits)
     f32x4 acc[4];
-    stomp_noise_product(Lp, e, j, g, acc);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+        StompEps8 b;
+        stomp_split8(ev[0], b);
+        stomp_noise_product_kb<0>(Limg, b, j, g, acc);
+        stomp_split8(ev[1], b);
+        stomp_noise_product_kb<1>(Limg, b, j, g, acc);
+    }
     MPB_STAMP(3);
     __syncthreads();  // every wave has read its A operands: the L image is dead, its space becomes the wave tiles
     MPB_STAMP(4);
@@ -446,7 +439,7 @@ __global__ __launch_bounds__(256) void stomp_sample_cost_hx_kernel(
     float* __restrict__ costs, const float* __restrict__ Lmat, const float* __restrict__ geom,
     int P, int S, int H, int d, float k_sigma, float weight, uint32_t seed_lo, uint32_t seed_hi, uint32_t iter,
     uint32_t particle_offset) {
-    __shared__ __attribute__((aligned(16))) float Lp[64 * 64];
+    __shared__ __attribute__((aligned(16))) unsigned Limg[STOMP_LIMG_WORDS_FULL];   // one block of L as three bf16 components
     __shared__ __attribute__((aligned(16))) float Nt[4][64 * NT_STRIDE];
     __shared__ float4 otab[MPB_GRID_MAX_SPH + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -455,7 +448,6 @@ __global__ __launch_bounds__(256) void stomp_sample_cost_hx_kernel(
     const int p = live ? r / S : 0, s = live ? r - p * S : 0;
     const int j = lane & 15, g = lane >> 4;
     const int Mc = (H + 63) >> 6;                                   // chunks in use (block-uniform)
-    const f32x4* Lp4 = reinterpret_cast<const f32x4*>(Lp);
     float* nt = Nt[wave];
     f32x4 acc[M][4];
 #pragma unroll
@@ -465,48 +457,51 @@ __global__ __launch_bounds__(256) void stomp_sample_cost_hx_kernel(
 #pragma unroll
     for (int kc = 0; kc < M; ++kc) {
         if (kc < Mc) {
-            // ---- B operand of this column chunk: eps[c = j][k = 64 kc + 4 ks + g]
-            float e[16];
-            if (eps != nullptr) {
+            // ---- eps[c = j][k = 64 kc + 32 kb + 8 g + e] of this column chunk as the three bf16 operand components of its
+            //      two column blocks (mpb_stomp_noise.h; device noise: Philox calls 2 kb, 2 kb + 1 of the chunk)
+            StompEps8 sp[2];
 #pragma unroll
-                for (int ks = 0; ks < 16; ++ks) {
-                    const int k = 64 * kc + 4 * ks + g;
-                    e[ks] = (j < d && k < H) ? eps[(((size_t)s * d + j) * P + p) * H + k] : 0.f;
-                }
-            } else {
+            for (int kb = 0; kb < 2; ++kb) {
+                float v[8];
+                if (eps != nullptr) {
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    float n[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (j < d)
-                        stomp_eps4(particle_offset + (uint32_t)p, (uint32_t)s, (uint32_t)j, (uint32_t)g,
-                                   (uint32_t)(kc << 4) | (uint32_t)q4, iter, seed_lo, seed_hi, n);
-                    e[4 * q4 + 0] = n[0]; e[4 * q4 + 1] = n[1]; e[4 * q4 + 2] = n[2]; e[4 * q4 + 3] = n[3];
+                    for (int e8 = 0; e8 < 8; ++e8) {
+                        const int k = 64 * kc + 32 * kb + 8 * g + e8;
+                        v[e8] = (j < d && k < H) ? eps[(((size_t)s * d + j) * P + p) * H + k] : 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        float n[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (j < d)
+                            stomp_eps4(particle_offset + (uint32_t)p, (uint32_t)s, (uint32_t)j, (uint32_t)g,
+                                       (uint32_t)(kc << 4) | (uint32_t)(2 * kb + q), iter, seed_lo, seed_hi, n);
+                        v[4 * q + 0] = n[0]; v[4 * q + 1] = n[1]; v[4 * q + 2] = n[2]; v[4 * q + 3] = n[3];
+                    }
                 }
+                stomp_split8(v, sp[kb]);
             }
 #pragma unroll
             for (int hc = kc; hc < M; ++hc) {
                 if (hc < Mc) {
-                    // ---- stage block (hc, kc) of L in the permuted layout of the H = 64 kernel
+                    // ---- stage block (hc, kc) of L as its MFMA image (zero past H); a diagonal block only has its lower triangle
                     __syncthreads();
-                    for (int v = threadIdx.x; v < 64 * 64; v += 256) {
-                        const int row = v >> 6, col = v & 63;
-                        const int gr = 64 * hc + row, gc = 64 * kc + col;
-                        const float lv = (gr < H && gc < H) ? Lmat[(size_t)gr * H + gc] : 0.f;
-                        const int m = row >> 4, i = row & 15, ks = col >> 2, gg = col & 3;
-                        Lp[((((m * 4 + (ks >> 2)) * 4 + gg) * 16 + i) << 2) + (ks & 3)] = lv;
+                    for (int v4 = threadIdx.x; v4 < 64 * 16; v4 += 256) {
+                        const int row = v4 >> 4, col0 = (v4 & 15) << 2;
+                        const int gr = 64 * hc + row, gc = 64 * kc + col0;
+                        f32x4 lv;
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4) lv[e4] = (gr < H && gc + e4 < H) ? Lmat[(size_t)gr * H + gc + e4] : 0.f;
+                        if (hc == kc) stomp_l_image_store<false>(Limg, row, col0, lv);
+                        else stomp_l_image_store<true>(Limg, row, col0, lv);
                     }
                     __syncthreads();
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-#pragma unroll
-                        for (int ks4 = 0; ks4 < 4; ++ks4) {
-                            if (hc == kc && ks4 > m) continue;          // upper triangle of a diagonal block
-                            const f32x4 a = Lp4[((m * 4 + ks4) * 4 + g) * 16 + j];
-                            acc[hc][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], e[4 * ks4 + 0], acc[hc][m], 0, 0, 0);
-                            acc[hc][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], e[4 * ks4 + 1], acc[hc][m], 0, 0, 0);
-                            acc[hc][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], e[4 * ks4 + 2], acc[hc][m], 0, 0, 0);
-                            acc[hc][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], e[4 * ks4 + 3], acc[hc][m], 0, 0, 0);
-                        }
+                    if (hc == kc) {
+                        stomp_noise_product_kb<0, false>(Limg, sp[0], j, g, acc[hc]);
+                        stomp_noise_product_kb<1, false>(Limg, sp[1], j, g, acc[hc]);
+                    } else {
+                        stomp_noise_product_kb<0, true>(Limg, sp[0], j, g, acc[hc]);
+                        stomp_noise_product_kb<1, true>(Limg, sp[1], j, g, acc[hc]);
                     }
                 }
             }
@@ -566,7 +561,8 @@ __global__ __launch_bounds__(256) void stomp_sample_cost_hx_kernel(
     }
     if (WITH_COST) {
         float c = 0.f;
-        unsigned* gridw = reinterpret_cast<unsigned*>(Lp);
+        static_assert(STOMP_LIMG_WORDS_FULL >= MPB_GRID_MAX_CELLS, "the grid reuses the L image");
+        unsigned* gridw = Limg;                                  // (the L image is dead by now)
         for (const float* gp = geom; gp != nullptr; gp = geom_next(gp)) {
             const GeomView G = geom_view(gp);
             const bool use_grid = grid_usable(G);

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
     constexpr int H = 64;
     constexpr int N = H * DCH;                    // elements of a trajectory
     static_assert(N <= FUSED_THREADS && N + 2 <= FUSED_XCHG, "one thread per trajectory element");
-    __shared__ __attribute__((aligned(16))) float Lp[H * H];                                  // 16 KB
+    __shared__ __attribute__((aligned(16))) unsigned Limg[STOMP_LIMG_WORDS];                  // 18 KB: L as three bf16 components
     __shared__ __attribute__((aligned(16))) float tiles[FUSED_WAVES * H * NT_STRIDE];         // 80 KB
     __shared__ __attribute__((aligned(16))) unsigned gridw[MPB_GRID_MAX_CELLS];               // 16 KB
     __shared__ float4 otab[MPB_GRID_MAX_SPH + 1];                                             //  1 KB
@@ -143,12 +143,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         }
         for (int i = tid; i <= G0.n_sph && i <= MPB_GRID_MAX_SPH; i += FUSED_THREADS)
             otab[i] = (i < G0.n_sph) ? reinterpret_cast<const float4*>(G0.sph)[i] : make_float4(-1.0e9f, -1.0e9f, -1.0e9f, 0.f);
-        // permuted L image and padded Sigma image: one float4 per thread each
+        // L as the three-component bf16 MFMA image (mpb_stomp_noise.h) and the padded Sigma image: one float4 per thread each
         const f32x4 lv = reinterpret_cast<const f32x4*>(Lmat)[tid];
         const f32x4 sv = reinterpret_cast<const f32x4*>(Sigma)[tid];
         const int row = tid >> 4, col0 = (tid & 15) << 2;
-#pragma unroll
-        for (int e4 = 0; e4 < 4; ++e4) Lp[stomp_l_image_index(row, col0 + e4)] = lv[e4];
+        stomp_l_image_store(Limg, row, col0, lv);
         *reinterpret_cast<f32x4*>(sig_l + row * FUSED_LD + col0) = sv;
     }
     __syncthreads();
@@ -168,11 +167,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
     // ---- noise of iteration 0: straight into the wave's tile ([waypoint][channel], stride NT_STRIDE)
     float* nt = tiles + wave * (H * NT_STRIDE);
     {
-        float e[16];
         f32x4 acc[4];
-        stomp_b_operand<DCH>(e, eps ? eps + (size_t)(live ? s : 0) * DCH * P * H : nullptr, P, p, j, g,
-                             particle_offset + (uint32_t)p, (uint32_t)s, iter0, seed_lo, seed_hi);
-        stomp_noise_product(Lp, e, j, g, acc);
+        stomp_noise_bf16<DCH>(Limg, acc, eps ? eps + (size_t)(live ? s : 0) * DCH * P * H : nullptr, P, p, j, g,
+                              particle_offset + (uint32_t)p, (uint32_t)s, iter0, seed_lo, seed_hi);
         stomp_noise_to_tile(nt, acc, lane);
     }
 
@@ -307,7 +304,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
             // the partner's latency.  (Drawing it before barrier 1 at the lowest issue priority, to fill the wait for the
             // block's slowest rollout, was measured 15 % slower: the rollouts leave few issue slots free, and the matrix
             // work that follows then runs with no Philox of another wave to overlap with.)
-            float e[16];
             f32x4 acc[4];
             // (opaque copies: the first Philox round multiplies two counter words that do not change from one iteration to
             // the next, and the compiler would hoist those products out of the loop and keep -- spill -- them)
@@ -321,10 +317,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
 #ifndef FUSED_NOISE_PRIO
 #define FUSED_NOISE_PRIO STOMP_PRIO_PROGRESS
 #endif
-            stomp_b_operand<DCH, FUSED_NOISE_PRIO>(e, eps ? eps + (size_t)it_n * eps_stride + (size_t)(s_n < S ? s_n : 0) * DCH * P * H : nullptr, P, p, jv, gv,
-                                                   particle_offset + (uint32_t)p, (uint32_t)s_n, iter0 + (uint32_t)it_n, seed_lo, seed_hi,
-                                                   3 - (wave >> 2));
-            stomp_noise_product(Lp, e, j, g, acc);
+            stomp_noise_bf16<DCH, FUSED_NOISE_PRIO>(Limg, acc, eps ? eps + (size_t)it_n * eps_stride + (size_t)(s_n < S ? s_n : 0) * DCH * P * H : nullptr,
+                                                    P, p, jv, gv, particle_offset + (uint32_t)p, (uint32_t)s_n, iter0 + (uint32_t)it_n,
+                                                    seed_lo, seed_hi, 3 - (wave >> 2));
             stomp_noise_to_tile(nt, acc, lane);           // (the samples packed in the tile were consumed before barrier 2)
             if (FUSED_NOISE_PRIO == STOMP_PRIO_STAGGER) __builtin_amdgcn_s_setprio(0);
         }

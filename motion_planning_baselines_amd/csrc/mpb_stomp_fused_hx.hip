@@ -20,6 +20,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "mpb_common.h"
 #include "mpb_geom.h"
 #include "mpb_stomp_noise.h"
@@ -67,7 +69,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
     constexpr int TILE = 64 * DX;                      // floats of a wave's tile: its chunk of one rollout, rows packed
     static_assert(HC == 1 || HC == 2, "horizons up to 128 support points");
     static_assert(HP * DX + 2 <= HX_XCHG, "exchange slot too small");
-    __shared__ __attribute__((aligned(16))) float Lp[NLB * 4096];
+    // the 64 x 64 blocks of the lower triangle of L as three-component bf16 MFMA images (mpb_stomp_noise.h): block 0 = (0,0)
+    // and block 2 = (1,1) are diagonal blocks (6 tiles, 18 KB), block 1 = (1,0) is full (8 tiles, 24 KB)
+    constexpr int LIMG_WORDS = (HC == 1) ? STOMP_LIMG_WORDS : 2 * STOMP_LIMG_WORDS + STOMP_LIMG_WORDS_FULL;
+    __shared__ __attribute__((aligned(16))) unsigned Limg[LIMG_WORDS];
     __shared__ __attribute__((aligned(16))) float tiles[FUSED_WAVES * TILE];
     __shared__ __attribute__((aligned(16))) unsigned gridw[MPB_GRID_MAX_CELLS];
     __shared__ float4 otab[MPB_GRID_MAX_SPH + 1];
@@ -109,11 +114,14 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
 #pragma unroll
     for (int b = 0; b < NLB; ++b) {
         const int hc = (b == 0) ? 0 : 1, kc = (b == 2) ? 1 : 0;
-        for (int v = tid; v < 4096; v += FUSED_THREADS) {
-            const int row = v >> 6, col = v & 63;
-            const int gr = 64 * hc + row, gc = 64 * kc + col;
-            Lp[b * 4096 + stomp_l_image_index(row, col)] = (gr < H && gc < H) ? Lmat[(size_t)gr * H + gc] : 0.f;
-        }
+        // one thread per four consecutive columns of a row (zero past H)
+        const int row = tid >> 4, col0 = (tid & 15) << 2;
+        const int gr = 64 * hc + row, gc = 64 * kc + col0;
+        f32x4 lv;
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) lv[e4] = (gr < H && gc + e4 < H) ? Lmat[(size_t)gr * H + gc + e4] : 0.f;
+        if (b == 1) stomp_l_image_store<true>(Limg + STOMP_LIMG_WORDS, row, col0, lv);
+        else stomp_l_image_store<false>(Limg + (b == 0 ? 0 : STOMP_LIMG_WORDS + STOMP_LIMG_WORDS_FULL), row, col0, lv);
     }
     for (int i = tid; i < 16 * DLD; i += FUSED_THREADS) delta[i] = 0.f;        // (padding rows / columns stay zero)
     if (HC == 1) {
@@ -133,7 +141,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
 
     float* nt = tiles + wave * TILE;
     const size_t eps_stride = (size_t)S * d * P * H;
-    const f32x4* Lp4 = reinterpret_cast<const f32x4*>(Lp);
 
     // the noise rows of (iteration it_n, sample s_n) for this wave's chunk, parked in the wave's tile (rows packed, stride d).
     // Block-uniform call sites only (two chunks: one workgroup barrier inside).
@@ -143,14 +150,15 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
         for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
         int jv = j, gv = g;
         asm volatile("" : "+v"(jv), "+v"(gv));
-        // B... the eps columns of chunk kc as MFMA operand: e[ks] = eps[c = j][k = 64 kc + 4 ks + g]
+        // the eps columns of chunk kc as the values of this lane: v[32 KB' + e] = eps[c = j][k = 64 kc + 32 KB' + 8 g + e]
+        // (device noise: Philox calls 2 KB', 2 KB' + 1 of the chunk -- mpb_stomp_noise.h, stomp_eps_column)
         auto operand = [&](int kc, float (&e)[16]) {
             if (eps != nullptr) {
                 const float* ep = eps + (size_t)it_n * eps_stride + (((size_t)(s_n < S ? s_n : 0) * d + (jv < d ? jv : 0)) * P + p) * H;
 #pragma unroll
-                for (int ks = 0; ks < 16; ++ks) {
-                    const int k = 64 * kc + 4 * ks + gv;
-                    e[ks] = (jv < d && k < H) ? ep[k] : 0.f;
+                for (int u = 0; u < 16; ++u) {
+                    const int k = 64 * kc + 32 * (u >> 3) + 8 * gv + (u & 7);
+                    e[u] = (jv < d && k < H) ? ep[k] : 0.f;
                 }
             } else {
 #pragma unroll
@@ -164,24 +172,29 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
                 }
             }
         };
-        auto product = [&](int b, bool diagonal, const float (&e)[16]) {      // acc += (block b of L) * e, transposed
+        // acc += (block b of L) * e, issued transposed; both column blocks of the 64-column chunk
+        auto product = [&](auto bc, const float (&e)[16]) {
+            constexpr int b = decltype(bc)::value;
+            constexpr bool full = b == 1;
+            const unsigned* img = Limg + (b == 0 ? 0 : (b == 1 ? STOMP_LIMG_WORDS : STOMP_LIMG_WORDS + STOMP_LIMG_WORDS_FULL));
+            StompEps8 sp;
+            float eh[8];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int u = 0; u < 8; ++u) eh[u] = e[u];
+            stomp_split8(eh, sp);
+            stomp_noise_product_kb<0, full, true>(img, sp, j, g, acc);
 #pragma unroll
-                for (int ks4 = 0; ks4 < 4; ++ks4) {
-                    if (diagonal && ks4 > m) continue;                      // upper triangle of a diagonal block
-                    const f32x4 a = Lp4[b * 1024 + ((m * 4 + ks4) * 4 + g) * 16 + j];
-                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(e[4 * ks4 + 0], a[0], acc[m], 0, 0, 0);
-                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(e[4 * ks4 + 1], a[1], acc[m], 0, 0, 0);
-                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(e[4 * ks4 + 2], a[2], acc[m], 0, 0, 0);
-                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(e[4 * ks4 + 3], a[3], acc[m], 0, 0, 0);
-                }
-            }
+            for (int u = 0; u < 8; ++u) eh[u] = e[8 + u];
+            stomp_split8(eh, sp);
+            stomp_noise_product_kb<1, full, true>(img, sp, j, g, acc);
         };
+        using B0 = std::integral_constant<int, 0>;
+        using B1 = std::integral_constant<int, 1>;
+        using B2 = std::integral_constant<int, 2>;
         float e[16];
         operand(hcw, e);                                   // every wave draws the columns of ITS chunk
         if (HC == 1) {
-            product(0, true, e);
+            product(B0{}, e);
         } else {
             // the second-chunk wave of a rollout also needs the first chunk's columns: its partner has just drawn them and
             // hands them over through the (free) tile of the second-chunk wave instead of both drawing them (device
@@ -194,7 +207,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
             }
             if (share) __syncthreads();
             if (hcw == 0) {
-                product(0, true, e);
+                product(B0{}, e);
             } else {
                 float e0[16];
                 if (share) {
@@ -207,8 +220,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
                 } else {
                     operand(0, e0);
                 }
-                product(1, false, e0);                     // same accumulation order as the two-kernel path: kc = 0, then 1
-                product(2, true, e);
+                product(B1{}, e0);                         // same accumulation order as the two-kernel path: kc = 0, then 1
+                product(B2{}, e);
             }
         }
         float nz[16];

@@ -15,7 +15,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define NT_STRIDE 20  // floats per waypoint row of a wave's noise tile: 80 B keeps ds_read_b128 conflict-free
 
 // Standard normals of the H = 64 paths: one Philox4x32-7 call per (particle, sample, channel j, k-group g, quarter q4)
-// yields eps[j][k] for k = 16*q4 + 4*r + g, r = 0..3.  The counter holds the GLOBAL particle id, so the noise does not
+// yields four normals; which columns k of eps[j][.] they are is the caller's (H = 64 paths: stomp_eps_column; the chunked
+// paths for other horizons: k = 64 kc + 16 q4 + 4 r + g).  The counter holds the GLOBAL particle id, so the noise does not
 // depend on how the particles are sharded over GPUs (nor on which kernel draws it).
 __device__ __forceinline__ void stomp_eps4(uint32_t p_global, uint32_t s, uint32_t j, uint32_t g, uint32_t q4,
                                            uint32_t iter, uint32_t seed_lo, uint32_t seed_hi, float (&n)[4]) {
@@ -87,6 +88,154 @@ __device__ __forceinline__ void stomp_noise_product(const float* __restrict__ Lp
             acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], e[4 * ks4 + 3], acc[m], 0, 0, 0);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same product on the bf16 matrix pipe, EXACT in fp32 inputs (round 4).
+//
+// v_mfma_f32_16x16x4_f32 runs on the fp32 multipliers the vector instructions use: 32 cycles for 1 024 multiply-adds, no
+// overlap with another wave's VALU work (profiles/r03_microbench_overlap.txt) -- the 40 MFMAs of the product were 15 % of
+// the C3 iteration.  v_mfma_f32_16x16x32_bf16 does 8 192 multiply-adds in ~16-20 cycles and holds the vector issue for
+// about half of them (profiles/r04_microbench_overlap_bf16.txt).  An fp32 value is the exact sum of three bf16 values
+// (truncation split: 8 + 8 + 8 significant bits, same exponent range), so
+//     L * eps = sum over the six component pairs (h,h) (h,m) (m,h) (h,l) (l,h) (m,m) of  L_a * eps_b   + O(2^-24 |L||eps|)
+// with every bf16 x bf16 product exact in the fp32 accumulator: the dropped pairs (m,l) (l,m) (l,l) are below the rounding of
+// an fp32 dot product.  36 bf16 MFMAs (6 lower-triangular (row tile, 32-column block) pairs x 6 component pairs) replace
+// 40 fp32 ones at a quarter of the pipe time; splitting eps costs ~11 VALU instructions per pair of values.
+//
+// Operand layout of a 16 x 16 x 32 tile: lane (i = l & 15, g = l >> 4) holds A[i][8 g + e], e = 0..7, and B[8 g + e][j = l & 15];
+// D as for the fp32 form (lane (j, g) holds D[4 g + rr][j]).  Column k = 32 kb + 8 g + e of a 64-column chunk.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// image of one 64 x 64 block of L: a DIAGONAL (lower-triangular) block stores 6 (row tile m, column block kb) tiles --
+// (0,0) (1,0) (2,0) (3,0) (2,1) (3,1); the two above the diagonal are zero and never multiplied -- a FULL (off-diagonal,
+// horizons beyond 64) block all 8
+#define STOMP_LIMG_TILES 6
+#define STOMP_LIMG_WORDS (3 * STOMP_LIMG_TILES * 4 * 16 * 4)  // 32-bit words of a diagonal block's three-component image: 18 KB
+#define STOMP_LIMG_WORDS_FULL (3 * 8 * 4 * 16 * 4)            // of a full block's: 24 KB
+template <bool FULL>
+__device__ __forceinline__ constexpr int stomp_limg_tile(int m, int kb) { return FULL ? m + 4 * kb : (kb == 0 ? m : 2 + m); }
+
+// x = h + m + l exactly, each a bf16 value held in the top half of an fp32 word (truncation split)
+__device__ __forceinline__ void stomp_split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+    h = __float_as_uint(x);
+    const float r1 = x - __uint_as_float(h & 0xFFFF0000u);
+    m = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(m & 0xFFFF0000u);
+    l = __float_as_uint(r2);                                  // (only the top halves of h, m, l are used)
+}
+// top halves of two words -> one word of two bf16 (lo: element 2 i, hi: element 2 i + 1)
+__device__ __forceinline__ unsigned stomp_pack_top(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
+
+// four consecutive columns col0 .. col0 + 3 (col0 a multiple of 4) of row `row` of a 64 x 64 block into the block's
+// three-component bf16 image (32-bit words; entry ((c * TILES + t) * 4 + g) * 16 + i = eight bf16 of row 16 m + i, columns
+// 32 kb + 8 g .. + 7).  Diagonal block: the tiles above the diagonal (m < 2, kb = 1) are not stored.
+template <bool FULL = false>
+__device__ __forceinline__ void stomp_l_image_store(unsigned* __restrict__ img, int row, int col0, f32x4 lv) {
+    const int m = row >> 4, i = row & 15, kb = col0 >> 5, g = (col0 & 31) >> 3, e0 = col0 & 7;
+    if (!FULL && kb == 1 && m < 2) return;
+    unsigned h[4], md[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) stomp_split3(lv[e], h[e], md[e], l[e]);
+    const int t = stomp_limg_tile<FULL>(m, kb);
+    const int w = ((t * 4 + g) * 16 + i) * 4 + (e0 >> 1);
+    constexpr int CW = (FULL ? 8 : STOMP_LIMG_TILES) * 4 * 16 * 4;   // words per component
+    *reinterpret_cast<uint2*>(img + w) = make_uint2(stomp_pack_top(h[0], h[1]), stomp_pack_top(h[2], h[3]));
+    *reinterpret_cast<uint2*>(img + CW + w) = make_uint2(stomp_pack_top(md[0], md[1]), stomp_pack_top(md[2], md[3]));
+    *reinterpret_cast<uint2*>(img + 2 * CW + w) = make_uint2(stomp_pack_top(l[0], l[1]), stomp_pack_top(l[2], l[3]));
+}
+
+// the eight values v[e] = eps[c][32 kb + 8 g + e] of a lane as the three bf16 operand components
+struct StompEps8 { u32x4 h, m, l; };
+__device__ __forceinline__ void stomp_split8(const float (&v)[8], StompEps8& b) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        stomp_split3(v[2 * q], h0, m0, l0);
+        stomp_split3(v[2 * q + 1], h1, m1, l1);
+        b.h[q] = stomp_pack_top(h0, h1);
+        b.m[q] = stomp_pack_top(m0, m1);
+        b.l[q] = stomp_pack_top(l0, l1);
+    }
+}
+
+// Standard normals of the H = 64 paths, column assignment of the bf16 product: the r-th normal of Philox call q4 of lane
+// group g is eps[j][k] with k = 32 (q4 >> 1) + 8 g + 4 (q4 & 1) + r  (calls 0, 1: column block kb = 0; calls 2, 3: kb = 1).
+__device__ __forceinline__ constexpr int stomp_eps_column(int g, int q4, int r) { return 32 * (q4 >> 1) + 8 * g + 4 * (q4 & 1) + r; }
+
+// acc[m] += rows 16 m .. 16 m + 15 of (column block KB of the 64 x 64 block behind `img`) * eps, for the row tiles the
+// column block reaches (diagonal block: KB = 0 all four, KB = 1 m = 2, 3; full block: all four).  Small component pairs
+// first.  TRANSPOSED: the product is issued as eps * L^T -- lane (j, g) then holds D[channel 4 g + rr][waypoint 16 m + j]
+// (the generalised persistent kernel transposes by lane permutes instead of an LDS round trip); operand registers are
+// the same either way.
+template <int KB, bool FULL = false, bool TRANSPOSED = false>
+__device__ __forceinline__ void stomp_noise_product_kb(const unsigned* __restrict__ img, const StompEps8& b, int j, int g, f32x4 (&acc)[4]) {
+    const u32x4* img4 = reinterpret_cast<const u32x4*>(img);
+    constexpr int CQ = (FULL ? 8 : STOMP_LIMG_TILES) * 4 * 16;       // 16-byte entries per component
+    const bf16x8 bh = __builtin_bit_cast(bf16x8, b.h), bm = __builtin_bit_cast(bf16x8, b.m), bl = __builtin_bit_cast(bf16x8, b.l);
+#pragma unroll
+    for (int m = ((KB == 0 || FULL) ? 0 : 2); m < 4; ++m) {
+        const int q = (stomp_limg_tile<FULL>(m, KB) * 4 + g) * 16 + j;
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, img4[q]), am = __builtin_bit_cast(bf16x8, img4[CQ + q]),
+                     al = __builtin_bit_cast(bf16x8, img4[2 * CQ + q]);
+        if (!TRANSPOSED) {
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[m], 0, 0, 0);
+        } else {
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, am, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, am, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, ah, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah, acc[m], 0, 0, 0);
+        }
+    }
+}
+
+// the eight values of column block KB for lane (j, g): drawn (Philox calls 2 KB, 2 KB + 1) or loaded (eps_s: pre-drawn
+// normals laid out (d, P, H) for this sample, pointer already at [s]); zero for the padding channels j >= DCH
+template <int DCH, int KB, int PRIO>
+__device__ __forceinline__ void stomp_eps8(float (&v)[8], const float* __restrict__ eps_s, int P, int p, int j, int g,
+                                           uint32_t p_global, uint32_t s, uint32_t iter, uint32_t seed_lo, uint32_t seed_hi) {
+    constexpr int H = 64;
+    if (eps_s != nullptr) {
+        const f32x4* ep = reinterpret_cast<const f32x4*>(eps_s + ((size_t)(j < DCH ? j : 0) * P + p) * H + 32 * KB + 8 * g);
+        const f32x4 a = (j < DCH) ? ep[0] : f32x4{0.f, 0.f, 0.f, 0.f}, b = (j < DCH) ? ep[1] : f32x4{0.f, 0.f, 0.f, 0.f};
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int q4 = 2 * KB + q;
+            float n[4] = {0.f, 0.f, 0.f, 0.f};
+            if (PRIO == STOMP_PRIO_PROGRESS) stomp_setprio(3 - q4);
+            if (j < DCH) stomp_eps4(p_global, s, (uint32_t)j, (uint32_t)g, (uint32_t)q4, iter, seed_lo, seed_hi, n);
+            v[4 * q + 0] = n[0]; v[4 * q + 1] = n[1]; v[4 * q + 2] = n[2]; v[4 * q + 3] = n[3];
+        }
+    }
+}
+
+// acc[m] = rows 16 m .. 16 m + 15 of L * eps for the wave's rollout: draw / load, split and multiply, column block by column block
+template <int DCH, int PRIO = STOMP_PRIO_NONE>
+__device__ __forceinline__ void stomp_noise_bf16(const unsigned* __restrict__ img, f32x4 (&acc)[4], const float* __restrict__ eps_s,
+                                                 int P, int p, int j, int g, uint32_t p_global, uint32_t s, uint32_t iter,
+                                                 uint32_t seed_lo, uint32_t seed_hi, int level = 0) {
+    if (PRIO == STOMP_PRIO_STAGGER && eps_s == nullptr) stomp_setprio(level);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float v[8];
+    StompEps8 b;
+    stomp_eps8<DCH, 0, PRIO>(v, eps_s, P, p, j, g, p_global, s, iter, seed_lo, seed_hi);
+    stomp_split8(v, b);
+    stomp_noise_product_kb<0>(img, b, j, g, acc);
+    stomp_eps8<DCH, 1, PRIO>(v, eps_s, P, p, j, g, p_global, s, iter, seed_lo, seed_hi);
+    stomp_split8(v, b);
+    stomp_noise_product_kb<1>(img, b, j, g, acc);
 }
 
 // D tiles (lane = channel) -> the wave's LDS tile [waypoint][channel] -> this lane's waypoint row (lane = waypoint).

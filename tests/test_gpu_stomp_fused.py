@@ -136,19 +136,28 @@ def test_stomp_run_pointmass_generic_model(gpu_device):
     R = stomp_precision_matrix(H, wl['params']['dt'], 0.1, cpu)
     Sigma, L = torch.inverse(R).to(dev).contiguous(), precision_to_scale_tril(R).to(dev).contiguous()
     geom = ops.DeviceGeometry(wl['robot'], wl['field'], dev)
-    res = []
-    for fused in (True, False):
-        means = wl['means0'].clone()
-        samples = torch.empty(P, S, H, d, device=dev)
-        costs, weights = torch.empty(P, S, device=dev), torch.empty(P, S, device=dev)
-        if fused:
-            ws = _ws(P, S, H, d, dev)
-            ops.stomp_run(means, None, samples, costs, weights, L, Sigma, geom, S, 2, 1e6, 1.0, 0.1, 1e5, ws, n_iters=5, seed=2)
-        else:
-            ops.stomp_step(means, None, samples, costs, weights, L, Sigma, geom, S, 2, 1e6, 1.0, 0.1, 1e5, n_iters=5, seed=2)
-        torch.cuda.synchronize()
-        res.append((means, samples, costs))
-    assert rel_err(res[0][0], res[1][0]) < 2e-5 and rel_err(res[0][1], res[1][1]) < 2e-5
+    def run(n):
+        res = []
+        for fused in (True, False):
+            means = wl['means0'].clone()
+            samples = torch.empty(P, S, H, d, device=dev)
+            costs, weights = torch.empty(P, S, device=dev), torch.empty(P, S, device=dev)
+            if fused:
+                ws = _ws(P, S, H, d, dev)
+                ops.stomp_run(means, None, samples, costs, weights, L, Sigma, geom, S, 2, 1e6, 1.0, 0.1, 1e5, ws, n_iters=n, seed=2)
+            else:
+                ops.stomp_step(means, None, samples, costs, weights, L, Sigma, geom, S, 2, 1e6, 1.0, 0.1, 1e5, n_iters=n, seed=2)
+            torch.cuda.synchronize()
+            res.append((means, samples, costs))
+        return res
+    # one iteration: the same samples and costs bit for bit (same noise functions, same evaluator), means to the rounding of
+    # the two softmax forms; five free-running iterations on device noise: north_star's bar (the two forms' 1e-6 per
+    # iteration is amplified by the loop: 2.8e-5 measured with this seed)
+    one = run(1)
+    assert torch.equal(one[0][1], one[1][1]) and torch.equal(one[0][2], one[1][2])
+    assert rel_err(one[0][0], one[1][0]) < 5e-6
+    res = run(5)
+    assert rel_err(res[0][0], res[1][0]) < 1e-4 and rel_err(res[0][1], res[1][1]) < 1e-4
     np.testing.assert_allclose(res[0][2].cpu().numpy(), res[1][2].cpu().numpy(), rtol=1e-3, atol=1e-2)
 
 
