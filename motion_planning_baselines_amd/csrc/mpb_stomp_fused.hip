@@ -309,6 +309,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
             // the next, and the compiler would hoist those products out of the loop and keep -- spill -- them)
             int jv = j, gv = g;
             asm volatile("" : "+v"(jv), "+v"(gv));
+            // (likewise the key: the seven round keys seed + r * W are loop invariants the compiler hoists -- twelve SGPRs that
+            // do not survive the cost phase, i.e. 52 v_readlane of SGPR-spill reloads per iteration on the pipe that binds the
+            // kernel, where recomputing them is twelve s_add on the scalar unit)
+            uint32_t slo = seed_lo, shi = seed_hi;
+            asm volatile("" : "+s"(slo), "+s"(shi));
             // (a k-block pipelined form -- Philox of block q+1 issued between the MFMAs of block q, straight-line code -- was
             // measured 3 % slower: the waves of a SIMD already overlap one wave's matrix work with another's Philox)
             // issue priority by progress through the draws (mpb_stomp_noise.h).  Measured against it on the same box
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
 #endif
             stomp_noise_bf16<DCH, FUSED_NOISE_PRIO>(Limg, acc, eps ? eps + (size_t)it_n * eps_stride + (size_t)(s_n < S ? s_n : 0) * DCH * P * H : nullptr,
                                                     P, p, jv, gv, particle_offset + (uint32_t)p, (uint32_t)s_n, iter0 + (uint32_t)it_n,
-                                                    seed_lo, seed_hi, 3 - (wave >> 2));
+                                                    slo, shi, 3 - (wave >> 2));
             stomp_noise_to_tile(nt, acc, lane);           // (the samples packed in the tile were consumed before barrier 2)
             if (FUSED_NOISE_PRIO == STOMP_PRIO_STAGGER) __builtin_amdgcn_s_setprio(0);
         }

@@ -150,6 +150,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
         for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
         int jv = j, gv = g;
         asm volatile("" : "+v"(jv), "+v"(gv));
+        uint32_t slo = seed_lo, shi = seed_hi;     // (opaque: keeps the round keys from being hoisted out of the loop and spilled)
+        asm volatile("" : "+s"(slo), "+s"(shi));
         // the eps columns of chunk kc as the values of this lane: v[32 KB' + e] = eps[c = j][k = 64 kc + 32 KB' + 8 g + e]
         // (device noise: Philox calls 2 KB', 2 KB' + 1 of the chunk -- mpb_stomp_noise.h, stomp_eps_column)
         auto operand = [&](int kc, float (&e)[16]) {
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
                     stomp_setprio(3 - q4);
                     if (jv < d)
                         stomp_eps4(particle_offset + (uint32_t)p, (uint32_t)s_n, (uint32_t)jv, (uint32_t)gv,
-                                   (uint32_t)(kc << 4) | (uint32_t)q4, iter0 + (uint32_t)it_n, seed_lo, seed_hi, n);
+                                   (uint32_t)(kc << 4) | (uint32_t)q4, iter0 + (uint32_t)it_n, slo, shi, n);
                     e[4 * q4 + 0] = n[0]; e[4 * q4 + 1] = n[1]; e[4 * q4 + 2] = n[2]; e[4 * q4 + 3] = n[3];
                 }
             }
