@@ -367,6 +367,22 @@ int mpb_mppi_step(float *mean, const float *eps, const float *scale_tril, const 
                   int NP, int S, int T, int c, int control_type, float dt,
                   float k_sigma, float weight, float temp, float step_size,
                   int n_iters, uint64_t seed, uint32_t iter0, void *stream);
+/* The point-particle system as stand-alone entry points, for code written against the reference's system object
+ * (dynamics/point.py); mpb_mppi_step fuses the same arithmetic.
+ * mpb_point_dynamics -- PointParticleDynamics.dynamics (point.py:102-140): x_next = x + (clamp(u, ctrl_min, ctrl_max) +
+ *   dyn_std * noise) * dt over n rows of `dim` entries (the reference's xdot = cat(x[..., state_dim:], u) has an empty
+ *   first part); noise NULL = deterministic, else (n, dim) standard normals (the reference draws them with torch.randn).
+ * mpb_point_traj_cost -- PointParticleDynamics.traj_cost (point.py:154-226): X (T, B, state_dim), U (T, B, ctrl_dim) in the
+ *   reference's time-major layout, goal (state_dim), discount (T) -> costs (B) = sum_t disc_t (w_pos |X - goal|^2 +
+ *   w_ctrl |U|^2) + w_pos_T disc_{T-1} |X_{T-1} - goal|^2 + energy; w_vel is accepted and unused (quirk Q8: the reference
+ *   slices dX[..., state_dim:control_dim], an empty tensor); `energy` is the scalar the caller's cost object contributes
+ *   (quirk Q6: cost.eval(cat(X, U)).sum(-1) collapses to ONE number added to every rollout; 0 without one). */
+int mpb_point_dynamics(const float *x, const float *u, const float *ctrl_min, const float *ctrl_max, const float *dyn_std,
+                       const float *noise, float *x_next, size_t n, int dim, float dt, void *stream);
+int mpb_point_traj_cost(const float *X, const float *U, const float *goal, const float *discount, float w_pos, float w_vel,
+                        float w_ctrl, float w_pos_T, float energy, float *costs, int T, int B, int state_dim, int ctrl_dim,
+                        void *stream);
+
 
 /* ---------------------------------------------------------------------------------------------
  * StochGPMP -- replaces StochGPMP.sample_and_eval / _get_costs / _update_distribution

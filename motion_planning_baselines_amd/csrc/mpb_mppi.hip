@@ -475,3 +475,69 @@ extern "C" int mpb_mppi_step(float* mean, const float* eps, const float* scale_t
                        noise_mode);
     return mpb_check_launch("mpb_mppi_step");
 }
+
+// ------------------------------------------------------------------------------------------------
+// The point-particle system as stand-alone entry points (dynamics/point.py): code written against the reference's
+// `system.dynamics(x, u)` / `system.traj_cost(X, U)` runs on these; the MPPI kernel above fuses the same arithmetic.
+// ------------------------------------------------------------------------------------------------
+// x_next = x + (clamp(u, ctrl_min, ctrl_max) + dyn_std * noise) * dt   (point.py:102-140; the reference's xdot = cat(x[..., state_dim:], u)
+// has an EMPTY first part: the state holds state_dim entries), n rows of dim entries; noise NULL: deterministic
+__global__ void point_dynamics_kernel(const float* __restrict__ x, const float* __restrict__ u, const float* __restrict__ ctrl_min,
+                                      const float* __restrict__ ctrl_max, const float* __restrict__ dyn_std,
+                                      const float* __restrict__ noise, float* __restrict__ x_next, size_t n_elem, int dim, float dt) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_elem) return;
+    const int d = (int)(i % (size_t)dim);
+    float uc = fminf(fmaxf(u[i], ctrl_min[d]), ctrl_max[d]);
+    if (noise) uc += dyn_std[d] * noise[i];
+    x_next[i] = fmaf(uc, dt, x[i]);
+}
+
+extern "C" int mpb_point_dynamics(const float* x, const float* u, const float* ctrl_min, const float* ctrl_max, const float* dyn_std,
+                                  const float* noise, float* x_next, size_t n, int dim, float dt, void* stream) {
+    if (!x || !u || !ctrl_min || !ctrl_max || !x_next || (noise && !dyn_std)) return mpb_fail(MPB_E_INVALID, "mpb_point_dynamics: null pointer");
+    if (dim < 1 || dim > 64) return mpb_fail(MPB_E_INVALID, "mpb_point_dynamics: bad dimension");
+    if (n == 0) return MPB_OK;
+    const size_t ne = n * (size_t)dim;
+    hipLaunchKernelGGL(point_dynamics_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, u, ctrl_min,
+                       ctrl_max, dyn_std, noise, x_next, ne, dim, dt);
+    return mpb_check_launch("mpb_point_dynamics");
+}
+
+// quadratic trajectory cost of B rollouts (point.py:154-226): X (T, B, sd), U (T, B, cd) in the reference's time-major
+// layout, one thread per rollout (adjacent threads read adjacent rows: coalesced);
+//   cost_b = sum_t disc_t (w_pos |X_tb - goal|^2 + w_ctrl |U_tb|^2) + w_posT disc_{T-1} |X_{T-1,b} - goal|^2 + energy
+// the velocity term of the reference slices dX[..., state_dim:control_dim], which is empty (quirk Q8): it contributes 0.
+__global__ void point_traj_cost_kernel(const float* __restrict__ X, const float* __restrict__ U, const float* __restrict__ goal,
+                                       const float* __restrict__ discount, float w_pos, float w_ctrl, float w_posT, float energy,
+                                       float* __restrict__ out, int T, int B, int sd, int cd) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float pos = 0.f, ctrl = 0.f, last = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const float* xr = X + ((size_t)t * B + b) * sd;
+        const float* ur = U + ((size_t)t * B + b) * cd;
+        float sx = 0.f, su = 0.f;
+        for (int d = 0; d < sd; ++d) { const float e = xr[d] - goal[d]; sx = fmaf(e, e, sx); }
+        for (int d = 0; d < cd; ++d) su = fmaf(ur[d], ur[d], su);
+        const float dsc = discount[t];
+        pos = fmaf(sx * w_pos, dsc, pos);
+        ctrl = fmaf(su * w_ctrl, dsc, ctrl);
+        last = sx;
+    }
+    out[b] = pos + 0.f + ctrl + (last * w_posT) * discount[T - 1] + energy;   // (pos + vel + control + terminal + energy, point.py:225)
+}
+
+extern "C" int mpb_point_traj_cost(const float* X, const float* U, const float* goal, const float* discount, float w_pos, float w_vel,
+                                   float w_ctrl, float w_pos_T, float energy, float* costs, int T, int B, int state_dim, int ctrl_dim,
+                                   void* stream) {
+    (void)w_vel;     // (quirk Q8: the velocity slice is empty)
+    if (!X || !U || !goal || !discount || !costs) return mpb_fail(MPB_E_INVALID, "mpb_point_traj_cost: null pointer");
+    if (T < 1 || B < 0 || state_dim < 1 || state_dim > 64 || ctrl_dim < 1 || ctrl_dim > 64)
+        return mpb_fail(MPB_E_INVALID, "mpb_point_traj_cost: bad shape");
+    if (B == 0) return MPB_OK;
+    hipLaunchKernelGGL(point_traj_cost_kernel, dim3((B + 127) / 128), dim3(128), 0, (hipStream_t)stream, X, U, goal, discount,
+                       w_pos, w_ctrl, w_pos_T, energy, costs, T, B, state_dim, ctrl_dim);
+    return mpb_check_launch("mpb_point_traj_cost");
+}
+

@@ -708,6 +708,38 @@ def mppi_step(mean, eps, scale_tril, cov_inv, state0, goal, ctrl_min, ctrl_max, 
 
 
 @_on_tensor_device
+def point_dynamics(x, u, ctrl_min, ctrl_max, dt, dyn_std=None, noise=None):
+    """PointParticleDynamics.dynamics (point.py:102-140): x, u (..., dim) contiguous fp32 of the same shape -> x_next."""
+    dim = x.shape[-1]
+    _chk(x, tuple(x.shape), 'x')
+    _chk(u, tuple(x.shape), 'u')
+    _chk(ctrl_min, (dim,), 'ctrl_min')
+    _chk(ctrl_max, (dim,), 'ctrl_max')
+    if noise is not None:
+        _chk(noise, tuple(x.shape), 'noise')
+        _chk(dyn_std, (dim,), 'dyn_std')
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().mpb_point_dynamics(_ptr(x), _ptr(u), _ptr(ctrl_min), _ptr(ctrl_max), _ptr(dyn_std if noise is not None else None),
+                                            _ptr(noise), _ptr(out), x.numel() // dim, dim, float(dt), _stream()), 'mpb_point_dynamics')
+    return out
+
+
+@_on_tensor_device
+def point_traj_cost(X, U, goal, discount, w_pos, w_vel, w_ctrl, w_pos_T, energy=0.0):
+    """PointParticleDynamics.traj_cost (point.py:154-226): X (T,B,sd), U (T,B,cd), goal (sd), discount (T) -> costs (B)."""
+    T, B, sd = X.shape
+    cd = U.shape[-1]
+    _chk(X, (T, B, sd), 'X')
+    _chk(U, (T, B, cd), 'U')
+    _chk(goal, (sd,), 'goal')
+    _chk(discount, (T,), 'discount')
+    out = torch.empty(B, device=X.device, dtype=torch.float32)
+    _lib.check(_lib.lib().mpb_point_traj_cost(_ptr(X), _ptr(U), _ptr(goal), _ptr(discount), float(w_pos), float(w_vel), float(w_ctrl),
+                                             float(w_pos_T), float(energy), _ptr(out), T, B, sd, cd, _stream()), 'mpb_point_traj_cost')
+    return out
+
+
+@_on_tensor_device
 def mvn_sample_dense(means, eps, tril_t, n, seed=0):
     """x = mean + L eps from a dense scale_tril handed over transposed (mpb_mvn_sample_dense): means (G,M) fp64, eps None or
     (n,G,M) fp64, tril_t (M,M) fp64 with tril_t[k,m] = L[m,k] -> (G*n, M) fp32, row mode * n + sample."""

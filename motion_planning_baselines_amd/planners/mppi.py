@@ -13,7 +13,8 @@ from .costs.cost_functions import fusable_collision
 
 
 from .dynamics.point import PointParticleDynamics  # noqa: F401  (import path of the reference kept: planners.dynamics.point)
-from .priors.gaussian import check_Cov_is_valid, const_ctrl_Cov, diag_Cov  # noqa: F401
+from .priors.gaussian import (ControlTrajectoryGaussian, check_Cov_is_valid, const_ctrl_Cov, diag_Cov,  # noqa: F401
+                              get_multivar_gaussian_prior)
 
 
 BEST_COST_NONE = 3.0e38     # "no sample seen yet" of the device-side best-cost tracker
@@ -98,6 +99,17 @@ class MPPI(MPPlanner):
                 cc, weight = fused
                 geom, k_sigma = cc.device_geometry(self.device), cc.k_sigma
         return state, goal, geom, k_sigma, weight
+
+    @property
+    def ctrl_dist(self):
+        """The sampling distribution as the reference's object (mppi.py:42-49: `planner.ctrl_dist.Cov`, `.sample(n)`), its means
+        synchronised with the planner's current mean on access (the one-launch loop samples inside the kernel and does
+        not go through this object)."""
+        if getattr(self, '_ctrl_dist', None) is None:
+            self._ctrl_dist = ControlTrajectoryGaussian(self.rollout_steps, self.control_dim, self._mean, self.Cov,
+                                                        tensor_args=dict(device=self.device, dtype=torch.float32), seed=self.seed)
+        self._ctrl_dist.update_means(self._mean)
+        return self._ctrl_dist
 
     @property
     def best_cost(self):
