@@ -54,7 +54,8 @@ int mpb_geom_check(const float *geom_host, int n_words);
  * (csrc/mpb_model_*.h) every chained field is tagged with AND whose cost-only kernels can run (every field has a
  * usable broad-phase grid); 0 = generic table-driven kernels; bit 8 = every chained field has a usable broad-phase
  * grid (what the persistent STOMP kernel needs); bit 9 = point robot with ONE field of at most 32 spheres and 8 boxes
- * (CHOMP's four-lanes-per-waypoint kernel keeps such an obstacle set in registers).  Entry points that take `geom_flags` expect the value
+ * (CHOMP's four-lanes-per-waypoint kernel keeps such an obstacle set in registers); bits 16-28 = cells of the largest
+ * broad-phase grid of the chain when bit 8 is set (what a kernel that stages the grid in LDS has to reserve).  Entry points that take `geom_flags` expect the value
  * computed from the host copy of the very buffer `geom` points to (0 is always valid); a kernel re-checks the tag
  * against the device header and writes NaN costs if they disagree. */
 int mpb_geom_flags(const float *geom_host, int n_words, int *flags);
@@ -348,7 +349,9 @@ int mpb_gpmp2_step(float *x, const float *start, const float *goal, const float 
  * goal (NP,c); ctrl_min / ctrl_max (c); discount (T); c_weights = {pos, vel, ctrl, pos_T};
  * control_type 0 = velocity (state_dim = c); 1 = acceleration is MPB_E_UNSUPPORTED (the reference's
  * acceleration mode slices an empty tensor, point.py:114-118, and cannot run).
- * geom optional (NULL = no collision term).  With geom, the reference's quirk Q6 is reproduced:
+ * geom optional (NULL = no collision term); geom_flags = mpb_geom_flags(host copy of geom) (0 is always valid): with a
+ * single grid-backed field the collision cost of a rollout goes through the broad-phase grid (staged in LDS: one
+ * candidate look-up per waypoint instead of the exhaustive obstacle loop; same bits).  With geom, the reference's quirk Q6 is reproduced:
  * the per-sample collision costs are summed into ONE scalar that is added to every sample's cost.
  * Outputs of the last iteration: controls (NP,S,T,c), states (NP,S,T,c), costs (NP,S), weights (NP,S).
  * best_cost (NP) in/out + best_states (NP,T,c) out, both or neither (NULL): MPPI._save_best
@@ -361,7 +364,7 @@ int mpb_gpmp2_step(float *x, const float *start, const float *goal, const float 
  * ------------------------------------------------------------------------------------------- */
 int mpb_mppi_step(float *mean, const float *eps, const float *scale_tril, const float *cov_inv,
                   const float *state0, const float *goal, const float *ctrl_min, const float *ctrl_max,
-                  const float *discount, const float *c_weights, const float *geom,
+                  const float *discount, const float *c_weights, const float *geom, int geom_flags,
                   float *controls, float *states, float *costs, float *weights,
                   float *best_cost, float *best_states,
                   int NP, int S, int T, int c, int control_type, float dt,

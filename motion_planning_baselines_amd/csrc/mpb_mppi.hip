@@ -64,6 +64,8 @@ struct MppiLds {
     float* epsw;   // W*c*T : standard normals of the sample a wave is working on, [wave][i][t]
     float* trilT;  // c*T*T : scale_tril transposed [i][k][t] (only when it fits); matrix path: c*4096, the MFMA images
     float* E;      // matrix path: c*Spad*64 standard normals of EVERY sample, [i][s][k & 3][k >> 2] (zero beyond T / S)
+    unsigned* gridw;   // grid path (ONE grid-backed collision field): the broad-phase grid, grid_words words ...
+    float4* otab;      // ... and the obstacle table (n_sph + 1 entries, the last one the far dummy)
 };
 
 // How U = mean + scale_tril @ eps is formed (mpb_mppi_step picks):
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
     float* __restrict__ states, float* __restrict__ costs, float* __restrict__ weights,
     float* __restrict__ best_cost, float* __restrict__ best_states, int S, int T, int c,
     float dt, float k_sigma, float weight, float temp, float step_size, int n_iters, uint32_t seed_lo,
-    uint32_t seed_hi, uint32_t iter0, int noise_mode) {
+    uint32_t seed_hi, uint32_t iter0, int noise_mode, int grid_words) {
     extern __shared__ float lds[];
     const int nw = blockDim.x >> 6, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     MppiLds M;
@@ -103,6 +105,20 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
     if (matrix) {                      // (no per-wave normals: the slab holds every sample's)
         M.trilT = lds + (((M.epsw - lds) + 3) & ~(ptrdiff_t)3);                       // 16-byte rows for ds_read_b128
         M.E = M.trilT + (size_t)c * 4096;
+    }
+    // collision through the broad-phase grid: the launcher reserved grid_words + 4 (MPB_GRID_MAX_SPH + 1) words behind
+    // everything else when geom_flags promised ONE grid-backed field; the device header has the last word
+    GeomView G0;
+    bool use_grid = false;
+    if (geom != nullptr) {
+        G0 = geom_view(geom);
+        use_grid = grid_words > 0 && G0.next == 0 && grid_usable(G0) && G0.n_cells <= grid_words;
+        if (use_grid) {
+            float* tail = matrix ? M.E + (size_t)c * Spad * 64 : (tril_in_lds ? M.trilT + (size_t)c * T * T : M.trilT);
+            M.gridw = reinterpret_cast<unsigned*>(lds + (((tail - lds) + 3) & ~(ptrdiff_t)3));
+            M.otab = reinterpret_cast<float4*>(M.gridw + ((grid_words + 3) & ~3));
+            grid_stage(G0, M.gridw, M.otab, threadIdx.x, blockDim.x);
+        }
     }
     const int prob = blockIdx.x;
     float* m = mean + (size_t)prob * T * c;
@@ -301,7 +317,8 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
                         float q[MPB_MAX_DOF], dq[MPB_MAX_DOF];
 #pragma unroll
                         for (int i = 0; i < MPB_MAX_DOF; ++i) q[i] = (i < MPPI_MAX_C && i < c) ? x[i < MPPI_MAX_C ? i : 0] : 0.f;
-                        coll_l += waypoint_cost_chain<false>(geom, q, dq);
+                        // (same bits either way: the grid only culls, tests/test_gpu_parity_gpmp2_mppi.py)
+                        coll_l += use_grid ? G0.fscale * waypoint_cost_grid(G0, M.gridw, M.otab, q) : waypoint_cost_chain<false>(geom, q, dq);
                     }
                     if (last) {                                 // API-visible outputs of the last iteration
                         float* Ug = controls + (((size_t)prob * S + s) * T + t) * c;
@@ -430,7 +447,7 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
 
 extern "C" int mpb_mppi_step(float* mean, const float* eps, const float* scale_tril, const float* cov_inv,
                              const float* state0, const float* goal, const float* ctrl_min, const float* ctrl_max,
-                             const float* discount, const float* c_weights, const float* geom, float* controls,
+                             const float* discount, const float* c_weights, const float* geom, int geom_flags, float* controls,
                              float* states, float* costs, float* weights, float* best_cost, float* best_states,
                              int NP, int S, int T, int c, int control_type,
                              float dt, float k_sigma, float weight, float temp, float step_size, int n_iters,
@@ -468,11 +485,25 @@ extern "C" int mpb_mppi_step(float* mean, const float* eps, const float* scale_t
     int noise_mode = (T <= 64 && with_matrix <= budget) ? MPPI_NOISE_MATRIX : (with_tril <= budget ? MPPI_NOISE_LDS : MPPI_NOISE_GLOBAL);
     if (force_mode == MPPI_NOISE_GLOBAL) noise_mode = MPPI_NOISE_GLOBAL;
     if (force_mode == MPPI_NOISE_LDS && with_tril <= budget) noise_mode = MPPI_NOISE_LDS;
-    const size_t lds = (noise_mode == MPPI_NOISE_MATRIX ? with_matrix : noise_mode == MPPI_NOISE_LDS ? with_tril : base) * sizeof(float);
+    size_t lds_words = noise_mode == MPPI_NOISE_MATRIX ? with_matrix : noise_mode == MPPI_NOISE_LDS ? with_tril : base;
+    // ONE grid-backed collision field (geom_flags bit 8, bits 16-28 = its cells): the grid + obstacle table ride in LDS when
+    // they fit next to the rest (and, with two workgroups per CU, leave room for the second one)
+    int grid_words = 0;
+    static const int no_grid = getenv("MPB_MPPI_NO_GRID") ? atoi(getenv("MPB_MPPI_NO_GRID")) : 0;           // tuning / tests
+    if (geom && (geom_flags & 0x100) && !no_grid) {
+        const int cells = (geom_flags >> 16) & 0x1FFF;
+        const size_t extra = 4 + (size_t)((cells + 3) & ~3) + 4 * (MPB_GRID_MAX_SPH + 1);
+        const size_t cap = (nw <= 8 ? 78 : 150) * 1024 / sizeof(float);
+        if (cells > 0 && lds_words + extra <= cap) {
+            grid_words = cells;
+            lds_words += extra;
+        }
+    }
+    const size_t lds = lds_words * sizeof(float);
     hipLaunchKernelGGL(mppi_kernel, dim3(NP), dim3(64 * nw), lds, (hipStream_t)stream, mean, eps, scale_tril, cov_inv,
                        state0, goal, ctrl_min, ctrl_max, discount, c_weights, geom, controls, states, costs, weights,
                        best_cost, best_states, S, T, c, dt, k_sigma, weight, temp, step_size, n_iters, (uint32_t)seed, (uint32_t)(seed >> 32), iter0,
-                       noise_mode);
+                       noise_mode, grid_words);
     return mpb_check_launch("mpb_mppi_step");
 }
 

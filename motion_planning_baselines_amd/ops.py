@@ -701,7 +701,8 @@ def mppi_step(mean, eps, scale_tril, cov_inv, state0, goal, ctrl_min, ctrl_max, 
     _chk(best_states, (NP, T, c), 'best_states', allow_none=True)
     _lib.check(_lib.lib().mpb_mppi_step(
         _ptr(mean), _ptr(eps), _ptr(scale_tril), _ptr(cov_inv), _ptr(state0), _ptr(goal), _ptr(ctrl_min), _ptr(ctrl_max),
-        _ptr(discount), _ptr(c_weights), _ptr(None if geom is None else geom.buf), _ptr(controls), _ptr(states),
+        _ptr(discount), _ptr(c_weights), _ptr(None if geom is None else geom.buf), 0 if geom is None else int(geom.flags),
+        _ptr(controls), _ptr(states),
         _ptr(costs), _ptr(weights), _ptr(best_cost), _ptr(best_states), NP, S, T, c, 0, float(dt), float(k_sigma),
         float(weight), float(temp),
         float(step_size), int(n_iters), int(seed) & (2 ** 64 - 1), int(iter0), _stream()), 'mpb_mppi_step')
