@@ -531,12 +531,23 @@ def bench_mppi(dev, steps, NP=1024):
         run(steps)
     t = sorted(run(steps) for _ in range(5))[2]
     alg = 4 * (2 * S * T * c + 2 * T * c + 2 * S)          # bytes per problem and iteration
+    roof = {'bound': 'hbm (nominal)', 'achieved': alg * NP * steps / t / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': alg * NP * steps / t / 1e9 / HBM_PEAK_GBS,
+            'note': 'controls + states written per iteration; the kernel keeps a problem in one workgroup (wave = sample)'}
+    pmc, pmc_file = latest_profile('r*_mppi_pmc_mppi.json')
+    if pmc and pmc.get('SQ_INSTS_VALU_per_wave_iteration') and NP == 1024:
+        # what binds it: fp32 VALU issue (instruction count of the committed rocprofv3 PMC passes of this very entry,
+        # scripts/prof_mppi.py, x the waves of a launch / the time measured here)
+        ginstr = pmc['SQ_INSTS_VALU_per_wave_iteration'] * pmc['waves_per_launch'] / (t / steps) / 1e9
+        roof = {'bound': 'valu', 'achieved': ginstr, 'peak': VALU_PEAK_GINSTR, 'unit': 'G wave-instr/s', 'frac': ginstr / VALU_PEAK_GINSTR,
+                'valu_instructions_per_wave_iteration': pmc['SQ_INSTS_VALU_per_wave_iteration'], 'pmc_source': pmc_file,
+                'lds_bank_conflict_frac_of_lds_cycles': (pmc['SQ_LDS_BANK_CONFLICT_per_wave_iteration'] / pmc['SQ_LDS_IDX_ACTIVE_per_wave_iteration']
+                                                         if pmc.get('SQ_LDS_IDX_ACTIVE_per_wave_iteration') else None),
+                'scratch_bytes_per_lane': pmc.get('scratch_bytes'), 'hbm_nominal': roof}
     return {'workload': 'MPPI point mass, %d problems x S=%d samples x T=%d steps x c=%d, %d iterations per launch' % (NP, S, T, c, steps),
             'metric': 'mppi_problem_iterations_per_sec', 'value': NP * steps / t, 'unit': 'problem-iters/s',
             'ms_per_step': 1e3 * t / steps, 'us_per_problem_iteration': 1e6 * t / steps / NP, 'dtype': 'f32',
-            'roofline': {'bound': 'hbm (nominal)', 'achieved': alg * NP * steps / t / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': alg * NP * steps / t / 1e9 / HBM_PEAK_GBS,
-                         'note': 'controls + states written per iteration; the kernel keeps a problem in one workgroup (wave = sample)'}}
+            'roofline': roof}
 
 
 def self_launch(n):

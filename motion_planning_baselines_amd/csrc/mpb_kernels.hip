@@ -164,7 +164,7 @@ extern "C" int mpb_geom_flags(const float* g, int n_words, int* flags) {
     const int32_t* g0 = reinterpret_cast<const int32_t*>(g);
     const bool point_small = g0[2] == MPB_KIND_POINT && g0[27] == 0 && g0[6] <= 32 && g0[7] <= 8;
     *flags = (model > 0 ? (model & 0xFF) : 0) | (all_grids ? 0x100 : 0) | (point_small ? 0x200 : 0) |
-             (all_grids ? (max_cells & 0x1FFF) << 16 : 0);
+             (g0[2] == MPB_KIND_POINT ? 0x400 : 0) | (all_grids ? (max_cells & 0x1FFF) << 16 : 0);
     return MPB_OK;
 }
 

@@ -21,6 +21,7 @@
 #include "mpb_stomp_noise.h"   // the permuted MFMA image of a 64 x 64 lower-triangular factor (stomp_l_image_index)
 
 #define MPPI_MAX_C 4
+#define MPPI_E_STRIDE 68   // words between the samples of the normals slab: 64 + 4, so that the 16-byte operand reads of the lanes of a tile row land on different banks
 
 __device__ __forceinline__ float block_sum(float v, float* red, int lane, int wave, int nw) {
     v = wave_sum_f32(v);
@@ -63,7 +64,7 @@ struct MppiLds {
     float* Us;     // S*c*T : controls of every sample, [s][i][t]
     float* epsw;   // W*c*T : standard normals of the sample a wave is working on, [wave][i][t]
     float* trilT;  // c*T*T : scale_tril transposed [i][k][t] (only when it fits); matrix path: c*4096, the MFMA images
-    float* E;      // matrix path: c*Spad*64 standard normals of EVERY sample, [i][s][k & 3][k >> 2] (zero beyond T / S)
+    float* E;      // matrix path: c*Spad*MPPI_E_STRIDE standard normals of EVERY sample, [i][s][k & 3][k >> 2] (zero beyond T / S)
     unsigned* gridw;   // grid path (ONE grid-backed collision field): the broad-phase grid, grid_words words ...
     float4* otab;      // ... and the obstacle table (n_sph + 1 entries, the last one the far dummy)
 };
@@ -80,16 +81,21 @@ struct MppiLds {
 #define MPPI_NOISE_LDS 1
 #define MPPI_NOISE_MATRIX 2
 
+// CC: the control dimension as a compile-time constant (2: the reference example's point mass; 0: run-time c <= MPPI_MAX_C);
+// GRID: collision through the broad-phase grid (ONE grid-backed field) -- the exhaustive evaluator, with its blocks of obstacles
+// in scalar registers, lives in the other instantiation (one kernel holding both spilled 48 VGPRs and 292 SGPRs)
+template <int CC, bool GRID>
 __global__ __launch_bounds__(1024) void mppi_kernel(
     float* __restrict__ mean, const float* __restrict__ eps, const float* __restrict__ tril,
     const float* __restrict__ cov_inv, const float* __restrict__ state0, const float* __restrict__ goal,
     const float* __restrict__ ctrl_min, const float* __restrict__ ctrl_max, const float* __restrict__ discount,
     const float* __restrict__ cw, const float* __restrict__ geom, float* __restrict__ controls,
     float* __restrict__ states, float* __restrict__ costs, float* __restrict__ weights,
-    float* __restrict__ best_cost, float* __restrict__ best_states, int S, int T, int c,
+    float* __restrict__ best_cost, float* __restrict__ best_states, int S, int T, int c_rt,
     float dt, float k_sigma, float weight, float temp, float step_size, int n_iters, uint32_t seed_lo,
     uint32_t seed_hi, uint32_t iter0, int noise_mode, int grid_words) {
     extern __shared__ float lds[];
+    const int c = CC ? CC : c_rt;
     const int nw = blockDim.x >> 6, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     MppiLds M;
     M.wvec = lds;
@@ -98,9 +104,10 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
     M.cst = M.wts + ((S + 3) & ~3);
     M.coll = M.cst + ((S + 3) & ~3);
     M.Us = M.coll + ((S + 3) & ~3);
-    M.epsw = M.Us + (size_t)S * c * T;
+    M.epsw = M.Us + (size_t)S * (c * T + 4);
     M.trilT = M.epsw + (size_t)nw * c * T;
     const bool tril_in_lds = noise_mode == MPPI_NOISE_LDS, matrix = noise_mode == MPPI_NOISE_MATRIX;
+    const int us_stride = c * T + 4;                   // words between the samples of the controls slab (see the matrix product)
     const int Spad = (S + 15) & ~15;
     if (matrix) {                      // (no per-wave normals: the slab holds every sample's)
         M.trilT = lds + (((M.epsw - lds) + 3) & ~(ptrdiff_t)3);                       // 16-byte rows for ds_read_b128
@@ -112,9 +119,9 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
     bool use_grid = false;
     if (geom != nullptr) {
         G0 = geom_view(geom);
-        use_grid = grid_words > 0 && G0.next == 0 && grid_usable(G0) && G0.n_cells <= grid_words;
+        use_grid = GRID && grid_words > 0 && G0.next == 0 && G0.kind == MPB_KIND_POINT && grid_usable(G0) && G0.n_cells <= grid_words;
         if (use_grid) {
-            float* tail = matrix ? M.E + (size_t)c * Spad * 64 : (tril_in_lds ? M.trilT + (size_t)c * T * T : M.trilT);
+            float* tail = matrix ? M.E + (size_t)c * Spad * MPPI_E_STRIDE : (tril_in_lds ? M.trilT + (size_t)c * T * T : M.trilT);
             M.gridw = reinterpret_cast<unsigned*>(lds + (((tail - lds) + 3) & ~(ptrdiff_t)3));
             M.otab = reinterpret_cast<float4*>(M.gridw + ((grid_words + 3) & ~3));
             grid_stage(G0, M.gridw, M.otab, threadIdx.x, blockDim.x);
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
             const int i = e >> 12, row = (e >> 6) & 63, col = e & 63;
             M.trilT[i * 4096 + stomp_l_image_index(row, col)] = (row < T && col < T) ? tril[((size_t)i * T + row) * T + col] : 0.f;
         }
-        for (int e = threadIdx.x; e < c * Spad * 64; e += blockDim.x) M.E[e] = 0.f;      // padding samples / steps stay zero
+        for (int e = threadIdx.x; e < c * Spad * MPPI_E_STRIDE; e += blockDim.x) M.E[e] = 0.f;      // padding samples / steps stay zero
     }
     float gl[MPPI_MAX_C], x0[MPPI_MAX_C], umin[MPPI_MAX_C], umax[MPPI_MAX_C];
 #pragma unroll
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
             if (eps != nullptr) {
                 for (int e = threadIdx.x; e < c * S * T; e += blockDim.x) {
                     const int i = e / (S * T), r = e - i * S * T, ss = r / T, t = r - ss * T;
-                    M.E[(((size_t)i * Spad + ss) * 4 + (t & 3)) * 16 + (t >> 2)] =
+                    M.E[((size_t)i * Spad + ss) * MPPI_E_STRIDE + (t & 3) * 16 + (t >> 2)] =
                         eps[((((size_t)it * gridDim.x + prob) * c + i) * S + ss) * T + t];
                 }
             } else {
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
                     box_muller(rr.z, rr.w, n[2], n[3]);
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        if (4 * g4 + q < T) M.E[(((size_t)i * Spad + ss) * 4 + q) * 16 + g4] = n[q];
+                        if (4 * g4 + q < T) M.E[((size_t)i * Spad + ss) * MPPI_E_STRIDE + q * 16 + g4] = n[q];
                 }
             }
             __syncthreads();
@@ -198,22 +205,25 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
             for (int tile = wave; tile < c * 4 * NT; tile += nw) {
                 const int i = tile / (4 * NT), r = tile - i * 4 * NT, mt = r / NT, nt = r - mt * NT;
                 if (16 * mt >= T) continue;                                              // (wave-uniform)
-                const f32x4* e4 = reinterpret_cast<const f32x4*>(M.E + (((size_t)i * Spad + 16 * nt + j) * 4 + g) * 16);
+                const f32x4* e4 = reinterpret_cast<const f32x4*>(M.E + ((size_t)i * Spad + 16 * nt + j) * MPPI_E_STRIDE + g * 16);
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 for (int ks4 = 0; ks4 <= mt; ++ks4) {
                     const f32x4 a = L4[i * 1024 + ((mt * 4 + ks4) * 4 + g) * 16 + j];
                     const f32x4 b = e4[ks4];
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b[0], a[0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b[1], a[1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b[2], a[2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b[3], a[3], acc, 0, 0, 0);
                 }
-                // acc[r] = (L eps)[t = 16 mt + 4 g + r][sample 16 nt + j]
-                const int ss = 16 * nt + j;
+                // issued TRANSPOSED (A = eps, B = L^T: same operand registers): acc[r] = (L eps)[t = 16 mt + j][sample 16 nt + 4 g + r]
+                // -- the 16 lanes of a row write 16 consecutive steps of one sample, and the sample stride of the slab
+                // (c T + 4 words) puts the four rows on different banks: conflict-free (the untransposed form wrote 16
+                // samples at the same step: a 16-way conflict, 66 % of the kernel's LDS cycles in round 3)
+                const int t = 16 * mt + j;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int t = 16 * mt + 4 * g + q;
-                    if (ss < S && t < T) M.Us[((size_t)ss * c + i) * T + t] = m[t * c + i] + acc[q];
+                    const int ss = 16 * nt + 4 * g + q;
+                    if (ss < S && t < T) M.Us[(size_t)ss * us_stride + i * T + t] = m[t * c + i] + acc[q];
                 }
             }
             __syncthreads();
@@ -258,7 +268,7 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
                 for (int i = 0; i < MPPI_MAX_C; ++i) {
                     u[i] = 0.f;
                     if (matrix) {
-                        if (i < c && on) u[i] = M.Us[((size_t)s * c + i) * T + t];
+                        if (i < c && on) u[i] = M.Us[(size_t)s * us_stride + i * T + t];
                     } else if (i < c && on) {
                         // U = mean + L eps (gaussian.py:276-298), ascending k like the matmul row
                         float a = 0.f;
@@ -284,7 +294,7 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
                             for (int k = 0; k < kend; ++k) a = fmaf(row[k], ew[i * T + k], a);
                         }
                         u[i] = m[t * c + i] + a;
-                        M.Us[((size_t)s * c + i) * T + t] = u[i];
+                        M.Us[(size_t)s * us_stride + i * T + t] = u[i];
                     }
                 }
                 // ---- Euler rollout (mppi.py:205-209, point.py:112, :139): x_t = x_0 + sum_{k<t} clamp(u_k) dt
@@ -318,7 +328,20 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
 #pragma unroll
                         for (int i = 0; i < MPB_MAX_DOF; ++i) q[i] = (i < MPPI_MAX_C && i < c) ? x[i < MPPI_MAX_C ? i : 0] : 0.f;
                         // (same bits either way: the grid only culls, tests/test_gpu_parity_gpmp2_mppi.py)
-                        coll_l += use_grid ? G0.fscale * waypoint_cost_grid(G0, M.gridw, M.otab, q) : waypoint_cost_chain<false>(geom, q, dq);
+                        if (GRID) {
+                            // (the launcher picked this instantiation from geom_flags; a device header that disagrees poisons
+                            // the cost instead of being mis-read)
+                            if (use_grid) {      // the point branch of waypoint_cost_grid (mpb_geom.h), same expressions
+                                const float px[1] = {q[0]}, py[1] = {q[1]}, pz[1] = {(G0.n_dof > 2) ? q[2] : 0.f}, rl[1] = {G0.links[4]};
+                                float cg = 0.f;
+                                spheres_hinge_grid<1>(G0, M.gridw, M.otab, px, py, pz, rl, cg);
+                                coll_l += G0.fscale * cg;
+                            } else {
+                                coll_l += __uint_as_float(0x7FC00000u);
+                            }
+                        } else {
+                            coll_l += waypoint_cost_chain<false>(geom, q, dq);
+                        }
                     }
                     if (last) {                                 // API-visible outputs of the last iteration
                         float* Ug = controls + (((size_t)prob * S + s) * T + t) * c;
@@ -379,7 +402,7 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
                     const bool on = t < T;
 #pragma unroll
                     for (int i = 0; i < MPPI_MAX_C; ++i) {
-                        const float u = (i < c && on) ? M.Us[((size_t)bi * c + i) * T + t] : 0.f;
+                        const float u = (i < c && on) ? M.Us[(size_t)bi * us_stride + i * T + t] : 0.f;
                         const float v = (i < c && on) ? fminf(fmaxf(u, umin[i]), umax[i]) * dt : 0.f;
                         const float inc = wave_scan_incl(v, lane);
                         const float x = x0[i] + (carry[i] + (inc - v));
@@ -433,12 +456,12 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     wv[u] = M.wts[ss + u];
-                    uv[u] = M.Us[((size_t)(ss + u) * c + i) * T + t];
+                    uv[u] = M.Us[(size_t)(ss + u) * us_stride + i * T + t];
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) a += wv[u] * (uv[u] - mu);
             }
-            for (; ss < S; ++ss) a += M.wts[ss] * (M.Us[((size_t)ss * c + i) * T + t] - mu);
+            for (; ss < S; ++ss) a += M.wts[ss] * (M.Us[(size_t)ss * us_stride + i * T + t] - mu);
             m[t * c + i] = mu + step_size * a;
         }
         __threadfence_block();
@@ -475,12 +498,12 @@ extern "C" int mpb_mppi_step(float* mean, const float* eps, const float* scale_t
     int nw = S < 16 ? S : 16;
     if (NP >= 2 * n_cu && S >= 16) nw = 8;
     if (force_nw > 0 && force_nw <= 16 && force_nw <= S) nw = force_nw;
-    const size_t base = (size_t)c * T + 64 + 3 * (size_t)((S + 3) & ~3) + (size_t)S * c * T + (size_t)nw * c * T;
+    const size_t base = (size_t)c * T + 64 + 3 * (size_t)((S + 3) & ~3) + (size_t)S * (c * T + 4) + (size_t)nw * c * T;
     const size_t with_tril = base + (size_t)c * T * T;
     const size_t budget = 150 * 1024 / sizeof(float);
     if (base > budget) return mpb_fail(MPB_E_UNSUPPORTED, "mpb_mppi_step: S*T*c too large for the LDS controls slab");
     // the matrix path swaps the per-wave normals + transposed factor for the MFMA images + every sample's normals
-    const size_t with_matrix = base - (size_t)nw * c * T + 4 + (size_t)c * 4096 + (size_t)c * ((S + 15) & ~15) * 64;
+    const size_t with_matrix = base - (size_t)nw * c * T + 4 + (size_t)c * 4096 + (size_t)c * ((S + 15) & ~15) * MPPI_E_STRIDE;
     static const int force_mode = getenv("MPB_MPPI_NOISE") ? atoi(getenv("MPB_MPPI_NOISE")) : -1;     // tuning / tests: 0, 1, 2
     int noise_mode = (T <= 64 && with_matrix <= budget) ? MPPI_NOISE_MATRIX : (with_tril <= budget ? MPPI_NOISE_LDS : MPPI_NOISE_GLOBAL);
     if (force_mode == MPPI_NOISE_GLOBAL) noise_mode = MPPI_NOISE_GLOBAL;
@@ -490,7 +513,7 @@ extern "C" int mpb_mppi_step(float* mean, const float* eps, const float* scale_t
     // they fit next to the rest (and, with two workgroups per CU, leave room for the second one)
     int grid_words = 0;
     static const int no_grid = getenv("MPB_MPPI_NO_GRID") ? atoi(getenv("MPB_MPPI_NO_GRID")) : 0;           // tuning / tests
-    if (geom && (geom_flags & 0x100) && !no_grid) {
+    if (geom && (geom_flags & 0x500) == 0x500 && !no_grid) {       // grid-backed fields, point robot
         const int cells = (geom_flags >> 16) & 0x1FFF;
         const size_t extra = 4 + (size_t)((cells + 3) & ~3) + 4 * (MPB_GRID_MAX_SPH + 1);
         const size_t cap = (nw <= 8 ? 78 : 150) * 1024 / sizeof(float);
@@ -500,10 +523,16 @@ extern "C" int mpb_mppi_step(float* mean, const float* eps, const float* scale_t
         }
     }
     const size_t lds = lds_words * sizeof(float);
-    hipLaunchKernelGGL(mppi_kernel, dim3(NP), dim3(64 * nw), lds, (hipStream_t)stream, mean, eps, scale_tril, cov_inv,
-                       state0, goal, ctrl_min, ctrl_max, discount, c_weights, geom, controls, states, costs, weights,
-                       best_cost, best_states, S, T, c, dt, k_sigma, weight, temp, step_size, n_iters, (uint32_t)seed, (uint32_t)(seed >> 32), iter0,
-                       noise_mode, grid_words);
+#define MPPI_LAUNCH(CC, GRID)                                                                                                   \
+    hipLaunchKernelGGL((mppi_kernel<CC, GRID>), dim3(NP), dim3(64 * nw), lds, (hipStream_t)stream, mean, eps, scale_tril, cov_inv, \
+                       state0, goal, ctrl_min, ctrl_max, discount, c_weights, geom, controls, states, costs, weights, best_cost,  \
+                       best_states, S, T, c, dt, k_sigma, weight, temp, step_size, n_iters, (uint32_t)seed,                        \
+                       (uint32_t)(seed >> 32), iter0, noise_mode, grid_words)
+    if (c == 2 && grid_words > 0) MPPI_LAUNCH(2, true);
+    else if (c == 2) MPPI_LAUNCH(2, false);
+    else if (grid_words > 0) MPPI_LAUNCH(0, true);
+    else MPPI_LAUNCH(0, false);
+#undef MPPI_LAUNCH
     return mpb_check_launch("mpb_mppi_step");
 }
 
