@@ -85,7 +85,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
     __shared__ int s_abort;
     __shared__ unsigned s_ticket;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int lane = tid & 63;                                   // (re-derived per pass from an opaque copy: see HX_FRESH_LANE)
     const int d = DCH ? DCH : d_rt;
     const int N = H * d;
     unsigned* wsu = reinterpret_cast<unsigned*>(ws);
@@ -106,7 +107,16 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
     const int hcw = (HC == 1) ? 0 : ((wave >> 2) & 1);
     const int rw = (HC == 1) ? wave : ((wave & 3) | ((wave >> 3) << 2));
     auto wave_of = [](int r, int hc) { return (HC == 1) ? r : ((r & 3) | (hc << 2) | ((r >> 2) << 3)); };
-    const int j = lane & 15, g = lane >> 4;
+    int j = lane & 15, g = lane >> 4;
+    // per-lane index arithmetic (tile rows, operand addresses, masks) is loop invariant, and the compiler hoists ALL of it out
+    // of the iteration loop: ~30 VGPRs that do not survive the cost phase and came back as 65 scratch reloads per iteration
+    // (124 B / lane).  Re-deriving lane / j / g from an opaque copy at the top of every pass keeps them local to it.
+#define HX_FRESH_LANE()                          \
+    do {                                         \
+        asm volatile("" : "+v"(lane));           \
+        j = lane & 15;                           \
+        g = lane >> 4;                           \
+    } while (0)
 
     // ---- constants into LDS (once): the broad-phase grid + obstacle table, the blocks of L as permuted MFMA images
     GeomView G0 = geom_view(geom);
@@ -247,6 +257,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
         for (int u = 0; u < EPT; ++u) d_run[u] = 0.f;
 #pragma nounroll
         for (int bt = 0; bt < nb; ++bt) {
+            HX_FRESH_LANE();
             const int s = (chunk * nb + bt) * RB + rw;                       // this wave's sample in this batch
             const bool live = s < S;
             // ============ A. samples: x = mean + noise (zero at both ends, stomp.py:105-106), stored, kept packed in the tile
@@ -278,7 +289,12 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
                 if (((H * d) & 3) == 0 && ((64 * d) & 3) == 0) {
                     const f32x4* pk4 = reinterpret_cast<const f32x4*>(nt);
                     f32x4* out4 = reinterpret_cast<f32x4*>(sbase);
-                    for (int idx = lane; 4 * idx < nfl; idx += 64) out4[idx] = pk4[idx];
+                    // (a fixed trip count, masked: the open-ended loop kept a 64-bit induction pointer alive across the phase)
+#pragma unroll
+                    for (int k = 0; k < (16 * DX + 63) / 64; ++k) {
+                        const int idx = lane + 64 * k;
+                        if (4 * idx < nfl) out4[idx] = pk4[idx];
+                    }
                 } else {
                     for (int idx = lane; idx < nfl; idx += 64) sbase[idx] = nt[idx];
                 }
@@ -362,6 +378,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
             if (it_n < n_run) draw_noise(it_n, (chunk * nb + (more ? bt + 1 : 0)) * RB + rw);
         }
         __builtin_amdgcn_s_setprio(0);
+        HX_FRESH_LANE();
         int tq = tid;
         asm volatile("" : "+v"(tq));
         // ============ D. exchange: publish this unit's partial, wait for the partners', combine in chunk order
