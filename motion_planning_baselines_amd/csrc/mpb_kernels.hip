@@ -149,13 +149,14 @@ extern "C" int mpb_geom_flags(const float* g, int n_words, int* flags) {
     *flags = 0;
     const int rc = mpb_geom_check(g, n_words);
     if (rc) return rc;
-    int model = -1, max_cells = 0;
+    int model = -1, max_cells = 0, n_fields = 0;
     bool all_grids = true;
     for (int off = 0;;) {
         const int32_t* gi = reinterpret_cast<const int32_t*>(g + off);
         const bool grid_ok = gi[26] > 0 && gi[26] <= MPB_GRID_MAX_CELLS && gi[6] <= MPB_GRID_MAX_SPH;   // grid_usable()
         all_grids = all_grids && grid_ok;
         if (gi[26] > max_cells) max_cells = gi[26];
+        ++n_fields;
         const int m = grid_ok ? gi[29] : 0;
         model = (model < 0 || model == m) ? m : 0;
         if (gi[27] == 0) break;
@@ -164,7 +165,8 @@ extern "C" int mpb_geom_flags(const float* g, int n_words, int* flags) {
     const int32_t* g0 = reinterpret_cast<const int32_t*>(g);
     const bool point_small = g0[2] == MPB_KIND_POINT && g0[27] == 0 && g0[6] <= 32 && g0[7] <= 8;
     *flags = (model > 0 ? (model & 0xFF) : 0) | (all_grids ? 0x100 : 0) | (point_small ? 0x200 : 0) |
-             (g0[2] == MPB_KIND_POINT ? 0x400 : 0) | (all_grids ? (max_cells & 0x1FFF) << 16 : 0);
+             (g0[2] == MPB_KIND_POINT ? 0x400 : 0) | (n_fields == 1 ? 0x1000 : 0) |
+             (all_grids ? (max_cells & 0x1FFF) << 16 : 0);
     return MPB_OK;
 }
 

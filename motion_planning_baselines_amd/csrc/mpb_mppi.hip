@@ -513,7 +513,7 @@ extern "C" int mpb_mppi_step(float* mean, const float* eps, const float* scale_t
     // they fit next to the rest (and, with two workgroups per CU, leave room for the second one)
     int grid_words = 0;
     static const int no_grid = getenv("MPB_MPPI_NO_GRID") ? atoi(getenv("MPB_MPPI_NO_GRID")) : 0;           // tuning / tests
-    if (geom && (geom_flags & 0x500) == 0x500 && !no_grid) {       // grid-backed fields, point robot
+    if (geom && (geom_flags & 0x1500) == 0x1500 && !no_grid) {     // ONE grid-backed field, point robot
         const int cells = (geom_flags >> 16) & 0x1FFF;
         const size_t extra = 4 + (size_t)((cells + 3) & ~3) + 4 * (MPB_GRID_MAX_SPH + 1);
         const size_t cap = (nw <= 8 ? 78 : 150) * 1024 / sizeof(float);

@@ -304,10 +304,14 @@ def test_geometry_model_tag_and_flags():
     gi = buf.view(np.int32)
     assert gi[29] == 1 and int(buf.view(np.uint32)[30]) == ((1 << 31) - 1) & ~0b111      # the three base spheres are pruned here
     _lib.geom_check(buf)
-    assert _lib.geom_flags(buf) == (1 | 0x100)
-    assert _lib.geom_flags(G.pack_geometry(robot, field, use_model=False)) == 0x100
+    # (bit 12: one field; bits 16-28: the cells of its broad-phase grid)
+    n_cells = int(gi[26])
+    assert _lib.geom_flags(buf) == (1 | 0x100 | 0x1000 | n_cells << 16)
+    assert _lib.geom_flags(G.pack_geometry(robot, field, use_model=False)) == (0x100 | 0x1000 | n_cells << 16)
     full = G.pack_geometry(robot, field, prune_static=False)
-    assert int(full.view(np.uint32)[30]) == (1 << 31) - 1 and _lib.geom_flags(full) == (1 | 0x100)
+    assert int(full.view(np.uint32)[30]) == (1 << 31) - 1 and _lib.geom_flags(full) == (1 | 0x100 | 0x1000 | n_cells << 16)
+    two = G.pack_geometry(robot, [field, G.env_spheres_3d(seed=5)])
+    assert not (_lib.geom_flags(two) & 0x1000) and (_lib.geom_flags(two) & 0x1FF) == (1 | 0x100)
     # a robot that is not the Panda bit for bit is not tagged
     other = G.RobotPanda()
     other.link_offset[5, 1] += 1e-4
@@ -320,10 +324,11 @@ def test_geometry_model_tag_and_flags():
         _lib.geom_check(forged)
     # point robot: no model, grid usable; box-only field: no grid at all
     pm = G.pack_geometry(G.RobotPointMass(2, radius=0.01), G.env_grid_circles_2d())
-    assert _lib.geom_flags(pm) == 0x100          # 49 circles: too many for the in-register CHOMP kernel (bit 9)
-    assert _lib.geom_flags(G.pack_geometry(G.RobotPointMass(2, radius=0.01), G.env_dense_2d())) == (0x100 | 0x200)
+    assert (_lib.geom_flags(pm) & 0xFFFF) == (0x100 | 0x400 | 0x1000)          # 49 circles: too many for the in-register CHOMP kernel (bit 9)
+    assert _lib.geom_flags(pm) >> 16 == int(pm.view(np.int32)[26])
+    assert (_lib.geom_flags(G.pack_geometry(G.RobotPointMass(2, radius=0.01), G.env_dense_2d())) & 0xFFFF) == (0x100 | 0x200 | 0x400 | 0x1000)
     boxes = G.CollisionField(boxes=np.array([[0.2, 0.2, 0.1, 0.1]], np.float32), margin=0.01)
-    assert _lib.geom_flags(G.pack_geometry(G.RobotPointMass(2, radius=0.01), boxes)) == 0x200
+    assert _lib.geom_flags(G.pack_geometry(G.RobotPointMass(2, radius=0.01), boxes)) == (0x200 | 0x400 | 0x1000)
 
 
 def test_stomp_workspace_size():
