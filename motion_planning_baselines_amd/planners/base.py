@@ -193,6 +193,13 @@ class OptimizationPlanner(MPPlanner):
         tril = f64(gp_prior_scale_tril(Ud, Uo)) if H <= 128 else None      # dense GEMM on the matrix cores
         return ops.gp_prior_sample(f64(means), eps, f64(Ud), f64(Uo), n, D, seed=seed, scale_tril=tril)
 
+    def get_GP_prior(self, start_K, gp_K, goal_K, state_init, particle_means=None, goal_states=None, tensor_args=None):
+        """base.py:115-139: the GP trajectory prior over the planner's horizon as a MultiMPPrior (GPU sampling)."""
+        from .costs.factors.mp_priors_multi import MultiMPPrior
+        return MultiMPPrior(self.n_support_points - 1, self.dt, self.dim, self.n_dof, start_K, gp_K, state_init,
+                            K_g_inv=goal_K, means=particle_means, goal_states=goal_states,
+                            tensor_args=self.tensor_args if tensor_args is None else tensor_args)
+
     def const_vel_trajectories(self, start_state, multi_goal_states):
         """base.py:141-153, incl. its quirk: the velocity channel is (goal - start) / (H * dt), not / ((H-1) * dt).
         One (H, 2D) straight line per goal; host-side set-up arithmetic (a few KB), placed on the planner's device."""

@@ -89,6 +89,7 @@ class GPMP2(OptimizationPlanner):
             raise NotImplementedError(f"solver_params['method'] must be one of {SOLVE_METHODS}")   # gpmp2.py:457, :489
         self.robot = robot
         self.d_state_opt = 2 * n_dof
+        self.sigma_start_sample, self.sigma_goal_sample = sigma_start_sample, sigma_goal_sample
         self.goal_directed = multi_goal_states is not None
         if not self.goal_directed:
             self.num_goals = 1                                                                     # gpmp2.py:136-137
@@ -148,6 +149,30 @@ class GPMP2(OptimizationPlanner):
             self._goal = self._start                 # never read: the goal factor's weight is zero
         self._ws = ops.gpmp2_workspace(B, self.n_support_points, self.n_dof, self.device)
         self.costs = torch.zeros(B, device=self.device, dtype=torch.float32)
+
+    def set_prior_factors(self):
+        """gpmp2.py:201-248: the initialisation / sampling factor objects (UnaryFactor, GPFactor) as attributes, for callers that
+        read them; the planner itself samples through the structured factor (get_random_trajs) and never touches them."""
+        from .costs.factors.gp_factor import GPFactor
+        from .costs.factors.unary_factor import UnaryFactor
+        ta = dict(device=self.device, dtype=torch.float32)
+        H = self.n_support_points
+        self.start_prior_init = UnaryFactor(self.d_state_opt, self.sigma_start_init, self.start_state, ta)
+        self.gp_prior_init = GPFactor(self.n_dof, self.sigma_gp_init, self.dt, H - 1, ta)
+        if self.goal_directed:
+            self.multi_goal_prior_init = [UnaryFactor(self.d_state_opt, self.sigma_goal_init, self.multi_goal_states[i], ta)
+                                          for i in range(self.num_goals)]
+        self.start_prior_sample = UnaryFactor(self.d_state_opt, self.sigma_start_sample, self.start_state, ta)
+        if self.goal_directed:
+            self.multi_goal_prior_sample = [UnaryFactor(self.d_state_opt, self.sigma_goal_sample, self.multi_goal_states[i], ta)
+                                            for i in range(self.num_goals)]
+
+    def get_dist(self, start_K, gp_K, goal_K, state_init, particle_means=None, goal_states=None):
+        """gpmp2.py:250-271: MultiMPPrior over the planner's horizon (2 n_dof states per support point)."""
+        from .costs.factors.mp_priors_multi import MultiMPPrior
+        return MultiMPPrior(self.n_support_points - 1, self.dt, 2 * self.n_dof, self.n_dof, start_K, gp_K, state_init,
+                            K_g_inv=goal_K, means=particle_means, goal_states=goal_states,
+                            tensor_args=dict(device=self.device, dtype=torch.float32))
 
     def set_problem_states(self, starts, goals):
         """Per-particle start / goal positions (B,D): thousands of independent problems in one planner."""

@@ -49,6 +49,30 @@ class StochGPMP(OptimizationPlanner):
         self._weights = None
         self.reset(initial_particle_means=initial_particle_means)
 
+    def set_prior_factors(self):
+        """stoch_gpmp.py:149-198: the initialisation / sampling factor objects (UnaryFactor, GPFactor) as attributes, for callers that
+        read them; the planner itself samples through the structured factor (get_random_trajs) and never touches them."""
+        from .costs.factors.gp_factor import GPFactor
+        from .costs.factors.unary_factor import UnaryFactor
+        ta = dict(device=self.device, dtype=torch.float32)
+        H = self.n_support_points
+        self.start_prior_init = UnaryFactor(self.d_state_opt, self.sigma_start_init, self.start_state, ta)
+        self.gp_prior_init = GPFactor(self.n_dof, self.sigma_gp_init, self.dt, H - 1, ta)
+        if True:
+            self.multi_goal_prior_init = [UnaryFactor(self.d_state_opt, self.sigma_goal_init, self.multi_goal_states[i], ta)
+                                          for i in range(self.num_goals)]
+        self.start_prior_sample = UnaryFactor(self.d_state_opt, self.sig_sample[0], self.start_state, ta)
+        self.gp_prior_sample = GPFactor(self.n_dof, self.sig_sample[1], self.dt, H - 1, ta)
+        self.multi_goal_prior_sample = [UnaryFactor(self.d_state_opt, self.sig_sample[2], self.multi_goal_states[i], ta)
+                                        for i in range(self.num_goals)]
+
+    def get_prior_dist(self, start_K, gp_K, goal_K, state_init, particle_means=None, goal_states=None):
+        """stoch_gpmp.py:212-233: MultiMPPrior over the planner's horizon (2 n_dof states per support point)."""
+        from .costs.factors.mp_priors_multi import MultiMPPrior
+        return MultiMPPrior(self.n_support_points - 1, self.dt, 2 * self.n_dof, self.n_dof, start_K, gp_K, state_init,
+                            K_g_inv=goal_K, means=particle_means, goal_states=goal_states,
+                            tensor_args=dict(device=self.device, dtype=torch.float32))
+
     def reset(self, start_state=None, multi_goal_states=None, initial_particle_means=None):
         """stoch_gpmp.py:97-141: new start / goal states re-target the planner (:99-103)."""
         if start_state is not None:
