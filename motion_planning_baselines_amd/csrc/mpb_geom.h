@@ -100,10 +100,16 @@ __device__ __forceinline__ GeomView geom_view(const float* __restrict__ g) {
     return v;
 }
 
-// sin and cos together, |x| up to a few hundred: Cody-Waite reduction by pi/2 in three fma steps, then
-// the cephes single-precision minimax polynomials on [-pi/4, pi/4] (max abs error 9e-8, measured against
-// fp64).  ~25 VALU instructions for both values; ocml sinf + cosf cost ~4x that because of their
-// huge-argument path.  Joint angles are bounded by the joint limits plus STOMP noise.
+// sin and cos together, |x| up to a few thousand.  Round 4: reduction by PI (three-term Cody-Waite, fma) to r in
+// [-pi/2, pi/2] and minimax polynomials on that interval (fitted for this file: odd degree 11 / even degree 8 in r,
+// scripts/sincos_fit.py), so that the quadrant logic is ONE sign, (-1)^k on both values, applied as an xor with the low
+// bit of k -- which the round-to-nearest of the reduction delivers for free (magic-number add: the integer sits in the low
+// mantissa bits).  21 VALU instructions for both values, none of them a compare / select (the pi/2 form with the cephes
+// polynomials on [-pi/4, pi/4] took 29, eight of them half-rate compares, selects and converts: 7 x 8 per waypoint).
+// Max abs error against fp64 over |x| <= 20: sin 1.16e-7, cos 1.28e-7 (rms 2.1e-8 / 3.2e-8; the pi/2 form: 9.1e-8 / 9.2e-8,
+// rms 2.1e-8 -- one ulp either way; emulated in scripts/sincos_fit.py, measured on the device by scripts/sincos_accuracy.hip).
+// ocml sinf + cosf cost ~4x that because of their huge-argument path.  Joint angles are bounded by the limits plus STOMP noise.
+#ifdef MPB_SINCOS_PI2   // the former pi/2 form, kept for A/B measurements (scripts/ab_k20.sh)
 __device__ __forceinline__ void fast_sincos(float x, float& sn, float& cs) {
     const float k = rintf(x * 0.6366197466850281f);
     float r = fmaf(-k, 1.5707963705062866f, x);
@@ -119,6 +125,23 @@ __device__ __forceinline__ void fast_sincos(float x, float& sn, float& cs) {
     sn = (q & 2) ? -a : a;
     cs = ((q + 1) & 2) ? -b : b;
 }
+#else
+__device__ __forceinline__ void fast_sincos(float x, float& sn, float& cs) {
+    const float t = fmaf(x, 0.3183098861837907f, 12582912.0f);        // 1.5 * 2^23 + rint(x / pi): valid for |x| < 1e6
+    const float k = t - 12582912.0f;
+    float r = fmaf(-k, 3.1415927410125732f, x);
+    r = fmaf(-k, -8.742277657347586e-08f, r);
+    r = fmaf(-k, -3.552713678800501e-15f, r);
+    const float u = r * r;
+    const float s = fmaf(r * u, fmaf(u, fmaf(u, fmaf(u, fmaf(u, -2.4080563321e-08f, 2.7536482321e-06f), -1.9841086760e-04f),
+                                             8.3333328366e-03f), -1.6666667163e-01f), r);
+    const float c = fmaf(u * u, fmaf(u, fmaf(u, fmaf(u, -2.6546715048e-07f, 2.4786108042e-05f), -1.3888812391e-03f), 4.1666667908e-02f),
+                         fmaf(-0.5f, u, 1.0f));
+    const unsigned sg = __float_as_uint(t) << 31;                      // parity of k
+    sn = __uint_as_float(__float_as_uint(s) ^ sg);
+    cs = __uint_as_float(__float_as_uint(c) ^ sg);
+}
+#endif
 
 // v_sqrt_f32: 1 ulp, one quarter-rate instruction (the IEEE-correct expansion hipcc emits for sqrtf is
 // ~20 VALU instructions).  Arguments are squared distances, far inside the range that needs no scaling.

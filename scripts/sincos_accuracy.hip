@@ -1,9 +1,12 @@
-// Accuracy of the hardware v_sin_f32 / v_cos_f32 (input in revolutions) against fp64 sin / cos, and of the polynomial
-// fast_sincos used by the FK code, over |x| <= 8 rad.   hipcc --offload-arch=gfx950 -O3 scripts/sincos_accuracy.hip -o /tmp/sc
+// Accuracy against fp64 sin / cos over |x| <= 20 rad of: the hardware v_sin_f32 / v_cos_f32 (input in revolutions); the
+// product's fast_sincos (csrc/mpb_geom.h: round 4, reduction by pi, one xor for the sign); the pi/2 form it replaced.
+//   hipcc --offload-arch=gfx950 -O3 -Imotion_planning_baselines_amd/csrc scripts/sincos_accuracy.hip -o /tmp/sc
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
-__device__ __forceinline__ void fast_sincos(float x, float& sn, float& cs) {
+char* mpb_err_buf() { static char b[512]; return b; }
+#include "../motion_planning_baselines_amd/csrc/mpb_geom.h"
+__device__ __forceinline__ void sincos_pi2_form(float x, float& sn, float& cs) {
     const float k = rintf(x * 0.6366197466850281f);
     float r = fmaf(-k, 1.5707963705062866f, x);
     r = fmaf(-k, -4.371138828673793e-08f, r);
@@ -21,27 +24,31 @@ __device__ __forceinline__ void fast_sincos(float x, float& sn, float& cs) {
 __global__ void k(double* err, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float x = -8.0f + 16.0f * (float)i / (float)n;
+    const float x = -20.0f + 40.0f * (float)i / (float)n;
     const double sd = sin((double)x), cd = cos((double)x);
     // hardware: revolutions; v_fract keeps the argument in [0,1)
     const float rev = x * 0.15915494309189535f;
     const float fr = rev - floorf(rev);
     const float hs = __builtin_amdgcn_sinf(fr), hc = __builtin_amdgcn_cosf(fr);
-    float ps, pc;
+    float ps, pc, os, oc;
     fast_sincos(x, ps, pc);
-    err[4 * i + 0] = fabs((double)hs - sd);
-    err[4 * i + 1] = fabs((double)hc - cd);
-    err[4 * i + 2] = fabs((double)ps - sd);
-    err[4 * i + 3] = fabs((double)pc - cd);
+    sincos_pi2_form(x, os, oc);
+    err[6 * i + 0] = fabs((double)hs - sd);
+    err[6 * i + 1] = fabs((double)hc - cd);
+    err[6 * i + 2] = fabs((double)ps - sd);
+    err[6 * i + 3] = fabs((double)pc - cd);
+    err[6 * i + 4] = fabs((double)os - sd);
+    err[6 * i + 5] = fabs((double)oc - cd);
 }
 int main() {
     const int n = 1 << 22;
-    double* d; hipMalloc(&d, sizeof(double) * 4 * n);
+    double* d; (void)hipMalloc(&d, sizeof(double) * 6 * n);
     hipLaunchKernelGGL(k, dim3(n / 256), dim3(256), 0, 0, d, n);
-    double* h = (double*)malloc(sizeof(double) * 4 * n);
-    hipMemcpy(h, d, sizeof(double) * 4 * n, hipMemcpyDeviceToHost);
-    double m[4] = {0, 0, 0, 0};
-    for (int i = 0; i < n; ++i) for (int c = 0; c < 4; ++c) if (h[4 * i + c] > m[c]) m[c] = h[4 * i + c];
-    printf("max abs error over [-8, 8] rad: v_sin %.3e  v_cos %.3e   polynomial sin %.3e cos %.3e\n", m[0], m[1], m[2], m[3]);
+    double* h = (double*)malloc(sizeof(double) * 6 * n);
+    (void)hipMemcpy(h, d, sizeof(double) * 6 * n, hipMemcpyDeviceToHost);
+    double m[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n; ++i) for (int c = 0; c < 6; ++c) if (h[6 * i + c] > m[c]) m[c] = h[6 * i + c];
+    printf("max abs error over [-20, 20] rad: v_sin %.3e  v_cos %.3e   fast_sincos (pi form) sin %.3e cos %.3e   pi/2 form sin %.3e cos %.3e\n",
+           m[0], m[1], m[2], m[3], m[4], m[5]);
     return 0;
 }
