@@ -420,7 +420,11 @@ def bench_c4(dev, steps, with_cpu=True):
         it_s = med / steps
         ginstr = pmc['SQ_INSTS_VALU_per_wave'] * pmc['waves_per_launch'] / it_s / 1e9
         peak64 = 1024 * 2.4 / 4.7
+        peak64_spec = 1024 * 2.4 / 4.0          # the spec rate: 78.6 TFLOP/s fp64 vector / (64 lanes x 2 flop) = 614.4 G wave-instr/s
         out['roofline']['valu_f64'] = {'achieved': ginstr, 'peak': peak64, 'unit': 'G wave-instr/s', 'frac': ginstr / peak64,
+                                       'peak_spec': peak64_spec, 'frac_of_spec': ginstr / peak64_spec,
+                                       'peak_note': '`peak` = the microbenched 4.7 cycles per fp64 wave-instruction (profiles/r01_microbench_valu.txt), '
+                                                    '`peak_spec` = the 4 cycles of the data sheet',
                                        'valu_instructions_per_wave': pmc['SQ_INSTS_VALU_per_wave'], 'pmc_source': pmc_file}
         cls = {c: pmc.get('SQ_INSTS_VALU_%s_per_wave' % c) for c in ('ADD_F64', 'MUL_F64', 'FMA_F64', 'TRANS_F64', 'INT32', 'INT64', 'CVT')}
         if all(v is not None for v in cls.values()) and pmc.get('SQ_INSTS_MFMA_per_wave') is not None:
