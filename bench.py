@@ -693,12 +693,19 @@ def main():
         # the noise occupies the same fp32 pipe for 32 cycles per instruction.  Pipe cycles per wave-iteration =
         # 2 x VALU + 32 x MFMA (every VALU instruction counted at the full rate although v_min / v_max / v_cvt / 3-source v_fma / ... take 4 cycles and v_sqrt / v_sin 8,
         # profiles/r03_microbench_rates.txt: a lower bound of the occupancy)
-        cyc = 2.0 * valu + 32.0 * mfma
+        # round 4: the noise product runs as v_mfma_f32_16x16x32_bf16 (16 cycles each, and -- unlike the fp32 MFMA -- beside
+        # vector work: SQ_VALU_MFMA_COEXEC_CYCLES > 0); the matrix pipe's busy cycles are taken from the counter itself
+        busy = pmc.get('SQ_VALU_MFMA_BUSY_CYCLES_per_launch')
+        mfma_cyc = (busy / pmc['waves_per_launch'] / pmc['iterations_per_launch']) if busy else 32.0 * mfma
+        cyc = 2.0 * valu + mfma_cyc
         pipe = cyc * (P * S) / (k_ms * 1e-3) / 1e9
         roof['fp32_pipe'] = {'achieved': pipe, 'peak': 1024 * 2.4, 'unit': 'G SIMD-cycles/s', 'frac': pipe / (1024 * 2.4),
-                             'mfma_instructions_per_wave_iteration': mfma,
-                             'note': 'fp32 VALU issue (2 cycles per wave-instruction) + fp32 MFMA (32 cycles each) share one pipe per '
-                                     'SIMD; peak = 1024 SIMDs x 2.4 GHz; `frac` above counts the VALU instructions alone, as in rounds 1-2'}
+                             'mfma_instructions_per_wave_iteration': mfma, 'mfma_busy_cycles_per_wave_iteration': mfma_cyc,
+                             'mfma_valu_coexec_cycles_per_launch': pmc.get('SQ_VALU_MFMA_COEXEC_CYCLES_per_launch'),
+                             'note': 'fp32 VALU issue (2 cycles per wave-instruction) + the matrix pipe\'s busy cycles (SQ_VALU_MFMA_BUSY_CYCLES: '
+                                     '36 bf16 MFMAs at 16 cycles + 4 fp32 MFMAs at 32 per wave-iteration; an upper bound of their cost to the vector '
+                                     'pipe since round 4: the bf16 ones partly run beside vector work, see mfma_valu_coexec_cycles); peak = 1024 '
+                                     'SIMDs x 2.4 GHz; `frac` above counts the VALU instructions alone, as in rounds 1-2'}
     cls = {c: pmc.get('SQ_INSTS_VALU_%s_per_wave_iteration' % c) for c in ('ADD_F32', 'MUL_F32', 'FMA_F32', 'TRANS_F32', 'INT32', 'INT64', 'CVT')} \
         if (pmc and c3_shape) else {}
     if valu and mfma is not None and all(v is not None for v in cls.values()) and cls:
@@ -709,7 +716,7 @@ def main():
         #         at 2: a strict lower bound of the pipe occupancy;
         #   mid : those classes at 3 (fma, int32) and 3.5 (the rest, mostly 4-cycle instructions).
         other = valu - sum(cls.values())
-        fixed = 2.0 * (cls['ADD_F32'] + cls['MUL_F32']) + 8.0 * cls['TRANS_F32'] + 4.0 * (cls['INT64'] + cls['CVT']) + 32.0 * mfma
+        fixed = 2.0 * (cls['ADD_F32'] + cls['MUL_F32']) + 8.0 * cls['TRANS_F32'] + 4.0 * (cls['INT64'] + cls['CVT']) + mfma_cyc
         low = fixed + 2.0 * (cls['FMA_F32'] + cls['INT32'] + other)
         mid = fixed + 3.0 * (cls['FMA_F32'] + cls['INT32']) + 3.5 * other
         per_s = (P * S) / (k_ms * 1e-3) / 1e9 / (1024 * 2.4)
