@@ -306,3 +306,29 @@ def test_mppi_grid_collision_equals_exhaustive(gpu_device, tmp_path):
     for k in ('controls', 'states', 'costs', 'weights', 'mean'):
         assert res[0][k].tobytes() == res[1][k].tobytes(), k
     assert float(res[0]['costs'].min()) > 0
+
+
+def test_point_entry_points_edge_cases(gpu_device):
+    """mpb_point_dynamics / mpb_point_traj_cost (round 4): empty batches are no-ops, one-step horizons and three-dimensional
+    states work, wrong devices / shapes / strides are refused with an exception (never a silent CPU path)."""
+    from motion_planning_baselines_amd import ops
+    dev = gpu_device
+    f = lambda a: torch.as_tensor(a, dtype=torch.float32).contiguous().to(dev)
+    lo, hi = f([-1., -1., -1.]), f([1., 1., 1.])
+    assert ops.point_dynamics(torch.empty(0, 1, 3, device=dev), torch.empty(0, 1, 3, device=dev), lo, hi, 0.1).shape == (0, 1, 3)
+    x = f(np.arange(12).reshape(2, 2, 3) * 0.1)
+    u = f(np.full((2, 2, 3), 2.0))
+    np.testing.assert_allclose(ops.point_dynamics(x, u, lo, hi, 0.5).cpu().numpy(), x.cpu().numpy() + 0.5, rtol=1e-6)
+    with pytest.raises(ValueError):
+        ops.point_dynamics(x.cpu(), u, lo, hi, 0.5)
+    with pytest.raises(ValueError):
+        ops.point_dynamics(x.transpose(0, 1), u.transpose(0, 1), lo, hi, 0.5)          # not contiguous
+    # one step, three state dimensions, a two-dimensional control
+    X, U = f(np.ones((1, 4, 3))), f(np.full((1, 4, 2), 2.0))
+    c = ops.point_traj_cost(X, U, f([0., 0., 0.]), f([0.5]), 2.0, 7.0, 3.0, 10.0, energy=1.5)
+    want = 0.5 * (2.0 * 3.0 + 3.0 * 8.0) + 10.0 * 3.0 * 0.5 + 1.5
+    np.testing.assert_allclose(c.cpu().numpy(), np.full(4, want, np.float32), rtol=1e-6)
+    assert ops.point_traj_cost(torch.empty(3, 0, 2, device=dev), torch.empty(3, 0, 2, device=dev), f([0., 0.]), f([1., 1., 1.]),
+                               1., 1., 1., 1.).shape == (0,)
+    with pytest.raises(ValueError):
+        ops.point_traj_cost(X, U, f([0., 0.]), f([0.5]), 1., 1., 1., 1.)                # goal of the wrong length
