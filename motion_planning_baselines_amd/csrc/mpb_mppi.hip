@@ -555,9 +555,9 @@ __global__ void point_dynamics_kernel(const float* __restrict__ x, const float* 
 
 extern "C" int mpb_point_dynamics(const float* x, const float* u, const float* ctrl_min, const float* ctrl_max, const float* dyn_std,
                                   const float* noise, float* x_next, size_t n, int dim, float dt, void* stream) {
-    if (!x || !u || !ctrl_min || !ctrl_max || !x_next || (noise && !dyn_std)) return mpb_fail(MPB_E_INVALID, "mpb_point_dynamics: null pointer");
     if (dim < 1 || dim > 64) return mpb_fail(MPB_E_INVALID, "mpb_point_dynamics: bad dimension");
-    if (n == 0) return MPB_OK;
+    if (n == 0) return MPB_OK;                   // (an empty batch has no buffers to speak of)
+    if (!x || !u || !ctrl_min || !ctrl_max || !x_next || (noise && !dyn_std)) return mpb_fail(MPB_E_INVALID, "mpb_point_dynamics: null pointer");
     const size_t ne = n * (size_t)dim;
     hipLaunchKernelGGL(point_dynamics_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, u, ctrl_min,
                        ctrl_max, dyn_std, noise, x_next, ne, dim, dt);
@@ -592,10 +592,10 @@ extern "C" int mpb_point_traj_cost(const float* X, const float* U, const float* 
                                    float w_ctrl, float w_pos_T, float energy, float* costs, int T, int B, int state_dim, int ctrl_dim,
                                    void* stream) {
     (void)w_vel;     // (quirk Q8: the velocity slice is empty)
-    if (!X || !U || !goal || !discount || !costs) return mpb_fail(MPB_E_INVALID, "mpb_point_traj_cost: null pointer");
     if (T < 1 || B < 0 || state_dim < 1 || state_dim > 64 || ctrl_dim < 1 || ctrl_dim > 64)
         return mpb_fail(MPB_E_INVALID, "mpb_point_traj_cost: bad shape");
     if (B == 0) return MPB_OK;
+    if (!X || !U || !goal || !discount || !costs) return mpb_fail(MPB_E_INVALID, "mpb_point_traj_cost: null pointer");
     hipLaunchKernelGGL(point_traj_cost_kernel, dim3((B + 127) / 128), dim3(128), 0, (hipStream_t)stream, X, U, goal, discount,
                        w_pos, w_ctrl, w_pos_T, energy, costs, T, B, state_dim, ctrl_dim);
     return mpb_check_launch("mpb_point_traj_cost");
