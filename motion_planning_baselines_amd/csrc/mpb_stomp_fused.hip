@@ -156,10 +156,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
     const int chunk = exchange ? ticket - p * nc : 0;
     int s = chunk * FUSED_WAVES + wave;                 // this wave's sample (NB > 1: of the current batch)
     bool live = s < S;
-    if (tid < N) mean_l[tid] = means[(size_t)p * N + tid];
+    // the particle's mean: fetched now, dropped into LDS behind the first noise draw (which needs the unit, not the mean: its
+    // ~1.7 us of Philox + matrix work hide the load's round trip at kernel entry)
+    const float mean_reg = (tid < N) ? means[(size_t)p * N + tid] : 0.f;
     // header word 1 = this call's tag; word 0 (the error word) counts only when it equals it
     if (ticket == 0 && tid == 0) st_agent_u(wsu + FUSED_HDR_TAG, tag0);    // (unit 0 is drawn exactly once)
-    __syncthreads();
     LSTAMP(2);
 
     const size_t eps_stride = (size_t)S * DCH * P * H;
@@ -172,6 +173,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
                               particle_offset + (uint32_t)p, (uint32_t)s, iter0, seed_lo, seed_hi);
         stomp_noise_to_tile(nt, acc, lane);
     }
+    if (tid < N) mean_l[tid] = mean_reg;
+    __syncthreads();
 
     LSTAMP(3);
     const int n_run = s_abort ? 0 : n_iters;          // (block-uniform: written before the barriers above)
