@@ -45,8 +45,9 @@ class GPMP2(OptimizationPlanner):
 
     Differences, all forced by the hot path living on the GPU:
       * ``collision_fields`` (+ a CostCollision given as ``extra_costs``) hold one to four CollisionFields in total
-        (chained in one geometry buffer, one block of collision rows per field like the reference); any other kind
-        of extra cost raises NotImplementedError (in the reference only costs with a real get_linear_system can be
+        (chained in one geometry buffer, one block of collision rows per field like the reference); a CostGP / CostGoalPrior
+        on the planner's own start / goal states as extra cost is folded into the solve's sigmas (its precision adds);
+        any other kind of extra cost raises NotImplementedError (in the reference only costs with a real get_linear_system can be
         extra costs at all: the others return None and fail at the unpack, cost_functions.py:122-126);
       * ``solver_params['method']``: 'cholesky', 'inverse' and 'lstq' (gpmp2.py:432-491) all run the block solve --
         they are three dense solvers of the same SPD system; 'cholesky-sparse' raises like the reference (:457);
@@ -75,13 +76,29 @@ class GPMP2(OptimizationPlanner):
         collision_fields = list(collision_fields or [])
         extra_costs = list(extra_costs or [])
         scales = [1.0] * len(collision_fields)
+        n_fields_own = len(collision_fields)
+        # the sigmas the block solve runs on: an extra CostGP / CostGoalPrior on the planner's OWN start / goal states is one
+        # more factor of a kind the solve already assembles in registers -- its rows stack under the planner's
+        # (cost_functions.py:107-144), i.e. its precision ADDS to theirs: folded into effective sigmas (round 4)
+        eff = dict(start=float(sigma_start), gp=float(sigma_gp), goal=float(sigma_goal_prior))
+        merge = lambda a, b: (1.0 / a ** 2 + 1.0 / b ** 2) ** -0.5
+        same = lambda a, b: a is not None and b is not None and tuple(a.shape) == tuple(b.shape) and \
+            bool(torch.equal(a.detach().cpu().float(), b.detach().cpu().float()))
         for c in extra_costs:
-            # an extra CostCollision is one more block of collision rows with K = I / sigma_e^2: chained as a further
-            # field whose share is (sigma_coll / sigma_e)^2 of the common 1 / sigma_coll^2
-            if not isinstance(c, CostCollision) or c.field is None:
-                raise NotImplementedError('GPMP2 extra_costs: only CostCollision members are wired into the block solve')
-            collision_fields.append(c.field)
-            scales.append((sigma_coll / c.sigma_coll) ** 2)
+            if isinstance(c, CostCollision) and c.field is not None:
+                # an extra CostCollision is one more block of collision rows with K = I / sigma_e^2: chained as a further
+                # field whose share is (sigma_coll / sigma_e)^2 of the common 1 / sigma_coll^2
+                collision_fields.append(c.field)
+                scales.append((sigma_coll / c.sigma_coll) ** 2)
+            elif isinstance(c, CostGP) and c.dt == dt and same(c.start_state, torch.cat((start_state, torch.zeros_like(start_state)))):
+                eff['start'], eff['gp'] = merge(eff['start'], c.sigma_start), merge(eff['gp'], c.sigma_gp)
+            elif isinstance(c, CostGoalPrior) and multi_goal_states is not None and \
+                    c.num_particles_per_goal == num_particles_per_goal and \
+                    same(c.multi_goal_states, torch.cat((multi_goal_states, torch.zeros_like(multi_goal_states)), dim=-1)):
+                eff['goal'] = merge(eff['goal'], c.sigma_goal_prior)
+            else:
+                raise NotImplementedError('GPMP2 extra_costs: a CostCollision, or a CostGP / CostGoalPrior on the planner\'s own '
+                                          'start / goal states, is wired into the block solve; any other term is not')
         if not collision_fields or len(collision_fields) > 4:
             raise NotImplementedError('GPMP2 on the GPU takes one to four CollisionFields')
         solver_params = solver_params or dict(delta=1e-2, trust_region=True, method='cholesky')
@@ -95,7 +112,7 @@ class GPMP2(OptimizationPlanner):
             self.num_goals = 1                                                                     # gpmp2.py:136-137
         self._cost_kwargs = dict(robot=robot, n_support_points=n_support_points, dt=dt, start_state=start_state,
                                  multi_goal_states=multi_goal_states, num_particles_per_goal=num_particles_per_goal,
-                                 collision_fields=collision_fields[:len(collision_fields) - len(extra_costs)],
+                                 collision_fields=collision_fields[:n_fields_own],
                                  extra_costs=extra_costs, sigma_start=sigma_start, sigma_gp=sigma_gp,
                                  sigma_coll=sigma_coll, sigma_goal_prior=sigma_goal_prior, tensor_args=tensor_args)
         self._cost = None
@@ -104,7 +121,7 @@ class GPMP2(OptimizationPlanner):
         self.stop_criteria = stop_criteria
         self.N = self.d_state_opt * n_support_points
         # no goal factor: sigma_goal = 0 is the C-ABI's explicit "precision 0" (include/mpb.h), not an infinite sigma
-        self.sigmas = (sigma_start, sigma_gp, sigma_goal_prior if self.goal_directed else 0.0, sigma_coll)
+        self.sigmas = (eff['start'], eff['gp'], eff['goal'] if self.goal_directed else 0.0, sigma_coll)
         self.process_group = process_group
         self.geom = ops.DeviceGeometry(robot, collision_fields, self.device, scales=scales)   # one CostCollision per field (gpmp2.py:70-78)
         self.costs = None

@@ -390,3 +390,43 @@ def test_stomp_step_profile_matches_step(gpu_device):
         outs.append((means.clone(), samples.clone(), costs.clone()))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('kind', ['gp', 'goal'])
+def test_gpmp2_extra_trajectory_prior_cost(gpu_device, kind):
+    """extra_costs with a CostGP / CostGoalPrior on the planner's own start / goal states (round 4): one more factor of a kind
+    the block solve already assembles -- its rows stack under the planner's (cost_functions.py:107-144), so the precisions add.
+    Checked against the dense fp64 solution of the composite's OWN linear system (which lists the extra factor as its own rows)."""
+    from motion_planning_baselines_amd.planners.costs.cost_functions import CostGP, CostGoalPrior
+    g = load_golden('gpmp2_pm2d_h8_f64')
+    dev = gpu_device
+    ta = dict(device=dev, dtype=torch.float32)
+    base, robot, _ = _gpmp2_from_golden(g, dev)
+    B, H, D, dt = int(g['B']), int(g['H']), int(g['D']), float(g['dt'])
+    z = torch.zeros(D, device=dev)
+    if kind == 'gp':
+        extra = CostGP(robot, H, torch.cat((T(g['start']).float().to(dev), z)), dt,
+                       dict(sigma_start=2.0 * float(g['sigma_start']), sigma_gp=0.5 * float(g['sigma_gp'])), tensor_args=ta)
+    else:
+        extra = CostGoalPrior(robot, H, multi_goal_states=torch.cat((T(g['goal']).float().to(dev), z)).unsqueeze(0),
+                              num_particles_per_goal=B, num_samples=1, sigma_goal_prior=3.0 * float(g['sigma_goal_prior']), tensor_args=ta)
+    pl, _, _ = _gpmp2_from_golden(g, dev, extra_costs=[extra])
+    assert len(pl.cost.cost_l) == len(base.cost.cost_l) + 1 and pl.sigmas != base.sigmas
+    x0 = T(g['means0']).float()
+    A, b, K = (t.cpu().double() for t in pl.cost.get_linear_system(x0.to(dev)))
+    N = H * 2 * D
+    AtA = A.transpose(1, 2) @ K @ A
+    I = torch.eye(N, dtype=torch.float64)
+    JtJ = AtA + float(g['delta']) * (AtA.mean(0) * I if bool(g['trust_region']) else I)
+    d = torch.linalg.solve(JtJ, A.transpose(1, 2) @ K @ b).reshape(B, H, 2 * D)
+    want = x0.double() + float(g['step_size']) * d
+    got = pl.optimize(opt_iters=1).cpu().double()
+    step_err = float(((got - x0.double()) - float(g['step_size']) * d).abs().max() / d.abs().max())
+    assert step_err < 5e-5 and rel_err(got, want) < 1e-5, step_err
+    assert not torch.equal(got.float(), base.optimize(opt_iters=1).cpu())
+    # a prior on OTHER states is a different factor: not foldable, refused
+    if kind == 'gp':
+        other = CostGP(robot, H, torch.cat((T(g['start']).float().to(dev) + 0.1, z)), dt,
+                       dict(sigma_start=1.0, sigma_gp=1.0), tensor_args=ta)
+        with pytest.raises(NotImplementedError):
+            _gpmp2_from_golden(g, dev, extra_costs=[other])
