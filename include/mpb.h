@@ -255,6 +255,20 @@ int mpb_stomp_run_timed(float *means, const float *eps, float *samples, float *c
                         float k_sigma, float weight, float lr, float temperature,
                         int n_iters, uint64_t seed, uint32_t iter0, uint32_t particle_offset,
                         uint32_t *status, uint32_t *tag_out, float *means_copy, void *stream, float *kernel_ms);
+/* A persistent-launch call with everything but (n_iters, iter0, means_copy, stream) fixed, kept on the library's side (round 4):
+ * for a binding whose foreign-function marshalling is not free (ctypes: ~3 us for the 28 arguments of mpb_stomp_run_checked,
+ * a quarter of the host side of a call).  mpb_stomp_plan_create validates and copies the arguments (host memory only: one small
+ * malloc, the one place the library allocates; device noise only, eps = NULL); mpb_stomp_plan_launch == mpb_stomp_run_checked on
+ * them (same failure contract, same tag); mpb_stomp_plan_destroy frees the record.  The caller keeps every buffer alive. */
+typedef struct mpb_stomp_plan_s mpb_stomp_plan;
+int mpb_stomp_plan_create(mpb_stomp_plan **plan, float *means, float *samples, float *costs, float *weights,
+                          const float *L, const float *Sigma, const float *geom, int geom_flags,
+                          float *workspace, size_t workspace_bytes, int P, int S, int H, int d, int D,
+                          float k_sigma, float weight, float lr, float temperature, uint64_t seed, uint32_t particle_offset,
+                          uint32_t *status);
+int mpb_stomp_plan_launch(mpb_stomp_plan *plan, int n_iters, uint32_t iter0, float *means_copy, void *stream, uint32_t *tag_out);
+int mpb_stomp_plan_destroy(mpb_stomp_plan *plan);
+
 int mpb_stomp_sample(const float *means, const float *eps, float *samples, const float *L,
                      const float *geom, int geom_flags, float *costs, /* geom, costs both NULL: sample only; both set: fused cost */
                      int P, int S, int H, int d, float k_sigma, float weight,

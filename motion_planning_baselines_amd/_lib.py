@@ -57,6 +57,9 @@ SIGNATURES = {
     'mpb_gp_prior_sample': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _u64, _p],
     'mpb_gp_prior_sample_dense': [_p, _p, _p, _p, _i, _i, _i, _i, _u64, _p],
     'mpb_mvn_sample_dense': [_p, _p, _p, _p, _i, _i, _i, _u64, _p],
+    'mpb_stomp_plan_create': [_p] * 8 + [_i, _p, ctypes.c_size_t, _i, _i, _i, _i, _i, _f, _f, _f, _f, _u64, _u32, _p],
+    'mpb_stomp_plan_launch': [_p, _i, _u32, _p, _p, _p],
+    'mpb_stomp_plan_destroy': [_p],
     'mpb_point_dynamics': [_p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t, _i, _f, _p],
     'mpb_point_traj_cost': [_p, _p, _p, _p, _f, _f, _f, _f, _f, _p, _i, _i, _i, _i, _p],
     'mpb_mppi_step': [_p] * 11 + [_i] + [_p] * 6 + [_i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _u64, _u32, _p],

@@ -13,6 +13,17 @@ from . import _lib
 from .geometry import count_fields, pack_geometry
 
 
+# the raw handle of a device's current stream: torch.cuda.current_stream(dev).cuda_stream builds a Stream object per call (~2.5 us,
+# a quarter of the host side of a persistent STOMP call); torch keeps the raw getter its own launchers use
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
+def raw_stream(device_index):
+    if _raw_stream is not None:
+        return _raw_stream(device_index)
+    return torch.cuda.current_stream(device_index).cuda_stream
+
+
 def _stream():
     # called inside _on_tensor_device: the current device is the tensors' device
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -462,7 +473,21 @@ class StompRunPlan:
         self._status = status
         self._status_ptr = status.ptr()
         self._tag_ref = c.byref(status.tag_c)
-        self._fn = _lib.lib().mpb_stomp_run_checked
+        # the same arguments kept on the library's side (mpb_stomp_plan_*): launch() hands over four values per call
+        h = c.c_void_p(0)
+        _lib.check(_lib.lib().mpb_stomp_plan_create(
+            c.byref(h), _ptr(means), _ptr(samples), _ptr(costs), _ptr(weights), _ptr(L), _ptr(Sigma), _ptr(geom.buf), int(geom.flags),
+            _ptr(workspace), workspace.numel() * 4, P, S, H, d, D, float(k_sigma), float(weight), float(lr), float(temperature),
+            int(seed) & (2 ** 64 - 1), int(particle_offset), self._status_ptr), 'mpb_stomp_plan_create')
+        self._handle = h
+        self._launch = _lib.lib().mpb_stomp_plan_launch
+        self._destroy = _lib.lib().mpb_stomp_plan_destroy
+
+    def __del__(self):
+        h = getattr(self, '_handle', None)
+        if h is not None and h.value:
+            self._destroy(h)
+            self._handle = None
 
     def launch_timed(self, n_iters, iter0, means_copy=None):
         """launch() with the kernel's own duration measured on the dispatch (mpb_stomp_run_timed): synchronises; returns ms."""
@@ -477,9 +502,8 @@ class StompRunPlan:
 
     def launch(self, n_iters, iter0, means_copy=None):
         """Enqueue the call on the current stream of the plan's device (which must be the current device)."""
-        rc = self._fn(*self._head, int(n_iters), self._seed, int(iter0), self._poff, self._status_ptr, self._tag_ref,
-                      None if means_copy is None else means_copy.data_ptr(),
-                      torch.cuda.current_stream(self.device).cuda_stream)
+        rc = self._launch(self._handle, n_iters, iter0, None if means_copy is None else means_copy.data_ptr(),
+                          raw_stream(self.device.index), self._tag_ref)
         if rc != 0:
             _lib.check(rc, 'mpb_stomp_run')
         return self._status.note_launch()

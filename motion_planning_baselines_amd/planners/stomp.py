@@ -35,6 +35,9 @@ def precision_to_scale_tril(P):
     return torch.linalg.solve_triangular(L_inv, Id, upper=False).contiguous()   # (some LAPACK back-ends hand back a transposed view)
 
 
+_current_device = getattr(torch._C, '_cuda_getDevice', torch.cuda.current_device)     # (the raw getter: no lazy-init bookkeeping per call)
+
+
 class PersistentLaunchLost(MPBError):
     """A persistent (one-launch) optimisation loop was abandoned by the device side: see STOMP's `check` argument."""
 
@@ -224,7 +227,7 @@ class STOMP(OptimizationPlanner):
             # finite-difference velocities, from the means)
             copy = None if self.pos_only else torch.empty_like(self._particle_means)
             if (self.persistent and self.noise == 'philox' and self._particle_means.is_cuda
-                    and torch.cuda.current_device() == self._particle_means.device.index):
+                    and _current_device() == self._particle_means.device.index):
                 # device noise: nothing changes between calls but the iteration counter -- arguments validated once
                 key = (self._particle_means.data_ptr(), self.state_particles.data_ptr(), self.costs.data_ptr(),
                        self._weights_buf.data_ptr(), self.scale_tril.data_ptr(), self.Sigma.data_ptr(), geom.buf.data_ptr(),
