@@ -154,7 +154,7 @@ def stomp_parity(wl, L, Sigma, eps_parity, gpu, kept):
 class Clock:
     """R timed blocks of one callable, each bracketed by barrier + synchronize, MAX over the ranks.
 
-    The closing bracket first spins on an event query (host polling, no sleep) and THEN calls the barrier and
+    The closing bracket first spins on a stream query (host polling, no sleep) and THEN calls the barrier and
     torch.cuda.synchronize(), which by then return at once: the timed region still ends when every kernel of the block has
     finished and synchronize() has returned, but the runtime's blocking wait is taken out of it -- on this pool
     hipDeviceSynchronize wakes up 15-25 us late for about half the launches of one particular duration (~360 us, i.e.
@@ -173,18 +173,20 @@ class Clock:
         if self.dist is not None:
             self.dist.all_reduce(self._flag)
         if spin or self.dist is not None:
-            ev = torch.cuda.Event()
-            ev.record()
-            while not ev.query():
-                pass
+            self._spin()
         torch.cuda.synchronize()
 
-    def wait(self):
-        """This rank has finished everything it enqueued (host spin on an event, then synchronize)."""
-        ev = torch.cuda.Event()
-        ev.record()
-        while not ev.query():
+    @staticmethod
+    def _spin():
+        """Host polling until the current stream has drained (hipStreamQuery: no marker packet behind the kernel -- an event
+        recorded for the purpose is one more packet the queue processes after the kernel's end, ~2-3 us in the timed region)."""
+        s = torch.cuda.current_stream()
+        while not s.query():
             pass
+
+    def wait(self):
+        """This rank has finished everything it enqueued (host spin on the stream, then synchronize)."""
+        self._spin()
         torch.cuda.synchronize()
 
     def blocks(self, fn, repeats, before=None):
