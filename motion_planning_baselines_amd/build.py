@@ -23,10 +23,32 @@ OUT = os.path.join(CSRC, 'libmpb_hip.so')
 DEBUG_OUT = os.path.join(CSRC, 'libmpb_hip_debug.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
          '-ffinite-math-only', '-fno-signed-zeros', '-fno-slp-vectorize']
+# what the compiler made of every kernel (registers, spills, scratch, LDS), written next to the library by build(): the
+# persistent kernels sit at their register budget, and a change anywhere in their phases can tip loop invariants into scratch
+# (round 4: twice) -- tests/test_host_logic.py holds the headline instantiations to 0 B
+RESOURCES = os.path.join(CSRC, 'kernel_resources.json')
+REMARKS = ['-Rpass-analysis=kernel-resource-usage']
+
+
+def parse_resource_remarks(text):
+    """{mangled kernel name: {vgprs, sgpr_spill, vgpr_spill, scratch, lds, occupancy}} from -Rpass-analysis=kernel-resource-usage."""
+    import re
+    out, cur = {}, None
+    keys = {'VGPRs': 'vgprs', 'AGPRs': 'agprs', 'ScratchSize [bytes/lane]': 'scratch', 'Occupancy [waves/SIMD]': 'occupancy',
+            'SGPRs Spill': 'sgpr_spill', 'VGPRs Spill': 'vgpr_spill', 'LDS Size [bytes/block]': 'lds', 'TotalSGPRs': 'sgprs'}
+    for line in text.splitlines():
+        m = re.search(r'remark: Function Name: (\S+)', line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r'remark:\s+([A-Za-z \[\]/]+): (\d+) \[-Rpass-analysis', line)
+        if m and cur is not None and m.group(1).strip() in keys:
+            cur[keys[m.group(1).strip()]] = int(m.group(2))
+    return out
 
 
 def _stale():
-    if not os.path.exists(OUT) or not os.path.exists(DEBUG_OUT):
+    if not os.path.exists(OUT) or not os.path.exists(DEBUG_OUT) or not os.path.exists(RESOURCES):
         return True
     t = min(os.path.getmtime(OUT), os.path.getmtime(DEBUG_OUT))
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h'))]
@@ -80,13 +102,23 @@ def build(force=False, verbose=True):
     for src in SOURCES + DEBUG_SOURCES:
         obj = os.path.join(CSRC, src.replace('.hip', '.o'))
         objs.append(obj)
-        cmd = [hipcc, *FLAGS, *EXTRA.get(src, []), '-c', os.path.join(CSRC, src), '-o', obj]
+        cmd = [hipcc, *FLAGS, *EXTRA.get(src, []), *REMARKS, '-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
-        procs.append((cmd, subprocess.Popen(cmd)))
+        procs.append((cmd, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
+    resources = {}
     for cmd, p in procs:
-        if p.wait() != 0:
-            raise RuntimeError('hipcc failed: ' + ' '.join(cmd))
+        _, err = p.communicate()
+        rest = '\n'.join(l for l in err.splitlines() if 'kernel-resource-usage' not in l and not l.lstrip().startswith(('|', '^')) and l.strip()
+                         and not __import__('re').match(r'^\s*\d+ \|', l))
+        if p.returncode != 0:
+            raise RuntimeError('hipcc failed: ' + ' '.join(cmd) + '\n' + err[-4000:])
+        if verbose and rest:
+            print(rest, file=sys.stderr, flush=True)
+        resources.update(parse_resource_remarks(err))
+    import json
+    with open(RESOURCES, 'w') as fh:
+        json.dump(resources, fh, indent=0, sort_keys=True)
     n = len(SOURCES)
     for out, o in ((OUT, objs[:n]), (DEBUG_OUT, objs[n:])):
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *o, '-o', out]

@@ -1,7 +1,7 @@
 // mpb_debug.hip -- test aids of the C-ABI: what the tests need to look INSIDE the product kernels' random-number path.
 //   mpb_debug_philox          raw Philox4x32-R words (R = 7: the STOMP kernels; R = 10: everything else) for given
 //                             counters / keys -- compared with the published Random123 known-answer vectors;
-//   mpb_debug_stomp_normals   the standard normals exactly as the STOMP kernels draw them (stomp_eps4: Philox4x32-7 +
+//   mpb_debug_stomp_normals   the standard normals exactly as the STOMP kernels draw them (stomp_normals_lo / _hi: Philox4x32-7 +
 //                             Box-Muller on the hardware log2 / sqrt / sin / cos units), laid out (iters, P, S, d, H)
 //                             -- for the statistical tests of the throughput-mode noise (tests/test_gpu_rng.py).
 //   mpb_debug_occupy          workgroups that each hold a CU's LDS for a given time (the lost-launch tests).
@@ -35,30 +35,35 @@ extern "C" int mpb_debug_philox(const uint32_t* ctr, const uint32_t* key, uint32
     return mpb_check_launch("mpb_debug_philox");
 }
 
-// one thread per (iteration, particle, sample, channel j, k-group g, quarter q4): the four normals of one stomp_eps4 call,
-// eps[j][k = stomp_eps_column(g, q4, r)], r = 0..3 -- the very call of stomp_eps8 (mpb_stomp_noise.h)
+// one thread per (iteration, particle, sample, channel j, k-group g): the sixteen normals of that lane of the STOMP kernels
+// (stomp_normals_lo / _hi, mpb_stomp_noise.h: three Philox calls), eps[j][k = stomp_eps_column(g, u >> 2, u & 3)], u = 0..15
 __global__ void debug_stomp_normals_kernel(float* __restrict__ out, int P, int S, int d, int n_iters, uint32_t seed_lo,
                                            uint32_t seed_hi, uint32_t iter0, uint32_t particle_offset) {
-    const size_t n = (size_t)n_iters * P * S * d * 16;
+    const size_t n = (size_t)n_iters * P * S * d * 4;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t q4 = i & 3, g = (i >> 2) & 3;
-    size_t r = i >> 4;
+    const uint32_t g = i & 3;
+    size_t r = i >> 2;
     const uint32_t j = r % d; r /= d;
     const uint32_t s = r % S; r /= S;
     const uint32_t p = r % P; r /= P;
     const uint32_t it = (uint32_t)r;
-    float nrm[4];
-    stomp_eps4(particle_offset + p, s, j, g, q4, iter0 + it, seed_lo, seed_hi, nrm);
+    float lo[8], hi[8];
+    uint32_t carry[2];
+    stomp_normals_lo<STOMP_PRIO_NONE>(particle_offset + p, s, j, g, 0u, iter0 + it, seed_lo, seed_hi, lo, carry);
+    stomp_normals_hi<STOMP_PRIO_NONE>(particle_offset + p, s, j, g, 0u, iter0 + it, seed_lo, seed_hi, carry, hi);
     float* o = out + ((((size_t)it * P + p) * S + s) * d + j) * 64;
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) o[stomp_eps_column((int)g, (int)q4, rr)] = nrm[rr];
+    for (int u = 0; u < 8; ++u) {
+        o[stomp_eps_column((int)g, u >> 2, u & 3)] = lo[u];
+        o[stomp_eps_column((int)g, 2 + (u >> 2), u & 3)] = hi[u];
+    }
 }
 
 extern "C" int mpb_debug_stomp_normals(float* out, int P, int S, int d, int n_iters, uint64_t seed, uint32_t iter0,
                                        uint32_t particle_offset, void* stream) {
     if (!out || P < 1 || S < 1 || d < 1 || d > 16 || n_iters < 1) return mpb_fail(MPB_E_INVALID, "mpb_debug_stomp_normals: bad argument");
-    const size_t n = (size_t)n_iters * P * S * d * 16;
+    const size_t n = (size_t)n_iters * P * S * d * 4;
     if (n > 0x7FFFFFFFull * 256ull) return mpb_fail(MPB_E_INVALID, "mpb_debug_stomp_normals: too many draws for one launch");
     hipLaunchKernelGGL(debug_stomp_normals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, P, S,
                        d, n_iters, (uint32_t)seed, (uint32_t)(seed >> 32), iter0, particle_offset);

@@ -312,9 +312,10 @@ __global__ __launch_bounds__(64 * MPB_A_WPB, 16 / MPB_A_WPB) void stomp_sample_c
     MPB_STAMP(1);
     // ---- eps[c = j][k = 32 kb + 8 g + e] of both column blocks, drawn (or loaded) BEFORE L is needed
     float ev[2][8];
+    uint32_t carry[2] = {0u, 0u};
     const float* eps_s = eps ? eps + (size_t)s * DCH * P * H : nullptr;
-    stomp_eps8<DCH, 0, STOMP_PRIO_NONE>(ev[0], eps_s, P, p, j, g, particle_offset + (uint32_t)p, (uint32_t)s, iter, seed_lo, seed_hi);
-    stomp_eps8<DCH, 1, STOMP_PRIO_NONE>(ev[1], eps_s, P, p, j, g, particle_offset + (uint32_t)p, (uint32_t)s, iter, seed_lo, seed_hi);
+    stomp_eps8<DCH, 0, STOMP_PRIO_NONE>(ev[0], carry, eps_s, P, p, j, g, particle_offset + (uint32_t)p, (uint32_t)s, iter, seed_lo, seed_hi);
+    stomp_eps8<DCH, 1, STOMP_PRIO_NONE>(ev[1], carry, eps_s, P, p, j, g, particle_offset + (uint32_t)p, (uint32_t)s, iter, seed_lo, seed_hi);
     MPB_STAMP(2);
     // L as the three-component bf16 MFMA image (mpb_stomp_noise.h)
     unsigned* Limg = reinterpret_cast<unsigned*>(Lp);
@@ -464,6 +465,7 @@ __global__ __launch_bounds__(256) void stomp_sample_cost_hx_kernel(
             // ---- eps[c = j][k = 64 kc + 32 kb + 8 g + e] of this column chunk as the three bf16 operand components of its
             //      two column blocks (mpb_stomp_noise.h; device noise: Philox calls 2 kb, 2 kb + 1 of the chunk)
             StompEps8 sp[2];
+            uint32_t carry[2] = {0u, 0u};
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 float v[8];
@@ -475,12 +477,14 @@ __global__ __launch_bounds__(256) void stomp_sample_cost_hx_kernel(
                     }
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        float n[4] = {0.f, 0.f, 0.f, 0.f};
-                        if (j < d)
-                            stomp_eps4(particle_offset + (uint32_t)p, (uint32_t)s, (uint32_t)j, (uint32_t)g,
-                                       (uint32_t)(kc << 4) | (uint32_t)(2 * kb + q), iter, seed_lo, seed_hi, n);
-                        v[4 * q + 0] = n[0]; v[4 * q + 1] = n[1]; v[4 * q + 2] = n[2]; v[4 * q + 3] = n[3];
+                    for (int q = 0; q < 8; ++q) v[q] = 0.f;
+                    if (j < d) {
+                        if (kb == 0)
+                            stomp_normals_lo<STOMP_PRIO_NONE>(particle_offset + (uint32_t)p, (uint32_t)s, (uint32_t)j, (uint32_t)g,
+                                                              (uint32_t)(kc << 4), iter, seed_lo, seed_hi, v, carry);
+                        else
+                            stomp_normals_hi<STOMP_PRIO_NONE>(particle_offset + (uint32_t)p, (uint32_t)s, (uint32_t)j, (uint32_t)g,
+                                                              (uint32_t)(kc << 4), iter, seed_lo, seed_hi, carry, v);
                     }
                 }
                 stomp_split8(v, sp[kb]);

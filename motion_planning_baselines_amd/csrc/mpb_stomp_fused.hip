@@ -158,7 +158,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
     bool live = s < S;
     // the particle's mean: fetched now, dropped into LDS behind the first noise draw (which needs the unit, not the mean: its
     // ~1.7 us of Philox + matrix work hide the load's round trip at kernel entry)
-    const float mean_reg = (tid < N) ? means[(size_t)p * N + tid] : 0.f;
+    // (exchange layout only: in the two-batch instantiations the value carried across the draw pushed 14 VGPRs to scratch)
+    float mean_reg = 0.f;
+    if (NB == 1) mean_reg = (tid < N) ? means[(size_t)p * N + tid] : 0.f;
+    else if (tid < N) mean_l[tid] = means[(size_t)p * N + tid];
     // header word 1 = this call's tag; word 0 (the error word) counts only when it equals it
     if (ticket == 0 && tid == 0) st_agent_u(wsu + FUSED_HDR_TAG, tag0);    // (unit 0 is drawn exactly once)
     LSTAMP(2);
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
                               particle_offset + (uint32_t)p, (uint32_t)s, iter0, seed_lo, seed_hi);
         stomp_noise_to_tile(nt, acc, lane);
     }
-    if (tid < N) mean_l[tid] = mean_reg;
+    if (NB == 1 && tid < N) mean_l[tid] = mean_reg;
     __syncthreads();
 
     LSTAMP(3);
@@ -328,7 +331,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
             stomp_noise_bf16<DCH, FUSED_NOISE_PRIO>(Limg, acc, eps ? eps + (size_t)it_n * eps_stride + (size_t)(s_n < S ? s_n : 0) * DCH * P * H : nullptr,
                                                     P, p, jv, gv, particle_offset + (uint32_t)p, (uint32_t)s_n, iter0 + (uint32_t)it_n,
                                                     slo, shi, 3 - (wave >> 2));
-            stomp_noise_to_tile(nt, acc, lane);           // (the samples packed in the tile were consumed before barrier 2)
+            // (the tile addresses of the write below from an opaque copy of the lane: hoisted out of the loop they are four VGPRs
+            // the cost phase does not have)
+            int lane_w = lane;
+            asm volatile("" : "+v"(lane_w));
+            stomp_noise_to_tile(nt, acc, lane_w);         // (the samples packed in the tile were consumed before barrier 2)
             if (FUSED_NOISE_PRIO == STOMP_PRIO_STAGGER) __builtin_amdgcn_s_setprio(0);
         }
         }   // batches

@@ -173,15 +173,19 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
                     e[u] = (jv < d && k < H) ? ep[k] : 0.f;
                 }
             } else {
+                float lo8[8], hi8[8];
+                uint32_t carry[2] = {0u, 0u};
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    float n[4] = {0.f, 0.f, 0.f, 0.f};
-                    stomp_setprio(3 - q4);
-                    if (jv < d)
-                        stomp_eps4(particle_offset + (uint32_t)p, (uint32_t)s_n, (uint32_t)jv, (uint32_t)gv,
-                                   (uint32_t)(kc << 4) | (uint32_t)q4, iter0 + (uint32_t)it_n, slo, shi, n);
-                    e[4 * q4 + 0] = n[0]; e[4 * q4 + 1] = n[1]; e[4 * q4 + 2] = n[2]; e[4 * q4 + 3] = n[3];
+                for (int q = 0; q < 8; ++q) lo8[q] = hi8[q] = 0.f;
+                if (jv < d) {
+                    stomp_normals_lo<STOMP_PRIO_PROGRESS>(particle_offset + (uint32_t)p, (uint32_t)s_n, (uint32_t)jv, (uint32_t)gv,
+                                                          (uint32_t)(kc << 4), iter0 + (uint32_t)it_n, slo, shi, lo8, carry);
+                    stomp_normals_hi<STOMP_PRIO_PROGRESS>(particle_offset + (uint32_t)p, (uint32_t)s_n, (uint32_t)jv, (uint32_t)gv,
+                                                          (uint32_t)(kc << 4), iter0 + (uint32_t)it_n, slo, shi, carry, hi8);
                 }
+                stomp_setprio(0);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { e[q] = lo8[q]; e[8 + q] = hi8[q]; }
             }
         };
         // acc += (block b of L) * e, issued transposed; both column blocks of the 64-column chunk

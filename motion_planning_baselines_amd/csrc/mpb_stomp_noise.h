@@ -1,12 +1,10 @@
 // mpb_stomp_noise.h -- the time-correlated STOMP noise  N = L * eps  of one rollout per wave on the matrix cores
 // (shared by the two-kernel path, mpb_kernels.hip, and the persistent fused kernel, mpb_stomp_fused.hip).
 //
-// L (64 x 64 lower-triangular scale_tril of the precision matrix R) is the A operand of exact-fp32
-// v_mfma_f32_16x16x4_f32 tiles, eps (64 x d standard normals) the B operand:
-//   A  L[16m+i][4ks+g]   (lane i = l&15, g = l>>4)  from an LDS image laid out so that one ds_read_b128 per lane
-//                         delivers four k-steps, conflict-free (stomp_l_image_index);
-//   B  eps[c=j][4ks+g]   (lane j = l&15, g = l>>4)  generated in registers (Philox) or loaded;
-//   lower-triangular: row tile m only needs k-steps ks <= 4m+3  ->  40 instead of 64 MFMAs.
+// L (64 x 64 lower-triangular scale_tril of the precision matrix R) is the A operand, eps (64 x d standard normals, generated
+// in registers -- Philox + Box-Muller -- or loaded) the B operand of v_mfma_f32_16x16x32_bf16 tiles on an exact three-way bf16
+// split of both (below); lower-triangular: row tile m only needs the 32-column blocks up to its diagonal.
+// (stomp_l_image_index is the permuted fp32 image of rounds 1-3, still used by the MPPI kernel's fp32 product.)
 #pragma once
 #include "mpb_common.h"
 
@@ -14,27 +12,27 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define NT_STRIDE 20  // floats per waypoint row of a wave's noise tile: 80 B keeps ds_read_b128 conflict-free
 
-// Standard normals of the H = 64 paths: one Philox4x32-7 call per (particle, sample, channel j, k-group g, quarter q4)
-// yields four normals; which columns k of eps[j][.] they are is the caller's (H = 64 paths: stomp_eps_column; the chunked
-// paths for other horizons: k = 64 kc + 16 q4 + 4 r + g).  The counter holds the GLOBAL particle id, so the noise does not
-// depend on how the particles are sharded over GPUs (nor on which kernel draws it).
-__device__ __forceinline__ void stomp_eps4(uint32_t p_global, uint32_t s, uint32_t j, uint32_t g, uint32_t q4,
-                                           uint32_t iter, uint32_t seed_lo, uint32_t seed_hi, float (&n)[4]) {
-    const uint4 rr = philox4x32<7>(make_uint4(p_global, s, (j << 16) | (g << 8) | q4, iter), make_uint2(seed_lo, seed_hi));
-    box_muller(rr.x, rr.y, n[0], n[1]);
-    box_muller(rr.z, rr.w, n[2], n[3]);
+// Standard normals of a lane for one 64-column chunk: SIXTEEN per (particle, sample, channel j, k-group g), from THREE
+// Philox4x32-7 calls (round 4; rounds 1-3 spent a call per four normals and used 24 of every 32 bits): the twelve words are
+// cut into sixteen 24-bit fields f_0 .. f_15 (word triple (a, b, c) -> a >> 8, a[7:0] b[31:16], b[15:0] c[31:24], c[23:0]),
+// Box-Muller takes them in pairs (f_2i -> radius, f_2i+1 -> angle), normal u is eps[j][column] with the column the caller's
+// (H = 64 paths: stomp_eps_column(g, u >> 2, u & 3) = 32 (u >> 3) + 8 g + (u & 7); the chunked paths add 64 kc).  The counter
+// holds the GLOBAL particle id (the noise does not depend on the sharding nor on which kernel draws it), word 2 = (j << 16) |
+// (g << 8) | call with call = (kc << 4) | {0, 1, 2}.  The draw comes in two halves so that the matrix product of the first
+// column block runs between them: normals 0-7 need words 0-5 (calls 0, 1; words 6, 7 are carried), normals 8-15 words 6-11.
+__device__ __forceinline__ void box_muller24(uint32_t f1, uint32_t f2, float& n0, float& n1) {
+    const float u1 = (f1 + 1u) * (1.0f / 16777216.0f);  // (0,1]
+    const float u2 = f2 * (1.0f / 16777216.0f);         // [0,1)
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __log2f(u1));   // raw v_sqrt_f32 / v_log_f32, as box_muller
+    n0 = r * __builtin_amdgcn_cosf(u2);
+    n1 = r * __builtin_amdgcn_sinf(u2);
 }
-
-// B operand of one rollout: e[ks] = eps[c = j][k = 4 ks + g], ks = 0..15 (zero for the padding channels j >= DCH).
-// eps_rollout != nullptr: pre-drawn normals, laid out (d, P, H) for this sample (pointer already at [s]).
-// PRIO: what the wave does to its issue priority while it draws (the caller resets it after the matrix product).
-//   STOMP_PRIO_PROGRESS  lower it as the wave advances through the four draws (3, 2, 1, 0): the SIMD arbiter serves its
-//       oldest wave first, which left alone makes the waves of a SIMD finish one after the other, the last one running
-//       alone (see model_group_positions in mpb_geom.h).  For kernels whose waves do VALU work only.
-//   STOMP_PRIO_STAGGER   one fixed level per wave, `level` = 0..3, different for the (up to four) waves of a SIMD: the
-//       draws are VALU work, the product that follows them runs on the matrix pipe, and the two overlap only when the
-//       waves of a SIMD are in DIFFERENT halves -- so here the waves are made to finish one after the other on purpose:
-//       the wave with the highest level draws at full rate and multiplies while the others still draw.
+__device__ __forceinline__ void stomp_fields4(uint32_t a, uint32_t b, uint32_t c, float (&n)[4]) {
+    const uint32_t f0 = a >> 8, f1 = __builtin_amdgcn_alignbit(a, b, 16) & 0xFFFFFFu, f2 = __builtin_amdgcn_alignbit(b, c, 24) & 0xFFFFFFu,
+                   f3 = c & 0xFFFFFFu;
+    box_muller24(f0, f1, n[0], n[1]);
+    box_muller24(f2, f3, n[2], n[3]);
+}
 #define STOMP_PRIO_NONE 0
 #define STOMP_PRIO_PROGRESS 1
 #define STOMP_PRIO_STAGGER 2
@@ -46,25 +44,37 @@ __device__ __forceinline__ void stomp_setprio(int level) {       // (the operand
         default: __builtin_amdgcn_s_setprio(3); break;
     }
 }
-template <int DCH, int PRIO = STOMP_PRIO_NONE>
-__device__ __forceinline__ void stomp_b_operand(float (&e)[16], const float* __restrict__ eps_s, int P, int p, int j, int g,
-                                                uint32_t p_global, uint32_t s, uint32_t iter, uint32_t seed_lo, uint32_t seed_hi,
-                                                int level = 0) {
-    constexpr int H = 64;
-    if (eps_s != nullptr) {
-        const float* ep = eps_s + ((size_t)(j < DCH ? j : 0) * P + p) * H + g;
+// normals 0-7 (column block 0 of the chunk); `carry` = words 6, 7 for stomp_normals_hi.  PRIO == STOMP_PRIO_PROGRESS: the issue
+// priority falls as the wave advances through its three calls (3, 2, then 1 in stomp_normals_hi; see stomp_eps8)
+template <int PRIO>
+__device__ __forceinline__ void stomp_normals_lo(uint32_t p_global, uint32_t s, uint32_t j, uint32_t g, uint32_t call0, uint32_t iter,
+                                                 uint32_t seed_lo, uint32_t seed_hi, float (&n)[8], uint32_t (&carry)[2]) {
+    const uint32_t z = (j << 16) | (g << 8) | call0;
+    if (PRIO == STOMP_PRIO_PROGRESS) stomp_setprio(3);
+    const uint4 r0 = philox4x32<7>(make_uint4(p_global, s, z, iter), make_uint2(seed_lo, seed_hi));
+    float a[4], b[4];
+    stomp_fields4(r0.x, r0.y, r0.z, a);
+    // (one call at a time: interleaved by the scheduler the two calls and their Box-Muller chains want ~15 more VGPRs than
+    // the phase has -- they went to scratch)
+    __builtin_amdgcn_sched_barrier(0);
+    if (PRIO == STOMP_PRIO_PROGRESS) stomp_setprio(2);
+    const uint4 r1 = philox4x32<7>(make_uint4(p_global, s, z + 1u, iter), make_uint2(seed_lo, seed_hi));
+    stomp_fields4(r0.w, r1.x, r1.y, b);
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) e[ks] = (j < DCH) ? ep[4 * ks] : 0.f;
-    } else {
-        if (PRIO == STOMP_PRIO_STAGGER) stomp_setprio(level);
+    for (int q = 0; q < 4; ++q) { n[q] = a[q]; n[4 + q] = b[q]; }
+    carry[0] = r1.z;
+    carry[1] = r1.w;
+}
+template <int PRIO>
+__device__ __forceinline__ void stomp_normals_hi(uint32_t p_global, uint32_t s, uint32_t j, uint32_t g, uint32_t call0, uint32_t iter,
+                                                 uint32_t seed_lo, uint32_t seed_hi, const uint32_t (&carry)[2], float (&n)[8]) {
+    if (PRIO == STOMP_PRIO_PROGRESS) stomp_setprio(1);
+    const uint4 r2 = philox4x32<7>(make_uint4(p_global, s, ((j << 16) | (g << 8) | call0) + 2u, iter), make_uint2(seed_lo, seed_hi));
+    float a[4], b[4];
+    stomp_fields4(carry[0], carry[1], r2.x, a);
+    stomp_fields4(r2.y, r2.z, r2.w, b);
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            float n[4] = {0.f, 0.f, 0.f, 0.f};
-            if (PRIO == STOMP_PRIO_PROGRESS) stomp_setprio(3 - q4);
-            if (j < DCH) stomp_eps4(p_global, s, (uint32_t)j, (uint32_t)g, (uint32_t)q4, iter, seed_lo, seed_hi, n);
-            e[4 * q4 + 0] = n[0]; e[4 * q4 + 1] = n[1]; e[4 * q4 + 2] = n[2]; e[4 * q4 + 3] = n[3];
-        }
-    }
+    for (int q = 0; q < 4; ++q) { n[q] = a[q]; n[4 + q] = b[q]; }
 }
 
 // index of L[row][col] in the permuted LDS image: Lp[(((m*4 + ks4)*4 + g)*16 + i)*4 + kk] = L[16m+i][4*(4*ks4+kk) + g]
@@ -73,25 +83,8 @@ __device__ __forceinline__ int stomp_l_image_index(int row, int col) {
     return ((((m * 4 + (ks >> 2)) * 4 + gq) * 16 + i) << 2) + (ks & 3);
 }
 
-// acc[m] = rows 16m..16m+15 of L * eps for the wave's rollout (lane (j, g) holds D[row = 4g + rr][col = j] in acc[m][rr])
-__device__ __forceinline__ void stomp_noise_product(const float* __restrict__ Lp, const float (&e)[16], int j, int g, f32x4 (&acc)[4]) {
-    const f32x4* Lp4 = reinterpret_cast<const f32x4*>(Lp);
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks4 = 0; ks4 <= m; ++ks4) {
-            const f32x4 a = Lp4[((m * 4 + ks4) * 4 + g) * 16 + j];
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], e[4 * ks4 + 0], acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], e[4 * ks4 + 1], acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], e[4 * ks4 + 2], acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], e[4 * ks4 + 3], acc[m], 0, 0, 0);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// The same product on the bf16 matrix pipe, EXACT in fp32 inputs (round 4).
+// The product on the bf16 matrix pipe, EXACT in fp32 inputs (round 4; rounds 1-3: 40 v_mfma_f32_16x16x4_f32 per rollout).
 //
 // v_mfma_f32_16x16x4_f32 runs on the fp32 multipliers the vector instructions use: 32 cycles for 1 024 multiply-adds, no
 // overlap with another wave's VALU work (profiles/r03_microbench_overlap.txt) -- the 40 MFMAs of the product were 15 % of
@@ -161,8 +154,7 @@ __device__ __forceinline__ void stomp_split8(const float (&v)[8], StompEps8& b) 
     }
 }
 
-// Standard normals of the H = 64 paths, column assignment of the bf16 product: the r-th normal of Philox call q4 of lane
-// group g is eps[j][k] with k = 32 (q4 >> 1) + 8 g + 4 (q4 & 1) + r  (calls 0, 1: column block kb = 0; calls 2, 3: kb = 1).
+// column of a 64-column chunk that normal u = 4 q4 + r of lane group g lands on (stomp_normals_lo / _hi): 32 (u >> 3) + 8 g + (u & 7)
 __device__ __forceinline__ constexpr int stomp_eps_column(int g, int q4, int r) { return 32 * (q4 >> 1) + 8 * g + 4 * (q4 & 1) + r; }
 
 // acc[m] += rows 16 m .. 16 m + 15 of (column block KB of the 64 x 64 block behind `img`) * eps, for the row tiles the
@@ -198,11 +190,11 @@ __device__ __forceinline__ void stomp_noise_product_kb(const unsigned* __restric
     }
 }
 
-// the eight values of column block KB for lane (j, g): drawn (Philox calls 2 KB, 2 KB + 1) or loaded (eps_s: pre-drawn
-// normals laid out (d, P, H) for this sample, pointer already at [s]); zero for the padding channels j >= DCH
+// the eight values of column block KB for lane (j, g): drawn (stomp_normals_lo / _hi: `carry` links the two halves) or loaded
+// (eps_s: pre-drawn normals laid out (d, P, H) for this sample, pointer already at [s]); zero for the padding channels j >= DCH
 template <int DCH, int KB, int PRIO>
-__device__ __forceinline__ void stomp_eps8(float (&v)[8], const float* __restrict__ eps_s, int P, int p, int j, int g,
-                                           uint32_t p_global, uint32_t s, uint32_t iter, uint32_t seed_lo, uint32_t seed_hi) {
+__device__ __forceinline__ void stomp_eps8(float (&v)[8], uint32_t (&carry)[2], const float* __restrict__ eps_s, int P, int p, int j,
+                                           int g, uint32_t p_global, uint32_t s, uint32_t iter, uint32_t seed_lo, uint32_t seed_hi) {
     constexpr int H = 64;
     if (eps_s != nullptr) {
         const f32x4* ep = reinterpret_cast<const f32x4*>(eps_s + ((size_t)(j < DCH ? j : 0) * P + p) * H + 32 * KB + 8 * g);
@@ -210,12 +202,10 @@ __device__ __forceinline__ void stomp_eps8(float (&v)[8], const float* __restric
         v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
     } else {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int q4 = 2 * KB + q;
-            float n[4] = {0.f, 0.f, 0.f, 0.f};
-            if (PRIO == STOMP_PRIO_PROGRESS) stomp_setprio(3 - q4);
-            if (j < DCH) stomp_eps4(p_global, s, (uint32_t)j, (uint32_t)g, (uint32_t)q4, iter, seed_lo, seed_hi, n);
-            v[4 * q + 0] = n[0]; v[4 * q + 1] = n[1]; v[4 * q + 2] = n[2]; v[4 * q + 3] = n[3];
+        for (int q = 0; q < 8; ++q) v[q] = 0.f;
+        if (j < DCH) {
+            if (KB == 0) stomp_normals_lo<PRIO>(p_global, s, (uint32_t)j, (uint32_t)g, 0u, iter, seed_lo, seed_hi, v, carry);
+            else stomp_normals_hi<PRIO>(p_global, s, (uint32_t)j, (uint32_t)g, 0u, iter, seed_lo, seed_hi, carry, v);
         }
     }
 }
@@ -229,35 +219,19 @@ __device__ __forceinline__ void stomp_noise_bf16(const unsigned* __restrict__ im
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
     float v[8];
+    uint32_t carry[2] = {0u, 0u};
     StompEps8 b;
-    stomp_eps8<DCH, 0, PRIO>(v, eps_s, P, p, j, g, p_global, s, iter, seed_lo, seed_hi);
+    stomp_eps8<DCH, 0, PRIO>(v, carry, eps_s, P, p, j, g, p_global, s, iter, seed_lo, seed_hi);
     stomp_split8(v, b);
     stomp_noise_product_kb<0>(img, b, j, g, acc);
-    stomp_eps8<DCH, 1, PRIO>(v, eps_s, P, p, j, g, p_global, s, iter, seed_lo, seed_hi);
+    stomp_eps8<DCH, 1, PRIO>(v, carry, eps_s, P, p, j, g, p_global, s, iter, seed_lo, seed_hi);
     stomp_split8(v, b);
     stomp_noise_product_kb<1>(img, b, j, g, acc);
+    if (PRIO == STOMP_PRIO_PROGRESS && eps_s == nullptr) stomp_setprio(0);
 }
 
-// D tiles (lane = channel) -> the wave's LDS tile [waypoint][channel] -> this lane's waypoint row (lane = waypoint).
-// Written and read back by the SAME wave (LDS operations of a wave complete in order: no barrier).
-template <int DCH>
-__device__ __forceinline__ void stomp_noise_rows(float* __restrict__ nt, const f32x4 (&acc)[4], int lane, float (&nz)[16]) {
-    const int j = lane & 15, g = lane >> 4;
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) nt[(16 * m + 4 * g + rr) * NT_STRIDE + j] = acc[m][rr];
-    __builtin_amdgcn_wave_barrier();
-    const f32x4* row = reinterpret_cast<const f32x4*>(nt + lane * NT_STRIDE);
-#pragma unroll
-    for (int v = 0; v < (DCH + 3) / 4; ++v) {
-        const f32x4 t = row[v];
-        nz[4 * v + 0] = t[0]; nz[4 * v + 1] = t[1]; nz[4 * v + 2] = t[2]; nz[4 * v + 3] = t[3];
-    }
-    __builtin_amdgcn_wave_barrier();
-}
-
-// the two halves of stomp_noise_rows for callers that park the noise in the tile between producing and consuming it
+// D tiles (lane = channel) -> the wave's LDS tile [waypoint][channel] (stomp_noise_to_tile), read back as this lane's waypoint row
+// (stomp_noise_row; lane = waypoint).  Written and read by the SAME wave (LDS operations of a wave complete in order: no barrier).
 __device__ __forceinline__ void stomp_noise_to_tile(float* __restrict__ nt, const f32x4 (&acc)[4], int lane) {
     const int j = lane & 15, g = lane >> 4;
 #pragma unroll

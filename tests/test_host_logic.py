@@ -424,3 +424,30 @@ def test_bench_self_launch_command(monkeypatch):
     assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and int(cmd[cmd.index('--master-port') + 1]) > 0
     assert cmd[-6:] == ['--gpus', '4', '--steps', '20', '--warmup', '5'] and cmd[-7].endswith('bench.py')
     assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+
+
+def test_headline_kernels_have_no_scratch():
+    """The persistent STOMP kernels run at their register budget (16 waves per workgroup: 128 VGPRs): a change anywhere in
+    their phases can tip loop invariants into scratch -- it happened twice in round 4, once unnoticed for several commits
+    (-4 % on the headline).  build() records what the compiler made of every kernel (csrc/kernel_resources.json,
+    -Rpass-analysis=kernel-resource-usage); the instantiations the bench line runs must have 0 B of scratch."""
+    import json
+    from motion_planning_baselines_amd import build
+    build.build(verbose=False)
+    res = json.load(open(build.RESOURCES))
+
+    def find(prefix):
+        hits = {k: v for k, v in res.items() if k.startswith(prefix)}
+        assert len(hits) == 1, (prefix, list(hits))
+        return next(iter(hits.values()))
+    must = ['_Z18stomp_fused_kernelILi14ELi1ELi1EE', '_Z18stomp_fused_kernelILi14ELi1ELi2EE',     # C3 (exchange), C5 (two batches)
+            '_Z18stomp_fused_kernelILi7ELi1ELi1EE', '_Z18stomp_fused_kernelILi7ELi1ELi2EE',       # the same, pos_only
+            '_Z21stomp_fused_hx_kernelILi14ELi1ELi2EE', '_Z21stomp_fused_hx_kernelILi14ELi1ELi1EE',   # H = 128 / H < 64
+            '_Z11mppi_kernelILi2ELb1EE']                                                                # the mppi entry
+    for name in must:
+        r = find(name)
+        assert r['scratch'] == 0 and r['vgpr_spill'] == 0, (name, r)
+        assert r['vgprs'] + r.get('agprs', 0) <= 128, (name, r)
+    # the other persistent instantiations: reported, bounded (generic run-time-d walk: DESIGN section 5b)
+    worst = max(v['scratch'] for k, v in res.items() if 'stomp_fused' in k)
+    assert worst <= 160, worst
