@@ -588,16 +588,97 @@ __device__ __forceinline__ void grid_stage(const GeomView& G, unsigned* gridw, f
         otab[i] = (i < G.n_sph) ? sp[i] : make_float4(-1.0e9f, -1.0e9f, -1.0e9f, 0.f);
 }
 
+// OFFSET WORDS (persistent STOMP kernels; round 4): the LDS copy of the grid re-encoded while it is staged, so that the
+// look-up of the walk needs no index arithmetic.  The obstacle table has at most 64 entries of 16 B (63 spheres + the far
+// dummy): a byte offset into it fits ten bits.  Word: bits 0-9 slot 0 as a byte offset (an empty cell: the dummy's),
+// bits 10-19 / 20-29 slots 1 / 2 as byte offsets, 0 = unused (an unused lane of a later trip then reads obstacle 0: any
+// obstacle that is not a candidate of the cell is beyond margin + r of every point in it and cannot change a hinge -- the
+// property the overflow path rests on); bit 31: the cell lists more than three obstacles -> exhaustive loop.  Obstacle
+// 0 can only sit in slot 0 (the host lists candidates in ascending order; any order is handled).  Against the byte
+// form per group of four spheres: slot 0's address is one v_and (was and + shift), "does any lane need another trip"
+// one compare of the four words or-ed together (was a field extract and a compare per sphere), and the overflow test
+// rides on it (was a compare per sphere): 104 -> 91 vector instructions per group on the common path.
+__device__ __forceinline__ unsigned grid_offset_word(unsigned w, unsigned n_sph) {
+    if (w == MPB_GRID_OVERFLOW) return 0x80000000u | (n_sph << 4);
+    unsigned b[4] = {0u, 0u, 0u, 0u}, n = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned v = (w >> (8 * k)) & 0xFFu;
+        if (v < n_sph) {                                            // used slots, in the order found
+#pragma unroll
+            for (int t = 0; t < 4; ++t) if ((unsigned)t == n) b[t] = v;
+            ++n;
+        }
+    }
+    if (n > 3) return 0x80000000u | (n_sph << 4);
+    // obstacle 0 to the front (its offset, 0, means "unused" in the later slots)
+    if (n > 1 && b[1] == 0u) { b[1] = b[0]; b[0] = 0u; }
+    if (n > 2 && b[2] == 0u) { b[2] = b[0]; b[0] = 0u; }
+    unsigned r = ((n > 0 ? b[0] : n_sph) << 4);
+    if (n > 1) r |= b[1] << 14;
+    if (n > 2) r |= b[2] << 24;
+    return r;
+}
+__device__ __forceinline__ void grid_stage_offsets(const GeomView& G, unsigned* gridw, float4* otab, int tid, int nthreads) {
+    for (int i = tid; i < G.n_cells; i += nthreads) gridw[i] = grid_offset_word(G.grid[i], (unsigned)G.n_sph);
+    const float4* sp = reinterpret_cast<const float4*>(G.sph);
+    for (int i = tid; i <= G.n_sph; i += nthreads)
+        otab[i] = (i < G.n_sph) ? sp[i] : make_float4(-1.0e9f, -1.0e9f, -1.0e9f, 0.f);
+}
+
 // N collision spheres at once: the N grid words are fetched together and every trip of the candidate
 // loop issues N obstacle-table reads before the N distance evaluations, so the LDS latency is paid
 // once per group instead of once per sphere.  Adds the N hinges to `cost` one by one, in sphere order
 // (the same association as the exhaustive path, so both paths agree bit for bit).
-template <int N>
+template <int N, bool OFFS = false>
 __device__ __forceinline__ void spheres_hinge_grid(const GeomView& G, const unsigned* gridw, const float4* otab,
                                                    const float (&x)[N], const float (&y)[N], const float (&z)[N],
                                                    const float (&rl)[N], float& cost) {
     unsigned w[N];
     float best[N];
+    if constexpr (OFFS) {
+        // the grid as offset words (grid_offset_word): slot 0 of every sphere unconditionally, the rest behind ONE test
+        const char* ob = reinterpret_cast<const char*>(otab);
+        float4 s0[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) w[i] = gridw[grid_cell<true>(G, x[i], y[i], z[i])];
+#pragma unroll
+        for (int i = 0; i < N; ++i) s0[i] = *reinterpret_cast<const float4*>(ob + (w[i] & 0x3FFu));
+        unsigned comb = w[0];
+#pragma unroll
+        for (int i = 1; i < N; ++i) comb |= w[i];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const float dx = x[i] - s0[i].x, dy = y[i] - s0[i].y, dz = z[i] - s0[i].z;
+            best[i] = fast_sqrt(dx * dx + dy * dy + dz * dz) - s0[i].w;
+        }
+        if (__ballot(comb > 0x3FFu) != 0ull) {
+            if (__builtin_expect(__ballot((int)comb < 0) != 0ull, 0)) {
+                // some lane sits in a crowded cell: exhaustive exact loop for this group (rare)
+                for (int o = 0; o < G.n_sph; ++o) {
+                    const float4 s = otab[o];
+#pragma unroll
+                    for (int i = 0; i < N; ++i) {
+                        const float dx = x[i] - s.x, dy = y[i] - s.y, dz = z[i] - s.z;
+                        best[i] = fminf(best[i], fast_sqrt(dx * dx + dy * dy + dz * dz) - s.w);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 1; k < 3; ++k) {
+                    if (k > 1 && __ballot(comb > 0xFFFFFu) == 0ull) break;
+                    float4 s[N];
+#pragma unroll
+                    for (int i = 0; i < N; ++i) s[i] = *reinterpret_cast<const float4*>(ob + ((w[i] >> (10 * k)) & 0x3FFu));
+#pragma unroll
+                    for (int i = 0; i < N; ++i) {
+                        const float dx = x[i] - s[i].x, dy = y[i] - s[i].y, dz = z[i] - s[i].z;
+                        best[i] = fminf(best[i], fast_sqrt(dx * dx + dy * dy + dz * dz) - s[i].w);
+                    }
+                }
+            }
+        }
+    } else {
     unsigned long long over = 0ull;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -645,6 +726,7 @@ __device__ __forceinline__ void spheres_hinge_grid(const GeomView& G, const unsi
             }
         }
     }
+    }   // byte form
     // boxes are few: exhaustive
     const float4* bp = reinterpret_cast<const float4*>(G.box);
     for (int o = 0; o < G.n_box; ++o) {
@@ -662,12 +744,13 @@ __device__ __forceinline__ void spheres_hinge_grid(const GeomView& G, const unsi
     for (int i = 0; i < N; ++i) cost += fmaxf(G.margin + rl[i] - best[i], 0.f);   // parked slots: best = 3e38 -> +0
 }
 
+template <bool OFFS = false>
 __device__ __forceinline__ float waypoint_cost_grid(const GeomView& G, const unsigned* gridw, const float4* otab,
                                                     const float (&q)[MPB_MAX_DOF]) {
     if (G.kind == MPB_KIND_POINT) {
         const float x[1] = {q[0]}, y[1] = {q[1]}, z[1] = {(G.n_dof > 2) ? q[2] : 0.f}, rl[1] = {G.links[4]};
         float c = 0.f;
-        spheres_hinge_grid<1>(G, gridw, otab, x, y, z, rl, c);
+        spheres_hinge_grid<1, OFFS>(G, gridw, otab, x, y, z, rl, c);
         return c;
     }
 #ifndef MPB_GRID_N
@@ -715,7 +798,7 @@ __device__ __forceinline__ float waypoint_cost_grid(const GeomView& G, const uns
                 x[i] = y[i] = z[i] = FAR;
             }
         }
-        spheres_hinge_grid<N>(G, gridw, otab, x, y, z, rl, cost);
+        spheres_hinge_grid<N, OFFS>(G, gridw, otab, x, y, z, rl, cost);
     }
 #ifndef MPB_NO_COST_PRIO
     __builtin_amdgcn_s_setprio(0);
@@ -821,7 +904,7 @@ __device__ __forceinline__ bool model_group_dispatch(int grp, ModelFK& F, const 
     return run;
 }
 
-template <class M>
+template <class M, bool OFFS = false>
 __device__ __forceinline__ float waypoint_cost_grid_model(const GeomView& G, const unsigned* gridw, const float4* otab,
                                                           const float (&q)[MPB_MAX_DOF]) {
     constexpr int NG = (M::N_FRAME1 + 3) / 4 + (M::N_LINKS - M::N_FRAME1 + 3) / 4;
@@ -835,7 +918,7 @@ __device__ __forceinline__ float waypoint_cost_grid_model(const GeomView& G, con
     for (int grp = 0; grp < NG; ++grp) {
         float x[4], y[4], z[4], rl[4];
         const bool run = model_group_dispatch<M>(grp, F, q, keep, x, y, z, rl, std::make_integer_sequence<int, NG>{});
-        if (run) spheres_hinge_grid<4>(G, gridw, otab, x, y, z, rl, cost);
+        if (run) spheres_hinge_grid<4, OFFS>(G, gridw, otab, x, y, z, rl, cost);
     }
 #ifndef MPB_NO_COST_PRIO
     __builtin_amdgcn_s_setprio(0);

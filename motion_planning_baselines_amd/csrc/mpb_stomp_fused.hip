@@ -139,7 +139,13 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         const int n_pad16 = (G0.n_cells + MPB_GRID_PAD - 1) / MPB_GRID_PAD * (MPB_GRID_PAD / 4);   // uint4s in the padded section
         for (int u = 0; u < (MPB_GRID_MAX_CELLS / 4 + FUSED_THREADS - 1) / FUSED_THREADS; ++u) {
             const int i = tid + FUSED_THREADS * u;
-            if (u < g_rounds && i < n_pad16) reinterpret_cast<uint4*>(gridw)[i] = g4[i];
+            if (u < g_rounds && i < n_pad16) {
+                // (as offset words: mpb_geom.h, grid_offset_word)
+                const uint4 gw = g4[i];
+                const unsigned ns = (unsigned)G0.n_sph;
+                reinterpret_cast<uint4*>(gridw)[i] = make_uint4(grid_offset_word(gw.x, ns), grid_offset_word(gw.y, ns),
+                                                                grid_offset_word(gw.z, ns), grid_offset_word(gw.w, ns));
+            }
         }
         for (int i = tid; i <= G0.n_sph && i <= MPB_GRID_MAX_SPH; i += FUSED_THREADS)
             otab[i] = (i < G0.n_sph) ? reinterpret_cast<const float4*>(G0.sph)[i] : make_float4(-1.0e9f, -1.0e9f, -1.0e9f, 0.f);
@@ -169,8 +175,23 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
     const size_t eps_stride = (size_t)S * DCH * P * H;
 
     // ---- noise of iteration 0: straight into the wave's tile ([waypoint][channel], stride NT_STRIDE)
+    // (PAIRED, 2 DCH <= 16: waves 0-7 draw and multiply for two rollouts each -- their own and wave + 8's --, waves 8-15 skip
+    // the phase: mpb_stomp_noise.h, stomp_noise_bf16_pair)
+#ifdef FUSED_NO_PAIR   // (A/B builds)
+    constexpr bool PAIRED = false;
+#else
+    constexpr bool PAIRED = 2 * DCH <= 16;
+#endif
+    constexpr int PAIR_STRIDE = FUSED_WAVES / 2;
     float* nt = tiles + wave * (H * NT_STRIDE);
-    {
+    if constexpr (PAIRED) {
+        if (wave < PAIR_STRIDE) {
+            f32x4 acc[4];
+            stomp_noise_bf16_pair<DCH>(Limg, acc, eps, P, S, p, j, g, particle_offset + (uint32_t)p, (uint32_t)s, (uint32_t)(s + PAIR_STRIDE),
+                                       iter0, seed_lo, seed_hi);
+            stomp_noise_to_tile_pair<DCH>(nt, nt + PAIR_STRIDE * (H * NT_STRIDE), acc, lane);
+        }
+    } else {
         f32x4 acc[4];
         stomp_noise_bf16<DCH>(Limg, acc, eps ? eps + (size_t)(live ? s : 0) * DCH * P * H : nullptr, P, p, j, g,
                               particle_offset + (uint32_t)p, (uint32_t)s, iter0, seed_lo, seed_hi);
@@ -235,15 +256,15 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
             for (const float* gp = geom;;) {
                 if (gp != geom) {     // a chained field: its grid replaces the first one's (restored before the next iteration)
                     __syncthreads();
-                    grid_stage(G, gridw, otab, tid, FUSED_THREADS);
+                    grid_stage_offsets(G, gridw, otab, tid, FUSED_THREADS);
                     __syncthreads();
                 }
                 if (live && h >= 1) {
                     if (MODEL == PandaModel::ID) {
-                        if (G.model == PandaModel::ID) c = fmaf(G.fscale, waypoint_cost_grid_model<PandaModel>(G, gridw, otab, q), c);
+                        if (G.model == PandaModel::ID) c = fmaf(G.fscale, waypoint_cost_grid_model<PandaModel, true>(G, gridw, otab, q), c);
                         else bad = true;
                     } else {
-                        c = fmaf(G.fscale, waypoint_cost_grid(G, gridw, otab, q), c);
+                        c = fmaf(G.fscale, waypoint_cost_grid<true>(G, gridw, otab, q), c);
                     }
                 }
                 if (G.next == 0) break;
@@ -252,7 +273,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
             }
             if (G0.next != 0) {       // more than one field: put the first field's grid back for the next iteration
                 __syncthreads();
-                grid_stage(G0, gridw, otab, tid, FUSED_THREADS);
+                grid_stage_offsets(G0, gridw, otab, tid, FUSED_THREADS);
             }
             const double csum = wave_sum_f64((double)c);
             const float cw = weight * (k_sigma * (float)csum);
@@ -328,16 +349,28 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
 #ifndef FUSED_NOISE_PRIO
 #define FUSED_NOISE_PRIO STOMP_PRIO_PROGRESS
 #endif
-            stomp_noise_bf16<DCH, FUSED_NOISE_PRIO>(Limg, acc, eps ? eps + (size_t)it_n * eps_stride + (size_t)(s_n < S ? s_n : 0) * DCH * P * H : nullptr,
-                                                    P, p, jv, gv, particle_offset + (uint32_t)p, (uint32_t)s_n, iter0 + (uint32_t)it_n,
-                                                    slo, shi, 3 - (wave >> 2));
             // (the tile addresses of the write below from an opaque copy of the lane: hoisted out of the loop they are four VGPRs
             // the cost phase does not have)
             int lane_w = lane;
             asm volatile("" : "+v"(lane_w));
-            stomp_noise_to_tile(nt, acc, lane_w);         // (the samples packed in the tile were consumed before barrier 2)
+            if constexpr (PAIRED) {
+                if (wave < PAIR_STRIDE) {
+                    stomp_noise_bf16_pair<DCH, FUSED_NOISE_PRIO>(Limg, acc, eps ? eps + (size_t)it_n * eps_stride : nullptr, P, S, p, jv, gv,
+                                                                 particle_offset + (uint32_t)p, (uint32_t)s_n, (uint32_t)(s_n + PAIR_STRIDE),
+                                                                 iter0 + (uint32_t)it_n, slo, shi, 3 - (wave >> 1));
+                    // (the partner's tile: its samples were consumed before barrier 2 like this wave's own)
+                    stomp_noise_to_tile_pair<DCH>(nt, nt + PAIR_STRIDE * (H * NT_STRIDE), acc, lane_w);
+                }
+            } else {
+                stomp_noise_bf16<DCH, FUSED_NOISE_PRIO>(Limg, acc, eps ? eps + (size_t)it_n * eps_stride + (size_t)(s_n < S ? s_n : 0) * DCH * P * H : nullptr,
+                                                        P, p, jv, gv, particle_offset + (uint32_t)p, (uint32_t)s_n, iter0 + (uint32_t)it_n,
+                                                        slo, shi, 3 - (wave >> 2));
+                stomp_noise_to_tile(nt, acc, lane_w);         // (the samples packed in the tile were consumed before barrier 2)
+            }
             if (FUSED_NOISE_PRIO == STOMP_PRIO_STAGGER) __builtin_amdgcn_s_setprio(0);
         }
+        // (paired draw, a batch to go: the next batch reads tiles another wave has just written)
+        if (PAIRED && more_batches) __syncthreads();
         }   // batches
         float m_all = mb, z_all = zb, f_own = 1.f, f_own0 = 1.f;
         const unsigned tag = tag0 + (unsigned)it;

@@ -230,6 +230,71 @@ __device__ __forceinline__ void stomp_noise_bf16(const unsigned* __restrict__ im
     if (PRIO == STOMP_PRIO_PROGRESS && eps_s == nullptr) stomp_setprio(0);
 }
 
+// TWO rollouts per product (2 DCH <= 16; round 4): the matrix instruction has 16 operand columns and a rollout fills DCH of them --
+// at DCH = 7 the draws above run on 28 of the wave's 64 lanes.  Here column j < DCH is channel j of sample s0, column
+// DCH <= j < 2 DCH channel j - DCH of sample s1: one wave draws and multiplies for two rollouts on 56 lanes, its partner wave
+// skips the phase -- half the wave-instructions of the Philox / Box-Muller / split / matrix work per workgroup.  The counter
+// words of a draw are the rollout's own (sample, channel, k-group), and a column of the product does not see the other
+// columns: the samples are bit for bit those of stomp_noise_bf16.  eps_it: the pre-drawn normals of this iteration ((S, d, P,
+// H), or nullptr), S their sample count (a sample index beyond it reads sample 0: never stored).
+template <int DCH>
+struct StompPairLane { int jj; uint32_t ss; bool act; };
+template <int DCH>
+__device__ __forceinline__ StompPairLane<DCH> stomp_pair_lane(int j, uint32_t s0, uint32_t s1) {
+    static_assert(2 * DCH <= 16, "two rollouts must fit the 16 operand columns");
+    const bool second = j >= DCH;
+    return StompPairLane<DCH>{second ? j - DCH : j, second ? s1 : s0, j < 2 * DCH};
+}
+template <int DCH, int KB, int PRIO>
+__device__ __forceinline__ void stomp_eps8_pair(float (&v)[8], uint32_t (&carry)[2], const float* __restrict__ eps_it, int P, int S, int p,
+                                                const StompPairLane<DCH>& pl, int g, uint32_t p_global, uint32_t iter, uint32_t seed_lo,
+                                                uint32_t seed_hi) {
+    constexpr int H = 64;
+    if (eps_it != nullptr) {
+        const size_t sa = pl.ss < (uint32_t)S ? pl.ss : 0u;
+        const f32x4* ep = reinterpret_cast<const f32x4*>(eps_it + ((sa * DCH + (size_t)pl.jj) * P + p) * H + 32 * KB + 8 * g);
+        const f32x4 a = pl.act ? ep[0] : f32x4{0.f, 0.f, 0.f, 0.f}, b = pl.act ? ep[1] : f32x4{0.f, 0.f, 0.f, 0.f};
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = 0.f;
+        if (pl.act) {
+            if (KB == 0) stomp_normals_lo<PRIO>(p_global, pl.ss, (uint32_t)pl.jj, (uint32_t)g, 0u, iter, seed_lo, seed_hi, v, carry);
+            else stomp_normals_hi<PRIO>(p_global, pl.ss, (uint32_t)pl.jj, (uint32_t)g, 0u, iter, seed_lo, seed_hi, carry, v);
+        }
+    }
+}
+template <int DCH, int PRIO = STOMP_PRIO_NONE>
+__device__ __forceinline__ void stomp_noise_bf16_pair(const unsigned* __restrict__ img, f32x4 (&acc)[4], const float* __restrict__ eps_it,
+                                                      int P, int S, int p, int j, int g, uint32_t p_global, uint32_t s0, uint32_t s1,
+                                                      uint32_t iter, uint32_t seed_lo, uint32_t seed_hi, int level = 0) {
+    if (PRIO == STOMP_PRIO_STAGGER && eps_it == nullptr) stomp_setprio(level);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const StompPairLane<DCH> pl = stomp_pair_lane<DCH>(j, s0, s1);
+    float v[8];
+    uint32_t carry[2] = {0u, 0u};
+    StompEps8 b;
+    stomp_eps8_pair<DCH, 0, PRIO>(v, carry, eps_it, P, S, p, pl, g, p_global, iter, seed_lo, seed_hi);
+    stomp_split8(v, b);
+    stomp_noise_product_kb<0>(img, b, j, g, acc);
+    stomp_eps8_pair<DCH, 1, PRIO>(v, carry, eps_it, P, S, p, pl, g, p_global, iter, seed_lo, seed_hi);
+    stomp_split8(v, b);
+    stomp_noise_product_kb<1>(img, b, j, g, acc);
+    if (PRIO == STOMP_PRIO_PROGRESS && eps_it == nullptr) stomp_setprio(0);
+}
+// the D tiles of a paired product -> the two rollouts' LDS tiles (nt0: columns j < DCH, nt1: DCH <= j < 2 DCH; the columns
+// beyond carry zeros into nt1's padding channels)
+template <int DCH>
+__device__ __forceinline__ void stomp_noise_to_tile_pair(float* __restrict__ nt0, float* __restrict__ nt1, const f32x4 (&acc)[4], int lane) {
+    const int j = lane & 15, g = lane >> 4;
+    float* nt = (j >= DCH) ? nt1 + (j - DCH) : nt0 + j;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) nt[(16 * m + 4 * g + rr) * NT_STRIDE] = acc[m][rr];
+}
+
 // D tiles (lane = channel) -> the wave's LDS tile [waypoint][channel] (stomp_noise_to_tile), read back as this lane's waypoint row
 // (stomp_noise_row; lane = waypoint).  Written and read by the SAME wave (LDS operations of a wave complete in order: no barrier).
 __device__ __forceinline__ void stomp_noise_to_tile(float* __restrict__ nt, const f32x4 (&acc)[4], int lane) {
