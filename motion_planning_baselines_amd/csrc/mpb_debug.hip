@@ -37,6 +37,11 @@ extern "C" int mpb_debug_philox(const uint32_t* ctr, const uint32_t* key, uint32
 
 // one thread per (iteration, particle, sample, channel j, k-group g): the sixteen normals of that lane of the STOMP kernels
 // (stomp_normals_lo / _hi, mpb_stomp_noise.h: three Philox calls), eps[j][k = stomp_eps_column(g, u >> 2, u & 3)], u = 0..15
+#ifdef MPB_DEBUG_RAW_NORMALS
+#define DBGQ(x) (x)
+#else
+#define DBGQ(x) stomp_eps_quantise(x)
+#endif
 __global__ void debug_stomp_normals_kernel(float* __restrict__ out, int P, int S, int d, int n_iters, uint32_t seed_lo,
                                            uint32_t seed_hi, uint32_t iter0, uint32_t particle_offset) {
     const size_t n = (size_t)n_iters * P * S * d * 4;
@@ -55,8 +60,9 @@ __global__ void debug_stomp_normals_kernel(float* __restrict__ out, int P, int S
     float* o = out + ((((size_t)it * P + p) * S + s) * d + j) * 64;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-        o[stomp_eps_column((int)g, u >> 2, u & 3)] = lo[u];
-        o[stomp_eps_column((int)g, 2 + (u >> 2), u & 3)] = hi[u];
+        // (as they enter the product: the two leading bf16 components, mpb_stomp_noise.h)
+        o[stomp_eps_column((int)g, u >> 2, u & 3)] = DBGQ(lo[u]);
+        o[stomp_eps_column((int)g, 2 + (u >> 2), u & 3)] = DBGQ(hi[u]);
     }
 }
 

@@ -333,10 +333,8 @@ __global__ __launch_bounds__(64 * MPB_A_WPB, 16 / MPB_A_WPB) void stomp_sample_c
     for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
     {
         StompEps8 b;
-        stomp_split8(ev[0], b);
-        stomp_noise_product_kb<0>(Limg, b, j, g, acc);
-        stomp_split8(ev[1], b);
-        stomp_noise_product_kb<1>(Limg, b, j, g, acc);
+        stomp_split_product<0>(Limg, ev[0], b, eps_s != nullptr, j, g, acc);
+        stomp_split_product<1>(Limg, ev[1], b, eps_s != nullptr, j, g, acc);
     }
     MPB_STAMP(3);
     __syncthreads();  // every wave has read its A operands: the L image is dead, its space becomes the wave tiles
@@ -487,7 +485,8 @@ __global__ __launch_bounds__(256) void stomp_sample_cost_hx_kernel(
                                                               (uint32_t)(kc << 4), iter, seed_lo, seed_hi, carry, v);
                     }
                 }
-                stomp_split8(v, sp[kb]);
+                if (eps != nullptr) stomp_split8<true>(v, sp[kb]);
+                else stomp_split8<false>(v, sp[kb]);           // (drawn normals: two components, mpb_stomp_noise.h)
             }
 #pragma unroll
             for (int hc = kc; hc < M; ++hc) {
@@ -504,12 +503,20 @@ __global__ __launch_bounds__(256) void stomp_sample_cost_hx_kernel(
                         else stomp_l_image_store<true>(Limg, row, col0, lv);
                     }
                     __syncthreads();
-                    if (hc == kc) {
-                        stomp_noise_product_kb<0, false>(Limg, sp[0], j, g, acc[hc]);
-                        stomp_noise_product_kb<1, false>(Limg, sp[1], j, g, acc[hc]);
+                    if (eps != nullptr) {
+                        if (hc == kc) {
+                            stomp_noise_product_kb<0, false>(Limg, sp[0], j, g, acc[hc]);
+                            stomp_noise_product_kb<1, false>(Limg, sp[1], j, g, acc[hc]);
+                        } else {
+                            stomp_noise_product_kb<0, true>(Limg, sp[0], j, g, acc[hc]);
+                            stomp_noise_product_kb<1, true>(Limg, sp[1], j, g, acc[hc]);
+                        }
+                    } else if (hc == kc) {
+                        stomp_noise_product_kb<0, false, false, false>(Limg, sp[0], j, g, acc[hc]);
+                        stomp_noise_product_kb<1, false, false, false>(Limg, sp[1], j, g, acc[hc]);
                     } else {
-                        stomp_noise_product_kb<0, true>(Limg, sp[0], j, g, acc[hc]);
-                        stomp_noise_product_kb<1, true>(Limg, sp[1], j, g, acc[hc]);
+                        stomp_noise_product_kb<0, true, false, false>(Limg, sp[0], j, g, acc[hc]);
+                        stomp_noise_product_kb<1, true, false, false>(Limg, sp[1], j, g, acc[hc]);
                     }
                 }
             }

@@ -273,7 +273,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
             }
             if (G0.next != 0) {       // more than one field: put the first field's grid back for the next iteration
                 __syncthreads();
-                grid_stage_offsets(G0, gridw, otab, tid, FUSED_THREADS);
+                // (from an opaque copy of the thread index: the per-thread source addresses of this rare path are loop invariants
+                // the compiler would otherwise carry -- spill -- through every iteration)
+                int tid_o = tid;
+                asm volatile("" : "+v"(tid_o));
+                grid_stage_offsets(G0, gridw, otab, tid_o, FUSED_THREADS);
             }
             const double csum = wave_sum_f64((double)c);
             const float cw = weight * (k_sigma * (float)csum);
@@ -391,6 +395,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
             float mk[FUSED_MAX_CHUNKS], zk[FUSED_MAX_CHUNKS], dk[FUSED_MAX_CHUNKS];
             const granule_t* slot0 = xch + ((size_t)(it & 1) * P * nc + (size_t)p * nc) * FUSED_XCHG;
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            // (measured and dropped, round 4: the first attempt's loads issued inside the noise phase, ahead of their use: the
+            // twelve registers they hold there cost more than the round trip they hide -- 13.2 -> 13.4 us per iteration)
             for (;;) {
                 bool ok = true;
 #pragma unroll

@@ -197,12 +197,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
             float eh[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) eh[u] = e[u];
-            stomp_split8(eh, sp);
-            stomp_noise_product_kb<0, full, true>(img, sp, j, g, acc);
+            stomp_split_product<0, full, true>(img, eh, sp, eps != nullptr, j, g, acc);
 #pragma unroll
             for (int u = 0; u < 8; ++u) eh[u] = e[8 + u];
-            stomp_split8(eh, sp);
-            stomp_noise_product_kb<1, full, true>(img, sp, j, g, acc);
+            stomp_split_product<1, full, true>(img, eh, sp, eps != nullptr, j, g, acc);
         };
         using B0 = std::integral_constant<int, 0>;
         using B1 = std::integral_constant<int, 1>;

@@ -13,25 +13,33 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define NT_STRIDE 20  // floats per waypoint row of a wave's noise tile: 80 B keeps ds_read_b128 conflict-free
 
 // Standard normals of a lane for one 64-column chunk: SIXTEEN per (particle, sample, channel j, k-group g), from THREE
-// Philox4x32-7 calls (round 4; rounds 1-3 spent a call per four normals and used 24 of every 32 bits): the twelve words are
-// cut into sixteen 24-bit fields f_0 .. f_15 (word triple (a, b, c) -> a >> 8, a[7:0] b[31:16], b[15:0] c[31:24], c[23:0]),
-// Box-Muller takes them in pairs (f_2i -> radius, f_2i+1 -> angle), normal u is eps[j][column] with the column the caller's
+// Philox4x32-7 calls (round 4; rounds 1-3 spent a call per four normals): the twelve words are cut into sixteen 23-bit
+// fields, each dropped straight into the mantissa of a float in [1, 2) -- word triple (a, b, c) -> a[31:9], a[8:0] b[31:18],
+// b[17:0] c[31:27], c[22:0]; one v_alignbit or v_and_or per field, no integer-to-float conversion, no scaling --, and
+// Box-Muller takes them in pairs (m_2i -> radius: u = 2 - m in (0, 1], exact; m_2i+1 -> angle: v_sin / v_cos count in
+// revolutions and have period 1, so m itself is the argument).  Normal u is eps[j][column] with the column the caller's
 // (H = 64 paths: stomp_eps_column(g, u >> 2, u & 3) = 32 (u >> 3) + 8 g + (u & 7); the chunked paths add 64 kc).  The counter
 // holds the GLOBAL particle id (the noise does not depend on the sharding nor on which kernel draws it), word 2 = (j << 16) |
 // (g << 8) | call with call = (kc << 4) | {0, 1, 2}.  The draw comes in two halves so that the matrix product of the first
 // column block runs between them: normals 0-7 need words 0-5 (calls 0, 1; words 6, 7 are carried), normals 8-15 words 6-11.
-__device__ __forceinline__ void box_muller24(uint32_t f1, uint32_t f2, float& n0, float& n1) {
-    const float u1 = (f1 + 1u) * (1.0f / 16777216.0f);  // (0,1]
-    const float u2 = f2 * (1.0f / 16777216.0f);         // [0,1)
-    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __log2f(u1));   // raw v_sqrt_f32 / v_log_f32, as box_muller
-    n0 = r * __builtin_amdgcn_cosf(u2);
-    n1 = r * __builtin_amdgcn_sinf(u2);
+// What enters the product is the normal cut to SIXTEEN significant bits (its two leading bf16 components, below): a drawn
+// normal is DEFINED as that value (stomp_eps_quantise; mpb_debug_stomp_normals returns it).
+__device__ __forceinline__ void box_muller23(uint32_t m1, uint32_t m2, float& n0, float& n1) {
+    // (no contraction: the normal is the ROUNDED product r * cos -- the split below subtracts from it, and fma(r, cos, -h) is not
+    // (r * cos) - h; the compiler did fuse the two in one of the kernels that draw this stream and not in the others)
+#pragma clang fp contract(off)
+    const float u1 = 2.0f - __uint_as_float(m1);                                  // (0, 1], exact (Sterbenz)
+    const float ang = __uint_as_float(m2);                                        // revolutions, [1, 2)
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // raw v_sqrt_f32 / v_log_f32 (log2)
+    n0 = r * __builtin_amdgcn_cosf(ang);
+    n1 = r * __builtin_amdgcn_sinf(ang);
 }
 __device__ __forceinline__ void stomp_fields4(uint32_t a, uint32_t b, uint32_t c, float (&n)[4]) {
-    const uint32_t f0 = a >> 8, f1 = __builtin_amdgcn_alignbit(a, b, 16) & 0xFFFFFFu, f2 = __builtin_amdgcn_alignbit(b, c, 24) & 0xFFFFFFu,
-                   f3 = c & 0xFFFFFFu;
-    box_muller24(f0, f1, n[0], n[1]);
-    box_muller24(f2, f3, n[2], n[3]);
+    constexpr uint32_t ONE = 0x3F800000u, MANT = 0x007FFFFFu;
+    const uint32_t f0 = __builtin_amdgcn_alignbit(0x7Fu, a, 9), f1 = (__builtin_amdgcn_alignbit(a, b, 18) & MANT) | ONE,
+                   f2 = (__builtin_amdgcn_alignbit(b, c, 27) & MANT) | ONE, f3 = (c & MANT) | ONE;
+    box_muller23(f0, f1, n[0], n[1]);
+    box_muller23(f2, f3, n[2], n[3]);
 }
 #define STOMP_PRIO_NONE 0
 #define STOMP_PRIO_PROGRESS 1
@@ -113,6 +121,7 @@ __device__ __forceinline__ constexpr int stomp_limg_tile(int m, int kb) { return
 
 // x = h + m + l exactly, each a bf16 value held in the top half of an fp32 word (truncation split)
 __device__ __forceinline__ void stomp_split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+#pragma clang fp contract(off)
     h = __float_as_uint(x);
     const float r1 = x - __uint_as_float(h & 0xFFFF0000u);
     m = __float_as_uint(r1);
@@ -140,18 +149,37 @@ __device__ __forceinline__ void stomp_l_image_store(unsigned* __restrict__ img, 
     *reinterpret_cast<uint2*>(img + 2 * CW + w) = make_uint2(stomp_pack_top(l[0], l[1]), stomp_pack_top(l[2], l[3]));
 }
 
-// the eight values v[e] = eps[c][32 kb + 8 g + e] of a lane as the three bf16 operand components
+// the eight values v[e] = eps[c][32 kb + 8 g + e] of a lane as the three bf16 operand components.  LOW = false (drawn
+// normals): only the two leading components -- the value that enters the product is v cut to 16 significant bits, which IS the
+// drawn normal by definition (stomp_eps_quantise); 6 instead of 13 vector instructions per pair of values and one matrix
+// instruction less per tile.  Injected normals (LOW = true) are arbitrary fp32 values and keep all three.
 struct StompEps8 { u32x4 h, m, l; };
+template <bool LOW = true>
 __device__ __forceinline__ void stomp_split8(const float (&v)[8], StompEps8& b) {
+#pragma clang fp contract(off)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        unsigned h0, m0, l0, h1, m1, l1;
-        stomp_split3(v[2 * q], h0, m0, l0);
-        stomp_split3(v[2 * q + 1], h1, m1, l1);
-        b.h[q] = stomp_pack_top(h0, h1);
-        b.m[q] = stomp_pack_top(m0, m1);
-        b.l[q] = stomp_pack_top(l0, l1);
+        if (LOW) {
+            unsigned h0, m0, l0, h1, m1, l1;
+            stomp_split3(v[2 * q], h0, m0, l0);
+            stomp_split3(v[2 * q + 1], h1, m1, l1);
+            b.h[q] = stomp_pack_top(h0, h1);
+            b.m[q] = stomp_pack_top(m0, m1);
+            b.l[q] = stomp_pack_top(l0, l1);
+        } else {
+            const unsigned h0 = __float_as_uint(v[2 * q]), h1 = __float_as_uint(v[2 * q + 1]);
+            const float r0 = v[2 * q] - __uint_as_float(h0 & 0xFFFF0000u), r1 = v[2 * q + 1] - __uint_as_float(h1 & 0xFFFF0000u);
+            b.h[q] = stomp_pack_top(h0, h1);
+            b.m[q] = stomp_pack_top(__float_as_uint(r0), __float_as_uint(r1));
+            b.l[q] = 0u;
+        }
     }
+}
+// a drawn normal as it enters the product: its two leading bf16 components
+__device__ __forceinline__ float stomp_eps_quantise(float x) {
+#pragma clang fp contract(off)
+    const float h = __uint_as_float(__float_as_uint(x) & 0xFFFF0000u);
+    return h + __uint_as_float(__float_as_uint(x - h) & 0xFFFF0000u);
 }
 
 // column of a 64-column chunk that normal u = 4 q4 + r of lane group g lands on (stomp_normals_lo / _hi): 32 (u >> 3) + 8 g + (u & 7)
@@ -159,10 +187,10 @@ __device__ __forceinline__ constexpr int stomp_eps_column(int g, int q4, int r) 
 
 // acc[m] += rows 16 m .. 16 m + 15 of (column block KB of the 64 x 64 block behind `img`) * eps, for the row tiles the
 // column block reaches (diagonal block: KB = 0 all four, KB = 1 m = 2, 3; full block: all four).  Small component pairs
-// first.  TRANSPOSED: the product is issued as eps * L^T -- lane (j, g) then holds D[channel 4 g + rr][waypoint 16 m + j]
+// first; LOW = false: eps has no third component (drawn normals, stomp_split8<false>).  TRANSPOSED: the product is issued as eps * L^T -- lane (j, g) then holds D[channel 4 g + rr][waypoint 16 m + j]
 // (the generalised persistent kernel transposes by lane permutes instead of an LDS round trip); operand registers are
 // the same either way.
-template <int KB, bool FULL = false, bool TRANSPOSED = false>
+template <int KB, bool FULL = false, bool TRANSPOSED = false, bool LOW = true>
 __device__ __forceinline__ void stomp_noise_product_kb(const unsigned* __restrict__ img, const StompEps8& b, int j, int g, f32x4 (&acc)[4]) {
     const u32x4* img4 = reinterpret_cast<const u32x4*>(img);
     constexpr int CQ = (FULL ? 8 : STOMP_LIMG_TILES) * 4 * 16;       // 16-byte entries per component
@@ -175,14 +203,14 @@ __device__ __forceinline__ void stomp_noise_product_kb(const unsigned* __restric
         if (!TRANSPOSED) {
             acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, acc[m], 0, 0, 0);
             acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[m], 0, 0, 0);
+            if (LOW) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[m], 0, 0, 0);
             acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, acc[m], 0, 0, 0);
             acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, acc[m], 0, 0, 0);
             acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[m], 0, 0, 0);
         } else {
             acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, am, acc[m], 0, 0, 0);
             acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al, acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah, acc[m], 0, 0, 0);
+            if (LOW) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah, acc[m], 0, 0, 0);
             acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, am, acc[m], 0, 0, 0);
             acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, ah, acc[m], 0, 0, 0);
             acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah, acc[m], 0, 0, 0);
@@ -210,6 +238,19 @@ __device__ __forceinline__ void stomp_eps8(float (&v)[8], uint32_t (&carry)[2], 
     }
 }
 
+// split + multiply one column block: injected values (wave-uniform `injected`) with all three components, drawn ones with two
+template <int KB, bool FULL = false, bool TRANSPOSED = false>
+__device__ __forceinline__ void stomp_split_product(const unsigned* __restrict__ img, const float (&v)[8], StompEps8& b, bool injected,
+                                                    int j, int g, f32x4 (&acc)[4]) {
+    if (injected) {
+        stomp_split8<true>(v, b);
+        stomp_noise_product_kb<KB, FULL, TRANSPOSED, true>(img, b, j, g, acc);
+    } else {
+        stomp_split8<false>(v, b);
+        stomp_noise_product_kb<KB, FULL, TRANSPOSED, false>(img, b, j, g, acc);
+    }
+}
+
 // acc[m] = rows 16 m .. 16 m + 15 of L * eps for the wave's rollout: draw / load, split and multiply, column block by column block
 template <int DCH, int PRIO = STOMP_PRIO_NONE>
 __device__ __forceinline__ void stomp_noise_bf16(const unsigned* __restrict__ img, f32x4 (&acc)[4], const float* __restrict__ eps_s,
@@ -222,11 +263,9 @@ __device__ __forceinline__ void stomp_noise_bf16(const unsigned* __restrict__ im
     uint32_t carry[2] = {0u, 0u};
     StompEps8 b;
     stomp_eps8<DCH, 0, PRIO>(v, carry, eps_s, P, p, j, g, p_global, s, iter, seed_lo, seed_hi);
-    stomp_split8(v, b);
-    stomp_noise_product_kb<0>(img, b, j, g, acc);
+    stomp_split_product<0>(img, v, b, eps_s != nullptr, j, g, acc);
     stomp_eps8<DCH, 1, PRIO>(v, carry, eps_s, P, p, j, g, p_global, s, iter, seed_lo, seed_hi);
-    stomp_split8(v, b);
-    stomp_noise_product_kb<1>(img, b, j, g, acc);
+    stomp_split_product<1>(img, v, b, eps_s != nullptr, j, g, acc);
     if (PRIO == STOMP_PRIO_PROGRESS && eps_s == nullptr) stomp_setprio(0);
 }
 
@@ -276,11 +315,9 @@ __device__ __forceinline__ void stomp_noise_bf16_pair(const unsigned* __restrict
     uint32_t carry[2] = {0u, 0u};
     StompEps8 b;
     stomp_eps8_pair<DCH, 0, PRIO>(v, carry, eps_it, P, S, p, pl, g, p_global, iter, seed_lo, seed_hi);
-    stomp_split8(v, b);
-    stomp_noise_product_kb<0>(img, b, j, g, acc);
+    stomp_split_product<0>(img, v, b, eps_it != nullptr, j, g, acc);
     stomp_eps8_pair<DCH, 1, PRIO>(v, carry, eps_it, P, S, p, pl, g, p_global, iter, seed_lo, seed_hi);
-    stomp_split8(v, b);
-    stomp_noise_product_kb<1>(img, b, j, g, acc);
+    stomp_split_product<1>(img, v, b, eps_it != nullptr, j, g, acc);
     if (PRIO == STOMP_PRIO_PROGRESS && eps_it == nullptr) stomp_setprio(0);
 }
 // the D tiles of a paired product -> the two rollouts' LDS tiles (nt0: columns j < DCH, nt1: DCH <= j < 2 DCH; the columns
