@@ -124,7 +124,7 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
             float* tail = matrix ? M.E + (size_t)c * Spad * MPPI_E_STRIDE : (tril_in_lds ? M.trilT + (size_t)c * T * T : M.trilT);
             M.gridw = reinterpret_cast<unsigned*>(lds + (((tail - lds) + 3) & ~(ptrdiff_t)3));
             M.otab = reinterpret_cast<float4*>(M.gridw + ((grid_words + 3) & ~3));
-            grid_stage(G0, M.gridw, M.otab, threadIdx.x, blockDim.x);
+            grid_stage_offsets(G0, M.gridw, M.otab, threadIdx.x, blockDim.x);     // (offset words: mpb_geom.h)
         }
     }
     const int prob = blockIdx.x;
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
                             if (use_grid) {      // the point branch of waypoint_cost_grid (mpb_geom.h), same expressions
                                 const float px[1] = {q[0]}, py[1] = {q[1]}, pz[1] = {(G0.n_dof > 2) ? q[2] : 0.f}, rl[1] = {G0.links[4]};
                                 float cg = 0.f;
-                                spheres_hinge_grid<1>(G0, M.gridw, M.otab, px, py, pz, rl, cg);
+                                spheres_hinge_grid<1, true>(G0, M.gridw, M.otab, px, py, pz, rl, cg);
                                 coll_l += G0.fscale * cg;
                             } else {
                                 coll_l += __uint_as_float(0x7FC00000u);

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
 
     // ---- constants into LDS (once): the broad-phase grid + obstacle table, the blocks of L as permuted MFMA images
     GeomView G0 = geom_view(geom);
-    grid_stage(G0, gridw, otab, tid, FUSED_THREADS);
+    grid_stage_offsets(G0, gridw, otab, tid, FUSED_THREADS);      // (as offset words: mpb_geom.h, grid_offset_word)
 #pragma unroll
     for (int b = 0; b < NLB; ++b) {
         const int hc = (b == 0) ? 0 : 1, kc = (b == 2) ? 1 : 0;
@@ -312,15 +312,15 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
                 for (const float* gp = geom;;) {
                     if (gp != geom) {     // a chained field: its grid replaces the first one's (restored before the next pass)
                         __syncthreads();
-                        grid_stage(G, gridw, otab, tid, FUSED_THREADS);
+                        grid_stage_offsets(G, gridw, otab, tid, FUSED_THREADS);
                         __syncthreads();
                     }
                     if (live && on && h >= 1) {
                         if (MODEL == PandaModel::ID) {
-                            if (G.model == PandaModel::ID) c = fmaf(G.fscale, waypoint_cost_grid_model<PandaModel>(G, gridw, otab, q), c);
+                            if (G.model == PandaModel::ID) c = fmaf(G.fscale, waypoint_cost_grid_model<PandaModel, true>(G, gridw, otab, q), c);
                             else bad = true;
                         } else {
-                            c = fmaf(G.fscale, waypoint_cost_grid(G, gridw, otab, q), c);
+                            c = fmaf(G.fscale, waypoint_cost_grid<true>(G, gridw, otab, q), c);
                         }
                     }
                     if (G.next == 0) break;
@@ -329,7 +329,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
                 }
                 if (G0.next != 0) {
                     __syncthreads();
-                    grid_stage(G0, gridw, otab, tid, FUSED_THREADS);
+                    int tid_o = tid;                         // (opaque: this rare path's source addresses must not be hoisted)
+                    asm volatile("" : "+v"(tid_o));
+                    grid_stage_offsets(G0, gridw, otab, tid_o, FUSED_THREADS);
                 }
                 const double csum = wave_sum_f64((double)c);
                 if (lane == 0) cst[wave] = bad ? __uint_as_float(0x7FC00000u) : (float)csum;
