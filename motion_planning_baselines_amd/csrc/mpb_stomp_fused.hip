@@ -204,9 +204,29 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
     const int n_run = s_abort ? 0 : n_iters;          // (block-uniform: written before the barriers above)
     for (int it = 0; it < n_run; ++it) {
         // (NB > 1) partials of the batches, as the exchange path would publish them
-        float pm0 = -3.0e38f, pz0 = 0.f, pd0 = 0.f, pe0 = 0.f, pm1 = -3.0e38f, pz1 = 0.f, pd1 = 0.f, pe1 = 0.f;
+        float pm0 = -3.0e38f, pz0 = 0.f, pe0 = 0.f, pm1 = -3.0e38f, pz1 = 0.f, pe1 = 0.f;
+        f32x4 sd0 = {0.f, 0.f, 0.f, 0.f}, sd1 = {0.f, 0.f, 0.f, 0.f};      // Sigma times the partial of batch 0 / 1 (or of the only chunk), waves 0-3
         float mb = 0.f, zb = 0.f, ex = 0.f, dpart = 0.f;
         int tq = 0, hh = 0, cc = 0, sl = 0;
+        // Sigma (64 x 64) times a (64 x d) tile held transposed in `delta`, on the matrix pipe: waves 0-3 (one per SIMD) own 16
+        // rows each; the k index of a lane is 16 (lane >> 4) + 4 q + e, so that both operands are read as four 16-byte pieces
+        // per lane -- every word of Sigma and delta leaves LDS once per workgroup (the per-element form read a whole row and a
+        // whole column per thread: 458 KB of LDS traffic per iteration, 2.3 us of a 16.8 us iteration by duplication).
+        // Returns acc[r] = row 16 wave + 4 lg + r, channel li (lanes li >= DCH: zeros).
+        auto sigma_times_delta = [&](int li, int lg) {
+            const float* arow = sig_l + (16 * wave + li) * FUSED_LD + 16 * lg;
+            const float* brow = delta + (li < DCH ? li : 0) * FUSED_LD + 16 * lg;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(arow + 4 * q);
+                f32x4 bv = *reinterpret_cast<const f32x4*>(brow + 4 * q);
+                if (li >= DCH) bv = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], acc, 0, 0, 0);
+            }
+            return acc;
+        };
 #pragma nounroll
         for (int bt = 0; bt < NB; ++bt) {
         if (NB > 1) { s = bt * FUSED_WAVES + wave; live = s < S; }
@@ -259,7 +279,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
                     grid_stage_offsets(G, gridw, otab, tid, FUSED_THREADS);
                     __syncthreads();
                 }
+#ifdef FUSED_T_SKIP_COST   // (wrong-result timing switch, tuning builds only)
+                if (false) {
+#else
                 if (live && h >= 1) {
+#endif
                     if (MODEL == PandaModel::ID) {
                         if (G.model == PandaModel::ID) c = fmaf(G.fscale, waypoint_cost_grid_model<PandaModel, true>(G, gridw, otab, q), c);
                         else bad = true;
@@ -314,23 +338,49 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
             }
         }
         if (NB > 1) {            // (wave-uniform) keep this batch's partial
-            if (bt == 0) { pm0 = mb; pz0 = zb; pd0 = dpart; pe0 = ex; } else { pm1 = mb; pz1 = zb; pd1 = dpart; pe1 = ex; }
+            if (bt == 0) { pm0 = mb; pz0 = zb; pe0 = ex; } else { pm1 = mb; pz1 = zb; pe1 = ex; }
         }
         FSTAMP(4);
         const unsigned tag = tag0 + (unsigned)it;                  // unique per (call, iteration): stale granules never match
-        if (NB == 1 && nc > 1) {
-            // ============ D. publish the partial as tagged granules, then -- before reading the partners' -- the noise of
-            //              the next iteration: by then their granules have long landed
+        // ============ D. Sigma times THIS chunk's (batch's) partial, before any combining (round 4): Sigma (sum_k f_k D_k) =
+        //              sum_k f_k (Sigma D_k), so the matrix product can run per partial ahead of the exchange instead of on
+        //              the combined sum after it.  What follows the poll is then elementwise -- combine, divide, add to the
+        //              mean, one barrier -- where it used to be delta -> LDS, barrier, matrix product, barrier: the partner's
+        //              round trip no longer has an LDS round trip and a barrier queued behind it.  m and z go out first; behind
+        //              the barrier that also says "the samples in the tiles are consumed" waves 0-3 multiply -- and publish
+        //              (exchange layout) or keep (two batches / a single chunk) the product -- while the other waves start the
+        //              next iteration's noise.  All layouts combine the same products with the same expressions: same bits.
+        if (NB == 1 && nc > 1 && tq == 0) {
             granule_t* mine = xch + ((size_t)(it & 1) * P * nc + (size_t)p * nc + chunk) * FUSED_XCHG;
-            if (tq < N) st_granule(mine + 2 + tq, dpart, tag);
-            if (tq == 0) { st_granule(mine + 0, mb, tag); st_granule(mine + 1, zb, tag); }
+            st_granule(mine + 0, mb, tag);
+            st_granule(mine + 1, zb, tag);
         }
-        __syncthreads();                                                     // (2) the samples in the tiles are consumed
+        if (tq < N) delta[cc * FUSED_LD + hh] = dpart;
+        __syncthreads();                                                     // (2) the samples in the tiles are consumed, delta complete
+        if (wave < 4) {
+            const int li = tq & 15, lg = (tq >> 4) & 3;
+            const f32x4 sd = sigma_times_delta(li, lg);
+            if (NB == 1 && nc > 1) {
+                granule_t* mine = xch + ((size_t)(it & 1) * P * nc + (size_t)p * nc + chunk) * FUSED_XCHG;
+                if (li < DCH) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st_granule(mine + 2 + (16 * wave + 4 * lg + r) * DCH + li, sd[r], tag);
+                }
+            } else if (NB > 1 && bt > 0) {
+                sd1 = sd;
+            } else {
+                sd0 = sd;
+            }
+        }
         FSTAMP(5);
         const bool more_batches = NB > 1 && bt + 1 < NB;
         const int it_n = more_batches ? it : it + 1;                       // (iteration, batch) whose noise is drawn now
         const int s_n = NB > 1 ? (more_batches ? bt + 1 : 0) * FUSED_WAVES + wave : s;
+#ifdef FUSED_T_SKIP_NOISE   // (wrong-result timing switch, tuning builds only: is the draw on the iteration's critical path?)
+        if (false) {
+#else
         if (it_n < n_run) {
+#endif
             // the noise of the NEXT iteration (it does not depend on the means) is drawn here, between publishing and polling:
             // the partner's latency.  (Drawing it before barrier 1 at the lowest issue priority, to fill the wait for the
             // block's slowest rollout, was measured 15 % slower: the rollouts leave few issue slots free, and the matrix
@@ -376,18 +426,19 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         // (paired draw, a batch to go: the next batch reads tiles another wave has just written)
         if (PAIRED && more_batches) __syncthreads();
         }   // batches
-        float m_all = mb, z_all = zb, f_own = 1.f, f_own0 = 1.f;
+        float m_all = mb, z_all = zb, f_own = 1.f, f_own0 = 1.f, f_sd0 = 1.f, f_sd1 = 0.f;
         const unsigned tag = tag0 + (unsigned)it;
-        float dsum = dpart;
+        float dsum = 0.f;
         FSTAMP(6);
         if (NB > 1) {
             // the two batches combined in batch order with the expressions of the exchange path below
             m_all = fmaxf(pm0, pm1);
             const float f0 = expf(pm0 - m_all), f1 = expf(pm1 - m_all);
             z_all = fmaf(f1, pz1, fmaf(f0, pz0, 0.f));
-            dsum = fmaf(f1, pd1, fmaf(f0, pd0, 0.f));
             f_own0 = f0;
             f_own = f1;
+            f_sd0 = f0;
+            f_sd1 = f1;
         }
         if (NB == 1 && nc > 1) {
             // every thread waits for ITS granules of every chunk (its own included: the very bits the partners read) --
@@ -433,59 +484,31 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
             f_own = expf(mb - m_all);
         }
         FSTAMP(8);
-        // ============ E. weights out, delta (transposed) -> mean += lr * Sigma @ delta
+        // ============ E. weights out; mean += lr * (sum_k f_k Sigma D_k) / z
         if (NB > 1) {
             const int sl0 = tq & 15;
             if (tq < FUSED_WAVES && sl0 < S) weights[(size_t)p * S + sl0] = pe0 * f_own0 / z_all;
             if (tq < FUSED_WAVES && sl < S) weights[(size_t)p * S + sl] = pe1 * f_own / z_all;
         } else if (tq < FUSED_WAVES && sl < S) weights[(size_t)p * S + sl] = ex * f_own / z_all;
-        if (tq < N) delta[cc * FUSED_LD + hh] = dsum / z_all;
-        __syncthreads();                                                                        // (4) delta complete
-        FSTAMP(9);
-        if (s_abort) break;                                                                     // block-uniform (set before barrier 4)
-#ifdef FUSED_VALU_MATVEC
-        if (tq < N) {
-            float a4[4] = {0.f, 0.f, 0.f, 0.f};
-            const float4* dcol = reinterpret_cast<const float4*>(delta + cc * FUSED_LD);
-            const float4* srow = reinterpret_cast<const float4*>(sig_l + hh * FUSED_LD);
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const float4 dv = dcol[k], sv = srow[k];
-                a4[k & 3] = fmaf(sv.x, dv.x, a4[k & 3]);
-                a4[k & 3] = fmaf(sv.y, dv.y, a4[k & 3]);
-                a4[k & 3] = fmaf(sv.z, dv.z, a4[k & 3]);
-                a4[k & 3] = fmaf(sv.w, dv.w, a4[k & 3]);
-            }
-            mean_l[tq] += lr * ((a4[0] + a4[1]) + (a4[2] + a4[3]));
-        }
-#else
-        // Sigma (64 x 64) times delta (64 x d) on the matrix pipe: waves 0-3 (one per SIMD) own 16 rows each; the k index
-        // of a lane is 16 (lane >> 4) + 4 q + e, so that both operands are read as four 16-byte pieces per lane -- every word
-        // of Sigma and delta leaves LDS once per workgroup (the per-element form read a whole row and a whole column per
-        // thread: 458 KB of LDS traffic per iteration, 2.3 us of a 16.8 us iteration by duplication)
-        if (wave < 4) {
+        if (NB == 1 && nc > 1) {
+            if (tq < N) mean_l[tq] += lr * (dsum / z_all);
+        } else if (wave < 4) {
+            // (the products are still in the registers of waves 0-3: row 16 wave + 4 lg + r, channel li)
             const int li = tq & 15, lg = (tq >> 4) & 3;
-            const float* arow = sig_l + (16 * wave + li) * FUSED_LD + 16 * lg;
-            const float* brow = delta + (li < DCH ? li : 0) * FUSED_LD + 16 * lg;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 av = *reinterpret_cast<const f32x4*>(arow + 4 * q);
-                f32x4 bv = *reinterpret_cast<const f32x4*>(brow + 4 * q);
-                if (li >= DCH) bv = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], acc, 0, 0, 0);
-            }
-            // acc[r] = row 16 wave + 4 lg + r, channel li
             if (li < DCH) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mean_l[(16 * wave + 4 * lg + r) * DCH + li] += lr * acc[r];
+                for (int r = 0; r < 4; ++r) {
+                    float ds = fmaf(f_sd0, sd0[r], 0.f);
+                    if (NB > 1) ds = fmaf(f_sd1, sd1[r], ds);
+                    mean_l[(16 * wave + 4 * lg + r) * DCH + li] += lr * (ds / z_all);
+                }
             }
         }
-#endif
+        FSTAMP(9);
         FSTAMP(10);
         __syncthreads();                                                                        // (5) new mean visible, tiles free
         FSTAMP(11);
+        if (s_abort) break;                                                                     // block-uniform (set before barrier 5)
         if (it < 3) LSTAMP(4 + it);
     }
     const int aborted = s_abort;                        // (block-uniform: last written before a barrier every thread passed)
