@@ -447,7 +447,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
             const granule_t* slot0 = xch + ((size_t)(it & 1) * P * nc + (size_t)p * nc) * FUSED_XCHG;
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             // (measured and dropped, round 4: the first attempt's loads issued inside the noise phase, ahead of their use: the
-            // twelve registers they hold there cost more than the round trip they hide -- 13.2 -> 13.4 us per iteration)
+            // twelve registers they hold there cost more than the round trip they hide -- 13.2 -> 13.4 us per iteration; issued
+            // only just ahead of the noise tile's sixteen LDS stores they still tip 17 VGPRs of the kernel into scratch)
             for (;;) {
                 bool ok = true;
 #pragma unroll
