@@ -42,7 +42,7 @@ extern "C" {
 
 /* ABI version in the low 16 bits (MPB_ABI_VERSION: bumped whenever a signature of this header changes positionally; a
  * binding must refuse a library that reports another number); bit 30 set = a tuning build (compiled with wrong-result timing switches: never a product library) */
-#define MPB_ABI_VERSION 3
+#define MPB_ABI_VERSION 4
 #define MPB_VERSION_TUNING_BUILD 0x40000000
 int mpb_version(void);
 const char *mpb_last_error(void);
@@ -195,12 +195,13 @@ int mpb_stomp_step_profile(float *means, float *samples, float *costs, float *we
                            float k_sigma, float weight, float lr, float temperature,
                            int n_iters, uint64_t seed, uint32_t iter0, uint32_t particle_offset, void *stream,
                            float *sample_kernel_ms, float *update_kernel_ms);
+#define MPB_STOMP_WS_HEADER_BYTES 1280
 /* The same loop as ONE persistent launch (csrc/mpb_stomp_fused.hip): a workgroup of 16 waves owns (particle, chunk of 16
  * samples) for all n_iters iterations -- constants, means and the iteration's samples stay in LDS, the partners of a
  * particle (S > 16) exchange their 3.6 KB partial sums through `workspace`; no per-iteration launch ramps or dispatch
  * gaps.  Same arguments and outputs as mpb_stomp_step plus the caller-allocated workspace (mpb_stomp_workspace_bytes;
- * its first 64 bytes must be ZERO before the first call -- mpb_stomp_workspace_init -- and are maintained by the library
- * afterwards; the rest need not be initialised; one workspace serves one call at a time).  Served for H = 64, S <= 64,
+ * its header, the first MPB_STOMP_WS_HEADER_BYTES, must be ZERO before the first call -- mpb_stomp_workspace_init -- and is
+ * maintained by the library afterwards (ABI 4: 1 280 bytes, the counters the workgroups hit at start-up one cache line each; 64 before); the rest need not be initialised; one workspace serves one call at a time).  Served for H = 64, S <= 64,
  * grid-backed fields (geom_flags bit 8); any other call -- or workspace == NULL -- runs mpb_stomp_step
  * (mpb_stomp_run_path tells which, without launching).  The softmax is evaluated as exp(x - m) / z over per-chunk
  * partials, the same weights up to rounding.  When the particles are at least as many as the CUs (and 16 < S <= 32) one

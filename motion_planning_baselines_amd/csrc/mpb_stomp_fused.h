@@ -18,8 +18,13 @@
 #define FUSED_HDR_TAG 1      // tag of the last call
 #define FUSED_HDR_DONE 2     // workgroups of the running call that have left; 0 between calls
 #define FUSED_HDR_WHY 3      // why FUSED_HDR_ERR was raised: 1 = partner timed out, 2 = header not initialised
-#define FUSED_HDR_BEGIN 4    // words 4, 5 (one 8-byte word): ~(earliest start of a workgroup of the running call); 0 between calls
-#define FUSED_HDR_TICKET 8   // words 8..15: next ticket of each of the 8 unit pools of the running call; 0 between calls
+// Every workgroup hits the start stamp and a ticket pool with an atomic when it starts: in one 64-byte line (rounds 2-4) those
+// 512 read-modify-writes queued behind each other at one L2 channel -- a workgroup had its ticket 5.7 us after it entered the
+// kernel (scripts/stamps_launch.py).  The stamp and each pool now sit in a 128-byte line of their own.
+#define FUSED_HDR_BEGIN 32   // words 32, 33 (one 8-byte word): ~(earliest start of a workgroup of the running call); 0 between calls
+#define FUSED_HDR_TICKET 64  // word 64 + 32 k: next ticket of unit pool k (8 pools) of the running call; 0 between calls
+#define FUSED_HDR_POOL_STRIDE 32
+#define FUSED_HDR_WORDS 320  // the header: 1 280 bytes, zero before the first call (mpb_stomp_workspace_init)
 // unit pools: pool x owns the particles p = x (mod FUSED_POOLS); a workgroup draws from the pool of the XCD it runs on
 // first (partners then share an L2: speed only), from the next pools once that one is exhausted
 #ifndef FUSED_POOLS
@@ -62,7 +67,7 @@ __device__ __forceinline__ unsigned fused_draw_unit(unsigned* wsu, int P, int nc
         const unsigned pool = (xcc + k) % FUSED_POOLS;
         const unsigned size = ((unsigned)P + FUSED_POOLS - 1u - pool) / FUSED_POOLS * (unsigned)nc;
         if (size == 0u) continue;
-        const unsigned t = __hip_atomic_fetch_add(wsu + FUSED_HDR_TICKET + pool, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned t = __hip_atomic_fetch_add(wsu + FUSED_HDR_TICKET + FUSED_HDR_POOL_STRIDE * pool, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t < size) {
             got = true;
             u = (FUSED_POOLS * (t / (unsigned)nc) + pool) * (unsigned)nc + t % (unsigned)nc;
@@ -103,7 +108,7 @@ __device__ __forceinline__ void fused_leave(unsigned* wsu, unsigned* status_host
     const unsigned left = __hip_atomic_fetch_add(wsu + FUSED_HDR_DONE, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (left == gridDim.x - 1u && aborted != 2) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) st_agent_u(wsu + FUSED_HDR_TICKET + k, 0u);
+        for (int k = 0; k < 8; ++k) st_agent_u(wsu + FUSED_HDR_TICKET + FUSED_HDR_POOL_STRIDE * k, 0u);
         st_agent_u(wsu + FUSED_HDR_DONE, 0u);
         if (status_host) {
             unsigned long long* b64 = reinterpret_cast<unsigned long long*>(wsu + FUSED_HDR_BEGIN);

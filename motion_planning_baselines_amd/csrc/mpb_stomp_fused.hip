@@ -42,9 +42,9 @@
 #include "mpb_stomp_noise.h"
 #include "mpb_stomp_fused.h"
 
-// workspace layout: 16 floats of header ([0] = error word), then 2 parities x P x nc x FUSED_XCHG granules (8 B each):
+// workspace layout: FUSED_HDR_WORDS floats of header ([0] = error word; mpb_stomp_fused.h), then 2 parities x P x nc x FUSED_XCHG granules (8 B each):
 // granule 0 = m, 1 = z, 2 + t = partial sum of trajectory element t
-static inline size_t fused_ws_floats(int P, int nc) { return 16 + 2 * 2 * (size_t)P * nc * FUSED_XCHG; }
+static inline size_t fused_ws_floats(int P, int nc) { return FUSED_HDR_WORDS + 2 * 2 * (size_t)P * nc * FUSED_XCHG; }
 
 #ifdef MPB_STAMPS   // diagnostic build only: s_memtime per wave at the phase boundaries of iteration 2
 __device__ unsigned long long g_fstamps[256 * FUSED_WAVES * 12];
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
     }
     LSTAMP(1);
     const int j = lane & 15, g = lane >> 4;
-    granule_t* xch = reinterpret_cast<granule_t*>(ws + 16);
+    granule_t* xch = reinterpret_cast<granule_t*>(ws + FUSED_HDR_WORDS);
 
     // ---- constants into LDS (once)
     GeomView G0 = geom_view(geom);
@@ -584,7 +584,7 @@ static FusedPlan fused_plan(int geom_flags, int P, int S, int H, int d) {
     f.two_batches = f.nc == 2 && force_nb != 1 && (force_nb == 2 || 188 * r2 < 100 * r1);
     const bool exchange = f.nc > 1 && !f.two_batches;
     f.path = exchange ? MPB_STOMP_PATH_PERSISTENT_EXCHANGE : MPB_STOMP_PATH_PERSISTENT;
-    f.ws_bytes = (exchange ? fused_ws_floats(P, f.nc) : 16) * sizeof(float);
+    f.ws_bytes = (exchange ? fused_ws_floats(P, f.nc) : FUSED_HDR_WORDS) * sizeof(float);
     return f;
 }
 
@@ -593,12 +593,12 @@ extern "C" size_t mpb_stomp_workspace_bytes(int P, int S, int H, int d) {
     // what the layout the launcher will pick needs (grid-backed fields assumed; a call the persistent kernel cannot
     // serve needs none): the exchange area only when partner workgroups exchange partials, else just the header
     const FusedPlan f = fused_plan(0x100, P, S, H, d);
-    return f.path == MPB_STOMP_PATH_TWO_KERNEL ? 16 * sizeof(float) : f.ws_bytes;
+    return f.path == MPB_STOMP_PATH_TWO_KERNEL ? FUSED_HDR_WORDS * sizeof(float) : f.ws_bytes;
 }
 
 extern "C" int mpb_stomp_workspace_init(float* workspace, size_t workspace_bytes, void* stream) {
-    if (!workspace || workspace_bytes < 64) return mpb_fail(MPB_E_INVALID, "mpb_stomp_workspace_init: workspace too small");
-    if (hipMemsetAsync(workspace, 0, 64, (hipStream_t)stream) != hipSuccess) return mpb_fail(MPB_E_HIP, "mpb_stomp_workspace_init: memset failed");
+    if (!workspace || workspace_bytes < FUSED_HDR_WORDS * sizeof(float)) return mpb_fail(MPB_E_INVALID, "mpb_stomp_workspace_init: workspace too small");
+    if (hipMemsetAsync(workspace, 0, FUSED_HDR_WORDS * sizeof(float), (hipStream_t)stream) != hipSuccess) return mpb_fail(MPB_E_HIP, "mpb_stomp_workspace_init: memset failed");
     return MPB_OK;
 }
 

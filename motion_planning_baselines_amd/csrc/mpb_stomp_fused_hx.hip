@@ -30,7 +30,7 @@
 #define HX_XCHG 2064                       // granules per published partial: m, z, then H*d <= 2048 values, padded
 #define HX_MAX_NB 8
 
-static inline size_t hx_ws_floats(int P, int nc) { return 16 + 2 * 2 * (size_t)P * nc * HX_XCHG; }
+static inline size_t hx_ws_floats(int P, int nc) { return FUSED_HDR_WORDS + 2 * 2 * (size_t)P * nc * HX_XCHG; }
 
 // acc[n] (lane (j, g): D[channel 4g + rr][waypoint 16 n + j]) -> nz[c] of THIS lane's waypoint (lane = 16 g + j): a 4 x 4
 // block transpose over the four 16-lane rows, per accumulator register rr
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
     const int d = DCH ? DCH : d_rt;
     const int N = H * d;
     unsigned* wsu = reinterpret_cast<unsigned*>(ws);
-    granule_t* xch = reinterpret_cast<granule_t*>(ws + 16);
+    granule_t* xch = reinterpret_cast<granule_t*>(ws + FUSED_HDR_WORDS);
     const bool exchange = nc > 1;
     if (tid == 0) {
         s_abort = 0;
@@ -543,7 +543,7 @@ bool mpb_fused_hx_plan(int geom_flags, int n_cu, int P, int S, int H, int d, int
     }
     *nc_out = nc;
     *nb_out = nb;
-    *ws_bytes = (nc > 1 ? hx_ws_floats(P, nc) : 16) * sizeof(float);
+    *ws_bytes = (nc > 1 ? hx_ws_floats(P, nc) : FUSED_HDR_WORDS) * sizeof(float);
     return true;
 }
 

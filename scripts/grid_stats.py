@@ -64,3 +64,9 @@ def stats(cell, maxdim, per_link=False):
           f'  mean trips/group {trips.mean():.3f}  (>=2: {np.mean(trips >= 2):.2f}, >=3: {np.mean(trips >= 3):.2f}, 4+: {np.mean(trips >= 4):.2f})')
 for cell, md in ((0.14, 16), (0.11, 20)):
     stats(cell, md)
+# what a larger LDS grid would buy (MPB_GRID_MAX_CELLS is 4096 words = 16 KB): the finest cell that fits 8 192 / 16 384 words
+for mc in (8192, 16384):
+    geometry.GRID_MAX_CELLS = mc
+    print('GRID_MAX_CELLS', mc)
+    stats(0.14, 64)
+geometry.GRID_MAX_CELLS = 4096

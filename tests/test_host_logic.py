@@ -334,18 +334,18 @@ def test_geometry_model_tag_and_flags():
 def test_stomp_workspace_size():
     from motion_planning_baselines_amd import _lib
     f = _lib.lib().mpb_stomp_workspace_bytes
-    assert f(128, 32, 64, 14) == 4 * 16 + 8 * (2 * 128 * 2 * 912)          # header + 8-byte {value, tag} granules, two parities
-    assert f(3, 5, 64, 7) == 4 * 16 and f(0, 32, 64, 14) == 0              # one workgroup per particle: the header only
-    assert f(4096, 32, 64, 14) == 4 * 16                                   # at least as many particles as CUs: two batches, no exchange
-    assert f(8, 32, 48, 14) == 4 * 16 + 8 * (2 * 8 * 2 * 2064)            # H != 64: the generalised kernel's exchange slots (2 + H*d <= 2064 granules)
-    assert f(8, 32, 200, 14) == 4 * 16                                     # a shape no persistent kernel serves (H > 128)
+    assert f(128, 32, 64, 14) == 4 * 320 + 8 * (2 * 128 * 2 * 912)          # header + 8-byte {value, tag} granules, two parities
+    assert f(3, 5, 64, 7) == 4 * 320 and f(0, 32, 64, 14) == 0              # one workgroup per particle: the header only
+    assert f(4096, 32, 64, 14) == 4 * 320                                   # at least as many particles as CUs: two batches, no exchange
+    assert f(8, 32, 48, 14) == 4 * 320 + 8 * (2 * 8 * 2 * 2064)            # H != 64: the generalised kernel's exchange slots (2 + H*d <= 2064 granules)
+    assert f(8, 32, 200, 14) == 4 * 320                                     # a shape no persistent kernel serves (H > 128)
     # which path a call takes is a pure host-side function of the shape, the geometry flags and the workspace size
     path = _lib.lib().mpb_stomp_run_path
     assert path(0x100 | 1, f(128, 32, 64, 14), 128, 32, 64, 14) == 1       # exchange layout
     assert path(0x100 | 1, 64, 128, 32, 64, 14) == 0                       # workspace too small: two-kernel loop
-    assert path(0x100, 64, 4096, 32, 64, 14) == 2 and path(0x100, 64, 8, 16, 64, 7) == 2
+    assert path(0x100, 1280, 4096, 32, 64, 14) == 2 and path(0x100, 1280, 8, 16, 64, 7) == 2      # the header alone (MPB_STOMP_WS_HEADER_BYTES)
     assert path(0, 1 << 30, 128, 32, 64, 14) == 0 and path(0x100, 1 << 30, 128, 32, 200, 14) == 0
-    assert path(0x100, 1 << 30, 128, 32, 128, 14) == 1 and path(0x100, 64, 300, 32, 128, 14) == 2   # H = 128: generalised kernel
+    assert path(0x100, 1 << 30, 128, 32, 128, 14) == 1 and path(0x100, 1280, 300, 32, 128, 14) == 2   # H = 128: generalised kernel
     assert path(0x100, 1 << 30, 2, 128, 32, 7) == 1 and path(0x100, 1 << 30, 128, 32, 64, 5) == 1  # S = 128; d = 5
 
 
