@@ -27,7 +27,7 @@
 // at once; the caller (planners/stomp.py) turns that into an exception.  The last workgroup out resets the counters.
 // With at least as many particles as CUs the launcher picks the other layout of the same kernel (template NB = 2): ONE
 // workgroup per particle runs the particle's S <= 32 samples as two batches of 16 and keeps the batches' partials in
-// registers -- no exchange, six instead of ten block barriers and one update instead of two per particle and iteration
+// registers -- no exchange, five instead of six block barriers and one update instead of two per particle and iteration
 // (C5's per-GPU load: 0.531 -> 0.497 ms / iteration); the partials are combined with the expressions of the exchange
 // path, so both layouts produce the same bits (tests/test_gpu_stomp_fused.py).
 #include <hip/hip_runtime.h>
@@ -83,7 +83,7 @@ extern "C" int mpb_debug_read_lstamps(unsigned long long* dst, int n) {
 
 // NB = 1: the unit is (particle, chunk of 16 samples), partners exchange partials through the workspace (above).
 // NB = 2: one workgroup per particle runs its S <= 32 samples as two batches of 16, one after the other, and keeps the
-//         batches' partials in registers -- no exchange, six instead of ten block barriers per particle and iteration, one
+//         batches' partials in registers -- no exchange, five instead of six block barriers per particle and iteration, one
 //         update instead of two.  For loads with at least as many particles as CUs (C5); the partials are combined with
 //         the very expressions of the exchange path, so both layouts produce the same bits.
 template <int DCH, int MODEL, int NB>
