@@ -81,6 +81,21 @@ extern "C" int mpb_debug_read_lstamps(unsigned long long* dst, int n) {
 #define LSTAMP(k)
 #endif
 
+template <int DCH>
+struct FusedSmem {
+    float4 otab[MPB_GRID_MAX_SPH + 1];                       //  1 KB: obstacle table + the far dummy
+    unsigned gridw[MPB_GRID_MAX_CELLS];                      // 16 KB: broad-phase grid (offset words)
+    unsigned Limg[STOMP_LIMG_WORDS];                         // 18 KB: L as three bf16 components
+    float sig_l[64 * FUSED_LD];                              // 17 KB: Sigma, padded rows
+    float mean_l[64 * DCH];                                  // 3.5 KB
+    float delta[DCH * FUSED_LD];                             // 3.7 KB (transposed)
+    float cst[FUSED_WAVES];
+    int s_abort;
+    unsigned s_ticket;
+    unsigned pad_[2];
+    float tiles[FUSED_WAVES * 64 * NT_STRIDE];               // 80 KB: the waves' sample tiles
+};
+
 // NB = 1: the unit is (particle, chunk of 16 samples), partners exchange partials through the workspace (above).
 // NB = 2: one workgroup per particle runs its S <= 32 samples as two batches of 16, one after the other, and keeps the
 //         batches' partials in registers -- no exchange, five instead of six block barriers per particle and iteration, one
@@ -96,16 +111,21 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
     constexpr int H = 64;
     constexpr int N = H * DCH;                    // elements of a trajectory
     static_assert(N <= FUSED_THREADS && N + 2 <= FUSED_XCHG, "one thread per trajectory element");
-    __shared__ __attribute__((aligned(16))) unsigned Limg[STOMP_LIMG_WORDS];                  // 18 KB: L as three bf16 components
-    __shared__ __attribute__((aligned(16))) float tiles[FUSED_WAVES * H * NT_STRIDE];         // 80 KB
-    __shared__ __attribute__((aligned(16))) unsigned gridw[MPB_GRID_MAX_CELLS];               // 16 KB
-    __shared__ float4 otab[MPB_GRID_MAX_SPH + 1];                                             //  1 KB
-    __shared__ __attribute__((aligned(16))) float sig_l[H * FUSED_LD];                        // 17 KB
-    __shared__ __attribute__((aligned(16))) float mean_l[N];                                  // 3.5 KB
-    __shared__ __attribute__((aligned(16))) float delta[DCH * FUSED_LD];                      // 3.7 KB (transposed)
-    __shared__ float cst[FUSED_WAVES];
-    __shared__ int s_abort;
-    __shared__ unsigned s_ticket;
+    // ONE shared object with the layout fixed by hand: what the walk reads at random -- the obstacle table, the grid -- and the
+    // constants of the other phases sit in the first 64 KB, where an LDS instruction's 16-bit offset field reaches them (left
+    // to the linker the table landed at 141 536: a v_add per read to form the address, four per group of spheres and trip);
+    // the 80 KB of sample tiles come last
+    __shared__ __attribute__((aligned(16))) FusedSmem<DCH> sm;
+    float4 (&otab)[MPB_GRID_MAX_SPH + 1] = sm.otab;
+    unsigned (&gridw)[MPB_GRID_MAX_CELLS] = sm.gridw;
+    unsigned (&Limg)[STOMP_LIMG_WORDS] = sm.Limg;
+    float (&sig_l)[64 * FUSED_LD] = sm.sig_l;
+    float (&mean_l)[64 * DCH] = sm.mean_l;
+    float (&delta)[DCH * FUSED_LD] = sm.delta;
+    float (&cst)[FUSED_WAVES] = sm.cst;
+    float (&tiles)[FUSED_WAVES * 64 * NT_STRIDE] = sm.tiles;
+    int& s_abort = sm.s_abort;
+    unsigned& s_ticket = sm.s_ticket;
 
     // the wave index as a SCALAR: everything derived from it (sample index, tile and output base addresses) then sits in
     // SGPRs, and per-lane addresses are a 32-bit offset from a uniform base instead of hoisted 64-bit VGPR pairs (which spill)
