@@ -72,18 +72,37 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
     // the 64 x 64 blocks of the lower triangle of L as three-component bf16 MFMA images (mpb_stomp_noise.h): block 0 = (0,0)
     // and block 2 = (1,1) are diagonal blocks (6 tiles, 18 KB), block 1 = (1,0) is full (8 tiles, 24 KB)
     constexpr int LIMG_WORDS = (HC == 1) ? STOMP_LIMG_WORDS : 2 * STOMP_LIMG_WORDS + STOMP_LIMG_WORDS_FULL;
-    __shared__ __attribute__((aligned(16))) unsigned Limg[LIMG_WORDS];
-    __shared__ __attribute__((aligned(16))) float tiles[FUSED_WAVES * TILE];
-    __shared__ __attribute__((aligned(16))) unsigned gridw[MPB_GRID_MAX_CELLS];
-    __shared__ float4 otab[MPB_GRID_MAX_SPH + 1];
-    __shared__ __attribute__((aligned(16))) float mean_l[HP * DX];
-    __shared__ __attribute__((aligned(16))) float delta[16 * DLD];
-    __shared__ __attribute__((aligned(16))) float sig_l[HC == 1 ? 64 * DLD : 4];   // H <= 64: Sigma stays in LDS (padded rows)
-    __shared__ float cst[FUSED_WAVES];
-    __shared__ float ewl[HX_MAX_NB * FUSED_WAVES];     // exp(logit - batch max) of the unit's samples
-    __shared__ float mbl[HX_MAX_NB];                   // the batches' maxima
-    __shared__ int s_abort;
-    __shared__ unsigned s_ticket;
+    // (one shared object, layout fixed by hand: the obstacle table, the grid and the small arrays first -- inside the reach of an
+    // LDS instruction's 16-bit offset field --, the L images and the sample tiles behind them; mpb_stomp_fused.hip)
+    struct Smem {
+        float4 otab[MPB_GRID_MAX_SPH + 1];
+        unsigned gridw[MPB_GRID_MAX_CELLS];
+        unsigned Limg[LIMG_WORDS];
+        float mean_l[HP * DX];
+        float delta[16 * DLD];
+        float sig_l[HC == 1 ? 64 * DLD : 4];           // H <= 64: Sigma stays in LDS (padded rows)
+        float cst[FUSED_WAVES];
+        float ewl[HX_MAX_NB * FUSED_WAVES];            // exp(logit - batch max) of the unit's samples
+        float mbl[HX_MAX_NB];                          // the batches' maxima
+        int s_abort;
+        unsigned s_ticket;
+        unsigned pad_[2];
+        float tiles[FUSED_WAVES * TILE];
+    };
+    static_assert((HX_MAX_NB * FUSED_WAVES + HX_MAX_NB) % 4 == 0, "Limg must stay 16-byte aligned");
+    __shared__ __attribute__((aligned(16))) Smem sm;
+    float4 (&otab)[MPB_GRID_MAX_SPH + 1] = sm.otab;
+    unsigned (&gridw)[MPB_GRID_MAX_CELLS] = sm.gridw;
+    float (&mean_l)[HP * DX] = sm.mean_l;
+    float (&delta)[16 * DLD] = sm.delta;
+    float (&sig_l)[HC == 1 ? 64 * DLD : 4] = sm.sig_l;
+    float (&cst)[FUSED_WAVES] = sm.cst;
+    float (&ewl)[HX_MAX_NB * FUSED_WAVES] = sm.ewl;
+    float (&mbl)[HX_MAX_NB] = sm.mbl;
+    int& s_abort = sm.s_abort;
+    unsigned& s_ticket = sm.s_ticket;
+    unsigned (&Limg)[LIMG_WORDS] = sm.Limg;
+    float (&tiles)[FUSED_WAVES * TILE] = sm.tiles;
 
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int lane = tid & 63;                                   // (re-derived per pass from an opaque copy: see HX_FRESH_LANE)
