@@ -262,7 +262,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         if (DCH % 2 == 0) {
 #pragma unroll
             for (int c = 0; c < DCH; c += 2) {
+#ifdef FUSED_T_A_NOMEAN   // (wrong-result timing switch, tuning builds only)
+                const float2 mv = make_float2(0.f, 0.f);
+#else
                 const float2 mv = *reinterpret_cast<const float2*>(mean_l + h * DCH + c);
+#endif
                 x[c] = mv.x + (edge ? 0.f : nz[c]);
                 x[c + 1] = mv.y + (edge ? 0.f : nz[c + 1]);
             }
@@ -275,7 +279,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
             for (int c = 0; c < DCH; ++c) nt[h * DCH + c] = x[c];
         }
         __builtin_amdgcn_wave_barrier();
+#ifdef FUSED_T_A_NOSTORE   // (wrong-result timing switch, tuning builds only)
+        if (false) {
+#else
         if (live) {
+#endif
             const f32x4* pk4 = reinterpret_cast<const f32x4*>(nt);
             f32x4* out4 = reinterpret_cast<f32x4*>(samples + ((size_t)p * S + s) * N);     // uniform
 #pragma unroll
