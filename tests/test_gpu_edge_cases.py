@@ -332,3 +332,69 @@ def test_point_entry_points_edge_cases(gpu_device):
                                1., 1., 1., 1.).shape == (0,)
     with pytest.raises(ValueError):
         ops.point_traj_cost(X, U, f([0., 0.]), f([0.5]), 1., 1., 1., 1.)                # goal of the wrong length
+
+
+def _rewrite_grid_words(host, fn):
+    """A copy of a packed geometry buffer with every (non-overflow) word of its broad-phase grid rewritten by fn(slots, n_sph)
+    -> slots (lists of obstacle indices; pack_geometry header: [6] n_spheres, [16] off_grid, [26] n_cells)."""
+    out = host.copy()
+    w = out.view(np.uint32)
+    ns, off, n = int(w[6]), int(w[16]), int(w[26])
+    for i in range(off, off + n):
+        word = int(w[i])
+        if word == 0xFFFFFFFE:
+            continue
+        slots = [(word >> (8 * k)) & 0xFF for k in range(4)]
+        slots = fn([b for b in slots if b < ns], ns)
+        slots = (list(slots) + [ns] * 4)[:4]
+        w[i] = slots[0] | (slots[1] << 8) | (slots[2] << 16) | (slots[3] << 24)
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('pos_only', [False, True])
+def test_grid_words_in_any_order_and_with_extra_candidates(gpu_device, pos_only):
+    """The kernels that stage the grid as offset words (round 4: csrc/mpb_geom.h grid_offset_word -- the persistent STOMP
+    kernels, MPPI) re-encode every cell while they copy it.  The encoding must not depend on what the host happened to
+    produce: candidates listed in DESCENDING order (obstacle 0 then sits in a later slot, whose offset 0 means "unused" in
+    the new form), and cells padded with obstacles that are no candidates at all (harmless by construction -- and a cell with
+    four entries takes the exhaustive path) give the same bits as the host's own grid, on the persistent and on the
+    two-kernel path."""
+    from motion_planning_baselines_amd import ops, workloads
+    from motion_planning_baselines_amd.planners.stomp import precision_to_scale_tril, stomp_precision_matrix
+    dev = gpu_device
+    P, S, H = 5, 32, 64
+    wl = workloads.panda_spheres_stomp(P, dev, H=H, S=S, pos_only=pos_only)
+    d = wl['means0'].shape[-1]
+    R = stomp_precision_matrix(H, wl['params']['dt'], 0.1, dict(device='cpu', dtype=torch.float32))
+    Sigma, L = torch.inverse(R).to(dev).contiguous(), precision_to_scale_tril(R).to(dev).contiguous()
+    base = ops.DeviceGeometry(wl['robot'], wl['field'], dev)
+    n_used = []
+
+    def descending(slots, ns):
+        n_used.append(len(slots))
+        return sorted(slots, reverse=True)
+
+    def padded(slots, ns):
+        extra = [o for o in range(ns) if o not in slots]
+        return list(slots) + extra[:max(0, (len(slots) + 1 + len(slots) % 2) - len(slots))]      # one or two non-candidates more
+
+    variants = [base, ops.DeviceGeometry.from_packed(_rewrite_grid_words(base.host, descending), dev),
+                ops.DeviceGeometry.from_packed(_rewrite_grid_words(base.host, padded), dev)]
+    assert max(n_used) >= 2                                      # (the scene has cells with several candidates)
+    res = []
+    for geom in variants:
+        for ws in (ops.stomp_workspace(P, S, H, d, dev), None):  # persistent / two-kernel
+            m = wl['means0'].clone()
+            s, c, w = torch.empty(P, S, H, d, device=dev), torch.empty(P, S, device=dev), torch.empty(P, S, device=dev)
+            ops.stomp_run(m, None, s, c, w, L, Sigma, geom, S, 7, 1e6, 1.0, 0.1, 1.0, ws, n_iters=3, seed=11)
+            torch.cuda.synchronize()
+            if ws is not None:
+                assert not ops.stomp_run_timed_out(ws)
+            res.append((ws is not None, m, s, c))
+    for persistent in (True, False):
+        ref = next(r for r in res if r[0] == persistent)
+        for r in res:
+            if r[0] == persistent:
+                assert torch.equal(r[3], ref[3]) and torch.equal(r[2], ref[2]) and torch.equal(r[1], ref[1])
+    assert float(res[0][3].max()) > 0
