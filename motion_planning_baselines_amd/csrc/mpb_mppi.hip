@@ -186,8 +186,15 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
                         eps[((((size_t)it * gridDim.x + prob) * c + i) * S + ss) * T + t];
                 }
             } else {
-                for (int l = threadIdx.x; l < c * S * G4; l += blockDim.x) {
-                    const int i = l / (S * G4), r = l - i * S * G4, ss = r / G4, g4 = r - ss * G4;
+                // (which thread draws which (sample, group of four steps): groups fastest only over FOUR values, then eight
+                // samples -- 32 consecutive lanes then write banks 4 ss + g4 = 0..31 of the slab (its sample stride is 4 mod 32),
+                // where groups fastest over all sixteen put two samples on the same banks: the 2-way conflict that was left
+                // of round 3's 16-way one.  The counters do not depend on the lane: same stream)
+                const int G4q = (G4 + 3) >> 2;
+                for (int l = threadIdx.x; l < c * S * 4 * G4q; l += blockDim.x) {
+                    const int glo = l & 3, r1 = l >> 2, ss = r1 % S, r2 = r1 / S, ghi = r2 % G4q, i = r2 / G4q;
+                    const int g4 = 4 * ghi + glo;
+                    if (g4 >= G4) continue;
                     const uint4 rr = philox4x32_10(make_uint4((uint32_t)prob, (uint32_t)ss, (uint32_t)g4 | ((uint32_t)i << 16),
                                                               iter0 + (uint32_t)it),
                                                    make_uint2(seed_lo, seed_hi));
