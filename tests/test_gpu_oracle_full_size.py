@@ -30,13 +30,13 @@ def _gmax(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
 
 
-def _c3(dev, P, S=32):
+def _c3(dev, P, S=32, H=64):
     from motion_planning_baselines_amd import ops, workloads
     from motion_planning_baselines_amd.planners.stomp import precision_to_scale_tril, stomp_precision_matrix
-    wl = workloads.panda_spheres_stomp(P, dev, S=S, pos_only=False)
+    wl = workloads.panda_spheres_stomp(P, dev, H=H, S=S, pos_only=False)
     prm = wl['params']
     cpu = dict(device='cpu', dtype=torch.float32)
-    R = stomp_precision_matrix(64, prm['dt'], prm['sigma_spectral'], cpu)
+    R = stomp_precision_matrix(H, prm['dt'], prm['sigma_spectral'], cpu)
     return wl, torch.inverse(R).contiguous(), precision_to_scale_tril(R).contiguous(), ops.DeviceGeometry(wl['robot'], wl['field'], dev)
 
 
@@ -81,12 +81,13 @@ def _check_iteration(tag, got, ref32, ref64, n_pos, temperature):
     return e_g, e_w
 
 
-@pytest.mark.parametrize('P,path', [(128, 'exchange'), (256, 'two-batch')])
-def test_stomp_c3_persistent_vs_oracle_full_size(gpu_device, P, path):
+@pytest.mark.parametrize('P,path,H', [(128, 'exchange', 64), (256, 'two-batch', 64), (128, 'exchange', 128)])
+def test_stomp_c3_persistent_vs_oracle_full_size(gpu_device, P, path, H):
+    """(H = 128: the bench line's `h128` entry, the generalised persistent kernel)"""
     from motion_planning_baselines_amd import ops
     dev = gpu_device
-    S, H, n_it = 32, 64, 2
-    wl, Sigma, L, geom = _c3(dev, P, S)
+    S, n_it = 32, 2
+    wl, Sigma, L, geom = _c3(dev, P, S, H)
     prm = wl['params']
     d = wl['means0'].shape[-1]
     ksig = 1.0 / wl['sigma_coll'] ** 2
@@ -111,7 +112,7 @@ def test_stomp_c3_persistent_vs_oracle_full_size(gpu_device, P, path):
     refs = []
     for it in range(n_it):
         r32, r64 = _oracle_iter(wl, prev, eps[it], L, Sigma, torch.float32), _oracle_iter(wl, prev, eps[it], L, Sigma, torch.float64)
-        _check_iteration('C3 P=%d teacher-forced it %d' % (P, it), run(prev, eps_d[it:it + 1], 1), r32, r64, 7, prm['temperature'])
+        _check_iteration('C3 P=%d H=%d teacher-forced it %d' % (P, H, it), run(prev, eps_d[it:it + 1], 1), r32, r64, 7, prm['temperature'])
         refs.append(r32)
         prev = r32['means']
     # free running: both iterations inside ONE persistent launch, against the oracle's free-running fp32 / fp64 runs
@@ -122,7 +123,7 @@ def test_stomp_c3_persistent_vs_oracle_full_size(gpu_device, P, path):
     got = run(wl['means0'].cpu(), eps_d, n_it)
     env = _gmax(refs[-1]['means'], m64)
     err, errw = _gmax(got[0], refs[-1]['means']), rel_err_waypoint(got[0], refs[-1]['means'], 7)
-    print('C3 P=%d free-running %d iterations: global-max %.2e per-waypoint %.2e (reference fp32-vs-fp64 envelope %.2e)' % (P, n_it, err, errw, env))
+    print('C3 P=%d H=%d free-running %d iterations: global-max %.2e per-waypoint %.2e (reference fp32-vs-fp64 envelope %.2e)' % (P, H, n_it, err, errw, env))
     assert err < max(REL, 2.0 * env)
 
 
