@@ -135,6 +135,18 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, fl
     n1 = r * __builtin_amdgcn_sinf(u2);
 }
 
+// the same from the top 23 bits of each word dropped straight into the mantissa of a float in [1, 2) (round 4, as the STOMP
+// draw does: mpb_stomp_noise.h): radius from u = 2 - m in (0, 1] (exact), the angle is m itself (v_sin / v_cos count in
+// revolutions, period 1) -- no integer-to-float conversion, no scaling
+__device__ __forceinline__ void box_muller_m23(uint32_t a, uint32_t b, float& n0, float& n1) {
+#pragma clang fp contract(off)
+    const float u1 = 2.0f - __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, a, 9));
+    const float ang = __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, b, 9));
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+    n0 = r * __builtin_amdgcn_cosf(ang);
+    n1 = r * __builtin_amdgcn_sinf(ang);
+}
+
 // The first D floats of a waypoint row into q[0..D) (zero beyond): 8-byte loads when the row starts 8-byte aligned
 // (`even` = the row stride in floats is even and so is the base: wave-uniform), else element by element.  A lane's row is
 // 28-64 contiguous bytes, so every load instruction of a wave touches the same ~28 cache lines whatever its width:

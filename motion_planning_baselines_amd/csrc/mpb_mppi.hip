@@ -195,12 +195,12 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
                     const int glo = l & 3, r1 = l >> 2, ss = r1 % S, r2 = r1 / S, ghi = r2 % G4q, i = r2 / G4q;
                     const int g4 = 4 * ghi + glo;
                     if (g4 >= G4) continue;
-                    const uint4 rr = philox4x32_10(make_uint4((uint32_t)prob, (uint32_t)ss, (uint32_t)g4 | ((uint32_t)i << 16),
+                    const uint4 rr = philox4x32<7>(make_uint4((uint32_t)prob, (uint32_t)ss, (uint32_t)g4 | ((uint32_t)i << 16),
                                                               iter0 + (uint32_t)it),
                                                    make_uint2(seed_lo, seed_hi));
                     float n[4];
-                    box_muller(rr.x, rr.y, n[0], n[1]);
-                    box_muller(rr.z, rr.w, n[2], n[3]);
+                    box_muller_m23(rr.x, rr.y, n[0], n[1]);
+                    box_muller_m23(rr.z, rr.w, n[2], n[3]);
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         if (4 * g4 + q < T) M.E[((size_t)i * Spad + ss) * MPPI_E_STRIDE + q * 16 + g4] = n[q];
@@ -249,12 +249,12 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
                 const int G4 = (T + 3) >> 2;
                 for (int l = lane; l < c * G4; l += 64) {
                     const int i = l / G4, g4 = l - i * G4;
-                    const uint4 r = philox4x32_10(make_uint4((uint32_t)prob, (uint32_t)s, (uint32_t)g4 | ((uint32_t)i << 16),
+                    const uint4 r = philox4x32<7>(make_uint4((uint32_t)prob, (uint32_t)s, (uint32_t)g4 | ((uint32_t)i << 16),
                                                              iter0 + (uint32_t)it),
                                                   make_uint2(seed_lo, seed_hi));
                     float n[4];
-                    box_muller(r.x, r.y, n[0], n[1]);
-                    box_muller(r.z, r.w, n[2], n[3]);
+                    box_muller_m23(r.x, r.y, n[0], n[1]);
+                    box_muller_m23(r.z, r.w, n[2], n[3]);
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         if (4 * g4 + q < T) ew[i * T + 4 * g4 + q] = n[q];
