@@ -166,7 +166,9 @@ int mpb_field_cost_points_vjp(const float *pts, const float *geom, const float *
  *
  * means (P,H,d) in/out, updated in place n_iters times.
  * eps: NULL -> standard normals are generated on the device (Philox4x32, 7 rounds, keyed by `seed`,
- *      counter = (particle_offset + p, s, waypoint, iter0 + i); result independent of sharding);
+ *      counter = (particle_offset + p, s, (channel, waypoint group, call), iter0 + i); Box-Muller on 23-bit uniforms, a
+ *      drawn normal carries 16 significant bits -- csrc/mpb_stomp_noise.h; result independent of sharding and of the
+ *      kernel that serves the call);
  *      else (n_iters, S, d, P, H): pre-drawn standard normals in the reference's draw order
  *      (one MultivariateNormal.sample((S,d)) of batch shape (P,) and event shape (H,) per iteration).
  * samples (P,S,H,d), costs (P,S), weights (P,S): outputs of the LAST iteration (all required).
