@@ -19,14 +19,18 @@ const char *mpb_debug_last_error(void);
  * keeps the chip busy" of the time-out tests); `sink` is one device word (never written in practice). */
 int mpb_debug_occupy(int n_blocks, uint64_t usec, uint32_t *sink, void *stream);
 /* Test aids for the random-number path (csrc/mpb_debug.hip; not on a product path).
- * mpb_debug_philox: out[4i..4i+3] = Philox4x32-`rounds`(ctr[4i..4i+3], key[2i..2i+1]), rounds = 7 (the STOMP kernels) or
- * 10 (every other kernel), device pointers -- for the Random123 known-answer vectors.
+ * mpb_debug_philox: out[4i..4i+3] = Philox4x32-`rounds`(ctr[4i..4i+3], key[2i..2i+1]), rounds = 7 (the STOMP kernels and, since
+ * ABI 4, the MPPI kernel) or 10 (every other kernel), device pointers -- for the Random123 known-answer vectors.
  * mpb_debug_stomp_normals: the standard normals of n_iters STOMP iterations exactly as mpb_stomp_step / mpb_stomp_run draw
  * them in throughput mode (eps == NULL): out (n_iters, P, S, d, 64), element [it][p][s][c][k] = eps of iteration
- * iter0 + it, global particle particle_offset + p, sample s, channel c, waypoint k. */
+ * iter0 + it, global particle particle_offset + p, sample s, channel c, waypoint k.
+ * mpb_debug_stomp_normals_h: the same for any horizon H <= 256 (the chunked kernels draw 64 columns per chunk kc = k / 64):
+ * out (n_iters, P, S, d, 64 * ceil(H / 64)); the columns k >= H are drawn by the kernels too and meet zero columns of L. */
 int mpb_debug_philox(const uint32_t *ctr, const uint32_t *key, uint32_t *out, int n, int rounds, void *stream);
 int mpb_debug_stomp_normals(float *out, int P, int S, int d, int n_iters, uint64_t seed, uint32_t iter0,
                             uint32_t particle_offset, void *stream);
+int mpb_debug_stomp_normals_h(float *out, int P, int S, int d, int H, int n_iters, uint64_t seed, uint32_t iter0,
+                              uint32_t particle_offset, void *stream);
 
 #ifdef __cplusplus
 }

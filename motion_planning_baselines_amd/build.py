@@ -5,6 +5,7 @@
 import os
 import subprocess
 import sys
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
@@ -105,10 +106,16 @@ def build(force=False, verbose=True):
         cmd = [hipcc, *FLAGS, *EXTRA.get(src, []), *REMARKS, '-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
-        procs.append((cmd, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
+        # (stderr to a file, not a pipe: the resource remarks of the templated kernels overflow a 64 KB pipe buffer, and a
+        # compile blocked in write() behind the one being drained serialises the build)
+        log = tempfile.TemporaryFile(mode='w+')
+        procs.append((cmd, subprocess.Popen(cmd, stderr=log, text=True), log))
     resources = {}
-    for cmd, p in procs:
-        _, err = p.communicate()
+    for cmd, p, log in procs:
+        p.wait()
+        log.seek(0)
+        err = log.read()
+        log.close()
         rest = '\n'.join(l for l in err.splitlines() if 'kernel-resource-usage' not in l and not l.lstrip().startswith(('|', '^')) and l.strip()
                          and not __import__('re').match(r'^\s*\d+ \|', l))
         if p.returncode != 0:

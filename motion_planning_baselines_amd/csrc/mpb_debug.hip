@@ -1,8 +1,8 @@
 // mpb_debug.hip -- test aids of the C-ABI: what the tests need to look INSIDE the product kernels' random-number path.
-//   mpb_debug_philox          raw Philox4x32-R words (R = 7: the STOMP kernels; R = 10: everything else) for given
+//   mpb_debug_philox          raw Philox4x32-R words (R = 7: the STOMP and MPPI kernels; R = 10: everything else) for given
 //                             counters / keys -- compared with the published Random123 known-answer vectors;
 //   mpb_debug_stomp_normals   the standard normals exactly as the STOMP kernels draw them (stomp_normals_lo / _hi: Philox4x32-7 +
-//                             Box-Muller on the hardware log2 / sqrt / sin / cos units), laid out (iters, P, S, d, H)
+//                             Box-Muller on the hardware log2 / sqrt / sin / cos units), laid out (iters, P, S, d, 64 ceil(H / 64))
 //                             -- for the statistical tests of the throughput-mode noise (tests/test_gpu_rng.py).
 //   mpb_debug_occupy          workgroups that each hold a CU's LDS for a given time (the lost-launch tests).
 // None is on a product path: this file is the ONLY source of libmpb_hip_debug.so (include/mpb_debug.h), a library of its
@@ -42,22 +42,23 @@ extern "C" int mpb_debug_philox(const uint32_t* ctr, const uint32_t* key, uint32
 #else
 #define DBGQ(x) stomp_eps_quantise(x)
 #endif
-__global__ void debug_stomp_normals_kernel(float* __restrict__ out, int P, int S, int d, int n_iters, uint32_t seed_lo,
+__global__ void debug_stomp_normals_kernel(float* __restrict__ out, int P, int S, int d, int HC, int n_iters, uint32_t seed_lo,
                                            uint32_t seed_hi, uint32_t iter0, uint32_t particle_offset) {
-    const size_t n = (size_t)n_iters * P * S * d * 4;
+    const size_t n = (size_t)n_iters * P * S * d * HC * 4;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t g = i & 3;
     size_t r = i >> 2;
+    const uint32_t kc = r % HC; r /= HC;              // 64-column chunk of the horizon (the chunked kernels: call0 = kc << 4)
     const uint32_t j = r % d; r /= d;
     const uint32_t s = r % S; r /= S;
     const uint32_t p = r % P; r /= P;
     const uint32_t it = (uint32_t)r;
     float lo[8], hi[8];
     uint32_t carry[2];
-    stomp_normals_lo<STOMP_PRIO_NONE>(particle_offset + p, s, j, g, 0u, iter0 + it, seed_lo, seed_hi, lo, carry);
-    stomp_normals_hi<STOMP_PRIO_NONE>(particle_offset + p, s, j, g, 0u, iter0 + it, seed_lo, seed_hi, carry, hi);
-    float* o = out + ((((size_t)it * P + p) * S + s) * d + j) * 64;
+    stomp_normals_lo<STOMP_PRIO_NONE>(particle_offset + p, s, j, g, kc << 4, iter0 + it, seed_lo, seed_hi, lo, carry);
+    stomp_normals_hi<STOMP_PRIO_NONE>(particle_offset + p, s, j, g, kc << 4, iter0 + it, seed_lo, seed_hi, carry, hi);
+    float* o = out + (((((size_t)it * P + p) * S + s) * d + j) * HC + kc) * 64;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         // (as they enter the product: the two leading bf16 components, mpb_stomp_noise.h)
@@ -66,14 +67,20 @@ __global__ void debug_stomp_normals_kernel(float* __restrict__ out, int P, int S
     }
 }
 
-extern "C" int mpb_debug_stomp_normals(float* out, int P, int S, int d, int n_iters, uint64_t seed, uint32_t iter0,
-                                       uint32_t particle_offset, void* stream) {
-    if (!out || P < 1 || S < 1 || d < 1 || d > 16 || n_iters < 1) return mpb_fail(MPB_E_INVALID, "mpb_debug_stomp_normals: bad argument");
-    const size_t n = (size_t)n_iters * P * S * d * 4;
+extern "C" int mpb_debug_stomp_normals_h(float* out, int P, int S, int d, int H, int n_iters, uint64_t seed, uint32_t iter0,
+                                         uint32_t particle_offset, void* stream) {
+    if (!out || P < 1 || S < 1 || d < 1 || d > 16 || n_iters < 1 || H < 1 || H > 256)
+        return mpb_fail(MPB_E_INVALID, "mpb_debug_stomp_normals: bad argument");
+    const int HC = (H + 63) / 64;
+    const size_t n = (size_t)n_iters * P * S * d * HC * 4;
     if (n > 0x7FFFFFFFull * 256ull) return mpb_fail(MPB_E_INVALID, "mpb_debug_stomp_normals: too many draws for one launch");
     hipLaunchKernelGGL(debug_stomp_normals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, P, S,
-                       d, n_iters, (uint32_t)seed, (uint32_t)(seed >> 32), iter0, particle_offset);
+                       d, HC, n_iters, (uint32_t)seed, (uint32_t)(seed >> 32), iter0, particle_offset);
     return mpb_check_launch("mpb_debug_stomp_normals");
+}
+extern "C" int mpb_debug_stomp_normals(float* out, int P, int S, int d, int n_iters, uint64_t seed, uint32_t iter0,
+                                       uint32_t particle_offset, void* stream) {
+    return mpb_debug_stomp_normals_h(out, P, S, d, 64, n_iters, seed, iter0, particle_offset, stream);
 }
 
 // test aid (mpb_debug_occupy): workgroups that each take a whole CU's LDS and spin for a given time -- the "other stream

@@ -537,13 +537,15 @@ def debug_philox(ctr, key, rounds):
     return out.cpu().numpy().view(np.uint32)
 
 
-def debug_stomp_normals(P, S, d, n_iters, device, seed=0, iter0=0, particle_offset=0):
-    """Test aid: the standard normals the STOMP kernels draw in throughput mode, (n_iters, P, S, d, 64) fp32."""
-    out = torch.empty(n_iters, P, S, d, 64, device=device, dtype=torch.float32)
+def debug_stomp_normals(P, S, d, n_iters, device, seed=0, iter0=0, particle_offset=0, H=64):
+    """Test aid: the standard normals the STOMP kernels draw in throughput mode, (n_iters, P, S, d, 64 * ceil(H / 64)) fp32
+    (columns k >= H are drawn by the kernels as well and meet zero columns of L)."""
+    Hp = 64 * ((int(H) + 63) // 64)
+    out = torch.empty(n_iters, P, S, d, Hp, device=device, dtype=torch.float32)
     with torch.cuda.device(out.device):
-        _lib.debug_check(_lib.debug_lib().mpb_debug_stomp_normals(_ptr(out), int(P), int(S), int(d), int(n_iters),
-                                                      int(seed) & (2 ** 64 - 1), int(iter0), int(particle_offset), _stream()),
-                   'mpb_debug_stomp_normals')
+        _lib.debug_check(_lib.debug_lib().mpb_debug_stomp_normals_h(_ptr(out), int(P), int(S), int(d), int(H), int(n_iters),
+                                                                    int(seed) & (2 ** 64 - 1), int(iter0), int(particle_offset), _stream()),
+                         'mpb_debug_stomp_normals_h')
     return out
 
 
