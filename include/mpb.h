@@ -172,6 +172,9 @@ int mpb_field_cost_points_vjp(const float *pts, const float *geom, const float *
  *      else (n_iters, S, d, P, H): pre-drawn standard normals in the reference's draw order
  *      (one MultivariateNormal.sample((S,d)) of batch shape (P,) and event shape (H,) per iteration).
  * samples (P,S,H,d), costs (P,S), weights (P,S): outputs of the LAST iteration (all required).
+ * Alignment: means, eps, samples, L, Sigma, geom (and the workspace / means_copy of mpb_stomp_run*) must be 16-byte aligned --
+ *      the kernels move them as 16-byte vectors; a pointer that is not is refused with MPB_E_INVALID (allocations of hipMalloc /
+ *      PyTorch-ROCm are 256-byte aligned; a VIEW at an odd element offset is what trips this).
  * L (H,H): scale_tril of the noise distribution, Sigma (H,H) = inverse(R): constants the host
  *      computes exactly as the reference does (stomp.py:63-64, :88-95) -- SURVEY.md H2.
  * mpb_stomp_step runs the fused path (sample+cost kernel, update kernel per iteration).  Everything is
@@ -361,7 +364,11 @@ int mpb_gpmp2_step(float *x, const float *start, const float *goal, const float 
  * One problem per workgroup; NP independent problems per launch (the reference class is NP = 1);
  * all n_iters iterations inside one launch.
  *
- * mean (NP,T,c) in/out; eps NULL -> device Philox, else (n_iters,NP,c,S,T) standard normals (per
+ * mean (NP,T,c) in/out; eps NULL -> standard normals generated on the device (since ABI 4: Philox4x32 with 7 rounds keyed by
+ * `seed`, counter = (problem, sample, (t / 4) | dim << 16, iter0 + i), one call per four consecutive time steps; Box-Muller
+ * on the top 23 bits of each word, so |n| <= sqrt(2 ln 2^23) = 5.65; ABI 3 drew Philox4x32-10 with 24-bit uniforms: the
+ * device-noise streams of STOMP and MPPI are NOT reproducible across ABI 3 -> 4; mpb_debug_mppi_normals of include/mpb_debug.h
+ * returns the stream), else (n_iters,NP,c,S,T) standard normals (per
  * control dimension, in the reference's draw order); scale_tril, cov_inv (c,T,T); state0 (NP,c);
  * goal (NP,c); ctrl_min / ctrl_max (c); discount (T); c_weights = {pos, vel, ctrl, pos_T};
  * control_type 0 = velocity (state_dim = c); 1 = acceleration is MPB_E_UNSUPPORTED (the reference's

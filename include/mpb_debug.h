@@ -31,6 +31,10 @@ int mpb_debug_stomp_normals(float *out, int P, int S, int d, int n_iters, uint64
                             uint32_t particle_offset, void *stream);
 int mpb_debug_stomp_normals_h(float *out, int P, int S, int d, int H, int n_iters, uint64_t seed, uint32_t iter0,
                               uint32_t particle_offset, void *stream);
+/* mpb_debug_mppi_normals: the standard normals mpb_mppi_step draws in throughput mode (eps == NULL), laid out as its injected
+ * eps: out (n_iters, NP, c, S, T), element [it][problem][dim][s][t] -- Philox4x32-7, counter (problem, s, (t / 4) | dim << 16,
+ * iter0 + it), Box-Muller on 23-bit uniforms (csrc/mpb_common.h box_muller_m23). */
+int mpb_debug_mppi_normals(float *out, int NP, int S, int T, int c, int n_iters, uint64_t seed, uint32_t iter0, void *stream);
 
 #ifdef __cplusplus
 }

@@ -72,6 +72,7 @@ DEBUG_SIGNATURES = {
     'mpb_debug_philox': [_p, _p, _p, _i, _i, _p],
     'mpb_debug_stomp_normals': [_p, _i, _i, _i, _i, _u64, _u32, _u32, _p],
     'mpb_debug_stomp_normals_h': [_p, _i, _i, _i, _i, _i, _u64, _u32, _u32, _p],
+    'mpb_debug_mppi_normals': [_p, _i, _i, _i, _i, _i, _u64, _u32, _p],
 }
 ABI_VERSION = 4          # include/mpb.h MPB_ABI_VERSION
 

@@ -21,6 +21,12 @@ static inline int mpb_fail(int code, const char* msg) {
     snprintf(mpb_err_buf(), 512, "%s", msg);
     return code;
 }
+// the STOMP kernels read eps / L / Sigma / the means and write the samples as 16-byte vectors: a pointer the C-ABI is handed must
+// be 16-byte aligned (a view at a 4-byte offset into an allocation would be misaligned dwordx4 accesses)
+static inline bool mpb_misaligned16(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr,
+                                    const void* e = nullptr, const void* f = nullptr) {
+    return ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d) | ((uintptr_t)e) | ((uintptr_t)f)) & 15u) != 0;
+}
 static inline int mpb_check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

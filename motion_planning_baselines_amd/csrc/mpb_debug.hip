@@ -4,6 +4,7 @@
 //   mpb_debug_stomp_normals   the standard normals exactly as the STOMP kernels draw them (stomp_normals_lo / _hi: Philox4x32-7 +
 //                             Box-Muller on the hardware log2 / sqrt / sin / cos units), laid out (iters, P, S, d, 64 ceil(H / 64))
 //                             -- for the statistical tests of the throughput-mode noise (tests/test_gpu_rng.py).
+//   mpb_debug_mppi_normals    the standard normals of the MPPI kernel's device draw, in the layout of its injected eps;
 //   mpb_debug_occupy          workgroups that each hold a CU's LDS for a given time (the lost-launch tests).
 // None is on a product path: this file is the ONLY source of libmpb_hip_debug.so (include/mpb_debug.h), a library of its
 // own that the tests load next to the product library; it shares device code with the product through the headers only.
@@ -81,6 +82,40 @@ extern "C" int mpb_debug_stomp_normals_h(float* out, int P, int S, int d, int H,
 extern "C" int mpb_debug_stomp_normals(float* out, int P, int S, int d, int n_iters, uint64_t seed, uint32_t iter0,
                                        uint32_t particle_offset, void* stream) {
     return mpb_debug_stomp_normals_h(out, P, S, d, 64, n_iters, seed, iter0, particle_offset, stream);
+}
+
+// the standard normals of the MPPI kernel's device draw (csrc/mpb_mppi.hip: one Philox4x32-7 call per (problem, sample,
+// group of four time steps | control dimension << 16, iteration) -> four normals by box_muller_m23), laid out as the injected
+// eps of mpb_mppi_step: (n_iters, NP, c, S, T)
+__global__ void debug_mppi_normals_kernel(float* __restrict__ out, int NP, int S, int T, int c, int n_iters, uint32_t seed_lo,
+                                          uint32_t seed_hi, uint32_t iter0) {
+    const int G4 = (T + 3) >> 2;
+    const size_t n = (size_t)n_iters * NP * c * S * G4;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    size_t r = idx;
+    const uint32_t g4 = r % G4; r /= G4;
+    const uint32_t s = r % S; r /= S;
+    const uint32_t i = r % c; r /= c;
+    const uint32_t prob = r % NP; r /= NP;
+    const uint32_t it = (uint32_t)r;
+    const uint4 w = philox4x32<7>(make_uint4(prob, s, g4 | (i << 16), iter0 + it), make_uint2(seed_lo, seed_hi));
+    float nrm[4];
+    box_muller_m23(w.x, w.y, nrm[0], nrm[1]);
+    box_muller_m23(w.z, w.w, nrm[2], nrm[3]);
+    float* o = out + ((((size_t)it * NP + prob) * c + i) * S + s) * T;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if ((int)(4 * g4 + q) < T) o[4 * g4 + q] = nrm[q];
+}
+
+extern "C" int mpb_debug_mppi_normals(float* out, int NP, int S, int T, int c, int n_iters, uint64_t seed, uint32_t iter0, void* stream) {
+    if (!out || NP < 1 || S < 1 || T < 1 || c < 1 || n_iters < 1) return mpb_fail(MPB_E_INVALID, "mpb_debug_mppi_normals: bad argument");
+    const size_t n = (size_t)n_iters * NP * c * S * ((T + 3) >> 2);
+    if (n > 0x7FFFFFFFull * 256ull) return mpb_fail(MPB_E_INVALID, "mpb_debug_mppi_normals: too many draws for one launch");
+    hipLaunchKernelGGL(debug_mppi_normals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, NP, S, T, c,
+                       n_iters, (uint32_t)seed, (uint32_t)(seed >> 32), iter0);
+    return mpb_check_launch("mpb_debug_mppi_normals");
 }
 
 // test aid (mpb_debug_occupy): workgroups that each take a whole CU's LDS and spin for a given time -- the "other stream

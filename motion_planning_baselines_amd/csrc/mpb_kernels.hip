@@ -1005,6 +1005,7 @@ extern "C" int mpb_stomp_sample(const float* means, const float* eps, float* sam
     if (!means || !samples || !L) return fail(MPB_E_INVALID, "%s: null pointer", __func__);
     if ((geom == nullptr) != (costs == nullptr)) return fail(MPB_E_INVALID, "%s: geom and costs must be given together", __func__);
     if (P < 0 || S < 1 || H < 3 || H > MPB_MAX_H || d < 1 || d > MPB_MAX_D) return fail(MPB_E_INVALID, "%s: bad shape", __func__);
+    if (mpb_misaligned16(means, eps, samples, L, geom)) return fail(MPB_E_INVALID, "%s: means / eps / samples / L / geom must be 16-byte aligned", __func__);
     if (P == 0) return MPB_OK;
     if (geom)
         launch_sample<true>(means, eps, samples, costs, L, geom, geom_flags, P, S, H, d, k_sigma, weight, seed, iter,
@@ -1022,6 +1023,7 @@ extern "C" int mpb_stomp_update(float* means, const float* samples, const float*
     if (!means || !samples || !costs || !weights) return fail(MPB_E_INVALID, "%s: null pointer", __func__);
     if (P < 0 || S < 1 || H < 3 || H > MPB_MAX_H || d < 1 || d > MPB_MAX_D) return fail(MPB_E_INVALID, "%s: bad shape", __func__);
     if (!(temperature > 0.f)) return fail(MPB_E_INVALID, "%s: temperature must be > 0", __func__);
+    if (mpb_misaligned16(means, samples, Sigma)) return fail(MPB_E_INVALID, "%s: means / samples / Sigma must be 16-byte aligned", __func__);
     if (P == 0) return MPB_OK;
     if (!launch_update(means, samples, costs, weights, Sigma, P, S, H, d, lr, temperature, (hipStream_t)stream))
         return fail(MPB_E_UNSUPPORTED, "%s: S + H*d too large for LDS", __func__);
@@ -1036,6 +1038,8 @@ extern "C" int mpb_stomp_step(float* means, const float* eps, float* samples, fl
     if (!means || !samples || !costs || !weights || !L || !Sigma || !geom) return fail(MPB_E_INVALID, "%s: null pointer", __func__);
     if (P < 0 || S < 1 || !shape_ok(H, d, D) || n_iters < 0) return fail(MPB_E_INVALID, "%s: bad shape", __func__);
     if (!(temperature > 0.f)) return fail(MPB_E_INVALID, "%s: temperature must be > 0", __func__);
+    if (mpb_misaligned16(means, eps, samples, L, Sigma, geom))
+        return fail(MPB_E_INVALID, "%s: means / eps / samples / L / Sigma / geom must be 16-byte aligned", __func__);
     size_t lds_b;
     int sig_lds;
     if (!update_lds(S, H, d, lds_b, sig_lds)) return fail(MPB_E_UNSUPPORTED, "%s: S + H*d too large for LDS", __func__);

@@ -661,6 +661,8 @@ extern "C" int mpb_stomp_run_checked(float* means, const float* eps, float* samp
     if (!means || !samples || !costs || !weights || !L || !Sigma || !geom) return mpb_fail(MPB_E_INVALID, "mpb_stomp_run: null pointer");
     if (P < 0 || S < 1 || n_iters < 0 || !(d == D || d == 2 * D)) return mpb_fail(MPB_E_INVALID, "mpb_stomp_run: bad shape");
     if (!(temperature > 0.f)) return mpb_fail(MPB_E_INVALID, "mpb_stomp_run: temperature must be > 0");
+    if (mpb_misaligned16(means, eps, samples, L, Sigma, geom) || mpb_misaligned16(workspace, means_copy))
+        return mpb_fail(MPB_E_INVALID, "mpb_stomp_run: means / eps / samples / L / Sigma / geom / workspace / means_copy must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     // the status block is host memory the device can write (pinned + mapped): its device address
     unsigned* status_dev = nullptr;
@@ -754,6 +756,8 @@ extern "C" int mpb_stomp_plan_create(mpb_stomp_plan** plan, float* means, float*
     if (!means || !samples || !costs || !weights || !L || !Sigma || !geom) return mpb_fail(MPB_E_INVALID, "mpb_stomp_plan_create: null pointer");
     if (P < 0 || S < 1 || !(d == D || d == 2 * D)) return mpb_fail(MPB_E_INVALID, "mpb_stomp_plan_create: bad shape");
     if (!(temperature > 0.f)) return mpb_fail(MPB_E_INVALID, "mpb_stomp_plan_create: temperature must be > 0");
+    if (mpb_misaligned16(means, samples, L, Sigma, geom, workspace))
+        return mpb_fail(MPB_E_INVALID, "mpb_stomp_plan_create: means / samples / L / Sigma / geom / workspace must be 16-byte aligned");
     mpb_stomp_plan_s* q = static_cast<mpb_stomp_plan_s*>(malloc(sizeof(mpb_stomp_plan_s)));
     if (!q) return mpb_fail(MPB_E_HIP, "mpb_stomp_plan_create: out of host memory");
     *q = mpb_stomp_plan_s{means, samples, costs, weights, L, Sigma, geom, geom_flags, workspace, workspace_bytes, P, S, H, d, D,

@@ -549,6 +549,15 @@ def debug_stomp_normals(P, S, d, n_iters, device, seed=0, iter0=0, particle_offs
     return out
 
 
+def debug_mppi_normals(NP, S, T, c, n_iters, device, seed=0, iter0=0):
+    """Test aid: the standard normals mppi_step draws in throughput mode, in the layout of its injected eps (n_iters, NP, c, S, T)."""
+    out = torch.empty(n_iters, NP, c, S, T, device=device, dtype=torch.float32)
+    with torch.cuda.device(out.device):
+        _lib.debug_check(_lib.debug_lib().mpb_debug_mppi_normals(_ptr(out), int(NP), int(S), int(T), int(c), int(n_iters),
+                                                                 int(seed) & (2 ** 64 - 1), int(iter0), _stream()), 'mpb_debug_mppi_normals')
+    return out
+
+
 def debug_occupy(n_blocks, usec, device):
     """Test aid: n_blocks workgroups that each take a CU's LDS and idle for `usec` microseconds on the current stream."""
     sink = torch.zeros(1, dtype=torch.int32, device=device)

@@ -5,6 +5,8 @@ The reference stacks a dense (A, b, K) per particle, forms A^T K A and calls a d
 block-tridiagonal form and solves them by block Cholesky in fp64 (csrc/mpb_gpmp2.hip); nothing dense is
 ever materialised, which is also what lets config C4 (B=2048, H=128, D=7: >150 GB dense) run at all.
 """
+import math
+
 import torch
 import torch.distributed as dist
 
@@ -84,17 +86,34 @@ class GPMP2(OptimizationPlanner):
         merge = lambda a, b: (1.0 / a ** 2 + 1.0 / b ** 2) ** -0.5
         same = lambda a, b: a is not None and b is not None and tuple(a.shape) == tuple(b.shape) and \
             bool(torch.equal(a.detach().cpu().float(), b.detach().cpu().float()))
+        def _same_problem(c, what):
+            """an extra factor is merged only if it is built for THIS planner's horizon and DoF: the reference stacks its rows
+            under the planner's (cost_functions.py:107-144) and fails at the concatenation when they do not match"""
+            if c.n_support_points != n_support_points or c.n_dof != n_dof:
+                raise ValueError('GPMP2 extra_costs: the %s is built for n_support_points=%s, n_dof=%s; this planner has %s, %s'
+                                 % (what, c.n_support_points, c.n_dof, n_support_points, n_dof))
         for c in extra_costs:
             if isinstance(c, CostCollision) and c.field is not None:
                 # an extra CostCollision is one more block of collision rows with K = I / sigma_e^2: chained as a further
                 # field whose share is (sigma_coll / sigma_e)^2 of the common 1 / sigma_coll^2
+                _same_problem(c, 'CostCollision')
                 collision_fields.append(c.field)
                 scales.append((sigma_coll / c.sigma_coll) ** 2)
-            elif isinstance(c, CostGP) and c.dt == dt and same(c.start_state, torch.cat((start_state, torch.zeros_like(start_state)))):
+            elif isinstance(c, CostGP):
+                _same_problem(c, 'CostGP')
+                if not math.isclose(float(c.dt), float(dt), rel_tol=1e-6, abs_tol=0.0):
+                    raise ValueError('GPMP2 extra_costs: the CostGP has dt=%r, the planner dt=%r' % (c.dt, dt))
+                if not same(c.start_state, torch.cat((start_state, torch.zeros_like(start_state)))):
+                    raise NotImplementedError('GPMP2 extra_costs: a CostGP on a start state other than the planner\'s own is not wired '
+                                              'into the block solve')
                 eff['start'], eff['gp'] = merge(eff['start'], c.sigma_start), merge(eff['gp'], c.sigma_gp)
-            elif isinstance(c, CostGoalPrior) and multi_goal_states is not None and \
-                    c.num_particles_per_goal == num_particles_per_goal and \
-                    same(c.multi_goal_states, torch.cat((multi_goal_states, torch.zeros_like(multi_goal_states)), dim=-1)):
+            elif isinstance(c, CostGoalPrior):
+                _same_problem(c, 'CostGoalPrior')
+                if multi_goal_states is None or c.num_particles_per_goal != num_particles_per_goal or \
+                        not same(c.multi_goal_states, torch.cat((multi_goal_states, torch.zeros_like(multi_goal_states)), dim=-1)):
+                    raise NotImplementedError('GPMP2 extra_costs: a CostGoalPrior is wired into the block solve on the planner\'s own goal '
+                                              'states and num_particles_per_goal only (num_samples does '
+                                              'not enter its get_linear_system, cost_functions.py:538-554)')
                 eff['goal'] = merge(eff['goal'], c.sigma_goal_prior)
             else:
                 raise NotImplementedError('GPMP2 extra_costs: a CostCollision, or a CostGP / CostGoalPrior on the planner\'s own '

@@ -6,6 +6,8 @@ bit-identical), buffer ownership, noise-source selection.  Device side: mpb_stom
 (csrc/mpb_kernels.hip) runs sample -> cost -> softmax -> covariance-weighted update for all
 ``opt_iters`` iterations without returning to Python.
 """
+import time
+
 import torch
 
 from .. import ops
@@ -36,6 +38,8 @@ def precision_to_scale_tril(P):
 
 
 _current_device = getattr(torch._C, '_cuda_getDevice', torch.cuda.current_device)     # (the raw getter: no lazy-init bookkeeping per call)
+_perf_counter = time.perf_counter
+_SYNC_SPIN_S = 1e-3          # check='sync': how long optimize() polls the stream before it blocks in the runtime
 
 
 class PersistentLaunchLost(MPBError):
@@ -53,7 +57,8 @@ class STOMP(OptimizationPlanner):
       seed / particle_offset: Philox key and global index of this shard's first particle.
       persistent: run a collision-only cost's loop as ONE persistent launch (mpb_stomp_run) where the shape allows it
              (default); False keeps the two-kernels-per-iteration path (mpb_stomp_step).
-      check: what happens when a persistent launch is LOST (include/mpb.h, "Failure contract": its workgroups wait for
+      check: (the default changed from 'deferred' to 'sync' with ABI 4: optimize() now waits for its launch -- it polls the
+             stream for at most 1 ms, then blocks in the runtime, GIL released.)  What happens when a persistent launch is LOST (include/mpb.h, "Failure contract": its workgroups wait for
              each other, every wait is bounded, and a wait that runs out -- the device stopped starting this launch's
              workgroups for seconds, e.g. another context holds every CU -- abandons the call).  'sync' (default):
              optimize() waits for the launch (host spin on an event, no sleep) and raises PersistentLaunchLost before it
@@ -196,8 +201,14 @@ class STOMP(OptimizationPlanner):
         if synchronize:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
-            while not ev.query():        # (host spin: the runtime's blocking wait wakes up tens of microseconds late)
-                pass
+            # host spin for a BOUNDED time (the runtime's blocking wait wakes up tens of microseconds late, which is what a
+            # short call feels), then the blocking wait: a long optimisation must not pin a core and hold the GIL against
+            # the caller's other threads (thread-per-GPU drivers, watchdogs) for its whole duration
+            t_end = _perf_counter() + _SYNC_SPIN_S
+            while not ev.query():
+                if _perf_counter() > t_end:
+                    ev.synchronize()     # (releases the GIL while it blocks)
+                    break
         lost = self._status.lost()
         if lost is not None:
             tag, why = lost

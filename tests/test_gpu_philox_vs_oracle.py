@@ -131,3 +131,82 @@ def test_device_noise_path_vs_oracle(gpu_device, P, S, H, pos_only, path):
     print('device noise, %s free-running %d iterations: global-max %.2e per-waypoint %.2e (reference fp32-vs-fp64 envelope %.2e)'
           % (tag, n_it, err, errw, env))
     assert err < max(REL, 2.0 * env)
+
+
+def test_mppi_device_noise_is_the_injected_path(gpu_device):
+    """MPPI's throughput-mode draw (Philox4x32-7 + box_muller_m23, csrc/mpb_mppi.hip) fetched through mpb_debug_mppi_normals
+    and INJECTED gives the same bits as the device draw (both feed the same fp32 matrix product), at the bench entry's shape;
+    and the oracle's sequential rollout (mppi.py:131-209, point.py:102-226) on those normals agrees on controls / states / costs
+    for every problem checked -- so what `mppi` times is under the oracle too."""
+    from motion_planning_baselines_amd import geometry as G, ops
+    from motion_planning_baselines_amd.planners.priors.gaussian import const_ctrl_Cov
+    from oracle import planners_ref as O
+    from oracle.geometry_ref import make_ref_geometry
+    dev = gpu_device
+    NP, S, T, c, n_it, seed, it0 = 64, 32, 64, 2, 2, 11, 5
+    ta = dict(device='cpu', dtype=torch.float32)
+    Cov = const_ctrl_Cov([0.3, 0.3], T, c, ta)
+    tril = torch.stack([torch.linalg.cholesky(Cov[..., i]) for i in range(c)]).contiguous()
+    cinv = torch.stack([torch.inverse(Cov[..., i]) for i in range(c)]).contiguous()
+    gen = torch.Generator().manual_seed(0)
+    state0 = torch.rand(NP, c, generator=gen) * 0.2 - 0.9
+    goal = torch.rand(NP, c, generator=gen) * 0.2 + 0.7
+    robot, field = G.RobotPointMass(2, radius=0.01), G.env_grid_circles_2d()
+    geom = ops.DeviceGeometry(robot, field, dev)
+    rr, rf = make_ref_geometry(robot, field, ta)
+    f = lambda t: t.contiguous().to(dev)
+    cmin, cmax, disc = torch.tensor([-1., -1.]), torch.tensor([1., 1.]), torch.ones(T)
+    cw = dict(pos=1.0, vel=1.0, ctrl=1.0, pos_T=100.0)
+    ks, wt, temp, step, dt = 1e6, 1.0, 1.0, 0.7, 0.04
+
+    def run(eps):
+        mean = torch.zeros(NP, T, c, device=dev)
+        out = [torch.empty(NP, S, T, c, device=dev), torch.empty(NP, S, T, c, device=dev), torch.empty(NP, S, device=dev),
+               torch.empty(NP, S, device=dev)]
+        ops.mppi_step(mean, eps, f(tril), f(cinv), f(state0), f(goal), f(cmin), f(cmax), f(disc), f(torch.tensor([1., 1., 1., 100.])),
+                      geom, *out, dt, k_sigma=ks, weight=wt, temp=temp, step_size=step, n_iters=n_it, seed=seed, iter0=it0)
+        torch.cuda.synchronize()
+        return [mean] + out
+    nrm = ops.debug_mppi_normals(NP, S, T, c, n_it, dev, seed=seed, iter0=it0)
+    torch.cuda.synchronize()
+    assert torch.isfinite(nrm).all() and float(nrm.abs().max()) <= 5.66 and abs(float(nrm.mean())) < 0.01 and abs(float(nrm.std()) - 1.0) < 0.01
+    drawn, injected = run(None), run(nrm)
+    for name, a, b in zip(('mean', 'controls', 'states', 'costs', 'weights'), drawn, injected):
+        assert torch.equal(a, b), name
+    eps = nrm.cpu()
+    for p in range(0, NP, 8):
+        m = torch.zeros(T, c)
+        for it in range(n_it):
+            pre = O.mppi_iteration(m, eps[it, p], tril, cinv, state0[p], goal[p], dt, cmin, cmax, cw, disc, temp, step, c)
+            q = pre['states'][:, 1:, :2]
+            shift = wt * ks * float(rf.compute_cost(q, rr.fk_map_collision(q)).sum())
+            out = O.mppi_iteration(m, eps[it, p], tril, cinv, state0[p], goal[p], dt, cmin, cmax, cw, disc, temp, step, c, shift_cost=shift)
+            m = out['mean']
+        assert _gmax(drawn[1][p], out['controls']) < 1e-5 and _gmax(drawn[2][p], out['states']) < 1e-5, p
+        assert _gmax(drawn[3][p], out['costs'].reshape(-1)) < 2e-5, p
+
+
+def test_stomp_entry_points_refuse_misaligned_pointers(gpu_device):
+    """eps / L / Sigma / means / samples are moved as 16-byte vectors; a view at a 4-byte offset is refused with
+    MPB_E_INVALID (include/mpb.h) instead of becoming misaligned dwordx4 accesses."""
+    from motion_planning_baselines_amd import ops
+    from motion_planning_baselines_amd._lib import MPBError
+    dev = gpu_device
+    P, S, H = 4, 8, 64
+    wl, Sigma, L, geom = _setup(dev, P, S, H, False)
+    d = wl['means0'].shape[-1]
+    samples, costs, weights = torch.empty(P, S, H, d, device=dev), torch.empty(P, S, device=dev), torch.empty(P, S, device=dev)
+    flat = torch.zeros(1 * S * d * P * H + 1, device=dev)
+    eps_off = flat[1:].view(1, S, d, P, H)
+    assert eps_off.is_contiguous() and eps_off.data_ptr() % 16 == 4
+    args = (samples, costs, weights, L.to(dev), Sigma.to(dev), geom, S, 7, 1.0, 1.0, 0.1, 1.0)
+    with pytest.raises(MPBError, match='16-byte aligned'):
+        ops.stomp_step(wl['means0'].clone(), eps_off, *args, n_iters=1)
+    ws = ops.stomp_workspace(P, S, H, d, dev)
+    with pytest.raises(MPBError, match='16-byte aligned'):
+        ops.stomp_run(wl['means0'].clone(), eps_off, *args, ws, n_iters=1)
+    with pytest.raises(MPBError, match='16-byte aligned'):
+        ops.stomp_sample(wl['means0'].clone(), eps_off[0], samples, L.to(dev), S)
+    # the aligned call goes through
+    ops.stomp_step(wl['means0'].clone(), torch.zeros(1, S, d, P, H, device=dev), *args, n_iters=1)
+    torch.cuda.synchronize()

@@ -430,3 +430,15 @@ def test_gpmp2_extra_trajectory_prior_cost(gpu_device, kind):
                        dict(sigma_start=1.0, sigma_gp=1.0), tensor_args=ta)
         with pytest.raises(NotImplementedError):
             _gpmp2_from_golden(g, dev, extra_costs=[other])
+        # a CostGP built for another horizon fails the reference at the row stacking: refused, not folded
+        longer = CostGP(robot, H + 1, torch.cat((T(g['start']).float().to(dev), z)), dt,
+                        dict(sigma_start=1.0, sigma_gp=1.0), tensor_args=ta)
+        with pytest.raises(ValueError):
+            _gpmp2_from_golden(g, dev, extra_costs=[longer])
+        with pytest.raises(ValueError):
+            _gpmp2_from_golden(g, dev, extra_costs=[CostGP(robot, H, torch.cat((T(g['start']).float().to(dev), z)), 2.0 * dt,
+                                                          dict(sigma_start=1.0, sigma_gp=1.0), tensor_args=ta)])
+        # a dt that differs by rounding is the same dt
+        near = CostGP(robot, H, torch.cat((T(g['start']).float().to(dev), z)), dt * (1.0 + 1e-9),
+                      dict(sigma_start=2.0 * float(g['sigma_start']), sigma_gp=0.5 * float(g['sigma_gp'])), tensor_args=ta)
+        assert _gpmp2_from_golden(g, dev, extra_costs=[near])[0].sigmas == pl.sigmas
