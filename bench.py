@@ -151,6 +151,105 @@ def stomp_parity(wl, L, Sigma, eps_parity, gpu, kept):
                        'the whole headline batch; GPU side: mpb_stomp_run_checked, persistent launch (path %d)' % gpu['path']}
 
 
+def stomp_parity_philox_gpu(wl, planner, cost, geom, n_it=2):
+    """GPU side of `parity.philox`: the code path the timed region runs -- device-drawn noise (eps = NULL: Philox4x32-7 +
+    Box-Muller, two-component bf16 split, 30-instruction matrix product) -- for the first n_it iterations of the headline
+    workload with the planner's own (seed, iter0 = 0, particle_offset), through mpb_stomp_run_checked; the normals the
+    kernels drew are fetched through the test aid mpb_debug_stomp_normals_h and (a) injected through the eps argument (the
+    three-component instantiation every golden test runs): the outputs must be the same BITS; (b) handed to the oracle
+    (stomp_parity_philox).  Untimed."""
+    from motion_planning_baselines_amd import ops
+    dev = wl['means0'].device
+    P, H, d = wl['means0'].shape
+    S = wl['params']['num_samples']
+    ws = ops.stomp_workspace(P, S, H, d, dev)
+    cc = cost.cost_l[0]
+    out = [torch.empty(P, S, H, d, device=dev), torch.empty(P, S, device=dev), torch.empty(P, S, device=dev)]
+
+    def run(n, eps):
+        means = wl['means0'].clone()
+        ops.stomp_run(means, eps, *out, planner.scale_tril, planner.Sigma, geom, S, 7, cc.k_sigma, 1.0, planner.lr, planner.temperature,
+                      ws, n_iters=n, seed=planner.seed, iter0=0, particle_offset=planner.particle_offset)
+        torch.cuda.synchronize()
+        assert not ops.stomp_run_timed_out(ws)
+        return [means.clone()] + [t.clone() for t in out]
+    nrm = ops.debug_stomp_normals(P, S, d, n_it, dev, seed=planner.seed, iter0=0, particle_offset=planner.particle_offset, H=H)
+    eps = nrm[..., :H].permute(0, 2, 3, 1, 4).contiguous()            # the reference's draw order (n_it, S, d, P, H)
+    first = run(1, None)                                              # samples of iteration 0: means0 + L @ normals[0]
+    noise = torch.einsum('hk,sdpk->pshd', planner.scale_tril.double(), eps[0].double())
+    noise[:, :, 0, :] = 0
+    noise[:, :, -1, :] = 0                                            # stomp.py:105-106
+    want = wl['means0'].double().unsqueeze(1) + noise
+    e_samples = float((first[1].double() - want).abs().max() / want.abs().max())
+    drawn, injected = run(n_it, None), run(n_it, eps)
+    same = all(torch.equal(a, b) for a, b in zip(drawn, injected))
+    return {'means': drawn[0].cpu(), 'costs': drawn[2].cpu(), 'eps': eps.cpu(), 'samples_vs_L_normals': e_samples,
+            'injected_same_bits': bool(same), 'path': ops.stomp_run_path(geom, ws, P, S, H, d)}
+
+
+def stomp_parity_philox(wl, L, Sigma, gpu):
+    """`parity.philox`: the device-noise path against the oracle on the normals the kernels drew (free running from the
+    initial means, the whole headline batch), next to the reference's own fp32-vs-fp64 envelope on the same normals."""
+    from oracle import planners_ref as O
+    from oracle.geometry_ref import make_ref_geometry
+    prm = wl['params']
+    outs = {}
+    for dtype in (torch.float32, torch.float64):
+        robot, field = make_ref_geometry(wl['robot'], wl['field'], dict(device='cpu', dtype=dtype))
+        m = wl['means0'].cpu().to(dtype)
+        for e in gpu['eps']:
+            out = O.stomp_iteration(m, e.to(dtype), L.to(dtype), Sigma.to(dtype), lambda x: O.collision_cost(x, robot, field, wl['sigma_coll']),
+                                    prm['step_size'], prm['temperature'])
+            m = out['means']
+        outs[dtype] = out
+    ref, ref64 = outs[torch.float32], outs[torch.float64]
+    gmax = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-12))
+    return {'iters': len(gpu['eps']), 'samples_vs_means_plus_L_normals_fp64': gpu['samples_vs_L_normals'],
+            'rel_err_means': gmax(gpu['means'], ref['means']), 'rel_err_means_per_waypoint': _per_waypoint(gpu['means'], ref['means']),
+            'rel_err_costs': gmax(gpu['costs'], ref['costs']),
+            'reference_fp32_vs_fp64_envelope_means': gmax(ref['means'], ref64['means']),
+            'injected_normals_same_bits': gpu['injected_same_bits'], 'bar': 1e-4,
+            'against': 'the TIMED instantiation (eps = NULL: device Philox draw, two-component bf16 split, 30-MFMA product; path %d): its '
+                       'drawn normals (mpb_debug_stomp_normals_h) fed to oracle/planners_ref.py stomp_iteration, free running; '
+                       '`injected_normals_same_bits`: the same normals through the eps argument (three-component instantiation) give '
+                       'bit-identical means / samples / costs / weights' % gpu['path']}
+
+
+def _per_waypoint(a, b, n_pos=7):
+    worst = 0.0
+    for sl in (slice(0, n_pos), slice(n_pos, a.shape[-1])):
+        if sl.start >= a.shape[-1]:
+            continue
+        nb = b[..., sl].double().norm(dim=-1)
+        den = nb.clamp_min(1e-2 * float(nb.max()))
+        worst = max(worst, float(((a[..., sl].double() - b[..., sl].double()).norm(dim=-1) / den).max()))
+    return worst
+
+
+def cpu_baseline_sample(wl, L, Sigma, n_particles, budget_s=6.0):
+    """The oracle's STOMP iteration on the FIRST n_particles particles of a workload (x its S samples), median seconds per
+    iteration over as many iterations as fit the budget (at least 2 after one warm-up)."""
+    from oracle import planners_ref as O
+    from oracle.geometry_ref import make_ref_geometry
+    ta = dict(device='cpu', dtype=torch.float32)
+    cores = cpu_threads()
+    prm = wl['params']
+    H, S, d = prm['n_support_points'], prm['num_samples'], wl['means0'].shape[-1]
+    robot, field = make_ref_geometry(wl['robot'], wl['field'], ta)
+    means = wl['means0'][:n_particles].cpu().clone()
+    ts, t_start = [], time.perf_counter()
+    for it in range(9):
+        t0 = time.perf_counter()
+        means = O.stomp_iteration(means, torch.empty(S, d, n_particles, H).normal_(), L, Sigma,
+                                  lambda x: O.collision_cost(x, robot, field, wl['sigma_coll']), prm['step_size'], prm['temperature'])['means']
+        if it > 0:
+            ts.append(time.perf_counter() - t0)
+        if len(ts) >= 2 and time.perf_counter() - t_start > budget_s:
+            break
+    ts.sort()
+    return ts[len(ts) // 2], cores, len(ts)
+
+
 class Clock:
     """R timed blocks of one callable, each bracketed by barrier + synchronize, MAX over the ranks.
 
@@ -247,13 +346,26 @@ def STOMP_two_kernel(wl, cost, dev, rank, P):
                  particle_offset=rank * P, persistent=False, check='deferred', **wl['params'])
 
 
-def run_stomp(planner, clock, dist, world, steps, warmup, repeats, preheat):
+def run_stomp(planner, clock, dist, world, steps, warmup, repeats, preheat, cold=False):
     """W untimed steps, then R blocks of EXACTLY `steps` steps (one C-ABI call = 2K launches) + the final gather."""
     # the final gather's destination: one flat (world * P, H, d) tensor (all_gather_into_tensor: one RCCL kernel, no
     # per-rank copy-out kernels)
     gathered = (torch.empty((world * planner._particle_means.shape[0],) + tuple(planner._particle_means.shape[1:]),
                             device=planner._particle_means.device) if dist is not None else None)
     means_init = planner._particle_means.clone()
+    run_stomp.cold_block_s = None
+    if cold and dist is None:
+        # `cold`: what `--preheat 0` would time as its FIRST block -- W warm-up steps (the first call into the library: workspace,
+        # plan, code object), then one K-step block from the initial means, bracketed like the timed blocks.  Untimed blocks of
+        # the protocol (pre-heat) come only after it.
+        planner.optimize(opt_iters=warmup)
+        planner._particle_means.copy_(means_init)
+        clock.barrier()
+        t0 = time.perf_counter()
+        planner.optimize(opt_iters=steps)
+        clock.barrier(spin=True)
+        run_stomp.cold_block_s = time.perf_counter() - t0
+        planner._particle_means.copy_(means_init)
     if preheat:
         # device pre-heat (untimed set-up, not part of W or K): `preheat` untimed blocks of the very shape that is timed below
         # (K steps from the initial means, synchronize).  The chip is power-managed: right after ONE long launch (round 2's
@@ -474,7 +586,7 @@ def bench_c4(dev, steps, with_cpu=True):
     return out
 
 
-def bench_h128(dev, steps):
+def bench_h128(dev, steps, with_cpu=True):
     """STOMP at H = 128 (two 64-waypoint chunks per rollout), P = 128, S = 32, d = 14: the generalised persistent kernel
     (csrc/mpb_stomp_fused_hx.hip) next to the two-kernel path."""
     from motion_planning_baselines_amd import ops
@@ -499,14 +611,32 @@ def bench_h128(dev, steps):
     two = STOMP_two_kernel(wl, cost, dev, 0, 128)
     two.optimize(opt_iters=steps)
     t2 = timed(two, steps)
-    return {'workload': 'panda_spheres STOMP B=4096 (P=128 x S=32) H=128 D=7 d=14, %d iterations per call' % steps,
-            'metric': 'stomp_trajectory_update_iters_per_sec', 'value': steps / t, 'unit': 'iters/s', 'ms_per_step': 1e3 * t / steps,
-            'path': {ops.STOMP_PATH_TWO_KERNEL: 'two-kernel', ops.STOMP_PATH_PERSISTENT_EXCHANGE: 'persistent (exchange)',
-                     ops.STOMP_PATH_PERSISTENT: 'persistent'}[path],
-            'two_kernel_path_ms_per_step': 1e3 * t2 / steps, 'dtype': 'f32'}
+    P, S, H, d = 128, 32, 128, wl['means0'].shape[-1]
+    it_s = t / steps
+    alg = 4 * (P * S * H * d + 2 * P * S)                  # per iteration of the persistent launch: samples, costs, weights written
+    roof = {'bound': 'hbm', 'achieved': alg / it_s / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': alg / it_s / 1e9 / HBM_PEAK_GBS,
+            'algorithmic_bytes_per_launch': alg, 'traffic': None}
+    pmc, pmc_file = latest_profile('r*_pmc_stomp_h128.json')
+    if pmc and pmc.get('SQ_INSTS_VALU_per_wave_iteration') and pmc.get('waves_per_launch'):
+        gi = pmc['SQ_INSTS_VALU_per_wave_iteration'] * pmc['waves_per_launch'] / it_s / 1e9
+        roof = {'bound': 'valu', 'achieved': gi, 'peak': VALU_PEAK_GINSTR, 'unit': 'G wave-instr/s', 'frac': gi / VALU_PEAK_GINSTR,
+                'valu_instructions_per_wave_iteration': pmc['SQ_INSTS_VALU_per_wave_iteration'], 'waves_per_launch': pmc['waves_per_launch'],
+                'mfma_instructions_per_wave_iteration': pmc.get('SQ_INSTS_MFMA_per_wave_iteration'),
+                'kernel': pmc.get('kernel'), 'pmc_source': pmc_file, 'traffic': pmc.get('hbm_bytes_per_iteration'), 'hbm': roof}
+    out = {'workload': 'panda_spheres STOMP B=4096 (P=128 x S=32) H=128 D=7 d=14, %d iterations per call' % steps,
+           'metric': 'stomp_trajectory_update_iters_per_sec', 'value': steps / t, 'unit': 'iters/s', 'ms_per_step': 1e3 * t / steps,
+           'path': {ops.STOMP_PATH_TWO_KERNEL: 'two-kernel', ops.STOMP_PATH_PERSISTENT_EXCHANGE: 'persistent (exchange)',
+                    ops.STOMP_PATH_PERSISTENT: 'persistent'}[path],
+           'two_kernel_path_ms_per_step': 1e3 * t2 / steps, 'dtype': 'f32', 'roofline': roof}
+    if with_cpu:
+        tc, cores, nit = cpu_baseline_sample(wl, pl.scale_tril.cpu(), pl.Sigma.cpu(), P)
+        out['cpu_baseline'] = {'value': 1.0 / tc, 'unit': 'iters/s', 'cores': cores, 'kind': 'port',
+                               'sample': 'oracle stomp_iteration on the full workload (P=%d x S=%d, H=%d), median of %d iterations = %.3f s'
+                                         % (P, S, H, nit, tc)}
+    return out
 
 
-def bench_mppi(dev, steps, NP=1024):
+def bench_mppi(dev, steps, NP=1024, with_cpu=True):
     """MPPI on NP independent point-mass problems (S = 32 control samples, T = 64 steps, c = 2; the reference example's
     shape, examples/pointmass_grid_circles_2d_MPPI.py:58-67) with the collision shift: one workgroup per problem."""
     from motion_planning_baselines_amd import geometry as G, ops
@@ -550,10 +680,56 @@ def bench_mppi(dev, steps, NP=1024):
                 'lds_bank_conflict_frac_of_lds_cycles': (pmc['SQ_LDS_BANK_CONFLICT_per_wave_iteration'] / pmc['SQ_LDS_IDX_ACTIVE_per_wave_iteration']
                                                          if pmc.get('SQ_LDS_IDX_ACTIVE_per_wave_iteration') else None),
                 'scratch_bytes_per_lane': pmc.get('scratch_bytes'), 'hbm_nominal': roof}
-    return {'workload': 'MPPI point mass, %d problems x S=%d samples x T=%d steps x c=%d, %d iterations per launch' % (NP, S, T, c, steps),
-            'metric': 'mppi_problem_iterations_per_sec', 'value': NP * steps / t, 'unit': 'problem-iters/s',
-            'ms_per_step': 1e3 * t / steps, 'us_per_problem_iteration': 1e6 * t / steps / NP, 'dtype': 'f32',
-            'roofline': roof}
+    out = {'workload': 'MPPI point mass, %d problems x S=%d samples x T=%d steps x c=%d, %d iterations per launch' % (NP, S, T, c, steps),
+           'metric': 'mppi_problem_iterations_per_sec', 'value': NP * steps / t, 'unit': 'problem-iters/s',
+           'ms_per_step': 1e3 * t / steps, 'us_per_problem_iteration': 1e6 * t / steps / NP, 'dtype': 'f32',
+           'roofline': roof}
+    if with_cpu:
+        # CPU: the oracle's sequential rollout (mppi.py:131-209, point.py:102-226, quirk Q6: two passes per iteration, the first
+        # for the collision shift) on the first 32 problems, one after the other as the reference class would run them
+        from oracle import planners_ref as O
+        from oracle.geometry_ref import make_ref_geometry
+        cores = cpu_threads()
+        cta = dict(device='cpu', dtype=torch.float32)
+        rr, rf = make_ref_geometry(G.RobotPointMass(2, radius=0.01), G.env_grid_circles_2d(), cta)
+        trc, cic, s0c, glc = tril.cpu(), cinv.cpu(), state0.cpu(), goal.cpu()
+        cmin, cmax, disc = torch.tensor([-1., -1.]), torch.tensor([1., 1.]), torch.ones(T)
+        cw = dict(pos=1.0, vel=1.0, ctrl=1.0, pos_T=100.0)
+        n_cpu, t0 = 32, None
+        for p in range(n_cpu + 2):
+            if p == 2:
+                t0 = time.perf_counter()             # (two untimed problems first)
+            e = torch.randn(c, S, T)
+            m = torch.zeros(T, c)
+            pre = O.mppi_iteration(m, e, trc, cic, s0c[p], glc[p], 0.04, cmin, cmax, cw, disc, 1.0, 0.7, c)
+            q = pre['states'][:, 1:, :2]
+            shift = 1e6 * float(rf.compute_cost(q, rr.fk_map_collision(q)).sum())
+            O.mppi_iteration(m, e, trc, cic, s0c[p], glc[p], 0.04, cmin, cmax, cw, disc, 1.0, 0.7, c, shift_cost=shift)
+        tc = (time.perf_counter() - t0) / n_cpu
+        out['cpu_baseline'] = {'value': 1.0 / tc, 'unit': 'problem-iters/s', 'cores': cores, 'kind': 'port',
+                               'sample': 'oracle mppi_iteration (sequential rollout + collision shift) on %d problems x S=%d, one iteration '
+                                         'each, one problem after the other: %.4f s per problem-iteration' % (n_cpu, S, tc)}
+    return out
+
+
+def visible_gpu_count():
+    """GPUs this process could use, WITHOUT touching the GPU (no HIP call, no torch.cuda call): the KFD topology nodes with
+    SIMDs (CPU nodes have simd_count 0), cut down by a *_VISIBLE_DEVICES list if one is set.  None when the topology cannot be read."""
+    root = '/sys/class/kfd/kfd/topology/nodes'
+    try:
+        n = 0
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, 'properties')) as fh:
+                props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+            if int(props.get('simd_count', '0')) > 0:
+                n += 1
+    except (OSError, ValueError):
+        return None
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != '':
+            n = min(n, len([x for x in v.split(',') if x.strip() != '']))
+    return n
 
 
 def self_launch(n):
@@ -563,6 +739,15 @@ def self_launch(n):
     and returns the launcher's exit code (non-zero if any rank failed)."""
     import socket
     import subprocess
+    backend = os.environ.get('MPB_DIST_BACKEND', 'nccl')
+    have = visible_gpu_count()
+    if backend == 'nccl' and have is not None and have < n:
+        # (RCCL: one rank per GPU.  Said here, before any rank starts, rather than as N tracebacks from set_device)
+        print('bench.py: --gpus %d but this node shows %d GPU(s) (KFD topology%s); run with --gpus <= %d, or with MPB_DIST_BACKEND=gloo '
+              'to rehearse several ranks on one GPU' % (n, have, ', *_VISIBLE_DEVICES applied' if any(
+                  os.environ.get(v) for v in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES')) else '', max(have, 1)),
+              file=sys.stderr, flush=True)
+        return 2
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
@@ -622,7 +807,8 @@ def main():
     prm = wl['params']
     H, d, D = prm['n_support_points'], wl['means0'].shape[-1], 7
     preheat = args.preheat if args.preheat >= 0 else max(8, min(60, 1200 // max(args.steps, 1)))
-    blocks = run_stomp(planner, clock, dist, world, args.steps, args.warmup, args.repeats, preheat=preheat)
+    blocks = run_stomp(planner, clock, dist, world, args.steps, args.warmup, args.repeats, preheat=preheat, cold=not args.main_only)
+    cold_block_s = run_stomp.cold_block_s
     elapsed, sp = spread(blocks, args.steps)
     timed_launch_ms = run_stomp.launch_ms[len(run_stomp.launch_ms) // 2]    # median over the R event-timed launches
     span = run_stomp.device_span_ms
@@ -742,12 +928,40 @@ def main():
                  'kernel_ms_iterations_%d_to_%d' % (n_prof, 2 * n_prof): later_ms,
                  'two_kernel_path_ms_per_step': two_ms, 'two_kernel_path_iters_per_sec': (1e3 / two_ms) if two_ms else None})
 
+    # ---- `k1`: the reference examples' calling pattern -- ONE iteration per optimize() call, each call waited for
+    # (check='sync', the planner's default; examples/pointmass_grid_circles_2d_STOMP.py:104-106: `for i in range(opt_iters):
+    # trajs = planner.optimize(opt_iters=1)`): every iteration pays the launch, the constants into LDS and the host side of a call
+    k1 = None
+    if not args.main_only and world == 1:
+        n_k1 = 300
+        planner.check = 'sync'
+        for _ in range(20):
+            planner.optimize(opt_iters=1)
+        ts = []
+        for _ in range(3):
+            planner._particle_means.copy_(means_init)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n_k1):
+                planner.optimize(opt_iters=1)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / n_k1)
+        planner.check = 'deferred'
+        t1 = sorted(ts)[1]
+        k1 = {'value': 1.0 / t1, 'unit': 'iters/s', 'ms_per_call': 1e3 * t1, 'calls': n_k1, 'check': 'sync',
+              'clears_10k_target': bool(1.0 / t1 >= 1e4),
+              'note': 'one STOMP iteration per optimize() call, every call waited for before the next (the loop of the reference\'s '
+                      'examples, examples/pointmass_grid_circles_2d_STOMP.py:104-106): ms_per_call = one steady iteration + '
+                      '`roofline.launch_fixed_ms` (launch + constants into LDS + first draw, t(1) - (t(2) - t(1)) on stream events) + the host '
+                      'side of a call (Python + ctypes + the wait); `value` of the main line amortises that fixed part over K steps'}
+
     # ---- parity of the headline workload against the oracle (GPU side here, untimed; the oracle side rides on the CPU baseline)
-    par_gpu = eps_parity = None
+    par_gpu = eps_parity = par_philox_gpu = None
     consts = (planner.scale_tril.cpu(), planner.Sigma.cpu())
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.main_only:
         eps_parity = torch.randn(2, S, d, P, H, generator=torch.Generator().manual_seed(1234))
         par_gpu = stomp_parity_gpu(wl, planner, cost, geom, eps_parity)
+        par_philox_gpu = stomp_parity_philox_gpu(wl, planner, cost, geom)
 
     # ---- BASELINE configs[4]'s per-GPU load with the same protocol (every N)
     c5 = None
@@ -765,6 +979,26 @@ def main():
               'steps': k5, 'ms_per_step': 1e3 * el5 / k5, 'repeats': sp5, 'scaling': 'weak',
               'particle_updates_per_sec': world * P5 * k5 / el5, 'rollouts_per_sec': world * P5 * S * k5 / el5,
               'hbm_frac': stomp_algorithmic_bytes(P5, S, H, d) * k5 / el5 / 1e9 / HBM_PEAK_GBS}
+        # its roofline: the two-batch instantiation stomp_fused_kernel<d, model, 2> has its own PMC passes (scripts/profile_c5.sh)
+        it5 = el5 / k5
+        alg5 = 4 * (P5 * S * H * d + 2 * P5 * S)          # per iteration of the persistent launch (means / constants stay in LDS)
+        roof5 = {'bound': 'hbm', 'achieved': alg5 / it5 / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': alg5 / it5 / 1e9 / HBM_PEAK_GBS,
+                 'algorithmic_bytes_per_launch': alg5, 'traffic': None}
+        pmc5, pmc5_file = latest_profile('r*_pmc_stomp_c5.json')
+        if pmc5 and pmc5.get('SQ_INSTS_VALU_per_wave_iteration') and pmc5.get('waves_per_launch') and not args.pos_only:
+            # waves of a launch x iterations: a wave of the two-batch layout runs TWO rollouts per iteration
+            gi5 = pmc5['SQ_INSTS_VALU_per_wave_iteration'] * pmc5['waves_per_launch'] / it5 / 1e9
+            roof5 = {'bound': 'valu', 'achieved': gi5, 'peak': VALU_PEAK_GINSTR, 'unit': 'G wave-instr/s', 'frac': gi5 / VALU_PEAK_GINSTR,
+                     'valu_instructions_per_wave_iteration': pmc5['SQ_INSTS_VALU_per_wave_iteration'], 'waves_per_launch': pmc5['waves_per_launch'],
+                     'kernel': pmc5.get('kernel'), 'pmc_source': pmc5_file, 'traffic': pmc5.get('hbm_bytes_per_iteration'), 'hbm': roof5}
+        c5['roofline'] = roof5
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            n5 = 128
+            t5, cores5, nit5 = cpu_baseline_sample(wl5, pl5.scale_tril.cpu(), pl5.Sigma.cpu(), n5)
+            c5['cpu_baseline'] = {'value': 1.0 / (t5 * (P5 / n5)), 'unit': 'iters/s', 'cores': cores5, 'kind': 'port', 'extrapolated': True,
+                                  'sample': 'oracle stomp_iteration on the first %d of the %d particles (x S=%d), median of %d iterations = '
+                                            '%.3f s, scaled x%d (particles are independent: the oracle\'s cost is linear in P)'
+                                            % (n5, P5, S, nit5, t5, P5 // n5)}
         del pl5, cost5, wl5
         torch.cuda.empty_cache()
 
@@ -795,12 +1029,20 @@ def main():
                             'block (it completes on no rank before every rank has contributed, i.e. finished its K steps; the host spins on an '
                             'event behind it, then synchronizes); the opening barrier (all_reduce of one element) and the all_reduce(MAX) of '
                             'the clock are outside'}
+        if cold_block_s is not None:
+            line['cold'] = {'ms_per_step': 1e3 * cold_block_s / args.steps, 'value': args.steps / cold_block_s, 'unit': 'iters/s',
+                            'note': 'the FIRST timed K-step block of the process with no pre-heat (what `--preheat 0` times first): only '
+                                    'the W warm-up steps precede it; the main line is the steady state after `preheat.untimed_blocks` such blocks'}
+        if k1 is not None:
+            line['k1'] = k1
         if c5 is not None:
             line['c5'] = c5
         if world == 1 and not args.no_cpu_baseline:
             med, cores, n_it, kept = cpu_baseline_stomp(wl, consts[0], consts[1], eps_parity if eps_parity is not None else [])
             if par_gpu is not None:
                 line['parity'] = stomp_parity(wl, consts[0], consts[1], eps_parity, par_gpu, kept)
+            if par_philox_gpu is not None:
+                line.setdefault('parity', {})['philox'] = stomp_parity_philox(wl, consts[0], consts[1], par_philox_gpu)
             line['cpu_baseline'] = {
                 'value': 1.0 / med, 'unit': 'iters/s', 'cores': cores, 'kind': 'port',
                 'sample': 'oracle/planners_ref.py stomp_iteration (PyTorch-CPU restatement of stomp.py:157-160 + build-defined '
@@ -809,8 +1051,8 @@ def main():
         if world == 1 and not args.no_other_configs and not args.main_only:
             line['c2'] = bench_c2(dev, 500, with_cpu=not args.no_cpu_baseline)
             line['c4'] = bench_c4(dev, 10, with_cpu=not args.no_cpu_baseline)
-            line['h128'] = bench_h128(dev, 50)
-            line['mppi'] = bench_mppi(dev, 50)
+            line['h128'] = bench_h128(dev, 50, with_cpu=not args.no_cpu_baseline)
+            line['mppi'] = bench_mppi(dev, 50, with_cpu=not args.no_cpu_baseline)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

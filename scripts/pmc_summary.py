@@ -91,16 +91,20 @@ with open(os.path.join(prof, f'{tag}_pmc_per_wave.md'), 'w') as fh:
     fh.write('\n'.join(lines))
 
 # the persistent STOMP kernel: one launch = MPB_ITERS iterations (scripts/profile_round.sh); per-iteration figures
-kf = [k for k in summary if 'stomp_fused_kernel' in k]
+# (MPB_PMC_NAME: which entry of the bench line the passes were taken for -- 'stomp' = the headline (C3), 'stomp_c5' = its
+#  two-batch instantiation at 4096 particles (scripts/profile_c5.sh), 'stomp_h128' = the generalised kernel at H = 128
+#  (scripts/profile_h128.sh); MPB_PMC_WORKLOAD describes the launches)
+kf = [k for k in summary if 'stomp_fused_kernel' in k or 'stomp_fused_hx_kernel' in k]
 if kf:
     import re
     k = kf[0]
     s = summary[k]
     waves = grid[k][0] // 64
     iters = int(os.environ.get('MPB_ITERS', 200))
+    pmc_name = os.environ.get('MPB_PMC_NAME', 'stomp')
     fetch_kb, write_kb = s.get('FETCH_SIZE'), s.get('WRITE_SIZE')
     per = lambda c: (s[c] / waves / iters) if c in s else None
-    out = {'kernel': re.sub(r'\(.*', '', k), 'workload': 'C3 P=128 S=32 H=64 d=14: bench.py\'s planner, launches of %d iterations from the initial means (scripts/prof_stomp.py, MPB_FUSED=1)' % iters,
+    out = {'kernel': re.sub(r'\(.*', '', k), 'workload': os.environ.get('MPB_PMC_WORKLOAD', 'C3 P=128 S=32 H=64 d=14') + ': bench.py\'s planner, launches of %d iterations from the initial means (scripts/prof_stomp.py, MPB_FUSED=1)' % iters,
            'waves_per_launch': waves, 'iterations_per_launch': iters, 'vgpr': grid[k][2], 'sgpr': grid[k][3], 'lds_bytes': grid[k][4],
            'scratch_bytes': grid[k][5],
            'SQ_INSTS_VALU_per_wave_iteration': per('SQ_INSTS_VALU'), 'SQ_INSTS_SALU_per_wave_iteration': per('SQ_INSTS_SALU'),
@@ -120,7 +124,10 @@ if kf:
     if 'SQ_VALU_MFMA_COEXEC_CYCLES' in s:
         out['SQ_VALU_MFMA_COEXEC_CYCLES_per_launch'] = s['SQ_VALU_MFMA_COEXEC_CYCLES']
         out['SQ_VALU_MFMA_BUSY_CYCLES_per_launch'] = s.get('SQ_VALU_MFMA_BUSY_CYCLES')
-    with open(os.path.join(prof, f'{tag}_pmc_stomp.json'), 'w') as fh:
+    for c in ('SQ_ACTIVE_INST_VALU', 'SQ_INSTS_BRANCH', 'SQ_LDS_BANK_CONFLICT', 'SQ_LDS_IDX_ACTIVE', 'SQ_INSTS_SMEM', 'SQ_INSTS_VMEM', 'SQ_ACTIVE_INST_SCA'):
+        if c in s:
+            out[c + '_per_wave_iteration'] = per(c)
+    with open(os.path.join(prof, f'{tag}_pmc_{pmc_name}.json'), 'w') as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps(out, indent=1))
 

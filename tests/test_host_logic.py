@@ -415,6 +415,8 @@ def test_bench_self_launch_command(monkeypatch):
     monkeypatch.setattr(subprocess, 'run', fake_run)
     monkeypatch.setattr(torch.cuda, 'set_device', lambda *a, **k: (_ for _ in ()).throw(AssertionError('GPU touched before the launch')))
     monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.delenv('MPB_DIST_BACKEND', raising=False)
+    monkeypatch.setattr(bench, 'visible_gpu_count', lambda: 8)
     monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '20', '--warmup', '5'])
     with pytest.raises(SystemExit) as e:
         bench.main()
@@ -424,6 +426,52 @@ def test_bench_self_launch_command(monkeypatch):
     assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and int(cmd[cmd.index('--master-port') + 1]) > 0
     assert cmd[-6:] == ['--gpus', '4', '--steps', '20', '--warmup', '5'] and cmd[-7].endswith('bench.py')
     assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+
+
+def test_bench_self_launch_preflight(monkeypatch, capsys, tmp_path):
+    """`python bench.py --gpus N` on a node that shows fewer than N GPUs says so and exits non-zero BEFORE
+    it starts a rank (and without touching the GPU: the count comes from the KFD topology); a gloo rehearsal (several ranks on
+    one GPU) and an unreadable topology are let through."""
+    import subprocess
+    import bench
+    started = []
+    monkeypatch.setattr(subprocess, 'run', lambda cmd, env=None, **kw: started.append(cmd) or subprocess.CompletedProcess(cmd, 0))
+    monkeypatch.setattr(torch.cuda, 'set_device', lambda *a, **k: (_ for _ in ()).throw(AssertionError('GPU touched before the launch')))
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.delenv('MPB_DIST_BACKEND', raising=False)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '8', '--steps', '20', '--warmup', '5'])
+    monkeypatch.setattr(bench, 'visible_gpu_count', lambda: 1)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 2 and not started
+    err = capsys.readouterr().err
+    assert '--gpus 8' in err and '1 GPU' in err
+    monkeypatch.setenv('MPB_DIST_BACKEND', 'gloo')                       # rehearsal: ranks share GPUs
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0 and len(started) == 1
+    monkeypatch.delenv('MPB_DIST_BACKEND')
+    monkeypatch.setattr(bench, 'visible_gpu_count', lambda: None)        # topology unreadable: the ranks will say what is wrong
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0 and len(started) == 2
+    # the count itself: nodes with SIMDs only, cut down by a *_VISIBLE_DEVICES list
+    import builtins
+    import os as _os
+    nodes = tmp_path / 'nodes'
+    for i, simd in enumerate((0, 0, 256, 256, 256)):
+        (nodes / str(i)).mkdir(parents=True)
+        (nodes / str(i) / 'properties').write_text('cpu_cores_count %d\nsimd_count %d\n' % (0 if simd else 64, simd))
+    monkeypatch.undo()
+    real_listdir, real_open = _os.listdir, builtins.open
+    root = '/sys/class/kfd/kfd/topology/nodes'
+    monkeypatch.setattr(_os, 'listdir', lambda p: real_listdir(str(nodes)) if p == root else real_listdir(p))
+    monkeypatch.setattr(builtins, 'open', lambda f, *a, **k: real_open(str(f).replace(root, str(nodes)), *a, **k))
+    for v in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        monkeypatch.delenv(v, raising=False)
+    assert bench.visible_gpu_count() == 3
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0,2')
+    assert bench.visible_gpu_count() == 2
 
 
 def test_headline_kernels_have_no_scratch():
