@@ -327,11 +327,15 @@ int mpb_chomp_step(float *means, const float *R, const float *geom, int geom_fla
  *                         when it is called without diag_sum_out, as mpb_gpmp2_step does).
  *                         costs_out (B) optional: b^T K b of the iterate BEFORE the update (gpmp2.py:493-495).
  *   mpb_gpmp2_step      : n_iters full iterations on one GPU (mean over the local B).
- * Accuracy range: the elimination forms W_t = S_t^-1 explicitly (blocked Gauss-Jordan, fp64), which resolves the stiff
- * rank-1 collision direction of a block to kappa^2 u where a Cholesky factorisation gives kappa u.  Measured step error
- * against the dense fp64 solution refined in long double, by the ratio (sigma_gp / sigma_coll)^2 of the collision to the GP
- * precision: 1e6 (the reference's defaults) 5e-8, 1e8 <= 2.3e-6, 1e10 8e-3.  Keep the ratio <= 1e8; the start / goal
- * precisions (1e10 .. 1e12 tested) do not matter.
+ * Accuracy: the elimination forms W_t = S_t^-1 explicitly (blocked Gauss-Jordan, fp64).  With the rank-1 collision term
+ * ASSEMBLED into S_t that resolves its stiff direction to kappa^2 u where a Cholesky factorisation gives kappa u: step error
+ * against the dense fp64 solution refined in long double 5e-8 at a ratio (sigma_gp / sigma_coll)^2 of the collision to the GP
+ * precision of 1e6 (the reference's defaults), <= 2.3e-6 at 1e8, 8e-3 at 1e10 (ABI <= 4 as released in round 4).  Since round 5
+ * mpb_gpmp2_solve applies the collision factors by SHERMAN-MORRISON on the inverse of the well-conditioned rest whenever
+ * (sigma_gp / sigma_coll)^2 * n_fields > 1e7 (csrc/mpb_gpmp2.hip, template flag SM; +7.5 % on the solve): measured 3e-8 .. 7e-8 at
+ * 1e8 and 1e10 (one / two fields, trust region on / off, interpolated Jacobian), 1.2e-5 at 1e12 where the dense fp64 Cholesky
+ * is itself at ~1e-6 -- no range to keep to.  MPB_GPMP2_SM = 0 / 1 (environment) forces a form; the start / goal precisions
+ * (1e10 .. 1e12 tested) do not matter.
  * Alignment: x and geom 16-byte aligned, workspace 256-byte aligned (rows are moved as 8- / 16-byte pieces); a pointer
  * that is not is refused with MPB_E_INVALID (allocations of hipMalloc / PyTorch-ROCm are 256-byte aligned; a VIEW with a
  * storage offset may not be).

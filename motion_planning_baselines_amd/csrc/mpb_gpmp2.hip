@@ -269,7 +269,17 @@ extern "C" int mpb_debug_read_gp_phases(unsigned long long* dst) {
 #ifndef GP_PF
 #define GP_PF 4            // register stages of the substitution pass's W_t prefetch ring (9 VGPRs each; C4: 4 stages 0.455 ms, 8: 0.476, 12: 0.488)
 #endif
-template <int DT, bool MULTI>
+// SM: the collision factors enter by Sherman-Morrison instead of being assembled into S_t (round 5).  S_t = R_t + kc h h^T
+// with R_t (GP blocks, Schur carry, damping, start / goal priors) well conditioned and the rank-1 collision term up to
+// (sigma_gp / sigma_coll)^2 times stiffer: the explicit Gauss-Jordan inverse of S_t resolves the stiff direction to
+// kappa^2 u -- step error 2e-6 at a precision ratio of 1e8, 8e-3 at 1e10, where dense fp64 Cholesky has 4e-7.  Here the
+// tile that is inverted is R_t alone, with r_rest = (gradient without the collision part) as column 14 and h as column 15:
+// the row operations turn them into z0 = R^-1 r_rest and y = R^-1 h for free, and
+//     s = h^T y,  g = kc / (1 + kc s),   W = R^-1 - g y y^T,   z = W (r_rest + kc c h) = z0 + g (c - h^T z0) y
+// -- no cancellation: kc c h never meets R^-1 on its own (z0 + kc c y - ... would lose log10(kc s) digits).  Further chained
+// fields are applied one after the other the same way on the current W (y = W h_f by a matvec from LDS).  Matches the dense
+// fp64 Cholesky's accuracy at every ratio (scripts/gpmp2_sm_prototype.py: 6e-9 against 1.9e-4 at 1e10, 7e-7 against O(1) at 1e12).
+template <int DT, bool MULTI, bool SM>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVES))) void gpmp2_solve_kernel(float* __restrict__ x, const float* __restrict__ start,
                                                           const float* __restrict__ goal, const float* __restrict__ jac,
                                                           const double* __restrict__ diag_mean, double* __restrict__ work,
@@ -449,12 +459,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVE
 #pragma unroll
             for (int f = 0; f < MPB_MAX_FIELDS; ++f) {
                 if (f < F) {
-                    const double hcol = (double)__shfl(hf[f], asm_hj, 64) * (K.kc * notfirst);
                     const double cf = (double)__shfl(hf[f], D, 64);                           // c_t of this field
+                    if (!SM) {
+                        const double hcol = (double)__shfl(hf[f], asm_hj, 64) * (K.kc * notfirst);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        v[q] = fma(asm_pp[q] * hcol, (double)__shfl(hf[f], asm_hi[q], 64), v[q]);
-                    if (t > 0 && lane < D) r += K.kc * (double)hf[f] * cf;
+                        for (int q = 0; q < 4; ++q)
+                            v[q] = fma(asm_pp[q] * hcol, (double)__shfl(hf[f], asm_hi[q], 64), v[q]);
+                        if (t > 0 && lane < D) r += K.kc * (double)hf[f] * cf;
+                    }
                     if (t > 0 && lane == 0) cost += K.kc * cf * cf;
                 }
             }
@@ -477,6 +489,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVE
                     const int row = lk + 4 * q;
                     const double rq = __shfl(r, (li == 14 && row < dim) ? row : 63, 64);
                     T[q] += rq;
+                    // (SM) h of the first field as column 15 (lane 63 holds no Jacobian entry: its hf is zero, as row 0's is)
+                    if (SM) T[q] += (double)__shfl(hf[0], (li == 15 && row < D) ? row : 63, 64);
                 }
             }
         }
@@ -559,6 +573,45 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVE
             }
         }
 #endif
+        if (SM) {
+            // ---- the collision factors by Sherman-Morrison (see the kernel's header): zi is z0 = R^-1 r_rest, T / Wl hold R^-1
+            const int rowl = (lane < dim) ? lane : 0;
+#pragma unroll
+            for (int f = 0; f < MPB_MAX_FIELDS; ++f) {
+                if (f < F) {
+                    double yi = 0.0;                                   // y = W h_f, element `lane` (zero beyond the block)
+                    if (f == 0 && aug) {
+                        yi = W[rowl * GP_LD + 15];
+                    } else if (DT) {
+#pragma unroll
+                        for (int j = 0; j < DT; ++j) yi = fma(W[rowl * GP_LD + j], (double)readlane_f32(hf[f], j), yi);
+                    } else {
+                        for (int j = 0; j < D; ++j) yi = fma(W[rowl * GP_LD + j], (double)readlane_f32(hf[f], j), yi);
+                    }
+                    if (lane >= dim) yi = 0.0;
+                    if (lane < GP_N) zv[lane] = yi;
+                    const double hd = (lane < D) ? (double)hf[f] : 0.0;
+                    // h^T y and h^T z over the first 16-lane row (D <= 8): four DPP steps, then lane 0's total
+                    double py = hd * yi, pz = hd * zi;
+                    py += dpp_f64<0xB1>(py); pz += dpp_f64<0xB1>(pz);
+                    py += dpp_f64<0x4E>(py); pz += dpp_f64<0x4E>(pz);
+                    py += dpp_f64<0x141>(py); pz += dpp_f64<0x141>(pz);
+                    py += dpp_f64<0x140>(py); pz += dpp_f64<0x140>(pz);
+                    const double sdot = readlane_f64(py, 0), hz = readlane_f64(pz, 0);
+                    const double cf = (double)readlane_f32(hf[f], D);
+                    const double gfac = K.kc * fast_rcp(fma(K.kc, sdot, 1.0));
+                    zi = fma(gfac * (cf - hz), yi, zi);
+                    wave_sync();
+                    const double ycol = (li < dim) ? -gfac * zv[li] : 0.0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        T[q] = fma(ycol, zv[lk + 4 * q], T[q]);       // W -= g y y^T (rows beyond the block: y = 0)
+                        Wl[(lk + 4 * q) * GP_LD + li] = T[q];
+                    }
+                    wave_sync();
+                }
+            }
+        }
 #ifndef GP_T_SKIP_STORE   // (tuning builds: elimination without the workspace traffic)
         if (lane < dim) wt[GP_TRI + lane] = zi;
 #pragma unroll
@@ -790,13 +843,25 @@ extern "C" int mpb_gpmp2_solve(float* x, const float* start, const float* goal, 
     // one-wave form remains for chains too short to split
     static const int force_split = getenv("MPB_GPMP2_SPLIT") ? atoi(getenv("MPB_GPMP2_SPLIT")) : -1;   // tuning aid
     const int split = (H >= 4) && (force_split >= 0 ? force_split != 0 : 1);
-#define GP_LAUNCH(DT)                                                                                                   \
-    if (n_fields == 1)                                                                                                  \
-        hipLaunchKernelGGL((gpmp2_solve_kernel<DT, false>), dim3(B), dim3(split ? 128 : 64), 0, (hipStream_t)stream, x, \
-                           start, goal, w.jac, dm, w.fz, costs_out, B, H, D, n_fields, split, K);                       \
-    else                                                                                                                \
-        hipLaunchKernelGGL((gpmp2_solve_kernel<DT, true>), dim3(B), dim3(split ? 128 : 64), 0, (hipStream_t)stream, x,  \
-                           start, goal, w.jac, dm, w.fz, costs_out, B, H, D, n_fields, split, K)
+    // Sherman-Morrison form of the collision factors (template flag SM, see the kernel): selected when the collision precision
+    // exceeds the GP precision by more than 1e7 (x the number of fields) -- below that the assembled form is accurate to
+    // <= 2e-6 of the step (tests) and C4 (ratio 1e6) keeps the kernel it was tuned with.  MPB_GPMP2_SM = 0 / 1 forces a form
+    // (A/B timing and the tests that run both on the same system).
+    const char* sm_env = getenv("MPB_GPMP2_SM");            // (read per call: the tests switch it within one process)
+    const int force_sm = sm_env ? atoi(sm_env) : -1;
+    const double ratio = ((double)sigma_gp / (double)sigma_coll) * ((double)sigma_gp / (double)sigma_coll) * n_fields;
+    const bool sm = force_sm >= 0 ? force_sm != 0 : ratio > 1e7;
+#define GP_LAUNCH_(DT, MULTI, SM)                                                                                              \
+    hipLaunchKernelGGL((gpmp2_solve_kernel<DT, MULTI, SM>), dim3(B), dim3(split ? 128 : 64), 0, (hipStream_t)stream, x, start, \
+                       goal, w.jac, dm, w.fz, costs_out, B, H, D, n_fields, split, K)
+#define GP_LAUNCH(DT)                                      \
+    if (n_fields == 1) {                                   \
+        if (sm) GP_LAUNCH_(DT, false, true);               \
+        else GP_LAUNCH_(DT, false, false);                 \
+    } else {                                               \
+        if (sm) GP_LAUNCH_(DT, true, true);                \
+        else GP_LAUNCH_(DT, true, false);                  \
+    }
     switch (D) {
         case 2: GP_LAUNCH(2); break;
         case 3: GP_LAUNCH(3); break;
@@ -804,6 +869,7 @@ extern "C" int mpb_gpmp2_solve(float* x, const float* start, const float* goal, 
         default: GP_LAUNCH(0); break;
     }
 #undef GP_LAUNCH
+#undef GP_LAUNCH_
     return mpb_check_launch("mpb_gpmp2_solve");
 }
 
