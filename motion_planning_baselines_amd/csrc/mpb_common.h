@@ -111,6 +111,12 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 }
 #endif
 
+// exp(x) and 1 / x on the hardware units, for the softmax algebra of the persistent STOMP kernels (round 5): v_exp_f32 of
+// x log2(e) (2 instructions where ocml's expf is ~15; relative error <= 2^-22 + |x| 2^-24, i.e. 1e-6 at logits of -16, below
+// which a weight is < 1e-7 of the largest) and v_rcp_f32 (1 ulp; the IEEE division hipcc emits is ~10 instructions).
+__device__ __forceinline__ float fast_expf(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float fast_rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
+
 // Philox4x32-R (Salmon et al., SC'11), counter-based: no state, result depends only on (key, counter).
 // R = 10 is the library default; R = 7 is the smallest round count the authors report as passing
 // BigCrush ("Crush-resistant") and is what the STOMP kernel uses (the generator is ~15 % of its VALU work).

@@ -630,7 +630,10 @@ __device__ __forceinline__ void grid_stage_offsets(const GeomView& G, unsigned* 
 // loop issues N obstacle-table reads before the N distance evaluations, so the LDS latency is paid
 // once per group instead of once per sphere.  Adds the N hinges to `cost` one by one, in sphere order
 // (the same association as the exhaustive path, so both paths agree bit for bit).
-template <int N, bool OFFS = false>
+// UNIT (compile-time robot models only): the caller guarantees every hinge margin + r_l - sdf is below 1 (pack_geometry tags a
+// buffer with a model only when margin + max r_l + max obstacle radius < 1 m, mpb_geom_check verifies it), so relu is the
+// [0, 1] clamp the VOP3 encoding applies for free on the subtraction -- same bits as v_max_f32(x, 0), which issues at half rate.
+template <int N, bool OFFS = false, bool UNIT = false>
 __device__ __forceinline__ void spheres_hinge_grid(const GeomView& G, const unsigned* gridw, const float4* otab,
                                                    const float (&x)[N], const float (&y)[N], const float (&z)[N],
                                                    const float (&rl)[N], float& cost) {
@@ -742,7 +745,10 @@ __device__ __forceinline__ void spheres_hinge_grid(const GeomView& G, const unsi
         }
     }
 #pragma unroll
-    for (int i = 0; i < N; ++i) cost += fmaxf(G.margin + rl[i] - best[i], 0.f);   // parked slots: best = 3e38 -> +0
+    for (int i = 0; i < N; ++i) {                                                 // parked slots: best = 3e38 / 1e9 -> +0
+        const float hinge = G.margin + rl[i] - best[i];
+        cost += UNIT ? fminf(fmaxf(hinge, 0.f), 1.f) : fmaxf(hinge, 0.f);
+    }
 }
 
 template <bool OFFS = false>
@@ -901,6 +907,7 @@ __device__ __forceinline__ bool model_group_dispatch(int grp, ModelFK& F, const 
                                                      std::integer_sequence<int, GRPS...>) {
     bool run = false;
     // one arm per group, selected by the wave-uniform group counter (scalar compares / branches)
+    // (a switch over the group index -- a jump table or a compare tree instead of the compare chain -- measured +1 %, round 5)
     ((grp == GRPS ? (void)(run = model_group_positions<M, GRPS>(F, q, keep, x, y, z, rl)) : (void)0), ...);
     return run;
 }
@@ -919,7 +926,7 @@ __device__ __forceinline__ float waypoint_cost_grid_model(const GeomView& G, con
     for (int grp = 0; grp < NG; ++grp) {
         float x[4], y[4], z[4], rl[4];
         const bool run = model_group_dispatch<M>(grp, F, q, keep, x, y, z, rl, std::make_integer_sequence<int, NG>{});
-        if (run) spheres_hinge_grid<4, OFFS>(G, gridw, otab, x, y, z, rl, cost);
+        if (run) spheres_hinge_grid<4, OFFS, true>(G, gridw, otab, x, y, z, rl, cost);
     }
 #ifndef MPB_NO_COST_PRIO
     __builtin_amdgcn_s_setprio(0);

@@ -69,6 +69,17 @@ static int model_check_as(const float* g, const char* who) {
         ++n;
     }
     if (n != gi[5] || (M::N_LINKS < 32 && (keep >> M::N_LINKS) != 0u)) return fail(MPB_E_INVALID, "%s: keep mask and link table disagree", who);
+    // the model kernels clamp a hinge to [0, 1] (mpb_geom.h, UNIT): margin + largest collision sphere + deepest possible
+    // penetration (sphere radius / smallest half extent of a box) must stay below 1
+    float rl_max = 0.f, deepest = 0.f;
+    for (int l = 0; l < M::N_LINKS; ++l) rl_max = M::LINK[l][3] > rl_max ? M::LINK[l][3] : rl_max;
+    for (int o = 0; o < gi[6]; ++o) deepest = g[gi[11] + 4 * o + 3] > deepest ? g[gi[11] + 4 * o + 3] : deepest;
+    for (int o = 0; o < gi[7]; ++o) {
+        const float* h = g + gi[12] + 8 * o + 4;
+        const float m = h[0] < h[1] ? (h[0] < h[2] ? h[0] : h[2]) : (h[1] < h[2] ? h[1] : h[2]);
+        deepest = m > deepest ? m : deepest;
+    }
+    if (!(g[8] + rl_max + deepest < 1.0f)) return fail(MPB_E_INVALID, "%s: a model-tagged scene must keep every hinge below 1 (margin + radii)", who);
     return MPB_OK;
 }
 

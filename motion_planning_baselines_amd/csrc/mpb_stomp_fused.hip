@@ -173,7 +173,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         const f32x4 lv = reinterpret_cast<const f32x4*>(Lmat)[tid];
         const f32x4 sv = reinterpret_cast<const f32x4*>(Sigma)[tid];
         const int row = tid >> 4, col0 = (tid & 15) << 2;
-        stomp_l_image_store(Limg, row, col0, lv);
+        // rows 0 and H - 1 of the image are ZERO: stomp.py:105-106 zeroes the noise of the first and the last waypoint, and a
+        // zero row of L makes those rows of L eps exact zeros for free -- the sample phase adds the noise row without a select
+        // (fourteen exec-mask regions per wave and iteration until round 4)
+        const bool edge_row = row == 0 || row == H - 1;
+        stomp_l_image_store(Limg, row, col0, edge_row ? f32x4{0.f, 0.f, 0.f, 0.f} : lv);
         *reinterpret_cast<f32x4*>(sig_l + row * FUSED_LD + col0) = sv;
     }
     __syncthreads();
@@ -193,6 +197,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
     LSTAMP(2);
 
     const size_t eps_stride = (size_t)S * DCH * P * H;
+    const float inv_temperature = 1.0f / temperature;
 
     // ---- noise of iteration 0: straight into the wave's tile ([waypoint][channel], stride NT_STRIDE)
     // (PAIRED, 2 DCH <= 16: waves 0-7 draw and multiply for two rollouts each -- their own and wave + 8's --, waves 8-15 skip
@@ -255,7 +260,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         float nz[16];
         stomp_noise_row<DCH>(nt, lane, nz);
         const int h = lane;
-        const bool edge = (h == 0) || (h == H - 1);
         float x[DCH];
         // (the 16 waves of the block do this at the same moment: the LDS pipe, not the VALU, paces this phase -- 8-byte
         // accesses where the row length allows it: DCH even -> every row starts 8-byte aligned)
@@ -267,14 +271,14 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
 #else
                 const float2 mv = *reinterpret_cast<const float2*>(mean_l + h * DCH + c);
 #endif
-                x[c] = mv.x + (edge ? 0.f : nz[c]);
-                x[c + 1] = mv.y + (edge ? 0.f : nz[c + 1]);
+                x[c] = mv.x + nz[c];                      // (rows 0 / H - 1 of the noise are exact zeros: the L image's rows are)
+                x[c + 1] = mv.y + nz[c + 1];
             }
 #pragma unroll
             for (int c = 0; c < DCH; c += 2) *reinterpret_cast<float2*>(nt + h * DCH + c) = make_float2(x[c], x[c + 1]);
         } else {
 #pragma unroll
-            for (int c = 0; c < DCH; ++c) x[c] = mean_l[h * DCH + c] + (edge ? 0.f : nz[c]);
+            for (int c = 0; c < DCH; ++c) x[c] = mean_l[h * DCH + c] + nz[c];
 #pragma unroll
             for (int c = 0; c < DCH; ++c) nt[h * DCH + c] = x[c];
         }
@@ -352,9 +356,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         const int lq = tq & 63;
         hh = (tq < N) ? tq / DCH : 0; cc = (tq < N) ? tq - hh * DCH : 0;   // the trajectory element this thread owns
         sl = (NB > 1 ? bt : chunk) * FUSED_WAVES + (lq & 15);              // every wave redundantly, lanes 0-15 carry the chunk
-        const float xs = (lq < FUSED_WAVES && sl < S) ? -cst[lq & 15] / temperature : -3.0e38f;
+        const float xs = (lq < FUSED_WAVES && sl < S) ? -cst[lq & 15] * inv_temperature : -3.0e38f;
         mb = wave_max_f32(xs);
-        ex = (lq < FUSED_WAVES && sl < S) ? expf(xs - mb) : 0.f;
+        ex = (lq < FUSED_WAVES && sl < S) ? fast_expf(xs - mb) : 0.f;
         zb = wave_sum_f32(ex);
         dpart = 0.f;
         if (tq < N) {
@@ -461,7 +465,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         if (NB > 1) {
             // the two batches combined in batch order with the expressions of the exchange path below
             m_all = fmaxf(pm0, pm1);
-            const float f0 = expf(pm0 - m_all), f1 = expf(pm1 - m_all);
+            const float f0 = fast_expf(pm0 - m_all), f1 = fast_expf(pm1 - m_all);
             z_all = fmaf(f1, pz1, fmaf(f0, pz0, 0.f));
             f_own0 = f0;
             f_own = f1;
@@ -505,22 +509,24 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
 #pragma unroll
             for (int k = 0; k < FUSED_MAX_CHUNKS; ++k) {
                 if (k < nc) {
-                    const float f = expf(mk[k] - m_all);
+                    const float f = fast_expf(mk[k] - m_all);
                     z_all = fmaf(f, zk[k], z_all);
                     dsum = fmaf(f, dk[k], dsum);
                 }
             }
-            f_own = expf(mb - m_all);
+            f_own = fast_expf(mb - m_all);
         }
         FSTAMP(8);
-        // ============ E. weights out; mean += lr * (sum_k f_k Sigma D_k) / z
+        // ============ E. weights out; mean += lr * (sum_k f_k Sigma D_k) / z   (z >= 1: it holds the term exp(0) of the maximum;
+        //              one v_rcp_f32 instead of an IEEE division per use, round 5)
+        const float rz = fast_rcpf(z_all);
         if (NB > 1) {
             const int sl0 = tq & 15;
-            if (tq < FUSED_WAVES && sl0 < S) weights[(size_t)p * S + sl0] = pe0 * f_own0 / z_all;
-            if (tq < FUSED_WAVES && sl < S) weights[(size_t)p * S + sl] = pe1 * f_own / z_all;
-        } else if (tq < FUSED_WAVES && sl < S) weights[(size_t)p * S + sl] = ex * f_own / z_all;
+            if (tq < FUSED_WAVES && sl0 < S) weights[(size_t)p * S + sl0] = pe0 * f_own0 * rz;
+            if (tq < FUSED_WAVES && sl < S) weights[(size_t)p * S + sl] = pe1 * f_own * rz;
+        } else if (tq < FUSED_WAVES && sl < S) weights[(size_t)p * S + sl] = ex * f_own * rz;
         if (NB == 1 && nc > 1) {
-            if (tq < N) mean_l[tq] += lr * (dsum / z_all);
+            if (tq < N) mean_l[tq] += lr * (dsum * rz);
         } else if (wave < 4) {
             // (the products are still in the registers of waves 0-3: row 16 wave + 4 lg + r, channel li)
             const int li = tq & 15, lg = (tq >> 4) & 3;
@@ -529,7 +535,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
                 for (int r = 0; r < 4; ++r) {
                     float ds = fmaf(f_sd0, sd0[r], 0.f);
                     if (NB > 1) ds = fmaf(f_sd1, sd1[r], ds);
-                    mean_l[(16 * wave + 4 * lg + r) * DCH + li] += lr * (ds / z_all);
+                    mean_l[(16 * wave + 4 * lg + r) * DCH + li] += lr * (ds * rz);
                 }
             }
         }

@@ -325,6 +325,17 @@ def links_that_can_touch(rs, fs, slack=1e-4):
     return keep
 
 
+def hinge_bound(rs, fs):
+    """Upper bound of a hinge margin + r_l - sdf of the scene: the signed distance to a sphere is >= -radius, to a box >= -(its
+    smallest half extent)."""
+    deepest = 0.0
+    if len(fs['spheres']):
+        deepest = max(deepest, float(np.max(np.asarray(fs['spheres'])[:, 3])))
+    if len(fs['boxes']):
+        deepest = max(deepest, float(np.max(np.min(np.asarray(fs['boxes'])[:, 3:6], axis=1))))
+    return float(fs['margin']) + float(np.max(rs['link_radius'])) + deepest
+
+
 def pack_geometry(robot, field, scales=None, prune_static=True, use_model=True):
     """Pack robot + collision field(s) into the flat fp32 word buffer the HIP kernels read.
 
@@ -379,6 +390,10 @@ def pack_geometry(robot, field, scales=None, prune_static=True, use_model=True):
     for name, mid in model_gen.MODEL_IDS.items():
         if use_model and model_gen.matches_model(rs, name):
             model_id, keep_mask = mid, (1 << len(rs['link_radius'])) - 1
+    if model_id and hinge_bound(rs, fs) >= 1.0:
+        # the model kernels take relu(hinge) as the [0, 1] clamp of the instruction encoding (csrc/mpb_geom.h, UNIT): a scene
+        # whose hinges could reach 1 m keeps the table-driven walk
+        model_id, keep_mask = 0, 0
     if prune_static and rs['kind'] == KIND_CHAIN:
         keep = links_that_can_touch(rs, fs)
         if model_id:
