@@ -24,7 +24,7 @@
 #include "mpb_model_panda.h"
 
 #define MPB_GEOM_MAGIC 0x4D504247
-#define MPB_GEOM_VERSION 5
+#define MPB_GEOM_VERSION 6
 #define MPB_MAX_FIELDS 4   // collision fields chained in one buffer (header word 27 = words to the next one)
 #define MPB_GEOM_HEADER_WORDS 32
 #define MPB_GRID_MAX_CELLS 4096
@@ -59,7 +59,8 @@ struct GeomView {
     // broad-phase grid over the inflated obstacle spheres (n_cells == 0: none)
     const unsigned* grid;
     int gnx, gny, gnz, n_cells;
-    float glx, gly, glz, gix, giy, giz;  // origin, 1 / cell size
+    float glx, gly, glz, gix, giy, giz;  // origin, 1 / cell size (version 6: on a lattice through 0 -- lo = (K - 1/2) h per axis)
+    int k_lin;                           // linear index of the lattice point the grid starts at: cell = round(x / h) - K per axis
     float fscale;                        // s_f: this field's share in  sum_f s_f * cost_f
     int next;                            // words from this header to the next chained field (0: last)
     int model;                           // compile-time robot model the tables equal bit for bit (0: none), mpb_model_*.h
@@ -93,6 +94,7 @@ __device__ __forceinline__ GeomView geom_view(const float* __restrict__ g) {
     v.glx = g[20]; v.gly = g[21]; v.glz = g[22];
     v.gix = g[23]; v.giy = g[24]; v.giz = g[25];
     v.n_cells = gi[26];
+    v.k_lin = gi[31];
     v.fscale = g[28];
     v.next = gi[27];
     v.model = gi[29];
@@ -580,6 +582,42 @@ __device__ __forceinline__ unsigned grid_cell(const GeomView& G, float x, float 
 #endif
 }
 
+// BYTE OFFSET of a point's grid word (persistent STOMP kernels, MPPI; geometry version 6), clamped to the grid.  The cells
+// sit on a lattice through the world origin (geometry.py build_grid): cell = round-to-nearest(x / h) - K per axis,
+// and fma(x, 1/h, 1.5 * 2^23) leaves that integer in the low mantissa bits of a float in [2^23, 2^24) -- ONE instruction with
+// two register sources and a literal (v_fmaak_f32: full rate) where floor((x - lo) / h) takes a three-source fma and a
+// convert (half rate each).  The linear index is combined in the same float form (two subtractions of the constant, two
+// v_fmac with a scalar factor: exact, every value is an integer below 2^22), the byte offset is one v_lshl_add_u32 of the bit
+// pattern, one v_min_u32 clamps it: 9 instructions at ~27 cycles where grid_cell<true> + the index shift are 10 at ~42
+// (profiles/r05_isa_cost_hist_before.md: 12 % of the vector pipe at C3).  A point outside the box, a parked slot at 1e9, inf
+// or NaN give SOME offset inside the grid, as before (whatever that cell lists yields hinge 0: the box bounds the inflated
+// obstacles); a point on a cell face goes to either neighbour (ties to even), which the host's 1e-5 m of slack on the
+// candidate radius covers like the fp32 rounding of the old form.
+struct GridAddr {
+    float gix_v, giy_v, giz_v;   // 1 / h per axis in VECTOR registers (v_fmaak takes the literal plus two registers; a scalar would make it a VOP3 fma)
+    float gnx_f, gny_f;  // row / slab lengths as floats (scalar operands of the two v_fmac)
+    unsigned c_rel;      // -4 * (bits(1.5 * 2^23) + k_lin): turns the bit pattern of 1.5 * 2^23 + linear index into a byte offset
+    unsigned max_rel;    // 4 * (n_cells - 1)
+};
+__device__ __forceinline__ GridAddr grid_addr(const GeomView& G) {
+    GridAddr A;
+    A.gix_v = G.gix; A.giy_v = G.giy; A.giz_v = G.giz;
+    asm volatile("" : "+v"(A.gix_v), "+v"(A.giy_v), "+v"(A.giz_v));
+    A.gnx_f = (float)G.gnx;
+    A.gny_f = (float)G.gny;
+    A.c_rel = 0u - 4u * (0x4B400000u + (unsigned)G.k_lin);
+    A.max_rel = 4u * (unsigned)(G.n_cells - 1);
+    return A;
+}
+__device__ __forceinline__ unsigned grid_cell_rel(const GridAddr& A, float x, float y, float z) {
+    constexpr float MAGIC = 12582912.0f;                 // 1.5 * 2^23
+    const float tx = fmaf(x, A.gix_v, MAGIC), ty = fmaf(y, A.giy_v, MAGIC), tz = fmaf(z, A.giz_v, MAGIC);
+    const float u = fmaf(tz - MAGIC, A.gny_f, ty);       // MAGIC + ry + gny rz
+    const float v = fmaf(u - MAGIC, A.gnx_f, tx);        // MAGIC + rx + gnx (ry + gny rz)
+    const unsigned rel = (__float_as_uint(v) << 2) + A.c_rel;
+    return min(rel, A.max_rel);
+}
+
 // cooperative staging by `nthreads` threads (caller synchronises before and after)
 __device__ __forceinline__ void grid_stage(const GeomView& G, unsigned* gridw, float4* otab, int tid, int nthreads) {
     for (int i = tid; i < G.n_cells; i += nthreads) gridw[i] = G.grid[i];
@@ -636,7 +674,7 @@ __device__ __forceinline__ void grid_stage_offsets(const GeomView& G, unsigned* 
 template <int N, bool OFFS = false, bool UNIT = false>
 __device__ __forceinline__ void spheres_hinge_grid(const GeomView& G, const unsigned* gridw, const float4* otab,
                                                    const float (&x)[N], const float (&y)[N], const float (&z)[N],
-                                                   const float (&rl)[N], float& cost) {
+                                                   const float (&rl)[N], float& cost, const GridAddr& GA = GridAddr{}) {
     unsigned w[N];
     float best[N];
     if constexpr (OFFS) {
@@ -644,7 +682,8 @@ __device__ __forceinline__ void spheres_hinge_grid(const GeomView& G, const unsi
         const char* ob = reinterpret_cast<const char*>(otab);
         float4 s0[N];
 #pragma unroll
-        for (int i = 0; i < N; ++i) w[i] = gridw[grid_cell<true>(G, x[i], y[i], z[i])];
+        for (int i = 0; i < N; ++i)
+            w[i] = *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(gridw) + grid_cell_rel(GA, x[i], y[i], z[i]));
 #pragma unroll
         for (int i = 0; i < N; ++i) s0[i] = *reinterpret_cast<const float4*>(ob + (w[i] & 0x3FFu));
         unsigned comb = w[0];
@@ -757,7 +796,7 @@ __device__ __forceinline__ float waypoint_cost_grid(const GeomView& G, const uns
     if (G.kind == MPB_KIND_POINT) {
         const float x[1] = {q[0]}, y[1] = {q[1]}, z[1] = {(G.n_dof > 2) ? q[2] : 0.f}, rl[1] = {G.links[4]};
         float c = 0.f;
-        spheres_hinge_grid<1, OFFS>(G, gridw, otab, x, y, z, rl, c);
+        spheres_hinge_grid<1, OFFS>(G, gridw, otab, x, y, z, rl, c, OFFS ? grid_addr(G) : GridAddr{});
         return c;
     }
 #ifndef MPB_GRID_N
@@ -770,6 +809,7 @@ __device__ __forceinline__ float waypoint_cost_grid(const GeomView& G, const uns
     F.tx = F.ty = F.tz = 0.f;
     F.frame = 0;
     float cost = 0.f;
+    const GridAddr GA = OFFS ? grid_addr(G) : GridAddr{};
     for (int l0 = 0; l0 < G.n_links; l0 += N) {
         const int nl = min(N, G.n_links - l0);
 #ifndef MPB_NO_COST_PRIO
@@ -805,7 +845,7 @@ __device__ __forceinline__ float waypoint_cost_grid(const GeomView& G, const uns
                 x[i] = y[i] = z[i] = FAR;
             }
         }
-        spheres_hinge_grid<N, OFFS>(G, gridw, otab, x, y, z, rl, cost);
+        spheres_hinge_grid<N, OFFS>(G, gridw, otab, x, y, z, rl, cost, GA);
     }
 #ifndef MPB_NO_COST_PRIO
     __builtin_amdgcn_s_setprio(0);
@@ -921,12 +961,13 @@ __device__ __forceinline__ float waypoint_cost_grid_model(const GeomView& G, con
     F.tx = F.ty = F.tz = 0.f;
     float cost = 0.f;
     const unsigned keep = G.keep_mask;
+    const GridAddr GA = OFFS ? grid_addr(G) : GridAddr{};
     // a real loop over the groups with ONE instance of the grid look-up (unrolling it per group is 60 KB of code)
 #pragma nounroll
     for (int grp = 0; grp < NG; ++grp) {
         float x[4], y[4], z[4], rl[4];
         const bool run = model_group_dispatch<M>(grp, F, q, keep, x, y, z, rl, std::make_integer_sequence<int, NG>{});
-        if (run) spheres_hinge_grid<4, OFFS, true>(G, gridw, otab, x, y, z, rl, cost);
+        if (run) spheres_hinge_grid<4, OFFS, true>(G, gridw, otab, x, y, z, rl, cost, GA);
     }
 #ifndef MPB_NO_COST_PRIO
     __builtin_amdgcn_s_setprio(0);

@@ -6,6 +6,7 @@
 //     geometry constants as scalar (SGPR) operands; the per-trajectory cost is a wave reduction.
 //   * B = P*S rollouts -> B waves; C3 (B = 4096) is exactly 4 waves per SIMD over the whole chip.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -113,6 +114,19 @@ static int geom_check_one(const float* g, int n_words, const char* who) {
     if ((off_links | off_sph | off_box | off_cull | off_fs | off_grid) & 3) return fail(MPB_E_INVALID, "%s: sections must be 16-byte aligned", who);
     if (n_cells < 0 || (n_cells > 0 && (gnx < 1 || gny < 1 || gnz < 1 || gnx * gny * gnz != n_cells)))
         return fail(MPB_E_INVALID, "%s: bad broad-phase grid dims", who);
+    if (n_cells > 0) {
+        // version 6: cells on a lattice through the origin -- lo = (K - 1/2) h per axis with integer K, and header word 31 =
+        // Kx + gnx (Ky + gny Kz): what grid_cell_rel (mpb_geom.h) turns round(x / h) into a cell with
+        long K[3];
+        for (int a = 0; a < 3; ++a) {
+            if (!(g[23 + a] > 0.f)) return fail(MPB_E_INVALID, "%s: bad grid cell size", who);
+            const double k = (double)g[20 + a] * (double)g[23 + a] + 0.5;
+            K[a] = lrint(k);
+            if (fabs(k - (double)K[a]) > 1e-3 || labs(K[a]) > 100000) return fail(MPB_E_INVALID, "%s: grid origin is not on the cell lattice", who);
+        }
+        if ((long)gi[31] != K[0] + (long)gnx * (K[1] + (long)gny * K[2])) return fail(MPB_E_INVALID, "%s: grid lattice index (word 31) does not match the origin", who);
+        if (labs((long)gi[31]) + (long)n_cells >= (1L << 21)) return fail(MPB_E_INVALID, "%s: grid too far from the origin for the fp32 cell index", who);
+    }
     for (int i = 0; i < n_cells; ++i) {   // every packed obstacle index must exist
         const uint32_t w = (uint32_t)gi[off_grid + i];
         if (w == 0xFFFFFFFEu) continue;

@@ -341,7 +341,7 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
                             if (use_grid) {      // the point branch of waypoint_cost_grid (mpb_geom.h), same expressions
                                 const float px[1] = {q[0]}, py[1] = {q[1]}, pz[1] = {(G0.n_dof > 2) ? q[2] : 0.f}, rl[1] = {G0.links[4]};
                                 float cg = 0.f;
-                                spheres_hinge_grid<1, true>(G0, M.gridw, M.otab, px, py, pz, rl, cg);
+                                spheres_hinge_grid<1, true>(G0, M.gridw, M.otab, px, py, pz, rl, cg, grid_addr(G0));
                                 coll_l += G0.fscale * cg;
                             } else {
                                 coll_l += __uint_as_float(0x7FC00000u);

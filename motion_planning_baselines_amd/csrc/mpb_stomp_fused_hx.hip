@@ -148,7 +148,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
         const int gr = 64 * hc + row, gc = 64 * kc + col0;
         f32x4 lv;
 #pragma unroll
-        for (int e4 = 0; e4 < 4; ++e4) lv[e4] = (gr < H && gc + e4 < H) ? Lmat[(size_t)gr * H + gc + e4] : 0.f;
+        for (int e4 = 0; e4 < 4; ++e4) lv[e4] = (gr > 0 && gr < H - 1 && gc + e4 < H) ? Lmat[(size_t)gr * H + gc + e4] : 0.f;   // (rows 0 / H - 1 of the image are zero: stomp.py:105-106, as in mpb_stomp_fused.hip)
         if (b == 1) stomp_l_image_store<true>(Limg + STOMP_LIMG_WORDS, row, col0, lv);
         else stomp_l_image_store<false>(Limg + (b == 0 ? 0 : STOMP_LIMG_WORDS + STOMP_LIMG_WORDS_FULL), row, col0, lv);
     }
@@ -167,6 +167,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
     if (unit == 0 && tid == 0) st_agent_u(wsu + FUSED_HDR_TAG, tag0);
     __syncthreads();
     const int n_run = s_abort ? 0 : n_iters;
+    const float inv_temperature = 1.0f / temperature;
 
     float* nt = tiles + wave * TILE;
     const size_t eps_stride = (size_t)S * d * P * H;
@@ -284,21 +285,20 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
             // ============ A. samples: x = mean + noise (zero at both ends, stomp.py:105-106), stored, kept packed in the tile
             const int h = 64 * hcw + lane;
             const bool on = h < H;
-            const bool edge = (h == 0) || (h == H - 1);
             float x[DX];
             if (DCH != 0 && (DCH % 2) == 0) {
 #pragma unroll
                 for (int c = 0; c < DX; c += 2) {
                     const float2 nv = *reinterpret_cast<const float2*>(nt + lane * DX + c);
                     const float2 mv = *reinterpret_cast<const float2*>(mean_l + (on ? h : 0) * DX + c);
-                    x[c] = mv.x + (edge ? 0.f : nv.x);
-                    x[c + 1] = mv.y + (edge ? 0.f : nv.y);
+                    x[c] = mv.x + nv.x;                  // (rows 0 / H - 1 of the noise are exact zeros: the L image's rows are)
+                    x[c + 1] = mv.y + nv.y;
                 }
 #pragma unroll
                 for (int c = 0; c < DX; c += 2) *reinterpret_cast<float2*>(nt + lane * DX + c) = make_float2(x[c], x[c + 1]);
             } else {
 #pragma unroll
-                for (int c = 0; c < DX; ++c) x[c] = (c < d) ? mean_l[(on ? h : 0) * d + c] + (edge ? 0.f : nt[lane * d + c]) : 0.f;
+                for (int c = 0; c < DX; ++c) x[c] = (c < d) ? mean_l[(on ? h : 0) * d + c] + nt[lane * d + c] : 0.f;
 #pragma unroll
                 for (int c = 0; c < DX; ++c)
                     if (c < d) nt[lane * d + c] = x[c];
@@ -367,14 +367,14 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
             const int sl = (chunk * nb + bt) * RB + rq;
             const bool carries = lq < RB && sl < S;
             if (tq < RB && sl < S) reinterpret_cast<unsigned*>(costs)[(size_t)p * S + sl] = poisoned ? 0x7FC00000u : __float_as_uint(cw);
-            const float xs = carries ? -cw / temperature : -3.0e38f;
+            const float xs = carries ? -cw * inv_temperature : -3.0e38f;
             const float mb = wave_max_f32(xs);
-            const float ex = carries ? expf(xs - mb) : 0.f;
+            const float ex = carries ? fast_expf(xs - mb) : 0.f;
             const float zb = wave_sum_f32(ex);
             if (tq < RB) ewl[bt * RB + tq] = ex;
             if (tq == 0) mbl[bt] = mb;
             const float m_new = fmaxf(m_run, mb);
-            const float f_old = expf(m_run - m_new), f_b = expf(mb - m_new);
+            const float f_old = fast_expf(m_run - m_new), f_b = fast_expf(mb - m_new);
             z_run = fmaf(zb, f_b, z_run * f_old);
             m_run = m_new;
 #pragma unroll
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
 #pragma unroll
             for (int k = 0; k < FUSED_MAX_CHUNKS; ++k) {
                 if (k < nc) {
-                    const float f = expf(mk[k] - m_all);
+                    const float f = fast_expf(mk[k] - m_all);
                     z_all = fmaf(f, zk[k], z_all);
 #pragma unroll
                     for (int u = 0; u < EPT; ++u) dsum[u] = fmaf(f, dk[k][u], dsum[u]);
@@ -465,16 +465,17 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
             }
         }
         // ============ E. weights out, delta (transposed) -> mean += lr * Sigma @ delta on the matrix cores
+        const float rz = fast_rcpf(z_all);          // (z >= 1; mpb_stomp_fused.hip, phase E)
         for (int i = tq; i < nb * RB; i += FUSED_THREADS) {
             const int sl = chunk * nb * RB + i;
-            if (sl < S) weights[(size_t)p * S + sl] = ewl[i] * expf(mbl[i / RB] - m_all) / z_all;
+            if (sl < S) weights[(size_t)p * S + sl] = ewl[i] * fast_expf(mbl[i / RB] - m_all) * rz;
         }
 #pragma unroll
         for (int u = 0; u < EPT; ++u) {
             const int e = tq + FUSED_THREADS * u;
             if (e < N) {
                 const int hh = e / d, cc = e - hh * d;
-                delta[cc * DLD + hh] = dsum[u] / z_all;
+                delta[cc * DLD + hh] = dsum[u] * rz;
             }
         }
         __syncthreads();                                                                        // (3) delta complete

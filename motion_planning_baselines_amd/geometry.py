@@ -27,7 +27,7 @@ import numpy as np
 import torch
 
 GEOM_MAGIC = 0x4D504247  # 'MPBG'
-GEOM_VERSION = 5
+GEOM_VERSION = 6
 MAX_FIELDS = 4           # collision fields chained in one buffer (csrc/mpb_geom.h MPB_MAX_FIELDS)
 GEOM_HEADER_WORDS = 32
 GRID_MAX_DIM = 64       # cells per axis of the broad-phase grid
@@ -230,7 +230,7 @@ class CollisionField:
         pass
 
 
-def build_grid(spheres, a_max, slack=1e-4):
+def build_grid(spheres, a_max, slack=1e-4, planar=False):
     """Uniform broad-phase grid over the inflated obstacle spheres (host, fp64).  None when there are no
     spheres or more than 254 of them (8-bit indices)."""
     n = len(spheres)
@@ -240,36 +240,65 @@ def build_grid(spheres, a_max, slack=1e-4):
     R = spheres[:, 3].astype(np.float64) + a_max + slack      # a sphere at x can matter only if |x - c| < R
     lo = (c - R[:, None]).min(0)
     hi = (c + R[:, None]).max(0)
-    ext = np.maximum(hi - lo, 1e-6)
-    # the finest cubic cell, from GRID_CELL down to GRID_CELL_MIN, whose grid still fits GRID_MAX_CELLS words of LDS: finer
-    # cells list fewer obstacles each, and the kernels' candidate loop runs max-over-the-wave(candidates) times (C3: 0.14 m
-    # -> 1.36 trips per group of four collision spheres, 0.125 m = 17 x 15 x 16 cells -> 1.27; planar problems get one
-    # layer of cells along a degenerate axis)
-    def dims_for(edge):
-        dd = np.clip(np.ceil(ext / edge).astype(np.int64), 1, GRID_MAX_DIM)
+    # Cells on a LATTICE through the world origin (geometry version 6): cell ix of an axis is [(K + ix - 1/2) h, (K + ix + 1/2) h)
+    # with integer K, i.e. round-to-nearest(x / h) - K -- which a kernel gets from ONE fma(x, 1/h, 1.5 * 2^23) (the integer lands
+    # in the low mantissa bits) where floor((x - lo) / h) took an fma with three register sources and a convert
+    # (csrc/mpb_geom.h, grid_cell_rel).  Per axis the smallest cell count n whose lattice-aligned edge h (the smallest h >=
+    # extent / n for which some lattice position covers [lo, hi]) does not exceed the target edge; the target goes from
+    # GRID_CELL down to GRID_CELL_MIN while the grid still fits GRID_MAX_CELLS words of LDS: finer cells list fewer
+    # obstacles each, and the kernels' candidate loop runs max-over-the-wave(candidates) times (C3: 17 x 15 x 16 cells of
+    # ~0.12 m -> 1.27 trips per group of four collision spheres); planar problems get one layer of cells along z.
+    flat = [planar and ax == 2 and np.ptp(c[:, ax]) == 0.0 for ax in range(3)]     # 2-D robots: every query point has z = 0
+
+    def fit_axis(a, b, edge):
+        """(n, h32, K): fewest cells of a lattice-aligned edge <= `edge` that cover [a, b]"""
+        n = max(int(np.ceil((b - a) / edge)), 1)
+        while n <= GRID_MAX_DIM:
+            h = (b - a) / n
+            while h <= edge * (1.0 + 1e-9):
+                inv32 = np.float32(1.0 / h)
+                he = 1.0 / float(inv32)                      # the edge the kernels effectively use
+                K = int(np.floor(a / he + 0.5))              # (K - 1/2) he <= a
+                if (K - 0.5 + n) * he >= b:
+                    return n, inv32, K
+                h *= 1.0 + 2e-4
+            n += 1
+        return None
+
+    def lattice(edge):
+        fits = []
         for ax in range(3):
-            if np.ptp(c[:, ax]) == 0.0:
-                dd[ax] = 1
-        return dd
+            if flat[ax]:                                     # one layer of cells, the one that holds the plane z = 0
+                fits.append((1, np.float32(1.0 / edge), 0))
+                continue
+            f = fit_axis(float(lo[ax]), float(hi[ax]), edge)
+            if f is None:
+                return None
+            fits.append(f)
+        return fits
     edge = GRID_CELL
-    dims = dims_for(edge)
-    while edge * GRID_REFINE >= GRID_CELL_MIN and dims_for(edge * GRID_REFINE).prod() <= GRID_MAX_CELLS:
+    fits = lattice(edge)
+    while edge * GRID_REFINE >= GRID_CELL_MIN:
+        t = lattice(edge * GRID_REFINE)
+        if t is None or int(np.prod([f[0] for f in t])) > GRID_MAX_CELLS:
+            break
         edge *= GRID_REFINE
-        dims = dims_for(edge)
-    if dims.prod() > GRID_MAX_CELLS:          # (GRID_CELL itself too fine for a very large scene: coarsen)
-        while dims.prod() > GRID_MAX_CELLS:
-            edge /= GRID_REFINE
-            dims = dims_for(edge)
-    cell = ext / dims
-    # the kernel computes floor((x - lo32) * inv32) in fp32: keep lo / inv exactly as stored, and add the
-    # worst-case fp32 index error (a point within 1e-5 of a cell face may land in the neighbour) to R
-    lo32 = lo.astype(np.float32)
-    inv32 = (1.0 / cell).astype(np.float32)
+        fits = t
+    while fits is None or int(np.prod([f[0] for f in fits])) > GRID_MAX_CELLS:      # (GRID_CELL itself too fine for a very large scene: coarsen)
+        edge /= GRID_REFINE
+        fits = lattice(edge)
+    dims = np.array([f[0] for f in fits], dtype=np.int64)
+    inv32 = np.array([f[1] for f in fits], dtype=np.float32)
+    K = np.array([f[2] for f in fits], dtype=np.int64)
     cell_eff = 1.0 / inv32.astype(np.float64)
+    lo_s = (K - 0.5) * cell_eff
+    lo32 = lo_s.astype(np.float32)
+    # the kernels take the cell from fp32 arithmetic on x: a point within ~1e-5 of a cell face may land in the neighbour --
+    # added to R, with the fp32 rounding of large coordinates
     Rg = R + 1e-5 + 1e-6 * np.abs(np.concatenate([lo, hi])).max()
     ix = [np.arange(d) for d in dims]
     X, Y, Z = np.meshgrid(ix[0], ix[1], ix[2], indexing='ij')
-    cmin = lo32.astype(np.float64) + np.stack([X, Y, Z], -1) * cell_eff          # (nx,ny,nz,3)
+    cmin = lo_s + np.stack([X, Y, Z], -1) * cell_eff          # (nx,ny,nz,3)
     cmax = cmin + cell_eff
     counts = np.zeros(dims, dtype=np.int64)
     lists = np.full((*dims, 4), n, dtype=np.uint32)      # empty slot = n: the far dummy the kernels append to the table
@@ -285,7 +314,8 @@ def build_grid(spheres, a_max, slack=1e-4):
     w = lists[..., 0] | (lists[..., 1] << 8) | (lists[..., 2] << 16) | (lists[..., 3] << 24)
     w = np.where(counts > 4, np.uint32(GRID_OVERFLOW), w.astype(np.uint32))
     words = np.ascontiguousarray(w.transpose(2, 1, 0)).reshape(-1).astype(np.uint32)   # x fastest
-    return dict(dims=dims.astype(np.int32), lo=lo32, inv=inv32, words=words,
+    k_lin = int(K[0] + dims[0] * (K[1] + dims[1] * K[2]))     # linear index of the lattice point (Kx, Ky, Kz): header word 31
+    return dict(dims=dims.astype(np.int32), lo=lo32, inv=inv32, words=words, k_lin=k_lin, K=K,
                 stats=dict(mean=float(counts.mean()), max=int(counts.max()), overflow=int((counts > 4).sum())))
 
 
@@ -416,7 +446,8 @@ def pack_geometry(robot, field, scales=None, prune_static=True, use_model=True):
     off_cull = off_box + 8 * n_box
     off_fs = off_cull + 8 * n_sph_pad
     off_grid = off_fs + n_fs
-    grid = build_grid(fs['spheres'], float(fs['margin']) + float(np.max(rs['link_radius'])))
+    grid = build_grid(fs['spheres'], float(fs['margin']) + float(np.max(rs['link_radius'])),
+                      planar=(rs['kind'] == KIND_POINT and rs['n_dof'] == 2 and (len(fs['spheres']) == 0 or bool(np.all(np.asarray(fs['spheres'])[:, 2] == 0.0)))))
     n_cells = 0 if grid is None else int(grid['words'].size)
     total = off_grid + (n_cells + GRID_PAD - 1) // GRID_PAD * GRID_PAD   # staged by the kernels in whole 16-byte rounds
     buf = np.zeros((total,), dtype=np.float32)
@@ -429,6 +460,7 @@ def pack_geometry(robot, field, scales=None, prune_static=True, use_model=True):
         buf[20:23] = grid['lo']
         buf[23:26] = grid['inv']
         ibuf[26] = n_cells
+        ibuf[31] = grid['k_lin']
         buf.view(np.uint32)[off_grid:off_grid + n_cells] = grid['words']
     buf[off_tf:off_links] = rs['joint_tf'].astype(np.float32).reshape(-1)
     links = np.zeros((n_links, 8), np.float32)

@@ -53,6 +53,8 @@ class GPMP2(OptimizationPlanner):
         extra costs at all: the others return None and fail at the unpack, cost_functions.py:122-126);
       * ``solver_params['method']``: 'cholesky', 'inverse' and 'lstq' (gpmp2.py:432-491) all run the block solve --
         they are three dense solvers of the same SPD system; 'cholesky-sparse' raises like the reference (:457);
+        ``_get_grad_terms`` / ``get_torch_solve`` exist as the reference's dense methods (for callers / subclasses), the
+        step itself does not go through them;
       * without goals (``multi_goal_states=None``, gpmp2.py:135-137) the goal factor is left out of the system;
       * extra kwarg ``process_group``: when given, the trust-region damping's batch mean (quirk Q9,
         gpmp2.py:361-367) is all-reduced over the group so that sharded runs equal the unsharded one.
@@ -232,6 +234,34 @@ class GPMP2(OptimizationPlanner):
         else:
             ops.gpmp2_step(x, self._start, self._goal, self.geom, self._ws, self.sigmas, self.dt, delta, trust,
                            self.step_size, n_iters=1, costs_out=self.costs, n_interp=self.n_interpolated_points)
+
+    # ---- the reference's dense building blocks, for subclasses / callers that use them directly ------------------------
+    def _get_grad_terms(self, A, b, K, delta=0., trust_region=False, sparse_computation=False,
+                        sparse_computation_block_diag=False):
+        """gpmp2.py:344-368 (dense branch): J^T J = A^T K A + delta I (or + delta * mean_b(A^T K A) o I with the trust region,
+        quirk Q9) and g = A^T K b from a DENSE (A, b, K) -- e.g. self.cost.get_linear_system(x) -- on the tensors' device.
+        The planner's own step never forms these (mpb_gpmp2_step assembles the same normal equations block-tridiagonally,
+        in registers); this is the reference's method for code that calls or overrides it.  The sparse_computation branches
+        of the reference build the same two tensors another way and are served by this one."""
+        N = A.shape[-1]
+        I = torch.eye(N, N, device=A.device, dtype=A.dtype)
+        A_t_K = A.transpose(-2, -1) @ K
+        A_t_A = A_t_K @ A
+        J_t_J = A_t_A + delta * (A_t_A.mean(0) * I if trust_region else I)
+        return J_t_J, A_t_K @ b
+
+    def get_torch_solve(self, A, b, method):
+        """gpmp2.py:432-491: d_theta = A^-1 b for dense batched SPD A (B,N,N), b (B,N,1) by the named dense method, on the
+        tensors' device ('cholesky-sparse' raises like the reference, :457).  The planner's step solves the same system by
+        block elimination inside mpb_gpmp2_solve and does not come through here."""
+        if method == 'inverse':
+            return torch.linalg.solve(A, b)
+        if method == 'cholesky':
+            l, _ = torch.linalg.cholesky_ex(A)
+            return torch.cholesky_solve(b, l)
+        if method == 'lstq':
+            return torch.linalg.lstsq(A, b)[0]
+        raise NotImplementedError(method)
 
     def optimize(self, opt_iters=None, debug=False, **observation):
         """gpmp2.py:273-306 incl. the optional relative-change stop criterion (:286-293)."""

@@ -12,6 +12,36 @@ from ... import ops
 from ..base import require_cuda
 
 
+class GMM:
+    """priors/gaussian.py:7-33: mixture of independent Gaussians over control trajectories -- means / sigmas
+    (num_particles, steps, ctrl_dim), weights (num_particles) -- on whatever device the tensors live (no planner of the
+    reference uses it; kept for code written against the module)."""
+
+    def __init__(self, means, sigmas, weights):
+        import torch.distributions as dist
+        self.num_particles, self.rollout_steps, self.ctrl_dim = means.shape
+        components = dist.Independent(dist.Normal(means, sigmas), 2)
+        self.dist = dist.mixture_same_family.MixtureSameFamily(dist.Categorical(weights), components)
+
+    def sample(self, num_samples):
+        """(steps-first transpose as the reference, :29-30; num_samples: a torch.Size / tuple like there, or an int)"""
+        shape = (num_samples,) if isinstance(num_samples, int) else tuple(num_samples)
+        return self.dist.sample(shape).transpose(0, 1)
+
+    def log_prob(self, x):
+        return self.dist.log_prob(x)
+
+
+def get_indep_gaussian_prior(sigma_init, rollout_steps, control_dim, mu_init=None, tensor_args=None):
+    """priors/gaussian.py:63-82: Normal(mu, sigma_init) per (step, control dimension); tensor_args (extra) places it on a device."""
+    import torch.distributions as dist
+    ta = tensor_args or {}
+    mu = torch.zeros(rollout_steps, control_dim, **ta)
+    if mu_init is not None:
+        mu[:, :] = torch.as_tensor(mu_init, **ta)
+    return dist.Normal(mu, torch.ones(rollout_steps, control_dim, **ta) * sigma_init)
+
+
 def avg_ctrl_to_goal(state, target, rollout_steps, dt, max_ctrl=100, control_type='velocity'):
     """gaussian.py:36-58 (host-side helper, velocity control)."""
     assert control_type in ['velocity', 'acceleration']

@@ -338,11 +338,18 @@ def gen_gp_prior(name, D, H, dt, seed):
         prior = MultiMPPrior(H - 1, dt, 2 * D, D, sK, Qi, start, K_g_inv=gK, goal_states=goal.unsqueeze(0),
                              tensor_args=ta)
         smp = prior.sample(6)
+    # the class's other public methods (mp_priors_multi.py:130-176, :213-259): log density of the samples (and of points well
+    # off the mean), the constant-velocity mean and the precision from the factor matrices
+    xs = smp.transpose(0, 1).reshape(6, 1, -1)
+    off = xs + 0.05 * torch.linspace(-1, 1, xs.shape[-1], dtype=torch.float64)
     np.savez_compressed(
         os.path.join(HERE, name + '.npz'), planner='gp_prior', D=D, H=H, dt=dt,
         start=npf(start), goal=npf(goal), sigma_start=1e-3, sigma_goal=1e-3, sigma_gp=5.0,
         Sigma_inv=npf(prior.Sigma_inv), mean=npf(prior.means), scale_tril=npf(prior.dist._unbroadcasted_scale_tril),
-        eps=npf(rec.draws[0]), samples=npf(smp))
+        eps=npf(rec.draws[0]), samples=npf(smp), log_prob=npf(prior.log_prob(xs)), log_prob_off=npf(prior.log_prob(off)),
+        const_vel_mean=npf(prior.get_const_vel_mean(start, goal.unsqueeze(0), dt, H - 1, D)),
+        const_vel_precision=npf(prior.get_const_vel_covariance(dt, sK, Qi, gK)),
+        const_vel_covariance=npf(prior.get_const_vel_covariance(dt, sK, Qi, gK, precision_matrix=False)))
     print(name, 'samples', smp.shape)
 
 
@@ -367,10 +374,23 @@ def gen_gp_prior_general(name, D, H, dt, seed):
     with EpsRecorder() as rec:
         prior = MultiMPPrior(H - 1, dt, sd, D, sK, Qi, start, K_g_inv=gK, goal_states=goals, tensor_args=ta)
         smp = prior.sample(5)
+    xs = smp.transpose(0, 1).reshape(5, 2, -1)
+    off = xs + 0.05 * torch.linspace(-1, 1, xs.shape[-1], dtype=torch.float64)
+    # set_Sigma_invs with a DIFFERENT precision per mode (mp_priors_multi.py:124-128), then a draw and the density
+    Sinv2 = torch.stack([prior.Sigma_inv, 2.5 * prior.Sigma_inv])
+    torch.manual_seed(seed + 7)
+    with EpsRecorder() as rec2:
+        prior.set_Sigma_invs(Sinv2)
+        smp2 = prior.sample(4)
+    lp2 = prior.log_prob(xs)
     np.savez_compressed(
         os.path.join(HERE, name + '.npz'), planner='gp_prior_general', D=D, H=H, dt=dt, start=npf(start), goals=npf(goals),
         K_s_inv=npf(sK), K_gp_inv=npf(Qi), K_g_inv=npf(gK), Sigma_inv=npf(prior.Sigma_inv), mean=npf(prior.means),
-        scale_tril=npf(prior.dist._unbroadcasted_scale_tril), eps=npf(rec.draws[0]), samples=npf(smp))
+        scale_tril=npf(prior.dist._unbroadcasted_scale_tril), eps=npf(rec.draws[0]), samples=npf(smp),
+        log_prob=npf(MultiMPPrior(H - 1, dt, sd, D, sK, Qi, start, K_g_inv=gK, goal_states=goals, tensor_args=ta).log_prob(xs)),
+        log_prob_off=npf(MultiMPPrior(H - 1, dt, sd, D, sK, Qi, start, K_g_inv=gK, goal_states=goals, tensor_args=ta).log_prob(off)),
+        const_vel_mean=npf(prior.get_const_vel_mean(start, goals, dt, H - 1, D)),
+        Sigma_invs2=npf(Sinv2), eps2=npf(rec2.draws[0]), samples2=npf(smp2), log_prob2=npf(lp2))
     print(name, 'samples', smp.shape)
 
 

@@ -366,11 +366,15 @@ def test_broad_phase_grid_is_conservative_and_fits(scene):
         c = rng.uniform(-6.0, 6.0, size=(40, 3))
         sph, a_max = np.concatenate([c, rng.uniform(0.1, 0.4, size=(40, 1))], 1).astype(np.float32), 0.13
     sph = np.asarray(sph, dtype=np.float32)
-    g = G.build_grid(sph, a_max)
+    g = G.build_grid(sph, a_max, planar=bool(np.ptp(sph[:, 2]) == 0.0))     # (pack_geometry passes planar for 2-D point robots)
     dims, lo, inv, words = g['dims'].astype(np.int64), g['lo'], g['inv'], g['words']
     n = len(sph)
     assert dims.prod() == len(words) <= G.GRID_MAX_CELLS and (dims >= 1).all() and (dims <= G.GRID_MAX_DIM).all()
     cell = 1.0 / inv.astype(np.float64)
+    # geometry version 6: cells on a lattice through the origin, lo = (K - 1/2) h per axis
+    K = g['K'].astype(np.int64)
+    assert np.allclose(lo.astype(np.float64) * inv.astype(np.float64) + 0.5, K, atol=1e-3)
+    assert g['k_lin'] == K[0] + dims[0] * (K[1] + dims[1] * K[2])
     if scene == 'large_3d':
         assert cell.max() > G.GRID_CELL                      # coarsened
     else:
@@ -385,12 +389,30 @@ def test_broad_phase_grid_is_conservative_and_fits(scene):
     f = np.floor(p * inv + (-lo * inv).astype(np.float32)).astype(np.float32)     # fma vs mul+add: inside the 1e-5 m slack
     f = np.clip(f, 0.0, (dims - 1).astype(np.float32))
     idx = ((f[:, 2] * np.float32(dims[1]) + f[:, 1]) * np.float32(dims[0]) + f[:, 0]).astype(np.int64)
+    inside = ((p >= lo) & (p <= lo + dims / inv)).all(1)
+    # ... and as grid_cell_rel does (persistent kernels, MPPI): fma(x, 1/h, 1.5 * 2^23) -- exact product, ONE rounding to the
+    # integer grid of [2^23, 2^24), ties to even --, the linear index combined in the same float form, clamped
+    MAGIC = 12582912.0
+    t = (p.astype(np.float64) * inv.astype(np.float64) + MAGIC).astype(np.float32).astype(np.float64) - MAGIC      # round(x / h) per axis
+    lin = t[:, 0] + dims[0] * (t[:, 1] + dims[1] * t[:, 2]) - g['k_lin']
+    idx2 = np.clip(lin, 0, len(words) - 1).astype(np.int64)
+    ins = ((t - K >= 0) & (t - K <= dims - 1)).all(1)                 # points whose cell lies inside the box on every axis
+    assert (np.abs(idx2[ins & inside] - idx[ins & inside]) <= dims[0] * dims[1] + dims[0] + 1).all()
+    for which, ii in (('floor', idx), ('lattice', idx2)):
+        ww = words[ii]
+        lst = np.stack([(ww >> (8 * s_)) & 0xFF for s_ in range(4)], 1)
+        d_ = np.linalg.norm(p[:, None, :3].astype(np.float64) - sph[None, :, :3].astype(np.float64), axis=2)
+        near_ = d_ < (sph[None, :, 3].astype(np.float64) + a_max)
+        for i in np.nonzero(near_.any(1))[0]:
+            if ww[i] == G.GRID_OVERFLOW:
+                continue
+            need = set(np.nonzero(near_[i])[0].tolist())
+            assert need <= set(lst[i].tolist()), (scene, which, i, need, lst[i])
     w = words[idx]
     listed = np.stack([(w >> (8 * s)) & 0xFF for s in range(4)], 1)
     d = np.linalg.norm(p[:, None, :3].astype(np.float64) - sph[None, :, :3].astype(np.float64), axis=2)
     near = d < (sph[None, :, 3].astype(np.float64) + a_max)                       # obstacles that can matter at p
-    inside = ((p >= lo) & (p <= lo + dims / inv)).all(1)     # outside the grid box nothing is within reach by construction
-    assert not near[~inside].any()
+    assert not near[~inside].any()                           # outside the grid box nothing is within reach by construction
     for i in np.nonzero(near.any(1))[0]:
         if w[i] == G.GRID_OVERFLOW:
             continue
