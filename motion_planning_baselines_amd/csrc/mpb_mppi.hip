@@ -98,7 +98,10 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
     const int c = CC ? CC : c_rt;
     const int nw = blockDim.x >> 6, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     MppiLds M;
-    M.wvec = lds;
+    // the mean of the problem lives in LDS for the whole launch (round 5: it was read from / written to global memory in three
+    // phases of every iteration, each a round trip on the iteration's critical path) and goes back once at the end
+    float* m = lds;
+    M.wvec = lds + ((c * T + 3) & ~3);
     M.red = M.wvec + c * T;
     M.wts = M.red + 64;
     M.cst = M.wts + ((S + 3) & ~3);
@@ -128,7 +131,8 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
         }
     }
     const int prob = blockIdx.x;
-    float* m = mean + (size_t)prob * T * c;
+    float* mean_g = mean + (size_t)prob * T * c;
+    for (int e = threadIdx.x; e < T * c; e += blockDim.x) m[e] = mean_g[e];
     const float w_pos = cw[0], w_ctrl = cw[2], w_posT = cw[3];
     if (tril_in_lds) {
         for (int e = threadIdx.x; e < c * T * T; e += blockDim.x) {       // coalesced read, transposed write
@@ -153,6 +157,8 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
         umax[i] = on ? ctrl_max[i] : 0.f;
     }
     float* ew = M.epsw + (size_t)wave * c * T;
+    const float inv_temp = 1.0f / temp;
+    const float dsc0 = (lane < T) ? discount[lane] : 0.f;        // the discount of this lane's step in the first 64-step chunk
     float best_c = (best_cost != nullptr) ? best_cost[prob] : 0.f;   // running best over all iterations (and calls)
 
     for (int it = 0; it < n_iters; ++it) {
@@ -169,12 +175,16 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
                 const float* row = cov_inv + ((size_t)i * T + t) * T;
                 for (int k = seg; k < T; k += 8) a = fmaf(row[k], m[k * c + i], a);
             }
-            a += __shfl_xor(a, 1, 64);
-            a += __shfl_xor(a, 2, 64);
-            a += __shfl_xor(a, 4, 64);
+            // (the eight partial sums meet on the DPP path: quad_perm [1,0,3,2], [2,3,0,1], then row_half_mirror brings the other
+            // quad of the eight-lane group -- the association of the xor-1, -2, -4 butterfly, without its three trips through
+            // the LDS crossbar)
+            a += dpp_f32<0xB1>(a);
+            a += dpp_f32<0x4E>(a);
+            a += dpp_f32<0x141>(a);
             if (e < c * T && seg == 0) M.wvec[e] = a;
         }
-        __syncthreads();
+        // (matrix path: the draw below does not need w; the barriers behind the draw and behind the product order it before the rollouts)
+        if (!matrix) __syncthreads();
         if (matrix) {
             // ---- the standard normals of EVERY sample (the same stream as below: one Philox call per (sample, dimension,
             //      group of four steps)), then U = mean + L eps on the matrix pipe, one (16 steps x 16 samples) tile per wave
@@ -325,7 +335,7 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
                             is = fmaf(u[i], M.wvec[i * T + t], is);
                         }
                     }
-                    const float dsc = discount[t];
+                    const float dsc = (base == 0) ? dsc0 : discount[t];
                     pos_l += pc * dsc;
                     ctl_l += cc * dsc;
                     is_l += is;
@@ -362,11 +372,14 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
                     }
                 }
             }
-            const float pos_cost = wave_sum_f32(pos_l), ctl_cost = wave_sum_f32(ctl_l), term = wave_sum_f32(term_l);
-            const float is_term = wave_sum_f32(is_l);
-            const float coll_s = wave_sum_f32(coll_l);
+            // the sample's cost = position + (velocity: empty slice, quirk Q8) + control + terminal + temp * importance term
+            // (point.py:198-226, mppi.py:125-128): the four per-step contributions are added PER LANE and reduced once (round 5:
+            // four wave reductions of ~15 vector instructions each were a tenth of the kernel's vector work); the collision
+            // part stays separate (quirk Q6 sums it over the samples)
+            const float cost_s = wave_sum_f32((pos_l + ctl_l) + (term_l + temp * is_l));
+            const float coll_s = (geom != nullptr) ? wave_sum_f32(coll_l) : 0.f;
             if (lane == 0) {
-                M.cst[s] = pos_cost + 0.f /* vel_cost: empty slice, quirk Q8 */ + ctl_cost + term + temp * is_term;
+                M.cst[s] = cost_s;
                 M.coll[s] = coll_s;
             }
         }
@@ -423,10 +436,11 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
         if (S <= 64) {
             // every wave repeats it on its own (lane = sample, wave reductions): no block-wide reduction, one barrier
             const float cs = (lane < S) ? M.cst[lane] + total : 0.f;
-            const float xs = (lane < S) ? -cs / temp : -3.0e38f;
+            // (v_exp / v_rcp: mpb_common.h fast_expf / fast_rcpf, as in the persistent STOMP kernels; the sum holds exp(0) = 1)
+            const float xs = (lane < S) ? -cs * inv_temp : -3.0e38f;
             const float mx = wave_max_f32(xs);
-            const float ex = (lane < S) ? expf(xs - mx) : 0.f;
-            const float w = ex / wave_sum_f32(ex);
+            const float ex = (lane < S) ? fast_expf(xs - mx) : 0.f;
+            const float w = ex * fast_rcpf(wave_sum_f32(ex));
             if (wave == 0 && lane < S) {
                 M.wts[lane] = w;
                 if (last) {
@@ -452,27 +466,25 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
             }
         }
         __syncthreads();
-        // ---- mean += step * sum_s w_s (U_s - mean)   (mppi.py:79-84), one thread per (i, t)
-        for (int e = threadIdx.x; e < T * c; e += blockDim.x) {
-            const int i = e / T, t = e - i * T;
+        // ---- mean += step * sum_s w_s (U_s - mean)   (mppi.py:79-84).  Sixteen elements (i, t) per wave, FOUR lanes per element
+        //      (one per 16-lane row): lane row p sums the samples s = p, p + 4, p + 8, ... in ascending order, the four partial
+        //      sums meet as (p0 + p1) + (p2 + p3) -- an association that depends on S alone, so the result does not depend on
+        //      how many waves the problem was given.  (One thread per element walked all S samples: 128 busy threads of 512,
+        //      two dependent LDS reads per sample each.)
+        for (int e0 = 0; e0 < T * c; e0 += 16 * nw) {
+            const int e = e0 + 16 * wave + (lane & 15), part = lane >> 4;
+            const bool on = e < T * c;
+            const int i = on ? e / T : 0, t = on ? e - i * T : 0;
             const float mu = m[t * c + i];
             float a = 0.f;
-            int ss = 0;
-            for (; ss + 8 <= S; ss += 8) {
-                float wv[8], uv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    wv[u] = M.wts[ss + u];
-                    uv[u] = M.Us[(size_t)(ss + u) * us_stride + i * T + t];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) a += wv[u] * (uv[u] - mu);
-            }
-            for (; ss < S; ++ss) a += M.wts[ss] * (M.Us[(size_t)ss * us_stride + i * T + t] - mu);
-            m[t * c + i] = mu + step_size * a;
+            for (int ss = part; ss < S; ss += 4) a += M.wts[ss] * (M.Us[(size_t)ss * us_stride + i * T + t] - mu);
+            a += __shfl_xor(a, 16, 64);
+            a += __shfl_xor(a, 32, 64);
+            if (on && part == 0) m[t * c + i] = mu + step_size * a;
         }
-        __threadfence_block();
     }
+    __syncthreads();
+    for (int e = threadIdx.x; e < T * c; e += blockDim.x) mean_g[e] = m[e];
 }
 
 extern "C" int mpb_mppi_step(float* mean, const float* eps, const float* scale_tril, const float* cov_inv,
@@ -505,7 +517,7 @@ extern "C" int mpb_mppi_step(float* mean, const float* eps, const float* scale_t
     int nw = S < 16 ? S : 16;
     if (NP >= 2 * n_cu && S >= 16) nw = 8;
     if (force_nw > 0 && force_nw <= 16 && force_nw <= S) nw = force_nw;
-    const size_t base = (size_t)c * T + 64 + 3 * (size_t)((S + 3) & ~3) + (size_t)S * (c * T + 4) + (size_t)nw * c * T;
+    const size_t base = (size_t)((c * T + 3) & ~3) + (size_t)c * T + 64 + 3 * (size_t)((S + 3) & ~3) + (size_t)S * (c * T + 4) + (size_t)nw * c * T;
     const size_t with_tril = base + (size_t)c * T * T;
     const size_t budget = 150 * 1024 / sizeof(float);
     if (base > budget) return mpb_fail(MPB_E_UNSUPPORTED, "mpb_mppi_step: S*T*c too large for the LDS controls slab");
