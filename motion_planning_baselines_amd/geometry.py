@@ -291,6 +291,10 @@ def build_grid(spheres, a_max, slack=1e-4, planar=False):
     inv32 = np.array([f[1] for f in fits], dtype=np.float32)
     K = np.array([f[2] for f in fits], dtype=np.int64)
     cell_eff = 1.0 / inv32.astype(np.float64)
+    # the kernels hold round(x / h) and the linear lattice index exactly in fp32 (integers below 2^22) and resolve a cell at
+    # |x| / h only while fp32 does: a scene that far from the origin gets no grid (the exhaustive evaluators serve it)
+    if np.abs(K).max() + dims.max() >= (1 << 16) or abs(int(K[0] + dims[0] * (K[1] + dims[1] * K[2]))) + int(dims.prod()) >= (1 << 21):
+        return None
     lo_s = (K - 0.5) * cell_eff
     lo32 = lo_s.astype(np.float32)
     # the kernels take the cell from fp32 arithmetic on x: a point within ~1e-5 of a cell face may land in the neighbour --

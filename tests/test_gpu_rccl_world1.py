@@ -75,6 +75,11 @@ def test_bench_bare_command_launches_its_own_ranks(gpu_device):
     assert line['dist']['backend'] == 'gloo' and line['scaling'] == 'weak' and 'c5' in line['scaling_note']
     assert line['metric'] == 'stomp_trajectory_update_iters_per_sec' and line['value'] > 1000
     assert line['c5']['value'] > 0 and 'cpu_baseline' not in line
+    #  the N > 1 line carries c5 with its roofline (VALU issue from the committed PMC pass of its own
+    # instantiation, HBM from the algorithmic bytes, counter traffic) and says what its scaling figures mean
+    r5 = line['c5']['roofline']
+    assert r5['frac'] > 0 and r5['unit'] in ('G wave-instr/s', 'GB/s') and 'traffic' in r5
+    assert 'c5' in line['scaling_note'] and line['c5']['scaling'] == 'weak' 
     # a mismatch between --gpus and an existing WORLD_SIZE is an error message, not an assert
     bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1'],
                          env=dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0'), capture_output=True, text=True, timeout=300)
