@@ -4,6 +4,7 @@
 #   * bench.py (the driver's command)                         -> profiles/<tag>_bench.json
 #   * rocprofv3 stats + PMC of the headline (profile_round.sh) -> <tag>_kernel_stats_bench.csv, <tag>_pmc_per_wave.md, <tag>_pmc_stomp.json
 #   * GPMP2 C4 (profile_gpmp2.sh), CHOMP C2, MPPI NP=1024      -> <tag>_gpmp2_*, <tag>_chomp_*, <tag>_mppi_*
+#   * c5 (<14,1,2> at P = 4096) and H = 128 PMC passes        -> <tag>_pmc_stomp_c5.json, <tag>_pmc_stomp_h128.json
 #   * large-B sweep                                             -> <tag>_large_b_sweep.txt
 #   * shapes beyond H = 64 / gradient evaluators                -> <tag>_other_shapes.txt
 # rocprofv3 counter passes run with --kernel-trace only (never with a sys / hip / hsa trace).
@@ -25,6 +26,9 @@ for drv in chomp mppi; do
   python3 scripts/pmc_summary.py $OUT ${TAG}_$drv > /dev/null
   echo "$drv passes done"
 done
+bash scripts/profile_c5.sh $TAG > gpurun_out/${TAG}_profile_c5.log 2>&1
+bash scripts/profile_h128.sh $TAG > gpurun_out/${TAG}_profile_h128.log 2>&1
+echo "c5 / h128 passes done"
 python3 scripts/bench_large_b.py > profiles/${TAG}_large_b_sweep.txt 2> gpurun_out/${TAG}_large_b.err
 echo "large-B sweep done"
 ( python3 scripts/bench_hx.py; python3 scripts/bench_grad.py ) > profiles/${TAG}_other_shapes.txt 2> gpurun_out/${TAG}_other.err
@@ -32,6 +36,9 @@ echo "large-B sweep done"
 python3 bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 cp gpurun_out/${TAG}_bench.json profiles/${TAG}_bench.json
 echo "bench done"
+# the two-rank rehearsal on this box's one GPU (gloo: ranks share the device; the 8-GPU node runs the same command on RCCL)
+MPB_DIST_BACKEND=gloo python3 bench.py --gpus 2 --steps 20 --warmup 5 > profiles/${TAG}_bench_2ranks_one_gpu_gloo.json 2> gpurun_out/${TAG}_bench2.err || true
+echo "two-rank rehearsal done"
 # what travels back from the GPU box is gpurun_out/ (<= 64 MiB): the summaries, not the raw rocprofv3 databases
 mkdir -p gpurun_out/profiles_${TAG}
 cp profiles/${TAG}_* gpurun_out/profiles_${TAG}/
