@@ -14,7 +14,9 @@ test aid mpb_debug_stomp_normals_h for the same (seed, iter0, particle_offset) a
   (iii) the same normals INJECTED through the eps argument (the LOW = true instantiation; their third bf16 component is
         zero by construction) give bit-identical samples, costs, weights and means.
 
-Shapes: C3 (P = 128, S = 32, H = 64, d = 14, sigma_coll = 1e-3: persistent exchange layout, stomp_fused_kernel<14,1,1> --
+(Round 5, later: the H = 64 kernel has separate instantiations for drawn and injected noise -- `INJ` -- so (iii) also holds the two
+instantiations to the same bits.)
+Shapes: C3 (P = 128, S = 32, H = 64, d = 14, sigma_coll = 1e-3: persistent exchange layout, stomp_fused_kernel<14,1,1,false> --
 the headline's instantiation), P = 256 (two-batch layout, <14,1,2>: the `c5` entry's), H = 128 (stomp_fused_hx_kernel, the
 product issued TRANSPOSED, chunked draw), d = 7 pos_only (stomp_noise_bf16_pair: two rollouts per product), H = 48 (the
 generalised kernel on a partial chunk: the drawn columns k >= H meet zero columns of L) and the two-kernel path
