@@ -52,7 +52,8 @@ __device__ __forceinline__ void hx_transpose_to_rows(const f32x4 (&acc)[4], floa
     }
 }
 
-template <int DCH, int MODEL, int HC>
+// INJ = false: the instantiation of the device-noise calls does not carry the injected-noise path (as in mpb_stomp_fused.hip)
+template <int DCH, int MODEL, int HC, bool INJ>
 __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
     float* __restrict__ means, const float* __restrict__ eps, float* __restrict__ samples, float* __restrict__ costs,
     float* __restrict__ weights, const float* __restrict__ Lmat, const float* __restrict__ Sigma,
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
     float weight, float lr, float temperature, int n_iters, uint32_t seed_lo, uint32_t seed_hi, uint32_t iter0,
     uint32_t particle_offset, uint32_t tag0, unsigned long long timeout_ticks, unsigned* __restrict__ status_host,
     float* __restrict__ means_copy) {
+    if (!INJ) eps = nullptr;
     constexpr int DX = DCH ? DCH : 16;                 // channels held in registers / tile rows
     constexpr int RB = FUSED_WAVES / HC;               // rollouts per pass
     constexpr int HP = 64 * HC;                        // padded horizon
@@ -574,10 +576,15 @@ int mpb_fused_hx_launch(float* means, const float* eps, float* samples, float* c
                         float* means_copy, hipStream_t st, const FusedProfile* prof) {
     const dim3 grid(P * nc), block(FUSED_THREADS);
     const int model = geom_flags & 0xFF;
-#define MPB_HX_LAUNCH(DCH, MODEL, HC)                                                                                          \
-    MPB_FUSED_LAUNCH(prof, (stomp_fused_hx_kernel<DCH, MODEL, HC>), grid, block, st, means, eps, samples, costs, weights, L,   \
-                     Sigma, geom, workspace, P, S, H, d, nc, nb, k_sigma, weight, lr, temperature, n_iters, lo, hi, iter0,     \
+#define MPB_HX_LAUNCH_(DCH, MODEL, HC, INJ)                                                                                        \
+    MPB_FUSED_LAUNCH(prof, (stomp_fused_hx_kernel<DCH, MODEL, HC, INJ>), grid, block, st, means, eps, samples, costs, weights, L,  \
+                     Sigma, geom, workspace, P, S, H, d, nc, nb, k_sigma, weight, lr, temperature, n_iters, lo, hi, iter0,         \
                      particle_offset, tag0, timeout, status_dev, means_copy)
+#define MPB_HX_LAUNCH(DCH, MODEL, HC)                       \
+    do {                                                    \
+        if (eps) MPB_HX_LAUNCH_(DCH, MODEL, HC, true);      \
+        else MPB_HX_LAUNCH_(DCH, MODEL, HC, false);         \
+    } while (0)
     if (H > 64) {
         if (model == PandaModel::ID && d == 7) MPB_HX_LAUNCH(7, PandaModel::ID, 2);
         else if (model == PandaModel::ID && d == 14) MPB_HX_LAUNCH(14, PandaModel::ID, 2);
@@ -588,5 +595,6 @@ int mpb_fused_hx_launch(float* means, const float* eps, float* samples, float* c
         else MPB_HX_LAUNCH(0, 0, 1);
     }
 #undef MPB_HX_LAUNCH
+#undef MPB_HX_LAUNCH_
     return mpb_check_launch("mpb_stomp_run");
 }

@@ -514,7 +514,8 @@ def test_headline_kernels_have_no_scratch():
             '_Z18stomp_fused_kernelILi14ELi1ELi1ELb1EE', '_Z18stomp_fused_kernelILi14ELi1ELi2ELb1EE',   # ... and their injected-noise twins (parity tests)
             '_Z18stomp_fused_kernelILi7ELi1ELi1ELb0EE', '_Z18stomp_fused_kernelILi7ELi1ELi2ELb0EE',     # the same, pos_only
             '_Z18stomp_fused_kernelILi7ELi1ELi1ELb1EE', '_Z18stomp_fused_kernelILi7ELi1ELi2ELb1EE',
-            '_Z21stomp_fused_hx_kernelILi14ELi1ELi2EE', '_Z21stomp_fused_hx_kernelILi14ELi1ELi1EE',   # H = 128 / H < 64
+            '_Z21stomp_fused_hx_kernelILi14ELi1ELi2ELb0EE', '_Z21stomp_fused_hx_kernelILi14ELi1ELi1ELb0EE',   # H = 128 / H < 64, device noise
+            '_Z21stomp_fused_hx_kernelILi14ELi1ELi2ELb1EE', '_Z21stomp_fused_hx_kernelILi14ELi1ELi1ELb1EE',   # ... injected noise
             '_Z11mppi_kernelILi2ELb1EE']                                                                # the mppi entry
     for name in must:
         r = find(name)
@@ -528,8 +529,9 @@ def test_headline_kernels_have_no_scratch():
         'gpmp2_solve_kernel<7,true,true>': 32,     # several collision fields AND the Sherman-Morrison form (256 registers + 7)
         'stomp_fused_kernel<14,0,2,true>': 28, 'stomp_fused_kernel<7,0,2,true>': 28, 'stomp_fused_kernel<7,0,2,false>': 16,
         'stomp_fused_kernel<6,0,2,true>': 8,       # table-driven walk, two batches (mostly the injected-noise twins)
-        'stomp_fused_hx_kernel<0,0,1>': 56, 'stomp_fused_hx_kernel<0,0,2>': 112,   # run-time d, table-driven walk
-        'stomp_fused_hx_kernel<7,1,2>': 20,
+        'stomp_fused_hx_kernel<0,0,1,true>': 56, 'stomp_fused_hx_kernel<0,0,2,true>': 112,   # run-time d, table-driven walk
+        'stomp_fused_hx_kernel<0,0,1,false>': 16, 'stomp_fused_hx_kernel<0,0,2,false>': 76,
+        'stomp_fused_hx_kernel<7,1,2,true>': 20,
     }
 
     def short(mangled):
