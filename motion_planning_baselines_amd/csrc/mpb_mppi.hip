@@ -84,7 +84,11 @@ struct MppiLds {
 // CC: the control dimension as a compile-time constant (2: the reference example's point mass; 0: run-time c <= MPPI_MAX_C);
 // GRID: collision through the broad-phase grid (ONE grid-backed field) -- the exhaustive evaluator, with its blocks of obstacles
 // in scalar registers, lives in the other instantiation (one kernel holding both spilled 48 VGPRs and 292 SGPRs)
-template <int CC, bool GRID>
+// MATRIX: the noise product of all samples on the matrix pipe (MPPI_NOISE_MATRIX) as a compile-time fact -- the instantiation then
+// carries neither the per-lane product nor its operands (round 5: the kernel spilled 155 SGPRs, a fifth of its vector
+// instructions were v_readlane / v_writelane of spilled scalars)
+// INJ: injected normals supported (eps != NULL); the device-noise instantiation does not carry that path.
+template <int CC, bool GRID, bool MATRIX, bool INJ>
 __global__ __launch_bounds__(1024) void mppi_kernel(
     float* __restrict__ mean, const float* __restrict__ eps, const float* __restrict__ tril,
     const float* __restrict__ cov_inv, const float* __restrict__ state0, const float* __restrict__ goal,
@@ -95,6 +99,7 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
     float dt, float k_sigma, float weight, float temp, float step_size, int n_iters, uint32_t seed_lo,
     uint32_t seed_hi, uint32_t iter0, int noise_mode, int grid_words) {
     extern __shared__ float lds[];
+    if (!INJ) eps = nullptr;
     const int c = CC ? CC : c_rt;
     const int nw = blockDim.x >> 6, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     MppiLds M;
@@ -109,7 +114,8 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
     M.Us = M.coll + ((S + 3) & ~3);
     M.epsw = M.Us + (size_t)S * (c * T + 4);
     M.trilT = M.epsw + (size_t)nw * c * T;
-    const bool tril_in_lds = noise_mode == MPPI_NOISE_LDS, matrix = noise_mode == MPPI_NOISE_MATRIX;
+    const bool matrix = MATRIX;                        // (the launcher picks the instantiation by noise_mode)
+    const bool tril_in_lds = !MATRIX && noise_mode == MPPI_NOISE_LDS;
     const int us_stride = c * T + 4;                   // words between the samples of the controls slab (see the matrix product)
     const int Spad = (S + 15) & ~15;
     if (matrix) {                      // (no per-wave normals: the slab holds every sample's)
@@ -167,11 +173,12 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
         // ---- w_i = Cov_inv[i] @ mean_i (vector of the importance-sampling term)
         // eight lanes per output row: each reads a contiguous eighth of the row (coalesced), the partial sums meet in
         // a three-step lane exchange.  (One thread per row walked the row with T dependent, uncoalesced global loads.)
-        for (int e0 = 0; e0 < c * T; e0 += blockDim.x >> 3) {
-            const int e = e0 + (threadIdx.x >> 3), seg = threadIdx.x & 7;
+        for (int i = 0; i < c; ++i)
+        for (int t0 = 0; t0 < T; t0 += blockDim.x >> 3) {
+            const int t = t0 + (threadIdx.x >> 3), seg = threadIdx.x & 7;
+            const int e = i * T + t;
             float a = 0.f;
-            if (e < c * T) {
-                const int i = e / T, t = e - i * T;
+            if (t < T) {
                 const float* row = cov_inv + ((size_t)i * T + t) * T;
                 for (int k = seg; k < T; k += 8) a = fmaf(row[k], m[k * c + i], a);
             }
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
             a += dpp_f32<0xB1>(a);
             a += dpp_f32<0x4E>(a);
             a += dpp_f32<0x141>(a);
-            if (e < c * T && seg == 0) M.wvec[e] = a;
+            if (t < T && seg == 0) M.wvec[e] = a;
         }
         // (matrix path: the draw below does not need w; the barriers behind the draw and behind the product order it before the rollouts)
         if (!matrix) __syncthreads();
@@ -200,9 +207,15 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
                 // samples -- 32 consecutive lanes then write banks 4 ss + g4 = 0..31 of the slab (its sample stride is 4 mod 32),
                 // where groups fastest over all sixteen put two samples on the same banks: the 2-way conflict that was left
                 // of round 3's 16-way one.  The counters do not depend on the lane: same stream)
+                // (round 5: a WAVE takes a (dimension, high group) pair -- wave-uniform, scalar arithmetic -- and its lanes run over
+                // (sample, low group): the flat index of round 4 cost four integer divisions by run-time values per draw, ~100
+                // vector instructions where the draw itself is ~110)
                 const int G4q = (G4 + 3) >> 2;
-                for (int l = threadIdx.x; l < c * S * 4 * G4q; l += blockDim.x) {
-                    const int glo = l & 3, r1 = l >> 2, ss = r1 % S, r2 = r1 / S, ghi = r2 % G4q, i = r2 / G4q;
+                const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+                for (int pr = wave_s; pr < c * G4q; pr += nw) {
+                    const int i = pr / G4q, ghi = pr - i * G4q;              // (scalar)
+                for (int ql = lane; ql < 4 * S; ql += 64) {
+                    const int glo = ql & 3, ss = ql >> 2;
                     const int g4 = 4 * ghi + glo;
                     if (g4 >= G4) continue;
                     const uint4 rr = philox4x32<7>(make_uint4((uint32_t)prob, (uint32_t)ss, (uint32_t)g4 | ((uint32_t)i << 16),
@@ -215,12 +228,19 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
                     for (int q = 0; q < 4; ++q)
                         if (4 * g4 + q < T) M.E[((size_t)i * Spad + ss) * MPPI_E_STRIDE + q * 16 + g4] = n[q];
                 }
+                }
             }
             __syncthreads();
             const int NT = Spad >> 4, j = lane & 15, g = lane >> 4;
             const f32x4* L4 = reinterpret_cast<const f32x4*>(M.trilT);
-            for (int tile = wave; tile < c * 4 * NT; tile += nw) {
-                const int i = tile / (4 * NT), r = tile - i * 4 * NT, mt = r / NT, nt = r - mt * NT;
+            // (tile = (i * 4 + mt) * NT + nt, every nw-th one this wave's: walked with scalar counters, no division)
+            const int wave_t = __builtin_amdgcn_readfirstlane(wave);
+            int tile_idx = 0, tile_next = wave_t;
+            for (int i = 0; i < c; ++i)
+            for (int mt = 0; mt < 4; ++mt)
+            for (int nt = 0; nt < NT; ++nt) {
+                if (tile_idx++ != tile_next) continue;
+                tile_next += nw;
                 if (16 * mt >= T) continue;                                              // (wave-uniform)
                 const f32x4* e4 = reinterpret_cast<const f32x4*>(M.E + ((size_t)i * Spad + 16 * nt + j) * MPPI_E_STRIDE + g * 16);
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -471,10 +491,11 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
         //      sums meet as (p0 + p1) + (p2 + p3) -- an association that depends on S alone, so the result does not depend on
         //      how many waves the problem was given.  (One thread per element walked all S samples: 128 busy threads of 512,
         //      two dependent LDS reads per sample each.)
-        for (int e0 = 0; e0 < T * c; e0 += 16 * nw) {
-            const int e = e0 + 16 * wave + (lane & 15), part = lane >> 4;
-            const bool on = e < T * c;
-            const int i = on ? e / T : 0, t = on ? e - i * T : 0;
+        for (int i = 0; i < c; ++i)
+        for (int t0 = 0; t0 < T; t0 += 16 * nw) {
+            const int tt = t0 + 16 * wave + (lane & 15), part = lane >> 4;
+            const bool on = tt < T;
+            const int t = on ? tt : 0;
             const float mu = m[t * c + i];
             float a = 0.f;
             for (int ss = part; ss < S; ss += 4) a += M.wts[ss] * (M.Us[(size_t)ss * us_stride + i * T + t] - mu);
@@ -542,8 +563,14 @@ extern "C" int mpb_mppi_step(float* mean, const float* eps, const float* scale_t
         }
     }
     const size_t lds = lds_words * sizeof(float);
-#define MPPI_LAUNCH(CC, GRID)                                                                                                   \
-    hipLaunchKernelGGL((mppi_kernel<CC, GRID>), dim3(NP), dim3(64 * nw), lds, (hipStream_t)stream, mean, eps, scale_tril, cov_inv, \
+#define MPPI_LAUNCH(CC, GRID)                                          \
+    do {                                                               \
+        if (noise_mode == MPPI_NOISE_MATRIX && eps) MPPI_LAUNCH_(CC, GRID, true, true);    \
+        else if (noise_mode == MPPI_NOISE_MATRIX) MPPI_LAUNCH_(CC, GRID, true, false);    \
+        else MPPI_LAUNCH_(CC, GRID, false, true);                      \
+    } while (0)
+#define MPPI_LAUNCH_(CC, GRID, MATRIX, INJ)                                                                                                   \
+    hipLaunchKernelGGL((mppi_kernel<CC, GRID, MATRIX, INJ>), dim3(NP), dim3(64 * nw), lds, (hipStream_t)stream, mean, eps, scale_tril, cov_inv, \
                        state0, goal, ctrl_min, ctrl_max, discount, c_weights, geom, controls, states, costs, weights, best_cost,  \
                        best_states, S, T, c, dt, k_sigma, weight, temp, step_size, n_iters, (uint32_t)seed,                        \
                        (uint32_t)(seed >> 32), iter0, noise_mode, grid_words)
@@ -552,6 +579,7 @@ extern "C" int mpb_mppi_step(float* mean, const float* eps, const float* scale_t
     else if (grid_words > 0) MPPI_LAUNCH(0, true);
     else MPPI_LAUNCH(0, false);
 #undef MPPI_LAUNCH
+#undef MPPI_LAUNCH_
     return mpb_check_launch("mpb_mppi_step");
 }
 
