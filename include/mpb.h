@@ -40,9 +40,16 @@ extern "C" {
 #define MPB_MAX_H 256
 #define MPB_MAX_DOF 8
 
-/* ABI version in the low 16 bits (MPB_ABI_VERSION: bumped whenever a signature of this header changes positionally; a
- * binding must refuse a library that reports another number); bit 30 set = a tuning build (compiled with wrong-result timing switches: never a product library) */
-#define MPB_ABI_VERSION 4
+/* ABI version in the low 16 bits (MPB_ABI_VERSION: bumped whenever a signature of this header changes positionally or a call that
+ * used to be accepted is now refused; a binding must refuse a library that reports another number); bit 30 set = a tuning build
+ * (compiled with wrong-result timing switches: never a product library).
+ * Changes:  4 (round 4)  workspace header of the persistent STOMP kernels 64 -> 1 280 bytes; device-noise streams of STOMP / MPPI
+ *                        changed (Philox4x32-7, 23-bit Box-Muller): not reproducible across 3 -> 4;
+ *           5 (round 5)  geometry buffers are version 6 (broad-phase grid on a lattice through the origin, header word 31; a
+ *                        version-5 buffer is refused by mpb_geom_check); the STOMP entry points refuse pointers that are not
+ *                        16-byte aligned; a model-tagged geometry must keep margin + radii below 1 m; mpb_gpmp2_solve applies the
+ *                        collision factors by Sherman-Morrison beyond a precision ratio of 1e7 (more accurate results there). */
+#define MPB_ABI_VERSION 5
 #define MPB_VERSION_TUNING_BUILD 0x40000000
 int mpb_version(void);
 const char *mpb_last_error(void);
