@@ -203,3 +203,44 @@ def test_two_batch_layout_equals_exchange_layout(gpu_device, tmp_path, P, S, pos
     for k in ('samples', 'costs', 'weights', 'means'):
         assert res[1][k].tobytes() == res[2][k].tobytes(), k
     assert np.isfinite(res[1]['means']).all() and float(res[1]['costs'].max()) > 0
+
+
+@pytest.mark.parametrize('shift', [(0.0, 0.0, 0.0), (-7.3, 2.1, -0.4), (55.0, -31.0, 12.0)])
+def test_lattice_grid_offset_equals_floor_form_on_shifted_scenes(gpu_device, shift):
+    """Geometry version 6: the persistent kernel takes a point's cell as round(x / h) - K from one fma per axis (grid_cell_rel,
+    csrc/mpb_geom.h), the two-kernel path as floor((x - lo) / h) from the same header.  A 3-D point robot among spheres shifted
+    far from the origin (negative and large lattice indices K): rollouts that cross cell faces everywhere -- the costs of the two
+    paths are the same BITS (candidate sets are conservative on both), and equal the exhaustive evaluator's."""
+    from motion_planning_baselines_amd import geometry as G, ops
+    from motion_planning_baselines_amd.planners.stomp import precision_to_scale_tril, stomp_precision_matrix
+    dev = gpu_device
+    rng = np.random.default_rng(3)
+    off = np.array(shift)
+    sph = np.concatenate([rng.uniform(-1, 1, (14, 3)) + off, rng.uniform(0.05, 0.2, (14, 1))], 1).astype(np.float32)
+    robot, field = G.RobotPointMass(3, radius=0.02), G.CollisionField(spheres=sph, margin=0.03)
+    geom = ops.DeviceGeometry(robot, field, dev)
+    assert geom.flags & 0x100
+    P, S, H, d = 6, 16, 64, 6
+    a = torch.linspace(0, 1, H).reshape(1, H, 1)
+    s0 = torch.tensor(rng.uniform(-1, 1, (P, 1, 3)) + off, dtype=torch.float32)
+    g0 = torch.tensor(rng.uniform(-1, 1, (P, 1, 3)) + off, dtype=torch.float32)
+    means0 = torch.cat([s0 * (1 - a) + g0 * a, torch.zeros(P, H, 3)], -1).contiguous().to(dev)
+    R = stomp_precision_matrix(H, 0.04, 0.1, dict(device='cpu', dtype=torch.float32))
+    Sigma, L = torch.inverse(R).to(dev).contiguous(), precision_to_scale_tril(R).to(dev).contiguous()
+    out = []
+    for fused in (True, False):
+        means = means0.clone()
+        samples, costs, weights = torch.empty(P, S, H, d, device=dev), torch.empty(P, S, device=dev), torch.empty(P, S, device=dev)
+        if fused:
+            ws = _ws(P, S, H, d, dev)
+            assert ops.stomp_run_path(geom, ws, P, S, H, d) != ops.STOMP_PATH_TWO_KERNEL
+            ops.stomp_run(means, None, samples, costs, weights, L, Sigma, geom, S, 3, 1e2, 1.0, 0.1, 1.0, ws, n_iters=1, seed=5)
+        else:
+            ops.stomp_step(means, None, samples, costs, weights, L, Sigma, geom, S, 3, 1e2, 1.0, 0.1, 1.0, n_iters=1, seed=5)
+        torch.cuda.synchronize()
+        out.append((samples, costs))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    assert float(out[0][1].max()) > 0.0                                     # the rollouts do collide
+    # ... and the stand-alone evaluator (exhaustive for point robots) on the same samples
+    ref = ops.cost_collision_eval(out[0][0].reshape(P * S, H, d).contiguous(), geom, 1e2).reshape(P, S)
+    np.testing.assert_allclose(out[0][1].cpu().numpy(), ref.cpu().numpy(), rtol=2e-6, atol=1e-6)
