@@ -12,7 +12,7 @@ import torch.distributed as dist
 
 from .. import ops
 from .base import OptimizationPlanner
-from .costs.cost_functions import CostCollision, CostComposite, CostGP, CostGoalPrior
+from .costs.cost_functions import Cost, CostCollision, CostComposite, CostGP, CostGoalPrior, _TrajectoryTermCost
 
 SOLVE_METHODS = ('cholesky', 'inverse', 'lstq')
 
@@ -49,8 +49,9 @@ class GPMP2(OptimizationPlanner):
       * ``collision_fields`` (+ a CostCollision given as ``extra_costs``) hold one to four CollisionFields in total
         (chained in one geometry buffer, one block of collision rows per field like the reference); a CostGP / CostGoalPrior
         on the planner's own start / goal states as extra cost is folded into the solve's sigmas (its precision adds);
-        any other kind of extra cost raises NotImplementedError (in the reference only costs with a real get_linear_system can be
-        extra costs at all: the others return None and fail at the unpack, cost_functions.py:122-126);
+        any OTHER extra cost that has a get_linear_system (the reference stacks whatever has one) switches the planner to the
+        reference's dense step on the device (torch.linalg in fp64: correct, dense-sized); a cost without one raises
+        (in the reference it fails at the unpack, cost_functions.py:122-126);
       * ``solver_params['method']``: 'cholesky', 'inverse' and 'lstq' (gpmp2.py:432-491) all run the block solve --
         they are three dense solvers of the same SPD system; 'cholesky-sparse' raises like the reference (:457);
         ``_get_grad_terms`` / ``get_torch_solve`` exist as the reference's dense methods (for callers / subclasses), the
@@ -88,6 +89,8 @@ class GPMP2(OptimizationPlanner):
         merge = lambda a, b: (1.0 / a ** 2 + 1.0 / b ** 2) ** -0.5
         same = lambda a, b: a is not None and b is not None and tuple(a.shape) == tuple(b.shape) and \
             bool(torch.equal(a.detach().cpu().float(), b.detach().cpu().float()))
+        dense_extras = []
+
         def _same_problem(c, what):
             """an extra factor is merged only if it is built for THIS planner's horizon and DoF: the reference stacks its rows
             under the planner's (cost_functions.py:107-144) and fails at the concatenation when they do not match"""
@@ -117,9 +120,16 @@ class GPMP2(OptimizationPlanner):
                                               'states and num_particles_per_goal only (num_samples does '
                                               'not enter its get_linear_system, cost_functions.py:538-554)')
                 eff['goal'] = merge(eff['goal'], c.sigma_goal_prior)
+            elif callable(getattr(c, 'get_linear_system', None)) and getattr(type(c), 'get_linear_system', None) not in (
+                    Cost.get_linear_system, _TrajectoryTermCost.get_linear_system):       # (those two are the reference's bare `pass`)
+                # any other cost with a linear system (the reference stacks whatever has one, cost_functions.py:107-144): its rows
+                # may couple any waypoints, so the chain structure of the block solve is gone -- the planner then takes the
+                # reference's own DENSE step on the device (composite get_linear_system -> _get_grad_terms -> get_torch_solve,
+                # in fp64): correct, and as expensive as the reference's (N^2 words per particle)
+                dense_extras.append(c)
             else:
-                raise NotImplementedError('GPMP2 extra_costs: a CostCollision, or a CostGP / CostGoalPrior on the planner\'s own '
-                                          'start / goal states, is wired into the block solve; any other term is not')
+                raise NotImplementedError('GPMP2 extra_costs: a cost without a get_linear_system of its own cannot enter the Gauss-Newton step '
+                                          '(the reference fails at the unpack, cost_functions.py:122-126)')
         if not collision_fields or len(collision_fields) > 4:
             raise NotImplementedError('GPMP2 on the GPU takes one to four CollisionFields')
         solver_params = solver_params or dict(delta=1e-2, trust_region=True, method='cholesky')
@@ -144,6 +154,7 @@ class GPMP2(OptimizationPlanner):
         # no goal factor: sigma_goal = 0 is the C-ABI's explicit "precision 0" (include/mpb.h), not an infinite sigma
         self.sigmas = (eff['start'], eff['gp'], eff['goal'] if self.goal_directed else 0.0, sigma_coll)
         self.process_group = process_group
+        self._dense_extras = dense_extras
         self.geom = ops.DeviceGeometry(robot, collision_fields, self.device, scales=scales)   # one CostCollision per field (gpmp2.py:70-78)
         self.costs = None
         self._ws = None
@@ -223,6 +234,14 @@ class GPMP2(OptimizationPlanner):
         delta = self.solver_params['delta']
         trust = self.solver_params.get('trust_region', False)
         x = self._particle_means
+        if self._dense_extras:
+            # gpmp2.py:308-342 as the reference runs it: dense (A, b, K) of every member, normal equations, dense solve (fp64)
+            A, b, K = (t.double() for t in self.cost.get_linear_system(x, n_interpolated_points=self.n_interpolated_points))
+            JtJ, g = self._get_grad_terms(A, b, K, delta=delta, trust_region=trust)
+            d_theta = self.get_torch_solve(JtJ, g, method=self.solver_params.get('method', 'cholesky')).reshape(B, H, 2 * D)
+            self.costs = (b.transpose(1, 2) @ K @ b).reshape(B).to(torch.float32)
+            x.add_((self.step_size * d_theta).to(x.dtype))
+            return
         if trust and self.process_group is not None and dist.get_world_size(self.process_group) > 1:
             ops.gpmp2_linearize(x, self.geom, self._ws, n_interp=self.n_interpolated_points)
             dsum = ops.gpmp2_diag(self._ws, B, H, D, self.sigmas, self.dt, n_fields=self.geom.n_fields)
