@@ -431,15 +431,17 @@ __global__ __launch_bounds__(64 * MPB_A_WPB, 16 / MPB_A_WPB) void stomp_sample_c
                     if (MODEL == PandaModel::ID) {
                         // the launcher picked this instantiation from the caller's geom_flags; the device header has the
                         // last word: a buffer that is not tagged with the model poisons the cost instead of being mis-read
+                        // (`bad` is set below, wave-uniformly: lane 0 -- waypoint 0, outside the walk -- writes the cost)
                         if (G.model == PandaModel::ID) c = fmaf(G.fscale, waypoint_cost_grid_model<PandaModel>(G, gridw, otab, q), c);
-                        else bad = true;
                     } else {
                         c = fmaf(G.fscale, waypoint_cost_grid(G, gridw, otab, q), c);
                     }
                 }
+                if (MODEL != 0 && G.model != MODEL) bad = true;
+            } else if (MODEL != 0) {
+                bad = true;                                  // model instantiations are only launched for grid-backed fields
             } else if (live && h >= 1) {
-                if (MODEL != 0) bad = true;                  // model instantiations are only launched for grid-backed fields
-                else c = fmaf(G.fscale, waypoint_cost<false>(G, q, dq), c);
+                c = fmaf(G.fscale, waypoint_cost<false>(G, q, dq), c);
             }
             if (G.next == 0) break;
             gp += G.next;

@@ -339,11 +339,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
                     if (live && on && h >= 1) {
                         if (MODEL == PandaModel::ID) {
                             if (G.model == PandaModel::ID) c = fmaf(G.fscale, waypoint_cost_grid_model<PandaModel, true>(G, gridw, otab, q), c);
-                            else bad = true;
                         } else {
                             c = fmaf(G.fscale, waypoint_cost_grid<true>(G, gridw, otab, q), c);
                         }
                     }
+                    if (MODEL != 0 && G.model != MODEL) bad = true;    // (wave-uniform: lane 0 -- possibly waypoint 0, outside the walk -- writes the cost)
                     if (G.next == 0) break;
                     gp += G.next;
                     G = geom_view(gp);

@@ -1,8 +1,8 @@
 """Instruction-COST histogram of the headline kernel's iteration loop.
 
-    python scripts/isa_cost_hist.py [--kernel '_Z18stomp_fused_kernelILi14ELi1ELi1ELb0EE'] [--pmc profiles/r04_pmc_stomp.json] > profiles/rXX_isa_cost_hist.md
+    python scripts/isa_cost_hist.py [--kernel '_Z18stomp_fused_kernelILi14ELi1ELi1ELb0ELb0EE'] [--pmc profiles/r04_pmc_stomp.json] > profiles/rXX_isa_cost_hist.md
 
-What binds `stomp_fused_kernel<14,1,1,false>` (the device-noise instantiation the bench times) is the vector pipe: SQ_ACTIVE_INST_VALU says it is ~100 % busy at 4.15 cycles per
+What binds `stomp_fused_kernel<14,1,1,false,false>` (the device-noise instantiation the bench times) is the vector pipe: SQ_ACTIVE_INST_VALU says it is ~100 % busy at 4.15 cycles per
 instruction where the full rate is 2.  This script prices the loop body by opcode:
 
   1. compiles csrc/mpb_stomp_fused.hip to assembly with the product's flags (hipcc -S --cuda-device-only), cuts out the kernel and
@@ -163,7 +163,7 @@ def split_blocks(text, kernel_prefix):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--kernel', default='_Z18stomp_fused_kernelILi14ELi1ELi1ELb0EE')
+    ap.add_argument('--kernel', default='_Z18stomp_fused_kernelILi14ELi1ELi1ELb0ELb0EE')
     ap.add_argument('--pmc', default=None)
     ap.add_argument('--slot2-share', type=float, default=0.15, help='share of the later-slot trips that are slot 2 (scripts/grid_stats.py)')
     ap.add_argument('--asm', default=None, help='use this assembly file instead of compiling')

@@ -246,3 +246,103 @@ def test_gpmp2_two_fields_with_interpolation_vs_oracle(gpu_device):
     assert float(dref.abs().max()) > 1e-4
     assert float((dgpu - dref).abs().max() / dref.abs().max()) < 2e-3
     np.testing.assert_allclose(costs.cpu().numpy(), out['costs'].numpy(), rtol=2e-3)
+
+
+@pytest.mark.parametrize('P,S', [(3, 6), (70, 64)])
+def test_persistent_stomp_one_field_flag_is_rechecked_on_the_device(gpu_device, P, S):
+    """The persistent STOMP kernel has a ONE-field instantiation (template flag CHAIN = false, csrc/mpb_stomp_fused.hip) the
+    launcher takes on geom_flags bit 12.  With two fields it must take the chained form (checked against the oracle); a caller
+    whose flags claim one field over a device buffer that chains two gets NaN costs, never the first field's costs alone."""
+    from motion_planning_baselines_amd import ops
+    from motion_planning_baselines_amd.planners.stomp import precision_to_scale_tril, stomp_precision_matrix
+    from oracle import planners_ref as O
+    from oracle.geometry_ref import make_ref_geometry
+    dev = gpu_device
+    robot, fields = _setup('panda')
+    D, H = robot.q_dim, 64
+    d = 2 * D
+    scales = [1.0, 0.6]
+    geom = ops.DeviceGeometry(robot, fields, dev, scales=scales)
+    assert not geom.flags & 0x1000 and geom.flags & 0x100
+    one = ops.DeviceGeometry(robot, fields[:1], dev)
+    assert one.flags & 0x1000
+    cpu = dict(device='cpu', dtype=torch.float32)
+    R = stomp_precision_matrix(H, 0.05, 1.0, cpu)
+    Sigma, L = torch.inverse(R).contiguous(), precision_to_scale_tril(R).contiguous()
+    means0 = _trajs(robot, P, H, d, 4)
+    g = torch.Generator().manual_seed(8)
+    eps = torch.randn(2, S, d, P, H, generator=g)
+    sigma = 0.4
+
+    def run(gm):
+        means = means0.clone().to(dev)
+        samples = torch.empty(P, S, H, d, device=dev)
+        costs = torch.empty(P, S, device=dev)
+        weights = torch.empty(P, S, device=dev)
+        ws = ops.stomp_workspace(P, S, H, d, dev)
+        assert ops.stomp_run_path(gm, ws, P, S, H, d) != ops.STOMP_PATH_TWO_KERNEL
+        ops.stomp_run(means, eps.to(dev), samples, costs, weights, L.to(dev), Sigma.to(dev), gm, S, D, 1.0 / sigma ** 2, 1.0,
+                      0.2, 0.7, ws, n_iters=2)
+        torch.cuda.synchronize()
+        return means.cpu(), costs.cpu()
+    if P <= 8:      # the chained form against the oracle (small enough for the CPU restatement)
+        ta64 = dict(device='cpu', dtype=torch.float64)
+        refs = [make_ref_geometry(robot, f, ta64) for f in fields]
+        cost_fn = lambda xx: sum(sc * O.collision_cost(xx, rr, rf, sigma) for sc, (rr, rf) in zip(scales, refs))
+        ref = means0.double()
+        for it in range(2):
+            out = O.stomp_iteration(ref, eps[it].double(), L.double(), Sigma.double(), cost_fn, 0.2, 0.7)
+            ref = out['means']
+        means, costs = run(geom)
+        np.testing.assert_allclose(costs.numpy(), out['costs'].numpy(), rtol=1e-4, atol=1e-4)
+        assert rel_err(means, ref) < RTOL
+    m1, c1 = run(one)
+    assert torch.isfinite(c1).all() and torch.isfinite(m1).all()
+
+    class Forged:
+        buf, flags = geom.buf, one.flags
+    _, cf = run(Forged)
+    assert torch.isnan(cf).all()
+
+
+@pytest.mark.parametrize('H', [64, 48, 128])
+def test_stomp_model_flag_is_rechecked_on_the_device(gpu_device, H):
+    """geom_flags' robot-model byte picks the compile-time-model instantiations of the STOMP kernels; the device header has the last
+    word.  A buffer WITHOUT the model tag (hinges that can exceed 1: geometry.hinge_bound) launched under flags that claim it gets NaN
+    costs from all three loop forms (persistent H = 64, persistent H != 64, two-kernel), not the [0, 1]-clamped walk's numbers."""
+    from motion_planning_baselines_amd import ops, geometry as G
+    from motion_planning_baselines_amd.planners.stomp import precision_to_scale_tril, stomp_precision_matrix
+    dev = gpu_device
+    robot = G.RobotPanda()
+    tagged = ops.DeviceGeometry(robot, [G.env_spheres_3d()], dev)
+    big = G.CollisionField(spheres=np.array([[0.5, 0.5, 0.5, 0.9], [-0.6, 0.2, 0.4, 0.1]], np.float32), margin=0.05)
+    plain = ops.DeviceGeometry(robot, [big], dev)
+    assert tagged.flags & 0xFF and not plain.flags & 0xFF and plain.flags & 0x100
+
+    class Forged:
+        buf, flags = plain.buf, tagged.flags
+    D, P, S = robot.q_dim, 4, 8
+    d = 2 * D
+    cpu = dict(device='cpu', dtype=torch.float32)
+    R = stomp_precision_matrix(H, 0.05, 1.0, cpu)
+    Sigma, L = torch.inverse(R).contiguous().to(dev), precision_to_scale_tril(R).contiguous().to(dev)
+    means0 = _trajs(robot, P, H, d, 4)
+    for use_ws in (True, False):
+        got = {}
+        for name, gm in (('plain', plain), ('forged', Forged)):
+            means = means0.clone().to(dev)
+            samples = torch.empty(P, S, H, d, device=dev)
+            costs = torch.zeros(P, S, device=dev)
+            weights = torch.empty(P, S, device=dev)
+            ws = ops.stomp_workspace(P, S, H, d, dev) if use_ws else None
+            ops.stomp_run(means, None, samples, costs, weights, L, Sigma, gm, S, D, 6.25, 1.0, 0.2, 0.7, ws, n_iters=2, seed=3)
+            torch.cuda.synchronize()
+            got[name] = costs.cpu()
+        assert torch.isfinite(got['plain']).all() and float(got['plain'].max()) > 0
+        # the forms with a compile-time-model instantiation poison; the two-kernel loop at H != 64 has none (table-driven walk
+        # whatever the flags say) and must give the plain buffer's numbers
+        table_only = not use_ws and H != 64
+        if table_only:
+            assert torch.equal(got['forged'], got['plain']), (H, use_ws)
+        else:
+            assert torch.isnan(got['forged']).all(), (H, use_ws, got['forged'])
