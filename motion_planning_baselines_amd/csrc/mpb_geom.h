@@ -586,35 +586,38 @@ __device__ __forceinline__ unsigned grid_cell(const GeomView& G, float x, float 
 // sit on a lattice through the world origin (geometry.py build_grid): cell = round-to-nearest(x / h) - K per axis,
 // and fma(x, 1/h, 1.5 * 2^23) leaves that integer in the low mantissa bits of a float in [2^23, 2^24) -- ONE instruction with
 // two register sources and a literal (v_fmaak_f32: full rate) where floor((x - lo) / h) takes a three-source fma and a
-// convert (half rate each).  The linear index is combined in the same float form (two subtractions of the constant, two
-// v_fmac with a scalar factor: exact, every value is an integer below 2^22), the byte offset is one v_lshl_add_u32 of the bit
-// pattern, one v_min_u32 clamps it: 9 instructions at ~27 cycles where grid_cell<true> + the index shift are 10 at ~42
-// (profiles/r05_isa_cost_hist_before.md: 12 % of the vector pipe at C3).  A point outside the box, a parked slot at 1e9, inf
-// or NaN give SOME offset inside the grid, as before (whatever that cell lists yields hinge 0: the box bounds the inflated
-// obstacles); a point on a cell face goes to either neighbour (ties to even), which the host's 1e-5 m of slack on the
-// candidate radius covers like the fp32 rounding of the old form.
+// convert (half rate each).  The linear index is combined on the BIT PATTERNS, modulo 2^32: two v_mad_u32_u24 (the low 24 bits of
+// a pattern are 2^22 + the integer; the constant parts are folded into c_rel), the byte offset is one v_lshl_add_u32, one
+// v_min_u32 clamps it: 7 instructions where grid_cell<true> + the index shift are 10 at ~42 cycles
+// (profiles/r05_isa_cost_hist_before.md: 12 % of the vector pipe at C3; the first form of this round combined in float -- two
+// subtractions of the constant, two v_fmac: 9 instructions -- and measured 3.5 % slower at C3 than the integer form).  A point
+// outside the box, a parked slot at 1e9, inf or NaN give SOME offset inside the grid, as before (whatever that cell lists yields
+// hinge 0: the box bounds the inflated obstacles); a point on a cell face goes to either neighbour (ties to even), which the
+// host's 1e-5 m of slack on the candidate radius covers like the fp32 rounding of the old form.
 struct GridAddr {
     float gix_v, giy_v, giz_v;   // 1 / h per axis in VECTOR registers (v_fmaak takes the literal plus two registers; a scalar would make it a VOP3 fma)
-    float gnx_f, gny_f;  // row / slab lengths as floats (scalar operands of the two v_fmac)
-    unsigned c_rel;      // -4 * (bits(1.5 * 2^23) + k_lin): turns the bit pattern of 1.5 * 2^23 + linear index into a byte offset
+    unsigned gnx_u, gnxy_u;      // row / slab lengths in cells (scalar operands of the two v_mad_u32_u24)
+    unsigned c_rel;      // -4 * (bits(1.5 * 2^23) + 2^22 (gnx + gnx gny) + k_lin): what the combined bit patterns carry besides the linear index
     unsigned max_rel;    // 4 * (n_cells - 1)
 };
 __device__ __forceinline__ GridAddr grid_addr(const GeomView& G) {
     GridAddr A;
     A.gix_v = G.gix; A.giy_v = G.giy; A.giz_v = G.giz;
     asm volatile("" : "+v"(A.gix_v), "+v"(A.giy_v), "+v"(A.giz_v));
-    A.gnx_f = (float)G.gnx;
-    A.gny_f = (float)G.gny;
-    A.c_rel = 0u - 4u * (0x4B400000u + (unsigned)G.k_lin);
+    A.gnx_u = (unsigned)G.gnx;
+    A.gnxy_u = (unsigned)G.gnx * (unsigned)G.gny;
+    A.c_rel = 0u - 4u * (0x4B400000u + 0x400000u * (A.gnx_u + A.gnxy_u) + (unsigned)G.k_lin);
     A.max_rel = 4u * (unsigned)(G.n_cells - 1);
     return A;
 }
 __device__ __forceinline__ unsigned grid_cell_rel(const GridAddr& A, float x, float y, float z) {
     constexpr float MAGIC = 12582912.0f;                 // 1.5 * 2^23
     const float tx = fmaf(x, A.gix_v, MAGIC), ty = fmaf(y, A.giy_v, MAGIC), tz = fmaf(z, A.giz_v, MAGIC);
-    const float u = fmaf(tz - MAGIC, A.gny_f, ty);       // MAGIC + ry + gny rz
-    const float v = fmaf(u - MAGIC, A.gnx_f, tx);        // MAGIC + rx + gnx (ry + gny rz)
-    const unsigned rel = (__float_as_uint(v) << 2) + A.c_rel;
+    // bits(t?) = 0x4B400000 + r?: the low 24 bits are 2^22 + r? (|r?| < 2^21: mpb_geom_check), which is what v_mad_u32_u24 multiplies
+    unsigned t, v;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(t) : "v"(ty), "s"(A.gnx_u), "v"(tx));     // bits(tx) + (2^22 + ry) gnx
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(v) : "v"(tz), "s"(A.gnxy_u), "v"(t));     // ... + (2^22 + rz) gnx gny
+    const unsigned rel = (v << 2) + A.c_rel;
     return min(rel, A.max_rel);
 }
 
@@ -671,7 +674,10 @@ __device__ __forceinline__ void grid_stage_offsets(const GeomView& G, unsigned* 
 // UNIT (compile-time robot models only): the caller guarantees every hinge margin + r_l - sdf is below 1 (pack_geometry tags a
 // buffer with a model only when margin + max r_l + max obstacle radius < 1 m, mpb_geom_check verifies it), so relu is the
 // [0, 1] clamp the VOP3 encoding applies for free on the subtraction -- same bits as v_max_f32(x, 0), which issues at half rate.
-template <int N, bool OFFS = false, bool UNIT = false>
+// RLM (compile-time robot models only): rl[] already holds margin + r_l (the model's arms add the margin to their literal radii,
+// one v_add with a literal in place of the v_mov that materialised the radius): the same (margin + r_l) - sdf, one instruction
+// per sphere less in the shared tail.
+template <int N, bool OFFS = false, bool UNIT = false, bool RLM = false>
 __device__ __forceinline__ void spheres_hinge_grid(const GeomView& G, const unsigned* gridw, const float4* otab,
                                                    const float (&x)[N], const float (&y)[N], const float (&z)[N],
                                                    const float (&rl)[N], float& cost, const GridAddr& GA = GridAddr{}) {
@@ -785,7 +791,7 @@ __device__ __forceinline__ void spheres_hinge_grid(const GeomView& G, const unsi
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) {                                                 // parked slots: best = 3e38 / 1e9 -> +0
-        const float hinge = G.margin + rl[i] - best[i];
+        const float hinge = (RLM ? rl[i] : G.margin + rl[i]) - best[i];
         cost += UNIT ? fminf(fmaxf(hinge, 0.f), 1.f) : fmaxf(hinge, 0.f);
     }
 }
@@ -899,7 +905,7 @@ __device__ __forceinline__ void model_fk_advance(ModelFK& F, const float (&q)[MP
 // the spheres on frame 1 first (the only ones static pruning can drop), then the rest, four at a time.
 template <class M, int GRP>
 __device__ __forceinline__ bool model_group_positions(ModelFK& F, const float (&q)[MPB_MAX_DOF], unsigned keep,
-                                                      float (&x)[4], float (&y)[4], float (&z)[4], float (&rl)[4]) {
+                                                      float (&x)[4], float (&y)[4], float (&z)[4], float (&rl)[4], float mrg) {
     constexpr float FAR = 1.0e9f;   // parked slot: outside the grid, no candidates
     constexpr int G1 = (M::N_FRAME1 + 3) / 4;
     constexpr bool first = GRP < G1;
@@ -927,13 +933,13 @@ __device__ __forceinline__ bool model_group_positions(ModelFK& F, const float (&
         const float pz = mad3(F.r20, ox, F.r21, oy, F.r22, oz, F.tz);
         if constexpr (first) {
             const bool on = (keep >> l) & 1u;                // wave-uniform
-            x[slot] = on ? px : FAR; y[slot] = on ? py : FAR; z[slot] = on ? pz : FAR; rl[slot] = on ? rad : 0.f;
+            x[slot] = on ? px : FAR; y[slot] = on ? py : FAR; z[slot] = on ? pz : FAR; rl[slot] = on ? mrg + rad : 0.f;
         } else {
-            x[slot] = px; y[slot] = py; z[slot] = pz; rl[slot] = rad;
+            x[slot] = px; y[slot] = py; z[slot] = pz; rl[slot] = mrg + rad;     // (margin + r_l: spheres_hinge_grid, RLM)
         }
     });
 #pragma unroll
-    for (int i = hi - lo; i < 4; ++i) { x[i] = y[i] = z[i] = FAR; rl[i] = 0.f; }
+    for (int i = hi - lo; i < 4; ++i) { x[i] = y[i] = z[i] = FAR; rl[i] = 0.f; }   // (parked: 0 - 1e9 clamps to 0 like margin - 1e9)
     if constexpr (first) {
         constexpr unsigned gmask = ((hi >= 32) ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
         return (keep & gmask) != 0u;                         // a frame-1 group with no survivor is skipped
@@ -943,12 +949,12 @@ __device__ __forceinline__ bool model_group_positions(ModelFK& F, const float (&
 
 template <class M, int... GRPS>
 __device__ __forceinline__ bool model_group_dispatch(int grp, ModelFK& F, const float (&q)[MPB_MAX_DOF], unsigned keep,
-                                                     float (&x)[4], float (&y)[4], float (&z)[4], float (&rl)[4],
+                                                     float (&x)[4], float (&y)[4], float (&z)[4], float (&rl)[4], float mrg,
                                                      std::integer_sequence<int, GRPS...>) {
     bool run = false;
     // one arm per group, selected by the wave-uniform group counter (scalar compares / branches)
     // (a switch over the group index -- a jump table or a compare tree instead of the compare chain -- measured +1 %, round 5)
-    ((grp == GRPS ? (void)(run = model_group_positions<M, GRPS>(F, q, keep, x, y, z, rl)) : (void)0), ...);
+    ((grp == GRPS ? (void)(run = model_group_positions<M, GRPS>(F, q, keep, x, y, z, rl, mrg)) : (void)0), ...);
     return run;
 }
 
@@ -962,12 +968,14 @@ __device__ __forceinline__ float waypoint_cost_grid_model(const GeomView& G, con
     float cost = 0.f;
     const unsigned keep = G.keep_mask;
     const GridAddr GA = OFFS ? grid_addr(G) : GridAddr{};
+    float mrg = G.margin;                    // in a VECTOR register: v_add takes the literal radius plus one register
+    asm volatile("" : "+v"(mrg));
     // a real loop over the groups with ONE instance of the grid look-up (unrolling it per group is 60 KB of code)
 #pragma nounroll
     for (int grp = 0; grp < NG; ++grp) {
         float x[4], y[4], z[4], rl[4];
-        const bool run = model_group_dispatch<M>(grp, F, q, keep, x, y, z, rl, std::make_integer_sequence<int, NG>{});
-        if (run) spheres_hinge_grid<4, OFFS, true>(G, gridw, otab, x, y, z, rl, cost, GA);
+        const bool run = model_group_dispatch<M>(grp, F, q, keep, x, y, z, rl, mrg, std::make_integer_sequence<int, NG>{});
+        if (run) spheres_hinge_grid<4, OFFS, true, true>(G, gridw, otab, x, y, z, rl, cost, GA);
     }
 #ifndef MPB_NO_COST_PRIO
     __builtin_amdgcn_s_setprio(0);

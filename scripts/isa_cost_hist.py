@@ -184,8 +184,17 @@ def main():
         return b['hdr'] if b['hdr'] is not None else (b['loop'][1] if b['loop'] else 0)
     hdr_block = {name_of(b): b for b in blocks if b['hdr'] is not None}
     it_loop = next(n for n, b in hdr_block.items() if b['hdr'] == 1 and b.get('children'))
-    grp_loop = next(n for n, b in hdr_block.items() if b['hdr'] == 3 and any(d == 4 for _, d in b.get('children', [])))
-    inner4 = [n for n, b in hdr_block.items() if b['hdr'] == 4]
+    # the obstacle walk: a loop over 4-cell groups with the later-slot loops inside; under a field loop (depth 3 / 4) in the chained
+    # instantiations, directly under the iteration loop (depth 2 / 3) in the one-field ones (CHAIN = false)
+    def find_grp(dg):
+        for n, b in hdr_block.items():
+            kids = [c for c, d in b.get('children', []) if d == dg + 1]
+            if b['hdr'] == dg and kids and any(x.startswith('v_sqrt_f32') for k in kids for x in hdr_block[k]['ins']):
+                return n, kids
+        return None, []
+    grp_loop, inner4 = find_grp(3)
+    if grp_loop is None:
+        grp_loop, inner4 = find_grp(2)
 
     def in_iteration_loop(b):
         if depth_of(b) == 0:
@@ -231,7 +240,7 @@ def main():
         return 'E combine / update'
 
     # the field loop (depth 2, parent of the group loop) and the poll loop (depth 2 with s_sleep / s_memrealtime)
-    field_loop = next(p for p, d in hdr_block[grp_loop]['parents'] if d == 2)
+    field_loop = next((p for p, d in hdr_block[grp_loop]['parents'] if d == 2 and hdr_block[grp_loop]['hdr'] == 3), None)
     poll_loops = set()
     for b in loop_blocks:
         if any('s_sleep' in x or 's_memrealtime' in x for x in b['ins']) and header_of(b) not in (it_loop, None):
