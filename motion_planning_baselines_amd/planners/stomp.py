@@ -88,6 +88,7 @@ class STOMP(OptimizationPlanner):
         self.check = check
         self._status = None              # host-visible status block of the persistent launches (allocated on first use)
         self._plan = None                # validated, pre-converted arguments of the persistent launch (ops.StompRunPlan)
+        self._last_tag = 0               # tag of the persistent launch the current optimize() call has made (0: none)
         self._traj_out = None
         self.lr = step_size
         self.sigma_spectral = sigma_spectral
@@ -181,9 +182,10 @@ class STOMP(OptimizationPlanner):
         """stomp.py:137-148: run the iterations, return the current trajectory (P,H,d) -- a copy of the means
         (base.py:204-213); where the persistent launch runs, the copy is written by that launch itself."""
         self._traj_out = None
+        self._last_tag = 0
         self._run_optimization(opt_iters, **observation)
         if self.check == 'sync':
-            self._raise_if_lost(synchronize=True)
+            self._raise_if_lost(synchronize=True, tag=self._last_tag)
         if self._traj_out is not None:
             out, self._traj_out = self._traj_out, None
             return out
@@ -193,22 +195,33 @@ class STOMP(OptimizationPlanner):
         self._raise_if_lost()
         return self._get_traj()
 
-    def _raise_if_lost(self, synchronize=False):
+    def _raise_if_lost(self, synchronize=False, tag=0):
         """Raise PersistentLaunchLost if a persistent launch issued by this planner has been abandoned (class docstring,
-        `check`).  Reads pinned host memory the kernel writes: no device synchronisation unless asked for."""
+        `check`).  Reads pinned host memory the kernel writes: no device synchronisation unless asked for.
+        synchronize: wait for the call that has just been enqueued -- `tag`: the persistent launch it made (0: none)."""
         if self._status is None:
             return
         if synchronize:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
             # host spin for a BOUNDED time (the runtime's blocking wait wakes up tens of microseconds late, which is what a
             # short call feels), then the blocking wait: a long optimisation must not pin a core and hold the GIL against
-            # the caller's other threads (thread-per-GPU drivers, watchdogs) for its whole duration
+            # the caller's other threads (thread-per-GPU drivers, watchdogs) for its whole duration.
+            # A persistent launch is waited for on its own STATUS BLOCK: the last workgroup out publishes the call's tag to
+            # pinned host memory (csrc/mpb_stomp_fused.h, fused_leave: word 0 completed, word 1 lost) -- no marker packet
+            # behind the kernel (an event costs ~3 us of queue processing after the kernel's end, and ~3 us of host calls to
+            # create, record and query).  Work enqueued later on the stream is ordered behind the kernel as always.
             t_end = _perf_counter() + _SYNC_SPIN_S
-            while not ev.query():
-                if _perf_counter() > t_end:
-                    ev.synchronize()     # (releases the GIL while it blocks)
-                    break
+            stream = torch.cuda.current_stream(self.device)
+            if tag:
+                view = self._status._view
+                while int(view[0]) != tag and int(view[1]) != tag:
+                    if _perf_counter() > t_end:
+                        stream.synchronize()     # (releases the GIL while it blocks)
+                        break
+            else:
+                while not stream.query():
+                    if _perf_counter() > t_end:
+                        stream.synchronize()
+                        break
         lost = self._status.lost()
         if lost is not None:
             tag, why = lost
@@ -250,11 +263,11 @@ class STOMP(OptimizationPlanner):
                         self._particle_means, self.state_particles, self.costs, self._weights_buf, self.scale_tril,
                         self.Sigma, geom, self.num_samples, self.n_dof, cc.k_sigma, weight, self.lr, self.temperature,
                         self._run_ws, self.seed, self.particle_offset, self._status)
-                plan.launch(opt_iters, self._iter, copy)
+                self._last_tag = plan.launch(opt_iters, self._iter, copy)
             else:
                 # the whole loop as one persistent launch where the shape allows it (H = 64, S <= 64, grid-backed fields);
                 # mpb_stomp_run falls back to the two-kernel loop by itself otherwise
-                ops.stomp_run(self._particle_means, self._draw_eps(opt_iters), self.state_particles, self.costs,
+                self._last_tag = ops.stomp_run(self._particle_means, self._draw_eps(opt_iters), self.state_particles, self.costs,
                               self._weights_buf, self.scale_tril, self.Sigma, geom, self.num_samples, self.n_dof, cc.k_sigma,
                               weight, self.lr, self.temperature, self._run_ws if self.persistent else None,
                               n_iters=opt_iters, seed=self.seed, iter0=self._iter, particle_offset=self.particle_offset,
