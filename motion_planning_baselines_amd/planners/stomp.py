@@ -89,6 +89,7 @@ class STOMP(OptimizationPlanner):
         self._status = None              # host-visible status block of the persistent launches (allocated on first use)
         self._plan = None                # validated, pre-converted arguments of the persistent launch (ops.StompRunPlan)
         self._last_tag = 0               # tag of the persistent launch the current optimize() call has made (0: none)
+        self._spare_copy = None          # the next call's return buffer (allocated while the previous launch runs)
         self._traj_out = None
         self.lr = step_size
         self.sigma_spectral = sigma_spectral
@@ -249,7 +250,14 @@ class STOMP(OptimizationPlanner):
                 self._status = ops.StompRunStatus()
             # the copy optimize() returns (base.py:204-213) is written by the launch itself (pos_only: _get_traj appends
             # finite-difference velocities, from the means)
-            copy = None if self.pos_only else torch.empty_like(self._particle_means)
+            copy = None
+            if not self.pos_only:
+                # (a buffer allocated behind the PREVIOUS launch, while that kernel ran: every call still returns a tensor of its
+                # own, and the allocator's ~2 us are not in front of this launch)
+                copy, self._spare_copy = self._spare_copy, None
+                m = self._particle_means
+                if copy is None or copy.shape != m.shape or copy.device != m.device or copy.dtype != m.dtype:
+                    copy = torch.empty_like(m)
             if (self.persistent and self.noise == 'philox' and self._particle_means.is_cuda
                     and _current_device() == self._particle_means.device.index):
                 # device noise: nothing changes between calls but the iteration counter -- arguments validated once
@@ -264,6 +272,8 @@ class STOMP(OptimizationPlanner):
                         self.Sigma, geom, self.num_samples, self.n_dof, cc.k_sigma, weight, self.lr, self.temperature,
                         self._run_ws, self.seed, self.particle_offset, self._status)
                 self._last_tag = plan.launch(opt_iters, self._iter, copy)
+                if copy is not None:
+                    self._spare_copy = torch.empty_like(copy)
             else:
                 # the whole loop as one persistent launch where the shape allows it (H = 64, S <= 64, grid-backed fields);
                 # mpb_stomp_run falls back to the two-kernel loop by itself otherwise
