@@ -111,6 +111,22 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 }
 #endif
 
+// A kernel argument RE-READ from the kernarg segment at its point of use (one s_load on the scalar-memory pipe) instead of being held in
+// scalar registers from the kernel's entry on.  The big kernels of this library carry 20-30 arguments; the ones a phase touches once per
+// iteration (output bases, a matrix used by one phase) are live across everything else, and under the 102-SGPR limit the compiler SPILLS such
+// values into the lanes of a vector register -- every reload is then a v_readlane on the vector pipe that binds these kernels.  `off` is the
+// argument's offset in the kernarg segment: offsetof in a mirror struct of the kernel's parameter list (explicit arguments are laid out in
+// order at their natural alignment).  The empty asm makes the segment pointer opaque, so the load can be neither hoisted nor merged with
+// another one: the value lives from here to its last use only.  The kernel must not ALSO use the parameter by name in a long-lived way.
+template <class T>
+__device__ __forceinline__ T kernarg_reload(unsigned off) {
+    typedef const __attribute__((address_space(4))) char* ka_ptr;
+    ka_ptr ka = (ka_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    return *(const __attribute__((address_space(4))) T*)(ka + off);
+}
+#define MPB_KARG(STRUCT, field) kernarg_reload<decltype(STRUCT::field)>((unsigned)offsetof(STRUCT, field))
+
 // exp(x) and 1 / x on the hardware units, for the softmax algebra of the persistent STOMP kernels (round 5): v_exp_f32 of
 // x log2(e) (2 instructions where ocml's expf is ~15; relative error <= 2^-22 + |x| 2^-24, i.e. 1e-6 at logits of -16, below
 // which a weight is < 1e-7 of the largest) and v_rcp_f32 (1 ulp; the IEEE division hipcc emits is ~10 instructions).

@@ -88,6 +88,16 @@ struct MppiLds {
 // carries neither the per-lane product nor its operands (round 5: the kernel spilled 155 SGPRs, a fifth of its vector
 // instructions were v_readlane / v_writelane of spilled scalars)
 // INJ: injected normals supported (eps != NULL); the device-noise instantiation does not carry that path.
+// mirror of mppi_kernel's parameter list: the offsets of its arguments in the kernarg segment (mpb_common.h, kernarg_reload)
+struct MppiKernargs {
+    float* mean; const float* eps; const float* tril; const float* cov_inv; const float* state0; const float* goal;
+    const float* ctrl_min; const float* ctrl_max; const float* discount; const float* cw; const float* geom; float* controls;
+    float* states; float* costs; float* weights; float* best_cost; float* best_states; int S, T, c_rt;
+    float dt, k_sigma, weight, temp, step_size; int n_iters; uint32_t seed_lo, seed_hi, iter0; int noise_mode, grid_words;
+};
+static_assert(sizeof(MppiKernargs) == 17 * 8 + 14 * 4, "mirror of the kernel's explicit arguments");
+#define MPPI_KARG(field) MPB_KARG(MppiKernargs, field)
+
 template <int CC, bool GRID, bool MATRIX, bool INJ>
 __global__ __launch_bounds__(1024) void mppi_kernel(
     float* __restrict__ mean, const float* __restrict__ eps, const float* __restrict__ tril,
@@ -136,6 +146,17 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
             grid_stage_offsets(G0, M.gridw, M.otab, threadIdx.x, blockDim.x);     // (offset words: mpb_geom.h)
         }
     }
+    // what the collision walk of a step needs of the field, formed ONCE (round 5: grid_addr() inside the step loop moved the three
+    // cell sizes into vector registers on every trip, and the view's header fields stayed live -- spilled -- across the whole loop)
+    GridAddr GA{};
+    float rl_m = 0.f, fscale0 = 0.f;
+    bool z_on = false;
+    if (GRID && use_grid) {
+        GA = grid_addr(G0);
+        rl_m = G0.margin + G0.links[4];        // margin + r_l: spheres_hinge_grid's RLM form, the same association
+        fscale0 = G0.fscale;
+        z_on = G0.n_dof > 2;
+    }
     const int prob = blockIdx.x;
     float* mean_g = mean + (size_t)prob * T * c;
     for (int e = threadIdx.x; e < T * c; e += blockDim.x) m[e] = mean_g[e];
@@ -165,7 +186,8 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
     float* ew = M.epsw + (size_t)wave * c * T;
     const float inv_temp = 1.0f / temp;
     const float dsc0 = (lane < T) ? discount[lane] : 0.f;        // the discount of this lane's step in the first 64-step chunk
-    float best_c = (best_cost != nullptr) ? best_cost[prob] : 0.f;   // running best over all iterations (and calls)
+    const bool has_best = best_cost != nullptr;
+    float best_c = has_best ? best_cost[prob] : 0.f;   // running best over all iterations (and calls)
 
     for (int it = 0; it < n_iters; ++it) {
         const bool last = it == n_iters - 1;
@@ -179,7 +201,7 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
             const int e = i * T + t;
             float a = 0.f;
             if (t < T) {
-                const float* row = cov_inv + ((size_t)i * T + t) * T;
+                const float* row = MPPI_KARG(cov_inv) + ((size_t)i * T + t) * T;     // (re-read per phase: kernarg_reload)
                 for (int k = seg; k < T; k += 8) a = fmaf(row[k], m[k * c + i], a);
             }
             // (the eight partial sums meet on the DPP path: quad_perm [1,0,3,2], [2,3,0,1], then row_half_mirror brings the other
@@ -355,7 +377,7 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
                             is = fmaf(u[i], M.wvec[i * T + t], is);
                         }
                     }
-                    const float dsc = (base == 0) ? dsc0 : discount[t];
+                    const float dsc = (base == 0) ? dsc0 : MPPI_KARG(discount)[t];
                     pos_l += pc * dsc;
                     ctl_l += cc * dsc;
                     is_l += is;
@@ -369,10 +391,10 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
                             // (the launcher picked this instantiation from geom_flags; a device header that disagrees poisons
                             // the cost instead of being mis-read)
                             if (use_grid) {      // the point branch of waypoint_cost_grid (mpb_geom.h), same expressions
-                                const float px[1] = {q[0]}, py[1] = {q[1]}, pz[1] = {(G0.n_dof > 2) ? q[2] : 0.f}, rl[1] = {G0.links[4]};
+                                const float px[1] = {q[0]}, py[1] = {q[1]}, pz[1] = {z_on ? q[2] : 0.f}, rl[1] = {rl_m};
                                 float cg = 0.f;
-                                spheres_hinge_grid<1, true>(G0, M.gridw, M.otab, px, py, pz, rl, cg, grid_addr(G0));
-                                coll_l += G0.fscale * cg;
+                                spheres_hinge_grid<1, true, false, true>(G0, M.gridw, M.otab, px, py, pz, rl, cg, GA);
+                                coll_l += fscale0 * cg;
                             } else {
                                 coll_l += __uint_as_float(0x7FC00000u);
                             }
@@ -381,8 +403,8 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
                         }
                     }
                     if (last) {                                 // API-visible outputs of the last iteration
-                        float* Ug = controls + (((size_t)prob * S + s) * T + t) * c;
-                        float* Xg = states + (((size_t)prob * S + s) * T + t) * c;   // velocity control: state_dim == c
+                        float* Ug = MPPI_KARG(controls) + (((size_t)prob * S + s) * T + t) * c;
+                        float* Xg = MPPI_KARG(states) + (((size_t)prob * S + s) * T + t) * c;   // velocity control: state_dim == c
 #pragma unroll
                         for (int i = 0; i < MPPI_MAX_C; ++i)
                             if (i < c) {
@@ -418,7 +440,7 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
         //      cheapest sample so far (first index on ties, like torch.argmin) and its state trajectory.  The states of
         //      every sample are not kept, so the winner's rollout is redone from its controls in LDS (same arithmetic
         //      as above, bit-identical); only wave 0 works, the others go on to the softmax
-        if (best_cost != nullptr && wave == 0) {
+        if (has_best && wave == 0) {
             float bv = 3.0e38f;
             int bi = 0;
             for (int ss = lane; ss < S; ss += 64) {
@@ -433,7 +455,7 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
             }
             if (bv < best_c) {                                   // wave-uniform
                 best_c = bv;
-                if (lane == 0) best_cost[prob] = bv;
+                if (lane == 0) MPPI_KARG(best_cost)[prob] = bv;
                 float carry[MPPI_MAX_C];
 #pragma unroll
                 for (int i = 0; i < MPPI_MAX_C; ++i) carry[i] = 0.f;
@@ -447,7 +469,7 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
                         const float inc = wave_scan_incl(v, lane);
                         const float x = x0[i] + (carry[i] + (inc - v));
                         carry[i] += readlane_f32(inc, 63);
-                        if (i < c && on) best_states[((size_t)prob * T + t) * c + i] = x;
+                        if (i < c && on) MPPI_KARG(best_states)[((size_t)prob * T + t) * c + i] = x;
                     }
                 }
             }
@@ -464,8 +486,8 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
             if (wave == 0 && lane < S) {
                 M.wts[lane] = w;
                 if (last) {
-                    costs[(size_t)prob * S + lane] = cs;
-                    weights[(size_t)prob * S + lane] = w;
+                    MPPI_KARG(costs)[(size_t)prob * S + lane] = cs;
+                    MPPI_KARG(weights)[(size_t)prob * S + lane] = w;
                 }
             }
         } else {
@@ -480,8 +502,8 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
                 const float w = expf(-cs / temp - mx) / z;
                 M.wts[ss] = w;
                 if (last) {
-                    costs[(size_t)prob * S + ss] = cs;
-                    weights[(size_t)prob * S + ss] = w;
+                    MPPI_KARG(costs)[(size_t)prob * S + ss] = cs;
+                    MPPI_KARG(weights)[(size_t)prob * S + ss] = w;
                 }
             }
         }
