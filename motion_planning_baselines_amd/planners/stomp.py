@@ -39,7 +39,7 @@ def precision_to_scale_tril(P):
 
 _current_device = getattr(torch._C, '_cuda_getDevice', torch.cuda.current_device)     # (the raw getter: no lazy-init bookkeeping per call)
 _perf_counter = time.perf_counter
-_SYNC_SPIN_S = 1e-3          # check='sync': how long optimize() polls the stream before it blocks in the runtime
+_SYNC_SPIN_S = 1e-3          # check='sync': how long optimize() polls (the launch's status block, or the stream) before it blocks in the runtime
 
 
 class PersistentLaunchLost(MPBError):
@@ -58,10 +58,10 @@ class STOMP(OptimizationPlanner):
       persistent: run a collision-only cost's loop as ONE persistent launch (mpb_stomp_run) where the shape allows it
              (default); False keeps the two-kernels-per-iteration path (mpb_stomp_step).
       check: (the default changed from 'deferred' to 'sync' with ABI 4: optimize() now waits for its launch -- it polls the
-             stream for at most 1 ms, then blocks in the runtime, GIL released.)  What happens when a persistent launch is LOST (include/mpb.h, "Failure contract": its workgroups wait for
+             launch's status block for at most 1 ms, then blocks in the runtime, GIL released.)  What happens when a persistent launch is LOST (include/mpb.h, "Failure contract": its workgroups wait for
              each other, every wait is bounded, and a wait that runs out -- the device stopped starting this launch's
              workgroups for seconds, e.g. another context holds every CU -- abandons the call).  'sync' (default):
-             optimize() waits for the launch (host spin on an event, no sleep) and raises PersistentLaunchLost before it
+             optimize() waits for the launch (host spin on the launch's pinned status block, no sleep) and raises PersistentLaunchLost before it
              returns -- a caller never holds the result of a lost call.  'deferred' (opt-in, for callers that queue more
              work behind optimize() and synchronise themselves, e.g. bench.py): optimize() returns without waiting and the
              loss is raised at the NEXT call into the planner (optimize / reset / sample / get_traj / persistent_timed_out);
