@@ -871,7 +871,12 @@ def main():
     if valu:
         ginstr = valu * (P * S) / (k_ms * 1e-3) / 1e9
         roof = {'bound': 'valu', 'achieved': ginstr, 'peak': VALU_PEAK_GINSTR, 'unit': 'G wave-instr/s',
-                'frac': ginstr / VALU_PEAK_GINSTR, 'valu_instructions_per_wave_iteration': valu, 'pmc_source': pmc_file}
+                'frac': ginstr / VALU_PEAK_GINSTR, 'valu_instructions_per_wave_iteration': valu, 'pmc_source': pmc_file,
+                'frac_note': 'vector instructions ISSUED per second over the issue peak (one wave-instruction per 2 cycles per SIMD): it falls when a '
+                             'round removes instructions faster than time (0.49 in round 4 at 2 045 instructions, 0.47 now at 1 796 and 9 % less time); '
+                             '`hbm.frac` is the algorithmic figure.  By phase (profiles/r05_stamps_fused.txt, diagnostic build): the collision-cost phase '
+                             '-- 54 % of an iteration -- issues one instruction per 2.43 cycles per SIMD, the rate scripts/microbench_rates.hip measures '
+                             'for its opcode mix; draw + noise product 19 % (vector and matrix work of a SIMD in turn); ~14 % synchronisation / latency'}
     else:   # no committed counter summary for this shape: the nominal bound
         roof = {'bound': 'hbm', 'achieved': hbm_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': hbm_gbs / HBM_PEAK_GBS}
     mfma = pmc.get('SQ_INSTS_MFMA_per_wave_iteration') if (pmc and c3_shape) else None
