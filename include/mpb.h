@@ -61,10 +61,10 @@ int mpb_geom_check(const float *geom_host, int n_words);
  * (csrc/mpb_model_*.h) every chained field is tagged with AND whose cost-only kernels can run (every field has a
  * usable broad-phase grid); 0 = generic table-driven kernels; bit 8 = every chained field has a usable broad-phase
  * grid (what the persistent STOMP kernel needs); bit 9 = point robot with ONE field of at most 32 spheres and 8 boxes
- * (CHOMP's four-lanes-per-waypoint kernel keeps such an obstacle set in registers); bit 10 = point robot; bit 12 = ONE field (no chain); bits 16-28 = cells of the largest
+ * (CHOMP's four-lanes-per-waypoint kernel keeps such an obstacle set in registers); bit 10 = point robot; bit 12 = ONE field (no chain: MPPI's LDS grid, the persistent STOMP kernels' one-field instantiations); bits 16-28 = cells of the largest
  * broad-phase grid of the chain when bit 8 is set (what a kernel that stages the grid in LDS has to reserve).  Entry points that take `geom_flags` expect the value
  * computed from the host copy of the very buffer `geom` points to (0 is always valid); a kernel re-checks the tag
- * against the device header and writes NaN costs if they disagree. */
+ * and the one-field promise against the device header and writes NaN costs if they disagree. */
 int mpb_geom_flags(const float *geom_host, int n_words, int *flags);
 
 /* ---------------------------------------------------------------------------------------------
