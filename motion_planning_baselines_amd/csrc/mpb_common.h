@@ -93,6 +93,38 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     v = fmaxf(v, dpp_f32<0x140>(v));
     return fmaxf(fmaxf(readlane_f32(v, 0), readlane_f32(v, 16)), fmaxf(readlane_f32(v, 32), readlane_f32(v, 48)));
 }
+// the same reductions over each ROW of sixteen lanes (every lane ends up with its row's result): for values replicated in the
+// four rows, these are wave_sum_f32 / wave_max_f32 without the four v_readlane and the combine -- and, the rows holding the same
+// values in the same lanes, the same bits as the full-wave forms give when rows 1-3 hold the neutral element
+__device__ __forceinline__ float row_sum_f32(float v) {
+    MPB_ASSERT_FULL_WAVE();
+    v += dpp_f32<0xB1>(v);
+    v += dpp_f32<0x4E>(v);
+    v += dpp_f32<0x141>(v);
+    v += dpp_f32<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ float row_max_f32(float v) {
+    MPB_ASSERT_FULL_WAVE();
+    v = fmaxf(v, dpp_f32<0xB1>(v));
+    v = fmaxf(v, dpp_f32<0x4E>(v));
+    v = fmaxf(v, dpp_f32<0x141>(v));
+    v = fmaxf(v, dpp_f32<0x140>(v));
+    return v;
+}
+// lane L of the caller's row, to every lane of the row (DPP row_newbcast, gfx90a and later): a v_readlane + scalar operand without
+// the trip through a scalar register
+template <int L>
+__device__ __forceinline__ float row_bcast_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + L, 0xF, 0xF, false));
+}
+// acc = fma(lane L of the caller's row of `a`, b, acc): v_fmac_f32 with its first source through DPP row_newbcast (written out: the
+// compiler folds a DPP move into a multiply, not into the accumulating form).  The caller keeps the DPP hazards: `a` written at least two
+// instructions earlier, no exec write by a vector instruction in the five before.
+template <int L>
+__device__ __forceinline__ void fmac_row_bcast_f32(float& acc, float a, float b) {
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(b), "n"(L));
+}
 __device__ __forceinline__ double wave_sum_f64(double v) {
     MPB_ASSERT_FULL_WAVE();
     v += dpp_f64<0xB1>(v);

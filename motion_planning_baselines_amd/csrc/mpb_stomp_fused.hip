@@ -366,18 +366,24 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         const int lq = tq & 63;
         hh = (tq < N) ? tq / DCH : 0; cc = (tq < N) ? tq - hh * DCH : 0;   // the trajectory element this thread owns
         sl = (NB > 1 ? bt : chunk) * FUSED_WAVES + (lq & 15);              // every wave redundantly, lanes 0-15 carry the chunk
-        const float xs = (lq < FUSED_WAVES && sl < S) ? -cst[lq & 15] * inv_temperature : -3.0e38f;
-        mb = wave_max_f32(xs);
-        ex = (lq < FUSED_WAVES && sl < S) ? fast_expf(xs - mb) : 0.f;
-        zb = wave_sum_f32(ex);
+        // (all FOUR rows of a wave carry the chunk's sixteen costs: the softmax statistics are row reductions -- no v_readlane, no
+        // combine across rows; same bits as the full-wave forms over one row and three rows of neutral elements -- and the weight of
+        // sample w reaches a lane's fma through DPP row_newbcast instead of a v_readlane and a scalar register)
+        const float xs = (sl < S) ? -cst[lq & 15] * inv_temperature : -3.0e38f;
+        mb = row_max_f32(xs);
+        ex = (sl < S) ? fast_expf(xs - mb) : 0.f;
+        zb = row_sum_f32(ex);
         dpart = 0.f;
-        if (tq < N) {
+        if (tq < N) {       // (N = 64 DCH: whole waves -- DPP reads the neighbours' registers, every lane of a wave that is here is active)
             const float mu = mean_l[tq];
-#pragma unroll
-            for (int w = 0; w < FUSED_WAVES; ++w) {
-                const float ew = readlane_f32(ex, w);
-                dpart = fmaf(ew, tiles[w * (H * NT_STRIDE) + tq] - mu, dpart);
-            }
+            // dpart = fma(ex[row lane w], df[w], dpart), w ascending: v_fmac_f32 with its first source through DPP row_newbcast.
+            // (Written out: the compiler folds a DPP move into a multiply but not into the accumulating form.  `ex` was written
+            // many instructions ago; the s_nop covers the exec write of the branch above, which the assembler does not see into.)
+            asm volatile("s_nop 4");
+            static_for<0, FUSED_WAVES>([&](auto wc) {
+                constexpr int w = decltype(wc)::value;
+                fmac_row_bcast_f32<w>(dpart, ex, tiles[w * (H * NT_STRIDE) + tq] - mu);
+            });
         }
         if (NB > 1) {            // (wave-uniform) keep this batch's partial
             if (bt == 0) { pm0 = mb; pz0 = zb; pe0 = ex; } else { pm1 = mb; pz1 = zb; pe1 = ex; }

@@ -367,12 +367,14 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
             const bool poisoned = __float_as_uint(c0) == 0x7FC00000u;     // (geometry / kernel mismatch: see mpb_geom_flags)
             const float cw = weight * (k_sigma * (poisoned ? 0.f : c0 + c1));
             const int sl = (chunk * nb + bt) * RB + rq;
-            const bool carries = lq < RB && sl < S;
+            const bool carries = (lq & 15) < RB && sl < S;                 // (all FOUR rows of a wave carry the pass's costs: below)
             if (tq < RB && sl < S) reinterpret_cast<unsigned*>(costs)[(size_t)p * S + sl] = poisoned ? 0x7FC00000u : __float_as_uint(cw);
             const float xs = carries ? -cw * inv_temperature : -3.0e38f;
-            const float mb = wave_max_f32(xs);
+            // (row reductions over replicated rows and DPP row_newbcast in the weighted sum: csrc/mpb_stomp_fused.hip, phase C -- same bits
+            // as the full-wave reductions over one carrying row, no v_readlane)
+            const float mb = row_max_f32(xs);
             const float ex = carries ? fast_expf(xs - mb) : 0.f;
-            const float zb = wave_sum_f32(ex);
+            const float zb = row_sum_f32(ex);
             if (tq < RB) ewl[bt * RB + tq] = ex;
             if (tq == 0) mbl[bt] = mb;
             const float m_new = fmaxf(m_run, mb);
@@ -386,12 +388,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
                     const int hc_e = (HC == 1) ? 0 : (e >= 64 * d ? 1 : 0);
                     const int off = e - 64 * d * hc_e;                  // rows of a tile are packed with stride d
                     const float mu = mean_l[e];
-                    float dp = 0.f;
-#pragma unroll
-                    for (int r = 0; r < RB; ++r) {
-                        const float ew = readlane_f32(ex, r);
-                        dp = fmaf(ew, tiles[wave_of(r, hc_e) * TILE + off] - mu, dp);
-                    }
+                    float dp = 0.f;           // (e < N: whole waves -- N = 64 d HC)
+                    static_for<0, RB>([&](auto rc) {
+                        constexpr int r = decltype(rc)::value;
+                        fmac_row_bcast_f32<r>(dp, ex, tiles[wave_of(r, hc_e) * TILE + off] - mu);
+                    });
                     d_run[u] = fmaf(dp, f_b, d_run[u] * f_old);
                 }
             }
