@@ -143,6 +143,25 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 }
 #endif
 
+// wave_sum_f32 for callers that need the total in ONE lane only: valid in LANE 63.  The four row totals meet through DPP row_bcast:15
+// (lane 15 of a row into the next row; rows 1 and 3 take it) and row_bcast:31 (lane 31 into rows 2 and 3; row 3 takes it): (r2 + r3) +
+// (r0 + r1) -- the association of wave_sum_f32, hence the same bits -- in two vector instructions where the four row totals cost four
+// v_readlane, each a round trip through a scalar register the adds then wait for.
+#ifndef MPB_SHFL_REDUCE
+__device__ __forceinline__ float wave_sum_f32_lane63(float v) {
+    MPB_ASSERT_FULL_WAVE();
+    v += dpp_f32<0xB1>(v);
+    v += dpp_f32<0x4E>(v);
+    v += dpp_f32<0x141>(v);
+    v += dpp_f32<0x140>(v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));   // row_bcast:15 -> rows 1, 3
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+#else
+__device__ __forceinline__ float wave_sum_f32_lane63(float v) { return wave_sum_f32(v); }
+#endif
+
 // A kernel argument RE-READ from the kernarg segment at its point of use (one s_load on the scalar-memory pipe) instead of being held in
 // scalar registers from the kernel's entry on.  The big kernels of this library carry 20-30 arguments; the ones a phase touches once per
 // iteration (output bases, a matrix used by one phase) are live across everything else, and under the 102-SGPR limit the compiler SPILLS such

@@ -418,9 +418,10 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
             // (point.py:198-226, mppi.py:125-128): the four per-step contributions are added PER LANE and reduced once (round 5:
             // four wave reductions of ~15 vector instructions each were a tenth of the kernel's vector work); the collision
             // part stays separate (quirk Q6 sums it over the samples)
-            const float cost_s = wave_sum_f32((pos_l + ctl_l) + (term_l + temp * is_l));
-            const float coll_s = (geom != nullptr) ? wave_sum_f32(coll_l) : 0.f;
-            if (lane == 0) {
+            // (the totals in lane 63 only: wave_sum_f32_lane63, mpb_common.h -- the same association without the trip through scalar registers)
+            const float cost_s = wave_sum_f32_lane63((pos_l + ctl_l) + (term_l + temp * is_l));
+            const float coll_s = (geom != nullptr) ? wave_sum_f32_lane63(coll_l) : 0.f;
+            if (lane == 63) {
                 M.cst[s] = cost_s;
                 M.coll[s] = coll_s;
             }
