@@ -510,20 +510,22 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
         }
         __syncthreads();
         // ---- mean += step * sum_s w_s (U_s - mean)   (mppi.py:79-84).  Sixteen elements (i, t) per wave, FOUR lanes per element
-        //      (one per 16-lane row): lane row p sums the samples s = p, p + 4, p + 8, ... in ascending order, the four partial
+        //      (one quad): lane p of the quad sums the samples s = p, p + 4, p + 8, ... in ascending order, the four partial
         //      sums meet as (p0 + p1) + (p2 + p3) -- an association that depends on S alone, so the result does not depend on
         //      how many waves the problem was given.  (One thread per element walked all S samples: 128 busy threads of 512,
         //      two dependent LDS reads per sample each.)
         for (int i = 0; i < c; ++i)
         for (int t0 = 0; t0 < T; t0 += 16 * nw) {
-            const int tt = t0 + 16 * wave + (lane & 15), part = lane >> 4;
+            // (the four partial sums of an element sit in one QUAD: they meet on DPP quad permutes -- [1,0,3,2], then [2,3,0,1] -- where
+            // a lane-row per partial sum needed two ds_bpermute round trips; the same association)
+            const int tt = t0 + 16 * wave + (lane >> 2), part = lane & 3;
             const bool on = tt < T;
             const int t = on ? tt : 0;
             const float mu = m[t * c + i];
             float a = 0.f;
             for (int ss = part; ss < S; ss += 4) a += M.wts[ss] * (M.Us[(size_t)ss * us_stride + i * T + t] - mu);
-            a += __shfl_xor(a, 16, 64);
-            a += __shfl_xor(a, 32, 64);
+            a += dpp_f32<0xB1>(a);
+            a += dpp_f32<0x4E>(a);
             if (on && part == 0) m[t * c + i] = mu + step_size * a;
         }
     }
