@@ -653,14 +653,21 @@ def bench_mppi(dev, steps, NP=1024, with_cpu=True):
     mean = torch.zeros(NP, T, c, device=dev)
     controls, states = torch.empty(NP, S, T, c, device=dev), torch.empty(NP, S, T, c, device=dev)
     costs, weights = torch.empty(NP, S, device=dev), torch.empty(NP, S, device=dev)
+    # MPPI._save_best runs in every iteration of the reference's loop (mppi.py:148, :164-168): the entry tracks the best sample too
+    # (until round 5 it passed no best buffers, which skips that phase)
+    track_best = os.environ.get('MPB_MPPI_BENCH_NO_BEST') is None
+    best_cost = torch.empty(NP, device=dev) if track_best else None
+    best_states = torch.zeros(NP, T, c, device=dev) if track_best else None
 
     def run(k):
         mean.zero_()
+        if track_best:
+            best_cost.fill_(3.0e38)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ops.mppi_step(mean, None, tril, cinv, state0, goal, f([-1., -1.]), f([1., 1.]), torch.ones(T, device=dev),
                       f([1., 1., 1., 100.]), geom, controls, states, costs, weights, 0.04, k_sigma=1e6, weight=1.0, temp=1.0,
-                      step_size=0.7, n_iters=k, seed=3)
+                      step_size=0.7, n_iters=k, seed=3, best_cost=best_cost, best_states=best_states)
         torch.cuda.synchronize()
         return time.perf_counter() - t0
     for _ in range(6):      # (untimed calls of the timed shape first: see bench_h128)
@@ -683,7 +690,7 @@ def bench_mppi(dev, steps, NP=1024, with_cpu=True):
     out = {'workload': 'MPPI point mass, %d problems x S=%d samples x T=%d steps x c=%d, %d iterations per launch' % (NP, S, T, c, steps),
            'metric': 'mppi_problem_iterations_per_sec', 'value': NP * steps / t, 'unit': 'problem-iters/s',
            'ms_per_step': 1e3 * t / steps, 'us_per_problem_iteration': 1e6 * t / steps / NP, 'dtype': 'f32',
-           'roofline': roof}
+           'save_best': bool(track_best), 'roofline': roof}
     if with_cpu:
         # CPU: the oracle's sequential rollout (mppi.py:131-209, point.py:102-226, quirk Q6: two passes per iteration, the first
         # for the collision shift) on the first 32 problems, one after the other as the reference class would run them

@@ -448,12 +448,12 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
                 const float v = M.cst[ss] + total;
                 if (v < bv) { bv = v; bi = ss; }
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const float ov = __shfl_xor(bv, off, 64);
-                const int oi = __shfl_xor(bi, off, 64);
-                if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-            }
+            // the wave's minimum, then the smallest index among the lanes that hold it (torch.argmin: first index on ties; indices are
+            // exact in fp32): two DPP reductions.  (A butterfly of (value, index) pairs was twelve ds_bpermute round trips on the path
+            // of the one wave every other wave then waits for at the barrier below.)
+            const float mn = -wave_max_f32(-bv);
+            bi = (int)(-wave_max_f32(bv == mn ? -(float)bi : -3.0e38f));
+            bv = mn;
             if (bv < best_c) {                                   // wave-uniform
                 best_c = bv;
                 if (lane == 0) MPPI_KARG(best_cost)[prob] = bv;
