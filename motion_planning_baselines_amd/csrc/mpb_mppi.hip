@@ -429,7 +429,9 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
         // ---- quirk Q6: the per-sample collision costs collapse into ONE scalar added to every sample
         float total = 0.f;
         __syncthreads();
-        if (geom != nullptr) {
+        // (S <= 64: only the waves of the two phases below that read it -- wave 0, save-best, and the softmax's wave -- form it)
+        const int sm_wave = has_best ? 1 : 0;       // the softmax runs BESIDE save-best on a wave of its own (S <= 64)
+        if (geom != nullptr && (S > 64 || wave <= sm_wave)) {
             // summed by every wave for itself in an order that depends on S alone (lane-strided partial sums, then the
             // wave reduction): the scalar -- and with it every cost and weight -- is the same however many waves the
             // problem was given (mpb_mppi_step picks 8 or 16 by the number of problems)
@@ -477,19 +479,22 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
         }
         // ---- softmax over samples (mppi.py:73-76)
         if (S <= 64) {
-            // every wave repeats it on its own (lane = sample, wave reductions): no block-wide reduction, one barrier
+            // ONE wave (lane = sample, wave reductions): no block-wide reduction, one barrier.  (Until round 5 every wave repeated it and
+            // wave 0 stored it -- behind save-best, with the other waves' copies competing for its SIMD.)
+            if (wave == sm_wave) {
             const float cs = (lane < S) ? M.cst[lane] + total : 0.f;
             // (v_exp / v_rcp: mpb_common.h fast_expf / fast_rcpf, as in the persistent STOMP kernels; the sum holds exp(0) = 1)
             const float xs = (lane < S) ? -cs * inv_temp : -3.0e38f;
             const float mx = wave_max_f32(xs);
             const float ex = (lane < S) ? fast_expf(xs - mx) : 0.f;
             const float w = ex * fast_rcpf(wave_sum_f32(ex));
-            if (wave == 0 && lane < S) {
+            if (lane < S) {
                 M.wts[lane] = w;
                 if (last) {
                     MPPI_KARG(costs)[(size_t)prob * S + lane] = cs;
                     MPPI_KARG(weights)[(size_t)prob * S + lane] = w;
                 }
+            }
             }
         } else {
             float mx = -3.0e38f;
