@@ -526,7 +526,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVE
                     const bool jin = (li >= k0) && (li < k0 + 2);
                     const double notj = jin ? 0.0 : 1.0;
                     // (the two row fetches through v_permlane32_swap / v_permlane16_swap instead of the LDS crossbar: measured 2 %
-                    // slower, twice -- with the reciprocal chain as it was and as it is now)
+                    // slower, twice -- with the reciprocal chain as it was and as it is now; round 5: only the EXCHANGE between lane rows
+                    // 2 half and 2 half + 1 that the update really needs, one v_permlane16_swap per dword + selects: +2.8 % -- the fetches
+                    // ride the LDS pipe for free, their replacements are vector instructions in a kernel at half of its fp64 issue peak)
                     const double am0 = fma(notj, __shfl(tk, (2 * half) * 16 + li, 64), (li == k0) ? 1.0 : 0.0);
                     const double am1 = fma(notj, __shfl(tk, (2 * half + 1) * 16 + li, 64), (li == k0 + 1) ? 1.0 : 0.0);
                     const double sel0 = (lk == 2 * half) ? 1.0 : 0.0, sel1 = (lk == 2 * half + 1) ? 1.0 : 0.0;
