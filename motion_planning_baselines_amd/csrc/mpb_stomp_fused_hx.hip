@@ -383,12 +383,16 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
             m_run = m_new;
 #pragma unroll
             for (int u = 0; u < EPT; ++u) {
-                const int e = tq + FUSED_THREADS * u;
-                if (e < N) {
+                const int e_raw = tq + FUSED_THREADS * u;
+                // WHOLE waves run the weighted sum (N = H d need not be a multiple of 64): DPP reads the source lanes' registers
+                // only while those lanes are enabled -- a lane row cut by `e < N` would drop the terms of its disabled source lanes.
+                // The lanes past N work on element N - 1 and their result is never read.
+                if ((e_raw & ~63) < N) {
+                    const int e = (e_raw < N) ? e_raw : N - 1;
                     const int hc_e = (HC == 1) ? 0 : (e >= 64 * d ? 1 : 0);
                     const int off = e - 64 * d * hc_e;                  // rows of a tile are packed with stride d
                     const float mu = mean_l[e];
-                    float dp = 0.f;           // (e < N: whole waves -- N = 64 d HC)
+                    float dp = 0.f;
                     static_for<0, RB>([&](auto rc) {
                         constexpr int r = decltype(rc)::value;
                         fmac_row_bcast_f32<r>(dp, ex, tiles[wave_of(r, hc_e) * TILE + off] - mu);

@@ -109,6 +109,9 @@ def test_hx_kernel_h64_equals_two_kernel_path(gpu_device, force_hx, P, S, pos_on
     ('panda', 3, 20, 100, False, 2),      # a ragged second chunk (36 waypoints), H*d = 1400
     ('panda', 6, 64, 32, True, 2),        # half a chunk
     ('panda', 5, 12, 48, False, 2),
+    ('panda', 4, 16, 50, True, 2),        # H d = 350: the last lane row of the weighted sum is cut at 14 lanes (DPP sources 14, 15 beyond it)
+    ('panda', 3, 24, 90, True, 2),        # two chunks, H d = 630 = 39 rows + 6 lanes
+    ('pm3d', 4, 16, 37, True, 2),         # run-time d = 3, H d = 111 = 6 rows + 15 lanes
     ('pm2d', 9, 24, 128, False, 2),       # run-time d = 4
     ('pm2d', 4, 40, 64, True, 2),         # d = 2 through the run-time-d kernel (forced below is not needed: H = 64 d = 2 is the other kernel's)
     ('pm3d', 5, 16, 96, True, 2),         # d = 3 (odd: scalar stores)
