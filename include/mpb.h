@@ -234,7 +234,11 @@ int mpb_stomp_step_profile(float *means, float *samples, float *costs, float *we
  *     100 MHz real-time counter when the launch's first unit started / when its last workgroup left (the launch's
  *     duration as the device saw it: a measurement aid that costs nothing); `tag_out` receives the tag
  *     of this call (0 when it ran the two-kernel loop, which cannot be lost).  The caller compares [1] with the tags it
- *     has issued whenever convenient -- planners/stomp.py raises at the next planner call.
+ *     has issued whenever convenient -- planners/stomp.py raises at the next planner call.  Word [0] says the tag was
+ *     PUBLISHED -- every workgroup's result stores are ordered before it (each wave drains its stores, a block barrier,
+ *     then the release) -- not that the kernel has retired: a consumer on ANOTHER stream must still order itself behind
+ *     the launch stream (event / stream wait); work on the launch stream and host reads after a stream / device
+ *     synchronise are ordered as always.
  * means_copy (P,H,d) or NULL: a second destination for the final means, written by the same launch (the reference's
  * optimize() returns a CLONE of its means, base.py:204-213: this saves the dependent copy kernel).
  * Not capturable in a HIP graph (the per-call tag is drawn on the host). */

@@ -118,12 +118,49 @@ template <int L>
 __device__ __forceinline__ float row_bcast_f32(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + L, 0xF, 0xF, false));
 }
-// acc = fma(lane L of the caller's row of `a`, b, acc): v_fmac_f32 with its first source through DPP row_newbcast (written out: the
-// compiler folds a DPP move into a multiply, not into the accumulating form).  The caller keeps the DPP hazards: `a` written at least two
-// instructions earlier, no exec write by a vector instruction in the five before.
-template <int L>
-__device__ __forceinline__ void fmac_row_bcast_f32(float& acc, float a, float b) {
-    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(b), "n"(L));
+// acc = fma(lane k of the caller's row of `a`, b[k], acc) for k = 0 .. N - 1 in ascending order: v_fmac_f32 with its first source through
+// DPP row_newbcast (written out: the compiler folds a DPP move into a multiply, not into the accumulating form).  ONE asm statement that
+// opens with its own wait states: the hardware does not interlock a DPP read against a vector write of the source register in the two
+// instructions before it, nor against a vector write of exec in the five before, and the compiler's hazard recogniser does not look
+// into inline assembly -- a separate `s_nop` statement could be scheduled away from the first fmac, or a register copy / reload of `a`
+// placed right in front of it.  `s_nop 4` = five wait states covers both rules whatever precedes the block; the fmacs
+// themselves do not write `a`.  (tests/test_host_logic.py checks the disassembly: every row_newbcast:0 fmac follows an s_nop 4.)
+template <int N>
+__device__ __forceinline__ void fmac_row_bcast_seq(float& acc, float a, const float (&b)[N]) {
+    static_assert(N == 8 || N == 16, "one asm block per supported length");
+    if constexpr (N == 16) {
+        asm(
+            "s_nop 4\n\t"
+            "v_fmac_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %1, %7 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %1, %8 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %1, %9 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %1, %10 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %1, %11 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %1, %12 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %1, %13 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %1, %14 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %1, %15 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %1, %16 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %1, %17 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+            : "+v"(acc) : "v"(a), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(b[8]), "v"(b[9]), "v"(b[10]), "v"(b[11]), "v"(b[12]), "v"(b[13]), "v"(b[14]), "v"(b[15]));
+    } else {
+        asm(
+            "s_nop 4\n\t"
+            "v_fmac_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %1, %7 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %1, %8 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %1, %9 row_newbcast:7 row_mask:0xf bank_mask:0xf"
+            : "+v"(acc) : "v"(a), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]));
+    }
 }
 __device__ __forceinline__ double wave_sum_f64(double v) {
     MPB_ASSERT_FULL_WAVE();

@@ -122,7 +122,9 @@ static int geom_check_one(const float* g, int n_words, const char* who) {
             if (!(g[23 + a] > 0.f)) return fail(MPB_E_INVALID, "%s: bad grid cell size", who);
             const double k = (double)g[20 + a] * (double)g[23 + a] + 0.5;
             K[a] = lrint(k);
-            if (fabs(k - (double)K[a]) > 1e-3 || labs(K[a]) > 100000) return fail(MPB_E_INVALID, "%s: grid origin is not on the cell lattice", who);
+            // (lo and 1/h are fp32: their product carries ~|K| 1.2e-7 of rounding, so the tolerance scales with |K| -- an absolute
+            // 1e-3 refused the grids build_grid makes beyond |K| ~ 16 700)
+            if (fabs(k - (double)K[a]) > 1e-3 + 4e-7 * fabs((double)K[a]) || labs(K[a]) > 100000) return fail(MPB_E_INVALID, "%s: grid origin is not on the cell lattice", who);
         }
         if ((long)gi[31] != K[0] + (long)gnx * (K[1] + (long)gny * K[2])) return fail(MPB_E_INVALID, "%s: grid lattice index (word 31) does not match the origin", who);
         if (labs((long)gi[31]) + (long)n_cells >= (1L << 21)) return fail(MPB_E_INVALID, "%s: grid too far from the origin for the fp32 cell index", who);

@@ -430,7 +430,9 @@ __global__ __launch_bounds__(1024) void mppi_kernel(
         float total = 0.f;
         __syncthreads();
         // (S <= 64: only the waves of the two phases below that read it -- wave 0, save-best, and the softmax's wave -- form it)
-        const int sm_wave = has_best ? 1 : 0;       // the softmax runs BESIDE save-best on a wave of its own (S <= 64)
+        // the softmax runs BESIDE save-best on a wave of its own (S <= 64) -- when the workgroup has a second wave (S = 1 or
+        // MPB_MPPI_WAVES=1 launch one: wave 0 then does both, one after the other)
+        const int sm_wave = (has_best && nw > 1) ? 1 : 0;
         if (geom != nullptr && (S > 64 || wave <= sm_wave)) {
             // summed by every wave for itself in an order that depends on S alone (lane-strided partial sums, then the
             // wave reduction): the scalar -- and with it every cost and weight -- is the same however many waves the

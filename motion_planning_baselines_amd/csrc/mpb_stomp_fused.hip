@@ -376,14 +376,12 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         dpart = 0.f;
         if (tq < N) {       // (N = 64 DCH: whole waves -- DPP reads the neighbours' registers, every lane of a wave that is here is active)
             const float mu = mean_l[tq];
-            // dpart = fma(ex[row lane w], df[w], dpart), w ascending: v_fmac_f32 with its first source through DPP row_newbcast.
-            // (Written out: the compiler folds a DPP move into a multiply but not into the accumulating form.  `ex` was written
-            // many instructions ago; the s_nop covers the exec write of the branch above, which the assembler does not see into.)
-            asm volatile("s_nop 4");
-            static_for<0, FUSED_WAVES>([&](auto wc) {
-                constexpr int w = decltype(wc)::value;
-                fmac_row_bcast_f32<w>(dpart, ex, tiles[w * (H * NT_STRIDE) + tq] - mu);
-            });
+            // dpart = fma(ex[row lane w], df[w], dpart), w ascending: v_fmac_f32 with its first source through DPP row_newbcast, the
+            // sixteen of them and their wait states in one asm statement (fmac_row_bcast_seq, mpb_common.h)
+            float df[FUSED_WAVES];
+#pragma unroll
+            for (int w = 0; w < FUSED_WAVES; ++w) df[w] = tiles[w * (H * NT_STRIDE) + tq] - mu;
+            fmac_row_bcast_seq(dpart, ex, df);
         }
         if (NB > 1) {            // (wave-uniform) keep this batch's partial
             if (bt == 0) { pm0 = mb; pz0 = zb; pe0 = ex; } else { pm1 = mb; pz1 = zb; pe1 = ex; }
@@ -574,6 +572,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
     if (aborted == 2 && (int)blockIdx.x < P && tid < N && means_copy) means_copy[(size_t)blockIdx.x * N + tid] = means[(size_t)blockIdx.x * N + tid];
     // ---- leaving: the error word (device header + the caller's host-visible status block), then the head count; the
     //      last workgroup out re-arms the header for the next call and reports the call as completed
+    //      (with check='sync' the host returns as soon as the status block holds the tag, so every wave's result stores
+    //      must be ordered before thread 0's release -- each wave drains its own stores, then the barrier; once per launch)
+    __threadfence();
+    __syncthreads();
     if (tid == 0) {
         LSTAMP(7);
         fused_leave(wsu, status_host, tag0, aborted);

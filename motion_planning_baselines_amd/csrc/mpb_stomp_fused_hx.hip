@@ -392,11 +392,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
                     const int hc_e = (HC == 1) ? 0 : (e >= 64 * d ? 1 : 0);
                     const int off = e - 64 * d * hc_e;                  // rows of a tile are packed with stride d
                     const float mu = mean_l[e];
-                    float dp = 0.f;
-                    static_for<0, RB>([&](auto rc) {
-                        constexpr int r = decltype(rc)::value;
-                        fmac_row_bcast_f32<r>(dp, ex, tiles[wave_of(r, hc_e) * TILE + off] - mu);
-                    });
+                    float dp = 0.f, df[RB];
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) df[r] = tiles[wave_of(r, hc_e) * TILE + off] - mu;
+                    fmac_row_bcast_seq(dp, ex, df);             // (one asm statement with its own DPP wait states: mpb_common.h)
                     d_run[u] = fmaf(dp, f_b, d_run[u] * f_old);
                 }
             }
@@ -545,6 +544,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
         for (int e = tid; e < N; e += FUSED_THREADS) means_copy[(size_t)p * N + e] = means[(size_t)p * N + e];
     if (aborted == 2 && (int)blockIdx.x < P && means_copy)       // (header not zeroed: no unit was drawn)
         for (int e = tid; e < N; e += FUSED_THREADS) means_copy[(size_t)blockIdx.x * N + e] = means[(size_t)blockIdx.x * N + e];
+    __threadfence();             // every wave's result stores before thread 0's release of the status tag (mpb_stomp_fused.hip)
+    __syncthreads();
     if (tid == 0) fused_leave(wsu, status_host, tag0, aborted);
 }
 

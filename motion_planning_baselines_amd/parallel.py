@@ -26,15 +26,28 @@ def shard_eps(eps, rank, world, particle_axis=2):
 
 def gather_means(local_means, n_particles_total, group=None, force=False):
     """All-gather the optimised means of every shard into the full (P,H,d) tensor (same on all ranks).
+    Equal shards (P divisible by the world size: every BASELINE config) go through ONE all_gather_into_tensor straight into
+    the result -- no per-rank staging buffers, no concatenation pass (C5: P extra copy kernels and a second 58.7 MB pass in the
+    list form of rounds 1-5).
     force: run the collective at world size 1 too (rehearsals of the RCCL path on a one-GPU box)."""
     world = dist.get_world_size(group)
     if world == 1 and not force:
         return local_means
-    sizes = [shard_range(n_particles_total, r, world) for r in range(world)]
-    bufs = [torch.empty((hi - lo, *local_means.shape[1:]), dtype=local_means.dtype, device=local_means.device)
-            for lo, hi in sizes]
-    dist.all_gather(bufs, local_means.contiguous(), group=group)
-    return torch.cat(bufs, 0)
+    local = local_means.contiguous()
+    if n_particles_total % world == 0:
+        assert local.shape[0] * world == n_particles_total, (local.shape, n_particles_total, world)
+        out = torch.empty((n_particles_total, *local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local, group=group)
+        return out
+    # ragged split (shard sizes differ by one): every shard padded to the largest, the same single collective, the padding rows
+    # cut on arrival (a list all_gather of unequal tensors is refused by gloo and serialised into per-rank broadcasts by RCCL)
+    sizes = [hi - lo for lo, hi in (shard_range(n_particles_total, r, world) for r in range(world))]
+    assert local.shape[0] == sizes[dist.get_rank(group)], (local.shape, sizes)
+    n_max = max(sizes)
+    padded = local if local.shape[0] == n_max else torch.cat([local, local.new_zeros((n_max - local.shape[0], *local.shape[1:]))], 0)
+    out = torch.empty((world * n_max, *local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, padded, group=group)
+    return torch.cat([out[r * n_max:r * n_max + n] for r, n in enumerate(sizes)], 0)
 
 
 def global_diag_mean(local_diag_sum, n_local, group=None):

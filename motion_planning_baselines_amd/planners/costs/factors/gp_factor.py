@@ -1,5 +1,14 @@
-"""GPFactor (mp_baselines/planners/costs/factors/gp_factor.py:4-65): constant-velocity GP prior between consecutive
-states -- Phi, Q^-1, the error x_{t+1} - Phi x_t and its constant Jacobians."""
+"""GPFactor: constant-velocity Gauss-Markov prior between consecutive states -- the GP-prior finite-difference smoothness
+term.  Drop-in for mp_baselines/planners/costs/factors/gp_factor.py:4-65: same constructor, public attributes (`phi`,
+`Q_c_inv`, `Q_inv`, `H1`, `H2`, `idx1`, `idx2`, `state_dim`, ...) and `get_error`.
+
+    Phi = [[I, dt I], [0, I]],   Q^-1 = [[12 / dt^3, -6 / dt^2], [-6 / dt^2, 4 / dt]] (x) Q_c^-1,   e_t = x_{t+1} - Phi x_t
+
+Design differences from the reference class: the error is one HIP pass over the batch (mpb_gp_factor_error: no index_select
+copies, no batched 2D x 2D matmul); Q^-1 is formed as the Kronecker product it is -- one broadcast multiply of the 2 x 2
+coefficient block with the per-factor Q_c^-1 instead of three scaled copies and three concatenations (the same single rounding
+per entry: fl(coefficient) * q); the constant Jacobians are broadcast VIEWS of one (2D, 2D) matrix each, not per-factor copies.
+"""
 import torch
 
 from .... import ops
@@ -8,39 +17,34 @@ from .... import ops
 class GPFactor:
 
     def __init__(self, dim, sigma, d_t, num_factors, tensor_args=None, Q_c_inv=None):
-        self.dim = dim
-        self.d_t = d_t
-        self.tensor_args = tensor_args
-        self.state_dim = self.dim * 2
-        self.num_factors = num_factors
-        dev = tensor_args['device']
-        self.idx1 = torch.arange(0, self.num_factors, device=dev)
-        self.idx2 = torch.arange(1, self.num_factors + 1, device=dev)
+        self.dim, self.state_dim = dim, 2 * dim
+        self.d_t, self.num_factors, self.tensor_args = d_t, num_factors, tensor_args
+        steps = torch.arange(num_factors + 1, device=tensor_args['device'])
+        self.idx1, self.idx2 = steps[:-1], steps[1:]                      # factor t joins states t and t + 1
         self.phi = self.calc_phi()
-        if Q_c_inv is None:
-            Q_c_inv = torch.eye(dim, **tensor_args) / sigma ** 2
-        self.Q_c_inv = torch.zeros(num_factors, dim, dim, **tensor_args) + Q_c_inv
-        self.Q_inv = self.calc_Q_inv()                      # (num_factors, 2D, 2D)
-        self.H1 = self.phi.unsqueeze(0).repeat(self.num_factors, 1, 1)
-        self.H2 = -1. * torch.eye(self.state_dim, **self.tensor_args).unsqueeze(0).repeat(self.num_factors, 1, 1)
+        power = torch.diag(torch.ones(dim, **tensor_args) / sigma ** 2) if Q_c_inv is None else torch.as_tensor(Q_c_inv, **tensor_args)
+        self.Q_c_inv = power.expand(num_factors, dim, dim).contiguous()   # one power-spectral block per factor
+        self.Q_inv = self.calc_Q_inv()                                    # (num_factors, 2D, 2D)
+        n = self.state_dim
+        self.H1 = self.phi.expand(num_factors, n, n)                      # d e_t / d x_t     (sign convention of the reference)
+        self.H2 = (-torch.eye(n, **tensor_args)).expand(num_factors, n, n)     # d e_t / d x_{t+1}
 
     def calc_phi(self):
-        """gp_factor.py:34-40 (set-up constants: a handful of torch calls at construction)."""
-        I = torch.eye(self.dim, **self.tensor_args)
-        Z = torch.zeros(self.dim, self.dim, **self.tensor_args)
-        return torch.cat((torch.cat((I, self.d_t * I), dim=1), torch.cat((Z, I), dim=1)), dim=0)
+        """State transition of the constant-velocity model over one step (gp_factor.py:34-40)."""
+        D = self.dim
+        phi = torch.eye(2 * D, **self.tensor_args)
+        phi[:D, D:].fill_diagonal_(self.d_t)
+        return phi
 
     def calc_Q_inv(self):
-        """gp_factor.py:42-50."""
-        m1 = 12. * (self.d_t ** -3.) * self.Q_c_inv
-        m2 = -6. * (self.d_t ** -2.) * self.Q_c_inv
-        m3 = 4. * (self.d_t ** -1.) * self.Q_c_inv
-        return torch.cat((torch.cat((m1, m2), dim=-1), torch.cat((m2, m3), dim=-1)), dim=-2)
+        """Inverse process noise of one step (gp_factor.py:42-50) as coefficient block (x) Q_c^-1."""
+        dt, D = self.d_t, self.dim
+        coef = torch.tensor([[12. * (dt ** -3.), -6. * (dt ** -2.)], [-6. * (dt ** -2.), 4. * (dt ** -1.)]], **self.tensor_args)
+        blocks = coef.view(1, 2, 1, 2, 1) * self.Q_c_inv.view(-1, 1, D, 1, D)          # [f, a, i, b, j] = coef[a, b] Q_c^-1[f, i, j]
+        return blocks.reshape(-1, 2 * D, 2 * D)
 
     def get_error(self, x_traj, calc_jacobian=True):
-        """gp_factor.py:52-65: error (B, num_factors, 2D, 1) on the GPU (mpb_gp_factor_error)."""
+        """(B, num_factors + 1, 2D) -> e (B, num_factors, 2D, 1) [, H1, H2]  (gp_factor.py:52-65), on the GPU."""
         assert x_traj.shape[1] == self.num_factors + 1 and x_traj.shape[2] == self.state_dim
         error = ops.gp_factor_error(x_traj.to(torch.float32).contiguous(), self.dim, self.d_t).unsqueeze(-1)
-        if calc_jacobian:
-            return error, self.H1, self.H2
-        return error
+        return (error, self.H1, self.H2) if calc_jacobian else error

@@ -236,8 +236,27 @@ class GPMP2(OptimizationPlanner):
         x = self._particle_means
         if self._dense_extras:
             # gpmp2.py:308-342 as the reference runs it: dense (A, b, K) of every member, normal equations, dense solve (fp64)
+            # (dense-sized: refused up front when the three (B, N, N)-class fp64 operands cannot fit, instead of dying in the allocator)
+            N = H * 2 * D
+            need = 4 * B * N * N * 8
+            free = torch.cuda.mem_get_info(self.device)[0] if self.device.type == 'cuda' else need
+            if need > free:
+                raise MemoryError(f'GPMP2 with a dense extra cost needs ~{need / 2 ** 30:.1f} GiB for B={B}, N={N} (the reference\'s dense '
+                                  f'step, gpmp2.py:355-368); {free / 2 ** 30:.1f} GiB free -- lower num_particles or drop the extra cost')
             A, b, K = (t.double() for t in self.cost.get_linear_system(x, n_interpolated_points=self.n_interpolated_points))
-            JtJ, g = self._get_grad_terms(A, b, K, delta=delta, trust_region=trust)
+            sharded = self.process_group is not None and dist.get_world_size(self.process_group) > 1
+            if trust and sharded:
+                # quirk Q9 under sharding (gpmp2.py:361-367): the damping is the mean of diag(A^T K A) over the GLOBAL batch --
+                # all-reduce the local sum of the diagonals and the local particle count, as the block path does
+                A_t_K = A.transpose(-2, -1) @ K
+                A_t_A = A_t_K @ A
+                dsum = torch.diagonal(A_t_A, dim1=-2, dim2=-1).sum(0)
+                nb = torch.tensor([float(B)], device=dsum.device, dtype=torch.float64)
+                dist.all_reduce(dsum, group=self.process_group)
+                dist.all_reduce(nb, group=self.process_group)
+                JtJ, g = A_t_A + delta * torch.diag(dsum / nb), A_t_K @ b
+            else:
+                JtJ, g = self._get_grad_terms(A, b, K, delta=delta, trust_region=trust)
             d_theta = self.get_torch_solve(JtJ, g, method=self.solver_params.get('method', 'cholesky')).reshape(B, H, 2 * D)
             self.costs = (b.transpose(1, 2) @ K @ b).reshape(B).to(torch.float32)
             x.add_((self.step_size * d_theta).to(x.dtype))

@@ -61,8 +61,10 @@ class STOMP(OptimizationPlanner):
              launch's status block for at most 1 ms, then blocks in the runtime, GIL released.)  What happens when a persistent launch is LOST (include/mpb.h, "Failure contract": its workgroups wait for
              each other, every wait is bounded, and a wait that runs out -- the device stopped starting this launch's
              workgroups for seconds, e.g. another context holds every CU -- abandons the call).  'sync' (default):
-             optimize() waits for the launch (host spin on the launch's pinned status block, no sleep) and raises PersistentLaunchLost before it
-             returns -- a caller never holds the result of a lost call.  'deferred' (opt-in, for callers that queue more
+             optimize() waits until the launch has PUBLISHED its completion tag (host spin on the launch's pinned status block, no sleep;
+             every result store of the launch is ordered before the tag, but the kernel may not have retired yet: work on
+             the current stream is ordered behind it as always, a consumer on another stream must wait on this stream) and
+             raises PersistentLaunchLost before it returns -- a caller never holds the result of a lost call.  'deferred' (opt-in, for callers that queue more
              work behind optimize() and synchronise themselves, e.g. bench.py): optimize() returns without waiting and the
              loss is raised at the NEXT call into the planner (optimize / reset / sample / get_traj / persistent_timed_out);
              the kernel reports into pinned host memory, so that check costs no synchronisation -- but a program whose

@@ -25,7 +25,11 @@ def _worker(rank, world, port, out):
     lo, hi = parallel.shard_range(P_total, rank, world)
     full = torch.arange(P_total * H * d, dtype=torch.float32).reshape(P_total, H, d)
     local = full[lo:hi].clone() * 2          # stand-in for "optimised" local means
-    gathered = parallel.gather_means(local, P_total)
+    gathered = parallel.gather_means(local, P_total)          # equal shards: one all_gather_into_tensor
+    # a ragged split (11 particles over 2 ranks: 6 + 5) pads to the largest shard
+    rlo, rhi = parallel.shard_range(11, rank, world)
+    rfull = torch.arange(11 * H * d, dtype=torch.float32).reshape(11, H, d)
+    ragged = parallel.gather_means(rfull[rlo:rhi].clone(), 11)
     # reference eps order (S,d,P,H): slicing the particle axis is non-contiguous
     eps = torch.arange(3 * d * P_total * H, dtype=torch.float32).reshape(3, d, P_total, H)
     loc_eps = parallel.shard_eps(eps, rank, world)
@@ -33,7 +37,7 @@ def _worker(rank, world, port, out):
     dsum = torch.full((H * d,), float(rank + 1), dtype=torch.float64) * (hi - lo)
     mean = parallel.global_diag_mean(dsum, hi - lo)
     if rank == 0:
-        torch.save(dict(gathered=gathered, ok_eps=bool(torch.equal(loc_eps, eps[:, :, lo:hi].contiguous())),
+        torch.save(dict(gathered=gathered, ragged_ok=bool(torch.equal(ragged, rfull)), ok_eps=bool(torch.equal(loc_eps, eps[:, :, lo:hi].contiguous())),
                         contiguous=loc_eps.is_contiguous(), mean=mean, lo=lo, hi=hi), out)
     dist.barrier()
     dist.destroy_process_group()
@@ -45,7 +49,7 @@ def test_two_rank_sharding_and_gather(tmp_path):
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     r = torch.load(out)
     full = torch.arange(10 * 8 * 4, dtype=torch.float32).reshape(10, 8, 4) * 2
-    assert torch.equal(r['gathered'], full)
+    assert torch.equal(r['gathered'], full) and r['ragged_ok']
     assert r['ok_eps'] and r['contiguous']
     assert (r['lo'], r['hi']) == (0, 5)
     # ranks hold 5 particles each with per-particle diag 1 and 2 -> global mean 1.5

@@ -154,9 +154,12 @@ def test_empty_and_invalid_arguments(gpu_device):
     (1, 20, 200, 2, False),    # scale_tril does not fit in LDS: global-memory path, four chunks
     (4, 16, 64, 1, False),     # one control dimension
     (2, 24, 96, 4, False),     # maximum control dimension
+    (2, 1, 64, 2, True),       # ONE sample: a one-wave workgroup (save-best and the softmax share wave 0)
+    (3, 2, 64, 2, True),       # two samples: the smallest workgroup with a softmax wave of its own
 ])
 def test_mppi_shapes_vs_oracle(gpu_device, NP, S, Tn, c, with_geom):
-    """MPPI kernel (wave = sample, lane = time step) on ragged shapes against the oracle's sequential rollout."""
+    """MPPI kernel (wave = sample, lane = time step) on ragged shapes against the oracle's sequential rollout.  Every case
+    tracks the best sample (mppi.py:164-168) as MPPI.optimize does."""
     from motion_planning_baselines_amd import geometry as G, ops
     from oracle import planners_ref as O
     from oracle.geometry_ref import make_ref_geometry
@@ -185,12 +188,14 @@ def test_mppi_shapes_vs_oracle(gpu_device, NP, S, Tn, c, with_geom):
     mean = f(mean0.clone())
     controls, states = torch.empty(NP, S, Tn, c, device=dev), torch.empty(NP, S, Tn, c, device=dev)
     costs, weights = torch.empty(NP, S, device=dev), torch.empty(NP, S, device=dev)
+    best_cost, best_states = torch.full((NP,), 3.0e38, device=dev), torch.zeros(NP, Tn, c, device=dev)
     ops.mppi_step(mean, f(eps), f(tril), f(cinv), f(state0), f(goal), f(cmin), f(cmax), f(disc),
                   f(torch.tensor([cw['pos'], cw['vel'], cw['ctrl'], cw['pos_T']])), geom, controls, states, costs, weights,
-                  dt, k_sigma=4.0, weight=1.5, temp=temp, step_size=step, n_iters=n_it)
+                  dt, k_sigma=4.0, weight=1.5, temp=temp, step_size=step, n_iters=n_it, best_cost=best_cost, best_states=best_states)
     torch.cuda.synchronize()
     for p in range(NP):
         m = mean0[p].clone()
+        best = (np.inf, None)
         for it in range(n_it):
             shift = 0.0
             if with_geom:      # quirk Q6: the summed collision cost of ALL samples shifts every sample's cost
@@ -200,6 +205,12 @@ def test_mppi_shapes_vs_oracle(gpu_device, NP, S, Tn, c, with_geom):
             out = O.mppi_iteration(m, eps[it, p], tril, cinv, state0[p], goal[p], dt, cmin, cmax, cw, disc, temp, step, c,
                                    shift_cost=shift)
             m = out['mean']
+            cst = out['costs'].reshape(-1)
+            if float(cst.min()) < best[0]:
+                best = (float(cst.min()), out['states'][int(cst.argmin())])
+        np.testing.assert_allclose(float(best_cost[p]), best[0], rtol=2e-4)
+        if S <= 2:           # (with more samples a near-tie may pick another winner in fp32: the cost above is the bar there)
+            assert rel_err(best_states[p], best[1]) < 1e-4
         assert rel_err(controls[p], out['controls']) < 1e-4
         assert rel_err(states[p], out['states']) < 1e-4
         np.testing.assert_allclose(costs[p].cpu().numpy(), out['costs'].reshape(-1).numpy(), rtol=2e-4)
@@ -256,12 +267,14 @@ geom = ops.DeviceGeometry(G.RobotPointMass(2, radius=0.01), G.env_grid_circles_2
 mean = torch.zeros(NP, T, c, device=dev)
 controls, states = torch.empty(NP, S, T, c, device=dev), torch.empty(NP, S, T, c, device=dev)
 costs, weights = torch.empty(NP, S, device=dev), torch.empty(NP, S, device=dev)
+best_cost, best_states = torch.full((NP,), 3.0e38, device=dev), torch.zeros(NP, T, c, device=dev)
 ops.mppi_step(mean, None, tril, cinv, state0, goal, f([-1., -1.]), f([1., 1.]), torch.ones(T, device=dev),
               f([1., 1., 1., 100.]), geom, controls, states, costs, weights, 0.04, k_sigma=1e3, weight=1.0, temp=1.0,
-              step_size=0.7, n_iters=3, seed=3)
+              step_size=0.7, n_iters=3, seed=3, best_cost=best_cost, best_states=best_states)
 torch.cuda.synchronize()
 np.savez(out, mean=mean.cpu().numpy(), controls=controls.cpu().numpy(), states=states.cpu().numpy(),
-         costs=costs.cpu().numpy(), weights=weights.cpu().numpy())
+         costs=costs.cpu().numpy(), weights=weights.cpu().numpy(), best_cost=best_cost.cpu().numpy(),
+         best_states=best_states.cpu().numpy())
 """
 
 
@@ -275,15 +288,16 @@ def test_mppi_same_bits_on_8_and_16_waves(gpu_device, tmp_path):
     import sys
     from conftest import ROOT
     res = {}
-    for nw in (16, 8, 5):
+    for nw in (16, 8, 5, 1):          # 1: a one-wave workgroup runs save-best and the softmax on the same wave
         out = str(tmp_path / f'nw{nw}.npz')
         env = dict(os.environ, MPB_MPPI_WAVES=str(nw), PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
         r = subprocess.run([sys.executable, '-c', _MPPI_WAVES_CHILD, out], cwd=ROOT, env=env, capture_output=True, text=True,
                            timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         res[nw] = np.load(out)
-    for k in ('controls', 'states', 'costs', 'weights', 'mean'):
-        assert res[16][k].tobytes() == res[8][k].tobytes() == res[5][k].tobytes(), k
+    for k in ('controls', 'states', 'costs', 'weights', 'mean', 'best_cost', 'best_states'):
+        assert res[16][k].tobytes() == res[8][k].tobytes() == res[5][k].tobytes() == res[1][k].tobytes(), k
+    assert float(res[16]['best_cost'].max()) < 1e30
     assert np.isfinite(res[16]['mean']).all() and float(np.abs(res[16]['mean']).max()) > 0
 
 

@@ -536,7 +536,7 @@ def test_headline_kernels_have_no_scratch():
         # (mostly the injected-noise twins: only the parity tests of several fields at P > 128 come here)
         'stomp_fused_kernel<14,0,2,true,true>': 32, 'stomp_fused_kernel<7,0,2,true,true>': 32, 'stomp_fused_kernel<7,0,2,false,true>': 16,
         'stomp_fused_kernel<14,1,2,true,true>': 48, 'stomp_fused_kernel<7,1,2,true,true>': 36, 'stomp_fused_kernel<7,1,2,false,true>': 16,
-        'stomp_fused_hx_kernel<0,0,1,true>': 72, 'stomp_fused_hx_kernel<0,0,2,true>': 144,   # run-time d, table-driven walk
+        'stomp_fused_hx_kernel<0,0,1,true>': 72, 'stomp_fused_hx_kernel<0,0,2,true>': 148,   # run-time d, table-driven walk
         'stomp_fused_hx_kernel<0,0,1,false>': 16, 'stomp_fused_hx_kernel<0,0,2,false>': 76,
         'stomp_fused_hx_kernel<14,1,1,false>': 8, 'stomp_fused_hx_kernel<7,1,1,true>': 8,   # H < 64
     }
@@ -601,3 +601,41 @@ def test_grid_lattice_far_and_negative_scenes():
     buf = G.pack_geometry(robot, G.CollisionField(spheres=far, margin=0.03))
     assert buf.view(np.int32)[26] == 0 and not (_lib.geom_flags(buf) & 0x100)
     _lib.geom_check(buf)
+
+
+def test_dpp_weighted_sum_keeps_its_wait_states(tmp_path):
+    """The persistent STOMP kernels accumulate the softmax-weighted sum with v_fmac_f32_dpp ... row_newbcast:k, written as inline
+    assembly (mpb_common.h, fmac_row_bcast_seq).  The compiler's hazard recogniser does not look into inline assembly and the
+    hardware does not interlock a DPP read against a preceding vector write of its source (2 wait states) or of exec (5):
+    the block opens with its own `s_nop 4`.  Checked on the code objects the library was linked from: every
+    row_newbcast:0 fmac is directly preceded by that s_nop, the k-th fmac of a block by the (k-1)-th, and no fmac of a block
+    writes the register the block reads through DPP."""
+    import shutil
+    import subprocess
+    from motion_planning_baselines_amd import build
+    build.build(verbose=False)
+    objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+    if not os.path.exists(objdump):
+        pytest.skip('llvm-objdump not in this image')
+    n_blocks = 0
+    for src in ('mpb_stomp_fused', 'mpb_stomp_fused_hx'):
+        obj = str(tmp_path / (src + '.o'))
+        shutil.copy(os.path.join(build.CSRC, src + '.o'), obj)
+        subprocess.run([objdump, '--offloading', obj], check=True, capture_output=True, cwd=str(tmp_path))
+        co = [f for f in os.listdir(tmp_path) if f.startswith(src + '.o.') and 'gfx950' in f]
+        assert len(co) == 1, co
+        text = subprocess.run([objdump, '-d', str(tmp_path / co[0])], check=True, capture_output=True, text=True).stdout
+        ins = [l.split('//')[0].strip() for l in text.splitlines() if l.startswith('\t')]
+        for i, l in enumerate(ins):
+            m = re.match(r'v_fmac_f32_dpp (v\d+), (v\d+), (v\d+) row_newbcast:(\d+) ', l)
+            if not m:
+                continue
+            acc, a, _, k = m.group(1), m.group(2), m.group(3), int(m.group(4))
+            assert acc != a, l
+            if k == 0:
+                n_blocks += 1
+                assert ins[i - 1] == 's_nop 4', (src, ins[i - 3:i + 1])
+            else:
+                p = re.match(r'v_fmac_f32_dpp (v\d+), (v\d+), (v\d+) row_newbcast:(\d+) ', ins[i - 1])
+                assert p and int(p.group(4)) == k - 1 and p.group(1) == acc and p.group(2) == a, (src, ins[i - 2:i + 1])
+    assert n_blocks >= 20           # every instantiation of both kernels carries at least one block
