@@ -92,6 +92,8 @@ class STOMP(OptimizationPlanner):
         self._plan = None                # validated, pre-converted arguments of the persistent launch (ops.StompRunPlan)
         self._last_tag = 0               # tag of the persistent launch the current optimize() call has made (0: none)
         self._spare_copy = None          # the next call's return buffer (allocated while the previous launch runs)
+        self._eps_ring = None            # noise='torch_cpu': pinned host / device double buffer of one iteration's normals
+        self._eps_dev = None             # noise='torch': device chunk buffer of normals
         self._traj_out = None
         self.lr = step_size
         self.sigma_spectral = sigma_spectral
@@ -279,11 +281,7 @@ class STOMP(OptimizationPlanner):
             else:
                 # the whole loop as one persistent launch where the shape allows it (H = 64, S <= 64, grid-backed fields);
                 # mpb_stomp_run falls back to the two-kernel loop by itself otherwise
-                self._last_tag = ops.stomp_run(self._particle_means, self._draw_eps(opt_iters), self.state_particles, self.costs,
-                              self._weights_buf, self.scale_tril, self.Sigma, geom, self.num_samples, self.n_dof, cc.k_sigma,
-                              weight, self.lr, self.temperature, self._run_ws if self.persistent else None,
-                              n_iters=opt_iters, seed=self.seed, iter0=self._iter, particle_offset=self.particle_offset,
-                              status=self._status if self.persistent else None, means_copy=copy)
+                self._last_tag = self._run_fused_injected(opt_iters, geom, cc, weight, copy)
             self._traj_out = copy
             self._iter += opt_iters
         elif not observation and device_plan(self.cost, self.device) is not None:
@@ -310,6 +308,55 @@ class STOMP(OptimizationPlanner):
                 self.costs = self._sample_and_eval(**observation)
                 self._update_distribution(self.costs, self.state_particles)
         self._weights = self._weights_buf.reshape(self.num_particles, self.num_samples, 1, 1)
+
+    def _run_fused_injected(self, opt_iters, geom, cc, weight, copy):
+        """The fused loop (mpb_stomp_run) outside the device-noise fast path: the IDENTICAL-SEED modes noise = 'torch_cpu' / 'torch'
+        (stomp.py:97-108 draws one (S,d,P,H) block of standard normals per iteration through the torch generator: the same
+        `normal_()` calls in the same order here, so `torch.manual_seed(s)` reproduces a reference run's noise bit for bit), and
+        device noise on the two-kernel path.  Returns the tag of the last persistent launch (0: none).
+
+        torch_cpu: the reference's generator runs on the HOST -- 3.7 M normals per C3 iteration, serial by construction (one
+        Mersenne-Twister stream) -- so the loop is a two-stage pipeline: block k of a two-deep ring of PINNED host buffers is
+        drawn while the GPU copies and consumes block k - 1 (async H2D on the launch stream, one n_iters = 1 launch per
+        iteration); an iteration costs max(host draw, H2D + kernel) = the host draw.  (Until round 5: all K blocks drawn,
+        stacked, copied from pageable memory, then one launch -- draw + stack + copy + kernel in series.)
+        torch: the draw is a device kernel per iteration into a chunk buffer, one launch per chunk of up to 16 iterations."""
+        run = lambda eps, n, it0, cp: ops.stomp_run(
+            self._particle_means, eps, self.state_particles, self.costs, self._weights_buf, self.scale_tril, self.Sigma, geom,
+            self.num_samples, self.n_dof, cc.k_sigma, weight, self.lr, self.temperature, self._run_ws if self.persistent else None,
+            n_iters=n, seed=self.seed, iter0=it0, particle_offset=self.particle_offset,
+            status=self._status if self.persistent else None, means_copy=cp)
+        if self.noise == 'philox' or opt_iters <= 0:
+            return run(None, opt_iters, self._iter, copy)
+        S, d, P, H = self.num_samples, self.d_state_opt, self.num_particles, self.n_support_points
+        tag = 0
+        if self.noise == 'torch':
+            chunk = min(opt_iters, 16)
+            buf = self._eps_dev
+            if buf is None or buf.shape != (chunk, S, d, P, H) or buf.device != self.device:
+                buf = self._eps_dev = torch.empty(chunk, S, d, P, H, device=self.device, dtype=torch.float32)
+            done = 0
+            while done < opt_iters:
+                n = min(chunk, opt_iters - done)
+                for i in range(n):
+                    buf[i].normal_()                    # one generator call per iteration, like the reference
+                tag = run(buf[:n], n, self._iter + done, copy if done + n == opt_iters else None)
+                done += n
+            return tag
+        ring = self._eps_ring
+        if ring is None or ring['host'][0].shape != (1, S, d, P, H) or ring['dev'][0].device != self.device:
+            ring = self._eps_ring = dict(
+                host=[torch.empty(1, S, d, P, H, dtype=torch.float32).pin_memory() for _ in range(2)],
+                dev=[torch.empty(1, S, d, P, H, device=self.device, dtype=torch.float32) for _ in range(2)],
+                copied=[torch.cuda.Event() for _ in range(2)])
+        for it in range(opt_iters):
+            k = it & 1
+            ring['copied'][k].synchronize()             # the copy that last read host block k has finished (no-op before its first use)
+            ring['host'][k].normal_()                   # the reference's draw, on the CPU generator
+            ring['dev'][k].copy_(ring['host'][k], non_blocking=True)
+            ring['copied'][k].record()
+            tag = run(ring['dev'][k], 1, self._iter + it, copy if it == opt_iters - 1 else None)
+        return tag
 
     def persistent_timed_out(self):
         """Was the last persistent launch lost (class docstring, `check`)?  Synchronises the stream and reads the

@@ -159,3 +159,88 @@ def test_stomp_class_h128_runs_persistent(gpu_device):
     assert not pl.persistent_timed_out()
     assert torch.isfinite(out).all() and torch.equal(out, pl._particle_means)
     assert float(c1.sum()) < 0.8 * float(c0.sum())
+
+
+def _sweep_shapes(n, seed):
+    """A seeded coarse sample of the generalised kernel's shape space: H in 17 .. 128, d in 1 .. 16 (= D or 2 D of a serial
+    chain with D <= 8 joints), S in 1 .. 40, P in 1 .. 12 -- with the residues that decide its code paths covered on purpose:
+    H d mod 16 (lane rows of the DPP weighted sum), H mod 64 / H > 64 (one or two horizon chunks), S mod 16 and S mod 8
+    (ragged last pass)."""
+    rng = np.random.RandomState(seed)
+    shapes, seen = [], set()
+    while len(shapes) < n:
+        # (every eighth shape sits on an edge of the horizon's chunking)
+        H = int(rng.randint(17, 129)) if len(shapes) % 8 else int(rng.choice([17, 63, 65, 127, 128, 33, 96, 31]))
+        D = int(rng.randint(1, 9))
+        pos_only = bool(rng.randint(0, 2))
+        d = D if pos_only else 2 * D
+        S = int(rng.randint(1, 41))
+        P = int(rng.randint(1, 13))
+        if H == 64 or (H, d, S) in seen:
+            continue
+        seen.add((H, d, S))
+        shapes.append((P, S, H, D, pos_only))
+    return shapes
+
+
+def test_hx_kernel_shape_space_sweep(gpu_device):
+    """VERDICT r05 item 7 (the round-5 bug at H = 37, d = 3 was found by reading, the shapes had been hand-picked): >= 64
+    seeded random shapes of stomp_fused_hx_kernel per run against the two-kernel path -- samples bit for bit (costs too
+    on one horizon chunk), weights / means to rounding, and K iterations in one launch == K one-iteration launches bit for
+    bit -- and, for a handful, the oracle's STOMP iteration on the drawn normals."""
+    from motion_planning_baselines_amd import ops
+    from test_gpu_generic_dof import make_arm, make_field, trajs
+    dev = gpu_device
+    shapes = _sweep_shapes(64, seed=20261004)
+    residues = {(H * (D if po else 2 * D)) % 16 for _, _, H, D, po in shapes}
+    assert len(residues) >= 10 and any(H > 64 for _, _, H, _, _ in shapes) and any(H < 64 for _, _, H, _, _ in shapes)
+    field = make_field()
+    geoms = {}
+    n_oracle = 0
+    for i, (P, S, H, D, pos_only) in enumerate(shapes):
+        d = D if pos_only else 2 * D
+        tag = 'P=%d S=%d H=%d D=%d d=%d' % (P, S, H, D, d)
+        if D not in geoms:
+            geoms[D] = (make_arm(D), ops.DeviceGeometry(make_arm(D), field, dev))
+        robot, geom = geoms[D]
+        means0 = trajs(D, P, H, d, seed=i).to(dev)
+        Sigma, L = _constants(H, 0.05, 0.05, dev)
+        mk = lambda: (torch.empty(P, S, H, d, device=dev), torch.empty(P, S, device=dev), torch.empty(P, S, device=dev))
+        ws = ops.stomp_workspace(P, S, H, d, dev)
+        assert ops.stomp_run_path(geom, ws, P, S, H, d) != ops.STOMP_PATH_TWO_KERNEL, tag
+        args = (L, Sigma, geom, S, D, 25.0, 1.0, 0.3, 2.0)
+        mf, (sf, cf, wf) = means0.clone(), mk()
+        ops.stomp_run(mf, None, sf, cf, wf, *args, ws, n_iters=1, seed=5, iter0=i)
+        mt, (st, ct, wt) = means0.clone(), mk()
+        ops.stomp_step(mt, None, st, ct, wt, *args, n_iters=1, seed=5, iter0=i)
+        torch.cuda.synchronize()
+        assert not ops.stomp_run_timed_out(ws), tag
+        assert torch.isfinite(mf).all(), tag
+        assert torch.equal(sf, st), tag
+        if H <= 64:
+            assert torch.equal(cf, ct), tag
+        else:
+            np.testing.assert_allclose(cf.cpu().numpy(), ct.cpu().numpy(), rtol=2e-6, atol=1e-7 * max(float(ct.max()), 1e-30), err_msg=tag)
+        np.testing.assert_allclose(wf.cpu().numpy(), wt.cpu().numpy(), rtol=1e-4, atol=2e-6, err_msg=tag)
+        assert rel_err(mf, mt) < 2e-5, (tag, rel_err(mf, mt))      # (soft weights at temperature 2: sums in another order)
+        # three iterations in one launch == three launches
+        m1, (s1, c1, w1) = means0.clone(), mk()
+        ops.stomp_run(m1, None, s1, c1, w1, *args, ws, n_iters=3, seed=5, iter0=7)
+        m2, (s2, c2, w2) = means0.clone(), mk()
+        for it in range(3):
+            ops.stomp_run(m2, None, s2, c2, w2, *args, ws, n_iters=1, seed=5, iter0=7 + it)
+        torch.cuda.synchronize()
+        assert not ops.stomp_run_timed_out(ws), tag
+        assert torch.equal(m1, m2) and torch.equal(s1, s2) and torch.equal(c1, c2) and torch.equal(w1, w2), tag
+        if i % 11 == 0:          # the oracle on the normals the kernel drew (stomp.py:150-160), one iteration
+            from oracle import planners_ref as O
+            from oracle.geometry_ref import make_ref_geometry
+            rr, rf = make_ref_geometry(robot, field)
+            nrm = ops.debug_stomp_normals(P, S, d, 1, dev, seed=5, iter0=i, particle_offset=0, H=H)
+            eps = nrm[0, ..., :H].permute(1, 2, 0, 3).contiguous().cpu()           # (S, d, P, H)
+            ref = O.stomp_iteration(means0.cpu(), eps, L.cpu(), Sigma.cpu(), lambda x: O.collision_cost(x, rr, rf, 0.2), 0.3, 2.0)
+            assert rel_err(sf, ref['samples']) < 2e-5, tag
+            np.testing.assert_allclose(cf.cpu().numpy(), ref['costs'].numpy(), rtol=1e-4, atol=1e-4 * max(float(ref['costs'].max()), 1e-6), err_msg=tag)
+            assert rel_err(mf, ref['means']) < 1e-4, (tag, rel_err(mf, ref['means']))
+            n_oracle += 1
+    assert n_oracle >= 5
