@@ -544,7 +544,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
         for (int e = tid; e < N; e += FUSED_THREADS) means_copy[(size_t)p * N + e] = means[(size_t)p * N + e];
     if (aborted == 2 && (int)blockIdx.x < P && means_copy)       // (header not zeroed: no unit was drawn)
         for (int e = tid; e < N; e += FUSED_THREADS) means_copy[(size_t)blockIdx.x * N + e] = means[(size_t)blockIdx.x * N + e];
-    __threadfence();             // every wave's result stores before thread 0's release of the status tag (mpb_stomp_fused.hip)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave's result stores acknowledged before thread 0's release of the status tag (mpb_stomp_fused.hip)
     __syncthreads();
     if (tid == 0) fused_leave(wsu, status_host, tag0, aborted);
 }
