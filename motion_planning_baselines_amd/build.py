@@ -9,14 +9,14 @@ import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['mpb_kernels.hip', 'mpb_stomp_fused.hip', 'mpb_stomp_fused_hx.hip', 'mpb_chomp.hip', 'mpb_gpmp2.hip', 'mpb_mppi.hip', 'mpb_prior.hip', 'mpb_stoch_gpmp.hip', 'mpb_costs.hip', 'mpb_points.hip']
+SOURCES = ['mpb_kernels.hip', 'mpb_stomp_fused.hip', 'mpb_stomp_fused_hx.hip', 'mpb_chomp.hip', 'mpb_gpmp2.hip', 'mpb_gpmp2_lr.hip', 'mpb_mppi.hip', 'mpb_prior.hip', 'mpb_stoch_gpmp.hip', 'mpb_costs.hip', 'mpb_points.hip']
 # the test aids (include/mpb_debug.h) are a library of their own: the product library exports the product ABI only
 DEBUG_SOURCES = ['mpb_debug.hip']
 # per-file extra flags: the latency-bound single-wave-per-problem kernels (CHOMP, GPMP2 solve, MPPI) gain 3-10 % from
 # LLVM's max-ILP scheduling strategy; the STOMP kernels of mpb_kernels.hip lose 2 % with it (measured, round 1)
 MAX_ILP = ['-mllvm', '-amdgpu-sched-strategy=max-ilp']
 # the STOMP / stand-alone cost kernels do best with the iterative-ILP strategy (fused step -1.3 %)
-EXTRA = {'mpb_chomp.hip': MAX_ILP, 'mpb_gpmp2.hip': MAX_ILP, 'mpb_mppi.hip': MAX_ILP,
+EXTRA = {'mpb_chomp.hip': MAX_ILP, 'mpb_gpmp2.hip': MAX_ILP, 'mpb_gpmp2_lr.hip': MAX_ILP, 'mpb_mppi.hip': MAX_ILP,
          'mpb_kernels.hip': ['-mllvm', '-amdgpu-sched-strategy=iterative-ilp'],
          'mpb_stomp_fused.hip': ['-mllvm', '-amdgpu-sched-strategy=iterative-ilp'],
          'mpb_stomp_fused_hx.hip': ['-mllvm', '-amdgpu-sched-strategy=iterative-ilp']}

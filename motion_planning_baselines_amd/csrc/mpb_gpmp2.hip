@@ -26,6 +26,8 @@
 
 #include "mpb_common.h"
 #include "mpb_geom.h"
+#include "mpb_gpmp2.h"
+static_assert(MPB_GP_MAX_FIELDS == MPB_MAX_FIELDS, "mpb_gpmp2.h mirrors mpb_geom.h");
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 #define GP_N 16            // padded block size (2D <= 16)
@@ -229,11 +231,6 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 }
 
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-
-struct GpConst {
-    double dt, ks, kgp, kg, kc, delta, step;
-    int trust;
-};
 
 // workspace doubles per waypoint: the upper triangle of the symmetric W_t (16x16 padded, row-major packed) + z_t.
 // The substitution pass is bound by this traffic at large B, so only the triangle is kept (152 instead of 272 words).
@@ -757,7 +754,10 @@ extern "C" size_t mpb_gpmp2_workspace_bytes(int B, int H, int D) {
     if (!gp_shape_ok(B, H, D)) return 0;
     const size_t jac = (size_t)MPB_MAX_FIELDS * B * H * (D + 1) * sizeof(float);   // one (h, c) set per chained field
     const size_t diag = 2 * (size_t)H * 2 * D * sizeof(double);
-    const size_t fz = (size_t)B * H * GP_WS_PER_T * sizeof(double);
+    // the elimination records of the block form -- or the tables and sweep records of the low-rank form (mpb_gpmp2_lr.hip), whichever is larger
+    size_t fz = (size_t)B * H * GP_WS_PER_T * sizeof(double);
+    const size_t lr = mpb_gpmp2_lr_ws_doubles(B, H, D) * sizeof(double);
+    if (fz < lr) fz = lr;
     return ((jac + 255) / 256) * 256 + ((diag + 255) / 256) * 256 + fz;
 }
 
@@ -840,6 +840,21 @@ extern "C" int mpb_gpmp2_solve(float* x, const float* start, const float* goal, 
     K.step = step_size;
     K.trust = trust_region;
     const double* dm = trust_region ? (diag_mean ? diag_mean : w.diag_mean) : nullptr;
+    // ---- which form.  The low-rank form (round 6, mpb_gpmp2_lr.hip: A0 shared by all particles and factored once per iteration,
+    // a dense solve of the size of a particle's ACTIVE collision rows) wherever its LDS tile holds the rows (F (H - 1) <= 127);
+    // the block elimination below otherwise.  MPB_GPMP2_FORM = lr / block forces one (tests, A/B timing); MPB_GPMP2_SM set
+    // (either value) means the block form, as before round 6.   (read per call: the tests switch within one process)
+    {
+        const char* form_env = getenv("MPB_GPMP2_FORM");
+        const bool want_block = (form_env && !strcmp(form_env, "block")) || (!form_env && getenv("MPB_GPMP2_SM") != nullptr);
+        if (form_env && !strcmp(form_env, "lr") && !mpb_gpmp2_lr_ok(H, D, n_fields))
+            return mpb_fail(MPB_E_UNSUPPORTED, "mpb_gpmp2_solve: MPB_GPMP2_FORM=lr, but n_fields * (H - 1) > 127");
+        if (!want_block && mpb_gpmp2_lr_ok(H, D, n_fields)) {
+            int rc = mpb_gpmp2_lr_launch(x, start, goal, w.jac, dm, w.fz, costs_out, B, H, D, n_fields, K, (hipStream_t)stream);
+            if (rc) return rc;
+            return mpb_check_launch("mpb_gpmp2_solve (low-rank form)");
+        }
+    }
     // two waves per particle (sweeps from both ends of the chain, see the kernel) halve the sequential chain: B = 256
     // -32 %; at B = 2048 the instruction throughput is the bound and both forms take the same time (measured).  The
     // one-wave form remains for chains too short to split

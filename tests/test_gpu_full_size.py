@@ -383,3 +383,43 @@ def test_bench_line_contract(gpu_device):
     # timings are reported, not asserted against a bar: a rare ~70 ms device stall on this pool would fail it
     assert r['kernel_ms'] > 0 and r['two_kernel_path_iters_per_sec'] > 0 and j['value'] > 0
     assert r['kernel_ms'] <= 1.25 * j['ms_per_step']        # the kernel's iteration cannot be slower than the step it is most of
+
+
+def test_gpmp2_low_rank_form_equals_block_elimination_at_c4(gpu_device, monkeypatch):
+    """Round 6: the low-rank form of the GPMP2 solve (mpb_gpmp2_lr.hip: A0 = priors + GP blocks + damping shared by all particles
+    and factored once, one dense solve per particle of the size of its ACTIVE collision rows) against the block elimination of
+    rounds 1-5 on the same linearisation, C4's shape and sigmas, 256 particles whose active sets run from none to ~100 rows, with
+    and without the trust region: the steps agree to the solvers' fp64 rounding, far below the fp32 storage of x."""
+    from motion_planning_baselines_amd import geometry as G, ops, workloads
+    dev = gpu_device
+    B, H, D = 256, 128, 7
+    robot, field = G.RobotPanda(), G.env_spheres_3d()
+    geom = ops.DeviceGeometry(robot, field, dev)
+    q = workloads.collision_free_configs(robot, field, 2 * B, 23, dev)
+    dt = 5.0 / H
+    x0 = workloads.straight_line_means(q[:B], q[B:], H, dt, False, dev)
+    z = torch.zeros(B, D, device=dev)
+    start = torch.cat([torch.from_numpy(q[:B]).to(dev), z], -1).contiguous()
+    goal = torch.cat([torch.from_numpy(q[B:]).to(dev), z], -1).contiguous()
+    sig = (1e-5, 1e-2, 1e-5, 1e-5)
+    ws = ops.gpmp2_workspace(B, H, D, dev)
+    rows = ops.gpmp2_collision_rows(x0, geom)[0]
+    n_act = (rows[..., :D].abs().sum(-1) > 0).sum(1)
+    assert int(n_act.max()) > 60 and int(n_act.min()) == 0, (int(n_act.min()), int(n_act.max()))
+    for trust in (True, False):
+        out = {}
+        for form in ('lr', 'block'):
+            monkeypatch.setenv('MPB_GPMP2_FORM', form)
+            x, c = x0.clone(), torch.empty(B, device=dev)
+            ops.gpmp2_step(x, start, goal, geom, ws, sig, dt, 1e-2, trust, 1.0, costs_out=c)
+            torch.cuda.synchronize()
+            out[form] = (x.double() - x0.double(), c)
+        monkeypatch.delenv('MPB_GPMP2_FORM')
+        d_lr, d_bl = out['lr'][0], out['block'][0]
+        per_particle = (d_lr - d_bl).abs().amax(dim=(1, 2)) / d_bl.abs().amax(dim=(1, 2)).clamp_min(1e-12)
+        # x is stored in fp32: two correct fp64 steps can round differently in the last place of x (6e-8 of |x| ~ 3)
+        ulp = 2.0 ** -23 * float(x0.abs().max())
+        assert float((d_lr - d_bl).abs().max()) <= 2.5 * ulp, (trust, float((d_lr - d_bl).abs().max()), ulp)
+        print('trust %d: low-rank vs block elimination, step rel diff per particle: max %.2e median %.2e' %
+              (trust, float(per_particle.max()), float(per_particle.median())))
+        np.testing.assert_allclose(out['lr'][1].cpu().numpy(), out['block'][1].cpu().numpy(), rtol=1e-5)

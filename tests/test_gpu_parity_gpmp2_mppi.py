@@ -21,23 +21,32 @@ def dev_geom(g, device):
     return DeviceGeometry(robot, field, device)
 
 
+def _set_gpmp2_form(monkeypatch, form):
+    """The three forms of the GPMP2 solve (csrc/mpb_gpmp2.hip, mpb_gpmp2_lr.hip): 'launcher' = the library's own choice (round 6:
+    the low-rank form wherever n_fields (H - 1) <= 127), 'block' = the block elimination of rounds 1-5 with its own choice between
+    the assembled and the Sherman-Morrison collision factors, 'sherman-morrison' = the block elimination with the latter forced."""
+    monkeypatch.delenv('MPB_GPMP2_SM', raising=False)
+    monkeypatch.delenv('MPB_GPMP2_FORM', raising=False)
+    if form in ('block', 'sherman-morrison'):
+        monkeypatch.setenv('MPB_GPMP2_FORM', 'block')
+    if form == 'sherman-morrison':
+        monkeypatch.setenv('MPB_GPMP2_SM', '1')
+
+
 @pytest.mark.parametrize('name', ['gpmp2_pm2d_h8_f64', 'gpmp2_pm2d_h8_notr_f64', 'gpmp2_panda_h16_f64',
                                   'gpmp2_pm2d_h8_f32', 'gpmp2_pm2d_h8_interp_f64', 'gpmp2_panda_h16_interp_f64',
                                   'gpmp2_pm2d_h8_2fields_f64',
                                   'gpmp2_panda_h64_f64',      # one full 64-waypoint chunk of the linearisation
                                   'gpmp2_panda_h128_f64'])    # C4's per-particle shape: N = 1792, 2 x 64 eliminations
-@pytest.mark.parametrize('form', ['launcher', 'sherman-morrison'])
+@pytest.mark.parametrize('form', ['launcher', 'block', 'sherman-morrison'])
 def test_gpmp2_vs_golden(gpu_device, name, form, monkeypatch):
-    """(form: the launcher's own choice -- every golden has a collision / GP precision ratio <= 1e6: the assembled form -- or the
-    Sherman-Morrison form of the collision factors forced through MPB_GPMP2_SM=1: same bars.)
+    """(form: _set_gpmp2_form -- every golden has a collision / GP precision ratio <= 1e6, so 'block' is the assembled form; all
+    three meet the same bars.)
     Teacher-forced Gauss-Newton steps.  The fp64 goldens are the reference run with
     tensor_args dtype=float64 (its fp32 dense Cholesky at kappa ~ 1e10+ is not reproducible: H4);
     the HIP path stores x in fp32 and solves in fp64, so the bar is fp32 storage rounding."""
     from motion_planning_baselines_amd import ops
-    if form == 'sherman-morrison':
-        monkeypatch.setenv('MPB_GPMP2_SM', '1')
-    else:
-        monkeypatch.delenv('MPB_GPMP2_SM', raising=False)
+    _set_gpmp2_form(monkeypatch, form)
     g = load_golden(name)
     dev = gpu_device
     geom = dev_geom(g, dev)
@@ -88,11 +97,12 @@ def _gpmp2_golden_step(name, dev):
 
 
 @pytest.mark.parametrize('name', ['gpmp2_pm2d_h8_notr_f64', 'gpmp2_panda_h16_f64'])
-def test_gpmp2_one_wave_and_two_wave_sweeps_agree(gpu_device, name, tmp_path):
-    """The solve kernel sweeps the chain from both ends with two waves per particle, and top-down with one wave when
+def test_gpmp2_one_wave_and_two_wave_sweeps_agree(gpu_device, name, tmp_path, monkeypatch):
+    """The block-elimination kernel sweeps the chain from both ends with two waves per particle, and top-down with one wave when
     the chain is too short to split (mpb_gpmp2.hip).  The one-wave form is forced on the same golden through the
     library's tuning switch (read once per process, hence the child process) and compared with the two-wave run."""
     import os, subprocess, sys
+    _set_gpmp2_form(monkeypatch, 'block')
     g, x2, c2 = _gpmp2_golden_step(name, gpu_device)
     out = tmp_path / 'one_wave.npz'
     code = ('import sys, numpy as np, torch; sys.path.insert(0, %r); sys.path.insert(0, %r);\n'
@@ -100,7 +110,7 @@ def test_gpmp2_one_wave_and_two_wave_sweeps_agree(gpu_device, name, tmp_path):
             'g, x, c = M._gpmp2_golden_step(%r, torch.device("cuda:0"))\n'
             'np.savez(%r, x=x.numpy(), c=c.numpy())\n') % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                                            os.path.dirname(os.path.abspath(__file__)), name, str(out))
-    env = dict(os.environ, MPB_GPMP2_SPLIT='0')
+    env = dict(os.environ, MPB_GPMP2_SPLIT='0', MPB_GPMP2_FORM='block')
     subprocess.run([sys.executable, '-c', code], check=True, env=env, timeout=600)
     z = np.load(out)
     x1, c1 = torch.from_numpy(z['x']), torch.from_numpy(z['c'])
@@ -111,10 +121,12 @@ def test_gpmp2_one_wave_and_two_wave_sweeps_agree(gpu_device, name, tmp_path):
     np.testing.assert_allclose(c1.numpy(), c2.numpy(), rtol=1e-6)
 
 
+@pytest.mark.parametrize('form', ['launcher', 'block'])
 @pytest.mark.parametrize('H', [2, 3, 4, 5])
-def test_gpmp2_short_chains(gpu_device, H):
-    """H = 2, 3 take the one-wave sweep, H = 4, 5 the shortest split chains (merge row 1 and 2): against the oracle's
-    dense restatement of the reference system (fp64)."""
+def test_gpmp2_short_chains(gpu_device, H, form, monkeypatch):
+    """Block form: H = 2, 3 take the one-wave sweep, H = 4, 5 the shortest split chains (merge row 1 and 2); low-rank form: chains of
+    two to five 2 x 2 blocks, at most four active rows -- against the oracle's dense restatement of the reference system (fp64)."""
+    _set_gpmp2_form(monkeypatch, form)
     from motion_planning_baselines_amd import geometry as G, ops
     from oracle import planners_ref as O
     from oracle.geometry_ref import make_ref_geometry
@@ -169,15 +181,20 @@ def _refined_solve(JtJ, g, l, refine):
     # the 1e8 and 1e10 cases above and the ones below -- 1e10 with the trust region / two fields / the interpolated Jacobian /
     # an odd horizon, and 1e12 -- meet the SAME bars as the well-conditioned cases (rounds 3-4: 2e-6 at 1e8, an 8e-3 "envelope" at 1e10)
     (128, True, 1, 0, (1e-5, 1.0, 1e-5, 1e-5)), (128, False, 2, 0, (1e-5, 1.0, 1e-5, 1e-5)), (65, False, 1, 2, (1e-5, 1.0, 1e-5, 1e-5)),
-    (128, False, 1, 0, (1e-5, 1.0, 1e-5, 1e-6))])
-def test_gpmp2_c4_shape_vs_oracle(gpu_device, H, trust, n_fields, n_interp, sig):
-    """One Gauss-Newton step at C4's per-particle shape (D = 7, H up to 128, C4's sigmas incl. 1/sigma^2 = 1e10) against
+    (128, False, 1, 0, (1e-5, 1.0, 1e-5, 1e-6)),
+    (64, True, 2, 0, None), (64, False, 2, 1, (1e-5, 1.0, 1e-5, 1e-5))])      # two fields within the low-rank form's tile (2 x 63 rows)
+@pytest.mark.parametrize('form', ['launcher', 'block'])
+def test_gpmp2_c4_shape_vs_oracle(gpu_device, H, trust, n_fields, n_interp, sig, form, monkeypatch):
+    """(form: _set_gpmp2_form -- round 6: the launcher takes the low-rank form wherever n_fields (H - 1) <= 127, i.e. every case here
+    but the two-field ones at H = 128; 'block' keeps the block elimination under the same bars.)
+    One Gauss-Newton step at C4's per-particle shape (D = 7, H up to 128, C4's sigmas incl. 1/sigma^2 = 1e10) against
     the oracle's DENSE fp64 restatement of the reference system (N = 2*7*H up to 1792; gpmp2.py:308-368, :451-452):
     the two-ended sweep's merge row, the 64-waypoint chunk carry of the linearisation and the long elimination chain
     at that conditioning.  Bars and the fp32-Jacobian cross-check: at the end of the function."""
     from motion_planning_baselines_amd import geometry as G, ops, workloads
     from oracle import planners_ref as O
     from oracle.geometry_ref import make_ref_geometry
+    _set_gpmp2_form(monkeypatch, form)
     dev = gpu_device
     B, D = 2, 7
     robot = G.RobotPanda()
