@@ -223,8 +223,12 @@ __global__ __launch_bounds__(64) void gpmp2_lr_sweep(float* __restrict__ x, cons
     const double s_p = (double)start[(size_t)pc * dim + i], s_v = (double)start[(size_t)pc * dim + D + i];
     const double g_p = (double)goal[(size_t)pc * dim + i], g_v = (double)goal[(size_t)pc * dim + D + i];
     float pf = xb[i], vf = xb[D + i];
-    double pcur = (double)pf, vcur = (double)vf, qpl = 0.0, qvl = 0.0;
+    double pcur = (double)pf, vcur = (double)vf;
+    // the priors without a branch in the loop: row 0 takes +ks (start - x_0) -- carried in as the "previous factor" of step 0 (the
+    // row's gradient is Phi^T q_t - q_{t-1}) --, row H - 1 takes +kg (goal - x_{H-1}) as the virtual q of its missing factor
+    double qpl = -K.ks * (s_p - pcur), qvl = -K.ks * (s_v - vcur);
     double r0 = 0.0, r1 = 0.0, f00 = 0.0, f01 = 0.0, f10 = 0.0, f11 = 0.0, cost = 0.0;
+    if (!FINAL) cost = K.ks * fma(s_p - pcur, s_p - pcur, (s_v - vcur) * (s_v - vcur));
     double* zr = zbuf + gl * LR_ZREC;
     const size_t zstep = NL * LR_ZREC;
     // (the ring slots must be (re)defined OUTSIDE any conditional: a slot loaded under `if (t < H)` reaches the next trip through a
@@ -246,30 +250,25 @@ __global__ __launch_bounds__(64) void gpmp2_lr_sweep(float* __restrict__ x, cons
                     }
                 }
                 const double pn = (double)pnf, vn = (double)vnf;
-                double qp = 0.0, qv = 0.0;
-                if (t < H - 1) {        // factor (t, t + 1): e = x_{t+1} - Phi x_t; Qi e
+                double qp, qv;
+                if (t < H - 1) {        // factor (t, t + 1): e = x_{t+1} - Phi x_t; Qi e      (wave-uniform branch)
                     const double ep = pn - fma(dt, vcur, pcur), ev = vn - vcur;
                     qp = fma(C.bq, ev, C.a * ep);
                     qv = fma(C.cq, ev, C.bq * ep);
                     if (!FINAL) cost += fma(ep, qp, ev * qv);
+                } else {                // the goal prior as the virtual q with Phi^T q = kg (goal - x)
+                    const double ep = g_p - pcur, ev = g_v - vcur;
+                    qp = K.kg * ep;
+                    qv = fma(-dt, qp, K.kg * ev);
+                    if (!FINAL) cost += K.kg * fma(ep, ep, ev * ev);
                 }
                 // this row takes Phi^T Qi e of its own factor and -Qi e of the previous one
                 double gp = qp - qpl, gv = fma(dt, qp, qv) - qvl;
                 qpl = qp; qvl = qv;
-                if (t == 0) {
-                    const double ep = s_p - pcur, ev = s_v - vcur;
-                    gp = fma(K.ks, ep, gp); gv = fma(K.ks, ev, gv);
-                    if (!FINAL) cost += K.ks * fma(ep, ep, ev * ev);
-                }
-                if (t == H - 1) {
-                    const double ep = g_p - pcur, ev = g_v - vcur;
-                    gp = fma(K.kg, ep, gp); gv = fma(K.kg, ev, gv);
-                    if (!FINAL) cost += K.kg * fma(ep, ep, ev * ev);
-                }
                 if (FINAL) {
-                    if (t > 0) gp += hw;
+                    gp += hw;           // (row 0: h = 0 and w = 0)
                     for (int f = 1; f < F; ++f)          // further chained fields (rare: not prefetched)
-                        if (t > 0) gp = fma((double)jac[(((size_t)f * B + pc) * H + t) * (D + 1) + i], wdense[((size_t)f * B + pc) * H + t], gp);
+                        gp = fma((double)jac[(((size_t)f * B + pc) * H + t) * (D + 1) + i], wdense[((size_t)f * B + pc) * H + t], gp);
                 }
                 const double* rc = tab + (size_t)t * LR_REC;
                 const double a0 = fma(-f10, r1, fma(-f00, r0, gp)), a1 = fma(-f11, r1, fma(-f01, r0, gv));
@@ -533,12 +532,13 @@ __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ ja
                 double xv[16];
 #pragma unroll
                 for (int c = 0; c < 16; ++c) xv[c] = Tij[lr_sw(r, c)];
+                // (column by column, every later column updated as soon as x_c is known: the dependent chain is 16 x (mul, fma), where
+                // the dot-product form accumulated 120 fma one after the other)
 #pragma unroll
                 for (int c = 0; c < 16; ++c) {
-                    double acc = xv[c];
+                    if (16 * J + c < n) xv[c] *= dinv[16 * J + c];                  // (padding columns: the identity)
 #pragma unroll
-                    for (int j = 0; j < c; ++j) acc = fma(-xv[j], Djj[lr_sw(c, j)], acc);
-                    xv[c] = (16 * J + c < n) ? acc * dinv[16 * J + c] : acc;      // (padding columns: the identity)
+                    for (int j = c + 1; j < 16; ++j) xv[j] = fma(-xv[c], Djj[lr_sw(j, c)], xv[j]);
                 }
 #pragma unroll
                 for (int c = 0; c < 16; ++c) Tij[lr_sw(r, c)] = xv[c];
