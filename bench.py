@@ -57,6 +57,21 @@ def latest_profile(pattern):
         return json.load(fh), os.path.relpath(files[-1], ROOT)
 
 
+def pmc_freshness(pmc):
+    """Are the counters of a committed summary those of the kernel this process runs?  Since round 6 a summary carries the SHA-1
+    of the kernel's sources as they were when the passes ran (scripts/pmc_summary.py: `pmc.sources_sha1`); recomputed here from
+    the tree.  None: a summary from before round 6 (no fingerprint)."""
+    meta = (pmc or {}).get('pmc')
+    if not meta:
+        return {'pmc_commit': None, 'pmc_matches_sources': None}
+    from motion_planning_baselines_amd import build as _build
+    try:
+        same = _build.sources_sha1(meta['sources']) == meta['sources_sha1']
+    except OSError:
+        same = False
+    return {'pmc_commit': meta.get('commit'), 'pmc_round': meta.get('round'), 'pmc_matches_sources': bool(same)}
+
+
 def cpu_threads():
     cores = min(os.cpu_count() or 1, 32)     # more intra-op threads than this only adds contention here
     torch.set_num_threads(cores)
@@ -439,6 +454,41 @@ def bench_seeded(wl, cost, dev, rank, P, steps):
     return out
 
 
+def bench_generic_model(wl, dev, rank, P, S, steps):
+    """`generic_model`: the main line's workload with the robot taken from the geometry buffer's TABLES (pack_geometry(use_model=False):
+    the table-driven chain walk any serial chain gets) instead of the compile-time Panda model whose DH entries and collision spheres
+    are literals of the instruction stream (csrc/mpb_model_panda.h, geometry flag bits 0-7) -- what a second robot costs on the same
+    persistent launch.  Same bits as the model walk (tests/test_gpu_stomp_fused.py)."""
+    from motion_planning_baselines_amd import ops
+    from motion_planning_baselines_amd.planners.stomp import STOMP
+    from motion_planning_baselines_amd.planners.costs.cost_functions import CostCollision, CostComposite
+    ta = dict(device=dev, dtype=torch.float32)
+    H = wl['params']['n_support_points']
+    cc = CostCollision(wl['robot'], H, field=wl['field'], sigma_coll=wl['sigma_coll'], tensor_args=ta)
+    cc._geom = ops.DeviceGeometry(wl['robot'], wl['field'], dev, use_model=False)
+    assert (cc._geom.flags & 0xFF) == 0
+    cost = CostComposite(wl['robot'], H, [cc], tensor_args=ta)
+    pl = STOMP(opt_iters=1, start_state=torch.from_numpy(wl['starts'][0]).to(dev), cost=cost, initial_particle_means=wl['means0'],
+               tensor_args=ta, noise='philox', seed=0, particle_offset=rank * P, check='deferred', **wl['params'])
+    for _ in range(10):
+        pl._particle_means.copy_(wl['means0'])
+        pl.optimize(opt_iters=steps)
+        torch.cuda.synchronize()
+    ts = []
+    for _ in range(9):
+        pl._particle_means.copy_(wl['means0'])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pl.optimize(opt_iters=steps)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    assert not pl.persistent_timed_out()
+    t = sorted(ts)[len(ts) // 2]
+    return {'value': steps / t, 'unit': 'iters/s', 'ms_per_step': 1e3 * t / steps, 'blocks': len(ts), 'path': int(pl.run_path()),
+            'note': 'table-driven robot (geometry flags model id 0) on the persistent launch, K = %d steps per block from the initial means, '
+                    'median of %d blocks bracketed by synchronize; the main line is the compile-time Panda model' % (steps, len(ts))}
+
+
 def run_stomp(planner, clock, dist, world, steps, warmup, repeats, preheat, cold=False):
     """W untimed steps, then R blocks of EXACTLY `steps` steps (one C-ABI call = 2K launches) + the final gather."""
     # the final gather's destination: one flat (world * P, H, d) tensor (all_gather_into_tensor: one RCCL kernel, no
@@ -554,7 +604,7 @@ def bench_c2(dev, steps, with_cpu=True):
     if pmc and pmc.get('SQ_INSTS_VALU_per_wave_iteration') and B == 1024:
         ginstr = pmc['SQ_INSTS_VALU_per_wave_iteration'] * pmc['waves_per_launch'] / (med / steps) / 1e9
         out['roofline'].update({'bound': 'valu', 'achieved': ginstr, 'peak': VALU_PEAK_GINSTR, 'unit': 'G wave-instr/s',
-                                'frac': ginstr / VALU_PEAK_GINSTR, 'pmc_source': pmc_file,
+                                'frac': ginstr / VALU_PEAK_GINSTR, 'pmc_source': pmc_file, **pmc_freshness(pmc),
                                 'valu_instructions_per_wave_iteration': pmc['SQ_INSTS_VALU_per_wave_iteration']})
     if with_cpu:
         # CPU: the oracle's autograd restatement of chomp.py:134-149 on the full batch
@@ -600,15 +650,34 @@ def bench_c4(dev, steps, with_cpu=True):
     pl.set_problem_states(torch.from_numpy(q[:B]).to(dev), torch.from_numpy(q[B:]).to(dev))
     pl.optimize(opt_iters=3)
     torch.cuda.synchronize()
-    blocks = []
-    for _ in range(5):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        pl.optimize(opt_iters=steps)
-        torch.cuda.synchronize()
-        blocks.append(time.perf_counter() - t0)
+
+    def timed_blocks(k, n_blocks=5):
+        """every block = the FIRST k iterations from the initial straight lines (round 6: the low-rank form's time depends on how
+        many waypoints are inside the hinge margin, which falls as the trajectories leave the obstacles; until round 5 the blocks
+        continued from wherever the previous block had left the particles, which the block elimination's time did not notice)"""
+        out = []
+        for _ in range(n_blocks):
+            pl._particle_means.copy_(means0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pl.optimize(opt_iters=k)
+            torch.cuda.synchronize()
+            out.append(time.perf_counter() - t0)
+        return out
+    blocks = timed_blocks(steps)
     med, sp = spread(blocks, steps)
     assert torch.isfinite(pl._particle_means).all()
+    first_ms = 1e3 * sorted(timed_blocks(1))[2]
+    # the block elimination of rounds 1-5 on the same blocks (MPB_GPMP2_FORM is read per call)
+    lr_form = os.environ.get('MPB_GPMP2_FORM', '') != 'block' and os.environ.get('MPB_GPMP2_SM') is None and (H - 1) <= 127
+    block_ms = None
+    if lr_form:
+        os.environ['MPB_GPMP2_FORM'] = 'block'
+        try:
+            pl.optimize(opt_iters=2)
+            block_ms = 1e3 * spread(timed_blocks(steps, 3), steps)[0] / steps
+        finally:
+            del os.environ['MPB_GPMP2_FORM']
     # structured flops (SURVEY 8d): per particle (H-1) block steps x (potrf 14^3/3 + trsm 14^3 + syrk/gemm 2*14^3)
     n = 2 * D
     flop_iter = B * (H - 1) * (n ** 3 / 3 + n ** 3 + 2 * n ** 3)
@@ -617,11 +686,20 @@ def bench_c4(dev, steps, with_cpu=True):
         'workload': 'panda_spheres GPMP2 B=%d H=%d D=%d (N=%d unknowns per particle), trust region, fp64 solve' % (B, H, D, n * H),
         'metric': 'gpmp2_trajectory_update_iters_per_sec', 'value': steps / med, 'unit': 'iters/s',
         'ms_per_step': 1e3 * med / steps, 'repeats': sp, 'dtype': 'f64',
+        'protocol': 'every block = the first %d iterations from the initial straight lines (reset before each block)' % steps,
+        'ms_first_iteration': first_ms,
+        'form': ('low-rank (csrc/mpb_gpmp2_lr.hip): A0 = priors + GP blocks + damping shared by all particles and factored once per '
+                 'iteration, two chain substitutions + one dense SPD solve over the ACTIVE collision rows per particle') if lr_form
+                else 'block elimination (csrc/mpb_gpmp2.hip)',
+        'block_form_ms_per_step': block_ms,
         'roofline': {'bound': 'mfma', 'achieved': tflops, 'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': tflops / FP64_MATRIX_PEAK_TFLOPS, 'structured_flop_per_iter': flop_iter,
-                     'note': 'block-tridiagonal (14x14 blocks) elimination, sequential in t: a latency chain, not a GEMM'}}
+                     'note': 'SURVEY 8(d)\'s structured count of the block-tridiagonal elimination (14 x 14 blocks, 127 block steps per particle) '
+                             'over the iteration\'s time, against the fp64 matrix peak -- the figure rounds 1-5 report.  The low-rank form of '
+                             'round 6 does NOT execute those flops: it solves the same system with ~30 kFLOP per particle (the sweeps) plus '
+                             'n_a^3 / 3 for its n_a active rows, bound by the latency of short dependent fp64 chains (DESIGN 6)'}}
     pmc, pmc_file = latest_profile('r*_pmc_solve.json')
-    if pmc and pmc.get('SQ_INSTS_VALU_per_wave') and B == 2048:
+    if pmc and pmc.get('SQ_INSTS_VALU_per_wave') and B == 2048 and not lr_form:
         # what actually binds the solve kernel (88 % of the iteration): fp64 VALU issue (4.7 cycles per wave-instruction,
         # profiles/r01_microbench_valu.txt) and the W_t workspace stream; the whole iteration's time is used (conservative)
         it_s = med / steps
@@ -632,7 +710,7 @@ def bench_c4(dev, steps, with_cpu=True):
                                        'peak_spec': peak64_spec, 'frac_of_spec': ginstr / peak64_spec,
                                        'peak_note': '`peak` = the microbenched 4.7 cycles per fp64 wave-instruction (profiles/r01_microbench_valu.txt), '
                                                     '`peak_spec` = the 4 cycles of the data sheet',
-                                       'valu_instructions_per_wave': pmc['SQ_INSTS_VALU_per_wave'], 'pmc_source': pmc_file}
+                                       'valu_instructions_per_wave': pmc['SQ_INSTS_VALU_per_wave'], 'pmc_source': pmc_file, **pmc_freshness(pmc)}
         cls = {c: pmc.get('SQ_INSTS_VALU_%s_per_wave' % c) for c in ('ADD_F64', 'MUL_F64', 'FMA_F64', 'TRANS_F64', 'INT32', 'INT64', 'CVT')}
         if all(v is not None for v in cls.values()) and pmc.get('SQ_INSTS_MFMA_per_wave') is not None:
             # the fp64 pipe of a SIMD by instruction class (architectural cycles per wave-instruction: fp64 add / mul / fma 4,
@@ -715,7 +793,7 @@ def bench_h128(dev, steps, with_cpu=True):
         roof = {'bound': 'valu', 'achieved': gi, 'peak': VALU_PEAK_GINSTR, 'unit': 'G wave-instr/s', 'frac': gi / VALU_PEAK_GINSTR,
                 'valu_instructions_per_wave_iteration': pmc['SQ_INSTS_VALU_per_wave_iteration'], 'waves_per_launch': pmc['waves_per_launch'],
                 'mfma_instructions_per_wave_iteration': pmc.get('SQ_INSTS_MFMA_per_wave_iteration'),
-                'kernel': pmc.get('kernel'), 'pmc_source': pmc_file, 'traffic': pmc.get('hbm_bytes_per_iteration'), 'hbm': roof}
+                'kernel': pmc.get('kernel'), 'pmc_source': pmc_file, **pmc_freshness(pmc), 'traffic': pmc.get('hbm_bytes_per_iteration'), 'hbm': roof}
     out = {'workload': 'panda_spheres STOMP B=4096 (P=128 x S=32) H=128 D=7 d=14, %d iterations per call' % steps,
            'metric': 'stomp_trajectory_update_iters_per_sec', 'value': steps / t, 'unit': 'iters/s', 'ms_per_step': 1e3 * t / steps,
            'path': {ops.STOMP_PATH_TWO_KERNEL: 'two-kernel', ops.STOMP_PATH_PERSISTENT_EXCHANGE: 'persistent (exchange)',
@@ -972,6 +1050,7 @@ def main():
         ginstr = valu * (P * S) / (k_ms * 1e-3) / 1e9
         roof = {'bound': 'valu', 'achieved': ginstr, 'peak': VALU_PEAK_GINSTR, 'unit': 'G wave-instr/s',
                 'frac': ginstr / VALU_PEAK_GINSTR, 'valu_instructions_per_wave_iteration': valu, 'pmc_source': pmc_file,
+                **pmc_freshness(pmc),
                 'frac_note': 'vector instructions ISSUED per second over the issue peak (one wave-instruction per 2 cycles per SIMD): it falls when a '
                              'round removes instructions faster than time (0.49 in round 4 at 2 045 instructions and 13.8 us per iteration of the timed launch; %.2f now at %d); ' % (ginstr / VALU_PEAK_GINSTR, round(valu)) +
                              '`hbm.frac` is the algorithmic figure.  By phase (profiles/r05_stamps_fused.txt, diagnostic build): the collision-cost phase '
@@ -1019,6 +1098,13 @@ def main():
                                       'note': 'class counters SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32 / INT32 / INT64 / CVT of the PMC passes, '
                                               'priced per profiles/r03_microbench_rates.txt; peak = 1024 SIMDs x 2.4 GHz; the hardware '
                                               'counts 0 cycles in which a matrix and a vector instruction executed together'}
+    if cls and all(v is not None for v in cls.values()) and valu:
+        # arithmetic actually done, next to the issue fraction: fp32 flops of the counted classes (fma = 2)
+        flop_wave_it = 64.0 * (2.0 * cls['FMA_F32'] + cls['ADD_F32'] + cls['MUL_F32'] + cls['TRANS_F32'])
+        tf = flop_wave_it * (P * S) / (k_ms * 1e-3) / 1e12
+        roof['fp32_flops'] = {'achieved': tf, 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': tf / 157.3,
+                              'note': 'SQ_INSTS_VALU_{FMA x 2, ADD, MUL, TRANS}_F32 x 64 lanes per wave-iteration over the kernel time; the '
+                                      'rest of the issued instructions are integer / convert / move / select / lane traffic'}
     roof.update({'kernel': 'stomp_fused_kernel<%d, model> (persistent: one launch = all iterations)' % d, 'traffic': traffic,
                  'hbm': {'achieved': hbm_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': hbm_gbs / HBM_PEAK_GBS,
                          'algorithmic_bytes_per_launch': alg_bytes_k, 'note': 'per iteration of the persistent launch'},
@@ -1068,9 +1154,10 @@ def main():
         eps_parity = torch.randn(2, S, d, P, H, generator=torch.Generator().manual_seed(1234))
         par_gpu = stomp_parity_gpu(wl, planner, cost, geom, eps_parity)
         par_philox_gpu = stomp_parity_philox_gpu(wl, planner, cost, geom, n_it=max(2, min(args.steps, 20)))
-    seeded = None
+    seeded = generic = None
     if rank == 0 and world == 1 and not args.main_only and not args.no_other_configs:
         seeded = bench_seeded(wl, cost, dev, rank, P, args.steps)
+        generic = bench_generic_model(wl, dev, rank, P, S, args.steps)
 
     # ---- BASELINE configs[4]'s per-GPU load with the same protocol (every N)
     c5 = None
@@ -1099,7 +1186,7 @@ def main():
             gi5 = pmc5['SQ_INSTS_VALU_per_wave_iteration'] * pmc5['waves_per_launch'] / it5 / 1e9
             roof5 = {'bound': 'valu', 'achieved': gi5, 'peak': VALU_PEAK_GINSTR, 'unit': 'G wave-instr/s', 'frac': gi5 / VALU_PEAK_GINSTR,
                      'valu_instructions_per_wave_iteration': pmc5['SQ_INSTS_VALU_per_wave_iteration'], 'waves_per_launch': pmc5['waves_per_launch'],
-                     'kernel': pmc5.get('kernel'), 'pmc_source': pmc5_file, 'traffic': pmc5.get('hbm_bytes_per_iteration'), 'hbm': roof5}
+                     'kernel': pmc5.get('kernel'), 'pmc_source': pmc5_file, **pmc_freshness(pmc5), 'traffic': pmc5.get('hbm_bytes_per_iteration'), 'hbm': roof5}
         c5['roofline'] = roof5
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             n5 = 128
@@ -1146,6 +1233,8 @@ def main():
             line['k1'] = k1
         if seeded is not None:
             line['seeded'] = seeded
+        if generic is not None:
+            line['generic_model'] = generic
         if c5 is not None:
             line['c5'] = c5
         if world == 1 and not args.no_cpu_baseline:

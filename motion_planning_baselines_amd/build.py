@@ -48,6 +48,35 @@ def parse_resource_remarks(text):
     return out
 
 
+# which sources define the kernels a counter summary (profiles/*_pmc_*.json) was taken for: the summary carries the SHA-1 of these
+# files as they were when the passes ran (scripts/pmc_summary.py), bench.py recomputes it and says when the kernel has changed since
+PMC_SOURCES = {
+    'stomp': ['mpb_stomp_fused.hip', 'mpb_stomp_fused.h', 'mpb_stomp_noise.h', 'mpb_geom.h', 'mpb_common.h', 'mpb_model_panda.h'],
+    'stomp_c5': ['mpb_stomp_fused.hip', 'mpb_stomp_fused.h', 'mpb_stomp_noise.h', 'mpb_geom.h', 'mpb_common.h', 'mpb_model_panda.h'],
+    'stomp_h128': ['mpb_stomp_fused_hx.hip', 'mpb_stomp_fused.h', 'mpb_stomp_noise.h', 'mpb_geom.h', 'mpb_common.h', 'mpb_model_panda.h'],
+    'kernelA': ['mpb_kernels.hip', 'mpb_stomp_noise.h', 'mpb_geom.h', 'mpb_common.h', 'mpb_model_panda.h'],
+    'solve': ['mpb_gpmp2.hip', 'mpb_gpmp2_lr.hip', 'mpb_gpmp2.h', 'mpb_geom.h', 'mpb_common.h'],
+    'chomp': ['mpb_chomp.hip', 'mpb_geom.h', 'mpb_common.h', 'mpb_model_panda.h'],
+    'mppi': ['mpb_mppi.hip', 'mpb_geom.h', 'mpb_common.h'],
+}
+
+
+def sources_sha1(files):
+    """SHA-1 over the named csrc files (name and content, in the order given) -- the fingerprint of a kernel's sources."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in files:
+        h.update(f.encode())
+        with open(os.path.join(CSRC, f), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def pmc_fingerprint(kind):
+    files = PMC_SOURCES[kind]
+    return {'sources': files, 'sources_sha1': sources_sha1(files), 'flags': FLAGS + EXTRA.get(files[0], [])}
+
+
 def _stale():
     if not os.path.exists(OUT) or not os.path.exists(DEBUG_OUT) or not os.path.exists(RESOURCES):
         return True

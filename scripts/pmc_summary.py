@@ -7,6 +7,22 @@ import csv, glob, json, os, re, shutil, sqlite3, sys
 from collections import defaultdict
 
 src, tag = sys.argv[1], sys.argv[2]
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from motion_planning_baselines_amd import build as _build
+
+
+def _dump(out, kind, path):
+    """every summary carries the fingerprint of the kernel sources it was taken from (and the commit, where a work tree is at hand:
+    the GPU box has none) -- bench.py compares it with the sources it runs"""
+    out['pmc'] = dict(_build.pmc_fingerprint(kind), round=tag.split('_')[0])
+    try:
+        import subprocess
+        out['pmc']['commit'] = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True, check=True,
+                                              cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip()
+    except Exception:
+        out['pmc']['commit'] = None
+    with open(path, 'w') as fh:
+        json.dump(out, fh, indent=1)
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof = os.path.join(root, 'profiles')
 os.makedirs(prof, exist_ok=True)
@@ -127,8 +143,7 @@ if kf:
     for c in ('SQ_ACTIVE_INST_VALU', 'SQ_INSTS_BRANCH', 'SQ_LDS_BANK_CONFLICT', 'SQ_LDS_IDX_ACTIVE', 'SQ_INSTS_SMEM', 'SQ_INSTS_VMEM', 'SQ_ACTIVE_INST_SCA'):
         if c in s:
             out[c + '_per_wave_iteration'] = per(c)
-    with open(os.path.join(prof, f'{tag}_pmc_{pmc_name}.json'), 'w') as fh:
-        json.dump(out, fh, indent=1)
+    _dump(out, pmc_name, os.path.join(prof, f'{tag}_pmc_{pmc_name}.json'))
     print(json.dumps(out, indent=1))
 
 kg = [k for k in summary if 'gpmp2_solve_kernel' in k]
@@ -144,8 +159,7 @@ if kg:   # GPMP2 C4 (scripts/prof_gpmp2.py: one iteration per launch)
               'SQ_VALU_MFMA_BUSY_CYCLES'):
         if c in s:
             out[c + ('_KB_raw_per_launch' if c.endswith('SIZE') else '_per_wave')] = s[c] if c.endswith('SIZE') else s[c] / waves
-    with open(os.path.join(prof, f'{tag}_pmc_solve.json'), 'w') as fh:
-        json.dump(out, fh, indent=1)
+    _dump(out, 'solve', os.path.join(prof, f'{tag}_pmc_solve.json'))
 
 kc = [k for k in summary if 'chomp_point4_kernel' in k]
 if kc:   # CHOMP C2 (scripts/prof_chomp.py: bench.py's c2 entry, MPB_CHOMP_ITERS iterations per launch)
@@ -158,8 +172,7 @@ if kc:   # CHOMP C2 (scripts/prof_chomp.py: bench.py's c2 entry, MPB_CHOMP_ITERS
            'SQ_INSTS_VALU_per_wave_iteration': s['SQ_INSTS_VALU'] / waves / iters if 'SQ_INSTS_VALU' in s else None,
            'SQ_INSTS_SALU_per_wave_iteration': s['SQ_INSTS_SALU'] / waves / iters if 'SQ_INSTS_SALU' in s else None,
            'SQ_INSTS_LDS_per_wave_iteration': s['SQ_INSTS_LDS'] / waves / iters if 'SQ_INSTS_LDS' in s else None}
-    with open(os.path.join(prof, f'{tag}_pmc_chomp.json'), 'w') as fh:
-        json.dump(out, fh, indent=1)
+    _dump(out, 'chomp', os.path.join(prof, f'{tag}_pmc_chomp.json'))
 
 km = [k for k in summary if 'mppi_kernel' in k]
 if km:   # MPPI, NP = 1024 problems (scripts/prof_mppi.py: bench.py's mppi entry, 50 iterations per launch)
@@ -172,8 +185,7 @@ if km:   # MPPI, NP = 1024 problems (scripts/prof_mppi.py: bench.py's mppi entry
     for c in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_LDS_BANK_CONFLICT', 'SQ_LDS_IDX_ACTIVE'):
         if c in s:
             out[c + '_per_wave_iteration'] = s[c] / waves / iters
-    with open(os.path.join(prof, f'{tag}_pmc_mppi.json'), 'w') as fh:
-        json.dump(out, fh, indent=1)
+    _dump(out, 'mppi', os.path.join(prof, f'{tag}_pmc_mppi.json'))
 
 ka = [k for k in summary if 'stomp_sample_cost' in k and 'true' in k]
 if ka:
@@ -189,7 +201,6 @@ if ka:
            'note': 'gfx950: FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads (MI355X_MICROARCH.md, HBM) -> the read '
                    'side is doubled; WRITE_SIZE is exact for 16-B-per-lane streaming stores',
            'hbm_bytes_per_launch': (2 * fetch_kb + write_kb) * 1024 if fetch_kb is not None and write_kb is not None else None}
-    with open(os.path.join(prof, f'{tag}_pmc_kernelA.json'), 'w') as fh:
-        json.dump(out, fh, indent=1)
+    _dump(out, 'kernelA', os.path.join(prof, f'{tag}_pmc_kernelA.json'))
     print(json.dumps(out, indent=1))
 print('\n'.join(lines[:60]))

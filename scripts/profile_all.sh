@@ -39,6 +39,25 @@ echo "bench done"
 # the two-rank rehearsal on this box's one GPU (gloo: ranks share the device; the 8-GPU node runs the same command on RCCL)
 MPB_DIST_BACKEND=gloo python3 bench.py --gpus 2 --steps 20 --warmup 5 > profiles/${TAG}_bench_2ranks_one_gpu_gloo.json 2> gpurun_out/${TAG}_bench2.err || true
 echo "two-rank rehearsal done"
+# round 6: refuse to finish on stale counters -- every profiles/*_pmc_*.json that bench.py would read (the newest per kind) must carry the
+# fingerprint of the kernel sources of THIS tree (scripts/pmc_summary.py stamps it; a file this run did not re-take, or one taken
+# before a kernel edit, fails here instead of pricing live times with old instruction counts)
+python3 - <<'PYEOF'
+import glob, json, os, sys
+sys.path.insert(0, os.getcwd())
+import bench
+bad = []
+for pat in ('r*_pmc_stomp.json', 'r*_pmc_stomp_c5.json', 'r*_pmc_stomp_h128.json', 'r*_pmc_solve.json', 'r*_pmc_chomp.json', 'r*_pmc_mppi.json'):
+    pmc, f = bench.latest_profile(pat)
+    if pmc is None:
+        continue
+    fresh = bench.pmc_freshness(pmc)['pmc_matches_sources']
+    print('%-44s %s' % (f, {True: 'matches the kernel sources', False: 'STALE', None: 'no fingerprint (taken before round 6)'}[fresh]))
+    if fresh is not True:
+        bad.append(f)
+if bad:
+    sys.exit('profile_all.sh: counter summaries that do not belong to this tree\'s kernels: ' + ', '.join(bad))
+PYEOF
 # what travels back from the GPU box is gpurun_out/ (<= 64 MiB): the summaries, not the raw rocprofv3 databases
 mkdir -p gpurun_out/profiles_${TAG}
 cp profiles/${TAG}_* gpurun_out/profiles_${TAG}/
