@@ -489,6 +489,44 @@ def bench_generic_model(wl, dev, rank, P, S, steps):
                     'median of %d blocks bracketed by synchronize; the main line is the compile-time Panda model' % (steps, len(ts))}
 
 
+def bench_crowded(dev, rank, P, S, steps):
+    """`crowded`: the main line's shape (P x S rollouts, H = 64, d = 14, Panda) in a scene of 200 obstacle spheres + 32 boxes -- beyond
+    the compact broad-phase grid (63 spheres, three candidates per cell), which until round 5 sent such a scene to the two-kernel
+    EXHAUSTIVE walk.  Round 6: geometry version 7 (list grid: any number of candidates per cell, boxes culled like spheres) on the
+    persistent launch (stomp_fused_hx_kernel<..., LIST>); the two-kernel exhaustive path next to it.  Same bits (tests)."""
+    from motion_planning_baselines_amd import workloads
+    from motion_planning_baselines_amd.planners.stomp import STOMP
+    from motion_planning_baselines_amd.planners.costs.cost_functions import CostCollision, CostComposite
+    wl = workloads.panda_crowded_stomp(P, dev, S=S)
+    H = wl['params']['n_support_points']
+    ta = dict(device=dev, dtype=torch.float32)
+    cost = CostComposite(wl['robot'], H, [CostCollision(wl['robot'], H, field=wl['field'], sigma_coll=wl['sigma_coll'], tensor_args=ta)],
+                         tensor_args=ta)
+    out = {'workload': 'panda STOMP P=%d x S=%d H=%d d=14, 200 obstacle spheres + 32 boxes (geometry version 7: list grid)' % (P, S, H)}
+    for name, persistent in (('persistent', True), ('two_kernel_exhaustive', False)):
+        pl = STOMP(opt_iters=1, start_state=torch.from_numpy(wl['starts'][0]).to(dev), cost=cost, initial_particle_means=wl['means0'],
+                   tensor_args=ta, noise='philox', seed=0, particle_offset=rank * P, check='deferred', persistent=persistent, **wl['params'])
+        for _ in range(4):
+            pl._particle_means.copy_(wl['means0'])
+            pl.optimize(opt_iters=steps)
+            torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            pl._particle_means.copy_(wl['means0'])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pl.optimize(opt_iters=steps)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        t = sorted(ts)[2]
+        out[name] = {'value': steps / t, 'unit': 'iters/s', 'ms_per_step': 1e3 * t / steps, 'path': int(pl.run_path())}
+        assert not pl.persistent_timed_out()
+    geom = cost.cost_l[0].device_geometry(dev)
+    gi = geom.host.view('int32')
+    out['grid'] = {'version': int(gi[1]), 'cells': [int(gi[17]), int(gi[18]), int(gi[19])], 'candidate_bytes': int(4 * (gi[13] - gi[16] - (gi[26] + 1023) // 1024 * 1024))}
+    return out
+
+
 def run_stomp(planner, clock, dist, world, steps, warmup, repeats, preheat, cold=False):
     """W untimed steps, then R blocks of EXACTLY `steps` steps (one C-ABI call = 2K launches) + the final gather."""
     # the final gather's destination: one flat (world * P, H, d) tensor (all_gather_into_tensor: one RCCL kernel, no
@@ -1154,10 +1192,11 @@ def main():
         eps_parity = torch.randn(2, S, d, P, H, generator=torch.Generator().manual_seed(1234))
         par_gpu = stomp_parity_gpu(wl, planner, cost, geom, eps_parity)
         par_philox_gpu = stomp_parity_philox_gpu(wl, planner, cost, geom, n_it=max(2, min(args.steps, 20)))
-    seeded = generic = None
+    seeded = generic = crowded = None
     if rank == 0 and world == 1 and not args.main_only and not args.no_other_configs:
         seeded = bench_seeded(wl, cost, dev, rank, P, args.steps)
         generic = bench_generic_model(wl, dev, rank, P, S, args.steps)
+        crowded = bench_crowded(dev, rank, P, S, args.steps)
 
     # ---- BASELINE configs[4]'s per-GPU load with the same protocol (every N)
     c5 = None
@@ -1235,6 +1274,8 @@ def main():
             line['seeded'] = seeded
         if generic is not None:
             line['generic_model'] = generic
+        if crowded is not None:
+            line['crowded'] = crowded
         if c5 is not None:
             line['c5'] = c5
         if world == 1 and not args.no_cpu_baseline:

@@ -25,6 +25,12 @@
 
 #define MPB_GEOM_MAGIC 0x4D504247
 #define MPB_GEOM_VERSION 6
+#define MPB_GEOM_VERSION_LIST 7  // a field whose grid section is a LIST grid (round 6: scenes beyond the compact grid's 63 spheres; geometry.py build_list_grid)
+#define MPB_LIST_MAX_SPH 255     // the list evaluators' sphere table (LDS): 255 + the far dummy
+#define MPB_LIST_MAX_BOX 127     // ... and box table: 127 + the far dummy
+#define MPB_LIST_MAX_CAND 16384  // bytes of candidate indices (LDS)
+#define MPB_LIST_CELL_MAX_SPH 126
+#define MPB_LIST_CELL_MAX_BOX 62
 #define MPB_MAX_FIELDS 4   // collision fields chained in one buffer (header word 27 = words to the next one)
 #define MPB_GEOM_HEADER_WORDS 32
 #define MPB_GRID_MAX_CELLS 4096
@@ -63,6 +69,9 @@ struct GeomView {
     int k_lin;                           // linear index of the lattice point the grid starts at: cell = round(x / h) - K per axis
     float fscale;                        // s_f: this field's share in  sum_f s_f * cost_f
     int next;                            // words from this header to the next chained field (0: last)
+    int version;                         // MPB_GEOM_VERSION (compact grid) or MPB_GEOM_VERSION_LIST
+    const unsigned char* cand;           // (list grid) candidate indices, behind the padded cell words
+    int n_cand;                          // ... bytes of them
     int model;                           // compile-time robot model the tables equal bit for bit (0: none), mpb_model_*.h
     unsigned keep_mask;                  // bit l: the model's collision sphere l is in the link table (static pruning)
 };
@@ -94,6 +103,12 @@ __device__ __forceinline__ GeomView geom_view(const float* __restrict__ g) {
     v.glx = g[20]; v.gly = g[21]; v.glz = g[22];
     v.gix = g[23]; v.giy = g[24]; v.giz = g[25];
     v.n_cells = gi[26];
+    v.version = gi[1];
+    {
+        const int off_cand = gi[16] + (gi[26] + MPB_GRID_PAD - 1) / MPB_GRID_PAD * MPB_GRID_PAD;
+        v.cand = reinterpret_cast<const unsigned char*>(g + off_cand);
+        v.n_cand = 4 * (gi[13] - off_cand);
+    }
     v.k_lin = gi[31];
     v.fscale = g[28];
     v.next = gi[27];
@@ -530,7 +545,7 @@ __device__ __forceinline__ float waypoint_cost_chain(const float* __restrict__ g
 #define MPB_COST_PRIO(r) ((r) < 3 ? (r) : 3)
 #endif
 __device__ __forceinline__ bool grid_usable(const GeomView& G) {
-    return G.n_cells > 0 && G.n_cells <= MPB_GRID_MAX_CELLS && G.n_sph <= MPB_GRID_MAX_SPH;
+    return G.version == MPB_GEOM_VERSION && G.n_cells > 0 && G.n_cells <= MPB_GRID_MAX_CELLS && G.n_sph <= MPB_GRID_MAX_SPH;
 }
 
 // clamped cell of a point, all in fp32: 3 fma + 3 floor + 3 med3 + 2 fma + 1 cvt (the integer formulation needs
@@ -796,13 +811,122 @@ __device__ __forceinline__ void spheres_hinge_grid(const GeomView& G, const unsi
     }
 }
 
-template <bool OFFS = false>
+// ------------------------------------------------------------------------------------------------
+// LIST grid (geometry version 7, round 6): scenes beyond the compact grid's 63 spheres / its three candidates per cell, boxes
+// culled like spheres.  A cell word names a RANGE of a byte array of candidate indices -- bits 0-14 start, 15-21 sphere count, 22-27
+// box count (the boxes follow the spheres), bit 31: the cell overflows a count field -- and the evaluator walks the longest range
+// among the wave's lanes, a lane whose range has ended reading the far dummy at the end of the table (no index clamp, no
+// branch).  Everything it reads sits in LDS (list_stage): cell words, candidate bytes, the sphere table (up to 255 + dummy) and the
+// box table (up to 127 + dummy).  The candidate sets are conservative (host, fp64), the distance expressions are the exhaustive
+// evaluator's and min is exact: the hinges are the bits of the exhaustive path's.
+// ------------------------------------------------------------------------------------------------
+struct ListView {
+    const unsigned* cellw;          // n_cells words
+    const unsigned char* cand;      // candidate bytes
+    const float4* stab;             // n_sph + 1 spheres (the last one the far dummy)
+    const float4* btab;             // 2 (n_box + 1) float4: centre, half extents (the last box the far dummy)
+};
+__device__ __forceinline__ bool list_usable(const GeomView& G) {
+    return G.version == MPB_GEOM_VERSION_LIST && G.n_cells > 0 && G.n_cells <= MPB_GRID_MAX_CELLS && G.n_sph <= MPB_LIST_MAX_SPH &&
+           G.n_box <= MPB_LIST_MAX_BOX && G.n_cand <= MPB_LIST_MAX_CAND + 16;
+}
+// cooperative staging by `nthreads` threads (caller synchronises before and after); cand_l: MPB_LIST_MAX_CAND + 16 bytes
+__device__ __forceinline__ void list_stage(const GeomView& G, unsigned* cellw_l, unsigned char* cand_l, float4* stab_l, float4* btab_l,
+                                           int tid, int nthreads) {
+    for (int i = tid; i < G.n_cells; i += nthreads) cellw_l[i] = G.grid[i];
+    const uint4* c4 = reinterpret_cast<const uint4*>(G.cand);
+    for (int i = tid; i < (G.n_cand >> 4); i += nthreads) reinterpret_cast<uint4*>(cand_l)[i] = c4[i];
+    const float4* sp = reinterpret_cast<const float4*>(G.sph);
+    for (int i = tid; i <= G.n_sph; i += nthreads) stab_l[i] = (i < G.n_sph) ? sp[i] : make_float4(-1.0e9f, -1.0e9f, -1.0e9f, 0.f);
+    const float4* bp = reinterpret_cast<const float4*>(G.box);
+    for (int i = tid; i < 2 * (G.n_box + 1); i += nthreads)
+        btab_l[i] = (i < 2 * G.n_box) ? bp[i] : ((i & 1) ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(-1.0e9f, -1.0e9f, -1.0e9f, 0.f));
+}
+
+template <int N, bool UNIT = false, bool RLM = false>
+__device__ __forceinline__ void spheres_hinge_list(const GeomView& G, const ListView& L, const float (&x)[N], const float (&y)[N],
+                                                   const float (&z)[N], const float (&rl)[N], float& cost, const GridAddr& GA) {
+    unsigned w[N];
+    float best[N];
+    unsigned comb = 0u;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        w[i] = *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(L.cellw) + grid_cell_rel(GA, x[i], y[i], z[i]));
+        best[i] = 3.0e38f;
+        comb |= w[i];
+    }
+    auto sphere = [&](int i, const float4 s) {
+        const float dx = x[i] - s.x, dy = y[i] - s.y, dz = z[i] - s.z;
+        best[i] = fminf(best[i], fast_sqrt(dx * dx + dy * dy + dz * dz) - s.w);
+    };
+    auto box = [&](int i, const float4 c, const float4 h) {
+        const float px = x[i] - c.x, py = y[i] - c.y, pz = z[i] - c.z;
+        const float ax = fabsf(px) - h.x, ay = fabsf(py) - h.y, az = fabsf(pz) - h.z;
+        const float qx = fmaxf(ax, 0.f), qy = fmaxf(ay, 0.f), qz = fmaxf(az, 0.f);
+        const float sd = fast_sqrt(qx * qx + qy * qy + qz * qz) + fminf(fmaxf(ax, fmaxf(ay, az)), 0.f);
+        best[i] = fminf(best[i], sd);
+    };
+    if (__builtin_expect(__ballot((int)comb < 0) != 0ull, 0)) {
+        // some lane sits in a cell that overflows a count field: every obstacle for this group (rare)
+        for (int o = 0; o < G.n_sph; ++o) {
+            const float4 s = L.stab[o];
+#pragma unroll
+            for (int i = 0; i < N; ++i) sphere(i, s);
+        }
+        for (int o = 0; o < G.n_box; ++o) {
+            const float4 c = L.btab[2 * o], h = L.btab[2 * o + 1];
+#pragma unroll
+            for (int i = 0; i < N; ++i) box(i, c, h);
+        }
+    } else {
+        unsigned st[N], ns[N], nb[N];
+        unsigned mns = 0u, mnb = 0u;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            st[i] = w[i] & 0x7FFFu; ns[i] = (w[i] >> 15) & 0x7Fu; nb[i] = (w[i] >> 22) & 0x3Fu;
+            mns = max(mns, ns[i]); mnb = max(mnb, nb[i]);
+        }
+        // as many trips as the longest sphere / box range among the wave's ACTIVE lanes (a ballot per trip: the callers run this
+        // under a lane mask -- waypoint 0, lanes past the horizon --, which rules the DPP reductions out)
+        const unsigned none_s = (unsigned)G.n_sph, none_b = (unsigned)G.n_box;
+        for (unsigned k = 0; __ballot(k < mns) != 0ull; ++k) {
+            float4 s[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const unsigned idx = (k < ns[i]) ? (unsigned)L.cand[st[i] + k] : none_s;
+                s[i] = L.stab[idx];
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i) sphere(i, s[i]);
+        }
+        for (unsigned k = 0; __ballot(k < mnb) != 0ull; ++k) {
+            float4 c[N], h[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const unsigned idx = (k < nb[i]) ? (unsigned)L.cand[st[i] + ns[i] + k] : none_b;
+                c[i] = L.btab[2 * idx];
+                h[i] = L.btab[2 * idx + 1];
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i) box(i, c[i], h[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {                                                 // parked slots: best = 1e9 -> +0
+        const float hinge = (RLM ? rl[i] : G.margin + rl[i]) - best[i];
+        cost += UNIT ? fminf(fmaxf(hinge, 0.f), 1.f) : fmaxf(hinge, 0.f);
+    }
+}
+
+// LIST: the field carries a list grid (version 7) staged in LDS as *LV; gridw / otab are not read
+template <bool OFFS = false, bool LIST = false>
 __device__ __forceinline__ float waypoint_cost_grid(const GeomView& G, const unsigned* gridw, const float4* otab,
-                                                    const float (&q)[MPB_MAX_DOF]) {
+                                                    const float (&q)[MPB_MAX_DOF], const ListView* LV = nullptr) {
     if (G.kind == MPB_KIND_POINT) {
         const float x[1] = {q[0]}, y[1] = {q[1]}, z[1] = {(G.n_dof > 2) ? q[2] : 0.f}, rl[1] = {G.links[4]};
         float c = 0.f;
-        spheres_hinge_grid<1, OFFS>(G, gridw, otab, x, y, z, rl, c, OFFS ? grid_addr(G) : GridAddr{});
+        if constexpr (LIST) spheres_hinge_list<1>(G, *LV, x, y, z, rl, c, grid_addr(G));
+        else spheres_hinge_grid<1, OFFS>(G, gridw, otab, x, y, z, rl, c, OFFS ? grid_addr(G) : GridAddr{});
         return c;
     }
 #ifndef MPB_GRID_N
@@ -815,7 +939,7 @@ __device__ __forceinline__ float waypoint_cost_grid(const GeomView& G, const uns
     F.tx = F.ty = F.tz = 0.f;
     F.frame = 0;
     float cost = 0.f;
-    const GridAddr GA = OFFS ? grid_addr(G) : GridAddr{};
+    const GridAddr GA = (OFFS || LIST) ? grid_addr(G) : GridAddr{};
     for (int l0 = 0; l0 < G.n_links; l0 += N) {
         const int nl = min(N, G.n_links - l0);
 #ifndef MPB_NO_COST_PRIO
@@ -851,7 +975,8 @@ __device__ __forceinline__ float waypoint_cost_grid(const GeomView& G, const uns
                 x[i] = y[i] = z[i] = FAR;
             }
         }
-        spheres_hinge_grid<N, OFFS>(G, gridw, otab, x, y, z, rl, cost, GA);
+        if constexpr (LIST) spheres_hinge_list<N>(G, *LV, x, y, z, rl, cost, GA);
+        else spheres_hinge_grid<N, OFFS>(G, gridw, otab, x, y, z, rl, cost, GA);
     }
 #ifndef MPB_NO_COST_PRIO
     __builtin_amdgcn_s_setprio(0);
@@ -958,16 +1083,16 @@ __device__ __forceinline__ bool model_group_dispatch(int grp, ModelFK& F, const 
     return run;
 }
 
-template <class M, bool OFFS = false>
+template <class M, bool OFFS = false, bool LIST = false>
 __device__ __forceinline__ float waypoint_cost_grid_model(const GeomView& G, const unsigned* gridw, const float4* otab,
-                                                          const float (&q)[MPB_MAX_DOF]) {
+                                                          const float (&q)[MPB_MAX_DOF], const ListView* LV = nullptr) {
     constexpr int NG = (M::N_FRAME1 + 3) / 4 + (M::N_LINKS - M::N_FRAME1 + 3) / 4;
     ModelFK F;
     F.r00 = 1.f; F.r01 = 0.f; F.r02 = 0.f; F.r10 = 0.f; F.r11 = 1.f; F.r12 = 0.f; F.r20 = 0.f; F.r21 = 0.f; F.r22 = 1.f;
     F.tx = F.ty = F.tz = 0.f;
     float cost = 0.f;
     const unsigned keep = G.keep_mask;
-    const GridAddr GA = OFFS ? grid_addr(G) : GridAddr{};
+    const GridAddr GA = (OFFS || LIST) ? grid_addr(G) : GridAddr{};
     float mrg = G.margin;                    // in a VECTOR register: v_add takes the literal radius plus one register
     asm volatile("" : "+v"(mrg));
     // a real loop over the groups with ONE instance of the grid look-up (unrolling it per group is 60 KB of code)
@@ -975,7 +1100,11 @@ __device__ __forceinline__ float waypoint_cost_grid_model(const GeomView& G, con
     for (int grp = 0; grp < NG; ++grp) {
         float x[4], y[4], z[4], rl[4];
         const bool run = model_group_dispatch<M>(grp, F, q, keep, x, y, z, rl, mrg, std::make_integer_sequence<int, NG>{});
-        if (run) spheres_hinge_grid<4, OFFS, true, true>(G, gridw, otab, x, y, z, rl, cost, GA);
+        if constexpr (LIST) {
+            if (run) spheres_hinge_list<4, true, true>(G, *LV, x, y, z, rl, cost, GA);
+        } else {
+            if (run) spheres_hinge_grid<4, OFFS, true, true>(G, gridw, otab, x, y, z, rl, cost, GA);
+        }
     }
 #ifndef MPB_NO_COST_PRIO
     __builtin_amdgcn_s_setprio(0);

@@ -94,7 +94,8 @@ static int model_check(const float* g, const char* who) {
 static int geom_check_one(const float* g, int n_words, const char* who) {
     if (!g || n_words < MPB_GEOM_HEADER_WORDS) return fail(MPB_E_INVALID, "%s: geometry buffer too small", who);
     const int32_t* gi = reinterpret_cast<const int32_t*>(g);
-    if (gi[0] != MPB_GEOM_MAGIC || gi[1] != MPB_GEOM_VERSION) return fail(MPB_E_INVALID, "%s: bad magic/version", who);
+    if (gi[0] != MPB_GEOM_MAGIC || (gi[1] != MPB_GEOM_VERSION && gi[1] != MPB_GEOM_VERSION_LIST)) return fail(MPB_E_INVALID, "%s: bad magic/version", who);
+    const bool list = gi[1] == MPB_GEOM_VERSION_LIST;       // version 7: the grid section is a list grid (mpb_geom.h, spheres_hinge_list)
     const int kind = gi[2], n_dof = gi[3], n_tf = gi[4], n_links = gi[5], n_sph = gi[6], n_box = gi[7];
     if (kind != MPB_KIND_POINT && kind != MPB_KIND_CHAIN) return fail(MPB_E_INVALID, "%s: unknown robot kind", who);
     if (n_dof < 1 || n_dof > MPB_MAX_DOF) return fail(MPB_E_INVALID, "%s: n_dof out of range", who);
@@ -109,8 +110,13 @@ static int geom_check_one(const float* g, int n_words, const char* who) {
     const int n_fs = (n_frames + 1 + 3) / 4 * 4;
     if (off_tf != MPB_GEOM_HEADER_WORDS || off_links != off_tf + 12 * n_tf || off_sph != off_links + 8 * n_links ||
         off_box != off_sph + 4 * n_sph || off_cull != off_box + 8 * n_box || off_fs != off_cull + 8 * n_sph_pad ||
-        off_grid != off_fs + n_fs || total != off_grid + (n_cells + MPB_GRID_PAD - 1) / MPB_GRID_PAD * MPB_GRID_PAD || total > n_words)
+        off_grid != off_fs + n_fs || total > n_words)
         return fail(MPB_E_INVALID, "%s: inconsistent section offsets", who);
+    const int off_cand = off_grid + (n_cells + MPB_GRID_PAD - 1) / MPB_GRID_PAD * MPB_GRID_PAD;
+    if (list ? (total < off_cand + 4 || ((total - off_cand) & 3)) : total != off_cand) return fail(MPB_E_INVALID, "%s: inconsistent section offsets", who);
+    if (list && (n_cells < 1 || n_cells > MPB_GRID_MAX_CELLS || n_sph > MPB_LIST_MAX_SPH || n_box > MPB_LIST_MAX_BOX ||
+                 4 * (total - off_cand) > MPB_LIST_MAX_CAND + 16))
+        return fail(MPB_E_INVALID, "%s: a list grid needs 1..4096 cells, <= 255 spheres, <= 127 boxes, <= 16 KB of candidates", who);
     if ((off_links | off_sph | off_box | off_cull | off_fs | off_grid) & 3) return fail(MPB_E_INVALID, "%s: sections must be 16-byte aligned", who);
     if (n_cells < 0 || (n_cells > 0 && (gnx < 1 || gny < 1 || gnz < 1 || gnx * gny * gnz != n_cells)))
         return fail(MPB_E_INVALID, "%s: bad broad-phase grid dims", who);
@@ -129,6 +135,21 @@ static int geom_check_one(const float* g, int n_words, const char* who) {
         if ((long)gi[31] != K[0] + (long)gnx * (K[1] + (long)gny * K[2])) return fail(MPB_E_INVALID, "%s: grid lattice index (word 31) does not match the origin", who);
         if (labs((long)gi[31]) + (long)n_cells >= (1L << 21)) return fail(MPB_E_INVALID, "%s: grid too far from the origin for the fp32 cell index", who);
     }
+    if (list) {   // every cell's candidate range must lie inside the candidate bytes and name existing obstacles
+        const unsigned char* cand = reinterpret_cast<const unsigned char*>(g + off_cand);
+        const int n_cand = 4 * (total - off_cand);
+        for (int i = 0; i < n_cells; ++i) {
+            const uint32_t w = (uint32_t)gi[off_grid + i];
+            if (w & 0x80000000u) continue;                    // overflowing cell: the kernels test every obstacle
+            const int start = (int)(w & 0x7FFFu), ns = (int)((w >> 15) & 0x7Fu), nb = (int)((w >> 22) & 0x3Fu);
+            if ((w & 0x70000000u) || ns > MPB_LIST_CELL_MAX_SPH || nb > MPB_LIST_CELL_MAX_BOX || start + ns + nb > n_cand)
+                return fail(MPB_E_INVALID, "%s: list-grid cell out of range", who);
+            for (int k = 0; k < ns; ++k)
+                if ((int)cand[start + k] >= n_sph) return fail(MPB_E_INVALID, "%s: grid cell references a missing obstacle", who);
+            for (int k = 0; k < nb; ++k)
+                if ((int)cand[start + ns + k] >= n_box) return fail(MPB_E_INVALID, "%s: grid cell references a missing obstacle", who);
+        }
+    } else
     for (int i = 0; i < n_cells; ++i) {   // every packed obstacle index must exist
         const uint32_t w = (uint32_t)gi[off_grid + i];
         if (w == 0xFFFFFFFEu) continue;
@@ -177,14 +198,16 @@ extern "C" int mpb_geom_flags(const float* g, int n_words, int* flags) {
     const int rc = mpb_geom_check(g, n_words);
     if (rc) return rc;
     int model = -1, max_cells = 0, n_fields = 0;
-    bool all_grids = true;
+    bool all_grids = true, all_lists = true;
     for (int off = 0;;) {
         const int32_t* gi = reinterpret_cast<const int32_t*>(g + off);
-        const bool grid_ok = gi[26] > 0 && gi[26] <= MPB_GRID_MAX_CELLS && gi[6] <= MPB_GRID_MAX_SPH;   // grid_usable()
+        const bool is_list = gi[1] == MPB_GEOM_VERSION_LIST;                                                // (checked above: usable as it stands)
+        const bool grid_ok = !is_list && gi[26] > 0 && gi[26] <= MPB_GRID_MAX_CELLS && gi[6] <= MPB_GRID_MAX_SPH;   // grid_usable()
         all_grids = all_grids && grid_ok;
+        all_lists = all_lists && is_list;
         if (gi[26] > max_cells) max_cells = gi[26];
         ++n_fields;
-        const int m = grid_ok ? gi[29] : 0;
+        const int m = (grid_ok || is_list) ? gi[29] : 0;
         model = (model < 0 || model == m) ? m : 0;
         if (gi[27] == 0) break;
         off += gi[27];
@@ -192,8 +215,8 @@ extern "C" int mpb_geom_flags(const float* g, int n_words, int* flags) {
     const int32_t* g0 = reinterpret_cast<const int32_t*>(g);
     const bool point_small = g0[2] == MPB_KIND_POINT && g0[27] == 0 && g0[6] <= 32 && g0[7] <= 8;
     *flags = (model > 0 ? (model & 0xFF) : 0) | (all_grids ? 0x100 : 0) | (point_small ? 0x200 : 0) |
-             (g0[2] == MPB_KIND_POINT ? 0x400 : 0) | (n_fields == 1 ? 0x1000 : 0) |
-             (all_grids ? (max_cells & 0x1FFF) << 16 : 0);
+             (g0[2] == MPB_KIND_POINT ? 0x400 : 0) | (n_fields == 1 ? 0x1000 : 0) | (all_lists ? 0x2000 : 0) |
+             ((all_grids || all_lists) ? (max_cells & 0x1FFF) << 16 : 0);
     return MPB_OK;
 }
 
@@ -972,7 +995,9 @@ static void launch_sample(const float* means, const float* eps, float* samples, 
                            dim3(64 * MPB_A_WPB), 0, st, means, eps, samples, costs, L, geom, P, S, k_sigma, weight, \
                            lo, hi, iter, particle_offset);                                                       \
         return;
-    if (H == 64 && WITH_COST && (geom_flags & 0xFF) == PandaModel::ID) {   // the Panda's channel counts (pos_only / not)
+    // (bit 8: every field COMPACT-grid-backed -- since round 6 the model byte is also set for list-grid scenes, which this kernel
+    // serves through the exhaustive walk)
+    if (H == 64 && WITH_COST && (geom_flags & 0xFF) == PandaModel::ID && (geom_flags & 0x100)) {   // the Panda's channel counts (pos_only / not)
         switch (d) {
             MPB_A_CASE(7, (WITH_COST ? PandaModel::ID : 0)) MPB_A_CASE(14, (WITH_COST ? PandaModel::ID : 0))
             default: break;

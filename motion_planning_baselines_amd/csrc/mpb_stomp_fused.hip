@@ -648,7 +648,12 @@ extern "C" size_t mpb_stomp_workspace_bytes(int P, int S, int H, int d) {
     // what the layout the launcher will pick needs (grid-backed fields assumed; a call the persistent kernel cannot
     // serve needs none): the exchange area only when partner workgroups exchange partials, else just the header
     const FusedPlan f = fused_plan(0x100, P, S, H, d);
-    return f.path == MPB_STOMP_PATH_TWO_KERNEL ? FUSED_HDR_WORDS * sizeof(float) : f.ws_bytes;
+    // (a scene packed with LIST grids -- geometry version 7, flag bit 13 -- goes to the generalised kernel even at H = 64, whose
+    // exchange slots are larger: the workspace serves whichever of the two the geometry will select)
+    const FusedPlan fl = fused_plan(0x2000, P, S, H, d);
+    size_t b = f.path == MPB_STOMP_PATH_TWO_KERNEL ? FUSED_HDR_WORDS * sizeof(float) : f.ws_bytes;
+    if (fl.path != MPB_STOMP_PATH_TWO_KERNEL && fl.ws_bytes > b) b = fl.ws_bytes;
+    return b;
 }
 
 extern "C" int mpb_stomp_workspace_init(float* workspace, size_t workspace_bytes, void* stream) {

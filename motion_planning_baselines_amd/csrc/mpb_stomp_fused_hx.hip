@@ -53,7 +53,10 @@ __device__ __forceinline__ void hx_transpose_to_rows(const f32x4 (&acc)[4], floa
 }
 
 // INJ = false: the instantiation of the device-noise calls does not carry the injected-noise path (as in mpb_stomp_fused.hip)
-template <int DCH, int MODEL, int HC, bool INJ>
+// LIST = true (round 6, H <= 64 only: the second horizon chunk leaves no LDS for it): the fields carry LIST grids (geometry version 7:
+// scenes beyond the compact grid's 63 spheres, boxes culled like spheres; mpb_geom.h, spheres_hinge_list) -- cell words, up to 16 KB of
+// candidate bytes, the sphere table (255) and the box table (127) in LDS, +24 KB.
+template <int DCH, int MODEL, int HC, bool INJ, bool LIST = false>
 __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
     float* __restrict__ means, const float* __restrict__ eps, float* __restrict__ samples, float* __restrict__ costs,
     float* __restrict__ weights, const float* __restrict__ Lmat, const float* __restrict__ Sigma,
@@ -70,6 +73,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
     constexpr int DLD = HP + 4;                        // row (floats) of the transposed delta tile
     constexpr int TILE = 64 * DX;                      // floats of a wave's tile: its chunk of one rollout, rows packed
     static_assert(HC == 1 || HC == 2, "horizons up to 128 support points");
+    static_assert(!LIST || HC == 1, "the list grid's tables only fit next to ONE horizon chunk");
     static_assert(HP * DX + 2 <= HX_XCHG, "exchange slot too small");
     // the 64 x 64 blocks of the lower triangle of L as three-component bf16 MFMA images (mpb_stomp_noise.h): block 0 = (0,0)
     // and block 2 = (1,1) are diagonal blocks (6 tiles, 18 KB), block 1 = (1,0) is full (8 tiles, 24 KB)
@@ -77,8 +81,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
     // (one shared object, layout fixed by hand: the obstacle table, the grid and the small arrays first -- inside the reach of an
     // LDS instruction's 16-bit offset field --, the L images and the sample tiles behind them; mpb_stomp_fused.hip)
     struct Smem {
-        float4 otab[MPB_GRID_MAX_SPH + 1];
+        float4 otab[(LIST ? MPB_LIST_MAX_SPH : MPB_GRID_MAX_SPH) + 1];
         unsigned gridw[MPB_GRID_MAX_CELLS];
+        float4 btab[LIST ? 2 * (MPB_LIST_MAX_BOX + 1) : 1];
+        unsigned char cand[LIST ? MPB_LIST_MAX_CAND + 16 : 16];
         unsigned Limg[LIMG_WORDS];
         float mean_l[HP * DX];
         float delta[16 * DLD];
@@ -93,8 +99,17 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
     };
     static_assert((HX_MAX_NB * FUSED_WAVES + HX_MAX_NB) % 4 == 0, "Limg must stay 16-byte aligned");
     __shared__ __attribute__((aligned(16))) Smem sm;
-    float4 (&otab)[MPB_GRID_MAX_SPH + 1] = sm.otab;
+    float4 (&otab)[(LIST ? MPB_LIST_MAX_SPH : MPB_GRID_MAX_SPH) + 1] = sm.otab;
     unsigned (&gridw)[MPB_GRID_MAX_CELLS] = sm.gridw;
+    const ListView LV = {sm.gridw, sm.cand, sm.otab, sm.btab};
+    // (a field's grid into LDS: offset words of the compact grid, or the list grid's four tables)
+    auto stage_field = [&](const GeomView& Gf, int t_) {
+        if constexpr (LIST) {
+            if (list_usable(Gf)) list_stage(Gf, sm.gridw, sm.cand, sm.otab, sm.btab, t_, FUSED_THREADS);
+        } else {
+            grid_stage_offsets(Gf, gridw, otab, t_, FUSED_THREADS);
+        }
+    };
     float (&mean_l)[HP * DX] = sm.mean_l;
     float (&delta)[16 * DLD] = sm.delta;
     float (&sig_l)[HC == 1 ? 64 * DLD : 4] = sm.sig_l;
@@ -141,7 +156,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
 
     // ---- constants into LDS (once): the broad-phase grid + obstacle table, the blocks of L as permuted MFMA images
     GeomView G0 = geom_view(geom);
-    grid_stage_offsets(G0, gridw, otab, tid, FUSED_THREADS);      // (as offset words: mpb_geom.h, grid_offset_word)
+    stage_field(G0, tid);                                         // (compact grid: as offset words, mpb_geom.h grid_offset_word)
 #pragma unroll
     for (int b = 0; b < NLB; ++b) {
         const int hc = (b == 0) ? 0 : 1, kc = (b == 2) ? 1 : 0;
@@ -333,17 +348,20 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
                 for (const float* gp = geom;;) {
                     if (gp != geom) {     // a chained field: its grid replaces the first one's (restored before the next pass)
                         __syncthreads();
-                        grid_stage_offsets(G, gridw, otab, tid, FUSED_THREADS);
+                        stage_field(G, tid);
                         __syncthreads();
                     }
-                    if (live && on && h >= 1) {
+                    // (the launcher picked LIST from geom_flags; a device header of the other format poisons the cost instead of
+                    // being mis-read)
+                    const bool fmt_ok = LIST ? list_usable(G) : (G.version == MPB_GEOM_VERSION);
+                    if (live && on && h >= 1 && fmt_ok) {
                         if (MODEL == PandaModel::ID) {
-                            if (G.model == PandaModel::ID) c = fmaf(G.fscale, waypoint_cost_grid_model<PandaModel, true>(G, gridw, otab, q), c);
+                            if (G.model == PandaModel::ID) c = fmaf(G.fscale, waypoint_cost_grid_model<PandaModel, true, LIST>(G, gridw, otab, q, &LV), c);
                         } else {
-                            c = fmaf(G.fscale, waypoint_cost_grid<true>(G, gridw, otab, q), c);
+                            c = fmaf(G.fscale, waypoint_cost_grid<true, LIST>(G, gridw, otab, q, &LV), c);
                         }
                     }
-                    if (MODEL != 0 && G.model != MODEL) bad = true;    // (wave-uniform: lane 0 -- possibly waypoint 0, outside the walk -- writes the cost)
+                    if (!fmt_ok || (MODEL != 0 && G.model != MODEL)) bad = true;    // (wave-uniform: lane 0 -- possibly waypoint 0, outside the walk -- writes the cost)
                     if (G.next == 0) break;
                     gp += G.next;
                     G = geom_view(gp);
@@ -352,7 +370,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
                     __syncthreads();
                     int tid_o = tid;                         // (opaque: this rare path's source addresses must not be hoisted)
                     asm volatile("" : "+v"(tid_o));
-                    grid_stage_offsets(G0, gridw, otab, tid_o, FUSED_THREADS);
+                    stage_field(G0, tid_o);
                 }
                 const double csum = wave_sum_f64((double)c);
                 if (lane == 0) cst[wave] = bad ? __uint_as_float(0x7FC00000u) : (float)csum;
@@ -554,7 +572,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
 // ------------------------------------------------------------------------------------------------
 // can this kernel serve the shape, and with which split of the S samples over workgroups (nc) and passes (nb)?
 bool mpb_fused_hx_plan(int geom_flags, int n_cu, int P, int S, int H, int d, int* nc_out, int* nb_out, size_t* ws_bytes) {
-    if (P < 1 || S < 1 || S > 128 || H < 3 || H > 128 || d < 1 || d > 16 || !(geom_flags & 0x100)) return false;
+    // every field grid-backed: compact grids (flag bit 8) at any horizon, list grids (bit 13, round 6) up to 64 support points
+    if (P < 1 || S < 1 || S > 128 || H < 3 || H > 128 || d < 1 || d > 16) return false;
+    if (!(geom_flags & 0x100) && !((geom_flags & 0x2000) && H <= 64)) return false;
     const int HC = H > 64 ? 2 : 1, RB = FUSED_WAVES / HC;
     const int passes = (S + RB - 1) / RB;                 // passes of RB rollouts a particle needs per iteration
     // few particles: as many workgroups per particle as fit the chip in one round (and the exchange allows); many
@@ -582,16 +602,25 @@ int mpb_fused_hx_launch(float* means, const float* eps, float* samples, float* c
                         float* means_copy, hipStream_t st, const FusedProfile* prof) {
     const dim3 grid(P * nc), block(FUSED_THREADS);
     const int model = geom_flags & 0xFF;
-#define MPB_HX_LAUNCH_(DCH, MODEL, HC, INJ)                                                                                        \
-    MPB_FUSED_LAUNCH(prof, (stomp_fused_hx_kernel<DCH, MODEL, HC, INJ>), grid, block, st, means, eps, samples, costs, weights, L,  \
+#define MPB_HX_LAUNCH_(DCH, MODEL, HC, INJ, LIST)                                                                                        \
+    MPB_FUSED_LAUNCH(prof, (stomp_fused_hx_kernel<DCH, MODEL, HC, INJ, LIST>), grid, block, st, means, eps, samples, costs, weights, L,  \
                      Sigma, geom, workspace, P, S, H, d, nc, nb, k_sigma, weight, lr, temperature, n_iters, lo, hi, iter0,         \
                      particle_offset, tag0, timeout, status_dev, means_copy)
-#define MPB_HX_LAUNCH(DCH, MODEL, HC)                       \
-    do {                                                    \
-        if (eps) MPB_HX_LAUNCH_(DCH, MODEL, HC, true);      \
-        else MPB_HX_LAUNCH_(DCH, MODEL, HC, false);         \
+#define MPB_HX_LAUNCH(DCH, MODEL, HC)                              \
+    do {                                                           \
+        if (eps) MPB_HX_LAUNCH_(DCH, MODEL, HC, true, false);      \
+        else MPB_HX_LAUNCH_(DCH, MODEL, HC, false, false);         \
     } while (0)
-    if (H > 64) {
+#define MPB_HX_LAUNCH_LIST(DCH, MODEL)                             \
+    do {                                                           \
+        if (eps) MPB_HX_LAUNCH_(DCH, MODEL, 1, true, true);        \
+        else MPB_HX_LAUNCH_(DCH, MODEL, 1, false, true);           \
+    } while (0)
+    if (!(geom_flags & 0x100)) {              // list grids (mpb_fused_hx_plan admitted them: H <= 64)
+        if (model == PandaModel::ID && d == 7) MPB_HX_LAUNCH_LIST(7, PandaModel::ID);
+        else if (model == PandaModel::ID && d == 14) MPB_HX_LAUNCH_LIST(14, PandaModel::ID);
+        else MPB_HX_LAUNCH_LIST(0, 0);
+    } else if (H > 64) {
         if (model == PandaModel::ID && d == 7) MPB_HX_LAUNCH(7, PandaModel::ID, 2);
         else if (model == PandaModel::ID && d == 14) MPB_HX_LAUNCH(14, PandaModel::ID, 2);
         else MPB_HX_LAUNCH(0, 0, 2);
@@ -601,6 +630,7 @@ int mpb_fused_hx_launch(float* means, const float* eps, float* samples, float* c
         else MPB_HX_LAUNCH(0, 0, 1);
     }
 #undef MPB_HX_LAUNCH
+#undef MPB_HX_LAUNCH_LIST
 #undef MPB_HX_LAUNCH_
     return mpb_check_launch("mpb_stomp_run");
 }

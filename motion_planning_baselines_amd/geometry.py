@@ -37,6 +37,16 @@ GRID_CELL_MIN = 0.05
 GRID_REFINE = 0.97
 GRID_PAD = 1024         # the grid section is padded to a multiple of this many words (one round of a 256-thread block's uint4 loads)
 GRID_OVERFLOW = 0xFFFFFFFE  # more than 4 candidates in the cell: the kernel tests every obstacle
+# geometry version 7 (round 6): fields whose obstacle set does not fit the compact grid (more than 63 spheres) carry a LIST grid --
+# a cell word holds (start, sphere count, box count) into a byte array of candidate indices that follows the cell words: any number of
+# candidates per cell, boxes culled like spheres (csrc/mpb_geom.h, spheres_hinge_list).  Limits = what the persistent kernel keeps in LDS
+GEOM_VERSION_LIST = 7
+LIST_MAX_SPH = 255        # 8-bit candidate indices; the kernels' sphere table holds 255 + the far dummy
+LIST_MAX_BOX = 127
+LIST_MAX_CAND = 16384     # bytes of candidate indices
+LIST_CELL_MAX_SPH = 126   # per cell (7-bit field; 127 marks an overflowing cell: exhaustive loop)
+LIST_CELL_MAX_BOX = 62    # per cell (6-bit field; 63 marks overflow)
+LIST_OVERFLOW = 0x80000000
 KIND_POINT = 0
 KIND_CHAIN = 1
 MAX_DOF = 8
@@ -230,6 +240,101 @@ class CollisionField:
         pass
 
 
+def _fit_axis(a, b, edge):
+    """(n, 1/h as fp32, K): fewest cells of a lattice-aligned edge <= `edge` that cover [a, b] (cells on a lattice through the world
+    origin: cell ix of an axis is [(K + ix - 1/2) h, (K + ix + 1/2) h), geometry version 6)"""
+    n = max(int(np.ceil((b - a) / edge)), 1)
+    while n <= GRID_MAX_DIM:
+        h = (b - a) / n
+        while h <= edge * (1.0 + 1e-9):
+            inv32 = np.float32(1.0 / h)
+            he = 1.0 / float(inv32)                      # the edge the kernels effectively use
+            K = int(np.floor(a / he + 0.5))              # (K - 1/2) he <= a
+            if (K - 0.5 + n) * he >= b:
+                return n, inv32, K
+            h *= 1.0 + 2e-4
+        n += 1
+    return None
+
+
+def build_list_grid(spheres, boxes, a_max, slack=1e-4, planar=False):
+    """Broad-phase LIST grid (geometry version 7) over the inflated obstacle spheres AND boxes, for scenes beyond the compact grid's 63
+    spheres: per cell the indices of every sphere / box a collision sphere of radius <= a_max - margin centred in the cell could be
+    within its hinge threshold of (conservative, fp64).  Cell words: bits 0-14 start into the candidate bytes, 15-21 sphere count,
+    22-27 box count (boxes follow the spheres), bit 31 = the cell overflows a count field (the kernels then test every obstacle).
+    The finest lattice cell (from GRID_CELL_MIN up) whose grid fits GRID_MAX_CELLS words and LIST_MAX_CAND candidate bytes.
+    None when the scene does not fit the kernels' tables (LIST_MAX_SPH / LIST_MAX_BOX) or no cell size fits."""
+    ns, nb = len(spheres), len(boxes)
+    if ns + nb == 0 or ns > LIST_MAX_SPH or nb > LIST_MAX_BOX:
+        return None
+    c = spheres[:, :3].astype(np.float64).reshape(-1, 3)
+    R = spheres[:, 3].astype(np.float64).reshape(-1) + a_max + slack
+    bc = boxes[:, 0:3].astype(np.float64).reshape(-1, 3)
+    bh = boxes[:, 3:6].astype(np.float64).reshape(-1, 3)
+    los = [c - R[:, None]] if ns else []
+    his = [c + R[:, None]] if ns else []
+    if nb:
+        los.append(bc - bh - (a_max + slack))
+        his.append(bc + bh + (a_max + slack))
+    lo, hi = np.concatenate(los).min(0), np.concatenate(his).max(0)
+    if planar:                                             # 2-D robots query z = 0 only: one layer of cells (2-D boxes are "infinite" in z)
+        lo[2], hi[2] = -0.5 * GRID_CELL, 0.5 * GRID_CELL
+    if np.any(hi - lo > 1.0e5):
+        return None
+    pad = 1e-5 + 1e-6 * float(np.abs(np.concatenate([lo, hi])).max())     # the kernels take the cell from fp32 arithmetic on x
+    edge = GRID_CELL_MIN
+    while edge < 4.0:
+        fits = [(1, np.float32(1.0 / GRID_CELL), 0) if (planar and ax == 2) else _fit_axis(float(lo[ax]), float(hi[ax]), edge) for ax in range(3)]
+        if all(f is not None for f in fits) and int(np.prod([f[0] for f in fits])) <= GRID_MAX_CELLS:
+            dims = np.array([f[0] for f in fits], dtype=np.int64)
+            inv32 = np.array([f[1] for f in fits], dtype=np.float32)
+            K = np.array([f[2] for f in fits], dtype=np.int64)
+            cell_eff = 1.0 / inv32.astype(np.float64)
+            if not (np.abs(K).max() + dims.max() >= (1 << 16) or abs(int(K[0] + dims[0] * (K[1] + dims[1] * K[2]))) + int(dims.prod()) >= (1 << 21)):
+                lo_s = (K - 0.5) * cell_eff
+                ix = [np.arange(d) for d in dims]
+                X, Y, Z = np.meshgrid(ix[0], ix[1], ix[2], indexing='ij')
+                cmin = lo_s + np.stack([X, Y, Z], -1) * cell_eff          # (nx, ny, nz, 3)
+                cmax = cmin + cell_eff
+                hit_s = np.zeros((*dims, ns), dtype=bool)
+                for o in range(ns):
+                    d = np.maximum(np.maximum(cmin - c[o], c[o] - cmax), 0.0)
+                    hit_s[..., o] = (d * d).sum(-1) < (R[o] + pad) ** 2
+                hit_b = np.zeros((*dims, nb), dtype=bool)
+                for o in range(nb):                                           # distance between the cell and the box, both axis aligned
+                    d = np.maximum(np.maximum(cmin - (bc[o] + bh[o]), (bc[o] - bh[o]) - cmax), 0.0)
+                    hit_b[..., o] = (d * d).sum(-1) < (a_max + slack + pad) ** 2
+                cs, cb = hit_s.sum(-1), hit_b.sum(-1)
+                over = (cs > LIST_CELL_MAX_SPH) | (cb > LIST_CELL_MAX_BOX)
+                total = int((cs + cb)[~over].sum())
+                if total <= LIST_MAX_CAND and total < (1 << 15):
+                    # cell words in x-fastest order, candidates in ascending index order (spheres, then boxes)
+                    order = (2, 1, 0)
+                    ncl = int(dims.prod())
+                    hs = np.ascontiguousarray(hit_s.transpose(*order, 3)).reshape(ncl, ns)
+                    hbx = np.ascontiguousarray(hit_b.transpose(*order, 3)).reshape(ncl, nb)
+                    ov = np.ascontiguousarray(over.transpose(*order)).reshape(-1)
+                    words = np.zeros(hs.shape[0], dtype=np.uint32)
+                    cand = []
+                    pos = 0
+                    for i in range(hs.shape[0]):
+                        if ov[i]:
+                            words[i] = LIST_OVERFLOW
+                            continue
+                        si, bi = np.nonzero(hs[i])[0], np.nonzero(hbx[i])[0]
+                        words[i] = pos | (len(si) << 15) | (len(bi) << 22)
+                        cand.extend(si.tolist())
+                        cand.extend(bi.tolist())
+                        pos += len(si) + len(bi)
+                    cand = np.asarray(cand + [0] * ((-len(cand)) % 16 or (16 if not cand else 0)), dtype=np.uint8)
+                    k_lin = int(K[0] + dims[0] * (K[1] + dims[1] * K[2]))
+                    return dict(dims=dims.astype(np.int32), lo=lo_s.astype(np.float32), inv=inv32, words=words, cand=cand, k_lin=k_lin, K=K,
+                                stats=dict(cell=float(cell_eff.max()), mean_sph=float(cs.mean()), max_sph=int(cs.max()), mean_box=float(cb.mean()),
+                                           max_box=int(cb.max()), overflow=int(over.sum()), cand_bytes=total))
+        edge /= GRID_REFINE
+    return None
+
+
 def build_grid(spheres, a_max, slack=1e-4, planar=False):
     """Uniform broad-phase grid over the inflated obstacle spheres (host, fp64).  None when there are no
     spheres or more than 254 of them (8-bit indices)."""
@@ -370,7 +475,13 @@ def hinge_bound(rs, fs):
     return float(fs['margin']) + float(np.max(rs['link_radius'])) + deepest
 
 
-def pack_geometry(robot, field, scales=None, prune_static=True, use_model=True):
+def field_needs_list_grid(field):
+    """The compact broad-phase grid (geometry version 6) serves up to 63 obstacle spheres (csrc/mpb_geom.h MPB_GRID_MAX_SPH); beyond
+    that a field takes the list grid of version 7 where it fits."""
+    return len(field.spec()['spheres']) > 63
+
+
+def pack_geometry(robot, field, scales=None, prune_static=True, use_model=True, list_grid=None):
     """Pack robot + collision field(s) into the flat fp32 word buffer the HIP kernels read.
 
     use_model: tag the buffer with the compile-time robot model its tables equal (model_gen.py), which lets the
@@ -391,6 +502,8 @@ def pack_geometry(robot, field, scales=None, prune_static=True, use_model=True):
       [12] off_boxes [13] total_words [14] off_cull [15] off_frame_start
       [16] off_grid [17..19] grid dims nx,ny,nz [20..22] grid origin (f32) [23..25] 1/cell size (f32)
       [26] n_cells (0: no grid) [27] words to the next chained field (0: none) [28] field scale s_f (f32)
+      (version 7: the grid section is a LIST grid -- build_list_grid -- and n_cand_words = total_words - off_grid - pad1024(n_cells) words of
+      candidate bytes follow the padded cell words)
       [29] compile-time robot model id (model_gen.py; 0: none -- set only when the robot's tables equal the model's
       bit for bit) [30] keep mask over the MODEL's collision spheres (bit l: sphere l is in the link table) [31] reserved
       joint_tf    : n_frames_tf x 12   (row-major 3x4)
@@ -413,7 +526,9 @@ def pack_geometry(robot, field, scales=None, prune_static=True, use_model=True):
         assert 1 <= len(fields) <= MAX_FIELDS, f'1..{MAX_FIELDS} collision fields per geometry buffer'
         scales = [1.0] * len(fields) if scales is None else [float(v) for v in scales]
         assert len(scales) == len(fields)
-        parts = [pack_geometry(robot, f, scales=[sc], prune_static=prune_static, use_model=use_model)
+        # (the persistent kernel stages ONE grid format per launch: when any field needs the list grid, all of them take it)
+        want_list = any(field_needs_list_grid(f) for f in fields) if list_grid is None else bool(list_grid)
+        parts = [pack_geometry(robot, f, scales=[sc], prune_static=prune_static, use_model=use_model, list_grid=want_list)
                  for f, sc in zip(fields, scales)]
         for i, part in enumerate(parts[:-1]):
             part.view(np.int32)[27] = part.size
@@ -450,13 +565,23 @@ def pack_geometry(robot, field, scales=None, prune_static=True, use_model=True):
     off_cull = off_box + 8 * n_box
     off_fs = off_cull + 8 * n_sph_pad
     off_grid = off_fs + n_fs
-    grid = build_grid(fs['spheres'], float(fs['margin']) + float(np.max(rs['link_radius'])),
-                      planar=(rs['kind'] == KIND_POINT and rs['n_dof'] == 2 and (len(fs['spheres']) == 0 or bool(np.all(np.asarray(fs['spheres'])[:, 2] == 0.0)))))
+    planar = (rs['kind'] == KIND_POINT and rs['n_dof'] == 2 and (len(fs['spheres']) == 0 or bool(np.all(np.asarray(fs['spheres'])[:, 2] == 0.0))))
+    a_max_g = float(fs['margin']) + float(np.max(rs['link_radius']))
+    want_list = field_needs_list_grid(field) if list_grid is None else bool(list_grid)
+    grid, version = None, GEOM_VERSION
+    if want_list:
+        grid = build_list_grid(np.asarray(fs['spheres']).reshape(-1, 4), np.asarray(fs['boxes']).reshape(-1, 6), a_max_g, planar=planar)
+        if grid is not None:
+            version = GEOM_VERSION_LIST
+    if grid is None:
+        grid = build_grid(fs['spheres'], a_max_g, planar=planar)
     n_cells = 0 if grid is None else int(grid['words'].size)
-    total = off_grid + (n_cells + GRID_PAD - 1) // GRID_PAD * GRID_PAD   # staged by the kernels in whole 16-byte rounds
+    n_cand_words = int(grid['cand'].size) // 4 if version == GEOM_VERSION_LIST else 0
+    off_cand = off_grid + (n_cells + GRID_PAD - 1) // GRID_PAD * GRID_PAD   # the cell words are staged by the kernels in whole 16-byte rounds
+    total = off_cand + n_cand_words
     buf = np.zeros((total,), dtype=np.float32)
     ibuf = buf.view(np.int32)
-    ibuf[0:8] = [GEOM_MAGIC, GEOM_VERSION, rs['kind'], rs['n_dof'], n_tf, n_links, n_sph, n_box]
+    ibuf[0:8] = [GEOM_MAGIC, version, rs['kind'], rs['n_dof'], n_tf, n_links, n_sph, n_box]
     buf[8] = fs['margin']
     ibuf[9:17] = [off_tf, off_links, off_sph, off_box, total, off_cull, off_fs, off_grid]
     if grid is not None:
@@ -466,6 +591,8 @@ def pack_geometry(robot, field, scales=None, prune_static=True, use_model=True):
         ibuf[26] = n_cells
         ibuf[31] = grid['k_lin']
         buf.view(np.uint32)[off_grid:off_grid + n_cells] = grid['words']
+        if version == GEOM_VERSION_LIST:
+            buf.view(np.uint8)[4 * off_cand:4 * off_cand + grid['cand'].size] = grid['cand']
     buf[off_tf:off_links] = rs['joint_tf'].astype(np.float32).reshape(-1)
     links = np.zeros((n_links, 8), np.float32)
     links.view(np.int32)[:, 0] = rs['link_frame'] if rs['kind'] == KIND_CHAIN else 1
@@ -552,3 +679,20 @@ def env_spheres_3d(seed=0, n_spheres=16, margin=0.05):
             continue
         out.append((c[0], c[1], c[2], r))
     return CollisionField(spheres=np.array(out, np.float32), margin=margin)
+
+
+def env_spheres_boxes_3d(seed=0, n_spheres=200, n_boxes=32, margin=0.04):
+    """A crowded 3-D scene (round 6): spheres r U[0.04, 0.12] and boxes with half extents U[0.03, 0.10], centres U[-0.8, 0.8]^3, none
+    within 0.25 of the base axis -- beyond the compact broad-phase grid (63 spheres), so pack_geometry gives it the LIST grid of
+    geometry version 7."""
+    rng = np.random.RandomState(seed)
+    sph, box = [], []
+    while len(sph) < n_spheres:
+        c, r = rng.uniform(-0.8, 0.8, 3), rng.uniform(0.04, 0.12)
+        if math.hypot(c[0], c[1]) - r > 0.25:
+            sph.append((*c, r))
+    while len(box) < n_boxes:
+        c, h = rng.uniform(-0.8, 0.8, 3), rng.uniform(0.03, 0.10, 3)
+        if math.hypot(c[0], c[1]) - math.hypot(h[0], h[1]) > 0.25:
+            box.append((*c, *h))
+    return CollisionField(spheres=np.array(sph, np.float32), boxes=np.array(box, np.float32) if n_boxes else None, margin=margin)

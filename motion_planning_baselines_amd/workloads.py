@@ -54,6 +54,18 @@ def panda_spheres_stomp(P, device, H=64, S=32, pos_only=False, seed=0, first_par
                 sigma_coll=1e-3)
 
 
+def panda_crowded_stomp(P, device, H=64, S=32, pos_only=False, seed=0):
+    """C3's shape in a crowded scene (200 spheres + 32 boxes, geometry.env_spheres_boxes_3d: the list grid of geometry version 7)."""
+    robot = G.RobotPanda()
+    field = G.env_spheres_boxes_3d(seed=seed)
+    dt = 5.0 / H
+    q = collision_free_configs(robot, field, 2 * P, seed + 31, device)
+    means0 = straight_line_means(q[:P], q[P:], H, dt, pos_only, device)
+    params = dict(n_dof=7, n_support_points=H, num_particles_per_goal=P, num_samples=S, dt=dt,
+                  temperature=1.0, step_size=0.1, sigma_spectral=0.1, pos_only=pos_only)
+    return dict(robot=robot, field=field, starts=q[:P], goals=q[P:], means0=means0, params=params, sigma_coll=1e-3)
+
+
 def pointmass_grid_circles_stomp(device, P=4, S=4, H=64):
     """C1 (examples/pointmass_grid_circles_2d_STOMP.py:53-96 parameters)."""
     robot = G.RobotPointMass(2, radius=0.01)

@@ -244,3 +244,79 @@ def test_hx_kernel_shape_space_sweep(gpu_device):
             assert rel_err(mf, ref['means']) < 1e-4, (tag, rel_err(mf, ref['means']))
             n_oracle += 1
     assert n_oracle >= 5
+
+
+def _list_scene(seed=0, n_sph=200, n_box=32, margin=0.04):
+    from motion_planning_baselines_amd import geometry as G
+    return G.env_spheres_boxes_3d(seed, n_sph, n_box, margin)
+
+
+@pytest.mark.parametrize('robot_kind,P,S,H,pos_only,use_model', [
+    ('panda', 16, 32, 64, False, True),      # C3's shape on a 200-sphere + 32-box scene: the model walk over the list grid
+    ('panda', 6, 20, 64, True, False),       # d = 7 through the table-driven walk (run-time d)
+    ('arm5', 5, 24, 48, False, False),       # a 5-joint chain, d = 10, H = 48
+    ('panda2', 4, 16, 64, False, True)])     # two chained fields, one of them small: both packed as list grids
+def test_list_grid_scene_on_the_persistent_path(gpu_device, robot_kind, P, S, H, pos_only, use_model):
+    """Round 6: a scene with 200 obstacle spheres and 32 boxes -- far beyond the compact grid's 63 spheres and
+    three candidates per cell, which dropped such scenes to the two-kernel EXHAUSTIVE walk -- stays on the persistent launch: the
+    geometry is packed as version 7 (list grid: any number of candidates per cell, boxes culled like spheres) and
+    stomp_fused_hx_kernel<..., LIST> keeps its tables in LDS.  Against the two-kernel path (exhaustive evaluator, every obstacle):
+    samples and costs bit for bit (conservative candidate sets, same expressions, exact min), weights / means to rounding; three
+    iterations in one launch == three launches; injected noise == device noise bits; and the oracle on the drawn normals."""
+    from motion_planning_baselines_amd import geometry as G, ops
+    from oracle import planners_ref as O
+    from oracle.geometry_ref import make_ref_geometry
+    from test_gpu_generic_dof import make_arm, trajs
+    dev = gpu_device
+    field = _list_scene()
+    if robot_kind == 'arm5':
+        robot, D = make_arm(5), 5
+    else:
+        robot, D = G.RobotPanda(), 7
+    fields = [G.env_spheres_3d(seed=2), field] if robot_kind == 'panda2' else field
+    geom = ops.DeviceGeometry(robot, fields, dev, use_model=use_model)
+    assert (geom.flags & 0x2100) == 0x2000 and bool(geom.flags & 0xFF) == use_model
+    d = D if pos_only else 2 * D
+    means0 = trajs(D, P, H, d, seed=3).to(dev)
+    Sigma, L = _constants(H, 0.05, 0.05, dev)
+    mk = lambda: (torch.empty(P, S, H, d, device=dev), torch.empty(P, S, device=dev), torch.empty(P, S, device=dev))
+    ws = ops.stomp_workspace(P, S, H, d, dev)
+    assert ops.stomp_run_path(geom, ws, P, S, H, d) != ops.STOMP_PATH_TWO_KERNEL
+    args = (L, Sigma, geom, S, D, 25.0, 1.0, 0.3, 2.0)
+    mf, (sf, cf, wf) = means0.clone(), mk()
+    ops.stomp_run(mf, None, sf, cf, wf, *args, ws, n_iters=1, seed=5, iter0=2)
+    mt, (st, ct, wt) = means0.clone(), mk()
+    ops.stomp_step(mt, None, st, ct, wt, *args, n_iters=1, seed=5, iter0=2)
+    torch.cuda.synchronize()
+    assert not ops.stomp_run_timed_out(ws)
+    assert torch.isfinite(mf).all() and float(ct.max()) > 0 and float((ct > 0).float().mean()) > 0.5
+    assert torch.equal(sf, st)
+    assert torch.equal(cf, ct), float((cf - ct).abs().max())
+    np.testing.assert_allclose(wf.cpu().numpy(), wt.cpu().numpy(), rtol=1e-4, atol=2e-6)
+    assert rel_err(mf, mt) < 2e-5
+    # three iterations in one launch == three launches; injected normals == the device's own draw
+    m1, (s1, c1, w1) = means0.clone(), mk()
+    ops.stomp_run(m1, None, s1, c1, w1, *args, ws, n_iters=3, seed=5, iter0=7)
+    m2, (s2, c2, w2) = means0.clone(), mk()
+    for it in range(3):
+        ops.stomp_run(m2, None, s2, c2, w2, *args, ws, n_iters=1, seed=5, iter0=7 + it)
+    nrm = ops.debug_stomp_normals(P, S, d, 3, dev, seed=5, iter0=7, particle_offset=0, H=H)
+    eps = nrm[..., :H].permute(0, 2, 3, 1, 4).contiguous()
+    m3, (s3, c3, w3) = means0.clone(), mk()
+    ops.stomp_run(m3, eps, s3, c3, w3, *args, ws, n_iters=3)
+    torch.cuda.synchronize()
+    assert not ops.stomp_run_timed_out(ws)
+    assert torch.equal(m1, m2) and torch.equal(s1, s2) and torch.equal(c1, c2) and torch.equal(w1, w2)
+    assert torch.equal(m1, m3) and torch.equal(s1, s3) and torch.equal(c1, c3) and torch.equal(w1, w3)
+    # the oracle (stomp.py:150-160) on the normals of the first launch
+    nrm = ops.debug_stomp_normals(P, S, d, 1, dev, seed=5, iter0=2, particle_offset=0, H=H)
+    e0 = nrm[0, ..., :H].permute(1, 2, 0, 3).contiguous().cpu()
+    fl = fields if isinstance(fields, list) else [fields]
+    refs = [make_ref_geometry(robot, f) for f in fl]
+
+    def cost_fn(x):
+        return sum(O.collision_cost(x, rr, rf, 0.2) for rr, rf in refs)
+    ref = O.stomp_iteration(means0.cpu(), e0, L.cpu(), Sigma.cpu(), cost_fn, 0.3, 2.0)
+    assert rel_err(sf, ref['samples']) < 2e-5
+    np.testing.assert_allclose(cf.cpu().numpy(), ref['costs'].numpy(), rtol=1e-4, atol=1e-4 * float(ref['costs'].max()))
+    assert rel_err(mf, ref['means']) < 1e-4

@@ -334,7 +334,9 @@ def test_geometry_model_tag_and_flags():
 def test_stomp_workspace_size():
     from motion_planning_baselines_amd import _lib
     f = _lib.lib().mpb_stomp_workspace_bytes
-    assert f(128, 32, 64, 14) == 4 * 320 + 8 * (2 * 128 * 2 * 912)          # header + 8-byte {value, tag} granules, two parities
+    # header + 8-byte {value, tag} granules, two parities: the H = 64 kernel's exchange slots hold 912 granules, the generalised
+    # kernel's 2064 -- which also serves H = 64 when the geometry carries list grids (round 6): the workspace fits either
+    assert f(128, 32, 64, 14) == 4 * 320 + 8 * (2 * 128 * 2 * 2064)
     assert f(3, 5, 64, 7) == 4 * 320 and f(0, 32, 64, 14) == 0              # one workgroup per particle: the header only
     assert f(4096, 32, 64, 14) == 4 * 320                                   # at least as many particles as CUs: two batches, no exchange
     assert f(8, 32, 48, 14) == 4 * 320 + 8 * (2 * 8 * 2 * 2064)            # H != 64: the generalised kernel's exchange slots (2 + H*d <= 2064 granules)
@@ -342,6 +344,8 @@ def test_stomp_workspace_size():
     # which path a call takes is a pure host-side function of the shape, the geometry flags and the workspace size
     path = _lib.lib().mpb_stomp_run_path
     assert path(0x100 | 1, f(128, 32, 64, 14), 128, 32, 64, 14) == 1       # exchange layout
+    assert path(0x100 | 1, 4 * 320 + 8 * (2 * 128 * 2 * 912), 128, 32, 64, 14) == 1    # ... which needs the smaller slots only
+    assert path(0x2000 | 1, f(128, 32, 64, 14), 128, 32, 64, 14) == 1 and path(0x2000 | 1, 1 << 30, 128, 32, 100, 14) == 0   # list grids: H <= 64
     assert path(0x100 | 1, 64, 128, 32, 64, 14) == 0                       # workspace too small: two-kernel loop
     assert path(0x100, 1280, 4096, 32, 64, 14) == 2 and path(0x100, 1280, 8, 16, 64, 7) == 2      # the header alone (MPB_STOMP_WS_HEADER_BYTES)
     assert path(0, 1 << 30, 128, 32, 64, 14) == 0 and path(0x100, 1 << 30, 128, 32, 200, 14) == 0
@@ -518,8 +522,8 @@ def test_headline_kernels_have_no_scratch():
             '_Z18stomp_fused_kernelILi7ELi1ELi1ELb1ELb0EE', '_Z18stomp_fused_kernelILi7ELi1ELi2ELb1ELb0EE',
             '_Z18stomp_fused_kernelILi7ELi1ELi1ELb0ELb1EE',
             '_Z18stomp_fused_kernelILi7ELi1ELi1ELb1ELb1EE',
-            '_Z21stomp_fused_hx_kernelILi14ELi1ELi2ELb0EE', '_Z21stomp_fused_hx_kernelILi14ELi1ELi2ELb1EE',   # H = 128: device / injected noise
-            '_Z21stomp_fused_hx_kernelILi14ELi1ELi1ELb1EE',                                                   # H < 64, injected noise
+            '_Z21stomp_fused_hx_kernelILi14ELi1ELi2ELb0ELb0EE', '_Z21stomp_fused_hx_kernelILi14ELi1ELi2ELb1ELb0EE',   # H = 128: device / injected noise
+            '_Z21stomp_fused_hx_kernelILi14ELi1ELi1ELb1ELb0EE',                                                       # H < 64, injected noise
             '_Z11mppi_kernelILi2ELb1ELb1ELb0EE', '_Z11mppi_kernelILi2ELb1ELb1ELb1EE']                     # the mppi entry (device / injected noise)
     for name in must:
         r = find(name)
@@ -536,9 +540,13 @@ def test_headline_kernels_have_no_scratch():
         # (mostly the injected-noise twins: only the parity tests of several fields at P > 128 come here)
         'stomp_fused_kernel<14,0,2,true,true>': 32, 'stomp_fused_kernel<7,0,2,true,true>': 32, 'stomp_fused_kernel<7,0,2,false,true>': 16,
         'stomp_fused_kernel<14,1,2,true,true>': 48, 'stomp_fused_kernel<7,1,2,true,true>': 36, 'stomp_fused_kernel<7,1,2,false,true>': 16,
-        'stomp_fused_hx_kernel<0,0,1,true>': 72, 'stomp_fused_hx_kernel<0,0,2,true>': 148,   # run-time d, table-driven walk
-        'stomp_fused_hx_kernel<0,0,1,false>': 16, 'stomp_fused_hx_kernel<0,0,2,false>': 76,
-        'stomp_fused_hx_kernel<14,1,1,false>': 8, 'stomp_fused_hx_kernel<7,1,1,true>': 8,   # H < 64
+        'stomp_fused_hx_kernel<0,0,1,true,false>': 8, 'stomp_fused_hx_kernel<0,0,2,true,false>': 120,   # run-time d, table-driven walk
+        'stomp_fused_hx_kernel<0,0,2,false,false>': 68,
+        'stomp_fused_hx_kernel<7,1,1,true,false>': 8,   # H < 64
+        # list-grid instantiations (round 6: scenes beyond 63 obstacle spheres, H <= 64)
+        'stomp_fused_hx_kernel<0,0,1,false,true>': 12, 'stomp_fused_hx_kernel<0,0,1,true,true>': 76,
+        'stomp_fused_hx_kernel<14,1,1,false,true>': 8, 'stomp_fused_hx_kernel<14,1,1,true,true>': 8,
+        'stomp_fused_hx_kernel<7,1,1,false,true>': 8, 'stomp_fused_hx_kernel<7,1,1,true,true>': 8,
     }
 
     def short(mangled):
@@ -639,3 +647,78 @@ def test_dpp_weighted_sum_keeps_its_wait_states(tmp_path):
                 p = re.match(r'v_fmac_f32_dpp (v\d+), (v\d+), (v\d+) row_newbcast:(\d+) ', ins[i - 1])
                 assert p and int(p.group(4)) == k - 1 and p.group(1) == acc and p.group(2) == a, (src, ins[i - 2:i + 1])
     assert n_blocks >= 20           # every instantiation of both kernels carries at least one block
+
+
+def _big_scene(seed=0, n_sph=200, n_box=32):
+    from motion_planning_baselines_amd import geometry as G
+    return G.env_spheres_boxes_3d(seed, n_sph, n_box)
+
+
+def test_list_grid_pack_check_flags_and_candidate_sets():
+    """Geometry version 7 (round 6): a field with more than 63 obstacle spheres carries a LIST grid -- any number of candidates per
+    cell, boxes culled like spheres.  pack_geometry builds it, mpb_geom_check accepts it (and refuses forged ranges), mpb_geom_flags
+    reports bit 13 (and not bit 8: the compact-grid kernels must not take it), the persistent launcher takes it up to H = 64; and the
+    candidate sets are CONSERVATIVE: for random query points every sphere / box within (margin + largest collision sphere) of the
+    point is listed in the point's cell, found the way the kernels find it (cell = round(x / h) - K on the lattice)."""
+    from motion_planning_baselines_amd import geometry as G, _lib
+    robot, field = G.RobotPanda(), _big_scene()
+    buf = G.pack_geometry(robot, field)
+    gi = buf.view(np.int32)
+    assert gi[1] == G.GEOM_VERSION_LIST and gi[6] == 200 and gi[7] == 32
+    _lib.geom_check(buf)
+    fl = _lib.geom_flags(buf)
+    assert (fl & 0x2000) and not (fl & 0x100) and (fl >> 16) == gi[26]
+    lib = _lib.lib()
+    assert lib.mpb_stomp_run_path(fl, 1 << 30, 128, 32, 64, 14) != 0 and lib.mpb_stomp_run_path(fl, 1 << 30, 128, 32, 48, 7) != 0
+    assert lib.mpb_stomp_run_path(fl, 1 << 30, 128, 32, 128, 14) == 0           # two horizon chunks leave no LDS for the tables
+    # a compact-grid scene is untouched; two fields: one needs the list grid -> both take it
+    small = G.env_spheres_3d()
+    assert G.pack_geometry(robot, small).view(np.int32)[1] == G.GEOM_VERSION
+    two = G.pack_geometry(robot, [small, field])
+    assert two.view(np.int32)[1] == G.GEOM_VERSION_LIST and (_lib.geom_flags(two) & 0x2100) == 0x2000
+    _lib.geom_check(two)
+    # forged ranges are refused
+    off_grid, n_cells, total = int(gi[16]), int(gi[26]), int(gi[13])
+    off_cand = off_grid + (n_cells + 1023) // 1024 * 1024
+    bad = buf.copy()
+    w = bad.view(np.uint32)
+    i = int(np.argmax((w[off_grid:off_grid + n_cells] >> 15) & 0x7F))
+    w[off_grid + i] = (4 * (total - off_cand) - 1) | (5 << 15)                  # range runs past the candidate bytes
+    with pytest.raises(_lib.MPBError):
+        _lib.geom_check(bad)
+    bad = buf.copy()
+    bad.view(np.uint8)[4 * off_cand] = 250                                       # a sphere index that does not exist
+    w = bad.view(np.uint32)
+    w[off_grid] = 0 | (1 << 15)
+    with pytest.raises(_lib.MPBError):
+        _lib.geom_check(bad)
+    # ---- conservative candidate sets
+    fs, rs = field.spec(), robot.spec()
+    a_max = float(fs['margin']) + float(np.max(rs['link_radius']))
+    inv = buf[23:26].astype(np.float64)
+    dims = gi[17:20].astype(np.int64)
+    lo = buf[20:23].astype(np.float64)
+    K = np.rint(lo * inv + 0.5).astype(np.int64)
+    words = buf.view(np.uint32)[off_grid:off_grid + n_cells]
+    cand = buf.view(np.uint8)[4 * off_cand:]
+    rng = np.random.RandomState(1)
+    pts = rng.uniform(-1.0, 1.0, (4000, 3))
+    sph, box = fs['spheres'].astype(np.float64), fs['boxes'].astype(np.float64)
+    checked = 0
+    for p in pts:
+        cell = np.rint(p * inv).astype(np.int64) - K
+        d_s = np.linalg.norm(p - sph[:, :3], axis=1) - sph[:, 3]
+        q = np.abs(p - box[:, :3]) - box[:, 3:6]
+        d_b = np.linalg.norm(np.maximum(q, 0), axis=1) + np.minimum(q.max(1), 0)
+        near_s, near_b = set(np.nonzero(d_s < a_max)[0]), set(np.nonzero(d_b < a_max)[0])
+        if np.any(cell < 0) or np.any(cell >= dims):
+            assert not near_s and not near_b, 'a point outside the grid must be beyond every threshold'
+            continue
+        wd = int(words[cell[0] + dims[0] * (cell[1] + dims[1] * cell[2])])
+        if wd & 0x80000000:
+            continue
+        st, ns, nb = wd & 0x7FFF, (wd >> 15) & 0x7F, (wd >> 22) & 0x3F
+        assert near_s <= set(cand[st:st + ns].tolist()), (p, near_s)
+        assert near_b <= set(cand[st + ns:st + ns + nb].tolist()), (p, near_b)
+        checked += bool(near_s or near_b)
+    assert checked > 500
