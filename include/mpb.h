@@ -38,7 +38,7 @@ extern "C" {
 #define MPB_E_HIP 3         /* a HIP runtime call failed; see mpb_last_error() */
 
 #define MPB_MAX_H 256
-#define MPB_MAX_DOF 8
+#define MPB_MAX_DOF 12
 
 /* ABI version in the low 16 bits (MPB_ABI_VERSION: bumped whenever a signature of this header changes positionally or a call that
  * used to be accepted is now refused; a binding must refuse a library that reports another number); bit 30 set = a tuning build

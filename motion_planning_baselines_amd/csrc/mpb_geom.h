@@ -39,7 +39,7 @@
 #define MPB_GRID_OVERFLOW 0xFFFFFFFEu   // a cell word packs four 8-bit obstacle indices; an unused slot holds n_sph (the far dummy)
 #define MPB_KIND_POINT 0
 #define MPB_KIND_CHAIN 1
-#define MPB_MAX_DOF 8
+#define MPB_MAX_DOF 12
 #define MPB_MAX_TF (MPB_MAX_DOF + 1)
 // collision spheres processed together (VGPR resident) by the exhaustive obstacle loop: 4.  (The cost-only path ran 8 at
 // a time in round 1; that evaluator is now the cold path -- fields without a usable broad-phase grid -- and at 8 it alone

@@ -749,6 +749,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MPB_GP_WAVE
 // C-ABI
 // ------------------------------------------------------------------------------------------------
 static bool gp_shape_ok(int B, int H, int D) { return B >= 0 && H >= 2 && H <= GP_MAXH && D >= 1 && D <= MPB_MAX_DOF; }
+// the block elimination keeps a 2D x 2D block in ONE 16 x 16 matrix-core tile: D <= 8; beyond that (D <= 12) only the low-rank form applies
+#define GP_BLOCK_MAX_DOF 8
 
 extern "C" size_t mpb_gpmp2_workspace_bytes(int B, int H, int D) {
     if (!gp_shape_ok(B, H, D)) return 0;
@@ -849,6 +851,8 @@ extern "C" int mpb_gpmp2_solve(float* x, const float* start, const float* goal, 
         const bool want_block = (form_env && !strcmp(form_env, "block")) || (!form_env && getenv("MPB_GPMP2_SM") != nullptr);
         if (form_env && !strcmp(form_env, "lr") && !mpb_gpmp2_lr_ok(H, D, n_fields))
             return mpb_fail(MPB_E_UNSUPPORTED, "mpb_gpmp2_solve: MPB_GPMP2_FORM=lr, but n_fields * (H - 1) > 127");
+        if (D > GP_BLOCK_MAX_DOF && (want_block || !mpb_gpmp2_lr_ok(H, D, n_fields)))
+            return mpb_fail(MPB_E_UNSUPPORTED, "mpb_gpmp2_solve: more than 8 degrees of freedom need the low-rank form (n_fields * (H - 1) <= 127, H <= 128)");
         if (!want_block && mpb_gpmp2_lr_ok(H, D, n_fields)) {
             int rc = mpb_gpmp2_lr_launch(x, start, goal, w.jac, dm, w.fz, costs_out, B, H, D, n_fields, K, (hipStream_t)stream);
             if (rc) return rc;

@@ -372,7 +372,8 @@ __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ ja
     double* wv = lds + (size_t)n_tiles_max * LR_TILE;
     double* dinv = wv + 128;
     float* hb = reinterpret_cast<float*>(dinv + 128);
-    int* tact = reinterpret_cast<int*>(hb + LR_NMAX * 8);
+    const int hs = (D <= 8) ? 8 : MPB_MAX_DOF;                  // floats per row of h (the launcher sizes the LDS for it)
+    int* tact = reinterpret_cast<int*>(hb + LR_NMAX * hs);
     int* fact = tact + 128;
     int* cnt = fact + 128;                                       // [0 .. 2 F): active rows of (field, 64-waypoint chunk)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
@@ -435,7 +436,8 @@ __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ ja
                 tact[pos] = ps ? myt2 : myt;
                 fact[pos] = ps ? myf2 : myf;
 #pragma unroll
-                for (int j = 0; j < MPB_MAX_DOF; ++j) hb[pos * 8 + j] = (j < D) ? (ps ? hrow2[j] : hrow[j]) : 0.f;
+                for (int j = 0; j < MPB_MAX_DOF; ++j)
+                    if (j < hs) hb[pos * hs + j] = (j < D) ? (ps ? hrow2[j] : hrow[j]) : 0.f;
                 wv[pos] = (double)(ps ? hrow2[D] : hrow[D]);     // c of the row (until the right-hand side takes the slot)
             }
         }
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ ja
     if (tid < n) {
         double sacc = wv[tid];
         const double* up = upos + (size_t)tact[tid] * NL + (size_t)b * D;
-        for (int j = 0; j < D; ++j) sacc -= (double)hb[tid * 8 + j] * up[j];
+        for (int j = 0; j < D; ++j) sacc -= (double)hb[tid * hs + j] * up[j];
         wv[tid] = sacc;
     }
     __syncthreads();
@@ -478,7 +480,7 @@ __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ ja
                 m = (a == cc) ? ikc : 0.0;
 #pragma unroll
                 for (int j = 0; j < MPB_MAX_DOF; ++j)
-                    if (j < D) m = fma((double)hb[a * 8 + j] * (double)hb[cc * 8 + j], gcur[j], m);
+                    if (j < D) m = fma((double)hb[a * hs + j] * (double)hb[cc * hs + j], gcur[j], m);
             } else if (a == n && cc < n) {
                 m = wv[cc];
             } else {
@@ -625,7 +627,7 @@ int mpb_gpmp2_lr_launch(float* x, const float* start, const float* goal, const f
                        n_fields, K);
     const int n_max = n_fields * (H - 1);
     const int trm = (n_max + 16) >> 4, ntm = (trm * (trm + 1)) >> 1;             // tiles of the largest system the shape allows
-    const size_t lds = ((size_t)ntm * LR_TILE + 256) * sizeof(double) + (size_t)LR_NMAX * 8 * sizeof(float) + (256 + 16) * sizeof(int);
+    const size_t lds = ((size_t)ntm * LR_TILE + 256) * sizeof(double) + (size_t)LR_NMAX * (D <= 8 ? 8 : MPB_MAX_DOF) * sizeof(float) + (256 + 16) * sizeof(int);
     hipLaunchKernelGGL(gpmp2_lr_cap, dim3(B), dim3(256), lds, stream, jac, upos, G, gpcost, wdense, costs_out, B, H, D, n_fields, ntm, K);
     hipLaunchKernelGGL(gpmp2_lr_sweep<true>, gs, dim3(64), lds_sweep, stream, x, start, goal, jac, wdense, rec, zbuf, upos, gpcost, B, H, D,
                        n_fields, K);

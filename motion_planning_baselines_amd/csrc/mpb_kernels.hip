@@ -220,7 +220,7 @@ extern "C" int mpb_geom_flags(const float* g, int n_words, int* flags) {
     return MPB_OK;
 }
 
-#define MPB_MAX_D (2 * MPB_MAX_DOF)
+#define MPB_MAX_D 16       // channels of a STOMP rollout (one matrix-core tile of channels): D <= 8 with velocities, D <= 12 position only
 
 // Measurement aid (mpb_stomp_step_profile): while these are set, the STOMP kernel launches record the pair on the
 // dispatch itself (hipExtLaunchKernelGGL: kernel begin / end timestamps, the quantity rocprofv3 --kernel-trace reports).
@@ -921,7 +921,7 @@ __global__ __launch_bounds__(256) void collision_cost_kernel(
                     if ((d & 1) == 0) {        // 8-byte pieces (rows start 8-byte aligned)
                         float2* g2 = reinterpret_cast<float2*>(grow);
 #pragma unroll
-                        for (int i = 0; i < MPB_MAX_D; i += 2) {
+                        for (int i = 0; i < 2 * MPB_MAX_DOF; i += 2) {      // (rows up to positions + velocities of MPB_MAX_DOF joints)
                             if (i < d) {
                                 const float g0 = (i < MPB_MAX_DOF && i < D && h >= h_begin) ? sc * dq[i < MPB_MAX_DOF ? i : 0] : 0.f;
                                 const float g1 = (i + 1 < MPB_MAX_DOF && i + 1 < D && h >= h_begin) ? sc * dq[i + 1 < MPB_MAX_DOF ? i + 1 : 0] : 0.f;
@@ -932,7 +932,7 @@ __global__ __launch_bounds__(256) void collision_cost_kernel(
                         }
                     } else {
 #pragma unroll
-                        for (int i = 0; i < MPB_MAX_D; ++i) {
+                        for (int i = 0; i < 2 * MPB_MAX_DOF; ++i) {
                             if (i < d) {
                                 const float gi = (i < MPB_MAX_DOF && i < D && h >= h_begin) ? sc * dq[i < MPB_MAX_DOF ? i : 0] : 0.f;
                                 grow[i] = first ? gi : grow[i] + gi;
@@ -1030,7 +1030,7 @@ extern "C" int mpb_cost_collision_eval(const float* trajs, const float* geom, fl
                                        int B, int H, int d, int h_begin, float k_sigma, float weight, void* stream) {
     if (B == 0) return MPB_OK;   // empty batch: nothing to do (and torch hands out null pointers for it)
     if (!trajs || !geom || !out) return fail(MPB_E_INVALID, "%s: null pointer", __func__);
-    if (B < 0 || H < 1 || d < 1 || d > MPB_MAX_D || h_begin < 0) return fail(MPB_E_INVALID, "%s: bad shape", __func__);
+    if (B < 0 || H < 1 || d < 1 || d > 2 * MPB_MAX_DOF || h_begin < 0) return fail(MPB_E_INVALID, "%s: bad shape", __func__);   // (rows of any width up to positions + velocities of 12 joints; the first n_dof channels are read)
     if (B == 0) return MPB_OK;
     hipLaunchKernelGGL((collision_cost_kernel<false, 0>), dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, trajs, geom,
                        out, per_waypoint, (float*)nullptr, B, H, d, h_begin, k_sigma, weight);
@@ -1041,7 +1041,7 @@ extern "C" int mpb_cost_collision_grad(const float* trajs, const float* geom, in
                                        int H, int d, int h_begin, float k_sigma, float weight, void* stream) {
     if (B == 0) return MPB_OK;
     if (!trajs || !geom || !out || !grad) return fail(MPB_E_INVALID, "%s: null pointer", __func__);
-    if (B < 0 || H < 1 || d < 1 || d > MPB_MAX_D || h_begin < 0) return fail(MPB_E_INVALID, "%s: bad shape", __func__);
+    if (B < 0 || H < 1 || d < 1 || d > 2 * MPB_MAX_DOF || h_begin < 0) return fail(MPB_E_INVALID, "%s: bad shape", __func__);   // (rows of any width up to positions + velocities of 12 joints; the first n_dof channels are read)
     if (B == 0) return MPB_OK;
     if ((geom_flags & 0xFF) == PandaModel::ID && (geom_flags & 0x100))
         hipLaunchKernelGGL((collision_cost_kernel<true, PandaModel::ID>), dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, trajs,

@@ -49,7 +49,7 @@ LIST_CELL_MAX_BOX = 62    # per cell (6-bit field; 63 marks overflow)
 LIST_OVERFLOW = 0x80000000
 KIND_POINT = 0
 KIND_CHAIN = 1
-MAX_DOF = 8
+MAX_DOF = 12
 BOX_2D_HALF_Z = 1.0e6  # 2-D boxes are 3-D boxes that are effectively infinite in z
 
 

@@ -1,4 +1,5 @@
-"""GPU: serial chains with D = 1, 4, 5, 6 and 8 (MPB_MAX_DOF) degrees of freedom -- the dof counts the kernels have no
+"""GPU: serial chains with D = 1, 4, 5, 6, 8, 9 and 12 (MPB_MAX_DOF since round 6: 8 until then; beyond 8 joints STOMP runs position only --
+its rollout tile holds 16 channels -- and GPMP2 takes the low-rank form, whose chains have no block-size limit) degrees of freedom -- the dof counts the kernels have no
 compile-time instance for (the reference's robots are D = 2, 3, 7): collision cost / gradient, STOMP (d = 2D up to 16 =
 MPB_MAX_D, chunked MFMA kernel), CHOMP (general kernel) and GPMP2 (run-time block size; D = 8 fills the 16 x 16 tile
 with no padding) against the oracle on small seeded inputs."""
@@ -12,7 +13,9 @@ pytestmark = pytest.mark.gpu
 
 # (a, d, alpha) rows in the modified-DH convention of geometry._mdh: a Panda-like arm with an eighth joint
 _MDH = [(0.0, 0.333, 0.0), (0.0, 0.0, -math.pi / 2), (0.0, 0.316, math.pi / 2), (0.0825, 0.0, math.pi / 2),
-        (-0.0825, 0.384, -math.pi / 2), (0.0, 0.0, math.pi / 2), (0.088, 0.0, math.pi / 2), (0.0, 0.12, -math.pi / 2)]
+        (-0.0825, 0.384, -math.pi / 2), (0.0, 0.0, math.pi / 2), (0.088, 0.0, math.pi / 2), (0.0, 0.12, -math.pi / 2),
+        # round 6: four more joints (MPB_MAX_DOF = 12)
+        (0.05, 0.0, math.pi / 2), (0.0, 0.15, -math.pi / 2), (0.04, 0.0, math.pi / 2), (0.0, 0.10, -math.pi / 2)]
 
 
 def rel_err(a, b):
@@ -52,7 +55,7 @@ def trajs(D, B, H, d, seed):
     return (torch.cat([q, 0.3 * torch.randn(B, H, d - D, generator=g)], -1) if d > D else q).contiguous()
 
 
-@pytest.mark.parametrize('D', [1, 4, 5, 6, 8])
+@pytest.mark.parametrize('D', [1, 4, 5, 6, 8, 9, 12])
 def test_cost_and_grad(gpu_device, D):
     from motion_planning_baselines_amd import ops
     from oracle import planners_ref as O
@@ -74,7 +77,7 @@ def test_cost_and_grad(gpu_device, D):
     assert float((diff > tol).float().mean()) < 3e-3
 
 
-@pytest.mark.parametrize('D,pos_only', [(1, False), (4, False), (4, True), (5, False), (6, True), (8, False), (8, True)])
+@pytest.mark.parametrize('D,pos_only', [(1, False), (4, False), (4, True), (5, False), (6, True), (8, False), (8, True), (9, True), (12, True)])
 def test_stomp(gpu_device, D, pos_only):
     from motion_planning_baselines_amd import ops
     from motion_planning_baselines_amd.planners.stomp import precision_to_scale_tril, stomp_precision_matrix
@@ -108,7 +111,7 @@ def test_stomp(gpu_device, D, pos_only):
     assert rel_err(means, ref) < 1e-4
 
 
-@pytest.mark.parametrize('D', [1, 4, 5, 6, 8])
+@pytest.mark.parametrize('D', [1, 4, 5, 6, 8, 9, 12])
 def test_gpmp2(gpu_device, D):
     from motion_planning_baselines_amd import ops
     from oracle import planners_ref as O
@@ -140,7 +143,7 @@ def test_gpmp2(gpu_device, D):
         np.testing.assert_allclose(costs.cpu().numpy(), ref['costs'].numpy(), rtol=2e-3)
 
 
-@pytest.mark.parametrize('D', [1, 4, 6, 8])
+@pytest.mark.parametrize('D', [1, 4, 6, 8, 9, 12])
 def test_chomp(gpu_device, D):
     from motion_planning_baselines_amd import ops
     from motion_planning_baselines_amd.planners.chomp import CHOMP

@@ -255,6 +255,7 @@ def _list_scene(seed=0, n_sph=200, n_box=32, margin=0.04):
     ('panda', 16, 32, 64, False, True),      # C3's shape on a 200-sphere + 32-box scene: the model walk over the list grid
     ('panda', 6, 20, 64, True, False),       # d = 7 through the table-driven walk (run-time d)
     ('arm5', 5, 24, 48, False, False),       # a 5-joint chain, d = 10, H = 48
+    ('arm9', 5, 24, 64, True, False),        # a 9-joint chain (MPB_MAX_DOF 12 since round 6), position only: d = 9
     ('panda2', 4, 16, 64, False, True)])     # two chained fields, one of them small: both packed as list grids
 def test_list_grid_scene_on_the_persistent_path(gpu_device, robot_kind, P, S, H, pos_only, use_model):
     """Round 6: a scene with 200 obstacle spheres and 32 boxes -- far beyond the compact grid's 63 spheres and
@@ -269,8 +270,9 @@ def test_list_grid_scene_on_the_persistent_path(gpu_device, robot_kind, P, S, H,
     from test_gpu_generic_dof import make_arm, trajs
     dev = gpu_device
     field = _list_scene()
-    if robot_kind == 'arm5':
-        robot, D = make_arm(5), 5
+    if robot_kind in ('arm5', 'arm9'):
+        D = int(robot_kind[3:])
+        robot = make_arm(D)
     else:
         robot, D = G.RobotPanda(), 7
     fields = [G.env_spheres_3d(seed=2), field] if robot_kind == 'panda2' else field
