@@ -436,8 +436,11 @@ __global__ __launch_bounds__(64 * MPB_A_WPB, 16 / MPB_A_WPB) void stomp_sample_c
     MPB_STAMP(5);
     if (WITH_COST) {
         float q[MPB_MAX_DOF], dq[MPB_MAX_DOF];
+        // (a row of d channels holds D = d or D = d / 2 joint positions: with more channels than MPB_MAX_DOF it must be d / 2 -- the
+            // joints beyond that are zeros the compiler can fold, which keeps the d = 14 kernels at the registers they had with 8)
+            constexpr int DQ_ = (DCH > MPB_MAX_DOF) ? DCH / 2 : DCH;
 #pragma unroll
-        for (int i = 0; i < MPB_MAX_DOF; ++i) q[i] = (i < DCH) ? x[i < DCH ? i : 0] : 0.f;
+            for (int i = 0; i < MPB_MAX_DOF; ++i) q[i] = (i < DQ_) ? x[i < DQ_ ? i : 0] : 0.f;
         float c = 0.f;
         bool bad = false;   // geom_flags and the device header disagree: the cost is poisoned (NaN bits), never mis-read
         // one pass per chained collision field (the reference sums one CostCollision per field); the first field's

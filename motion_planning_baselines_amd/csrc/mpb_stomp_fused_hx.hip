@@ -340,8 +340,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_hx_kernel(
             // ============ B. collision cost of this chunk of the rollout
             {
                 float q[MPB_MAX_DOF];
+                // (a row of d channels holds D = d or D = d / 2 joint positions: with more channels than MPB_MAX_DOF it must be d / 2 -- the
+            // joints beyond that are zeros the compiler can fold, which keeps the d = 14 kernels at the registers they had with 8)
+            constexpr int DQ_ = DCH ? ((DCH > MPB_MAX_DOF) ? DCH / 2 : DCH) : MPB_MAX_DOF;     // (run-time d: any joint count)
 #pragma unroll
-                for (int i = 0; i < MPB_MAX_DOF; ++i) q[i] = (i < DX) ? x[i < DX ? i : 0] : 0.f;
+            for (int i = 0; i < MPB_MAX_DOF; ++i) q[i] = (i < DQ_) ? x[i < DQ_ ? i : 0] : 0.f;
                 float c = 0.f;
                 bool bad = false;
                 GeomView G = G0;
