@@ -194,6 +194,10 @@ def test_gpmp2_c4_shape_vs_oracle(gpu_device, H, trust, n_fields, n_interp, sig,
     from motion_planning_baselines_amd import geometry as G, ops, workloads
     from oracle import planners_ref as O
     from oracle.geometry_ref import make_ref_geometry
+    # (the block elimination keeps the cases that exercise ITS machinery -- the horizons, the merge row, two fields, the
+    # Sherman-Morrison form at 1e10 / 1e12 --, not every sigma variation: each case solves a dense 1792-unknown system on the CPU)
+    if form == 'block' and sig is not None and not (sig in ((1e-5, 1.0, 1e-5, 1e-5), (1e-5, 1.0, 1e-5, 1e-6)) and n_interp == 0):
+        pytest.skip('sigma variation kept for the launcher\'s form only')
     _set_gpmp2_form(monkeypatch, form)
     dev = gpu_device
     B, D = 2, 7

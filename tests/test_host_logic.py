@@ -722,3 +722,23 @@ def test_list_grid_pack_check_flags_and_candidate_sets():
         assert near_b <= set(cand[st + ns:st + ns + nb].tolist()), (p, near_b)
         checked += bool(near_s or near_b)
     assert checked > 500
+
+
+@pytest.mark.parametrize('offset_m', [0.0, 2500.0, 5000.0, 40000.0])
+def test_scene_far_from_the_origin_packs_and_checks(offset_m):
+    """mpb_geom_check accepted the grid origin only within an ABSOLUTE 1e-3 of a lattice point, which the fp32 rounding
+    of lo and 1 / h exceeds beyond |K| ~ 16 700 cells (~2 km at C3's cell size) -- scenes that build_grid packs (it allows |K| + dims <
+    65 536) were refused by the C check.  The tolerance now scales with |K|: whatever pack_geometry produces passes the check, with a
+    grid where fp32 still resolves the cells and without one beyond."""
+    from motion_planning_baselines_amd import geometry as G, _lib
+    base = G.env_spheres_3d()
+    sph = base.spheres.copy()
+    sph[:, 0] += offset_m
+    field = G.CollisionField(spheres=sph, margin=base.margin)
+    buf = G.pack_geometry(G.RobotPanda(), field)
+    _lib.geom_check(buf)                                   # must not raise
+    n_cells = int(buf.view(np.int32)[26])
+    if offset_m <= 5000.0:
+        assert n_cells > 0 and (_lib.geom_flags(buf) & 0x100)
+    else:
+        assert n_cells == 0 and not (_lib.geom_flags(buf) & 0x100)      # too far for the fp32 cell index: the exhaustive evaluators serve it
