@@ -161,6 +161,23 @@ if kg:   # GPMP2 C4 (scripts/prof_gpmp2.py: one iteration per launch)
             out[c + ('_KB_raw_per_launch' if c.endswith('SIZE') else '_per_wave')] = s[c] if c.endswith('SIZE') else s[c] / waves
     _dump(out, 'solve', os.path.join(prof, f'{tag}_pmc_solve.json'))
 
+kl = [k for k in summary if 'gpmp2_lr_' in k or 'gpmp2_chain_kernel' in k]
+if kl:   # GPMP2 C4, low-rank form (round 6; scripts/prof_gpmp2.py: one iteration per launch from the initial state)
+    out = {'workload': 'C4 panda_spheres GPMP2 B=2048 H=128 D=7, low-rank form, first iteration from the initial means (scripts/prof_gpmp2.py)', 'kernels': {}}
+    for k in kl:
+        s = summary[k]
+        waves = max(grid[k][0] // 64, 1)
+        e = {'waves_per_launch': waves, 'vgpr': grid[k][2], 'lds_bytes': grid[k][4], 'scratch_bytes': grid[k][5]}
+        for c in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_INSTS_MFMA', 'SQ_INSTS_VMEM', 'SQ_WAVE_CYCLES', 'SQ_ACTIVE_INST_VALU', 'SQ_WAIT_INST_ANY',
+                  'SQ_LDS_BANK_CONFLICT', 'SQ_LDS_IDX_ACTIVE'):
+            if c in s:
+                e[c + '_per_wave'] = s[c] / waves
+        for c in ('FETCH_SIZE', 'WRITE_SIZE'):
+            if c in s:
+                e[c + '_KB_raw_per_launch'] = s[c]
+        out['kernels'][k.split('(')[0]] = e
+    _dump(out, 'solve', os.path.join(prof, f'{tag}_pmc_gpmp2_lr.json'))
+
 kc = [k for k in summary if 'chomp_point4_kernel' in k]
 if kc:   # CHOMP C2 (scripts/prof_chomp.py: bench.py's c2 entry, MPB_CHOMP_ITERS iterations per launch)
     k = kc[0]

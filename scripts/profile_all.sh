@@ -16,6 +16,7 @@ bash scripts/profile_round.sh $TAG 20 > gpurun_out/${TAG}_profile_round.log 2>&1
 echo "headline passes done"
 bash scripts/profile_gpmp2.sh $TAG > gpurun_out/${TAG}_profile_gpmp2.log 2>&1
 python3 scripts/pmc_summary.py gpurun_out/prof_${TAG}_gpmp2 ${TAG}_gpmp2 > /dev/null
+python3 scripts/pmc_summary.py gpurun_out/prof_${TAG}_gpmp2_block ${TAG}_gpmp2_block > /dev/null
 echo "gpmp2 passes done"
 for drv in chomp mppi; do
   OUT=gpurun_out/prof_${TAG}_$drv
@@ -47,7 +48,7 @@ import glob, json, os, sys
 sys.path.insert(0, os.getcwd())
 import bench
 bad = []
-for pat in ('r*_pmc_stomp.json', 'r*_pmc_stomp_c5.json', 'r*_pmc_stomp_h128.json', 'r*_pmc_solve.json', 'r*_pmc_chomp.json', 'r*_pmc_mppi.json'):
+for pat in ('r*_pmc_stomp.json', 'r*_pmc_stomp_c5.json', 'r*_pmc_stomp_h128.json', 'r*_pmc_solve.json', 'r*_pmc_gpmp2_lr.json', 'r*_pmc_chomp.json', 'r*_pmc_mppi.json'):
     pmc, f = bench.latest_profile(pat)
     if pmc is None:
         continue
@@ -62,5 +63,5 @@ PYEOF
 mkdir -p gpurun_out/profiles_${TAG}
 cp profiles/${TAG}_* gpurun_out/profiles_${TAG}/
 cp gpurun_out/prof_${TAG}/stats/*_results.db gpurun_out/profiles_${TAG}/ 2>/dev/null || true
-rm -rf gpurun_out/prof_${TAG} gpurun_out/prof_${TAG}_gpmp2 gpurun_out/prof_${TAG}_chomp gpurun_out/prof_${TAG}_mppi
+rm -rf gpurun_out/prof_${TAG} gpurun_out/prof_${TAG}_gpmp2 gpurun_out/prof_${TAG}_gpmp2_block gpurun_out/prof_${TAG}_chomp gpurun_out/prof_${TAG}_mppi
 echo "all done"
