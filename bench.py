@@ -892,7 +892,7 @@ def bench_mppi(dev, steps, NP=1024, with_cpu=True):
         # scripts/prof_mppi.py, x the waves of a launch / the time measured here)
         ginstr = pmc['SQ_INSTS_VALU_per_wave_iteration'] * pmc['waves_per_launch'] / (t / steps) / 1e9
         roof = {'bound': 'valu', 'achieved': ginstr, 'peak': VALU_PEAK_GINSTR, 'unit': 'G wave-instr/s', 'frac': ginstr / VALU_PEAK_GINSTR,
-                'valu_instructions_per_wave_iteration': pmc['SQ_INSTS_VALU_per_wave_iteration'], 'pmc_source': pmc_file,
+                'valu_instructions_per_wave_iteration': pmc['SQ_INSTS_VALU_per_wave_iteration'], 'pmc_source': pmc_file, **pmc_freshness(pmc),
                 'lds_bank_conflict_frac_of_lds_cycles': (pmc['SQ_LDS_BANK_CONFLICT_per_wave_iteration'] / pmc['SQ_LDS_IDX_ACTIVE_per_wave_iteration']
                                                          if pmc.get('SQ_LDS_IDX_ACTIVE_per_wave_iteration') else None),
                 'scratch_bytes_per_lane': pmc.get('scratch_bytes'), 'hbm_nominal': roof}
