@@ -48,8 +48,14 @@ extern "C" {
  *           5 (round 5)  geometry buffers are version 6 (broad-phase grid on a lattice through the origin, header word 31; a
  *                        version-5 buffer is refused by mpb_geom_check); the STOMP entry points refuse pointers that are not
  *                        16-byte aligned; a model-tagged geometry must keep margin + radii below 1 m; mpb_gpmp2_solve applies the
- *                        collision factors by Sherman-Morrison beyond a precision ratio of 1e7 (more accurate results there). */
-#define MPB_ABI_VERSION 5
+ *                        collision factors by Sherman-Morrison beyond a precision ratio of 1e7 (more accurate results there);
+ *           6 (round 6)  mpb_gpmp2_workspace_bytes and mpb_stomp_workspace_bytes return MORE (the low-rank form of the GPMP2 solve keeps
+ *                        its tables and sweep records in the workspace; the STOMP workspace also fits the generalised persistent
+ *                        kernel at H = 64, which serves list-grid scenes): a workspace sized by an older library is too small;
+ *                        geometry buffers of version 7 (LIST broad-phase grid, per field) are accepted next to version 6;
+ *                        MPB_MAX_DOF 8 -> 12; mpb_gpmp2_solve takes the low-rank form wherever n_fields (H - 1) <= 127 (same
+ *                        results to the solver's fp64 rounding). */
+#define MPB_ABI_VERSION 6
 #define MPB_VERSION_TUNING_BUILD 0x40000000
 int mpb_version(void);
 const char *mpb_last_error(void);
@@ -62,7 +68,11 @@ int mpb_geom_check(const float *geom_host, int n_words);
  * usable broad-phase grid); 0 = generic table-driven kernels; bit 8 = every chained field has a usable broad-phase
  * grid (what the persistent STOMP kernel needs); bit 9 = point robot with ONE field of at most 32 spheres and 8 boxes
  * (CHOMP's four-lanes-per-waypoint kernel keeps such an obstacle set in registers); bit 10 = point robot; bit 12 = ONE field (no chain: MPPI's LDS grid, the persistent STOMP kernels' one-field instantiations); bits 16-28 = cells of the largest
- * broad-phase grid of the chain when bit 8 is set (what a kernel that stages the grid in LDS has to reserve).  Entry points that take `geom_flags` expect the value
+ * broad-phase grid of the chain when bit 8 or bit 13 is set (what a kernel that stages the grid in LDS has to reserve); bit 13 (round 6) = every
+ * chained field carries a LIST grid (geometry version 7: a field with more than 63 obstacle spheres -- up to 255 spheres + 127 boxes, any number
+ * of candidates per cell, boxes culled like spheres; bit 8 is then clear): the generalised persistent STOMP kernel takes such a geometry up to
+ * H = 64 (csrc/mpb_stomp_fused_hx.hip, LIST), every other kernel walks such a field exhaustively; the model byte is also set for it, and
+ * consumers other than that kernel require bit 8 beside it.  Entry points that take `geom_flags` expect the value
  * computed from the host copy of the very buffer `geom` points to (0 is always valid); a kernel re-checks the tag
  * and the one-field promise against the device header and writes NaN costs if they disagree. */
 int mpb_geom_flags(const float *geom_host, int n_words, int *flags);
@@ -332,7 +342,13 @@ int mpb_chomp_step(float *means, const float *R, const float *geom, int geom_fla
  *                         trust-region damping uses the BATCH MEAN of that diagonal (gpmp2.py:361-367).
  *                         diag_sum_out NULL: kept in the workspace.  When sharded, the host all-reduces
  *                         the sums and passes diag_mean = sum / B_global to mpb_gpmp2_solve;
- *   mpb_gpmp2_solve     : assemble + block-Cholesky solve + x += step_size * dtheta.
+ *   mpb_gpmp2_solve     : assemble + solve + x += step_size * dtheta.  Two forms of the same fp64 solve: the LOW-RANK form
+ *                         (round 6, csrc/mpb_gpmp2_lr.hip: priors + GP blocks + damping are shared by all particles and decouple
+ *                         over the joints -- factored once per call --, the collision factors enter through a dense SPD system
+ *                         over each particle's ACTIVE rows; as accurate as dense fp64 Cholesky at every precision ratio) wherever
+ *                         n_fields * (H - 1) <= 127, and the block-tridiagonal elimination (csrc/mpb_gpmp2.hip) otherwise (D <= 8
+ *                         only: a 2D x 2D block must fit its 16 x 16 tile).  MPB_GPMP2_FORM = lr / block (environment, read per
+ *                         call) forces one; MPB_GPMP2_SM set means the block form.
  *                         trust_region == 0: damping delta * I (diag_mean ignored);
  *                         else delta * diag_mean (diag_mean NULL: the LOCAL mean mpb_gpmp2_diag leaves in the workspace
  *                         when it is called without diag_sum_out, as mpb_gpmp2_step does).

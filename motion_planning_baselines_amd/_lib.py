@@ -74,7 +74,7 @@ DEBUG_SIGNATURES = {
     'mpb_debug_stomp_normals_h': [_p, _i, _i, _i, _i, _i, _u64, _u32, _u32, _p],
     'mpb_debug_mppi_normals': [_p, _i, _i, _i, _i, _i, _u64, _u32, _p],
 }
-ABI_VERSION = 5          # include/mpb.h MPB_ABI_VERSION
+ABI_VERSION = 6          # include/mpb.h MPB_ABI_VERSION
 
 _lib = None
 _debug_lib = None
