@@ -21,17 +21,24 @@
 // scripts/gpmp2_lowrank_prototype.py (numpy fp64 against a long-double-refined dense solve): as accurate as dense fp64 Cholesky
 // at every collision / GP precision ratio from 1e6 to 1e14, active sets from 8 to 84 rows.
 //
-// Four launches per iteration:
+// Five launches per iteration, every one of them bound by the LATENCY of one particle's (or one joint's) dependent steps, not by
+// the batch (a lone wave issues one instruction per four cycles, an fp64 one per eight: what counts is the instruction COUNT on
+// the sequential path -- DESIGN.md section 6 has the per-kernel times on one particle):
 //   gpmp2_chain_kernel    shared by all particles: the block-Thomas factors (W_t = S_t^-1, F_t = W_t U) of the D chains and the
-//                         position-position entries G_i(s, t) of their inverses, D H^2 doubles (0.9 MB at C4: stays in L2);
-//   gpmp2_lr_sweep<false> u0: lane = (particle, joint) -- 9 particles per wave at D = 7 --, the factors in LDS, the joint's own
-//                         gradient formed on the fly from x (the GP factors couple a joint only with itself), H steps down and H
-//                         up with two dependent fma per step; x and the z_t records travel through register rings 16 steps
-//                         ahead (the first version of the round walked the chain inside the per-particle kernel with the factors
-//                         read from L2 one step ahead: 512 L2 round trips in a row per particle, 0.91 ms at C4);
-//   gpmp2_lr_cap          per particle, one wave: the active rows compacted by ballot, M (n_a x n_a) from the G table in 8 x 8 lane
-//                         tiles into LDS (packed lower triangle, column major), Cholesky and both triangular solves in LDS, w
-//                         scattered to a dense per-waypoint vector;
+//                         position-position entries G_i(s, t) of their inverses, D H^2 doubles (0.9 MB at C4: stays in L2).  One
+//                         lane walks the factorisation and the diagonal recurrence; what does not depend on the previous step
+//                         (D_t before, W_t / F_t / the recurrence's coefficients after) is done by all lanes and staged in LDS;
+//   gpmp2_lr_gradient     g_rest (priors + GP factors) and its cost, a lane per (waypoint, joint): nothing in it is sequential,
+//                         so it stays out of the sweeps (formed on the fly there it was 40 of a step's 60 instructions);
+//   gpmp2_lr_sweep<false> u0: lane = (particle, joint) -- 9 particles per wave at D = 7 --, the factor table in LDS (records read
+//                         one step ahead), H steps down and H up with two dependent fma per step; g and the z_t records travel
+//                         through register rings 16 steps ahead (the first version of the round walked the chain inside the
+//                         per-particle kernel with the factors read from L2 one step ahead: 512 L2 round trips in a row per
+//                         particle, 0.91 ms at C4);
+//   gpmp2_lr_cap          per particle, four waves: the active rows compacted by ballot, M (n_a x n_a) from the G table in 16 x 16
+//                         tiles into LDS (three tiles of loads in flight), tile Cholesky (POTRF in registers by readlane, TRSM a
+//                         lane per row, the trailing update on the fp64 MFMA), the right-hand side carried as row n_a, a blocked
+//                         back substitution, w scattered to a dense per-waypoint vector;
 //   gpmp2_lr_sweep<true>  dtheta = A0^-1 (g_rest + V w) and x += step * dtheta.
 // Against the block elimination of rounds 1-5 (mpb_gpmp2.hip: one 16 x 16 fp64 Gauss-Jordan inverse per waypoint and particle, 127
 // of them in a row; 352 MB of W_t records written and read back): ~1.2 MFLOP and ~2 600 dependent pivot steps per particle become
@@ -45,8 +52,10 @@
 
 #define LR_REC 8                       // doubles per (joint, waypoint) record: W00 W01 W11 F00 F01 F10 F11 (pad)
 #define LR_NMAX 127                    // active rows a particle may have (with the right-hand side 128 rows: 36 tiles of 16 x 16 doubles, 72 KB of LDS)
+#ifndef LR_PF
 #define LR_PF 16                       // steps the sweeps read ahead (register rings)
-#define LR_ZREC 3                      // doubles per (waypoint, lane) record of a sweep: z0, z1, (x_pos, x_vel as two floats)
+#endif
+#define LR_ZREC 2                      // doubles per (waypoint, lane) record of a sweep: z0, z1
 
 typedef double lr_d2 __attribute__((ext_vector_type(2)));
 
@@ -96,63 +105,101 @@ __device__ __forceinline__ LrCoef lr_coef(const GpConst& K) {
 // (t, c) and, by symmetry, to (c, t): c short steps instead of the 2 H of a substitution per column.
 // ------------------------------------------------------------------------------------------------
 #define LR_COLS 32
+#define LR_KK 10                       // doubles per waypoint of the chain kernel's coefficient table (nine used; even, so that pairs stay aligned)
 __global__ __launch_bounds__(LR_COLS) void gpmp2_chain_kernel(const double* __restrict__ diag_mean, double* __restrict__ rec_g,
                                                               double* __restrict__ G, int H, int D, GpConst K) {
     extern __shared__ double lds[];
     double* rec = lds;                                 // H x LR_REC
-    double* gd = lds + (size_t)H * LR_REC;             // H x 2: first the damping (position, velocity), then column 0 of G_{t,t}
+    double* gd = lds + (size_t)H * LR_REC;             // H x 2: column 0 of G_{t,t}
+    double* kk = gd + (size_t)H * 2;                   // H x LR_KK: first the chain's diagonal blocks D_t, then the coefficients of the diagonal recurrence
     const int i = blockIdx.x, c0 = blockIdx.y * LR_COLS, tid = threadIdx.x;
     const LrCoef C = lr_coef(K);
     const int dim = 2 * D;
-    // the damping of this joint's position / velocity rows, staged (the sequential loop below must not wait for global memory)
+#ifdef LR_T_CLK
+    unsigned long long clk_[6]; clk_[0] = wall_clock64();
+#define LR_CLK(k) clk_[k] = wall_clock64()
+#else
+#define LR_CLK(k)
+#endif
+    // ONE lane walks the two sequential recurrences below, and a wave issues one fp64 instruction per four cycles whatever the number
+    // of its lanes at work: a step costs its instruction COUNT (measured: 50 instructions a step, 290 cycles), not the depth of its
+    // dependent chain.  So everything that does not depend on the previous step is done by all lanes, before or after, and staged.
+    // D_t = (GP blocks) + damping + start / goal prior, a lane per waypoint
     for (int t = tid; t < H; t += LR_COLS) {
-        gd[2 * t] = K.trust ? K.delta * diag_mean[(size_t)t * dim + i] : K.delta;
-        gd[2 * t + 1] = K.trust ? K.delta * diag_mean[(size_t)t * dim + D + i] : K.delta;
+        const double first = (t == 0) ? 1.0 : 0.0, last = (t == H - 1) ? 1.0 : 0.0;
+        const double dp = K.trust ? K.delta * diag_mean[(size_t)t * dim + i] : K.delta;
+        const double dv = K.trust ? K.delta * diag_mean[(size_t)t * dim + D + i] : K.delta;
+        kk[t * LR_KK] = (1.0 - last) * C.p00 + (1.0 - first) * C.a + dp + first * K.ks + last * K.kg;
+        kk[t * LR_KK + 1] = (1.0 - last) * C.p01 + (1.0 - first) * C.bq;
+        kk[t * LR_KK + 2] = (1.0 - last) * C.p11 + (1.0 - first) * C.cq + dv + first * K.ks + last * K.kg;
     }
     __syncthreads();
+    LR_CLK(1);
     if (tid == 0) {
-        // block Thomas on the 2 x 2 chain of joint i:  S_0 = D_0,  W_t = S_t^-1,  F_t = W_t U,  S_{t+1} = D_{t+1} - U^T W_t U
-        double w00 = 0.0, w01 = 0.0, w11 = 0.0;
+        // block Thomas on the 2 x 2 chain of joint i:  S_0 = D_0,  S_{t+1} = D_{t+1} - U^T S_t^-1 U.  With S^-1 = adj(S) / det,
+        // U^T S^-1 U = N / det where N = U^T adj(S) U is three fma chains with CONSTANT coefficients (products of U's entries):
+        // 9 + 3 (S) + 2 (det) + 5 (reciprocal) instructions a step; S_t and 1 / det are kept, W_t and F_t follow in parallel below.
+        const double c00a = C.u00 * C.u00, c00b = -2.0 * C.u00 * C.u10, c00c = C.u10 * C.u10;                  // N00 = c00a s11 + c00b s01 + c00c s00
+        const double c01a = C.u00 * C.u01, c01b = -(C.u00 * C.u11 + C.u10 * C.u01), c01c = C.u10 * C.u11;      // N01
+        const double c11a = C.u01 * C.u01, c11b = -2.0 * C.u01 * C.u11, c11c = C.u11 * C.u11;                  // N11
+        double s00 = 0.0, s01 = 0.0, s11 = 0.0, idp = 0.0;        // (t = 0: the Schur term vanishes)
+        double e00 = kk[0], e01 = kk[1], e11 = kk[2];
 #pragma unroll 4
-        for (int t = 0; t < H; ++t) {          // (unrolled: the damping reads of later steps issue ahead of the dependent chain)
-            const double first = (t == 0) ? 1.0 : 0.0, last = (t == H - 1) ? 1.0 : 0.0;
-            const double dp = gd[2 * t], dv = gd[2 * t + 1];
-            double s00 = (1.0 - last) * C.p00 + (1.0 - first) * C.a + dp + first * K.ks + last * K.kg;
-            double s01 = (1.0 - last) * C.p01 + (1.0 - first) * C.bq;
-            double s11 = (1.0 - last) * C.p11 + (1.0 - first) * C.cq + dv + first * K.ks + last * K.kg;
-            if (t > 0) {
-                // U^T W U with W symmetric: X = W U, then U^T X
-                const double x00 = w00 * C.u00 + w01 * C.u10, x01 = w00 * C.u01 + w01 * C.u11;
-                const double x10 = w01 * C.u00 + w11 * C.u10, x11 = w01 * C.u01 + w11 * C.u11;
-                s00 -= C.u00 * x00 + C.u10 * x10;
-                s01 -= C.u00 * x01 + C.u10 * x11;
-                s11 -= C.u01 * x01 + C.u11 * x11;
-            }
-            const double id = lr_rcp(fma(s00, s11, -s01 * s01));
-            w00 = s11 * id; w01 = -s01 * id; w11 = s00 * id;
+        for (int t = 0; t < H; ++t) {
+            const double d00 = e00, d01 = e01, d11 = e11;
+            const int tn = (t + 1 < H) ? t + 1 : t;           // the next block is read BEFORE this step's stores (the compiler cannot
+            e00 = kk[tn * LR_KK]; e01 = kk[tn * LR_KK + 1]; e11 = kk[tn * LR_KK + 2];      // tell the two LDS arrays apart)
+            const double n00 = fma(c00a, s11, fma(c00b, s01, c00c * s00));
+            const double n01 = fma(c01a, s11, fma(c01b, s01, c01c * s00));
+            const double n11 = fma(c11a, s11, fma(c11b, s01, c11c * s00));
+            s00 = fma(-n00, idp, d00);
+            s01 = fma(-n01, idp, d01);
+            s11 = fma(-n11, idp, d11);
+            idp = lr_rcp(fma(s00, s11, -s01 * s01));
             double* r = rec + (size_t)t * LR_REC;
-            r[0] = w00; r[1] = w01; r[2] = w11;
-            r[3] = w00 * C.u00 + w01 * C.u10; r[4] = w00 * C.u01 + w01 * C.u11;          // F = W U
-            r[5] = w01 * C.u00 + w11 * C.u10; r[6] = w01 * C.u01 + w11 * C.u11;
-            r[7] = 0.0;
+            r[0] = s00; r[1] = s01; r[2] = s11; r[3] = idp;
         }
+    }
+    __syncthreads();
+    LR_CLK(2);
+    // W_t = adj(S_t) / det,  F_t = W_t U,  and the coefficients of  G_tt = W_t + F_t G_{t+1,t+1} F_t^T  written out in G's three entries
+    for (int t = tid; t < H; t += LR_COLS) {
+        double* r = rec + (size_t)t * LR_REC;
+        const double idp = r[3];
+        const double w00 = r[2] * idp, w01 = -r[1] * idp, w11 = r[0] * idp;
+        const double f00 = w00 * C.u00 + w01 * C.u10, f01 = w00 * C.u01 + w01 * C.u11;
+        const double f10 = w01 * C.u00 + w11 * C.u10, f11 = w01 * C.u01 + w11 * C.u11;
+        r[0] = w00; r[1] = w01; r[2] = w11; r[3] = f00; r[4] = f01; r[5] = f10; r[6] = f11; r[7] = 0.0;
+        double* k = kk + t * LR_KK;
+        k[0] = f00 * f00; k[1] = 2.0 * f00 * f01; k[2] = f01 * f01;
+        k[3] = f00 * f10; k[4] = fma(f00, f11, f01 * f10); k[5] = f01 * f11;
+        k[6] = f10 * f10; k[7] = 2.0 * f10 * f11; k[8] = f11 * f11;
+    }
+    __syncthreads();
+    LR_CLK(3);
+    if (tid == 0) {
         // diagonal blocks of the inverse, bottom up; column 0 (the response to a unit POSITION entry) of each is kept
-        double g00 = w00, g01 = w01, g11 = w11;
+        double g00 = rec[(size_t)(H - 1) * LR_REC], g01 = rec[(size_t)(H - 1) * LR_REC + 1], g11 = rec[(size_t)(H - 1) * LR_REC + 2];
         gd[2 * (H - 1)] = g00; gd[2 * (H - 1) + 1] = g01;
+        const int t0 = (H >= 2) ? H - 2 : 0;
+        double w0 = rec[(size_t)t0 * LR_REC], w1 = rec[(size_t)t0 * LR_REC + 1], w2 = rec[(size_t)t0 * LR_REC + 2];
+        double k0 = kk[t0 * LR_KK], k1 = kk[t0 * LR_KK + 1], k2 = kk[t0 * LR_KK + 2], k3 = kk[t0 * LR_KK + 3], k4 = kk[t0 * LR_KK + 4];
+        double k5 = kk[t0 * LR_KK + 5], k6 = kk[t0 * LR_KK + 6], k7 = kk[t0 * LR_KK + 7], k8 = kk[t0 * LR_KK + 8];
 #pragma unroll 4
         for (int t = H - 2; t >= 0; --t) {
-            const double* r = rec + (size_t)t * LR_REC;
-            const double f00 = r[3], f01 = r[4], f10 = r[5], f11 = r[6];
-            // Y = F G (G symmetric), then Y F^T
-            const double y00 = f00 * g00 + f01 * g01, y01 = f00 * g01 + f01 * g11;
-            const double y10 = f10 * g00 + f11 * g01, y11 = f10 * g01 + f11 * g11;
-            g00 = r[0] + (y00 * f00 + y01 * f01);
-            g01 = r[1] + (y00 * f10 + y01 * f11);
-            g11 = r[2] + (y10 * f10 + y11 * f11);
+            const double n00 = fma(k0, g00, w0) + fma(k2, g11, k1 * g01);
+            const double n01 = fma(k3, g00, w1) + fma(k5, g11, k4 * g01);
+            const double n11 = fma(k6, g00, w2) + fma(k8, g11, k7 * g01);
+            const int tn = (t > 0) ? t - 1 : 0;
+            w0 = rec[(size_t)tn * LR_REC]; w1 = rec[(size_t)tn * LR_REC + 1]; w2 = rec[(size_t)tn * LR_REC + 2];
+            k0 = kk[tn * LR_KK]; k1 = kk[tn * LR_KK + 1]; k2 = kk[tn * LR_KK + 2]; k3 = kk[tn * LR_KK + 3]; k4 = kk[tn * LR_KK + 4];
+            k5 = kk[tn * LR_KK + 5]; k6 = kk[tn * LR_KK + 6]; k7 = kk[tn * LR_KK + 7]; k8 = kk[tn * LR_KK + 8];
+            g00 = n00; g01 = n01; g11 = n11;
             gd[2 * t] = g00; gd[2 * t + 1] = g01;
         }
     }
     __syncthreads();
+    LR_CLK(4);
     if (blockIdx.y == 0)
         for (int e = tid; e < H * LR_REC; e += LR_COLS) rec_g[(size_t)i * H * LR_REC + e] = rec[e];
     const int c = c0 + tid;
@@ -168,162 +215,212 @@ __global__ __launch_bounds__(LR_COLS) void gpmp2_chain_kernel(const double* __re
         Gi[(size_t)t * H + c] = y0;
         Gi[(size_t)c * H + t] = y0;
     }
+#ifdef LR_T_CLK
+    LR_CLK(5);
+    if (blockIdx.x == 0 && c == H - 1)
+        printf("chain clk (10 ns): stage %llu fact %llu post %llu diag %llu cols %llu\n", clk_[1] - clk_[0], clk_[2] - clk_[1], clk_[3] - clk_[2],
+               clk_[4] - clk_[3], clk_[5] - clk_[4]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
-// A0^-1 applied to a gradient: lane = (particle, joint).  FINAL = false: the gradient is g_rest (priors + GP factors,
-// gpmp2.py:355-368 with the rows of cost_functions.py:291-314, :538-554); writes the position rows of u0 = A0^-1 g_rest (t major:
-// upos[t][lane]) and the cost b^T K b of those factors per particle (gpmp2.py:493-495).  FINAL = true: the gradient is
-// g_rest + V w (w: dense per field and waypoint, zero off the active rows); writes x += step * dtheta (gpmp2.py:326-331).
-// Forward r_t = g_t - F_{t-1}^T r_{t-1}, z_t = W_t r_t (records to zbuf, t major, with the lane's x_t beside them); backward
-// y_t = z_t - F_t y_{t+1}.
+// g_rest: the gradient without its collision part (start / goal priors and the GP factors, gpmp2.py:355-368 with the rows of
+// cost_functions.py:291-314, :538-554), fp64, laid out like x ((B, H, 2D)), and the cost b^T K b of those factors per particle
+// (gpmp2.py:493-495).  One wave per particle, lane = waypoint: nothing here depends on anything else, so it is kept OUT of the sweeps
+// (round 6, second version: formed on the fly inside the sweep it was 40 of a step's 60 instructions on the chain every lane walks
+// alone -- a sweep over one particle took 49 us whatever the batch size).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gpmp2_lr_gradient(const float* __restrict__ x, const float* __restrict__ start, const float* __restrict__ goal,
+                                                         double* __restrict__ g, double* __restrict__ gpcost, int B, int H, int D, GpConst K) {
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int dim = 2 * D;
+    const LrCoef C = lr_coef(K);
+    const double dt = K.dt;
+    const float* xb = x + (size_t)b * H * dim;
+    double* gb = g + (size_t)b * H * dim;
+    double cost = 0.0;
+    // a lane per (waypoint, joint), consecutive lanes = consecutive joints of a row: the D positions (and the D velocities) of a
+    // row are read and written as one piece (a lane per waypoint walking the joints touched 64 rows per instruction: 37 us at C4)
+    for (int e = lane; e < H * D; e += 64) {
+        const int t = e / D, j = e - t * D;
+        const float* xt = xb + (size_t)t * dim;
+        const double p = (double)xt[j], v = (double)xt[D + j];
+        double gp = 0.0, gv = 0.0;
+        if (t < H - 1) {        // factor (t, t + 1): e = x_{t+1} - Phi x_t; this row takes Phi^T Qi e
+            const double ep = (double)xt[dim + j] - fma(dt, v, p), ev = (double)xt[dim + D + j] - v;
+            const double qp = fma(C.bq, ev, C.a * ep), qv = fma(C.cq, ev, C.bq * ep);
+            gp = qp;
+            gv = fma(dt, qp, qv);
+            cost += fma(ep, qp, ev * qv);
+        }
+        if (t > 0) {            // factor (t - 1, t): this row takes -Qi e
+            const double pl = (double)xt[j - dim], vl = (double)xt[D + j - dim];
+            const double ep = p - fma(dt, vl, pl), ev = v - vl;
+            gp -= fma(C.bq, ev, C.a * ep);
+            gv -= fma(C.cq, ev, C.bq * ep);
+        }
+        if (t == 0) {
+            const double ep = (double)start[(size_t)b * dim + j] - p, ev = (double)start[(size_t)b * dim + D + j] - v;
+            gp = fma(K.ks, ep, gp); gv = fma(K.ks, ev, gv);
+            cost += K.ks * fma(ep, ep, ev * ev);
+        }
+        if (t == H - 1) {
+            const double ep = (double)goal[(size_t)b * dim + j] - p, ev = (double)goal[(size_t)b * dim + D + j] - v;
+            gp = fma(K.kg, ep, gp); gv = fma(K.kg, ev, gv);
+            cost += K.kg * fma(ep, ep, ev * ev);
+        }
+        gb[(size_t)t * dim + j] = gp;
+        gb[(size_t)t * dim + D + j] = gv;
+    }
+    cost = wave_sum_f64(cost);
+    if (lane == 0) gpcost[b] = cost;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A0^-1 applied to a gradient: lane = (particle, joint) -- 9 particles per wave at D = 7 --, the shared factors in LDS.
+// FINAL = false: the gradient is g_rest; writes the position rows of u0 = A0^-1 g_rest (t major: upos[t][lane]).
+// FINAL = true: the gradient is g_rest + V w (w: dense per field and waypoint, zero off the active rows); writes x += step * dtheta
+// (gpmp2.py:326-331).  Forward r_t = g_t - F_{t-1}^T r_{t-1}, z_t = W_t r_t (records to zbuf, t major); backward
+// y_t = z_t - F_t y_{t+1}.  A lane walks its chain alone (the kernel lasts 2 H steps whatever the batch): a step is the ring
+// hand-over of what it reads (16 steps ahead), four fma on the chain, four off it, one record store.
 // ------------------------------------------------------------------------------------------------
 template <bool FINAL>
-__global__ __launch_bounds__(64) void gpmp2_lr_sweep(float* __restrict__ x, const float* __restrict__ start, const float* __restrict__ goal,
-                                                     const float* __restrict__ jac, const double* __restrict__ wdense,
-                                                     const double* __restrict__ rec_g, double* __restrict__ zbuf, double* __restrict__ upos,
-                                                     double* __restrict__ gpcost, int B, int H, int D, int F, GpConst K) {
+__global__ __launch_bounds__(64) void gpmp2_lr_sweep(float* __restrict__ x, const double* __restrict__ g, const float* __restrict__ jac,
+                                                     const double* __restrict__ wdense, const double* __restrict__ rec_g,
+                                                     double* __restrict__ zbuf, double* __restrict__ upos, int B, int H, int D, int F, GpConst K) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x, dim = 2 * D;
     const int per = 64 / D;                                   // particles per wave
     const int stride = H * LR_REC + 2;                        // doubles between two joints' tables (+ 2: their records fall on different banks)
-    for (int e = lane; e < D * H * (LR_REC / 2); e += 64) {   // the shared factors into LDS, 16 bytes at a time
-        const int j = e / (H * (LR_REC / 2)), r = e - j * (H * (LR_REC / 2));
-        reinterpret_cast<lr_d2*>(lds + (size_t)j * stride)[r] = reinterpret_cast<const lr_d2*>(rec_g + (size_t)j * H * LR_REC)[r];
+    // the shared factors into LDS, 16 bytes at a time, EIGHT loads in flight per lane and joint (one load per trip with its index
+    // division cost the kernel ~30 us of serialised L2 round trips before its first step: a sweep took 43 us whatever it did per step)
+    for (int j = 0; j < D; ++j) {
+        const lr_d2* src = reinterpret_cast<const lr_d2*>(rec_g + (size_t)j * H * LR_REC);
+        lr_d2* dst = reinterpret_cast<lr_d2*>(lds + (size_t)j * stride);
+        const int n2 = H * (LR_REC / 2);
+        for (int e0 = 0; e0 < n2; e0 += 64 * 8) {
+            lr_d2 tmp[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + lane + 64 * u;
+                tmp[u] = src[e < n2 ? e : n2 - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + lane + 64 * u;
+                if (e < n2) dst[e] = tmp[u];
+            }
+        }
     }
     __syncthreads();
     const int pl = lane / D, i = lane - pl * D;
     const int p = blockIdx.x * per + pl;
-    const bool live = pl < per && p < B;
-    const int pc = live ? p : 0;                              // idle lanes shadow particle 0 (loads only; nothing is stored)
+    if (pl >= per || p >= B) return;                          // (no block barrier below: idle lanes leave, nothing is masked per step)
+    const bool live = true;
+    const int pc = p;
     const size_t NL = (size_t)B * D;                          // lanes of the whole batch: the t-major arrays' row length
     const size_t gl = (size_t)pc * D + i;
-    const LrCoef C = lr_coef(K);
-    const double dt = K.dt;
-    const float* xb = x + (size_t)pc * H * dim;
+    const double* gb = g + (size_t)pc * H * dim;
     const double* tab = lds + (size_t)i * stride;
     const float* jb = jac + (size_t)pc * H * (D + 1);
     const double* wb = wdense + (size_t)pc * H;
-    // ---- forward.  Per step ~25 fp64 instructions on the wave's critical path (the sweep is bound by their issue, not by memory:
-    //      everything it reads arrives through the rings): e_t and Qi e_t of factor (t, t + 1) once -- the row's share of factor
-    //      (t - 1, t) is the previous step's Qi e, carried --, two fma per component of r_t, z_t = W_t r_t.
-    float rp_[LR_PF], rv_[LR_PF], rh_[LR_PF];
-    double rw_[LR_PF];
+    // ---- forward
+    double rg0_[LR_PF], rg1_[LR_PF], rw_[LR_PF];
+    float rh_[LR_PF];
 #pragma unroll
-    for (int u = 0; u < LR_PF; ++u) {           // ring slot u <- waypoint 1 + u (what step u needs as its right neighbour)
-        const int tn = (1 + u < H) ? 1 + u : H - 1;
-        rp_[u] = xb[(size_t)tn * dim + i];
-        rv_[u] = xb[(size_t)tn * dim + D + i];
-        if (FINAL) {                            // (h w of waypoint u itself)
-            const int tc = (u < H) ? u : H - 1;
+    for (int u = 0; u < LR_PF; ++u) {           // ring slot u <- waypoint u
+        const int tc = (u < H) ? u : H - 1;
+        rg0_[u] = gb[(size_t)tc * dim + i];
+        rg1_[u] = gb[(size_t)tc * dim + D + i];
+        if (FINAL) {
             rh_[u] = jb[(size_t)tc * (D + 1) + i];
             rw_[u] = wb[tc];
         }
     }
-    const double s_p = (double)start[(size_t)pc * dim + i], s_v = (double)start[(size_t)pc * dim + D + i];
-    const double g_p = (double)goal[(size_t)pc * dim + i], g_v = (double)goal[(size_t)pc * dim + D + i];
-    float pf = xb[i], vf = xb[D + i];
-    double pcur = (double)pf, vcur = (double)vf;
-    // the priors without a branch in the loop: row 0 takes +ks (start - x_0) -- carried in as the "previous factor" of step 0 (the
-    // row's gradient is Phi^T q_t - q_{t-1}) --, row H - 1 takes +kg (goal - x_{H-1}) as the virtual q of its missing factor
-    double qpl = -K.ks * (s_p - pcur), qvl = -K.ks * (s_v - vcur);
-    double r0 = 0.0, r1 = 0.0, f00 = 0.0, f01 = 0.0, f10 = 0.0, f11 = 0.0, cost = 0.0;
-    if (!FINAL) cost = K.ks * fma(s_p - pcur, s_p - pcur, (s_v - vcur) * (s_v - vcur));
+    double r0 = 0.0, r1 = 0.0, f00 = 0.0, f01 = 0.0, f10 = 0.0, f11 = 0.0;
+    // the joint's factor record of the CURRENT step, read from LDS one step ahead (R0 .. R3 = W00 W01 | W11 F00 | F01 F10 | F11 -):
+    // read in the step that uses it, the LDS round trip sat on every step of the chain (~100 of a step's ~290 cycles)
+    const lr_d2* tab2 = reinterpret_cast<const lr_d2*>(tab);
+    lr_d2 R0 = tab2[0], R1 = tab2[1], R2 = tab2[2], R3 = tab2[3];
     double* zr = zbuf + gl * LR_ZREC;
     const size_t zstep = NL * LR_ZREC;
     // (the ring slots must be (re)defined OUTSIDE any conditional: a slot loaded under `if (t < H)` reaches the next trip through a
     // phi, the copy that resolves it sits at the end of the defining block and waits for the load it has just issued -- the first
-    // build of this kernel ran one memory round trip per step, 111 us.  Whole blocks of LR_PF steps carry no guard; the tail does.)
+    // build of this kernel ran one memory round trip per step.  Whole blocks of LR_PF steps carry no guard; the tail does.)
     auto fwd_step = [&](auto uc, int t) {
                 constexpr int u = decltype(uc)::value;
-                const float pnf = rp_[u], vnf = rv_[u];
-                double hw = 0.0;
-                if (FINAL) hw = (double)rh_[u] * rw_[u];
+#ifdef LR_T_NOLOAD     // (wrong-result timing switch, tuning builds only: the sweep without its ring loads)
+                double gp = 1.0;
+                const double gv = 0.5;
+#else
+                double gp = rg0_[u];
+                const double gv = rg1_[u];
+#endif
+                if (FINAL) gp = fma((double)rh_[u], rw_[u], gp);          // (row 0: h = 0 and w = 0)
                 {
-                    const int tn = (t + 1 + LR_PF < H) ? t + 1 + LR_PF : H - 1;
-                    rp_[u] = xb[(size_t)tn * dim + i];
-                    rv_[u] = xb[(size_t)tn * dim + D + i];
+                    const int tc = (t + LR_PF < H) ? t + LR_PF : H - 1;
+                    rg0_[u] = gb[(size_t)tc * dim + i];
+                    rg1_[u] = gb[(size_t)tc * dim + D + i];
                     if (FINAL) {
-                        const int tc = (t + LR_PF < H) ? t + LR_PF : H - 1;
                         rh_[u] = jb[(size_t)tc * (D + 1) + i];
                         rw_[u] = wb[tc];
                     }
                 }
-                const double pn = (double)pnf, vn = (double)vnf;
-                double qp, qv;
-                if (t < H - 1) {        // factor (t, t + 1): e = x_{t+1} - Phi x_t; Qi e      (wave-uniform branch)
-                    const double ep = pn - fma(dt, vcur, pcur), ev = vn - vcur;
-                    qp = fma(C.bq, ev, C.a * ep);
-                    qv = fma(C.cq, ev, C.bq * ep);
-                    if (!FINAL) cost += fma(ep, qp, ev * qv);
-                } else {                // the goal prior as the virtual q with Phi^T q = kg (goal - x)
-                    const double ep = g_p - pcur, ev = g_v - vcur;
-                    qp = K.kg * ep;
-                    qv = fma(-dt, qp, K.kg * ev);
-                    if (!FINAL) cost += K.kg * fma(ep, ep, ev * ev);
-                }
-                // this row takes Phi^T Qi e of its own factor and -Qi e of the previous one
-                double gp = qp - qpl, gv = fma(dt, qp, qv) - qvl;
-                qpl = qp; qvl = qv;
                 if (FINAL) {
-                    gp += hw;           // (row 0: h = 0 and w = 0)
                     for (int f = 1; f < F; ++f)          // further chained fields (rare: not prefetched)
                         gp = fma((double)jac[(((size_t)f * B + pc) * H + t) * (D + 1) + i], wdense[((size_t)f * B + pc) * H + t], gp);
                 }
-                const double* rc = tab + (size_t)t * LR_REC;
+                const lr_d2* rn = tab2 + (size_t)((t + 1 < H) ? t + 1 : t) * (LR_REC / 2);
+                const lr_d2 N0 = rn[0], N1 = rn[1], N2 = rn[2], N3 = rn[3];
                 const double a0 = fma(-f10, r1, fma(-f00, r0, gp)), a1 = fma(-f11, r1, fma(-f01, r0, gv));
                 r0 = a0; r1 = a1;
-                const double z0 = fma(rc[1], r1, rc[0] * r0), z1 = fma(rc[2], r1, rc[1] * r0);
-                f00 = rc[3]; f01 = rc[4]; f10 = rc[5]; f11 = rc[6];
-                if (live) {
-                    zr[0] = z0; zr[1] = z1;
-                    zr[2] = __longlong_as_double(((unsigned long long)__float_as_uint(vf) << 32) | __float_as_uint(pf));
-                }
+                const double z0 = fma(R0.y, r1, R0.x * r0), z1 = fma(R1.x, r1, R0.y * r0);
+                f00 = R1.y; f01 = R2.x; f10 = R2.y; f11 = R3.x;
+                R0 = N0; R1 = N1; R2 = N2; R3 = N3;
+#ifndef LR_T_NOSTORE   // (wrong-result timing switch, tuning builds only)
+                if (live) *reinterpret_cast<lr_d2*>(zr) = lr_d2{z0, z1};
+#else
+                if (live && t == 0) *reinterpret_cast<lr_d2*>(zr) = lr_d2{z0, z1};
+#endif
                 zr += zstep;
-                pcur = pn; vcur = vn; pf = pnf; vf = vnf;
     };
     int tb = 0;
     for (; tb + LR_PF <= H; tb += LR_PF) lr_static_for<0, LR_PF>([&](auto uc) { fwd_step(uc, tb + decltype(uc)::value); });
     lr_static_for<0, LR_PF>([&](auto uc) {
         if (tb + decltype(uc)::value < H) fwd_step(uc, tb + decltype(uc)::value);         // (wave-uniform)
     });
-    if (!FINAL) {
-        // the particle's share of the cost: the sum over its D lanes (a wave reduction would mix particles): through LDS
-        double* red = lds + (size_t)D * stride;
-        red[lane] = cost;
-        __syncthreads();
-        if (live && i == 0) {
-            double s = 0.0;
-            for (int j = 0; j < D; ++j) s += red[lane + j];
-            gpcost[p] = s;
-        }
-    }
-    // ---- backward: records H - 1 .. 0 through the ring
-    double q0[LR_PF], q1[LR_PF], q2[LR_PF];
+    // ---- backward: records H - 1 .. 0 through the ring (FINAL: the lane's x beside them)
+    lr_d2 q_[LR_PF];
+    float xp_[LR_PF], xv_[LR_PF];
+    const float* xb = x + (size_t)pc * H * dim;
 #pragma unroll
     for (int u = 0; u < LR_PF; ++u) {
         const int t = (H - 1 - u >= 0) ? H - 1 - u : 0;
-        const double* zr = zbuf + ((size_t)t * NL + gl) * LR_ZREC;
-        q0[u] = zr[0]; q1[u] = zr[1]; q2[u] = zr[2];
+        q_[u] = *reinterpret_cast<const lr_d2*>(zbuf + ((size_t)t * NL + gl) * LR_ZREC);
+        if (FINAL) { xp_[u] = xb[(size_t)t * dim + i]; xv_[u] = xb[(size_t)t * dim + D + i]; }
     }
     double y0 = 0.0, y1 = 0.0;            // (y_H = 0: the first step takes z_{H-1} as it is)
+    R1 = tab2[(size_t)(H - 1) * (LR_REC / 2) + 1]; R2 = tab2[(size_t)(H - 1) * (LR_REC / 2) + 2]; R3 = tab2[(size_t)(H - 1) * (LR_REC / 2) + 3];
     auto bwd_step = [&](auto uc, int t) {
                 constexpr int u = decltype(uc)::value;
-                const double z0 = q0[u], z1 = q1[u], xx = q2[u];
+                const lr_d2 zz = q_[u];
+                float xp = 0.f, xv = 0.f;
+                if (FINAL) { xp = xp_[u]; xv = xv_[u]; }
                 {
                     const int tn = (t - LR_PF >= 0) ? t - LR_PF : 0;
-                    const double* zq = zbuf + ((size_t)tn * NL + gl) * LR_ZREC;
-                    q0[u] = zq[0]; q1[u] = zq[1]; q2[u] = zq[2];
+                    q_[u] = *reinterpret_cast<const lr_d2*>(zbuf + ((size_t)tn * NL + gl) * LR_ZREC);
+                    if (FINAL) { xp_[u] = xb[(size_t)tn * dim + i]; xv_[u] = xb[(size_t)tn * dim + D + i]; }
                 }
-                const double* rc = tab + (size_t)t * LR_REC;
-                const double a0 = fma(-rc[4], y1, fma(-rc[3], y0, z0)), a1 = fma(-rc[6], y1, fma(-rc[5], y0, z1));
+                const lr_d2* rn = tab2 + (size_t)((t > 0) ? t - 1 : 0) * (LR_REC / 2);
+                const lr_d2 N1 = rn[1], N2 = rn[2], N3 = rn[3];
+                const double a0 = fma(-R2.x, y1, fma(-R1.y, y0, zz.x)), a1 = fma(-R3.x, y1, fma(-R2.y, y0, zz.y));
                 y0 = a0; y1 = a1;
+                R1 = N1; R2 = N2; R3 = N3;
                 if (live) {
                     if (FINAL) {
-                        const unsigned long long xu = __double_as_longlong(xx);
-                        const double xp = (double)__uint_as_float((unsigned)xu), xv = (double)__uint_as_float((unsigned)(xu >> 32));
-                        x[((size_t)p * H + t) * dim + i] = (float)(xp + K.step * y0);
-                        x[((size_t)p * H + t) * dim + D + i] = (float)(xv + K.step * y1);
+                        x[((size_t)p * H + t) * dim + i] = (float)((double)xp + K.step * y0);
+                        x[((size_t)p * H + t) * dim + D + i] = (float)((double)xv + K.step * y1);
                     } else {
                         upos[(size_t)t * NL + gl] = y0;
                     }
@@ -458,7 +555,16 @@ __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ ja
     {
         const double ikc = 1.0 / K.kc;
         const int r = tid >> 4, c = tid & 15;
-        auto fetch = [&](int I, int J, double (&gv)[MPB_MAX_DOF]) {
+        // tile q of the lower triangle, row major: (I, J) with q = I (I + 1) / 2 + J
+        auto tile_of = [](int q, int& I, int& J) {
+            I = (int)((__builtin_sqrtf(8.f * (float)q + 1.f) - 1.f) * 0.5f);
+            while ((I + 1) * (I + 2) / 2 <= q) ++I;
+            while (I * (I + 1) / 2 > q) --I;
+            J = q - I * (I + 1) / 2;
+        };
+        auto fetch = [&](int q, double (&gv)[MPB_MAX_DOF]) {
+            int I, J;
+            tile_of(q < ntl ? q : ntl - 1, I, J);
             int a = 16 * I + r, cc = 16 * J + c;
             if (cc > a) { const int t_ = a; a = cc; cc = t_; }              // (diagonal tiles are stored full: mirror)
             const bool on = a < n;
@@ -466,13 +572,9 @@ __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ ja
 #pragma unroll
             for (int j = 0; j < MPB_MAX_DOF; ++j) gv[j] = (j < D) ? Gst[(size_t)j * H * H] : 0.0;
         };
-        double gcur[MPB_MAX_DOF], gnxt[MPB_MAX_DOF];
-        int I = 0, J = 0;
-        fetch(0, 0, gcur);
-        for (int q = 0; q < ntl; ++q) {
-            int In = I, Jn = J + 1;
-            if (Jn > In) { ++In; Jn = 0; }
-            if (q + 1 < ntl) fetch(In, Jn, gnxt);
+        auto emit = [&](int q, const double (&gv)[MPB_MAX_DOF]) {
+            int I, J;
+            tile_of(q, I, J);
             int a = 16 * I + r, cc = 16 * J + c;
             if (cc > a) { const int t_ = a; a = cc; cc = t_; }
             double m;
@@ -480,23 +582,41 @@ __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ ja
                 m = (a == cc) ? ikc : 0.0;
 #pragma unroll
                 for (int j = 0; j < MPB_MAX_DOF; ++j)
-                    if (j < D) m = fma((double)hb[a * hs + j] * (double)hb[cc * hs + j], gcur[j], m);
+                    if (j < D) m = fma((double)hb[a * hs + j] * (double)hb[cc * hs + j], gv[j], m);
             } else if (a == n && cc < n) {
                 m = wv[cc];
             } else {
                 m = (a == cc) ? 1.0 : 0.0;
             }
             Tl[(size_t)lr_tile(I, J) * LR_TILE + lr_sw(r, c)] = m;
-#pragma unroll
-            for (int j = 0; j < MPB_MAX_DOF; ++j) gcur[j] = gnxt[j];
-            I = In; J = Jn;
+        };
+        // THREE tiles' G entries (L2, ~1 us) in flight per thread (one tile ahead, the loop paid most of a round trip per tile: 28 us
+        // of the 95 a particle with 116 active rows took)
+        double g0[MPB_MAX_DOF], g1[MPB_MAX_DOF], g2[MPB_MAX_DOF];
+        fetch(0, g0);
+        fetch(1, g1);
+        fetch(2, g2);
+#ifdef LR_T_CAP_NOASM      // (wrong-result timing switch, tuning builds only: the first tile alone)
+        const int ntl_run = 1;
+#else
+        const int ntl_run = ntl;
+#endif
+        for (int q = 0; q < ntl_run; q += 3) {
+            emit(q, g0);
+            fetch(q + 3, g0);
+            if (q + 1 < ntl_run) { emit(q + 1, g1); fetch(q + 4, g1); }
+            if (q + 2 < ntl_run) { emit(q + 2, g2); fetch(q + 5, g2); }
         }
     }
     __syncthreads();
     // ---- 4. tile Cholesky
     const int TC = (n + 15) >> 4;                                // tile columns with a pivot
     const int li = lane & 15, lk = lane >> 4;
+#ifdef LR_T_CAP_NOCHOL     // (wrong-result timing switch, tuning builds only)
+    for (int J = 0; J < 1; ++J) {
+#else
     for (int J = 0; J < TC; ++J) {
+#endif
         double* Djj = Tl + (size_t)lr_tile(J, J) * LR_TILE;
         if (wave == 0) {
             // POTRF: lane r < 16 holds row r of the diagonal tile
@@ -572,7 +692,10 @@ __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ ja
         }
         __syncthreads();
     }
-    // ---- 5. L^T w = y (y = row n), column oriented, one wave: w_k = y_k / l_kk, then y_j -= l_kj w_k for j < k (lanes = j, j + 64)
+    // ---- 5. L^T w = y (y = row n), one wave, a tile row at a time from the last: the 16 x 16 triangular system of the row's diagonal
+    //         tile with its entries in registers (lane j < 16 holds L[16 K + k][16 K + j], k = 0 .. 15: sixteen steps of readlane, mul,
+    //         fma), then y_j -= sum_k L[16 K + k][j] w_k for every j of the earlier tile rows (lanes = j, j + 64: sixteen independent
+    //         fma per lane).  (Column by column over all n with the L reads inside the dependent loop: 21 us at n = 116.)
     if (wave == 0) {
         const int In = n >> 4, rn = n & 15;
         double y[2];
@@ -581,15 +704,44 @@ __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ ja
             const int j = lane + 64 * ps;
             y[ps] = (j < n) ? Tl[(size_t)lr_tile(In, j >> 4) * LR_TILE + lr_sw(rn, j & 15)] : 0.0;
         }
-        for (int k = n - 1; k >= 0; --k) {
-            const double yk = (k < 64) ? lr_readlane(y[0], k) : lr_readlane(y[1], k - 64);
-            const double wk = yk * dinv[k];
-            if (lane == 0) wv[k] = wk;
-            const double* Lk = Tl + (size_t)lr_tile(k >> 4, 0) * LR_TILE;       // tile row of k
+#ifdef LR_T_CAP_NOBACK     // (wrong-result timing switch, tuning builds only)
+        for (int Kt = 0; Kt >= 0; --Kt) {
+#else
+        for (int Kt = TC - 1; Kt >= 0; --Kt) {
+#endif
+            const double* Dk = Tl + (size_t)lr_tile(Kt, Kt) * LR_TILE;
+            const int jl = lane & 15;
+            double Lc[16], di[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                Lc[k] = Dk[lr_sw(k, jl)];                                  // L[16 Kt + k][16 Kt + jl]
+                di[k] = (16 * Kt + k < n) ? dinv[16 * Kt + k] : 0.0;      // (padding columns: w = 0)
+            }
+            // this tile row's y in lanes 0 .. 15 of a register of its own
+            const int src = 16 * Kt + jl;
+            double yt = (src < 64) ? __shfl(y[0], src & 63, 64) : __shfl(y[1], (src - 64) & 63, 64);
+            double wk[16];
+            lr_static_for<0, 16>([&](auto kc) {
+                constexpr int k = 15 - decltype(kc)::value;
+                wk[k] = lr_readlane(yt, k) * di[k];
+                yt = fma(-Lc[k], wk[k], yt);                               // (lanes jl >= k: discarded)
+            });
+            if (lane < 16 && 16 * Kt + lane < n) {
+                double wl = 0.0;
+                lr_static_for<0, 16>([&](auto kc) { if (decltype(kc)::value == lane) wl = wk[decltype(kc)::value]; });
+                wv[16 * Kt + lane] = wl;
+            }
+            // earlier tile rows: y_j -= sum_k L[16 Kt + k][j] w_k
+            const double* Lrow = Tl + (size_t)lr_tile(Kt, 0) * LR_TILE;
 #pragma unroll
             for (int ps = 0; ps < 2; ++ps) {
                 const int j = lane + 64 * ps;
-                if (j < k) y[ps] = fma(-Lk[(size_t)(j >> 4) * LR_TILE + lr_sw(k & 15, j & 15)], wk, y[ps]);
+                if (j < 16 * Kt) {
+                    double acc = y[ps];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) acc = fma(-Lrow[(size_t)(j >> 4) * LR_TILE + lr_sw(k, j & 15)], wk[k], acc);
+                    y[ps] = acc;
+                }
             }
         }
     }
@@ -606,7 +758,8 @@ bool mpb_gpmp2_lr_ok(int H, int D, int n_fields) { return H >= 2 && D >= 1 && D 
 // doubles of workspace: shared tables (factor records, G) + per-batch arrays (sweep records, u0's position rows, w, the GP cost)
 size_t mpb_gpmp2_lr_ws_doubles(int B, int H, int D) {
     const size_t NL = (size_t)B * D;
-    return (size_t)D * H * LR_REC + (size_t)D * H * H + (size_t)H * NL * LR_ZREC + (size_t)H * NL + (size_t)MPB_GP_MAX_FIELDS * B * H + (size_t)B + 64;
+    return (size_t)D * H * LR_REC + (size_t)D * H * H + (size_t)H * NL * LR_ZREC + (size_t)H * NL + (size_t)MPB_GP_MAX_FIELDS * B * H + (size_t)B + 64 +
+           (size_t)B * H * 2 * D;          // ... and g_rest
 }
 
 int mpb_gpmp2_lr_launch(float* x, const float* start, const float* goal, const float* jac, const double* diag_mean, double* ws,
@@ -618,18 +771,18 @@ int mpb_gpmp2_lr_launch(float* x, const float* start, const float* goal, const f
     double* upos = zbuf + (size_t)H * NL * LR_ZREC;
     double* wdense = upos + (size_t)H * NL;
     double* gpcost = wdense + (size_t)MPB_GP_MAX_FIELDS * B * H;
-    const size_t lds_chain = ((size_t)H * LR_REC + (size_t)H * 2) * sizeof(double);
+    double* grest = gpcost + B + 64;
+    const size_t lds_chain = ((size_t)H * LR_REC + (size_t)H * 2 + (size_t)H * LR_KK) * sizeof(double);
     hipLaunchKernelGGL(gpmp2_chain_kernel, dim3(D, (H + LR_COLS - 1) / LR_COLS), dim3(LR_COLS), lds_chain, stream, diag_mean, rec, G, H, D, K);
     const int per = 64 / D;
-    const size_t lds_sweep = ((size_t)D * (H * LR_REC + 2) + 64) * sizeof(double);
+    const size_t lds_sweep = (size_t)D * (H * LR_REC + 2) * sizeof(double);
     const dim3 gs((B + per - 1) / per);
-    hipLaunchKernelGGL(gpmp2_lr_sweep<false>, gs, dim3(64), lds_sweep, stream, x, start, goal, jac, wdense, rec, zbuf, upos, gpcost, B, H, D,
-                       n_fields, K);
+    hipLaunchKernelGGL(gpmp2_lr_gradient, dim3((B + 3) / 4), dim3(256), 0, stream, x, start, goal, grest, gpcost, B, H, D, K);
+    hipLaunchKernelGGL(gpmp2_lr_sweep<false>, gs, dim3(64), lds_sweep, stream, x, grest, jac, wdense, rec, zbuf, upos, B, H, D, n_fields, K);
     const int n_max = n_fields * (H - 1);
     const int trm = (n_max + 16) >> 4, ntm = (trm * (trm + 1)) >> 1;             // tiles of the largest system the shape allows
     const size_t lds = ((size_t)ntm * LR_TILE + 256) * sizeof(double) + (size_t)LR_NMAX * (D <= 8 ? 8 : MPB_MAX_DOF) * sizeof(float) + (256 + 16) * sizeof(int);
     hipLaunchKernelGGL(gpmp2_lr_cap, dim3(B), dim3(256), lds, stream, jac, upos, G, gpcost, wdense, costs_out, B, H, D, n_fields, ntm, K);
-    hipLaunchKernelGGL(gpmp2_lr_sweep<true>, gs, dim3(64), lds_sweep, stream, x, start, goal, jac, wdense, rec, zbuf, upos, gpcost, B, H, D,
-                       n_fields, K);
+    hipLaunchKernelGGL(gpmp2_lr_sweep<true>, gs, dim3(64), lds_sweep, stream, x, grest, jac, wdense, rec, zbuf, upos, B, H, D, n_fields, K);
     return MPB_OK;
 }
