@@ -178,7 +178,9 @@ __global__ __launch_bounds__(LR_COLS) void gpmp2_chain_kernel(const double* __re
     __syncthreads();
     LR_CLK(3);
     if (tid == 0) {
-        // diagonal blocks of the inverse, bottom up; column 0 (the response to a unit POSITION entry) of each is kept
+        // diagonal blocks of the inverse, bottom up; column 0 (the response to a unit POSITION entry) of each is kept.  This block
+        // walks columns c0 .. c0 + 31 only, so the recurrence stops at c0 (the block of the last columns has the longest walks
+        // and the shortest recurrence)
         double g00 = rec[(size_t)(H - 1) * LR_REC], g01 = rec[(size_t)(H - 1) * LR_REC + 1], g11 = rec[(size_t)(H - 1) * LR_REC + 2];
         gd[2 * (H - 1)] = g00; gd[2 * (H - 1) + 1] = g01;
         const int t0 = (H >= 2) ? H - 2 : 0;
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(LR_COLS) void gpmp2_chain_kernel(const double* __re
         double k0 = kk[t0 * LR_KK], k1 = kk[t0 * LR_KK + 1], k2 = kk[t0 * LR_KK + 2], k3 = kk[t0 * LR_KK + 3], k4 = kk[t0 * LR_KK + 4];
         double k5 = kk[t0 * LR_KK + 5], k6 = kk[t0 * LR_KK + 6], k7 = kk[t0 * LR_KK + 7], k8 = kk[t0 * LR_KK + 8];
 #pragma unroll 4
-        for (int t = H - 2; t >= 0; --t) {
+        for (int t = H - 2; t >= c0; --t) {
             const double n00 = fma(k0, g00, w0) + fma(k2, g11, k1 * g01);
             const double n01 = fma(k3, g00, w1) + fma(k5, g11, k4 * g01);
             const double n11 = fma(k6, g00, w2) + fma(k8, g11, k7 * g01);

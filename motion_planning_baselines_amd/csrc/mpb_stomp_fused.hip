@@ -35,6 +35,7 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <type_traits>
 #include <chrono>
 
 #include "mpb_common.h"
@@ -81,7 +82,16 @@ extern "C" int mpb_debug_read_lstamps(unsigned long long* dst, int n) {
 #define LSTAMP(k)
 #endif
 
-template <int DCH>
+// PRE: the exchange layout's speculative copy of the partners' partials (below: "exchange prefetch"), a kilobyte per wave
+#ifdef FUSED_T_PRE_STATS   // tuning build: lanes x iterations whose prefetched granules were stale, by wave
+__device__ unsigned g_pre_miss[FUSED_WAVES];
+extern "C" int mpb_debug_read_pre_miss(unsigned* dst) {
+    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_pre_miss), sizeof(unsigned) * FUSED_WAVES) != hipSuccess) return 3;
+    unsigned z[FUSED_WAVES] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_pre_miss), z, sizeof(z)) == hipSuccess ? 0 : 3;
+}
+#endif
+template <int DCH, bool PRE>
 struct FusedSmem {
     float4 otab[MPB_GRID_MAX_SPH + 1];                       //  1 KB: obstacle table + the far dummy
     unsigned gridw[MPB_GRID_MAX_CELLS];                      // 16 KB: broad-phase grid (offset words)
@@ -94,6 +104,8 @@ struct FusedSmem {
     unsigned s_ticket;
     unsigned pad_[2];
     float tiles[FUSED_WAVES * 64 * NT_STRIDE];               // 80 KB: the waves' sample tiles
+    __attribute__((aligned(16))) granule_t pre[PRE ? FUSED_WAVES * 128 : 2];     // 16 KB: per wave, its 64 elements' granules of chunks 0 and 1
+    __attribute__((aligned(16))) granule_t premz[PRE ? FUSED_WAVES * 4 : 2];     // per wave: (m, z) of chunks 0 and 1
 };
 
 // NB = 1: the unit is (particle, chunk of 16 samples), partners exchange partials through the workspace (above).
@@ -122,7 +134,16 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
     // constants of the other phases sit in the first 64 KB, where an LDS instruction's 16-bit offset field reaches them (left
     // to the linker the table landed at 141 536: a v_add per read to form the address, four per group of spheres and trip);
     // the 80 KB of sample tiles come last
-    __shared__ __attribute__((aligned(16))) FusedSmem<DCH> sm;
+    // exchange prefetch: the layout with partners, one rollout per draw (the paired draw of d <= 8 leaves half the waves out of
+    // the noise phase; not built for it)
+    // (nor for the table-driven robot and the injected-noise instantiations: they sit at the register budget, and the handful of
+    // address registers of the prefetch tipped 10-19 VGPRs of theirs into scratch)
+#ifdef FUSED_NO_PRE   // (A/B builds)
+    constexpr bool PRE = false;
+#else
+    constexpr bool PRE = NB == 1 && 2 * DCH > 16 && MODEL != 0 && !INJ;
+#endif
+    __shared__ __attribute__((aligned(16))) FusedSmem<DCH, PRE> sm;
     float4 (&otab)[MPB_GRID_MAX_SPH + 1] = sm.otab;
     unsigned (&gridw)[MPB_GRID_MAX_CELLS] = sm.gridw;
     unsigned (&Limg)[STOMP_LIMG_WORDS] = sm.Limg;
@@ -236,6 +257,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
 
     LSTAMP(3);
     const int n_run = s_abort ? 0 : n_iters;          // (block-uniform: written before the barriers above)
+#ifdef FUSED_T_PRE_STATS
+    int pre_miss_ = 0;
+#endif
     for (int it = 0; it < n_run; ++it) {
         // (NB > 1) partials of the batches, as the exchange path would publish them
         float pm0 = -3.0e38f, pz0 = 0.f, pe0 = 0.f, pm1 = -3.0e38f, pz1 = 0.f, pe1 = 0.f;
@@ -407,6 +431,12 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         if (tq < N) delta[cc * FUSED_LD + hh] = dpart;
         __syncthreads();                                                     // (2) the samples in the tiles are consumed, delta complete
         if (wave < 4) {
+            // (round 6: at the highest issue priority.  These four waves left the previous noise phase at priority 0 and the other
+            // twelve enter the next one at 3: the product and the partner's granules waited until the draws were through --
+            // the stats build of the exchange prefetch showed the publish landing in the second half of the phase)
+#ifndef FUSED_NO_PUBPRIO
+            if (NB == 1) __builtin_amdgcn_s_setprio(3);
+#endif
             const int li = tq & 15, lg = (tq >> 4) & 3;
             const f32x4 sd = sigma_times_delta(li, lg);
             if (NB == 1 && nc > 1) {
@@ -465,9 +495,35 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
                     stomp_noise_to_tile_pair<DCH>(nt, nt + PAIR_STRIDE * (H * NT_STRIDE), acc, lane_w);
                 }
             } else {
-                stomp_noise_bf16<DCH, FUSED_NOISE_PRIO>(Limg, acc, eps ? eps + (size_t)it_n * eps_stride + (size_t)(s_n < S ? s_n : 0) * DCH * P * H : nullptr,
-                                                        P, p, jv, gv, particle_offset + (uint32_t)p, (uint32_t)s_n, iter0 + (uint32_t)it_n,
-                                                        slo, shi, 3 - (wave >> 2));
+                // EXCHANGE PREFETCH (round 6).  The poll after this phase was a full round trip of device-coherent loads on the
+                // iteration's critical path (~1.6 k of 28.5 k cycles: the partner published long before, the loads only left
+                // when the phase was over; issued into registers ahead of the phase they cost more than they hid, round 4).
+                // LDS-DMA needs no registers: half-way through the draw every wave copies the granules its own threads will
+                // ask for -- 64 elements x 2 chunks, 16 B per lane, and (m, z) of both chunks by two lanes -- into its own
+                // kilobyte of LDS (sc1: coherent at the device like the atomic loads of the poll).  The copy is SPECULATIVE: a
+                // granule whose tag is not this iteration's is simply not there yet, and its thread falls back to the poll.
+                auto prefetch = [&]() {
+                    if (PRE && nc == 2) {
+                        int lp = lane;
+                        asm volatile("" : "+v"(lp));          // (addresses formed here, not carried through the cost phase)
+                        const granule_t* slot0 = xch + ((size_t)(it & 1) * P * nc + (size_t)p * nc) * FUSED_XCHG;
+                        const int wv = wave < DCH ? wave : DCH - 1;                  // (waves beyond the trajectory: any valid piece)
+                        const granule_t* gsrc = slot0 + (size_t)(lp >> 5) * FUSED_XCHG + 2 + 64 * wv + 2 * (lp & 31);
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                                         (__attribute__((address_space(3))) void*)(sm.pre + wave * 128), 16, 0, 16);
+                        if (lp < 2)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(slot0 + (size_t)lp * FUSED_XCHG),
+                                                             (__attribute__((address_space(3))) void*)(sm.premz + wave * 4), 16, 0, 16);
+                    }
+                };
+                if constexpr (PRE)
+                    stomp_noise_bf16<DCH, FUSED_NOISE_PRIO>(Limg, acc, eps ? eps + (size_t)it_n * eps_stride + (size_t)(s_n < S ? s_n : 0) * DCH * P * H : nullptr,
+                                                            P, p, jv, gv, particle_offset + (uint32_t)p, (uint32_t)s_n, iter0 + (uint32_t)it_n,
+                                                            slo, shi, 3 - (wave >> 2), prefetch);
+                else
+                    stomp_noise_bf16<DCH, FUSED_NOISE_PRIO>(Limg, acc, eps ? eps + (size_t)it_n * eps_stride + (size_t)(s_n < S ? s_n : 0) * DCH * P * H : nullptr,
+                                                            P, p, jv, gv, particle_offset + (uint32_t)p, (uint32_t)s_n, iter0 + (uint32_t)it_n,
+                                                            slo, shi, 3 - (wave >> 2));
                 stomp_noise_to_tile(nt, acc, lane_w);         // (the samples packed in the tile were consumed before barrier 2)
             }
             if (FUSED_NOISE_PRIO == STOMP_PRIO_STAGGER) __builtin_amdgcn_s_setprio(0);
@@ -494,14 +550,38 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
             // no block barrier, no flag; combined in chunk order so that all partners compute bit-identical means
             float mk[FUSED_MAX_CHUNKS], zk[FUSED_MAX_CHUNKS], dk[FUSED_MAX_CHUNKS];
             const granule_t* slot0 = xch + ((size_t)(it & 1) * P * nc + (size_t)p * nc) * FUSED_XCHG;
+            // the prefetched copy first (see "exchange prefetch" in the noise phase): the wave's own LDS-DMAs, so no barrier
+            // (only in an iteration whose noise phase ran: otherwise the LDS copy is not this launch's)
+            bool have = false;
+            if (PRE && nc == 2 && it + 1 < n_run) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const granule_t* mine = sm.pre + wave * 128;
+                const granule_t* mz = sm.premz + wave * 4;
+                const granule_t g0 = mine[tq & 63], g1 = mine[64 + (tq & 63)];
+                const granule_t gm0 = mz[0], gz0 = mz[1], gm1 = mz[2], gz1 = mz[3];
+                have = (unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag && (unsigned)(gm0 >> 32) == tag && (unsigned)(gz0 >> 32) == tag &&
+                       (unsigned)(gm1 >> 32) == tag && (unsigned)(gz1 >> 32) == tag;
+#pragma unroll
+                for (int k = 2; k < FUSED_MAX_CHUNKS; ++k) { mk[k] = -3.0e38f; zk[k] = 0.f; dk[k] = 0.f; }
+                mk[0] = __uint_as_float((unsigned)gm0); zk[0] = __uint_as_float((unsigned)gz0);
+                mk[1] = __uint_as_float((unsigned)gm1); zk[1] = __uint_as_float((unsigned)gz1);
+                dk[0] = (tq < N) ? __uint_as_float((unsigned)g0) : 0.f;
+                dk[1] = (tq < N) ? __uint_as_float((unsigned)g1) : 0.f;
+            }
+#ifdef FUSED_T_PRE_STATS
+            if (!have) ++pre_miss_;
+#endif
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             // (measured and dropped, round 4: the first attempt's loads issued inside the noise phase, ahead of their use: the
             // twelve registers they hold there cost more than the round trip they hide -- 13.2 -> 13.4 us per iteration; issued
             // only just ahead of the noise tile's sixteen LDS stores they still tip 17 VGPRs of the kernel into scratch)
             for (;;) {
+                if (have) break;
                 bool ok = true;
-#pragma unroll
-                for (int k = 0; k < FUSED_MAX_CHUNKS; ++k) {
+                // (one chunk per call with a compile-time index: under the prefetch's branch the unroller gave up on the loop over
+                // k and the partials were selected by compares -- two dependent round trips where this is one)
+                auto poll_chunk = [&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
                     mk[k] = -3.0e38f; zk[k] = 0.f; dk[k] = 0.f;
                     if (k < nc) {
                         const granule_t* theirs = slot0 + (size_t)k * FUSED_XCHG;
@@ -512,7 +592,12 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
                         zk[k] = __uint_as_float((unsigned)gz);
                         dk[k] = (tq < N) ? __uint_as_float((unsigned)gd) : 0.f;
                     }
-                }
+                };
+                static_assert(FUSED_MAX_CHUNKS == 4, "poll_chunk is called once per chunk");
+                poll_chunk(std::integral_constant<int, 0>{});
+                poll_chunk(std::integral_constant<int, 1>{});
+                poll_chunk(std::integral_constant<int, 2>{});
+                poll_chunk(std::integral_constant<int, 3>{});
                 if (ok) break;
                 __builtin_amdgcn_s_sleep(2);
                 if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) { s_abort = 1; break; }
@@ -563,6 +648,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void stomp_fused_kernel(
         if (s_abort) break;                                                                     // block-uniform (set before barrier 5)
         if (it < 3) LSTAMP(4 + it);
     }
+#ifdef FUSED_T_PRE_STATS
+    if (pre_miss_ > 1) atomicAdd(&g_pre_miss[wave], (unsigned)(pre_miss_ - 1));     // (the last iteration has no prefetch)
+#endif
     const int aborted = s_abort;                        // (block-uniform: last written before a barrier every thread passed)
     if (!aborted && chunk == 0 && tid < N) {
         const float m = mean_l[tid];

@@ -252,10 +252,13 @@ __device__ __forceinline__ void stomp_split_product(const unsigned* __restrict__
 }
 
 // acc[m] = rows 16 m .. 16 m + 15 of L * eps for the wave's rollout: draw / load, split and multiply, column block by column block
-template <int DCH, int PRIO = STOMP_PRIO_NONE>
+struct StompNoMid { __device__ __forceinline__ void operator()() const {} };
+// `mid` runs between the two column blocks (the persistent kernel issues its exchange prefetch there: half the phase behind it
+// for the partner to have published, half ahead of it to cover the round trip)
+template <int DCH, int PRIO = STOMP_PRIO_NONE, typename MID = StompNoMid>
 __device__ __forceinline__ void stomp_noise_bf16(const unsigned* __restrict__ img, f32x4 (&acc)[4], const float* __restrict__ eps_s,
                                                  int P, int p, int j, int g, uint32_t p_global, uint32_t s, uint32_t iter,
-                                                 uint32_t seed_lo, uint32_t seed_hi, int level = 0) {
+                                                 uint32_t seed_lo, uint32_t seed_hi, int level = 0, MID mid = MID()) {
     if (PRIO == STOMP_PRIO_STAGGER && eps_s == nullptr) stomp_setprio(level);
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -264,6 +267,7 @@ __device__ __forceinline__ void stomp_noise_bf16(const unsigned* __restrict__ im
     StompEps8 b;
     stomp_eps8<DCH, 0, PRIO>(v, carry, eps_s, P, p, j, g, p_global, s, iter, seed_lo, seed_hi);
     stomp_split_product<0>(img, v, b, eps_s != nullptr, j, g, acc);
+    mid();
     stomp_eps8<DCH, 1, PRIO>(v, carry, eps_s, P, p, j, g, p_global, s, iter, seed_lo, seed_hi);
     stomp_split_product<1>(img, v, b, eps_s != nullptr, j, g, acc);
     if (PRIO == STOMP_PRIO_PROGRESS && eps_s == nullptr) stomp_setprio(0);
