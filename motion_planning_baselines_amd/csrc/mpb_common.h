@@ -11,7 +11,7 @@
 // itself, and such a library says so in mpb_version() (bit 30), which _lib.lib() refuses unless it was asked for the
 // variant explicitly (MPB_LIB_PATH).
 #if !defined(MPB_TUNING_BUILD) && (defined(GP_T_GJ_STEPS) || defined(GP_T_NO_Z) || defined(GP_T_SKIP_STORE) || defined(GP_T_SKIP_SUBST) || \
-                                   defined(FUSED_T_SKIP_NOISE) || defined(FUSED_T_SKIP_COST) || defined(FUSED_T_A_NOMEAN) || defined(FUSED_T_A_NOSTORE) || defined(LR_T_NOLOAD) || defined(LR_T_NOSTORE) || defined(LR_T_CAP_NOASM) || defined(LR_T_CAP_NOCHOL) || defined(LR_T_CAP_NOBACK) || defined(LR_T_CLK) || defined(FUSED_T_PRE_STATS))
+                                   defined(FUSED_T_SKIP_NOISE) || defined(FUSED_T_SKIP_COST) || defined(FUSED_T_A_NOMEAN) || defined(FUSED_T_A_NOSTORE) || defined(LR_T_NOLOAD) || defined(LR_T_NOSTORE) || defined(LR_T_CAP_NOASM) || defined(LR_T_CAP_NOCHOL) || defined(LR_T_CAP_NOBACK) || defined(LR_T_CLK) || defined(FUSED_T_PRE_STATS) || defined(LR_T_GRAD_NOSTORE))
 #error "a wrong-result tuning switch (GP_T_*) was defined without -DMPB_TUNING_BUILD"
 #endif
 

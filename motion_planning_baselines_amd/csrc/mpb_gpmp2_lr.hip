@@ -105,6 +105,8 @@ __device__ __forceinline__ LrCoef lr_coef(const GpConst& K) {
 // (t, c) and, by symmetry, to (c, t): c short steps instead of the 2 H of a substitution per column.
 // ------------------------------------------------------------------------------------------------
 #define LR_COLS 32
+#define LR_HMAX 128                    // waypoints (mpb_gpmp2_lr_ok: n_fields (H - 1) <= LR_NMAX)
+#define LR_ORD 9                       // size classes of the capacitance systems' launch order: 0 rows, 1-16, ..., 113-128 (largest first)
 #define LR_KK 10                       // doubles per waypoint of the chain kernel's coefficient table (nine used; even, so that pairs stay aligned)
 __global__ __launch_bounds__(LR_COLS) void gpmp2_chain_kernel(const double* __restrict__ diag_mean, double* __restrict__ rec_g,
                                                               double* __restrict__ G, int H, int D, GpConst K) {
@@ -233,18 +235,51 @@ __global__ __launch_bounds__(LR_COLS) void gpmp2_chain_kernel(const double* __re
 // alone -- a sweep over one particle took 49 us whatever the batch size).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gpmp2_lr_gradient(const float* __restrict__ x, const float* __restrict__ start, const float* __restrict__ goal,
-                                                         double* __restrict__ g, double* __restrict__ gpcost, int B, int H, int D, GpConst K) {
-    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= B) return;
+                                                         const float* __restrict__ jac, double* __restrict__ g, double* __restrict__ gpcost,
+                                                         int* __restrict__ ord, int B, int H, int D, int F, GpConst K) {
+    __shared__ double red_c[4];
+    __shared__ int red_n[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    // The capacitance kernel lasts as long as its largest system (one particle with 116 active rows: 87 us; the median particle has
+    // none), and two workgroups fit a CU: in batch order the largest system of C4 started in the third of four rounds.  So every
+    // particle gets a size class here -- rows with a non-zero hinge value, LR_ORD classes of 16 --, one extra workgroup of the
+    // sweep that follows sorts the particles by class, largest first (a counting sort in LDS; one atomic per particle on a
+    // counter per class in global memory cost this kernel 19 us: 2 048 returning atomics on nine addresses), and gpmp2_lr_cap
+    // takes them in that order.  (Scheduling only: the class is an estimate, nothing else reads it.)
+    int n_est = 0;
     const int dim = 2 * D;
     const LrCoef C = lr_coef(K);
     const double dt = K.dt;
-    const float* xb = x + (size_t)b * H * dim;
     double* gb = g + (size_t)b * H * dim;
     double cost = 0.0;
+    // the particle's trajectory through LDS: every load of the workgroup is in flight at once (read in place, an element's six
+    // neighbours were a round trip per trip of the loop below: 35 us at C4 for 52 MB of traffic)
+    __shared__ float xb[LR_HMAX * 2 * MPB_MAX_DOF];
+    {
+        const float* xg = x + (size_t)b * H * dim;
+        const int nx = H * dim;
+        float tmp[(LR_HMAX * 2 * MPB_MAX_DOF + 255) / 256];
+#pragma unroll
+        for (int u = 0; u < (LR_HMAX * 2 * MPB_MAX_DOF + 255) / 256; ++u) {
+            const int e = tid + 256 * u;
+            tmp[u] = (e < nx) ? xg[e] : 0.f;
+        }
+        // (the size estimate's loads behind the trajectory's, ahead of the first wait)
+        for (int r0 = 0; r0 < F * H; r0 += 256) {
+            const int r = r0 + tid, f = r / H, t = r - f * H;
+            const bool a = r < F * H && t > 0 && jac[(((size_t)f * B + b) * H + t) * (D + 1) + D] != 0.f;
+            n_est += __popcll(__ballot(a));
+        }
+#pragma unroll
+        for (int u = 0; u < (LR_HMAX * 2 * MPB_MAX_DOF + 255) / 256; ++u) {
+            const int e = tid + 256 * u;
+            if (e < nx) xb[e] = tmp[u];
+        }
+    }
+    __syncthreads();
     // a lane per (waypoint, joint), consecutive lanes = consecutive joints of a row: the D positions (and the D velocities) of a
     // row are read and written as one piece (a lane per waypoint walking the joints touched 64 rows per instruction: 37 us at C4)
-    for (int e = lane; e < H * D; e += 64) {
+    for (int e = tid; e < H * D; e += 256) {
         const int t = e / D, j = e - t * D;
         const float* xt = xb + (size_t)t * dim;
         const double p = (double)xt[j], v = (double)xt[D + j];
@@ -272,11 +307,21 @@ __global__ __launch_bounds__(256) void gpmp2_lr_gradient(const float* __restrict
             gp = fma(K.kg, ep, gp); gv = fma(K.kg, ev, gv);
             cost += K.kg * fma(ep, ep, ev * ev);
         }
+#ifndef LR_T_GRAD_NOSTORE
         gb[(size_t)t * dim + j] = gp;
         gb[(size_t)t * dim + D + j] = gv;
+#else
+        if (gp == 1.2345 && gv == 2.3456) gb[0] = 0.0;
+#endif
     }
     cost = wave_sum_f64(cost);
-    if (lane == 0) gpcost[b] = cost;
+    if (lane == 0) { red_c[wave] = cost; red_n[wave] = n_est; }
+    __syncthreads();
+    if (tid == 0) {
+        gpcost[b] = (red_c[0] + red_c[1]) + (red_c[2] + red_c[3]);
+        const int n = red_n[0] + red_n[1] + red_n[2] + red_n[3];
+        ord[b] = LR_ORD - 1 - min(LR_ORD - 1, (n + 15) >> 4);          // size class, 0 = largest (sorted by gpmp2_lr_sweep<false>'s extra workgroup)
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -290,9 +335,28 @@ __global__ __launch_bounds__(256) void gpmp2_lr_gradient(const float* __restrict
 template <bool FINAL>
 __global__ __launch_bounds__(64) void gpmp2_lr_sweep(float* __restrict__ x, const double* __restrict__ g, const float* __restrict__ jac,
                                                      const double* __restrict__ wdense, const double* __restrict__ rec_g,
-                                                     double* __restrict__ zbuf, double* __restrict__ upos, int B, int H, int D, int F, GpConst K) {
+                                                     double* __restrict__ zbuf, double* __restrict__ upos, int* __restrict__ ord, int B, int H, int D,
+                                                     int F, GpConst K) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x, dim = 2 * D;
+    if (!FINAL && blockIdx.x == gridDim.x - 1) {
+        // the extra workgroup: the particles sorted by size class (gpmp2_lr_gradient), largest first -- the order gpmp2_lr_cap
+        // takes them in.  A counting sort: class totals and positions by LDS atomics.
+        int* cnt = reinterpret_cast<int*>(lds);            // [0, LR_ORD): totals, then running offsets
+        if (lane < LR_ORD) cnt[lane] = 0;
+        lr_wave_sync();
+        for (int b0 = 0; b0 < B; b0 += 64)
+            if (b0 + lane < B) atomicAdd(&cnt[ord[b0 + lane]], 1);
+        lr_wave_sync();
+        if (lane == 0) {
+            int run = 0;
+            for (int c = 0; c < LR_ORD; ++c) { const int n = cnt[c]; cnt[c] = run; run += n; }
+        }
+        lr_wave_sync();
+        for (int b0 = 0; b0 < B; b0 += 64)
+            if (b0 + lane < B) ord[B + atomicAdd(&cnt[ord[b0 + lane]], 1)] = b0 + lane;
+        return;
+    }
     const int per = 64 / D;                                   // particles per wave
     const int stride = H * LR_REC + 2;                        // doubles between two joints' tables (+ 2: their records fall on different banks)
     // the shared factors into LDS, 16 bytes at a time, EIGHT loads in flight per lane and joint (one load per trip with its index
@@ -462,8 +526,8 @@ __device__ __forceinline__ double lr_rsqrt(double x) {                      // v
 
 __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ jac, const double* __restrict__ upos,
                                                    const double* __restrict__ G, const double* __restrict__ gpcost,
-                                                   double* __restrict__ wdense, float* __restrict__ costs_out, int B, int H, int D, int F,
-                                                   int n_tiles_max, GpConst K) {
+                                                   double* __restrict__ wdense, float* __restrict__ costs_out, const int* __restrict__ ord,
+                                                   int B, int H, int D, int F, int n_tiles_max, GpConst K) {
     extern __shared__ double lds[];
     // LDS: [ tiles | rhs / y / w (128) | 1 / l_kk (128) | h rows of the active set (LR_NMAX x 8 fp32) | waypoint and field of every
     //        active row (2 x 128 ints) | scratch ints ]
@@ -475,7 +539,9 @@ __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ ja
     int* tact = reinterpret_cast<int*>(hb + LR_NMAX * hs);
     int* fact = tact + 128;
     int* cnt = fact + 128;                                       // [0 .. 2 F): active rows of (field, 64-waypoint chunk)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the particle of this workgroup: largest systems first (gpmp2_lr_gradient, gpmp2_lr_sweep<false>)
+    const int b = ord[B + blockIdx.x];
     const size_t NL = (size_t)B * D;
     // ---- 1. the active collision rows, compacted (field major, then waypoint); the collision part of the cost.  Chunk (f, base) is
     //         examined by wave (2 f + base / 64) mod 4: counts first, then positions
@@ -761,7 +827,8 @@ bool mpb_gpmp2_lr_ok(int H, int D, int n_fields) { return H >= 2 && D >= 1 && D 
 size_t mpb_gpmp2_lr_ws_doubles(int B, int H, int D) {
     const size_t NL = (size_t)B * D;
     return (size_t)D * H * LR_REC + (size_t)D * H * H + (size_t)H * NL * LR_ZREC + (size_t)H * NL + (size_t)MPB_GP_MAX_FIELDS * B * H + (size_t)B + 64 +
-           (size_t)B * H * 2 * D;          // ... and g_rest
+           (size_t)B * H * 2 * D +         // ... and g_rest
+           (size_t)B + 1;                  // ... and the size class of every particle + the launch order of the capacitance systems (2 B ints)
 }
 
 int mpb_gpmp2_lr_launch(float* x, const float* start, const float* goal, const float* jac, const double* diag_mean, double* ws,
@@ -774,17 +841,18 @@ int mpb_gpmp2_lr_launch(float* x, const float* start, const float* goal, const f
     double* wdense = upos + (size_t)H * NL;
     double* gpcost = wdense + (size_t)MPB_GP_MAX_FIELDS * B * H;
     double* grest = gpcost + B + 64;
+    int* ord = reinterpret_cast<int*>(grest + (size_t)B * H * 2 * D);        // [0, B): size class of particle b; [B, 2 B): the particles, largest class first
     const size_t lds_chain = ((size_t)H * LR_REC + (size_t)H * 2 + (size_t)H * LR_KK) * sizeof(double);
     hipLaunchKernelGGL(gpmp2_chain_kernel, dim3(D, (H + LR_COLS - 1) / LR_COLS), dim3(LR_COLS), lds_chain, stream, diag_mean, rec, G, H, D, K);
     const int per = 64 / D;
     const size_t lds_sweep = (size_t)D * (H * LR_REC + 2) * sizeof(double);
     const dim3 gs((B + per - 1) / per);
-    hipLaunchKernelGGL(gpmp2_lr_gradient, dim3((B + 3) / 4), dim3(256), 0, stream, x, start, goal, grest, gpcost, B, H, D, K);
-    hipLaunchKernelGGL(gpmp2_lr_sweep<false>, gs, dim3(64), lds_sweep, stream, x, grest, jac, wdense, rec, zbuf, upos, B, H, D, n_fields, K);
+    hipLaunchKernelGGL(gpmp2_lr_gradient, dim3(B), dim3(256), 0, stream, x, start, goal, jac, grest, gpcost, ord, B, H, D, n_fields, K);
+    hipLaunchKernelGGL(gpmp2_lr_sweep<false>, dim3(gs.x + 1), dim3(64), lds_sweep, stream, x, grest, jac, wdense, rec, zbuf, upos, ord, B, H, D, n_fields, K);
     const int n_max = n_fields * (H - 1);
     const int trm = (n_max + 16) >> 4, ntm = (trm * (trm + 1)) >> 1;             // tiles of the largest system the shape allows
     const size_t lds = ((size_t)ntm * LR_TILE + 256) * sizeof(double) + (size_t)LR_NMAX * (D <= 8 ? 8 : MPB_MAX_DOF) * sizeof(float) + (256 + 16) * sizeof(int);
-    hipLaunchKernelGGL(gpmp2_lr_cap, dim3(B), dim3(256), lds, stream, jac, upos, G, gpcost, wdense, costs_out, B, H, D, n_fields, ntm, K);
-    hipLaunchKernelGGL(gpmp2_lr_sweep<true>, gs, dim3(64), lds_sweep, stream, x, grest, jac, wdense, rec, zbuf, upos, B, H, D, n_fields, K);
+    hipLaunchKernelGGL(gpmp2_lr_cap, dim3(B), dim3(256), lds, stream, jac, upos, G, gpcost, wdense, costs_out, ord, B, H, D, n_fields, ntm, K);
+    hipLaunchKernelGGL(gpmp2_lr_sweep<true>, gs, dim3(64), lds_sweep, stream, x, grest, jac, wdense, rec, zbuf, upos, ord, B, H, D, n_fields, K);
     return MPB_OK;
 }
