@@ -96,135 +96,194 @@ __device__ __forceinline__ LrCoef lr_coef(const GpConst& K) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// shared: factors of the D chains and the position-position entries of their inverses.
-// grid = (D, ceil(H / LR_COLS)), block = LR_COLS threads.  Every block factorises its joint's chain itself (H sequential 2 x 2
-// steps on one thread, operands in LDS: cheaper than a launch of its own) and runs the recurrence of the inverse's diagonal blocks,
-//     G_{H-1,H-1} = W_{H-1},      G_{t,t} = W_t + F_t G_{t+1,t+1} F_t^T,
-// then thread c walks column c of the inverse UP from its diagonal block, G_{t,c} = -F_t G_{t+1,c} (t < c: above the diagonal the
-// forward pass of a unit vector is zero, so the back substitution is this product alone), and writes the position-position entry to
-// (t, c) and, by symmetry, to (c, t): c short steps instead of the 2 H of a substitution per column.
+// A0^-1 by PARALLEL CYCLIC REDUCTION (round 6, third version of the shared part).  The block-Thomas sweeps of the second version
+// walked a chain of H 2 x 2 blocks one step after the other -- 2 H dependent steps per solve, a lane per (particle, joint), 228
+// waves on 1 024 SIMDs: 31 + 47 us per iteration at C4 whatever the batch, and 31 us more for the factors and the inverse's entries
+// (one lane per joint).  A0 is the same for every particle, so the MATRIX half of a cyclic reduction is shared: level l (stride
+// h = 2^l) replaces equation t by  eq_t + alpha_t eq_{t-h} + gamma_t eq_{t+h}  with
+//     alpha_t = -Lo_t Dg_{t-h}^-1,   gamma_t = -Up_t Dg_{t+h}^-1,
+//     Dg'_t = Dg_t + alpha_t Up_{t-h} + gamma_t Lo_{t+h},   Lo'_t = alpha_t Lo_{t-h},   Up'_t = gamma_t Up_{t+h}
+// (Lo / Up: the blocks that couple t to t - h / t + h; level 0: U^T / U), and after ceil(log2 H) levels every equation stands alone:
+// y_t = Dg_t^-1 r_t.  gpmp2_pcr_setup computes alpha, gamma of every level and the final inverses once per joint (a thread per
+// waypoint, neighbours through LDS: 7 levels at H = 128); a SOLVE is then, per level, r_t += alpha_t r_{t-h} + gamma_t r_{t+h} for
+// all t at once -- a wave per chain, lane = waypoints t and t + 64, the right-hand sides exchanged through LDS, PCR_NP chains per
+// wave sharing every coefficient read.  3.5 x the arithmetic of a Thomas sweep, none of it sequential.  Stability: every level is
+// a block Gaussian elimination of an SPD matrix in a symmetric order.
 // ------------------------------------------------------------------------------------------------
-#define LR_COLS 32
 #define LR_HMAX 128                    // waypoints (mpb_gpmp2_lr_ok: n_fields (H - 1) <= LR_NMAX)
 #define LR_ORD 9                       // size classes of the capacitance systems' launch order: 0 rows, 1-16, ..., 113-128 (largest first)
-#define LR_KK 10                       // doubles per waypoint of the chain kernel's coefficient table (nine used; even, so that pairs stay aligned)
-__global__ __launch_bounds__(LR_COLS) void gpmp2_chain_kernel(const double* __restrict__ diag_mean, double* __restrict__ rec_g,
-                                                              double* __restrict__ G, int H, int D, GpConst K) {
+#define PCR_NP 4                       // chains a wave solves at once
+#define PCR_WAVES 8
+#define PCR_THREADS (64 * PCR_WAVES)
+static inline int pcr_levels(int H) { int L = 0; for (int h = 1; h < H; h <<= 1) ++L; return L; }
+// coefficient table of a joint, 16-byte entries: [level][q][t], q = 0: (alpha00, alpha01), 1: (alpha10, alpha11), 2: (gamma00, gamma01),
+// 3: (gamma10, gamma11) -- a lane's reads of consecutive t fall on consecutive banks --, then [2][t]: the rows of Dg^-1 of the last level
+static inline size_t pcr_coef_entries(int H) { return (size_t)(4 * pcr_levels(H) + 2) * H; }
+
+// PCR_NP right-hand sides through the L levels.  r[k][e]: chain k at waypoint lane (e = 0) / lane + 64 (e = 1); on return the solution.
+// rb: this wave's PCR_NP x H exchange rows (one buffer: the LDS instructions of a wave execute in order, the reads of a level are all
+// issued before its successor's writes).
+__device__ __forceinline__ void pcr_solve(const lr_d2* __restrict__ coef, lr_d2* __restrict__ rb, int H, int L, int lane, lr_d2 (&r)[PCR_NP][2]) {
+    const int tt[2] = {lane, lane + 64};
+    const bool vv[2] = {lane < H, lane + 64 < H};
+    for (int l = 0, h = 1; l < L; ++l, h <<= 1) {
+#pragma unroll
+        for (int k = 0; k < PCR_NP; ++k) {
+            if (vv[0]) rb[k * H + tt[0]] = r[k][0];
+            if (vv[1]) rb[k * H + tt[1]] = r[k][1];
+        }
+        lr_wave_sync();
+        const lr_d2* cl = coef + (size_t)(4 * l) * H;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int t = vv[e] ? tt[e] : 0;
+            const lr_d2 a0 = cl[t], a1 = cl[H + t], c0 = cl[2 * H + t], c1 = cl[3 * H + t];
+            const int tm = (t - h >= 0) ? t - h : t, tp = (t + h < H) ? t + h : t;       // (out of range: alpha / gamma are zero)
+#pragma unroll
+            for (int k = 0; k < PCR_NP; ++k) {
+                const lr_d2 rm = rb[k * H + tm], rp = rb[k * H + tp];
+                const double nx = fma(c0.y, rp.y, fma(c0.x, rp.x, fma(a0.y, rm.y, fma(a0.x, rm.x, r[k][e].x))));
+                const double ny = fma(c1.y, rp.y, fma(c1.x, rp.x, fma(a1.y, rm.y, fma(a1.x, rm.x, r[k][e].y))));
+                r[k][e] = lr_d2{nx, ny};
+            }
+        }
+        lr_wave_sync();
+    }
+    const lr_d2* dl = coef + (size_t)(4 * L) * H;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int t = vv[e] ? tt[e] : 0;
+        const lr_d2 i0 = dl[t], i1 = dl[H + t];
+#pragma unroll
+        for (int k = 0; k < PCR_NP; ++k) {
+            const lr_d2 v = r[k][e];
+            r[k][e] = lr_d2{fma(i0.y, v.y, i0.x * v.x), fma(i1.y, v.y, i1.x * v.x)};
+        }
+    }
+}
+
+// a joint's table from global memory into LDS, eight 16-byte loads in flight per thread
+__device__ __forceinline__ void pcr_stage(const lr_d2* __restrict__ src, lr_d2* __restrict__ dst, int n, int tid) {
+    for (int e0 = 0; e0 < n; e0 += PCR_THREADS * 8) {
+        lr_d2 tmp[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + tid + PCR_THREADS * u;
+            tmp[u] = src[e < n ? e : n - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + tid + PCR_THREADS * u;
+            if (e < n) dst[e] = tmp[u];
+        }
+    }
+}
+
+struct Pcr22 { double a, b, c, d; };          // [[a, b], [c, d]]
+__device__ __forceinline__ Pcr22 pcr_inv(const Pcr22& m) {
+    const double id = lr_rcp(fma(m.a, m.d, -m.b * m.c));
+    return Pcr22{m.d * id, -m.b * id, -m.c * id, m.a * id};
+}
+__device__ __forceinline__ Pcr22 pcr_mul(const Pcr22& x, const Pcr22& y) {
+    return Pcr22{fma(x.b, y.c, x.a * y.a), fma(x.b, y.d, x.a * y.b), fma(x.d, y.c, x.c * y.a), fma(x.d, y.d, x.c * y.b)};
+}
+
+// ------------------------------------------------------------------------------------------------
+// shared: the reduction coefficients of the D chains (to coef_g, by the blocks with blockIdx.y = 0) and the position-position entries
+// G_i(s, t) of their inverses (D H^2 doubles, 0.9 MB at C4: stays in L2) -- column c is the solve of a unit position entry at c, the
+// columns split over the gridDim.y blocks of a joint, PCR_NP per wave and pass; written as ROW c (G is symmetric: a lane per t
+// then stores consecutive words).  Every block computes its joint's coefficients itself (7 levels of a thread per waypoint: cheaper
+// than a launch of its own).  grid = (D, NY), block = PCR_THREADS; LDS: the table | 12 H doubles of exchange | the waves' rows.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PCR_THREADS) void gpmp2_pcr_setup(const double* __restrict__ diag_mean, double* __restrict__ coef_g,
+                                                               double* __restrict__ G, int H, int D, int L, GpConst K) {
     extern __shared__ double lds[];
-    double* rec = lds;                                 // H x LR_REC
-    double* gd = lds + (size_t)H * LR_REC;             // H x 2: column 0 of G_{t,t}
-    double* kk = gd + (size_t)H * 2;                   // H x LR_KK: first the chain's diagonal blocks D_t, then the coefficients of the diagonal recurrence
-    const int i = blockIdx.x, c0 = blockIdx.y * LR_COLS, tid = threadIdx.x;
+    const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_coef = (4 * L + 2) * H;
+    lr_d2* coef = reinterpret_cast<lr_d2*>(lds);
+    double* xch = lds + 2 * (size_t)n_coef;                                  // H x 12: Dg, Lo, Up of every waypoint at the current level
+    lr_d2* rb = reinterpret_cast<lr_d2*>(xch + 12 * (size_t)H) + (size_t)wave * PCR_NP * H;
     const LrCoef C = lr_coef(K);
-    const int dim = 2 * D;
-#ifdef LR_T_CLK
-    unsigned long long clk_[6]; clk_[0] = wall_clock64();
-#define LR_CLK(k) clk_[k] = wall_clock64()
-#else
-#define LR_CLK(k)
-#endif
-    // ONE lane walks the two sequential recurrences below, and a wave issues one fp64 instruction per four cycles whatever the number
-    // of its lanes at work: a step costs its instruction COUNT (measured: 50 instructions a step, 290 cycles), not the depth of its
-    // dependent chain.  So everything that does not depend on the previous step is done by all lanes, before or after, and staged.
-    // D_t = (GP blocks) + damping + start / goal prior, a lane per waypoint
-    for (int t = tid; t < H; t += LR_COLS) {
+    const int dim = 2 * D, t = tid;
+    Pcr22 Dg{0, 0, 0, 0}, Lo{0, 0, 0, 0}, Up{0, 0, 0, 0};
+    if (t < H) {
+        // D_t = (GP blocks) + damping + start / goal prior (gpmp2.py:355-368; the damping is delta x the batch mean of the diagonal: Q9)
         const double first = (t == 0) ? 1.0 : 0.0, last = (t == H - 1) ? 1.0 : 0.0;
         const double dp = K.trust ? K.delta * diag_mean[(size_t)t * dim + i] : K.delta;
         const double dv = K.trust ? K.delta * diag_mean[(size_t)t * dim + D + i] : K.delta;
-        kk[t * LR_KK] = (1.0 - last) * C.p00 + (1.0 - first) * C.a + dp + first * K.ks + last * K.kg;
-        kk[t * LR_KK + 1] = (1.0 - last) * C.p01 + (1.0 - first) * C.bq;
-        kk[t * LR_KK + 2] = (1.0 - last) * C.p11 + (1.0 - first) * C.cq + dv + first * K.ks + last * K.kg;
+        Dg.a = (1.0 - last) * C.p00 + (1.0 - first) * C.a + dp + first * K.ks + last * K.kg;
+        Dg.b = Dg.c = (1.0 - last) * C.p01 + (1.0 - first) * C.bq;
+        Dg.d = (1.0 - last) * C.p11 + (1.0 - first) * C.cq + dv + first * K.ks + last * K.kg;
+        if (t > 0) Lo = Pcr22{C.u00, C.u10, C.u01, C.u11};                  // block (t, t - 1) = U^T
+        if (t < H - 1) Up = Pcr22{C.u00, C.u01, C.u10, C.u11};              // block (t, t + 1) = U
     }
-    __syncthreads();
-    LR_CLK(1);
-    if (tid == 0) {
-        // block Thomas on the 2 x 2 chain of joint i:  S_0 = D_0,  S_{t+1} = D_{t+1} - U^T S_t^-1 U.  With S^-1 = adj(S) / det,
-        // U^T S^-1 U = N / det where N = U^T adj(S) U is three fma chains with CONSTANT coefficients (products of U's entries):
-        // 9 + 3 (S) + 2 (det) + 5 (reciprocal) instructions a step; S_t and 1 / det are kept, W_t and F_t follow in parallel below.
-        const double c00a = C.u00 * C.u00, c00b = -2.0 * C.u00 * C.u10, c00c = C.u10 * C.u10;                  // N00 = c00a s11 + c00b s01 + c00c s00
-        const double c01a = C.u00 * C.u01, c01b = -(C.u00 * C.u11 + C.u10 * C.u01), c01c = C.u10 * C.u11;      // N01
-        const double c11a = C.u01 * C.u01, c11b = -2.0 * C.u01 * C.u11, c11c = C.u11 * C.u11;                  // N11
-        double s00 = 0.0, s01 = 0.0, s11 = 0.0, idp = 0.0;        // (t = 0: the Schur term vanishes)
-        double e00 = kk[0], e01 = kk[1], e11 = kk[2];
-#pragma unroll 4
-        for (int t = 0; t < H; ++t) {
-            const double d00 = e00, d01 = e01, d11 = e11;
-            const int tn = (t + 1 < H) ? t + 1 : t;           // the next block is read BEFORE this step's stores (the compiler cannot
-            e00 = kk[tn * LR_KK]; e01 = kk[tn * LR_KK + 1]; e11 = kk[tn * LR_KK + 2];      // tell the two LDS arrays apart)
-            const double n00 = fma(c00a, s11, fma(c00b, s01, c00c * s00));
-            const double n01 = fma(c01a, s11, fma(c01b, s01, c01c * s00));
-            const double n11 = fma(c11a, s11, fma(c11b, s01, c11c * s00));
-            s00 = fma(-n00, idp, d00);
-            s01 = fma(-n01, idp, d01);
-            s11 = fma(-n11, idp, d11);
-            idp = lr_rcp(fma(s00, s11, -s01 * s01));
-            double* r = rec + (size_t)t * LR_REC;
-            r[0] = s00; r[1] = s01; r[2] = s11; r[3] = idp;
+    for (int l = 0, h = 1; l < L; ++l, h <<= 1) {
+        if (t < H) {
+            double* w = xch + 12 * (size_t)t;
+            w[0] = Dg.a; w[1] = Dg.b; w[2] = Dg.c; w[3] = Dg.d;
+            w[4] = Lo.a; w[5] = Lo.b; w[6] = Lo.c; w[7] = Lo.d;
+            w[8] = Up.a; w[9] = Up.b; w[10] = Up.c; w[11] = Up.d;
         }
-    }
-    __syncthreads();
-    LR_CLK(2);
-    // W_t = adj(S_t) / det,  F_t = W_t U,  and the coefficients of  G_tt = W_t + F_t G_{t+1,t+1} F_t^T  written out in G's three entries
-    for (int t = tid; t < H; t += LR_COLS) {
-        double* r = rec + (size_t)t * LR_REC;
-        const double idp = r[3];
-        const double w00 = r[2] * idp, w01 = -r[1] * idp, w11 = r[0] * idp;
-        const double f00 = w00 * C.u00 + w01 * C.u10, f01 = w00 * C.u01 + w01 * C.u11;
-        const double f10 = w01 * C.u00 + w11 * C.u10, f11 = w01 * C.u01 + w11 * C.u11;
-        r[0] = w00; r[1] = w01; r[2] = w11; r[3] = f00; r[4] = f01; r[5] = f10; r[6] = f11; r[7] = 0.0;
-        double* k = kk + t * LR_KK;
-        k[0] = f00 * f00; k[1] = 2.0 * f00 * f01; k[2] = f01 * f01;
-        k[3] = f00 * f10; k[4] = fma(f00, f11, f01 * f10); k[5] = f01 * f11;
-        k[6] = f10 * f10; k[7] = 2.0 * f10 * f11; k[8] = f11 * f11;
-    }
-    __syncthreads();
-    LR_CLK(3);
-    if (tid == 0) {
-        // diagonal blocks of the inverse, bottom up; column 0 (the response to a unit POSITION entry) of each is kept.  This block
-        // walks columns c0 .. c0 + 31 only, so the recurrence stops at c0 (the block of the last columns has the longest walks
-        // and the shortest recurrence)
-        double g00 = rec[(size_t)(H - 1) * LR_REC], g01 = rec[(size_t)(H - 1) * LR_REC + 1], g11 = rec[(size_t)(H - 1) * LR_REC + 2];
-        gd[2 * (H - 1)] = g00; gd[2 * (H - 1) + 1] = g01;
-        const int t0 = (H >= 2) ? H - 2 : 0;
-        double w0 = rec[(size_t)t0 * LR_REC], w1 = rec[(size_t)t0 * LR_REC + 1], w2 = rec[(size_t)t0 * LR_REC + 2];
-        double k0 = kk[t0 * LR_KK], k1 = kk[t0 * LR_KK + 1], k2 = kk[t0 * LR_KK + 2], k3 = kk[t0 * LR_KK + 3], k4 = kk[t0 * LR_KK + 4];
-        double k5 = kk[t0 * LR_KK + 5], k6 = kk[t0 * LR_KK + 6], k7 = kk[t0 * LR_KK + 7], k8 = kk[t0 * LR_KK + 8];
-#pragma unroll 4
-        for (int t = H - 2; t >= c0; --t) {
-            const double n00 = fma(k0, g00, w0) + fma(k2, g11, k1 * g01);
-            const double n01 = fma(k3, g00, w1) + fma(k5, g11, k4 * g01);
-            const double n11 = fma(k6, g00, w2) + fma(k8, g11, k7 * g01);
-            const int tn = (t > 0) ? t - 1 : 0;
-            w0 = rec[(size_t)tn * LR_REC]; w1 = rec[(size_t)tn * LR_REC + 1]; w2 = rec[(size_t)tn * LR_REC + 2];
-            k0 = kk[tn * LR_KK]; k1 = kk[tn * LR_KK + 1]; k2 = kk[tn * LR_KK + 2]; k3 = kk[tn * LR_KK + 3]; k4 = kk[tn * LR_KK + 4];
-            k5 = kk[tn * LR_KK + 5]; k6 = kk[tn * LR_KK + 6]; k7 = kk[tn * LR_KK + 7]; k8 = kk[tn * LR_KK + 8];
-            g00 = n00; g01 = n01; g11 = n11;
-            gd[2 * t] = g00; gd[2 * t + 1] = g01;
+        __syncthreads();
+        if (t < H) {
+            Pcr22 al{0, 0, 0, 0}, ga{0, 0, 0, 0};
+            Pcr22 nDg = Dg, nLo{0, 0, 0, 0}, nUp{0, 0, 0, 0};
+            if (t - h >= 0) {
+                const double* m = xch + 12 * (size_t)(t - h);
+                const Pcr22 Dm{m[0], m[1], m[2], m[3]}, Lm{m[4], m[5], m[6], m[7]}, Um{m[8], m[9], m[10], m[11]};
+                const Pcr22 x = pcr_mul(Lo, pcr_inv(Dm));
+                al = Pcr22{-x.a, -x.b, -x.c, -x.d};
+                const Pcr22 du = pcr_mul(al, Um);
+                nDg.a += du.a; nDg.b += du.b; nDg.c += du.c; nDg.d += du.d;
+                nLo = pcr_mul(al, Lm);
+            }
+            if (t + h < H) {
+                const double* q = xch + 12 * (size_t)(t + h);
+                const Pcr22 Dp{q[0], q[1], q[2], q[3]}, Lp{q[4], q[5], q[6], q[7]}, Uq{q[8], q[9], q[10], q[11]};
+                const Pcr22 x = pcr_mul(Up, pcr_inv(Dp));
+                ga = Pcr22{-x.a, -x.b, -x.c, -x.d};
+                const Pcr22 dl = pcr_mul(ga, Lp);
+                nDg.a += dl.a; nDg.b += dl.b; nDg.c += dl.c; nDg.d += dl.d;
+                nUp = pcr_mul(ga, Uq);
+            }
+            lr_d2* cl = coef + (size_t)(4 * l) * H;
+            cl[t] = lr_d2{al.a, al.b}; cl[H + t] = lr_d2{al.c, al.d}; cl[2 * H + t] = lr_d2{ga.a, ga.b}; cl[3 * H + t] = lr_d2{ga.c, ga.d};
+            // (the reduced diagonal block is symmetric up to rounding: kept so)
+            const double off = 0.5 * (nDg.b + nDg.c);
+            Dg = Pcr22{nDg.a, off, off, nDg.d}; Lo = nLo; Up = nUp;
         }
+        __syncthreads();
+    }
+    if (t < H) {
+        const Pcr22 inv = pcr_inv(Dg);
+        coef[(size_t)(4 * L) * H + t] = lr_d2{inv.a, inv.b};
+        coef[(size_t)(4 * L + 1) * H + t] = lr_d2{inv.c, inv.d};
     }
     __syncthreads();
-    LR_CLK(4);
-    if (blockIdx.y == 0)
-        for (int e = tid; e < H * LR_REC; e += LR_COLS) rec_g[(size_t)i * H * LR_REC + e] = rec[e];
-    const int c = c0 + tid;
-    if (c >= H) return;
+    if (blockIdx.y == 0) {
+        lr_d2* dst = reinterpret_cast<lr_d2*>(coef_g) + (size_t)i * n_coef;
+        for (int e = tid; e < n_coef; e += PCR_THREADS) dst[e] = coef[e];
+    }
+    // the columns of this block
+    const int cpb = (H + gridDim.y - 1) / gridDim.y;
+    const int c_lo = blockIdx.y * cpb, c_hi = min(H, c_lo + cpb);
     double* Gi = G + (size_t)i * H * H;
-    double y0 = gd[2 * c], y1 = gd[2 * c + 1];
-    Gi[(size_t)c * H + c] = y0;
-#pragma unroll 4
-    for (int t = c - 1; t >= 0; --t) {
-        const double* r = rec + (size_t)t * LR_REC;
-        const double n0 = -(r[3] * y0 + r[4] * y1), n1 = -(r[5] * y0 + r[6] * y1);
-        y0 = n0; y1 = n1;
-        Gi[(size_t)t * H + c] = y0;
-        Gi[(size_t)c * H + t] = y0;
+    for (int c0 = c_lo + wave * PCR_NP; c0 < c_hi; c0 += PCR_WAVES * PCR_NP) {
+        lr_d2 r[PCR_NP][2];
+#pragma unroll
+        for (int k = 0; k < PCR_NP; ++k) {
+            r[k][0] = lr_d2{(lane == c0 + k) ? 1.0 : 0.0, 0.0};
+            r[k][1] = lr_d2{(lane + 64 == c0 + k) ? 1.0 : 0.0, 0.0};
+        }
+        pcr_solve(coef, rb, H, L, lane, r);
+#pragma unroll
+        for (int k = 0; k < PCR_NP; ++k) {
+            if (c0 + k < c_hi) {
+                if (lane < H) Gi[(size_t)(c0 + k) * H + lane] = r[k][0].x;
+                if (lane + 64 < H) Gi[(size_t)(c0 + k) * H + lane + 64] = r[k][1].x;
+            }
+        }
     }
-#ifdef LR_T_CLK
-    LR_CLK(5);
-    if (blockIdx.x == 0 && c == H - 1)
-        printf("chain clk (10 ns): stage %llu fact %llu post %llu diag %llu cols %llu\n", clk_[1] - clk_[0], clk_[2] - clk_[1], clk_[3] - clk_[2],
-               clk_[4] - clk_[3], clk_[5] - clk_[4]);
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -250,7 +309,6 @@ __global__ __launch_bounds__(256) void gpmp2_lr_gradient(const float* __restrict
     const int dim = 2 * D;
     const LrCoef C = lr_coef(K);
     const double dt = K.dt;
-    double* gb = g + (size_t)b * H * dim;
     double cost = 0.0;
     // the particle's trajectory through LDS: every load of the workgroup is in flight at once (read in place, an element's six
     // neighbours were a round trip per trip of the loop below: 35 us at C4 for 52 MB of traffic)
@@ -280,7 +338,7 @@ __global__ __launch_bounds__(256) void gpmp2_lr_gradient(const float* __restrict
     // a lane per (waypoint, joint), consecutive lanes = consecutive joints of a row: the D positions (and the D velocities) of a
     // row are read and written as one piece (a lane per waypoint walking the joints touched 64 rows per instruction: 37 us at C4)
     for (int e = tid; e < H * D; e += 256) {
-        const int t = e / D, j = e - t * D;
+        const int j = e / H, t = e - j * H;              // consecutive threads = consecutive waypoints of a joint: the stores below are whole lines
         const float* xt = xb + (size_t)t * dim;
         const double p = (double)xt[j], v = (double)xt[D + j];
         double gp = 0.0, gv = 0.0;
@@ -307,12 +365,7 @@ __global__ __launch_bounds__(256) void gpmp2_lr_gradient(const float* __restrict
             gp = fma(K.kg, ep, gp); gv = fma(K.kg, ev, gv);
             cost += K.kg * fma(ep, ep, ev * ev);
         }
-#ifndef LR_T_GRAD_NOSTORE
-        gb[(size_t)t * dim + j] = gp;
-        gb[(size_t)t * dim + D + j] = gv;
-#else
-        if (gp == 1.2345 && gv == 2.3456) gb[0] = 0.0;
-#endif
+        reinterpret_cast<lr_d2*>(g)[((size_t)j * B + b) * H + t] = lr_d2{gp, gv};
     }
     cost = wave_sum_f64(cost);
     if (lane == 0) { red_c[wave] = cost; red_n[wave] = n_est; }
@@ -325,178 +378,132 @@ __global__ __launch_bounds__(256) void gpmp2_lr_gradient(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// A0^-1 applied to a gradient: lane = (particle, joint) -- 9 particles per wave at D = 7 --, the shared factors in LDS.
-// FINAL = false: the gradient is g_rest; writes the position rows of u0 = A0^-1 g_rest (t major: upos[t][lane]).
-// FINAL = true: the gradient is g_rest + V w (w: dense per field and waypoint, zero off the active rows); writes x += step * dtheta
-// (gpmp2.py:326-331).  Forward r_t = g_t - F_{t-1}^T r_{t-1}, z_t = W_t r_t (records to zbuf, t major); backward
-// y_t = z_t - F_t y_{t+1}.  A lane walks its chain alone (the kernel lasts 2 H steps whatever the batch): a step is the ring
-// hand-over of what it reads (16 steps ahead), four fma on the chain, four off it, one record store.
+// A0^-1 applied to a gradient.  grid = (D, NG [+ 1]), block = PCR_THREADS: a block stages ITS joint's coefficient table (61 KB at
+// H = 128) and its waves take the particles of group blockIdx.y, PCR_NP at a time.  g: joint major, (D, B, H) pairs (position,
+// velocity) -- a chain's right-hand side is 2 KB in a row (gpmp2_lr_gradient writes it so).
+// FINAL = false: the gradient is g_rest; writes the position rows of u0 = A0^-1 g_rest, joint major (upos[j][b][t]).  Its extra
+// row of blocks (blockIdx.y = NG; block 0 of it works) sorts the particles by size class for gpmp2_lr_cap.
+// FINAL = true: the gradient is g_rest + V w (w: dense per field and waypoint, zero off the active rows); x += step * dtheta
+// (gpmp2.py:326-331).
 // ------------------------------------------------------------------------------------------------
 template <bool FINAL>
-__global__ __launch_bounds__(64) void gpmp2_lr_sweep(float* __restrict__ x, const double* __restrict__ g, const float* __restrict__ jac,
-                                                     const double* __restrict__ wdense, const double* __restrict__ rec_g,
-                                                     double* __restrict__ zbuf, double* __restrict__ upos, int* __restrict__ ord, int B, int H, int D,
-                                                     int F, GpConst K) {
+__global__ __launch_bounds__(PCR_THREADS) void gpmp2_pcr_solve(float* __restrict__ x, const double* __restrict__ g, const float* __restrict__ jac,
+                                                               const double* __restrict__ wdense, const double* __restrict__ coef_g,
+                                                               double* __restrict__ upos, int* __restrict__ ord, int B, int H, int D, int F,
+                                                               int L, int NG, GpConst K) {
     extern __shared__ double lds[];
-    const int lane = threadIdx.x, dim = 2 * D;
-    if (!FINAL && blockIdx.x == gridDim.x - 1) {
-        // the extra workgroup: the particles sorted by size class (gpmp2_lr_gradient), largest first -- the order gpmp2_lr_cap
-        // takes them in.  A counting sort: class totals and positions by LDS atomics.
+    const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (!FINAL && (int)blockIdx.y == NG) {
+        // the extra row: the particles sorted by size class (gpmp2_lr_gradient), largest first -- the order gpmp2_lr_cap takes them
+        // in.  A counting sort: class totals and positions by LDS atomics.
+        if (j != 0) return;
         int* cnt = reinterpret_cast<int*>(lds);            // [0, LR_ORD): totals, then running offsets
-        if (lane < LR_ORD) cnt[lane] = 0;
-        lr_wave_sync();
-        for (int b0 = 0; b0 < B; b0 += 64)
-            if (b0 + lane < B) atomicAdd(&cnt[ord[b0 + lane]], 1);
-        lr_wave_sync();
-        if (lane == 0) {
+        if (tid < LR_ORD) cnt[tid] = 0;
+        __syncthreads();
+        for (int b0 = 0; b0 < B; b0 += PCR_THREADS)
+            if (b0 + tid < B) atomicAdd(&cnt[ord[b0 + tid]], 1);
+        __syncthreads();
+        if (tid == 0) {
             int run = 0;
             for (int c = 0; c < LR_ORD; ++c) { const int n = cnt[c]; cnt[c] = run; run += n; }
         }
-        lr_wave_sync();
-        for (int b0 = 0; b0 < B; b0 += 64)
-            if (b0 + lane < B) ord[B + atomicAdd(&cnt[ord[b0 + lane]], 1)] = b0 + lane;
+        __syncthreads();
+        for (int b0 = 0; b0 < B; b0 += PCR_THREADS)
+            if (b0 + tid < B) ord[B + atomicAdd(&cnt[ord[b0 + tid]], 1)] = b0 + tid;
         return;
     }
-    const int per = 64 / D;                                   // particles per wave
-    const int stride = H * LR_REC + 2;                        // doubles between two joints' tables (+ 2: their records fall on different banks)
-    // the shared factors into LDS, 16 bytes at a time, EIGHT loads in flight per lane and joint (one load per trip with its index
-    // division cost the kernel ~30 us of serialised L2 round trips before its first step: a sweep took 43 us whatever it did per step)
-    for (int j = 0; j < D; ++j) {
-        const lr_d2* src = reinterpret_cast<const lr_d2*>(rec_g + (size_t)j * H * LR_REC);
-        lr_d2* dst = reinterpret_cast<lr_d2*>(lds + (size_t)j * stride);
-        const int n2 = H * (LR_REC / 2);
-        for (int e0 = 0; e0 < n2; e0 += 64 * 8) {
-            lr_d2 tmp[8];
+    const int n_coef = (4 * L + 2) * H;
+    lr_d2* coef = reinterpret_cast<lr_d2*>(lds);
+    lr_d2* rb = coef + n_coef + (size_t)wave * PCR_NP * H;
+    pcr_stage(reinterpret_cast<const lr_d2*>(coef_g) + (size_t)j * n_coef, coef, n_coef, tid);
+    __syncthreads();
+    const int per_block = (B + NG - 1) / NG;
+    const int p_lo = blockIdx.y * per_block, p_hi = min(B, p_lo + per_block);
+    const int tt[2] = {lane, lane + 64};
+    const bool vv[2] = {lane < H, lane + 64 < H};
+    for (int p0 = p_lo + wave * PCR_NP; p0 < p_hi; p0 += PCR_WAVES * PCR_NP) {
+        lr_d2 r[PCR_NP][2];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = e0 + lane + 64 * u;
-                tmp[u] = src[e < n2 ? e : n2 - 1];
-            }
+        for (int k = 0; k < PCR_NP; ++k) {
+            const int p = (p0 + k < p_hi) ? p0 + k : p_hi - 1;               // (beyond the group: a valid chain, not stored)
+            const lr_d2* gb = reinterpret_cast<const lr_d2*>(g) + ((size_t)j * B + p) * H;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = e0 + lane + 64 * u;
-                if (e < n2) dst[e] = tmp[u];
+            for (int e = 0; e < 2; ++e) {
+                lr_d2 v = vv[e] ? gb[tt[e]] : lr_d2{0.0, 0.0};
+                if (FINAL && vv[e]) {
+                    for (int f = 0; f < F; ++f) {
+                        const double w = wdense[((size_t)f * B + p) * H + tt[e]];
+                        if (w != 0.0) v.x = fma((double)jac[(((size_t)f * B + p) * H + tt[e]) * (D + 1) + j], w, v.x);     // (row 0: w = 0)
+                    }
+                }
+                r[k][e] = v;
             }
+        }
+        pcr_solve(coef, rb, H, L, lane, r);
+#pragma unroll
+        for (int k = 0; k < PCR_NP; ++k) {
+            const int p = p0 + k;
+            if (p < p_hi) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    if (vv[e]) {
+                        if (FINAL) {
+                            // the step of (particle, joint), joint major over the u0 rows (consumed by gpmp2_lr_cap): gpmp2_lr_apply adds
+                            // it to x row by row (written to x from here -- 4 bytes every 8 D -- the kernel took 66 us instead of 21)
+                            reinterpret_cast<float2*>(upos)[((size_t)j * B + p) * H + tt[e]] =
+                                make_float2((float)(K.step * r[k][e].x), (float)(K.step * r[k][e].y));
+                        } else {
+                            upos[((size_t)j * B + p) * H + tt[e]] = r[k][e].x;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// x += step * dtheta (gpmp2.py:326-331): the steps are joint major ((D, B, H) pairs of floats, gpmp2_pcr_solve<true>), x is (B, H, 2 D):
+// a workgroup per particle turns its rows through LDS, so both sides move in whole lines.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gpmp2_lr_apply(float* __restrict__ x, const float2* __restrict__ dth, int B, int H, int D) {
+    __shared__ float xs[LR_HMAX * 2 * MPB_MAX_DOF];
+    const int tid = threadIdx.x, b = blockIdx.x, dim = 2 * D, nx = H * dim;
+    float* xg = x + (size_t)b * nx;
+    constexpr int NT = (LR_HMAX * 2 * MPB_MAX_DOF + 255) / 256;
+    float tmp[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int e = tid + 256 * u;
+        tmp[u] = (e < nx) ? xg[e] : 0.f;
+    }
+    constexpr int ND = (LR_HMAX * MPB_MAX_DOF + 255) / 256;
+    float2 dv[ND];
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+        const int e = tid + 256 * u, j = e / H, t = e - j * H;
+        dv[u] = (e < H * D) ? dth[((size_t)j * B + b) * H + t] : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int e = tid + 256 * u;
+        if (e < nx) xs[e] = tmp[u];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+        const int e = tid + 256 * u, j = e / H, t = e - j * H;
+        if (e < H * D) {
+            xs[t * dim + j] += dv[u].x;
+            xs[t * dim + D + j] += dv[u].y;
         }
     }
     __syncthreads();
-    const int pl = lane / D, i = lane - pl * D;
-    const int p = blockIdx.x * per + pl;
-    if (pl >= per || p >= B) return;                          // (no block barrier below: idle lanes leave, nothing is masked per step)
-    const bool live = true;
-    const int pc = p;
-    const size_t NL = (size_t)B * D;                          // lanes of the whole batch: the t-major arrays' row length
-    const size_t gl = (size_t)pc * D + i;
-    const double* gb = g + (size_t)pc * H * dim;
-    const double* tab = lds + (size_t)i * stride;
-    const float* jb = jac + (size_t)pc * H * (D + 1);
-    const double* wb = wdense + (size_t)pc * H;
-    // ---- forward
-    double rg0_[LR_PF], rg1_[LR_PF], rw_[LR_PF];
-    float rh_[LR_PF];
 #pragma unroll
-    for (int u = 0; u < LR_PF; ++u) {           // ring slot u <- waypoint u
-        const int tc = (u < H) ? u : H - 1;
-        rg0_[u] = gb[(size_t)tc * dim + i];
-        rg1_[u] = gb[(size_t)tc * dim + D + i];
-        if (FINAL) {
-            rh_[u] = jb[(size_t)tc * (D + 1) + i];
-            rw_[u] = wb[tc];
-        }
+    for (int u = 0; u < NT; ++u) {
+        const int e = tid + 256 * u;
+        if (e < nx) xg[e] = xs[e];
     }
-    double r0 = 0.0, r1 = 0.0, f00 = 0.0, f01 = 0.0, f10 = 0.0, f11 = 0.0;
-    // the joint's factor record of the CURRENT step, read from LDS one step ahead (R0 .. R3 = W00 W01 | W11 F00 | F01 F10 | F11 -):
-    // read in the step that uses it, the LDS round trip sat on every step of the chain (~100 of a step's ~290 cycles)
-    const lr_d2* tab2 = reinterpret_cast<const lr_d2*>(tab);
-    lr_d2 R0 = tab2[0], R1 = tab2[1], R2 = tab2[2], R3 = tab2[3];
-    double* zr = zbuf + gl * LR_ZREC;
-    const size_t zstep = NL * LR_ZREC;
-    // (the ring slots must be (re)defined OUTSIDE any conditional: a slot loaded under `if (t < H)` reaches the next trip through a
-    // phi, the copy that resolves it sits at the end of the defining block and waits for the load it has just issued -- the first
-    // build of this kernel ran one memory round trip per step.  Whole blocks of LR_PF steps carry no guard; the tail does.)
-    auto fwd_step = [&](auto uc, int t) {
-                constexpr int u = decltype(uc)::value;
-#ifdef LR_T_NOLOAD     // (wrong-result timing switch, tuning builds only: the sweep without its ring loads)
-                double gp = 1.0;
-                const double gv = 0.5;
-#else
-                double gp = rg0_[u];
-                const double gv = rg1_[u];
-#endif
-                if (FINAL) gp = fma((double)rh_[u], rw_[u], gp);          // (row 0: h = 0 and w = 0)
-                {
-                    const int tc = (t + LR_PF < H) ? t + LR_PF : H - 1;
-                    rg0_[u] = gb[(size_t)tc * dim + i];
-                    rg1_[u] = gb[(size_t)tc * dim + D + i];
-                    if (FINAL) {
-                        rh_[u] = jb[(size_t)tc * (D + 1) + i];
-                        rw_[u] = wb[tc];
-                    }
-                }
-                if (FINAL) {
-                    for (int f = 1; f < F; ++f)          // further chained fields (rare: not prefetched)
-                        gp = fma((double)jac[(((size_t)f * B + pc) * H + t) * (D + 1) + i], wdense[((size_t)f * B + pc) * H + t], gp);
-                }
-                const lr_d2* rn = tab2 + (size_t)((t + 1 < H) ? t + 1 : t) * (LR_REC / 2);
-                const lr_d2 N0 = rn[0], N1 = rn[1], N2 = rn[2], N3 = rn[3];
-                const double a0 = fma(-f10, r1, fma(-f00, r0, gp)), a1 = fma(-f11, r1, fma(-f01, r0, gv));
-                r0 = a0; r1 = a1;
-                const double z0 = fma(R0.y, r1, R0.x * r0), z1 = fma(R1.x, r1, R0.y * r0);
-                f00 = R1.y; f01 = R2.x; f10 = R2.y; f11 = R3.x;
-                R0 = N0; R1 = N1; R2 = N2; R3 = N3;
-#ifndef LR_T_NOSTORE   // (wrong-result timing switch, tuning builds only)
-                if (live) *reinterpret_cast<lr_d2*>(zr) = lr_d2{z0, z1};
-#else
-                if (live && t == 0) *reinterpret_cast<lr_d2*>(zr) = lr_d2{z0, z1};
-#endif
-                zr += zstep;
-    };
-    int tb = 0;
-    for (; tb + LR_PF <= H; tb += LR_PF) lr_static_for<0, LR_PF>([&](auto uc) { fwd_step(uc, tb + decltype(uc)::value); });
-    lr_static_for<0, LR_PF>([&](auto uc) {
-        if (tb + decltype(uc)::value < H) fwd_step(uc, tb + decltype(uc)::value);         // (wave-uniform)
-    });
-    // ---- backward: records H - 1 .. 0 through the ring (FINAL: the lane's x beside them)
-    lr_d2 q_[LR_PF];
-    float xp_[LR_PF], xv_[LR_PF];
-    const float* xb = x + (size_t)pc * H * dim;
-#pragma unroll
-    for (int u = 0; u < LR_PF; ++u) {
-        const int t = (H - 1 - u >= 0) ? H - 1 - u : 0;
-        q_[u] = *reinterpret_cast<const lr_d2*>(zbuf + ((size_t)t * NL + gl) * LR_ZREC);
-        if (FINAL) { xp_[u] = xb[(size_t)t * dim + i]; xv_[u] = xb[(size_t)t * dim + D + i]; }
-    }
-    double y0 = 0.0, y1 = 0.0;            // (y_H = 0: the first step takes z_{H-1} as it is)
-    R1 = tab2[(size_t)(H - 1) * (LR_REC / 2) + 1]; R2 = tab2[(size_t)(H - 1) * (LR_REC / 2) + 2]; R3 = tab2[(size_t)(H - 1) * (LR_REC / 2) + 3];
-    auto bwd_step = [&](auto uc, int t) {
-                constexpr int u = decltype(uc)::value;
-                const lr_d2 zz = q_[u];
-                float xp = 0.f, xv = 0.f;
-                if (FINAL) { xp = xp_[u]; xv = xv_[u]; }
-                {
-                    const int tn = (t - LR_PF >= 0) ? t - LR_PF : 0;
-                    q_[u] = *reinterpret_cast<const lr_d2*>(zbuf + ((size_t)tn * NL + gl) * LR_ZREC);
-                    if (FINAL) { xp_[u] = xb[(size_t)tn * dim + i]; xv_[u] = xb[(size_t)tn * dim + D + i]; }
-                }
-                const lr_d2* rn = tab2 + (size_t)((t > 0) ? t - 1 : 0) * (LR_REC / 2);
-                const lr_d2 N1 = rn[1], N2 = rn[2], N3 = rn[3];
-                const double a0 = fma(-R2.x, y1, fma(-R1.y, y0, zz.x)), a1 = fma(-R3.x, y1, fma(-R2.y, y0, zz.y));
-                y0 = a0; y1 = a1;
-                R1 = N1; R2 = N2; R3 = N3;
-                if (live) {
-                    if (FINAL) {
-                        x[((size_t)p * H + t) * dim + i] = (float)((double)xp + K.step * y0);
-                        x[((size_t)p * H + t) * dim + D + i] = (float)((double)xv + K.step * y1);
-                    } else {
-                        upos[(size_t)t * NL + gl] = y0;
-                    }
-                }
-    };
-    int kb = 0;
-    for (; kb + LR_PF <= H; kb += LR_PF) lr_static_for<0, LR_PF>([&](auto uc) { bwd_step(uc, H - 1 - kb - decltype(uc)::value); });
-    lr_static_for<0, LR_PF>([&](auto uc) {
-        if (kb + decltype(uc)::value < H) bwd_step(uc, H - 1 - kb - decltype(uc)::value);
-    });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -540,9 +547,8 @@ __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ ja
     int* fact = tact + 128;
     int* cnt = fact + 128;                                       // [0 .. 2 F): active rows of (field, 64-waypoint chunk)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // the particle of this workgroup: largest systems first (gpmp2_lr_gradient, gpmp2_lr_sweep<false>)
+    // the particle of this workgroup: largest systems first (gpmp2_lr_gradient, gpmp2_pcr_solve<false>)
     const int b = ord[B + blockIdx.x];
-    const size_t NL = (size_t)B * D;
     // ---- 1. the active collision rows, compacted (field major, then waypoint); the collision part of the cost.  Chunk (f, base) is
     //         examined by wave (2 f + base / 64) mod 4: counts first, then positions
     const int nchunk = F * ((H + 63) >> 6);
@@ -611,8 +617,8 @@ __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ ja
     // ---- 2. right-hand side: c_a - h_a . u0[position rows of t_a]
     if (tid < n) {
         double sacc = wv[tid];
-        const double* up = upos + (size_t)tact[tid] * NL + (size_t)b * D;
-        for (int j = 0; j < D; ++j) sacc -= (double)hb[tid * hs + j] * up[j];
+        const double* up = upos + (size_t)b * H + tact[tid];                       // joint major: upos[j][b][t]
+        for (int j = 0; j < D; ++j) sacc -= (double)hb[tid * hs + j] * up[(size_t)j * B * H];
         wv[tid] = sacc;
     }
     __syncthreads();
@@ -826,7 +832,7 @@ bool mpb_gpmp2_lr_ok(int H, int D, int n_fields) { return H >= 2 && D >= 1 && D 
 // doubles of workspace: shared tables (factor records, G) + per-batch arrays (sweep records, u0's position rows, w, the GP cost)
 size_t mpb_gpmp2_lr_ws_doubles(int B, int H, int D) {
     const size_t NL = (size_t)B * D;
-    return (size_t)D * H * LR_REC + (size_t)D * H * H + (size_t)H * NL * LR_ZREC + (size_t)H * NL + (size_t)MPB_GP_MAX_FIELDS * B * H + (size_t)B + 64 +
+    return 2 * (size_t)D * pcr_coef_entries(H) + (size_t)D * H * H + (size_t)H * NL + (size_t)MPB_GP_MAX_FIELDS * B * H + (size_t)B + 64 +
            (size_t)B * H * 2 * D +         // ... and g_rest
            (size_t)B + 1;                  // ... and the size class of every particle + the launch order of the capacitance systems (2 B ints)
 }
@@ -834,25 +840,38 @@ size_t mpb_gpmp2_lr_ws_doubles(int B, int H, int D) {
 int mpb_gpmp2_lr_launch(float* x, const float* start, const float* goal, const float* jac, const double* diag_mean, double* ws,
                         float* costs_out, int B, int H, int D, int n_fields, const GpConst& K, hipStream_t stream) {
     const size_t NL = (size_t)B * D;
-    double* rec = ws;
-    double* G = rec + (size_t)D * H * LR_REC;
-    double* zbuf = G + (size_t)D * H * H;
-    double* upos = zbuf + (size_t)H * NL * LR_ZREC;
+    const int L = pcr_levels(H);
+    const size_t n_coef = pcr_coef_entries(H);
+    double* coef = ws;                                                   // D tables of n_coef 16-byte entries
+    double* G = coef + 2 * (size_t)D * n_coef;
+    double* upos = G + (size_t)D * H * H;
     double* wdense = upos + (size_t)H * NL;
     double* gpcost = wdense + (size_t)MPB_GP_MAX_FIELDS * B * H;
     double* grest = gpcost + B + 64;
     int* ord = reinterpret_cast<int*>(grest + (size_t)B * H * 2 * D);        // [0, B): size class of particle b; [B, 2 B): the particles, largest class first
-    const size_t lds_chain = ((size_t)H * LR_REC + (size_t)H * 2 + (size_t)H * LR_KK) * sizeof(double);
-    hipLaunchKernelGGL(gpmp2_chain_kernel, dim3(D, (H + LR_COLS - 1) / LR_COLS), dim3(LR_COLS), lds_chain, stream, diag_mean, rec, G, H, D, K);
-    const int per = 64 / D;
-    const size_t lds_sweep = (size_t)D * (H * LR_REC + 2) * sizeof(double);
-    const dim3 gs((B + per - 1) / per);
+    static const int n_cu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    const size_t lds_rows = (size_t)PCR_WAVES * PCR_NP * H * sizeof(lr_d2);
+    const size_t lds_setup = n_coef * sizeof(lr_d2) + 12 * (size_t)H * sizeof(double) + lds_rows;
+    const size_t lds_solve = n_coef * sizeof(lr_d2) + lds_rows;
+    const int NY = (H + PCR_WAVES * PCR_NP - 1) / (PCR_WAVES * PCR_NP);          // one pass of columns per block
+    hipLaunchKernelGGL(gpmp2_pcr_setup, dim3(D, NY), dim3(PCR_THREADS), lds_setup, stream, diag_mean, coef, G, H, D, L, K);
     hipLaunchKernelGGL(gpmp2_lr_gradient, dim3(B), dim3(256), 0, stream, x, start, goal, jac, grest, gpcost, ord, B, H, D, n_fields, K);
-    hipLaunchKernelGGL(gpmp2_lr_sweep<false>, dim3(gs.x + 1), dim3(64), lds_sweep, stream, x, grest, jac, wdense, rec, zbuf, upos, ord, B, H, D, n_fields, K);
+    // particle groups: one block per CU over the D joints, at least one pass of the waves per group
+    int NG = n_cu / D;
+    if (NG < 1) NG = 1;
+    if (NG > (B + PCR_WAVES * PCR_NP - 1) / (PCR_WAVES * PCR_NP)) NG = (B + PCR_WAVES * PCR_NP - 1) / (PCR_WAVES * PCR_NP);
+    hipLaunchKernelGGL(gpmp2_pcr_solve<false>, dim3(D, NG + 1), dim3(PCR_THREADS), lds_solve, stream, x, grest, jac, wdense, coef, upos, ord, B, H, D,
+                       n_fields, L, NG, K);
     const int n_max = n_fields * (H - 1);
     const int trm = (n_max + 16) >> 4, ntm = (trm * (trm + 1)) >> 1;             // tiles of the largest system the shape allows
     const size_t lds = ((size_t)ntm * LR_TILE + 256) * sizeof(double) + (size_t)LR_NMAX * (D <= 8 ? 8 : MPB_MAX_DOF) * sizeof(float) + (256 + 16) * sizeof(int);
     hipLaunchKernelGGL(gpmp2_lr_cap, dim3(B), dim3(256), lds, stream, jac, upos, G, gpcost, wdense, costs_out, ord, B, H, D, n_fields, ntm, K);
-    hipLaunchKernelGGL(gpmp2_lr_sweep<true>, gs, dim3(64), lds_sweep, stream, x, grest, jac, wdense, rec, zbuf, upos, ord, B, H, D, n_fields, K);
+    hipLaunchKernelGGL(gpmp2_pcr_solve<true>, dim3(D, NG), dim3(PCR_THREADS), lds_solve, stream, x, grest, jac, wdense, coef, upos, ord, B, H, D,
+                       n_fields, L, NG, K);
+    hipLaunchKernelGGL(gpmp2_lr_apply, dim3(B), dim3(256), 0, stream, x, reinterpret_cast<const float2*>(upos), B, H, D);
     return MPB_OK;
 }
