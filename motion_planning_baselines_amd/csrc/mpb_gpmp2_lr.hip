@@ -387,9 +387,9 @@ __global__ __launch_bounds__(256) void gpmp2_lr_gradient(const float* __restrict
 // (gpmp2.py:326-331).
 // ------------------------------------------------------------------------------------------------
 template <bool FINAL>
-__global__ __launch_bounds__(PCR_THREADS) void gpmp2_pcr_solve(float* __restrict__ x, const double* __restrict__ g, const float* __restrict__ jac,
+__global__ __launch_bounds__(PCR_THREADS) void gpmp2_pcr_solve(double* __restrict__ g, const float* __restrict__ jac,
                                                                const double* __restrict__ wdense, const double* __restrict__ coef_g,
-                                                               double* __restrict__ upos, int* __restrict__ ord, int B, int H, int D, int F,
+                                                               double* __restrict__ dth, int* __restrict__ ord, int B, int H, int D, int F,
                                                                int L, int NG, GpConst K) {
     extern __shared__ double lds[];
     const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -406,34 +406,45 @@ __global__ __launch_bounds__(PCR_THREADS) void gpmp2_pcr_solve(float* __restrict
         if (tid == 0) {
             int run = 0;
             for (int c = 0; c < LR_ORD; ++c) { const int n = cnt[c]; cnt[c] = run; run += n; }
+            ord[2 * B] = cnt[LR_ORD - 1];          // particles with collision rows: the first so many of the list (the last class has none)
         }
         __syncthreads();
         for (int b0 = 0; b0 < B; b0 += PCR_THREADS)
             if (b0 + tid < B) ord[B + atomicAdd(&cnt[ord[b0 + tid]], 1)] = b0 + tid;
         return;
     }
+    // FINAL: only the particles WITH collision rows (the head of the sorted list): the others' step is u0 itself (gpmp2_lr_apply)
+    const int n_part = FINAL ? ord[2 * B] : B;
+    const int per_block = (n_part + NG - 1) / NG;
+    const int p_lo = blockIdx.y * per_block, p_hi = min(n_part, p_lo + per_block);
+    if (p_lo >= p_hi) return;                                                 // (block-uniform, before any barrier)
     const int n_coef = (4 * L + 2) * H;
     lr_d2* coef = reinterpret_cast<lr_d2*>(lds);
     lr_d2* rb = coef + n_coef + (size_t)wave * PCR_NP * H;
     pcr_stage(reinterpret_cast<const lr_d2*>(coef_g) + (size_t)j * n_coef, coef, n_coef, tid);
     __syncthreads();
-    const int per_block = (B + NG - 1) / NG;
-    const int p_lo = blockIdx.y * per_block, p_hi = min(B, p_lo + per_block);
     const int tt[2] = {lane, lane + 64};
     const bool vv[2] = {lane < H, lane + 64 < H};
+    lr_d2* g2 = reinterpret_cast<lr_d2*>(g);
     for (int p0 = p_lo + wave * PCR_NP; p0 < p_hi; p0 += PCR_WAVES * PCR_NP) {
         lr_d2 r[PCR_NP][2];
+        int pk[PCR_NP];
 #pragma unroll
         for (int k = 0; k < PCR_NP; ++k) {
-            const int p = (p0 + k < p_hi) ? p0 + k : p_hi - 1;               // (beyond the group: a valid chain, not stored)
-            const lr_d2* gb = reinterpret_cast<const lr_d2*>(g) + ((size_t)j * B + p) * H;
+            const int a = (p0 + k < p_hi) ? p0 + k : p_hi - 1;               // (beyond the group: a valid chain, not stored)
+            const int p = FINAL ? ord[B + a] : a;
+            pk[k] = p;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                lr_d2 v = vv[e] ? gb[tt[e]] : lr_d2{0.0, 0.0};
-                if (FINAL && vv[e]) {
-                    for (int f = 0; f < F; ++f) {
-                        const double w = wdense[((size_t)f * B + p) * H + tt[e]];
-                        if (w != 0.0) v.x = fma((double)jac[(((size_t)f * B + p) * H + tt[e]) * (D + 1) + j], w, v.x);     // (row 0: w = 0)
+                lr_d2 v = lr_d2{0.0, 0.0};
+                if (vv[e]) {
+                    if (FINAL) {
+                        for (int f = 0; f < F; ++f) {
+                            const double w = wdense[((size_t)f * B + p) * H + tt[e]];
+                            if (w != 0.0) v.x = fma((double)jac[(((size_t)f * B + p) * H + tt[e]) * (D + 1) + j], w, v.x);     // (row 0: w = 0)
+                        }
+                    } else {
+                        v = g2[((size_t)j * B + p) * H + tt[e]];
                     }
                 }
                 r[k][e] = v;
@@ -442,18 +453,21 @@ __global__ __launch_bounds__(PCR_THREADS) void gpmp2_pcr_solve(float* __restrict
         pcr_solve(coef, rb, H, L, lane, r);
 #pragma unroll
         for (int k = 0; k < PCR_NP; ++k) {
-            const int p = p0 + k;
-            if (p < p_hi) {
+            if (p0 + k < p_hi) {
+                const int p = pk[k];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     if (vv[e]) {
+                        lr_d2* slot = g2 + ((size_t)j * B + p) * H + tt[e];
                         if (FINAL) {
-                            // the step of (particle, joint), joint major over the u0 rows (consumed by gpmp2_lr_cap): gpmp2_lr_apply adds
-                            // it to x row by row (written to x from here -- 4 bytes every 8 D -- the kernel took 66 us instead of 21)
-                            reinterpret_cast<float2*>(upos)[((size_t)j * B + p) * H + tt[e]] =
-                                make_float2((float)(K.step * r[k][e].x), (float)(K.step * r[k][e].y));
+                            // the step of (particle, joint) = step (u0 + A0^-1 V w), joint major over the rows gpmp2_lr_cap's w went through:
+                            // gpmp2_lr_apply adds it to x row by row (written to x from here -- 4 bytes every 8 D -- the kernel took 66 us
+                            // instead of 21)
+                            const lr_d2 u0 = *slot;
+                            reinterpret_cast<float2*>(dth)[((size_t)j * B + p) * H + tt[e]] =
+                                make_float2((float)(K.step * (u0.x + r[k][e].x)), (float)(K.step * (u0.y + r[k][e].y)));
                         } else {
-                            upos[((size_t)j * B + p) * H + tt[e]] = r[k][e].x;
+                            *slot = r[k][e];                                   // u0 over g_rest (position AND velocity rows)
                         }
                     }
                 }
@@ -463,13 +477,16 @@ __global__ __launch_bounds__(PCR_THREADS) void gpmp2_pcr_solve(float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// x += step * dtheta (gpmp2.py:326-331): the steps are joint major ((D, B, H) pairs of floats, gpmp2_pcr_solve<true>), x is (B, H, 2 D):
-// a workgroup per particle turns its rows through LDS, so both sides move in whole lines.
+// x += step * dtheta (gpmp2.py:326-331): the steps are joint major ((D, B, H) pairs of floats, gpmp2_pcr_solve<true>; for a particle
+// without collision rows: step * u0, gpmp2_pcr_solve<false>'s pairs), x is (B, H, 2 D): a workgroup per particle turns its rows through
+// LDS, so both sides move in whole lines.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gpmp2_lr_apply(float* __restrict__ x, const float2* __restrict__ dth, int B, int H, int D) {
+__global__ __launch_bounds__(256) void gpmp2_lr_apply(float* __restrict__ x, const float2* __restrict__ dth, const double* __restrict__ u0,
+                                                      const int* __restrict__ ord, int B, int H, int D, double step) {
     __shared__ float xs[LR_HMAX * 2 * MPB_MAX_DOF];
     const int tid = threadIdx.x, b = blockIdx.x, dim = 2 * D, nx = H * dim;
     float* xg = x + (size_t)b * nx;
+    const bool has_rows = ord[b] != LR_ORD - 1;                // (block-uniform: the particle's size class, gpmp2_lr_gradient)
     constexpr int NT = (LR_HMAX * 2 * MPB_MAX_DOF + 255) / 256;
     float tmp[NT];
 #pragma unroll
@@ -482,7 +499,15 @@ __global__ __launch_bounds__(256) void gpmp2_lr_apply(float* __restrict__ x, con
 #pragma unroll
     for (int u = 0; u < ND; ++u) {
         const int e = tid + 256 * u, j = e / H, t = e - j * H;
-        dv[u] = (e < H * D) ? dth[((size_t)j * B + b) * H + t] : make_float2(0.f, 0.f);
+        dv[u] = make_float2(0.f, 0.f);
+        if (e < H * D) {
+            if (has_rows) {
+                dv[u] = dth[((size_t)j * B + b) * H + t];
+            } else {            // no collision rows: w = 0 and the step is u0's (gpmp2_pcr_solve<true> skipped the particle)
+                const lr_d2 v = reinterpret_cast<const lr_d2*>(u0)[((size_t)j * B + b) * H + t];
+                dv[u] = make_float2((float)(step * v.x), (float)(step * v.y));
+            }
+        }
     }
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
@@ -617,8 +642,8 @@ __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ ja
     // ---- 2. right-hand side: c_a - h_a . u0[position rows of t_a]
     if (tid < n) {
         double sacc = wv[tid];
-        const double* up = upos + (size_t)b * H + tact[tid];                       // joint major: upos[j][b][t]
-        for (int j = 0; j < D; ++j) sacc -= (double)hb[tid * hs + j] * up[(size_t)j * B * H];
+        const lr_d2* up = reinterpret_cast<const lr_d2*>(upos) + (size_t)b * H + tact[tid];        // joint major pairs (position, velocity): u0[j][b][t]
+        for (int j = 0; j < D; ++j) sacc -= (double)hb[tid * hs + j] * up[(size_t)j * B * H].x;
         wv[tid] = sacc;
     }
     __syncthreads();
@@ -844,8 +869,8 @@ int mpb_gpmp2_lr_launch(float* x, const float* start, const float* goal, const f
     const size_t n_coef = pcr_coef_entries(H);
     double* coef = ws;                                                   // D tables of n_coef 16-byte entries
     double* G = coef + 2 * (size_t)D * n_coef;
-    double* upos = G + (size_t)D * H * H;
-    double* wdense = upos + (size_t)H * NL;
+    double* dth = G + (size_t)D * H * H;                                 // the steps of the particles with collision rows: (D, B, H) float pairs
+    double* wdense = dth + (size_t)H * NL;
     double* gpcost = wdense + (size_t)MPB_GP_MAX_FIELDS * B * H;
     double* grest = gpcost + B + 64;
     int* ord = reinterpret_cast<int*>(grest + (size_t)B * H * 2 * D);        // [0, B): size class of particle b; [B, 2 B): the particles, largest class first
@@ -864,14 +889,14 @@ int mpb_gpmp2_lr_launch(float* x, const float* start, const float* goal, const f
     int NG = n_cu / D;
     if (NG < 1) NG = 1;
     if (NG > (B + PCR_WAVES * PCR_NP - 1) / (PCR_WAVES * PCR_NP)) NG = (B + PCR_WAVES * PCR_NP - 1) / (PCR_WAVES * PCR_NP);
-    hipLaunchKernelGGL(gpmp2_pcr_solve<false>, dim3(D, NG + 1), dim3(PCR_THREADS), lds_solve, stream, x, grest, jac, wdense, coef, upos, ord, B, H, D,
+    hipLaunchKernelGGL(gpmp2_pcr_solve<false>, dim3(D, NG + 1), dim3(PCR_THREADS), lds_solve, stream, grest, jac, wdense, coef, dth, ord, B, H, D,
                        n_fields, L, NG, K);
     const int n_max = n_fields * (H - 1);
     const int trm = (n_max + 16) >> 4, ntm = (trm * (trm + 1)) >> 1;             // tiles of the largest system the shape allows
     const size_t lds = ((size_t)ntm * LR_TILE + 256) * sizeof(double) + (size_t)LR_NMAX * (D <= 8 ? 8 : MPB_MAX_DOF) * sizeof(float) + (256 + 16) * sizeof(int);
-    hipLaunchKernelGGL(gpmp2_lr_cap, dim3(B), dim3(256), lds, stream, jac, upos, G, gpcost, wdense, costs_out, ord, B, H, D, n_fields, ntm, K);
-    hipLaunchKernelGGL(gpmp2_pcr_solve<true>, dim3(D, NG), dim3(PCR_THREADS), lds_solve, stream, x, grest, jac, wdense, coef, upos, ord, B, H, D,
+    hipLaunchKernelGGL(gpmp2_lr_cap, dim3(B), dim3(256), lds, stream, jac, grest, G, gpcost, wdense, costs_out, ord, B, H, D, n_fields, ntm, K);
+    hipLaunchKernelGGL(gpmp2_pcr_solve<true>, dim3(D, NG), dim3(PCR_THREADS), lds_solve, stream, grest, jac, wdense, coef, dth, ord, B, H, D,
                        n_fields, L, NG, K);
-    hipLaunchKernelGGL(gpmp2_lr_apply, dim3(B), dim3(256), 0, stream, x, reinterpret_cast<const float2*>(upos), B, H, D);
+    hipLaunchKernelGGL(gpmp2_lr_apply, dim3(B), dim3(256), 0, stream, x, reinterpret_cast<const float2*>(dth), grest, ord, B, H, D, K.step);
     return MPB_OK;
 }
