@@ -546,6 +546,9 @@ __global__ __launch_bounds__(256) void gpmp2_lr_apply(float* __restrict__ x, con
 // (The first version of the round ran a left-looking column Cholesky on one wave out of a packed triangle: a particle with 116
 // active rows -- the largest of the 2 048 at C4 -- took ~0.45 ms, and the kernel lasts as long as its slowest particle.)
 // ------------------------------------------------------------------------------------------------
+#ifndef LR_ASM_RING
+#define LR_ASM_RING 6                                                        // tiles of M whose G entries are in flight
+#endif
 #define LR_TILE 256                                                          // doubles per tile
 __device__ __forceinline__ int lr_tile(int I, int J) { return ((I * (I + 1)) >> 1) + J; }            // J <= I
 __device__ __forceinline__ int lr_sw(int r, int c) { return (r << 4) + (c ^ r); }
@@ -556,6 +559,7 @@ __device__ __forceinline__ double lr_rsqrt(double x) {                      // v
     return y;
 }
 
+template <int DMAX>        // DMAX: 8 or DMAX -- the joints a row of h is unrolled over (D <= DMAX)
 __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ jac, const double* __restrict__ upos,
                                                    const double* __restrict__ G, const double* __restrict__ gpcost,
                                                    double* __restrict__ wdense, float* __restrict__ costs_out, const int* __restrict__ ord,
@@ -567,32 +571,38 @@ __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ ja
     double* wv = lds + (size_t)n_tiles_max * LR_TILE;
     double* dinv = wv + 128;
     float* hb = reinterpret_cast<float*>(dinv + 128);
-    const int hs = (D <= 8) ? 8 : MPB_MAX_DOF;                  // floats per row of h (the launcher sizes the LDS for it)
+    constexpr int hs = DMAX;                  // floats per row of h (the launcher sizes the LDS for it)
     int* tact = reinterpret_cast<int*>(hb + LR_NMAX * hs);
     int* fact = tact + 128;
     int* cnt = fact + 128;                                       // [0 .. 2 F): active rows of (field, 64-waypoint chunk)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // the particle of this workgroup: largest systems first (gpmp2_lr_gradient, gpmp2_pcr_solve<false>)
     const int b = ord[B + blockIdx.x];
+#ifdef LR_T_CLK
+    unsigned long long cclk_[7]; cclk_[0] = wall_clock64();
+#define CAP_CLK(k) cclk_[k] = wall_clock64()
+#else
+#define CAP_CLK(k)
+#endif
     // ---- 1. the active collision rows, compacted (field major, then waypoint); the collision part of the cost.  Chunk (f, base) is
     //         examined by wave (2 f + base / 64) mod 4: counts first, then positions
     const int nchunk = F * ((H + 63) >> 6);
     double cost = 0.0;
-    float hrow[MPB_MAX_DOF + 1];
+    float hrow[DMAX + 1];
     bool act = false;
     int myt = 0, myf = 0;
     // (F (H - 1) <= 127: at most 8 chunks, two per wave; a wave keeps the rows of its SECOND chunk in the second set below)
-    float hrow2[MPB_MAX_DOF + 1];
+    float hrow2[DMAX + 1];
     bool act2 = false;
     int myt2 = 0, myf2 = 0;
     for (int ch = wave; ch < nchunk; ch += 4) {
         const int f = ch / ((H + 63) >> 6), base = (ch - f * ((H + 63) >> 6)) << 6;
         const int t = base + lane;
         const float* jb = jac + ((size_t)f * B + b) * H * (D + 1);
-        float hr[MPB_MAX_DOF + 1];
+        float hr[DMAX + 1];
         bool a = false;
 #pragma unroll
-        for (int j = 0; j <= MPB_MAX_DOF; ++j) {
+        for (int j = 0; j <= DMAX; ++j) {
             hr[j] = (t < H && t > 0 && j <= D) ? jb[(size_t)t * (D + 1) + j] : 0.f;      // row 0 takes no collision factor
             if (j < D) a = a || (hr[j] != 0.f);
         }
@@ -604,11 +614,11 @@ __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ ja
         if (lane == 0) cnt[ch] = __popcll(m);
         if (ch < 4) {
 #pragma unroll
-            for (int j = 0; j <= MPB_MAX_DOF; ++j) hrow[j] = hr[j];
+            for (int j = 0; j <= DMAX; ++j) hrow[j] = hr[j];
             act = a; myt = t; myf = f;
         } else {
 #pragma unroll
-            for (int j = 0; j <= MPB_MAX_DOF; ++j) hrow2[j] = hr[j];
+            for (int j = 0; j <= DMAX; ++j) hrow2[j] = hr[j];
             act2 = a; myt2 = t; myf2 = f;
         }
     }
@@ -632,13 +642,14 @@ __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ ja
                 tact[pos] = ps ? myt2 : myt;
                 fact[pos] = ps ? myf2 : myf;
 #pragma unroll
-                for (int j = 0; j < MPB_MAX_DOF; ++j)
+                for (int j = 0; j < DMAX; ++j)
                     if (j < hs) hb[pos * hs + j] = (j < D) ? (ps ? hrow2[j] : hrow[j]) : 0.f;
                 wv[pos] = (double)(ps ? hrow2[D] : hrow[D]);     // c of the row (until the right-hand side takes the slot)
             }
         }
     }
     __syncthreads();
+    CAP_CLK(1);
     // ---- 2. right-hand side: c_a - h_a . u0[position rows of t_a]
     if (tid < n) {
         double sacc = wv[tid];
@@ -647,6 +658,7 @@ __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ ja
         wv[tid] = sacc;
     }
     __syncthreads();
+    CAP_CLK(2);
     // ---- 3. the tiles: M[a][c] = [a == c] / kc + sum_i h_a,i h_c,i G_i(t_a, t_c); row n = the right-hand side; identity beyond.
     //         A tile per pass of the 256 threads, the NEXT tile's G entries (L2) fetched before the current tile's arithmetic
     const int TR = (n + 16) >> 4;                                // tile rows that hold rows 0 .. n
@@ -654,33 +666,32 @@ __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ ja
     {
         const double ikc = 1.0 / K.kc;
         const int r = tid >> 4, c = tid & 15;
-        // tile q of the lower triangle, row major: (I, J) with q = I (I + 1) / 2 + J
-        auto tile_of = [](int q, int& I, int& J) {
-            I = (int)((__builtin_sqrtf(8.f * (float)q + 1.f) - 1.f) * 0.5f);
-            while ((I + 1) * (I + 2) / 2 <= q) ++I;
-            while (I * (I + 1) / 2 > q) --I;
-            J = q - I * (I + 1) / 2;
-        };
-        auto fetch = [&](int q, double (&gv)[MPB_MAX_DOF]) {
-            int I, J;
-            tile_of(q < ntl ? q : ntl - 1, I, J);
-            int a = 16 * I + r, cc = 16 * J + c;
+        // tile q of the lower triangle, row major: (I, J) with q = I (I + 1) / 2 + J.  The ring walks q in order: the fetches' and the
+        // emits' (I, J) are stepped, not solved from q (a square root and two correction loops per call were ~80 of a tile's ~400
+        // instructions)
+        int fI = 0, fJ = 0, fq = 0, eI = 0, eJ = 0;
+        auto fetch = [&](double (&gv)[DMAX]) {             // tile fq (beyond the last tile: the last one again)
+            int a = 16 * fI + r, cc = 16 * fJ + c;
             if (cc > a) { const int t_ = a; a = cc; cc = t_; }              // (diagonal tiles are stored full: mirror)
             const bool on = a < n;
             const double* Gst = G + (size_t)tact[on ? a : 0] * H + tact[on ? cc : 0];
 #pragma unroll
-            for (int j = 0; j < MPB_MAX_DOF; ++j) gv[j] = (j < D) ? Gst[(size_t)j * H * H] : 0.0;
+            for (int j = 0; j < DMAX; ++j) gv[j] = (j < D) ? Gst[(size_t)j * H * H] : 0.0;
+            if (fq + 1 < ntl) {
+                ++fq;
+                if (++fJ > fI) { ++fI; fJ = 0; }
+            }
         };
-        auto emit = [&](int q, const double (&gv)[MPB_MAX_DOF]) {
-            int I, J;
-            tile_of(q, I, J);
+        auto emit = [&](const double (&gv)[DMAX]) {        // the next tile in order
+            const int I = eI, J = eJ;
+            if (++eJ > eI) { ++eI; eJ = 0; }
             int a = 16 * I + r, cc = 16 * J + c;
             if (cc > a) { const int t_ = a; a = cc; cc = t_; }
             double m;
             if (a < n) {
                 m = (a == cc) ? ikc : 0.0;
 #pragma unroll
-                for (int j = 0; j < MPB_MAX_DOF; ++j)
+                for (int j = 0; j < DMAX; ++j)
                     if (j < D) m = fma((double)hb[a * hs + j] * (double)hb[cc * hs + j], gv[j], m);
             } else if (a == n && cc < n) {
                 m = wv[cc];
@@ -689,25 +700,27 @@ __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ ja
             }
             Tl[(size_t)lr_tile(I, J) * LR_TILE + lr_sw(r, c)] = m;
         };
-        // THREE tiles' G entries (L2, ~1 us) in flight per thread (one tile ahead, the loop paid most of a round trip per tile: 28 us
-        // of the 95 a particle with 116 active rows took)
-        double g0[MPB_MAX_DOF], g1[MPB_MAX_DOF], g2[MPB_MAX_DOF];
-        fetch(0, g0);
-        fetch(1, g1);
-        fetch(2, g2);
+        // LR_ASM_RING tiles' G entries (L2, ~1 us) in flight per thread.  (One tile ahead, the loop paid most of a round trip per tile:
+        // 28 us of the 95 a particle with 116 active rows took.  And a ring slot must be refilled OUTSIDE any conditional -- a fetch
+        // under `if (q + 1 < ntl)` reaches the next trip through a phi whose copy waits for the load it has just issued: the
+        // three-slot ring of the second version ran one tile ahead in effect.  A fetch beyond the last tile re-reads the last one.)
+        double gr[LR_ASM_RING][DMAX];
+        lr_static_for<0, LR_ASM_RING>([&](auto uc) { fetch(gr[decltype(uc)::value]); });
 #ifdef LR_T_CAP_NOASM      // (wrong-result timing switch, tuning builds only: the first tile alone)
         const int ntl_run = 1;
 #else
         const int ntl_run = ntl;
 #endif
-        for (int q = 0; q < ntl_run; q += 3) {
-            emit(q, g0);
-            fetch(q + 3, g0);
-            if (q + 1 < ntl_run) { emit(q + 1, g1); fetch(q + 4, g1); }
-            if (q + 2 < ntl_run) { emit(q + 2, g2); fetch(q + 5, g2); }
+        for (int q = 0; q < ntl_run; q += LR_ASM_RING) {
+            lr_static_for<0, LR_ASM_RING>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                if (q + u < ntl_run) emit(gr[u]);
+                fetch(gr[u]);
+            });
         }
     }
     __syncthreads();
+    CAP_CLK(3);
     // ---- 4. tile Cholesky
     const int TC = (n + 15) >> 4;                                // tile columns with a pivot
     const int li = lane & 15, lk = lane >> 4;
@@ -791,6 +804,7 @@ __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ ja
         }
         __syncthreads();
     }
+    CAP_CLK(4);
     // ---- 5. L^T w = y (y = row n), one wave, a tile row at a time from the last: the 16 x 16 triangular system of the row's diagonal
     //         tile with its entries in registers (lane j < 16 holds L[16 K + k][16 K + j], k = 0 .. 15: sixteen steps of readlane, mul,
     //         fma), then y_j -= sum_k L[16 K + k][j] w_k for every j of the earlier tile rows (lanes = j, j + 64: sixteen independent
@@ -845,8 +859,15 @@ __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ ja
         }
     }
     __syncthreads();
+    CAP_CLK(5);
     // ---- 6. w to its waypoints
     if (tid < n) wdense[((size_t)fact[tid] * B + b) * H + tact[tid]] = wv[tid];
+#ifdef LR_T_CLK
+    CAP_CLK(6);
+    if (blockIdx.x == 0 && tid == 0)
+        printf("cap clk (10 ns) n %d: compact %llu rhs %llu assemble %llu cholesky %llu back %llu scatter %llu\n", n, cclk_[1] - cclk_[0],
+               cclk_[2] - cclk_[1], cclk_[3] - cclk_[2], cclk_[4] - cclk_[3], cclk_[5] - cclk_[4], cclk_[6] - cclk_[5]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -894,7 +915,8 @@ int mpb_gpmp2_lr_launch(float* x, const float* start, const float* goal, const f
     const int n_max = n_fields * (H - 1);
     const int trm = (n_max + 16) >> 4, ntm = (trm * (trm + 1)) >> 1;             // tiles of the largest system the shape allows
     const size_t lds = ((size_t)ntm * LR_TILE + 256) * sizeof(double) + (size_t)LR_NMAX * (D <= 8 ? 8 : MPB_MAX_DOF) * sizeof(float) + (256 + 16) * sizeof(int);
-    hipLaunchKernelGGL(gpmp2_lr_cap, dim3(B), dim3(256), lds, stream, jac, grest, G, gpcost, wdense, costs_out, ord, B, H, D, n_fields, ntm, K);
+    if (D <= 8) hipLaunchKernelGGL(gpmp2_lr_cap<8>, dim3(B), dim3(256), lds, stream, jac, grest, G, gpcost, wdense, costs_out, ord, B, H, D, n_fields, ntm, K);
+    else hipLaunchKernelGGL(gpmp2_lr_cap<MPB_MAX_DOF>, dim3(B), dim3(256), lds, stream, jac, grest, G, gpcost, wdense, costs_out, ord, B, H, D, n_fields, ntm, K);
     hipLaunchKernelGGL(gpmp2_pcr_solve<true>, dim3(D, NG), dim3(PCR_THREADS), lds_solve, stream, grest, jac, wdense, coef, dth, ord, B, H, D,
                        n_fields, L, NG, K);
     hipLaunchKernelGGL(gpmp2_lr_apply, dim3(B), dim3(256), 0, stream, x, reinterpret_cast<const float2*>(dth), grest, ord, B, H, D, K.step);

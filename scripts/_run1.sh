@@ -12,3 +12,4 @@ for r in c.execute("select name, start, end from kernels"):
 for k,v in d.items():
     v.sort(); print(k, len(v), 'min',v[0],'med',v[len(v)//2], 'max', v[-1])
 PY
+MPB_LIB_PATH=$PWD/build_variants/clk.so python scripts/prof_gpmp2.py 2>&1 | grep "cap clk" | head -3
