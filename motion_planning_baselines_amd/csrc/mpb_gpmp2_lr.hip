@@ -549,6 +549,8 @@ __global__ __launch_bounds__(256) void gpmp2_lr_apply(float* __restrict__ x, con
 #ifndef LR_ASM_RING
 #define LR_ASM_RING 6                                                        // tiles of M whose G entries are in flight
 #endif
+#define CAP_THREADS 512                                                      // eight waves: the assembly, the TRSM rows and the trailing update spread over all of them
+#define CAP_SLOTS (CAP_THREADS / 256)                                        // tiles of M assembled per pass
 #define LR_TILE 256                                                          // doubles per tile
 __device__ __forceinline__ int lr_tile(int I, int J) { return ((I * (I + 1)) >> 1) + J; }            // J <= I
 __device__ __forceinline__ int lr_sw(int r, int c) { return (r << 4) + (c ^ r); }
@@ -559,8 +561,11 @@ __device__ __forceinline__ double lr_rsqrt(double x) {                      // v
     return y;
 }
 
-template <int DMAX>        // DMAX: 8 or DMAX -- the joints a row of h is unrolled over (D <= DMAX)
-__global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ jac, const double* __restrict__ upos,
+template <int DMAX>        // DMAX: 8 or MPB_MAX_DOF -- the joints a row of h is unrolled over (D <= DMAX)
+#ifndef CAP_WPE
+#define CAP_WPE 4
+#endif
+__global__ __launch_bounds__(CAP_THREADS, CAP_WPE) void gpmp2_lr_cap(const float* __restrict__ jac, const double* __restrict__ upos,
                                                    const double* __restrict__ G, const double* __restrict__ gpcost,
                                                    double* __restrict__ wdense, float* __restrict__ costs_out, const int* __restrict__ ord,
                                                    int B, int H, int D, int F, int n_tiles_max, GpConst K) {
@@ -595,7 +600,7 @@ __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ ja
     float hrow2[DMAX + 1];
     bool act2 = false;
     int myt2 = 0, myf2 = 0;
-    for (int ch = wave; ch < nchunk; ch += 4) {
+    for (int ch = wave; ch < nchunk && wave < 4; ch += 4) {      // (waves 0-3: the compaction is four waves' work)
         const int f = ch / ((H + 63) >> 6), base = (ch - f * ((H + 63) >> 6)) << 6;
         const int t = base + lane;
         const float* jb = jac + ((size_t)f * B + b) * H * (D + 1);
@@ -624,7 +629,7 @@ __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ ja
     }
     // the cost: the four waves' partial sums through LDS
     cost = wave_sum_f64(cost);
-    if (lane == 0) dinv[wave] = cost;
+    if (lane == 0 && wave < 4) dinv[wave] = cost;
     __syncthreads();
     if (costs_out != nullptr && tid == 0) costs_out[b] = (float)(((dinv[0] + dinv[1]) + (dinv[2] + dinv[3])) + gpcost[b]);
     int n = 0;
@@ -632,7 +637,7 @@ __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ ja
     if (n == 0) return;                                          // (block-uniform)
     for (int ps = 0; ps < 2; ++ps) {
         const int ch = wave + 4 * ps;
-        if (ch < nchunk) {
+        if (ch < nchunk && wave < 4) {
             int off = 0;
             for (int e = 0; e < ch; ++e) off += cnt[e];
             const bool a = ps ? act2 : act;
@@ -665,11 +670,16 @@ __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ ja
     const int ntl = (TR * (TR + 1)) >> 1;
     {
         const double ikc = 1.0 / K.kc;
-        const int r = tid >> 4, c = tid & 15;
+        const int r = (tid & 255) >> 4, c = tid & 15, slot = tid >> 8;          // CAP_SLOTS tiles per pass: tile q goes to slot q mod CAP_SLOTS
         // tile q of the lower triangle, row major: (I, J) with q = I (I + 1) / 2 + J.  The ring walks q in order: the fetches' and the
         // emits' (I, J) are stepped, not solved from q (a square root and two correction loops per call were ~80 of a tile's ~400
         // instructions)
         int fI = 0, fJ = 0, fq = 0, eI = 0, eJ = 0;
+        auto step = [](int& I, int& J) { if (++J > I) { ++I; J = 0; } };
+        for (int k = 0; k < slot; ++k) {                          // (this slot's first tile; with fewer tiles than slots: the last one)
+            if (fq + 1 < ntl) { ++fq; step(fI, fJ); }
+            step(eI, eJ);
+        }
         auto fetch = [&](double (&gv)[DMAX]) {             // tile fq (beyond the last tile: the last one again)
             int a = 16 * fI + r, cc = 16 * fJ + c;
             if (cc > a) { const int t_ = a; a = cc; cc = t_; }              // (diagonal tiles are stored full: mirror)
@@ -677,14 +687,14 @@ __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ ja
             const double* Gst = G + (size_t)tact[on ? a : 0] * H + tact[on ? cc : 0];
 #pragma unroll
             for (int j = 0; j < DMAX; ++j) gv[j] = (j < D) ? Gst[(size_t)j * H * H] : 0.0;
-            if (fq + 1 < ntl) {
-                ++fq;
-                if (++fJ > fI) { ++fI; fJ = 0; }
-            }
+#pragma unroll
+            for (int k = 0; k < CAP_SLOTS; ++k)
+                if (fq + 1 < ntl) { ++fq; step(fI, fJ); }
         };
         auto emit = [&](const double (&gv)[DMAX]) {        // the next tile in order
             const int I = eI, J = eJ;
-            if (++eJ > eI) { ++eI; eJ = 0; }
+#pragma unroll
+            for (int k = 0; k < CAP_SLOTS; ++k) step(eI, eJ);
             int a = 16 * I + r, cc = 16 * J + c;
             if (cc > a) { const int t_ = a; a = cc; cc = t_; }
             double m;
@@ -700,21 +710,22 @@ __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ ja
             }
             Tl[(size_t)lr_tile(I, J) * LR_TILE + lr_sw(r, c)] = m;
         };
-        // LR_ASM_RING tiles' G entries (L2, ~1 us) in flight per thread.  (One tile ahead, the loop paid most of a round trip per tile:
+        // RING tiles' G entries (L2, ~1 us) in flight per thread.  (One tile ahead, the loop paid most of a round trip per tile:
         // 28 us of the 95 a particle with 116 active rows took.  And a ring slot must be refilled OUTSIDE any conditional -- a fetch
         // under `if (q + 1 < ntl)` reaches the next trip through a phi whose copy waits for the load it has just issued: the
         // three-slot ring of the second version ran one tile ahead in effect.  A fetch beyond the last tile re-reads the last one.)
-        double gr[LR_ASM_RING][DMAX];
-        lr_static_for<0, LR_ASM_RING>([&](auto uc) { fetch(gr[decltype(uc)::value]); });
+        constexpr int RING = (DMAX <= 8) ? LR_ASM_RING : LR_ASM_RING / 2;          // (twelve joints: half the ring, or the tile's registers spill)
+        double gr[RING][DMAX];
+        lr_static_for<0, RING>([&](auto uc) { fetch(gr[decltype(uc)::value]); });
 #ifdef LR_T_CAP_NOASM      // (wrong-result timing switch, tuning builds only: the first tile alone)
         const int ntl_run = 1;
 #else
         const int ntl_run = ntl;
 #endif
-        for (int q = 0; q < ntl_run; q += LR_ASM_RING) {
-            lr_static_for<0, LR_ASM_RING>([&](auto uc) {
+        for (int q = slot; q < ntl_run; q += CAP_SLOTS * RING) {
+            lr_static_for<0, RING>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
-                if (q + u < ntl_run) emit(gr[u]);
+                if (q + CAP_SLOTS * u < ntl_run) emit(gr[u]);
                 fetch(gr[u]);
             });
         }
@@ -760,7 +771,7 @@ __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ ja
         // TRSM: rows of the tiles (I, J), I > J: x L_JJ^T = a by forward substitution, a lane per row
         {
             const int rows_below = 16 * (TR - J - 1);
-            for (int rr = tid; rr < rows_below; rr += 256) {
+            for (int rr = tid; rr < rows_below; rr += CAP_THREADS) {
                 const int I = J + 1 + (rr >> 4), r = rr & 15;
                 double* Tij = Tl + (size_t)lr_tile(I, J) * LR_TILE;
                 double xv[16];
@@ -785,7 +796,7 @@ __global__ __launch_bounds__(256) void gpmp2_lr_cap(const float* __restrict__ ja
             const int ng = (nb * (nb + 1)) >> 1;
             int I = J + 1, Kt = J + 1;
             for (int g = 0; g < ng; ++g) {
-                if ((g & 3) == wave) {
+                if ((g & (CAP_THREADS / 64 - 1)) == wave) {
                     double* C = Tl + (size_t)lr_tile(I, Kt) * LR_TILE;
                     const double* A = Tl + (size_t)lr_tile(I, J) * LR_TILE;
                     const double* Bt = Tl + (size_t)lr_tile(Kt, J) * LR_TILE;
@@ -915,8 +926,8 @@ int mpb_gpmp2_lr_launch(float* x, const float* start, const float* goal, const f
     const int n_max = n_fields * (H - 1);
     const int trm = (n_max + 16) >> 4, ntm = (trm * (trm + 1)) >> 1;             // tiles of the largest system the shape allows
     const size_t lds = ((size_t)ntm * LR_TILE + 256) * sizeof(double) + (size_t)LR_NMAX * (D <= 8 ? 8 : MPB_MAX_DOF) * sizeof(float) + (256 + 16) * sizeof(int);
-    if (D <= 8) hipLaunchKernelGGL(gpmp2_lr_cap<8>, dim3(B), dim3(256), lds, stream, jac, grest, G, gpcost, wdense, costs_out, ord, B, H, D, n_fields, ntm, K);
-    else hipLaunchKernelGGL(gpmp2_lr_cap<MPB_MAX_DOF>, dim3(B), dim3(256), lds, stream, jac, grest, G, gpcost, wdense, costs_out, ord, B, H, D, n_fields, ntm, K);
+    if (D <= 8) hipLaunchKernelGGL(gpmp2_lr_cap<8>, dim3(B), dim3(CAP_THREADS), lds, stream, jac, grest, G, gpcost, wdense, costs_out, ord, B, H, D, n_fields, ntm, K);
+    else hipLaunchKernelGGL(gpmp2_lr_cap<MPB_MAX_DOF>, dim3(B), dim3(CAP_THREADS), lds, stream, jac, grest, G, gpcost, wdense, costs_out, ord, B, H, D, n_fields, ntm, K);
     hipLaunchKernelGGL(gpmp2_pcr_solve<true>, dim3(D, NG), dim3(PCR_THREADS), lds_solve, stream, grest, jac, wdense, coef, dth, ord, B, H, D,
                        n_fields, L, NG, K);
     hipLaunchKernelGGL(gpmp2_lr_apply, dim3(B), dim3(256), 0, stream, x, reinterpret_cast<const float2*>(dth), grest, ord, B, H, D, K.step);
