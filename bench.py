@@ -726,16 +726,17 @@ def bench_c4(dev, steps, with_cpu=True):
         'ms_per_step': 1e3 * med / steps, 'repeats': sp, 'dtype': 'f64',
         'protocol': 'every block = the first %d iterations from the initial straight lines (reset before each block)' % steps,
         'ms_first_iteration': first_ms,
-        'form': ('low-rank (csrc/mpb_gpmp2_lr.hip): A0 = priors + GP blocks + damping shared by all particles and factored once per '
-                 'iteration, two chain substitutions + one dense SPD solve over the ACTIVE collision rows per particle') if lr_form
+        'form': ('low-rank (csrc/mpb_gpmp2_lr.hip): A0 = priors + GP blocks + damping shared by all particles -- its cyclic-reduction '
+                 'coefficients computed once per iteration, A0^-1 g by parallel cyclic reduction (a wave per chain) -- + one dense SPD '
+                 'solve over the ACTIVE collision rows per particle, largest systems first') if lr_form
                 else 'block elimination (csrc/mpb_gpmp2.hip)',
         'block_form_ms_per_step': block_ms,
         'roofline': {'bound': 'mfma', 'achieved': tflops, 'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': tflops / FP64_MATRIX_PEAK_TFLOPS, 'structured_flop_per_iter': flop_iter,
                      'note': 'SURVEY 8(d)\'s structured count of the block-tridiagonal elimination (14 x 14 blocks, 127 block steps per particle) '
                              'over the iteration\'s time, against the fp64 matrix peak -- the figure rounds 1-5 report.  The low-rank form of '
-                             'round 6 does NOT execute those flops: it solves the same system with ~30 kFLOP per particle (the sweeps) plus '
-                             'n_a^3 / 3 for its n_a active rows, bound by the latency of short dependent fp64 chains (DESIGN 6)'}}
+                             'round 6 does NOT execute those flops: it solves the same system with ~0.2 MFLOP per particle (the cyclic-reduction solves) plus '
+                             'n_a^3 / 3 for its n_a active rows; the iteration is bound by the latency of the largest capacitance system (DESIGN 6)'}}
     pmc, pmc_file = latest_profile('r*_pmc_solve.json')
     if pmc and pmc.get('SQ_INSTS_VALU_per_wave') and B == 2048 and not lr_form:
         # what actually binds the solve kernel (88 % of the iteration): fp64 VALU issue (4.7 cycles per wave-instruction,

@@ -161,7 +161,7 @@ if kg:   # GPMP2 C4 (scripts/prof_gpmp2.py: one iteration per launch)
             out[c + ('_KB_raw_per_launch' if c.endswith('SIZE') else '_per_wave')] = s[c] if c.endswith('SIZE') else s[c] / waves
     _dump(out, 'solve', os.path.join(prof, f'{tag}_pmc_solve.json'))
 
-kl = [k for k in summary if 'gpmp2_lr_' in k or 'gpmp2_chain_kernel' in k]
+kl = [k for k in summary if 'gpmp2_lr_' in k or 'gpmp2_pcr_' in k]
 if kl:   # GPMP2 C4, low-rank form (round 6; scripts/prof_gpmp2.py: one iteration per launch from the initial state)
     out = {'workload': 'C4 panda_spheres GPMP2 B=2048 H=128 D=7, low-rank form, first iteration from the initial means (scripts/prof_gpmp2.py)', 'kernels': {}}
     for k in kl:
