@@ -50,7 +50,7 @@ extern "C" {
  *                        16-byte aligned; a model-tagged geometry must keep margin + radii below 1 m; mpb_gpmp2_solve applies the
  *                        collision factors by Sherman-Morrison beyond a precision ratio of 1e7 (more accurate results there);
  *           6 (round 6)  mpb_gpmp2_workspace_bytes and mpb_stomp_workspace_bytes return MORE (the low-rank form of the GPMP2 solve keeps
- *                        its tables and sweep records in the workspace; the STOMP workspace also fits the generalised persistent
+ *                        its tables, right-hand sides and steps in the workspace; the STOMP workspace also fits the generalised persistent
  *                        kernel at H = 64, which serves list-grid scenes): a workspace sized by an older library is too small;
  *                        geometry buffers of version 7 (LIST broad-phase grid, per field) are accepted next to version 6;
  *                        MPB_MAX_DOF 8 -> 12; mpb_gpmp2_solve takes the low-rank form wherever n_fields (H - 1) <= 127 (same
