@@ -21,41 +21,29 @@
 // scripts/gpmp2_lowrank_prototype.py (numpy fp64 against a long-double-refined dense solve): as accurate as dense fp64 Cholesky
 // at every collision / GP precision ratio from 1e6 to 1e14, active sets from 8 to 84 rows.
 //
-// Five launches per iteration, every one of them bound by the LATENCY of one particle's (or one joint's) dependent steps, not by
-// the batch (a lone wave issues one instruction per four cycles, an fp64 one per eight: what counts is the instruction COUNT on
-// the sequential path -- DESIGN.md section 6 has the per-kernel times on one particle):
-//   gpmp2_chain_kernel    shared by all particles: the block-Thomas factors (W_t = S_t^-1, F_t = W_t U) of the D chains and the
-//                         position-position entries G_i(s, t) of their inverses, D H^2 doubles (0.9 MB at C4: stays in L2).  One
-//                         lane walks the factorisation and the diagonal recurrence; what does not depend on the previous step
-//                         (D_t before, W_t / F_t / the recurrence's coefficients after) is done by all lanes and staged in LDS;
-//   gpmp2_lr_gradient     g_rest (priors + GP factors) and its cost, a lane per (waypoint, joint): nothing in it is sequential,
-//                         so it stays out of the sweeps (formed on the fly there it was 40 of a step's 60 instructions);
-//   gpmp2_lr_sweep<false> u0: lane = (particle, joint) -- 9 particles per wave at D = 7 --, the factor table in LDS (records read
-//                         one step ahead), H steps down and H up with two dependent fma per step; g and the z_t records travel
-//                         through register rings 16 steps ahead (the first version of the round walked the chain inside the
-//                         per-particle kernel with the factors read from L2 one step ahead: 512 L2 round trips in a row per
-//                         particle, 0.91 ms at C4);
-//   gpmp2_lr_cap          per particle, four waves: the active rows compacted by ballot, M (n_a x n_a) from the G table in 16 x 16
-//                         tiles into LDS (three tiles of loads in flight), tile Cholesky (POTRF in registers by readlane, TRSM a
-//                         lane per row, the trailing update on the fp64 MFMA), the right-hand side carried as row n_a, a blocked
-//                         back substitution, w scattered to a dense per-waypoint vector;
-//   gpmp2_lr_sweep<true>  dtheta = A0^-1 (g_rest + V w) and x += step * dtheta.
+// Six launches per iteration (DESIGN.md section 6 has their times and what the two earlier versions of the round -- chains walked
+// inside the per-particle kernel, then block-Thomas sweeps with a lane per (particle, joint) -- taught):
+//   gpmp2_pcr_setup        shared by all particles: the cyclic-reduction coefficients of the D chains (below) and the
+//                          position-position entries G_i(s, t) of their inverses, D H^2 doubles (0.9 MB at C4: stays in L2);
+//   gpmp2_lr_gradient      g_rest (priors + GP factors), joint major, its cost, and the particle's size class (rows with a hinge);
+//   gpmp2_pcr_solve<false> u0 = A0^-1 g_rest, position and velocity rows, in place; one extra workgroup sorts the particles by class;
+//   gpmp2_lr_cap           per particle, eight waves, largest systems first: the active rows compacted by ballot, M (n_a x n_a) from
+//                          the G table in 16 x 16 tiles into LDS (six tiles of loads in flight), tile Cholesky (POTRF in registers
+//                          by readlane, TRSM a lane per row, the trailing update on the fp64 MFMA), the right-hand side carried as
+//                          row n_a, a blocked back substitution, w scattered to a dense per-waypoint vector;
+//   gpmp2_pcr_solve<true>  A0^-1 V w for the particles WITH rows, step = step (u0 + that), joint major;
+//   gpmp2_lr_apply         x += step, turned row-wise through LDS (particles without rows: step u0).
 // Against the block elimination of rounds 1-5 (mpb_gpmp2.hip: one 16 x 16 fp64 Gauss-Jordan inverse per waypoint and particle, 127
 // of them in a row; 352 MB of W_t records written and read back): ~1.2 MFLOP and ~2 600 dependent pivot steps per particle become
-// ~30 kFLOP and 4 H + 2 n_a short steps.  The block kernel stays for what this form does not take: chained fields whose rows
-// exceed the LDS tile (F (H - 1) > 127), H > 128.
+// ~0.2 MFLOP, none of it sequential, and 2 n_a short steps.  The block kernel stays for what this form does not take: chained
+// fields whose rows exceed the LDS tile (F (H - 1) > 127), H > 128.
 #include <stdlib.h>
 #include <type_traits>
 
 #include "mpb_common.h"
 #include "mpb_gpmp2.h"
 
-#define LR_REC 8                       // doubles per (joint, waypoint) record: W00 W01 W11 F00 F01 F10 F11 (pad)
 #define LR_NMAX 127                    // active rows a particle may have (with the right-hand side 128 rows: 36 tiles of 16 x 16 doubles, 72 KB of LDS)
-#ifndef LR_PF
-#define LR_PF 16                       // steps the sweeps read ahead (register rings)
-#endif
-#define LR_ZREC 2                      // doubles per (waypoint, lane) record of a sweep: z0, z1
 
 typedef double lr_d2 __attribute__((ext_vector_type(2)));
 
@@ -288,10 +276,9 @@ __global__ __launch_bounds__(PCR_THREADS) void gpmp2_pcr_setup(const double* __r
 
 // ------------------------------------------------------------------------------------------------
 // g_rest: the gradient without its collision part (start / goal priors and the GP factors, gpmp2.py:355-368 with the rows of
-// cost_functions.py:291-314, :538-554), fp64, laid out like x ((B, H, 2D)), and the cost b^T K b of those factors per particle
-// (gpmp2.py:493-495).  One wave per particle, lane = waypoint: nothing here depends on anything else, so it is kept OUT of the sweeps
-// (round 6, second version: formed on the fly inside the sweep it was 40 of a step's 60 instructions on the chain every lane walks
-// alone -- a sweep over one particle took 49 us whatever the batch size).
+// cost_functions.py:291-314, :538-554), fp64, JOINT MAJOR -- (D, B, H) pairs (position, velocity): the right-hand side of a chain
+// is 2 KB in a row for gpmp2_pcr_solve --, the cost b^T K b of those factors per particle (gpmp2.py:493-495), and the particle's size
+// class for the launch order of the capacitance systems.  A workgroup per particle.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gpmp2_lr_gradient(const float* __restrict__ x, const float* __restrict__ start, const float* __restrict__ goal,
                                                          const float* __restrict__ jac, double* __restrict__ g, double* __restrict__ gpcost,
@@ -302,7 +289,7 @@ __global__ __launch_bounds__(256) void gpmp2_lr_gradient(const float* __restrict
     // The capacitance kernel lasts as long as its largest system (one particle with 116 active rows: 87 us; the median particle has
     // none), and two workgroups fit a CU: in batch order the largest system of C4 started in the third of four rounds.  So every
     // particle gets a size class here -- rows with a non-zero hinge value, LR_ORD classes of 16 --, one extra workgroup of the
-    // sweep that follows sorts the particles by class, largest first (a counting sort in LDS; one atomic per particle on a
+    // solve that follows sorts the particles by class, largest first (a counting sort in LDS; one atomic per particle on a
     // counter per class in global memory cost this kernel 19 us: 2 048 returning atomics on nine addresses), and gpmp2_lr_cap
     // takes them in that order.  (Scheduling only: the class is an estimate, nothing else reads it.)
     int n_est = 0;
@@ -373,7 +360,7 @@ __global__ __launch_bounds__(256) void gpmp2_lr_gradient(const float* __restrict
     if (tid == 0) {
         gpcost[b] = (red_c[0] + red_c[1]) + (red_c[2] + red_c[3]);
         const int n = red_n[0] + red_n[1] + red_n[2] + red_n[3];
-        ord[b] = LR_ORD - 1 - min(LR_ORD - 1, (n + 15) >> 4);          // size class, 0 = largest (sorted by gpmp2_lr_sweep<false>'s extra workgroup)
+        ord[b] = LR_ORD - 1 - min(LR_ORD - 1, (n + 15) >> 4);          // size class, 0 = largest (sorted by gpmp2_pcr_solve<false>'s extra workgroup)
     }
 }
 
@@ -584,7 +571,7 @@ __global__ __launch_bounds__(CAP_THREADS, CAP_WPE) void gpmp2_lr_cap(const float
     // the particle of this workgroup: largest systems first (gpmp2_lr_gradient, gpmp2_pcr_solve<false>)
     const int b = ord[B + blockIdx.x];
 #ifdef LR_T_CLK
-    unsigned long long cclk_[7]; cclk_[0] = wall_clock64();
+    unsigned long long cclk_[7], cph_[3] = {0, 0, 0}; cclk_[0] = wall_clock64();
 #define CAP_CLK(k) cclk_[k] = wall_clock64()
 #else
 #define CAP_CLK(k)
@@ -741,6 +728,9 @@ __global__ __launch_bounds__(CAP_THREADS, CAP_WPE) void gpmp2_lr_cap(const float
     for (int J = 0; J < TC; ++J) {
 #endif
         double* Djj = Tl + (size_t)lr_tile(J, J) * LR_TILE;
+#ifdef LR_T_CLK
+        const unsigned long long ck0_ = wall_clock64();
+#endif
         if (wave == 0) {
             // POTRF: lane r < 16 holds row r of the diagonal tile
             const int r = lane & 15;
@@ -768,28 +758,44 @@ __global__ __launch_bounds__(CAP_THREADS, CAP_WPE) void gpmp2_lr_cap(const float
             }
         }
         __syncthreads();
-        // TRSM: rows of the tiles (I, J), I > J: x L_JJ^T = a by forward substitution, a lane per row
+#ifdef LR_T_CLK
+        const unsigned long long ck1_ = wall_clock64();
+#endif
+        // TRSM: rows of the tiles (I, J), I > J: x L_JJ^T = a by forward substitution, a lane per row, column by column -- every later
+        // column updated as soon as x_c is known: the dependent chain is 16 x (mul, fma), where the dot-product form accumulated 120
+        // fma one after the other.  The entries of L_JJ are the same for every row: lane l keeps ROW l mod 16 of the tile (and
+        // 1 / l_ll) in registers and the chain takes L[j][c] by v_readlane (read from LDS where they are used -- 120 broadcast
+        // reads -- the compiler waited for 81 LDS round trips inside the chain: 2.6 of the 4.8 us a tile column of the factorisation
+        // took; fetched a column ahead into registers instead, compiler and scheduler hoisted all 120 to the top and spilled ~250
+        // registers whatever fences stood between the columns)
         {
             const int rows_below = 16 * (TR - J - 1);
+            double Lrow[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) Lrow[c] = Djj[lr_sw(lane & 15, c)];
+            const double dv = (16 * J + (lane & 15) < n) ? dinv[16 * J + (lane & 15)] : 1.0;      // (padding columns: the identity)
             for (int rr = tid; rr < rows_below; rr += CAP_THREADS) {
                 const int I = J + 1 + (rr >> 4), r = rr & 15;
                 double* Tij = Tl + (size_t)lr_tile(I, J) * LR_TILE;
                 double xv[16];
 #pragma unroll
                 for (int c = 0; c < 16; ++c) xv[c] = Tij[lr_sw(r, c)];
-                // (column by column, every later column updated as soon as x_c is known: the dependent chain is 16 x (mul, fma), where
-                // the dot-product form accumulated 120 fma one after the other)
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    if (16 * J + c < n) xv[c] *= dinv[16 * J + c];                  // (padding columns: the identity)
-#pragma unroll
-                    for (int j = c + 1; j < 16; ++j) xv[j] = fma(-xv[c], Djj[lr_sw(j, c)], xv[j]);
-                }
+                lr_static_for<0, 16>([&](auto cc_) {
+                    constexpr int c = decltype(cc_)::value;
+                    xv[c] *= lr_readlane(dv, c);
+                    lr_static_for<c + 1, 16>([&](auto jj_) {
+                        constexpr int j = decltype(jj_)::value;
+                        xv[j] = fma(-xv[c], lr_readlane(Lrow[c], j), xv[j]);
+                    });
+                });
 #pragma unroll
                 for (int c = 0; c < 16; ++c) Tij[lr_sw(r, c)] = xv[c];
             }
         }
         __syncthreads();
+#ifdef LR_T_CLK
+        const unsigned long long ck2_ = wall_clock64();
+#endif
         // GEMM: A_IK -= L_IJ L_KJ^T for J < K <= I < TR on the matrix cores, tiles dealt to the waves
         {
             const int nb = TR - J - 1;
@@ -814,6 +820,9 @@ __global__ __launch_bounds__(CAP_THREADS, CAP_WPE) void gpmp2_lr_cap(const float
             }
         }
         __syncthreads();
+#ifdef LR_T_CLK
+        { const unsigned long long ck3_ = wall_clock64(); cph_[0] += ck1_ - ck0_; cph_[1] += ck2_ - ck1_; cph_[2] += ck3_ - ck2_; }
+#endif
     }
     CAP_CLK(4);
     // ---- 5. L^T w = y (y = row n), one wave, a tile row at a time from the last: the 16 x 16 triangular system of the row's diagonal
@@ -876,8 +885,9 @@ __global__ __launch_bounds__(CAP_THREADS, CAP_WPE) void gpmp2_lr_cap(const float
 #ifdef LR_T_CLK
     CAP_CLK(6);
     if (blockIdx.x == 0 && tid == 0)
-        printf("cap clk (10 ns) n %d: compact %llu rhs %llu assemble %llu cholesky %llu back %llu scatter %llu\n", n, cclk_[1] - cclk_[0],
-               cclk_[2] - cclk_[1], cclk_[3] - cclk_[2], cclk_[4] - cclk_[3], cclk_[5] - cclk_[4], cclk_[6] - cclk_[5]);
+        printf("cap clk (10 ns) n %d: compact %llu rhs %llu assemble %llu cholesky %llu (potrf %llu trsm %llu update %llu) back %llu scatter %llu\n", n,
+               cclk_[1] - cclk_[0], cclk_[2] - cclk_[1], cclk_[3] - cclk_[2], cclk_[4] - cclk_[3], cph_[0], cph_[1], cph_[2], cclk_[5] - cclk_[4],
+               cclk_[6] - cclk_[5]);
 #endif
 }
 
@@ -886,7 +896,7 @@ __global__ __launch_bounds__(CAP_THREADS, CAP_WPE) void gpmp2_lr_cap(const float
 // ------------------------------------------------------------------------------------------------
 bool mpb_gpmp2_lr_ok(int H, int D, int n_fields) { return H >= 2 && D >= 1 && D <= MPB_MAX_DOF && n_fields >= 1 && n_fields * (H - 1) <= LR_NMAX; }
 
-// doubles of workspace: shared tables (factor records, G) + per-batch arrays (sweep records, u0's position rows, w, the GP cost)
+// doubles of workspace: shared tables (cyclic-reduction coefficients, G) + per-batch arrays (the steps, w, the GP cost, g_rest / u0, the order)
 size_t mpb_gpmp2_lr_ws_doubles(int B, int H, int D) {
     const size_t NL = (size_t)B * D;
     return 2 * (size_t)D * pcr_coef_entries(H) + (size_t)D * H * H + (size_t)H * NL + (size_t)MPB_GP_MAX_FIELDS * B * H + (size_t)B + 64 +
