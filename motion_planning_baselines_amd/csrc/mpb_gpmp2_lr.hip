@@ -100,8 +100,15 @@ __device__ __forceinline__ LrCoef lr_coef(const GpConst& K) {
 // ------------------------------------------------------------------------------------------------
 #define LR_HMAX 128                    // waypoints (mpb_gpmp2_lr_ok: n_fields (H - 1) <= LR_NMAX)
 #define LR_ORD 9                       // size classes of the capacitance systems' launch order: 0 rows, 1-16, ..., 113-128 (largest first)
-#define PCR_NP 4                       // chains a wave solves at once
-#define PCR_WAVES 8
+// (measured at C4, waves x chains: 8 x 4 -- 23.1 / 19.7 us for the two solves --, 8 x 2 -- 24.0 / 18.9 --, 16 x 2 -- 21.4 / 15.2: the solves are
+// bound by the latency of a level's LDS round trips, not by LDS bandwidth -- dropping the last level's exchange changed nothing --, and
+// four waves per SIMD hide more of it than two)
+#ifndef PCR_NP
+#define PCR_NP 2                       // chains a wave solves at once (they share every coefficient read)
+#endif
+#ifndef PCR_WAVES
+#define PCR_WAVES 16
+#endif
 #define PCR_THREADS (64 * PCR_WAVES)
 static inline int pcr_levels(int H) { int L = 0; for (int h = 1; h < H; h <<= 1) ++L; return L; }
 // coefficient table of a joint, 16-byte entries: [level][q][t], q = 0: (alpha00, alpha01), 1: (alpha10, alpha11), 2: (gamma00, gamma01),
@@ -115,13 +122,26 @@ __device__ __forceinline__ void pcr_solve(const lr_d2* __restrict__ coef, lr_d2*
     const int tt[2] = {lane, lane + 64};
     const bool vv[2] = {lane < H, lane + 64 < H};
     for (int l = 0, h = 1; l < L; ++l, h <<= 1) {
+        const lr_d2* cl = coef + (size_t)(4 * l) * H;
+        if (h == 64) {
+            // the last level of 64 < H <= 128: waypoint t's partner t + 64 is the lane's own other element (t - 64 and t + 128 do not
+            // exist: their coefficients are zero) -- no exchange through LDS (a seventh of the solves' LDS traffic, which bounds them)
+            const int t0 = vv[0] ? tt[0] : 0, t1 = vv[1] ? tt[1] : 0;
+            const lr_d2 c0 = cl[2 * H + t0], c1 = cl[3 * H + t0], a0 = cl[t1], a1 = cl[H + t1];
+#pragma unroll
+            for (int k = 0; k < PCR_NP; ++k) {
+                const lr_d2 ra = r[k][0], rq = vv[1] ? r[k][1] : lr_d2{0.0, 0.0};
+                r[k][0] = lr_d2{fma(c0.y, rq.y, fma(c0.x, rq.x, ra.x)), fma(c1.y, rq.y, fma(c1.x, rq.x, ra.y))};
+                r[k][1] = lr_d2{fma(a0.y, ra.y, fma(a0.x, ra.x, rq.x)), fma(a1.y, ra.y, fma(a1.x, ra.x, rq.y))};
+            }
+            continue;
+        }
 #pragma unroll
         for (int k = 0; k < PCR_NP; ++k) {
             if (vv[0]) rb[k * H + tt[0]] = r[k][0];
             if (vv[1]) rb[k * H + tt[1]] = r[k][1];
         }
         lr_wave_sync();
-        const lr_d2* cl = coef + (size_t)(4 * l) * H;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int t = vv[e] ? tt[e] : 0;
@@ -924,7 +944,7 @@ int mpb_gpmp2_lr_launch(float* x, const float* start, const float* goal, const f
     const size_t lds_rows = (size_t)PCR_WAVES * PCR_NP * H * sizeof(lr_d2);
     const size_t lds_setup = n_coef * sizeof(lr_d2) + 12 * (size_t)H * sizeof(double) + lds_rows;
     const size_t lds_solve = n_coef * sizeof(lr_d2) + lds_rows;
-    const int NY = (H + PCR_WAVES * PCR_NP - 1) / (PCR_WAVES * PCR_NP);          // one pass of columns per block
+    const int NY = (H + 15) / 16;                                                // sixteen columns per block (one pass of eight of its waves: 12 us where a full pass of 32 columns took 15)
     hipLaunchKernelGGL(gpmp2_pcr_setup, dim3(D, NY), dim3(PCR_THREADS), lds_setup, stream, diag_mean, coef, G, H, D, L, K);
     hipLaunchKernelGGL(gpmp2_lr_gradient, dim3(B), dim3(256), 0, stream, x, start, goal, jac, grest, gpcost, ord, B, H, D, n_fields, K);
     // particle groups: one block per CU over the D joints, at least one pass of the waves per group
