@@ -488,29 +488,28 @@ __global__ __launch_bounds__(PCR_THREADS) void gpmp2_pcr_solve(double* __restric
 // without collision rows: step * u0, gpmp2_pcr_solve<false>'s pairs), x is (B, H, 2 D): a workgroup per particle turns its rows through
 // LDS, so both sides move in whole lines.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gpmp2_lr_apply(float* __restrict__ x, const float2* __restrict__ dth, const double* __restrict__ u0,
-                                                      const int* __restrict__ ord, int B, int H, int D, double step) {
-    __shared__ float xs[LR_HMAX * 2 * MPB_MAX_DOF];
-    const int tid = threadIdx.x, b = blockIdx.x, dim = 2 * D, nx = H * dim;
+template <int NTHR>
+__device__ __forceinline__ void lr_apply_rows(float* __restrict__ x, const float2* __restrict__ dth, const double* __restrict__ u0, bool has_rows,
+                                              int b, int B, int H, int D, double step, float* __restrict__ xs, int tid) {
+    const int dim = 2 * D, nx = H * dim;
     float* xg = x + (size_t)b * nx;
-    const bool has_rows = ord[b] != LR_ORD - 1;                // (block-uniform: the particle's size class, gpmp2_lr_gradient)
-    constexpr int NT = (LR_HMAX * 2 * MPB_MAX_DOF + 255) / 256;
+    constexpr int NT = (LR_HMAX * 2 * MPB_MAX_DOF + NTHR - 1) / NTHR;
     float tmp[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
-        const int e = tid + 256 * u;
+        const int e = tid + NTHR * u;
         tmp[u] = (e < nx) ? xg[e] : 0.f;
     }
-    constexpr int ND = (LR_HMAX * MPB_MAX_DOF + 255) / 256;
+    constexpr int ND = (LR_HMAX * MPB_MAX_DOF + NTHR - 1) / NTHR;
     float2 dv[ND];
 #pragma unroll
     for (int u = 0; u < ND; ++u) {
-        const int e = tid + 256 * u, j = e / H, t = e - j * H;
+        const int e = tid + NTHR * u, j = e / H, t = e - j * H;
         dv[u] = make_float2(0.f, 0.f);
         if (e < H * D) {
             if (has_rows) {
                 dv[u] = dth[((size_t)j * B + b) * H + t];
-            } else {            // no collision rows: w = 0 and the step is u0's (gpmp2_pcr_solve<true> skipped the particle)
+            } else {            // no collision rows: w = 0 and the step is u0's (gpmp2_pcr_solve<true> skips the particle)
                 const lr_d2 v = reinterpret_cast<const lr_d2*>(u0)[((size_t)j * B + b) * H + t];
                 dv[u] = make_float2((float)(step * v.x), (float)(step * v.y));
             }
@@ -518,13 +517,13 @@ __global__ __launch_bounds__(256) void gpmp2_lr_apply(float* __restrict__ x, con
     }
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
-        const int e = tid + 256 * u;
+        const int e = tid + NTHR * u;
         if (e < nx) xs[e] = tmp[u];
     }
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < ND; ++u) {
-        const int e = tid + 256 * u, j = e / H, t = e - j * H;
+        const int e = tid + NTHR * u, j = e / H, t = e - j * H;
         if (e < H * D) {
             xs[t * dim + j] += dv[u].x;
             xs[t * dim + D + j] += dv[u].y;
@@ -533,9 +532,17 @@ __global__ __launch_bounds__(256) void gpmp2_lr_apply(float* __restrict__ x, con
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
-        const int e = tid + 256 * u;
+        const int e = tid + NTHR * u;
         if (e < nx) xg[e] = xs[e];
     }
+}
+// (the particles WITH collision rows: the others were stepped by their capacitance workgroup, which had nothing else to do)
+__global__ __launch_bounds__(256) void gpmp2_lr_apply(float* __restrict__ x, const float2* __restrict__ dth, const double* __restrict__ u0,
+                                                      const int* __restrict__ ord, int B, int H, int D, double step) {
+    __shared__ float xs[LR_HMAX * 2 * MPB_MAX_DOF];
+    const int a = blockIdx.x;
+    if (a >= ord[2 * B]) return;                               // (block-uniform: the head of the sorted list)
+    lr_apply_rows<256>(x, dth, u0, true, ord[B + a], B, H, D, step, xs, threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -575,7 +582,7 @@ template <int DMAX>        // DMAX: 8 or MPB_MAX_DOF -- the joints a row of h is
 __global__ __launch_bounds__(CAP_THREADS, CAP_WPE) void gpmp2_lr_cap(const float* __restrict__ jac, const double* __restrict__ upos,
                                                    const double* __restrict__ G, const double* __restrict__ gpcost,
                                                    double* __restrict__ wdense, float* __restrict__ costs_out, const int* __restrict__ ord,
-                                                   int B, int H, int D, int F, int n_tiles_max, GpConst K) {
+                                                   float* __restrict__ x, int B, int H, int D, int F, int n_tiles_max, GpConst K) {
     extern __shared__ double lds[];
     // LDS: [ tiles | rhs / y / w (128) | 1 / l_kk (128) | h rows of the active set (LR_NMAX x 8 fp32) | waypoint and field of every
     //        active row (2 x 128 ints) | scratch ints ]
@@ -641,7 +648,13 @@ __global__ __launch_bounds__(CAP_THREADS, CAP_WPE) void gpmp2_lr_cap(const float
     if (costs_out != nullptr && tid == 0) costs_out[b] = (float)(((dinv[0] + dinv[1]) + (dinv[2] + dinv[3])) + gpcost[b]);
     int n = 0;
     for (int ch = 0; ch < nchunk; ++ch) n += cnt[ch];
-    if (n == 0) return;                                          // (block-uniform)
+    if (n == 0) {                                                // (block-uniform)
+        // a particle of the last size class (no hinge anywhere: w = 0) takes its step here, x += step u0 -- this workgroup has nothing
+        // else to do, and gpmp2_lr_apply is left with the particles that have rows (one with hinges but no gradient -- n = 0 in
+        // another class -- is on gpmp2_pcr_solve<true>'s list and stepped there)
+        if (ord[b] == LR_ORD - 1) lr_apply_rows<CAP_THREADS>(x, nullptr, upos, false, b, B, H, D, K.step, reinterpret_cast<float*>(lds), tid);
+        return;
+    }
     for (int ps = 0; ps < 2; ++ps) {
         const int ch = wave + 4 * ps;
         if (ch < nchunk && wave < 4) {
@@ -956,8 +969,8 @@ int mpb_gpmp2_lr_launch(float* x, const float* start, const float* goal, const f
     const int n_max = n_fields * (H - 1);
     const int trm = (n_max + 16) >> 4, ntm = (trm * (trm + 1)) >> 1;             // tiles of the largest system the shape allows
     const size_t lds = ((size_t)ntm * LR_TILE + 256) * sizeof(double) + (size_t)LR_NMAX * (D <= 8 ? 8 : MPB_MAX_DOF) * sizeof(float) + (256 + 16) * sizeof(int);
-    if (D <= 8) hipLaunchKernelGGL(gpmp2_lr_cap<8>, dim3(B), dim3(CAP_THREADS), lds, stream, jac, grest, G, gpcost, wdense, costs_out, ord, B, H, D, n_fields, ntm, K);
-    else hipLaunchKernelGGL(gpmp2_lr_cap<MPB_MAX_DOF>, dim3(B), dim3(CAP_THREADS), lds, stream, jac, grest, G, gpcost, wdense, costs_out, ord, B, H, D, n_fields, ntm, K);
+    if (D <= 8) hipLaunchKernelGGL(gpmp2_lr_cap<8>, dim3(B), dim3(CAP_THREADS), lds, stream, jac, grest, G, gpcost, wdense, costs_out, ord, x, B, H, D, n_fields, ntm, K);
+    else hipLaunchKernelGGL(gpmp2_lr_cap<MPB_MAX_DOF>, dim3(B), dim3(CAP_THREADS), lds, stream, jac, grest, G, gpcost, wdense, costs_out, ord, x, B, H, D, n_fields, ntm, K);
     hipLaunchKernelGGL(gpmp2_pcr_solve<true>, dim3(D, NG), dim3(PCR_THREADS), lds_solve, stream, grest, jac, wdense, coef, dth, ord, B, H, D,
                        n_fields, L, NG, K);
     hipLaunchKernelGGL(gpmp2_lr_apply, dim3(B), dim3(256), 0, stream, x, reinterpret_cast<const float2*>(dth), grest, ord, B, H, D, K.step);
