@@ -603,6 +603,15 @@ __global__ __launch_bounds__(CAP_THREADS, CAP_WPE) void gpmp2_lr_cap(const float
 #else
 #define CAP_CLK(k)
 #endif
+    // a particle of the last size class has no hinge anywhere (every c_t is zero, so every h_t is): its collision cost is zero, w = 0,
+    // and its step is u0's.  This workgroup takes that step, x += step u0, and is done -- no compaction (its jac rows are not even
+    // read), and gpmp2_lr_apply is left with the particles that have rows.  (More than half of C4's particles: with the compaction
+    // in front of the test the kernel did not get below 41 us however small the systems had become.)
+    if (ord[b] == LR_ORD - 1) {                                  // (block-uniform)
+        if (costs_out != nullptr && tid == 0) costs_out[b] = (float)gpcost[b];
+        lr_apply_rows<CAP_THREADS>(x, nullptr, upos, false, b, B, H, D, K.step, reinterpret_cast<float*>(lds), tid);
+        return;
+    }
     // ---- 1. the active collision rows, compacted (field major, then waypoint); the collision part of the cost.  Chunk (f, base) is
     //         examined by wave (2 f + base / 64) mod 4: counts first, then positions
     const int nchunk = F * ((H + 63) >> 6);
@@ -648,13 +657,7 @@ __global__ __launch_bounds__(CAP_THREADS, CAP_WPE) void gpmp2_lr_cap(const float
     if (costs_out != nullptr && tid == 0) costs_out[b] = (float)(((dinv[0] + dinv[1]) + (dinv[2] + dinv[3])) + gpcost[b]);
     int n = 0;
     for (int ch = 0; ch < nchunk; ++ch) n += cnt[ch];
-    if (n == 0) {                                                // (block-uniform)
-        // a particle of the last size class (no hinge anywhere: w = 0) takes its step here, x += step u0 -- this workgroup has nothing
-        // else to do, and gpmp2_lr_apply is left with the particles that have rows (one with hinges but no gradient -- n = 0 in
-        // another class -- is on gpmp2_pcr_solve<true>'s list and stepped there)
-        if (ord[b] == LR_ORD - 1) lr_apply_rows<CAP_THREADS>(x, nullptr, upos, false, b, B, H, D, K.step, reinterpret_cast<float*>(lds), tid);
-        return;
-    }
+    if (n == 0) return;                                          // (block-uniform; hinges without a gradient: on gpmp2_pcr_solve<true>'s list, stepped there)
     for (int ps = 0; ps < 2; ++ps) {
         const int ch = wave + 4 * ps;
         if (ch < nchunk && wave < 4) {
