@@ -169,6 +169,9 @@ def _refined_solve(JtJ, g, l, refine):
 @pytest.mark.parametrize('H,trust,n_fields,n_interp,sig', [
     (128, True, 1, 0, None), (128, False, 1, 0, None), (128, True, 2, 0, None), (128, True, 1, 2, None),   # C4's horizon
     (64, True, 1, 0, None), (65, True, 1, 0, None), (127, False, 1, 2, None),       # both sweep parities, chunk boundary
+    # round 6: horizons that are not powers of two below and above one wave's 64 waypoints (the cyclic reduction's partial last
+    # levels, lanes with one / two waypoints, the level whose partner is the lane's own other element)
+    (17, True, 1, 0, None), (37, False, 1, 0, None), (100, True, 1, 0, None),
     # STIFF systems without the trust region (the pivot reciprocal is v_rcp_f64 + ONE Newton step, validated at
     # C4's sigmas only; the reference's defaults are sigma_start = sigma_goal = sigma_coll = 1e-5, sigma_gp = 1e-2, i.e. a
     # collision-to-GP precision ratio of 1e6).  What limited the accuracy in rounds 3-4 was that ratio, not the start / goal
